@@ -1,0 +1,103 @@
+"""ctypes binding of libdreammat_hip.so (the C ABI declared in include/dreammat_hip.h).
+
+The product path FAILS LOUDLY when the HIP library is missing: there is no CPU or PyTorch fallback
+for any of these ops.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_float, c_int, c_int32, c_longlong, c_size_t, c_uint32, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdreammat_hip.so")
+
+_lib = None
+
+DM_ERRORS = {-1: "DM_ERR_ARG", -2: "DM_ERR_WORKSPACE", -3: "DM_ERR_UNSUPPORTED"}
+
+
+class DmError(RuntimeError):
+    pass
+
+
+class EnvAtlasStruct(ctypes.Structure):
+    _fields_ = [("spec", c_void_p), ("diff", c_void_p), ("fg_lut", c_void_p),
+                ("spec_env_stride", c_longlong), ("diff_env_stride", c_longlong),
+                ("mip_off", c_longlong * 8), ("mip_res", c_int * 8),
+                ("n_mips", c_int), ("diff_res", c_int), ("lut_res", c_int),
+                ("min_rough_mip", c_float), ("max_rough_mip", c_float)]
+
+
+class MatCfgStruct(ctypes.Structure):
+    _fields_ = [("min_metallic", c_float), ("max_metallic", c_float),
+                ("min_roughness", c_float), ("max_roughness", c_float)]
+
+
+_LL = c_longlong
+_SIGS = {
+    "dm_abi_version": (c_int, []),
+    "dm_mesh_build_topology": (c_int, [c_void_p, c_int32, c_void_p]),
+    "dm_vertex_transform": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "dm_raster_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "dm_rasterize": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                             c_void_p]),
+    "dm_raster_overflowed": (c_int, [c_void_p, c_void_p, POINTER(c_int)]),
+    "dm_interpolate": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, _LL, c_void_p, c_void_p]),
+    "dm_antialias_plan": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                  c_void_p]),
+    "dm_antialias_apply": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dm_antialias_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "dm_gbuffer_workspace_bytes": (c_size_t, [_LL]),
+    "dm_gbuffer_compact": (c_int, [c_void_p, _LL, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
+                                   _LL, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+                                   c_void_p]),
+    "dm_control_maps": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p]),
+    "dm_scatter_rows": (c_int, [c_void_p, c_void_p, _LL, c_void_p, _LL, _LL, c_int, c_void_p, c_void_p]),
+    "dm_gather_rows": (c_int, [c_void_p, c_void_p, _LL, c_void_p, c_int, c_void_p, _LL, _LL, c_void_p]),
+    "dm_hashgrid_fwd": (c_int, [c_void_p, _LL, _LL, c_void_p, _LL, c_void_p, c_int, POINTER(c_float),
+                                POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32), c_float, c_void_p, _LL, _LL,
+                                c_void_p]),
+    "dm_hashgrid_bwd": (c_int, [c_void_p, _LL, _LL, c_void_p, _LL, c_void_p, _LL, _LL, c_int, POINTER(c_float),
+                                POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32), c_float, c_void_p, c_void_p]),
+    "dm_shade_fwd": (c_int, [POINTER(EnvAtlasStruct), POINTER(MatCfgStruct), c_void_p, _LL, _LL, c_void_p, _LL, _LL,
+                             c_void_p, _LL, _LL, c_void_p, c_void_p, c_void_p, _LL, c_int, c_void_p, _LL, _LL,
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dm_shade_bwd": (c_int, [POINTER(EnvAtlasStruct), POINTER(MatCfgStruct), c_void_p, _LL, _LL, c_void_p, _LL, _LL,
+                             c_void_p, _LL, _LL, c_void_p, c_void_p, c_void_p, _LL, c_int, c_void_p, _LL, _LL,
+                             c_void_p, _LL, _LL, c_void_p]),
+    "dm_matreg_fwd": (c_int, [c_void_p, _LL, _LL, c_void_p, _LL, _LL, c_void_p, _LL, c_void_p, c_void_p]),
+    "dm_matreg_bwd": (c_int, [c_void_p, _LL, _LL, c_void_p, _LL, _LL, c_void_p, _LL, c_float, c_void_p, _LL, _LL,
+                              c_void_p, _LL, _LL, c_void_p]),
+    "dm_attention_fwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]
+                              + [_LL] * 12 + [c_float, c_void_p]),
+    "dm_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _LL, c_int, c_float, c_float, c_float, c_float,
+                             c_float, c_int, c_void_p]),
+}
+
+
+def lib():
+    """Loads the shared library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DmError(
+                f"{LIB_PATH} is missing: build it with `python -m dreammat_amd.csrc.build` "
+                "(hipcc --offload-arch=gfx950). The HIP library is mandatory: there is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        if rc < 0:
+            raise DmError(f"{what}: {DM_ERRORS.get(rc, rc)}")
+        raise DmError(f"{what}: hipError {rc}")
+
+
+def exported_symbols():
+    return sorted(_SIGS.keys())

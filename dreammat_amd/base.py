@@ -1,0 +1,91 @@
+"""Plugin base classes: threestudio/utils/base.py:21-118 (Updateable, BaseObject, BaseModule) and
+threestudio/utils/misc.py:28-29 (get_device) / :104-120 (barrier, broadcast)."""
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .config import parse_structured
+
+
+def get_rank():
+    for k in ("RANK", "LOCAL_RANK", "SLURM_PROCID", "JSM_NAMESPACE_RANK"):
+        if k in os.environ:
+            return int(os.environ[k])
+    return 0
+
+
+def get_local_rank():
+    return int(os.environ.get("LOCAL_RANK", 0))
+
+
+def get_device():
+    """misc.py:28-29 hard-codes cuda:{rank}; one process per GPU here as well."""
+    return torch.device(f"cuda:{get_local_rank()}")
+
+
+def barrier():
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        torch.distributed.barrier()
+
+
+class Updateable:
+    def do_update_step(self, epoch: int, global_step: int, on_load_weights: bool = False):
+        for attr in self.__dir__():
+            if attr.startswith("_"):
+                continue
+            try:
+                module = getattr(self, attr)
+            except Exception:
+                continue
+            if isinstance(module, Updateable):
+                module.do_update_step(epoch, global_step, on_load_weights=on_load_weights)
+        self.update_step(epoch, global_step, on_load_weights=on_load_weights)
+
+    def update_step(self, epoch: int, global_step: int, on_load_weights: bool = False):
+        pass
+
+
+class BaseObject(Updateable):
+    @dataclass
+    class Config:
+        pass
+
+    cfg: Config
+
+    def __init__(self, cfg=None, *args, **kwargs):
+        super().__init__()
+        self.cfg = parse_structured(self.Config, cfg)
+        self.device = get_device()
+        self.configure(*args, **kwargs)
+
+    def configure(self, *args, **kwargs):
+        pass
+
+
+class BaseModule(nn.Module, Updateable):
+    @dataclass
+    class Config:
+        weights: Optional[str] = None
+
+    cfg: Config
+
+    def __init__(self, cfg=None, *args, **kwargs):
+        super().__init__()
+        self.cfg = parse_structured(self.Config, cfg)
+        self.device = get_device()
+        self.configure(*args, **kwargs)
+        if self.cfg.weights is not None:
+            # "path:module_name" partial load (base.py:103-112, misc.py:32-62)
+            path, module_name = self.cfg.weights.split(":")
+            ckpt = torch.load(path, map_location="cpu")
+            sd = {k[len(module_name) + 1:]: v for k, v in ckpt["state_dict"].items() if k.startswith(module_name + ".")}
+            self.load_state_dict(sd)
+            self.do_update_step(ckpt.get("epoch", 0), ckpt.get("global_step", 0), on_load_weights=True)
+        self._dummy: torch.Tensor
+        self.register_buffer("_dummy", torch.zeros(0).float(), persistent=False)
+
+    def configure(self, *args, **kwargs):
+        pass

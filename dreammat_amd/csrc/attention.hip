@@ -1,0 +1,273 @@
+// Flash-style fused attention forward (QK^T . softmax . V) on MFMA for gfx950 -- bf16 in/out,
+// fp32 accumulate, no S x S materialisation.  Plugged in as the attention of the UNet/ControlNet
+// transformer blocks that diffusers runs for threestudio/models/guidance/dreammat_guidance.py
+// :205-241 (multi_control_forward) and :261-282 (forward_unet).
+//
+// Design (wave64, v_mfma_f32_32x32x16_bf16):
+//  * workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 query rows.
+//  * "swapped" products keep the softmax row on the lane:  S^T[kv,q] = K . Q^T  (A = K rows from
+//    LDS, B = Q rows from registers) so lane l holds 16+16 scores of query q = l&31, and
+//    O^T[d,q] = V^T . P^T (A = V^T rows from LDS, B = P straight from the score registers).
+//    No cross-lane shuffles except one lane^32 exchange for the row max / final row sum.
+//  * V arrives already transposed (vt[b,h,d,kv], produced for free by the projection GEMM), and
+//    the kv order inside each 16-wide MFMA k-step is permuted when the tile is written to LDS so
+//    that the accumulator layout of S^T *is* the B-operand layout of the P.V product.
+//  * K / V^T tiles (64 kv) are register-staged (global -> VGPR -> LDS, issue-early/write-late)
+//    into double-buffered LDS with 16 B row padding => conflict-free ds_read_b128; one barrier
+//    per KV tile.
+//  * head_dim D <= DP (template: 64/96/128/160), D % 8 == 0: SD-2.1 (64) and SD-1.5 (40/80/160)
+//    shapes are both covered, the pad columns are zero-filled in registers, never in memory.
+#include "dm_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct AttnArgs {
+    const __bf16* q; const __bf16* k; const __bf16* vt; __bf16* out;
+    long long q_bs, q_ss, q_hs;       // element strides: batch, sequence, head (d contiguous)
+    long long k_bs, k_ss, k_hs;
+    long long vt_bs, vt_hs, vt_ds;    // V^T: batch, head, d-row (kv contiguous)
+    long long o_bs, o_ss, o_hs;
+    int B, Hh, Sq, Skv, D;
+    float scale_log2;                 // softmax scale * log2(e)
+};
+
+constexpr int kQRowsPerWave = 32;
+constexpr int kWaves = 4;
+constexpr int kKvTile = 64;
+
+__device__ __forceinline__ uint4 ld16(const __bf16* p) { return *reinterpret_cast<const uint4*>(p); }
+
+template <int DP>
+__global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
+    constexpr int KSTEPS = DP / 16;       // MFMA k-steps over head_dim
+    constexpr int DT = DP / 32;           // 32-wide output d tiles
+    constexpr int KROW = DP * 2 + 16;     // bytes per K row in LDS (padded)
+    constexpr int VROW = kKvTile * 2 + 16;
+    constexpr int KBYTES = kKvTile * KROW;
+    constexpr int VBYTES = DP * VROW;
+    constexpr int CPR = DP / 8;           // 16 B chunks per K row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int bh = blockIdx.y, b = bh / a.Hh, h = bh - b * a.Hh;
+    const int q_row = blockIdx.x * (kWaves * kQRowsPerWave) + wave * kQRowsPerWave + l31;
+    const bool q_ok = q_row < a.Sq;
+    const int skv_pad8 = (a.Skv + 7) & ~7;
+
+    // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q][16kk + 8hi .. +7]
+    bf16x8 qf[KSTEPS];
+    {
+        const __bf16* qp = a.q + (long long)b * a.q_bs + (long long)q_row * a.q_ss + (long long)h * a.q_hs;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            int d = 16 * kk + 8 * hi;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q_ok && d < a.D) v = ld16(qp + d);
+            qf[kk] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+
+    const __bf16* kp = a.k + (long long)b * a.k_bs + (long long)h * a.k_hs;
+    const __bf16* vp = a.vt + (long long)b * a.vt_bs + (long long)h * a.vt_hs;
+
+    uint4 kreg[DT], vreg[DT];
+    auto load_tile = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < DT; ++i) {
+            int c = tid + 256 * i;
+            int row = c / CPR, col8 = c - row * CPR;
+            int kv = kv0 + row;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (kv < a.Skv && col8 * 8 < a.D) v = ld16(kp + (long long)kv * a.k_ss + col8 * 8);
+            kreg[i] = v;
+            int d = c >> 3, kc = c & 7;
+            uint4 w = make_uint4(0, 0, 0, 0);
+            if (d < a.D && kv0 + kc * 8 < skv_pad8) w = ld16(vp + (long long)d * a.vt_ds + kv0 + kc * 8);
+            vreg[i] = w;
+        }
+    };
+    auto write_tile = [&](int buf) {
+        char* kb = smem + buf * (KBYTES + VBYTES);
+        char* vb = kb + KBYTES;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) {
+            int c = tid + 256 * i;
+            int row = c / CPR, col8 = c - row * CPR;
+            *reinterpret_cast<uint4*>(kb + row * KROW + col8 * 16) = kreg[i];
+            int d = c >> 3, kc = c & 7;
+            // kv permutation inside each 16-group: [0-3, 8-11, 4-7, 12-15]
+            char* dst = vb + d * VROW + (kc >> 1) * 32 + (kc & 1) * 8;
+            *reinterpret_cast<uint2*>(dst) = make_uint2(vreg[i].x, vreg[i].y);
+            *reinterpret_cast<uint2*>(dst + 16) = make_uint2(vreg[i].z, vreg[i].w);
+        }
+    };
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int n_tiles = (a.Skv + kKvTile - 1) / kKvTile;
+    load_tile(0);
+    write_tile(0);
+    __syncthreads();
+
+    for (int j = 0; j < n_tiles; ++j) {
+        const int buf = j & 1;
+        const int kv0 = j * kKvTile;
+        if (j + 1 < n_tiles) load_tile(kv0 + kKvTile);
+        const char* kb = smem + buf * (KBYTES + VBYTES);
+        const char* vb = kb + KBYTES;
+
+        // ---- S^T = K . Q^T
+        f32x16 s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + (32 * t + l31) * KROW + 32 * kk + 16 * hi);
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[t], 0, 0, 0);
+            }
+        }
+        // ---- mask the ragged tail (cross-attention: Skv = 77)
+        if (kv0 + kKvTile > a.Skv) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int kv = kv0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (kv >= a.Skv) s[t][r] = -INFINITY;
+                }
+        }
+        // ---- online softmax (log2 domain), row = lane's query
+        float mx = s[0][0];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float m_new = fmaxf(m_run, mx * a.scale_log2);
+        float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = __builtin_amdgcn_exp2f(s[t][r] * a.scale_log2 - m_new);
+                s[t][r] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+
+        // ---- P -> bf16 B-operand fragments (no data movement: accumulator order == k-slot order)
+        bf16x8 pf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int t = ks >> 1, u = ks & 1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f32x2 two = {s[t][8 * u + 2 * e], s[t][8 * u + 2 * e + 1]};
+                bf16x2 pk = __builtin_convertvector(two, bf16x2);
+                pf[ks][2 * e] = pk[0];
+                pf[ks][2 * e + 1] = pk[1];
+            }
+        }
+        // ---- O^T += V^T . P^T
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + (32 * dt + l31) * VROW + 32 * ks + 16 * hi);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[dt], 0, 0, 0);
+            }
+
+        if (j + 1 < n_tiles) write_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: normalise, store O[q][d]
+    float l_tot = l_run + __shfl_xor(l_run, 32);
+    float inv = 1.0f / l_tot;
+    if (q_ok) {
+        __bf16* op = a.out + (long long)b * a.o_bs + (long long)q_row * a.o_ss + (long long)h * a.o_hs;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int d = 32 * dt + 8 * g + 4 * hi;
+                if (d < a.D) {
+                    f32x2 x0 = {o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv};
+                    f32x2 x1 = {o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
+                    bf16x2 y0 = __builtin_convertvector(x0, bf16x2), y1 = __builtin_convertvector(x1, bf16x2);
+                    bf16x4 y = {y0[0], y0[1], y1[0], y1[1]};
+                    *reinterpret_cast<bf16x4*>(op + d) = y;
+                }
+            }
+    }
+}
+
+template <int DP>
+int launch_attn(const AttnArgs& a, hipStream_t stream) {
+    constexpr int KROW = DP * 2 + 16, VROW = kKvTile * 2 + 16;
+    constexpr int LDS = 2 * (kKvTile * KROW + DP * VROW);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_fwd<DP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid(dm_div_up(a.Sq, kWaves * kQRowsPerWave), a.B * a.Hh);
+    hipLaunchKernelGGL(k_attn_fwd<DP>, grid, dim3(256), LDS, stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DM_OK : (int)e;
+}
+
+}  // namespace
+
+extern "C" {
+
+// q   [B, Sq, Hh, D]  via strides (q_bs, q_ss, q_hs), d contiguous
+// k   [B, Skv, Hh, D] via strides
+// vt  [B, Hh, D, Skv_pad] via strides (vt_bs, vt_hs, vt_ds), kv contiguous, rows zero-padded to a
+//     multiple of 8 kv (vt_ds % 8 == 0)
+// out [B, Sq, Hh, D]  via strides.  All pointers 16 B aligned, all strides multiples of 8 elements
+// (out: multiples of 4).  D % 8 == 0, D <= 160.  scale = softmax scale (1/sqrt(D) for diffusers).
+int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* out, int B, int Hh, int Sq, int Skv,
+                          int D, long long q_bs, long long q_ss, long long q_hs, long long k_bs, long long k_ss,
+                          long long k_hs, long long vt_bs, long long vt_hs, long long vt_ds, long long o_bs,
+                          long long o_ss, long long o_hs, float scale, hipStream_t stream) {
+    if (!q || !k || !vt || !out || B <= 0 || Hh <= 0 || Sq <= 0 || Skv <= 0 || D <= 0) return DM_ERR_ARG;
+    if (D % 8 != 0 || D > 160) return DM_ERR_UNSUPPORTED;
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15 || ((uintptr_t)out & 7)) return DM_ERR_ARG;
+    if ((q_bs | q_ss | q_hs | k_bs | k_ss | k_hs | vt_bs | vt_hs | vt_ds) & 7) return DM_ERR_ARG;
+    if ((o_bs | o_ss | o_hs) & 3) return DM_ERR_ARG;
+    if ((long long)B * Hh > 65535) return DM_ERR_UNSUPPORTED;
+    AttnArgs a;
+    a.q = (const __bf16*)q; a.k = (const __bf16*)k; a.vt = (const __bf16*)vt; a.out = (__bf16*)out;
+    a.q_bs = q_bs; a.q_ss = q_ss; a.q_hs = q_hs; a.k_bs = k_bs; a.k_ss = k_ss; a.k_hs = k_hs;
+    a.vt_bs = vt_bs; a.vt_hs = vt_hs; a.vt_ds = vt_ds; a.o_bs = o_bs; a.o_ss = o_ss; a.o_hs = o_hs;
+    a.B = B; a.Hh = Hh; a.Sq = Sq; a.Skv = Skv; a.D = D;
+    a.scale_log2 = scale * 1.4426950408889634f;
+    if (D <= 64) return launch_attn<64>(a, stream);
+    if (D <= 96) return launch_attn<96>(a, stream);
+    if (D <= 128) return launch_attn<128>(a, stream);
+    return launch_attn<160>(a, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+"""Builds dreammat_amd/libdreammat_hip.so for gfx950 with hipcc (in-tree, cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+LIB = os.path.join(PKG, "libdreammat_hip.so")
+OBJ = os.path.join(HERE, "_obj")
+
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+SOURCES = {
+    # the rasterizer's bit-exactness contract needs one rounding per written operation
+    "raster.hip": ["-ffp-contract=off"],
+    "shade.hip": ["-munsafe-fp-atomics"],
+    "hashgrid.hip": ["-munsafe-fp-atomics"],
+    "attention.hip": [],
+    "adam.hip": [],
+    "host.cpp": [],
+}
+HEADERS = ["dm_common.h", "raster_core.h", "shade_core.h"]
+
+
+def _newer(src, dst):
+    return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OBJ, exist_ok=True)
+    hdr_time = max(os.path.getmtime(os.path.join(HERE, h)) for h in HEADERS)
+    objs, rebuilt = [], False
+    for src, extra in SOURCES.items():
+        s = os.path.join(HERE, src)
+        o = os.path.join(OBJ, src + ".o")
+        if force or _newer(s, o) or hdr_time > os.path.getmtime(o):
+            cmd = [hipcc] + COMMON + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            rebuilt = True
+        objs.append(o)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,26 @@
+// Common helpers for the dreammat HIP library (gfx950 only; no CUDA/HIP dual paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DM_OK 0
+#define DM_ERR_ARG (-1)
+#define DM_ERR_WORKSPACE (-2)
+#define DM_ERR_UNSUPPORTED (-3)
+
+#define DM_HD __host__ __device__ __forceinline__
+
+// Launch-check: positive return = hipError_t.
+#define DM_LAUNCH_CHECK()                          \
+    do {                                           \
+        hipError_t e__ = hipGetLastError();        \
+        if (e__ != hipSuccess) return (int)e__;    \
+    } while (0)
+
+#define DM_HIP(expr)                               \
+    do {                                           \
+        hipError_t e__ = (expr);                   \
+        if (e__ != hipSuccess) return (int)e__;    \
+    } while (0)
+
+static inline int dm_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,142 @@
+// Multiresolution hash-grid encoding (forward gather / backward scatter-add) for gfx950.
+// Replaces tiny-cuda-nn's `tcnn.Encoding(3, {HashGrid,16,2,2^19,16,1.4473})` used by
+// threestudio/models/networks.py:55-64 <- threestudio/models/geometry/dreammat_mesh.py:128-130,250,
+// including contract_to_unisphere (geometry/base.py:20-32, bounded branch).
+// Layout: table [total_entries][2] fp32 (level-major, tcnn's flat parameter order);
+//         output enc addressed as out[m*rs + (2*level+f)*cs] -- the internal path uses the
+//         feature-major form (rs=1, cs=M) so both the gather results and the GEMM that consumes
+//         them are fully coalesced.
+// One thread per (point, level); blockIdx.y = level so a workgroup hammers one level's table
+// region (L2 locality).  Backward uses hardware fp32 atomics (-munsafe-fp-atomics).
+#include "dm_common.h"
+
+namespace {
+
+constexpr int kMaxLevels = 32;
+
+struct GridLevels {
+    float scale[kMaxLevels];
+    unsigned res[kMaxLevels];
+    unsigned size[kMaxLevels];     // entries in this level
+    unsigned offset[kMaxLevels];   // entry offset
+    int n_levels;
+};
+
+__device__ __forceinline__ unsigned grid_index(unsigned x, unsigned y, unsigned z, unsigned res, unsigned size) {
+    // tcnn grid_index<3>: dense while the running stride stays <= size, else coherent prime hash
+    unsigned stride = 1, index = 0;
+    bool overflow = false;
+    if (stride <= size) { index += x * stride; unsigned long long s = (unsigned long long)stride * res; if (s > 0xffffffffull) overflow = true; stride = (unsigned)s; }
+    if (!overflow && stride <= size) { index += y * stride; unsigned long long s = (unsigned long long)stride * res; if (s > 0xffffffffull) overflow = true; stride = (unsigned)s; }
+    if (!overflow && stride <= size) { index += z * stride; unsigned long long s = (unsigned long long)stride * res; if (s > 0xffffffffull) overflow = true; stride = (unsigned)s; }
+    if (overflow || size < stride) index = (x * 1u) ^ (y * 2654435761u) ^ (z * 805459861u);
+    return index % size;
+}
+
+struct HashArgs {
+    const float* x; long long x_rs, x_cs;      // points [M,3] world space
+    const float2* table;
+    float* out; long long out_rs, out_cs;      // enc [M, 2L]
+    const float* dout; long long dout_rs, dout_cs;
+    float* dtable;
+    const int* m_dev;                          // device row count (may be null => m_max)
+    long long m_max;
+    float inv_2r, radius;                      // contract_to_unisphere: (x + r) / (2r)
+    GridLevels lv;
+};
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_hashgrid(HashArgs a) {
+    long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long M = a.m_dev ? (long long)*a.m_dev : a.m_max;
+    if (m >= M) return;
+    const int l = blockIdx.y;
+    const float scale = a.lv.scale[l];
+    const unsigned res = a.lv.res[l], size = a.lv.size[l], off = a.lv.offset[l];
+    float pos[3], w[3];
+    unsigned cell[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float xn = (a.x[m * a.x_rs + d * a.x_cs] + a.radius) * a.inv_2r;
+        float p = xn * scale + 0.5f;
+        float fl = floorf(p);
+        w[d] = p - fl;
+        cell[d] = (unsigned)(int)fl;
+        pos[d] = p;
+    }
+    (void)pos;
+    if (!BWD) {
+        float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            unsigned cx = cell[0] + (c & 1), cy = cell[1] + ((c >> 1) & 1), cz = cell[2] + ((c >> 2) & 1);
+            float wt = ((c & 1) ? w[0] : 1.f - w[0]) * (((c >> 1) & 1) ? w[1] : 1.f - w[1]) *
+                       (((c >> 2) & 1) ? w[2] : 1.f - w[2]);
+            float2 t = a.table[off + grid_index(cx, cy, cz, res, size)];
+            acc.x += t.x * wt;
+            acc.y += t.y * wt;
+        }
+        a.out[m * a.out_rs + (2 * l) * a.out_cs] = acc.x;
+        a.out[m * a.out_rs + (2 * l + 1) * a.out_cs] = acc.y;
+    } else {
+        float g0 = a.dout[m * a.dout_rs + (2 * l) * a.dout_cs];
+        float g1 = a.dout[m * a.dout_rs + (2 * l + 1) * a.dout_cs];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            unsigned cx = cell[0] + (c & 1), cy = cell[1] + ((c >> 1) & 1), cz = cell[2] + ((c >> 2) & 1);
+            float wt = ((c & 1) ? w[0] : 1.f - w[0]) * (((c >> 1) & 1) ? w[1] : 1.f - w[1]) *
+                       (((c >> 2) & 1) ? w[2] : 1.f - w[2]);
+            float* dst = a.dtable + 2 * (size_t)(off + grid_index(cx, cy, cz, res, size));
+            atomicAdd(dst, g0 * wt);
+            atomicAdd(dst + 1, g1 * wt);
+        }
+    }
+}
+
+bool fill_levels(GridLevels& lv, int n_levels, const float* scale, const uint32_t* res, const uint32_t* size,
+                 const uint32_t* offset) {
+    if (n_levels <= 0 || n_levels > kMaxLevels || !scale || !res || !size || !offset) return false;
+    lv.n_levels = n_levels;
+    for (int i = 0; i < n_levels; ++i) {
+        if (size[i] == 0) return false;
+        lv.scale[i] = scale[i]; lv.res[i] = res[i]; lv.size[i] = size[i]; lv.offset[i] = offset[i];
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dm_hashgrid_fwd(const float* x, long long x_rs, long long x_cs, const int32_t* m_dev, long long m_max,
+                    const float* table, int n_levels, const float* lv_scale, const uint32_t* lv_res,
+                    const uint32_t* lv_size, const uint32_t* lv_offset, float radius, float* enc, long long enc_rs,
+                    long long enc_cs, hipStream_t stream) {
+    HashArgs a = {};
+    if (!x || !table || !enc || m_max <= 0 || !(radius > 0.f) || !fill_levels(a.lv, n_levels, lv_scale, lv_res, lv_size, lv_offset))
+        return DM_ERR_ARG;
+    a.x = x; a.x_rs = x_rs; a.x_cs = x_cs; a.table = (const float2*)table; a.out = enc; a.out_rs = enc_rs;
+    a.out_cs = enc_cs; a.m_dev = m_dev; a.m_max = m_max; a.radius = radius; a.inv_2r = 1.0f / (2.0f * radius);
+    dim3 grid(dm_div_up(m_max, 256), n_levels);
+    hipLaunchKernelGGL(k_hashgrid<false>, grid, dim3(256), 0, stream, a);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+// dtable must be zero-initialised (or hold the running gradient) by the caller: this ADDS into it.
+int dm_hashgrid_bwd(const float* x, long long x_rs, long long x_cs, const int32_t* m_dev, long long m_max,
+                    const float* denc, long long denc_rs, long long denc_cs, int n_levels, const float* lv_scale,
+                    const uint32_t* lv_res, const uint32_t* lv_size, const uint32_t* lv_offset, float radius,
+                    float* dtable, hipStream_t stream) {
+    HashArgs a = {};
+    if (!x || !denc || !dtable || m_max <= 0 || !(radius > 0.f) || !fill_levels(a.lv, n_levels, lv_scale, lv_res, lv_size, lv_offset))
+        return DM_ERR_ARG;
+    a.x = x; a.x_rs = x_rs; a.x_cs = x_cs; a.dout = denc; a.dout_rs = denc_rs; a.dout_cs = denc_cs;
+    a.dtable = dtable; a.m_dev = m_dev; a.m_max = m_max; a.radius = radius; a.inv_2r = 1.0f / (2.0f * radius);
+    dim3 grid(dm_div_up(m_max, 256), n_levels);
+    hipLaunchKernelGGL(k_hashgrid<true>, grid, dim3(256), 0, stream, a);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+}  // extern "C"

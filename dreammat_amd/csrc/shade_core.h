@@ -1,0 +1,182 @@
+// Per-pixel arithmetic of the fused G-buffer -> split-sum PBR shade kernel (forward + backward).
+// Follows threestudio/models/materials/dreammat_material.py:746-762 (material activation, split-sum
+// branch of forward) and :679-711 (shade_splitsum); lin2srgb = threestudio/utils/ops.py:83-88.
+// Texture fetch rules (FG LUT bilinear/clamp; cube bilinear; trilinear over the roughness mip chain)
+// restate nvdiffrast's dr.texture / ashawkey/envlight (see DESIGN.md "Texture rules").
+// Shared by shade.hip and the host emulation under tests/hostemu.
+#pragma once
+#include "dm_common.h"
+
+namespace dm {
+
+constexpr int kMaxMips = 8;
+
+struct EnvAtlas {
+    const float4* spec;          // [n_env][mips...] each mip = 6 faces x (R+2) x (R+2) RGBA texels (1-texel border)
+    const float4* diff;          // [n_env][6][(Rd+2)][(Rd+2)]
+    const float2* fg_lut;        // [lut_res][lut_res] (row = roughness, col = n.v)
+    long long spec_env_stride;   // texels
+    long long diff_env_stride;
+    long long mip_off[kMaxMips]; // texel offset of mip l inside one env
+    int mip_res[kMaxMips];
+    int n_mips;
+    int diff_res;
+    int lut_res;
+    float min_rough_mip, max_rough_mip;   // envlight MIN/MAX_ROUGHNESS (0.08, 0.5)
+};
+
+struct MatCfg {
+    float min_metallic, max_metallic, min_roughness, max_roughness;
+};
+
+struct F3 { float x, y, z; };
+DM_HD F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
+DM_HD F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+DM_HD F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+DM_HD F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+DM_HD F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+DM_HD float dot3(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DM_HD float sat(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+
+// nvdiffrast indexCubeMap: direction -> face, (u,v) in [0,1]
+DM_HD int cube_index(F3 d, float& u, float& v) {
+    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    int face; float c, a, b;
+    if (az > fmaxf(ax, ay)) { c = d.z; face = 4; a = (c > 0.f) ? d.x : -d.x; b = -d.y; }
+    else if (ay > ax)       { c = d.y; face = 2; a = d.x; b = (c > 0.f) ? d.z : -d.z; }
+    else                    { c = d.x; face = 0; a = (c > 0.f) ? -d.z : d.z; b = -d.y; }
+    if (c < 0.f) face += 1;
+    float m = 0.5f / fabsf(c);
+    u = sat(a * m + 0.5f);
+    v = sat(b * m + 0.5f);
+    return face;
+}
+
+// bilinear fetch from one padded cube mip
+DM_HD F3 cube_bilinear(const float4* __restrict__ tex, int R, F3 d) {
+    float u, v;
+    int face = cube_index(d, u, v);
+    float x = u * (float)R - 0.5f, y = v * (float)R - 0.5f;
+    float x0 = floorf(x), y0 = floorf(y);
+    float fx = x - x0, fy = y - y0;
+    int ix = (int)x0 + 1, iy = (int)y0 + 1;       // +1: border
+    int P = R + 2;
+    const float4* base = tex + ((size_t)face * P + iy) * P + ix;
+    float4 t00 = base[0], t10 = base[1], t01 = base[P], t11 = base[P + 1];
+    float w00 = (1.f - fx) * (1.f - fy), w10 = fx * (1.f - fy), w01 = (1.f - fx) * fy, w11 = fx * fy;
+    return f3(t00.x * w00 + t10.x * w10 + t01.x * w01 + t11.x * w11,
+              t00.y * w00 + t10.y * w10 + t01.y * w01 + t11.y * w11,
+              t00.z * w00 + t10.z * w10 + t01.z * w01 + t11.z * w11);
+}
+
+// envlight.get_mip: roughness -> (fractional) mip level, and d level / d roughness
+DM_HD float mip_level(const EnvAtlas& A, float rough, float& dlevel) {
+    float n2 = (float)(A.n_mips - 2);
+    float lo = A.min_rough_mip, hi = A.max_rough_mip;
+    float level;
+    if (rough < hi) {
+        float c = fminf(fmaxf(rough, lo), hi);
+        level = (c - lo) / (hi - lo) * n2;
+        dlevel = (rough >= lo && rough <= hi) ? n2 / (hi - lo) : 0.f;
+    } else {
+        float c = fminf(fmaxf(rough, hi), 1.0f);
+        level = (c - hi) / (1.0f - hi) + n2;
+        dlevel = (rough <= 1.0f) ? 1.0f / (1.0f - hi) : 0.f;
+    }
+    return level;
+}
+
+struct ShadeOut {
+    F3 color;        // clamp(albedo*diff + spec_albedo*spec, 0, 1)
+    F3 albedo, diffuse_light, specular_light, specular_albedo;
+    float metallic, roughness;
+};
+
+// Everything the backward needs is recomputed from the inputs (no saved tensors).
+struct ShadeCtx {
+    float s[5];          // sigmoid(features)
+    F3 albedo, F0, diff, spec, spec_albedo, pre;   // pre = unclamped colour
+    float metallic, roughness, fg0, fg1, dfg0_dv, dfg1_dv;
+    F3 dspec_dlevel; float dlevel_drough;
+};
+
+DM_HD float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+DM_HD void shade_eval(const EnvAtlas& A, const MatCfg& M, int env, F3 n, F3 v, const float feat[5], ShadeCtx& c) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) c.s[k] = sigmoidf(feat[k]);
+    c.albedo = f3(sat(c.s[0]), sat(c.s[1]), sat(c.s[2]));
+    c.metallic = c.s[3] * (M.max_metallic - M.min_metallic) + M.min_metallic;
+    c.roughness = c.s[4] * (M.max_roughness - M.min_roughness) + M.min_roughness;
+    float ndv = dot3(n, v);
+    F3 refl = n * (2.f * ndv) - v;
+    // FG LUT, bilinear / clamp
+    {
+        int L = A.lut_res;
+        float uu = sat(ndv), vv = sat(c.roughness);
+        float x = uu * (float)L - 0.5f, y = vv * (float)L - 0.5f;
+        float x0 = floorf(x), y0 = floorf(y);
+        float fx = x - x0, fy = y - y0;
+        int ix0 = (int)x0, iy0 = (int)y0;
+        int ix1 = min(ix0 + 1, L - 1), iy1 = min(iy0 + 1, L - 1);
+        ix0 = max(ix0, 0); iy0 = max(iy0, 0);
+        float2 t00 = A.fg_lut[iy0 * L + ix0], t10 = A.fg_lut[iy0 * L + ix1];
+        float2 t01 = A.fg_lut[iy1 * L + ix0], t11 = A.fg_lut[iy1 * L + ix1];
+        float r0x = t00.x + (t10.x - t00.x) * fx, r0y = t00.y + (t10.y - t00.y) * fx;
+        float r1x = t01.x + (t11.x - t01.x) * fx, r1y = t01.y + (t11.y - t01.y) * fx;
+        c.fg0 = r0x + (r1x - r0x) * fy;
+        c.fg1 = r0y + (r1y - r0y) * fy;
+        // d/d roughness of the bilinear interpolant (v = roughness inside (0,1) always: [0.1,0.95])
+        bool inside = c.roughness > 0.f && c.roughness < 1.f;
+        c.dfg0_dv = inside ? (r1x - r0x) * (float)L : 0.f;
+        c.dfg1_dv = inside ? (r1y - r0y) * (float)L : 0.f;
+    }
+    c.F0 = f3(0.04f * (1.f - c.metallic) + c.metallic * c.albedo.x,
+              0.04f * (1.f - c.metallic) + c.metallic * c.albedo.y,
+              0.04f * (1.f - c.metallic) + c.metallic * c.albedo.z);
+    c.spec_albedo = f3(c.F0.x * c.fg0 + c.fg1, c.F0.y * c.fg0 + c.fg1, c.F0.z * c.fg0 + c.fg1);
+    c.diff = cube_bilinear(A.diff + (size_t)env * A.diff_env_stride, A.diff_res, n);
+    {
+        float level = mip_level(A, c.roughness, c.dlevel_drough);
+        level = fminf(fmaxf(level, 0.f), (float)(A.n_mips - 1));
+        int l0 = min((int)floorf(level), A.n_mips - 1);
+        int l1 = min(l0 + 1, A.n_mips - 1);
+        float f = level - (float)l0;
+        const float4* envb = A.spec + (size_t)env * A.spec_env_stride;
+        F3 s0 = cube_bilinear(envb + A.mip_off[l0], A.mip_res[l0], refl);
+        F3 s1 = (l1 != l0) ? cube_bilinear(envb + A.mip_off[l1], A.mip_res[l1], refl) : s0;
+        c.spec = s0 * (1.f - f) + s1 * f;
+        c.dspec_dlevel = s1 - s0;
+    }
+    c.pre = c.albedo * c.diff + c.spec_albedo * c.spec;
+}
+
+DM_HD float lin2srgb1(float x) {
+    float r = (x > 0.0031308f) ? powf(fmaxf(x, 0.0031308f), 1.0f / 2.4f) * 1.055f - 0.055f : 12.92f * x;
+    return sat(r);
+}
+DM_HD F3 lin2srgb(F3 a) { return f3(lin2srgb1(a.x), lin2srgb1(a.y), lin2srgb1(a.z)); }
+
+// d loss / d features given d loss / d color
+DM_HD void shade_backward(const MatCfg& M, const ShadeCtx& c, F3 dcol, float dfeat[5]) {
+    // clamp(0,1) passes gradient where 0 <= pre <= 1 (torch.clamp semantics)
+    F3 g = f3((c.pre.x >= 0.f && c.pre.x <= 1.f) ? dcol.x : 0.f,
+              (c.pre.y >= 0.f && c.pre.y <= 1.f) ? dcol.y : 0.f,
+              (c.pre.z >= 0.f && c.pre.z <= 1.f) ? dcol.z : 0.f);
+    F3 gs = g * c.spec;                                 // d / d spec_albedo
+    F3 dalb = g * c.diff + gs * (c.fg0 * c.metallic);   // via diffuse term and F0
+    float dmet = c.fg0 * (gs.x * (c.albedo.x - 0.04f) + gs.y * (c.albedo.y - 0.04f) + gs.z * (c.albedo.z - 0.04f));
+    float dfg0 = dot3(gs, c.F0);
+    float dfg1 = gs.x + gs.y + gs.z;
+    F3 gsa = g * c.spec_albedo;                         // d / d spec light
+    float drough = dfg0 * c.dfg0_dv + dfg1 * c.dfg1_dv + dot3(gsa, c.dspec_dlevel) * c.dlevel_drough;
+    float ds[5];
+    // albedo = clamp(sigmoid, 0, 1): sigmoid is inside [0,1] => pass-through
+    ds[0] = dalb.x; ds[1] = dalb.y; ds[2] = dalb.z;
+    ds[3] = dmet * (M.max_metallic - M.min_metallic);
+    ds[4] = drough * (M.max_roughness - M.min_roughness);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) dfeat[k] = ds[k] * c.s[k] * (1.f - c.s[k]);
+}
+
+}  // namespace dm

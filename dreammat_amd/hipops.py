@@ -1,0 +1,380 @@
+"""torch-facing wrappers of the C ABI (include/dreammat_hip.h): device pointers + the current HIP
+stream go straight into libdreammat_hip.so; `torch.autograd.Function`s provide the backward passes.
+
+PyTorch is plumbing here (memory, streams, autograd graph) -- all arithmetic of these ops runs in the
+hand-written gfx950 kernels.  There is no fallback: CPU tensors or a missing library raise.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.DmError("dreammat_amd HIP ops need tensors on the MI355X (got a CPU tensor); "
+                               "there is no CPU fallback")
+
+
+def _f32c(t):
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+def _rs_cs(t):
+    """(row stride, col stride) in elements of a 2-D [N,C] view."""
+    return int(t.stride(0)), int(t.stride(1))
+
+
+# ------------------------------------------------------------------------------------------ mesh
+def build_topology(tri):
+    """[Nf,3] int tensor (any device) -> opp [Nf,3] int32 on the same device."""
+    t = tri.detach().to("cpu", torch.int32).contiguous().numpy()
+    opp = np.empty_like(t)
+    check(_lib.lib().dm_mesh_build_topology(t.ctypes.data, t.shape[0], opp.ctypes.data), "dm_mesh_build_topology")
+    return torch.from_numpy(opp).to(tri.device)
+
+
+# ------------------------------------------------------------------------------------------ raster
+def vertex_transform(v_pos, mvp):
+    _need_cuda(v_pos, mvp)
+    v_pos, mvp = _f32c(v_pos), _f32c(mvp)
+    B, Nv = mvp.shape[0], v_pos.shape[0]
+    out = torch.empty(B, Nv, 4, device=v_pos.device, dtype=torch.float32)
+    check(_lib.lib().dm_vertex_transform(v_pos.data_ptr(), Nv, mvp.data_ptr(), B, out.data_ptr(), _stream()),
+          "dm_vertex_transform")
+    return out
+
+
+class RasterContext:
+    """Plays the role of dr.RasterizeCudaContext (threestudio/utils/rasterize.py:12-20): owns the
+    triangle-bin workspace, reused across steps."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.ws = None
+        self.ws_mult = 1
+
+    def _workspace(self, B, Nf, H, W):
+        need = int(_lib.lib().dm_raster_workspace_bytes(B, Nf, H, W)) * self.ws_mult
+        if self.ws is None or self.ws.numel() < need:
+            self.ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self.ws
+
+    def rasterize(self, pos_clip, tri, H, W, check_overflow=False):
+        _need_cuda(pos_clip, tri)
+        pos_clip = _f32c(pos_clip)
+        assert tri.dtype == torch.int32 and tri.is_contiguous()
+        B, Nv = pos_clip.shape[0], pos_clip.shape[1]
+        rast = torch.empty(B, H, W, 4, device=pos_clip.device, dtype=torch.float32)
+        while True:
+            ws = self._workspace(B, tri.shape[0], H, W)
+            check(_lib.lib().dm_rasterize(pos_clip.data_ptr(), B, Nv, tri.data_ptr(), tri.shape[0], H, W,
+                                          rast.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "dm_rasterize")
+            if not check_overflow:
+                return rast
+            flag = ctypes.c_int(0)
+            check(_lib.lib().dm_raster_overflowed(ws.data_ptr(), _stream(), ctypes.byref(flag)), "dm_raster_overflowed")
+            if not flag.value:
+                return rast
+            self.ws_mult *= 2
+            self.ws = None
+
+
+def interpolate(attr, rast, tri):
+    _need_cuda(attr, rast, tri)
+    attr, rast = _f32c(attr), _f32c(rast)
+    C = attr.shape[-1]
+    out = torch.empty(*rast.shape[:-1], C, device=rast.device, dtype=torch.float32)
+    npix = rast.numel() // 4
+    check(_lib.lib().dm_interpolate(attr.data_ptr(), attr.shape[0], C, tri.data_ptr(), rast.data_ptr(), npix,
+                                    out.data_ptr(), _stream()), "dm_interpolate")
+    return out
+
+
+def antialias_plan(pos_clip, tri, opp, rast):
+    _need_cuda(pos_clip, tri, opp, rast)
+    B, H, W, _ = rast.shape
+    plan = torch.empty(B, H, W, 2, device=rast.device, dtype=torch.float32)
+    check(_lib.lib().dm_antialias_plan(pos_clip.data_ptr(), B, pos_clip.shape[1], tri.data_ptr(), opp.data_ptr(),
+                                       rast.data_ptr(), H, W, plan.data_ptr(), _stream()), "dm_antialias_plan")
+    return plan
+
+
+class _Antialias(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, color, plan):
+        _need_cuda(color, plan)
+        color = _f32c(color)
+        B, H, W, C = color.shape
+        out = torch.empty_like(color)
+        check(_lib.lib().dm_antialias_apply(color.data_ptr(), plan.data_ptr(), B, H, W, C, out.data_ptr(), _stream()),
+              "dm_antialias_apply")
+        ctx.save_for_backward(plan)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (plan,) = ctx.saved_tensors
+        g = _f32c(g)
+        B, H, W, C = g.shape
+        dcolor = torch.empty_like(g)
+        check(_lib.lib().dm_antialias_grad(g.data_ptr(), plan.data_ptr(), B, H, W, C, dcolor.data_ptr(), _stream()),
+              "dm_antialias_grad")
+        return dcolor, None
+
+
+def antialias(color, plan):
+    return _Antialias.apply(color, plan)
+
+
+class GBuffer:
+    """Compacted covered-pixel G-buffer (SoA, pitch = cap).  `n` is the host copy of the row count."""
+
+    def __init__(self, pix_idx, pos, pos_jitter, nrm, view, n_dev, n):
+        self.pix_idx, self.pos, self.pos_jitter, self.nrm, self.view = pix_idx, pos, pos_jitter, nrm, view
+        self.n_dev, self.n = n_dev, n
+
+
+def gbuffer_compact(rast, tri, v_pos, v_nrm, rays_d, jitter_u=None, jitter_n=None, jitter_eps=0.05):
+    _need_cuda(rast, tri, v_pos, v_nrm, rays_d)
+    dev = rast.device
+    npix = rast.numel() // 4
+    cap = npix
+    rays_d = _f32c(rays_d)
+    pix_idx = torch.empty(cap, dtype=torch.int32, device=dev)
+    pos = torch.empty(3, cap, device=dev)
+    nrm = torch.empty(3, cap, device=dev)
+    view = torch.empty(3, cap, device=dev)
+    pos_j = torch.empty(3, cap, device=dev) if jitter_u is not None else None
+    n_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+    wsb = int(_lib.lib().dm_gbuffer_workspace_bytes(npix))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    ju_t = _f32c(jitter_u) if jitter_u is not None else None   # keep the (possibly temporary) tensors alive
+    jn_t = _f32c(jitter_n) if jitter_n is not None else None
+    ju = ju_t.data_ptr() if ju_t is not None else None
+    jn = jn_t.data_ptr() if jn_t is not None else None
+    check(_lib.lib().dm_gbuffer_compact(rast.data_ptr(), npix, tri.data_ptr(), _f32c(v_pos).data_ptr(),
+                                        _f32c(v_nrm).data_ptr(), rays_d.data_ptr(), ju, jn, float(jitter_eps), cap,
+                                        pix_idx.data_ptr(), pos.data_ptr(),
+                                        pos_j.data_ptr() if pos_j is not None else None, nrm.data_ptr(),
+                                        view.data_ptr(), n_dev.data_ptr(), ws.data_ptr(), wsb, _stream()),
+          "dm_gbuffer_compact")
+    n = int(n_dev.item())   # the one host sync of the render path (sizes the torch-side tensors)
+    return GBuffer(pix_idx[:n], pos[:, :n], pos_j[:, :n] if pos_j is not None else None, nrm[:, :n], view[:, :n],
+                   n_dev, n)
+
+
+def control_maps(rast, tri, v_nrm, w2c):
+    _need_cuda(rast, tri, v_nrm, w2c)
+    B, H, W, _ = rast.shape
+    depth = torch.empty(B, H, W, 1, device=rast.device)
+    normal = torch.empty(B, H, W, 3, device=rast.device)
+    mm = torch.empty(2 * B, dtype=torch.int32, device=rast.device)
+    check(_lib.lib().dm_control_maps(rast.data_ptr(), B, H, W, tri.data_ptr(), _f32c(v_nrm).data_ptr(),
+                                     _f32c(w2c).data_ptr(), depth.data_ptr(), normal.data_ptr(), mm.data_ptr(),
+                                     _stream()), "dm_control_maps")
+    return depth, normal
+
+
+class _ScatterRows(torch.autograd.Function):
+    """dense[pix_idx] = rows  (raytracing_renderer.py:198); backward = gather."""
+
+    @staticmethod
+    def forward(ctx, rows, pix_idx, n_dev, dense_init):
+        _need_cuda(rows, pix_idx, dense_init)
+        C = rows.shape[1]
+        out = dense_init.clone()
+        rs, cs = _rs_cs(rows)
+        check(_lib.lib().dm_scatter_rows(pix_idx.data_ptr(), n_dev.data_ptr(), max(rows.shape[0], 1), rows.data_ptr(),
+                                         rs, cs, C, out.data_ptr(), _stream()), "dm_scatter_rows")
+        ctx.save_for_backward(pix_idx, n_dev)
+        ctx.n = rows.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pix_idx, n_dev = ctx.saved_tensors
+        g = _f32c(g)
+        C = g.shape[-1]
+        d = torch.empty(C, ctx.n, device=g.device)     # SoA
+        check(_lib.lib().dm_gather_rows(pix_idx.data_ptr(), n_dev.data_ptr(), max(ctx.n, 1), g.data_ptr(), C,
+                                        d.data_ptr(), 1, ctx.n, _stream()), "dm_gather_rows")
+        return d.t(), None, None, None
+
+
+def scatter_rows(rows, pix_idx, n_dev, dense_init):
+    """rows [N,C] (any strides), dense_init [P,C] contiguous -> [P,C]."""
+    return _ScatterRows.apply(rows, pix_idx, n_dev, dense_init)
+
+
+# ------------------------------------------------------------------------------------------ hash grid
+class GridSpec:
+    """Per-level constants of the multiresolution hash grid (tcnn HashGrid semantics)."""
+
+    def __init__(self, n_levels=16, n_features=2, log2_hashmap_size=19, base_resolution=16,
+                 per_level_scale=1.447269237440378):
+        import math
+        assert n_features == 2, "the HIP kernel is specialised for 2 features per level (dreammat.yaml:47)"
+        self.n_levels, self.n_features = n_levels, n_features
+        scale, res, size, offset = [], [], [], []
+        off = 0
+        for l in range(n_levels):
+            s = np.float32(math.pow(2.0, l * math.log2(per_level_scale)) * base_resolution - 1.0)
+            r = int(math.ceil(float(s))) + 1
+            n = min((r ** 3 + 7) // 8 * 8, 1 << log2_hashmap_size)
+            scale.append(float(s)); res.append(r); size.append(n); offset.append(off)
+            off += n
+        self.total_entries = off
+        self.n_params = off * n_features
+        self.n_output_dims = n_levels * n_features
+        self.c_scale = (ctypes.c_float * n_levels)(*scale)
+        self.c_res = (ctypes.c_uint32 * n_levels)(*res)
+        self.c_size = (ctypes.c_uint32 * n_levels)(*size)
+        self.c_offset = (ctypes.c_uint32 * n_levels)(*offset)
+        self.levels = [dict(scale=a, res=b, size=c, offset=d) for a, b, c, d in zip(scale, res, size, offset)]
+
+
+class _HashGrid(torch.autograd.Function):
+    """x [M,3] (any strides) -> enc, returned as an [M,2L] VIEW of a feature-major [2L,M] buffer."""
+
+    @staticmethod
+    def forward(ctx, x, table, spec, radius):
+        _need_cuda(x, table)
+        assert table.dtype == torch.float32 and table.is_contiguous()
+        M = x.shape[0]
+        F = spec.n_output_dims
+        enc = torch.empty(F, M, device=x.device, dtype=torch.float32)
+        if M > 0:
+            rs, cs = _rs_cs(x)
+            check(_lib.lib().dm_hashgrid_fwd(x.data_ptr(), rs, cs, None, M, table.data_ptr(), spec.n_levels,
+                                             spec.c_scale, spec.c_res, spec.c_size, spec.c_offset, float(radius),
+                                             enc.data_ptr(), 1, M, _stream()), "dm_hashgrid_fwd")
+        ctx.save_for_backward(x, table)
+        ctx.spec, ctx.radius = spec, radius
+        return enc.t()
+
+    @staticmethod
+    def backward(ctx, g):
+        x, table = ctx.saved_tensors
+        spec = ctx.spec
+        M = x.shape[0]
+        dtable = torch.zeros_like(table)
+        if M > 0:
+            rs, cs = _rs_cs(x)
+            grs, gcs = _rs_cs(g)
+            check(_lib.lib().dm_hashgrid_bwd(x.data_ptr(), rs, cs, None, M, g.data_ptr(), grs, gcs, spec.n_levels,
+                                             spec.c_scale, spec.c_res, spec.c_size, spec.c_offset, float(ctx.radius),
+                                             dtable.data_ptr(), _stream()), "dm_hashgrid_bwd")
+        return None, dtable, None, None
+
+
+def hashgrid_encode(x, table, spec, radius=1.0):
+    if x.dtype != torch.float32:
+        x = x.float()
+    return _HashGrid.apply(x, table, spec, radius)
+
+
+# ------------------------------------------------------------------------------------------ shading
+class _Shade(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, nrm, view, pix_idx, n_dev, env_of_view, atlas, mat, HW, want_debug):
+        _need_cuda(feat, nrm, view, pix_idx, env_of_view)
+        N = feat.shape[0]
+        dev = feat.device
+        color = torch.empty(3, N, device=dev)
+        dbg = [None] * 7
+        if want_debug:
+            dbg = [torch.empty(N, 3, device=dev) for _ in range(5)] + [torch.empty(N, 1, device=dev) for _ in range(2)]
+        if N > 0:
+            check(_lib.lib().dm_shade_fwd(ctypes.byref(atlas.struct), ctypes.byref(mat), nrm.data_ptr(), *_rs_cs(nrm),
+                                          view.data_ptr(), *_rs_cs(view), feat.data_ptr(), *_rs_cs(feat),
+                                          pix_idx.data_ptr(), env_of_view.data_ptr(), n_dev.data_ptr(), N, HW,
+                                          color.data_ptr(), 1, N,
+                                          *[d.data_ptr() if d is not None else None for d in dbg], _stream()),
+                  "dm_shade_fwd")
+        ctx.save_for_backward(feat, nrm, view, pix_idx, n_dev, env_of_view)
+        ctx.atlas, ctx.mat, ctx.HW = atlas, mat, HW
+        outs = (color.t(),) + tuple(d for d in dbg if d is not None)
+        ctx.mark_non_differentiable(*outs[1:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g, *unused):
+        feat, nrm, view, pix_idx, n_dev, env_of_view = ctx.saved_tensors
+        N = feat.shape[0]
+        dfeat = torch.zeros(5, N, device=feat.device)
+        if N > 0:
+            check(_lib.lib().dm_shade_bwd(ctypes.byref(ctx.atlas.struct), ctypes.byref(ctx.mat), nrm.data_ptr(),
+                                          *_rs_cs(nrm), view.data_ptr(), *_rs_cs(view), feat.data_ptr(), *_rs_cs(feat),
+                                          pix_idx.data_ptr(), env_of_view.data_ptr(), n_dev.data_ptr(), N, ctx.HW,
+                                          g.data_ptr(), *_rs_cs(g), dfeat.data_ptr(), 1, N, _stream()), "dm_shade_bwd")
+        return (dfeat.t(),) + (None,) * 9
+
+
+def shade(feat, nrm, view, pix_idx, n_dev, env_of_view, atlas, mat, HW, want_debug=True):
+    """-> (color [N,3], albedo, spec_light, diff_light, spec_color, diff_color, metallic, roughness)."""
+    return _Shade.apply(feat, nrm, view, pix_idx, n_dev, env_of_view, atlas, mat, HW, want_debug)
+
+
+class _MatReg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, featj, n_dev):
+        _need_cuda(feat, featj)
+        N = feat.shape[0]
+        loss = torch.zeros(1, device=feat.device)
+        if N > 0:
+            check(_lib.lib().dm_matreg_fwd(feat.data_ptr(), *_rs_cs(feat), featj.data_ptr(), *_rs_cs(featj),
+                                           n_dev.data_ptr(), N, loss.data_ptr(), _stream()), "dm_matreg_fwd")
+        ctx.save_for_backward(feat, featj, n_dev)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        feat, featj, n_dev = ctx.saved_tensors
+        N = feat.shape[0]
+        df = torch.zeros(5, N, device=feat.device)
+        dj = torch.zeros(5, N, device=feat.device)
+        if N > 0:
+            check(_lib.lib().dm_matreg_bwd(feat.data_ptr(), *_rs_cs(feat), featj.data_ptr(), *_rs_cs(featj),
+                                           n_dev.data_ptr(), N, 1.0, df.data_ptr(), 1, N, dj.data_ptr(),
+                                           1, N, _stream()), "dm_matreg_bwd")
+        return (df * g).t(), (dj * g).t(), None   # upstream scalar applied on device: no host sync
+
+
+def material_smoothness(feat, featj, n_dev):
+    return _MatReg.apply(feat, featj, n_dev)
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attention(q, k, vt, heads, scale=None):
+    """q [B,Sq,C], k [B,Skv,C] bf16 (C = heads*D, last dim contiguous), vt [B,C,Skv_pad] bf16
+    (V transposed, rows zero-padded to a multiple of 8) -> out [B,Sq,C] bf16."""
+    _need_cuda(q, k, vt)
+    assert q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and vt.dtype == torch.bfloat16
+    B, Sq, C = q.shape
+    Skv = k.shape[1]
+    D = C // heads
+    assert q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1
+    out = torch.empty(B, Sq, C, device=q.device, dtype=torch.bfloat16)
+    sc = float(scale) if scale is not None else float(D) ** -0.5
+    check(_lib.lib().dm_attention_fwd_bf16(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, heads, Sq,
+                                           Skv, D, q.stride(0), q.stride(1), D, k.stride(0), k.stride(1), D,
+                                           vt.stride(0), D * vt.stride(1), vt.stride(1), out.stride(0), out.stride(1),
+                                           D, sc, _stream()), "dm_attention_fwd_bf16")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ optimiser
+def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, grad_scale=1.0, zero_grad=True):
+    _need_cuda(param, grad, exp_avg, exp_avg_sq)
+    check(_lib.lib().dm_adam_step(param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(),
+                                  param.numel(), int(step), float(lr), float(beta1), float(beta2), float(eps),
+                                  float(grad_scale), int(bool(zero_grad)), _stream()), "dm_adam_step")

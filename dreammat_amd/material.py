@@ -1,0 +1,113 @@
+"""`dreammat-material` plugin (threestudio/models/materials/dreammat_material.py:346-797), split-sum
+branch.  forward() keeps the reference signature
+    forward(pts, features, features_jitter, viewdirs, normals, env_id) -> (outputs dict, mat_reg)
+and runs two HIP kernels: the fused activation + FG-LUT + env-lookup shade kernel and the smoothness
+regulariser.  `use_raytracing: true` (the reference default, Monte-Carlo shading with BVH
+visibility) is SURVEY row f-1 and not built yet: it raises.
+"""
+import os
+from dataclasses import dataclass
+from typing import Any, Optional
+
+import torch
+
+import dreammat_amd
+from . import _lib, hipops
+from .base import BaseModule
+from .envlight import EnvAtlas, approx_fg_lut, load_fg_lut, read_hdr
+
+
+@dreammat_amd.register("dreammat-material")
+class DreamMatMaterial(BaseModule):
+    @dataclass
+    class Config(BaseModule.Config):
+        material_activation: str = "sigmoid"
+        environment_texture: str = "load/lights/mud_road_puresky_1k.hdr"
+        environment_scale: float = 1.0
+        min_metallic: float = 0.0
+        max_metallic: float = 0.9
+        min_roughness_squre: float = 0.01
+        max_roughness_squre: float = 0.9
+        min_roughness: float = 0.1
+        max_roughness: float = 0.95
+        use_bump: bool = True
+        diffuse_sample_num: int = 512
+        specular_sample_num: int = 256
+        geometry_type: str = "schlick"
+        random_azimuth: bool = True
+        use_raytracing: bool = True
+        # additions (not in the reference): envlight cube resolutions and number of env maps
+        env_max_res: int = 128
+        env_min_res: int = 16
+        n_envs: int = 5
+        fg_lut_path: str = "load/lights/bsdf_256_256.bin"
+
+    cfg: Config
+    requires_normal = True
+
+    def configure(self, latlongs=None) -> None:
+        if self.cfg.material_activation != "sigmoid":
+            raise NotImplementedError("the fused shade kernel implements the sigmoid activation of dreammat.yaml:83")
+        if latlongs is None:
+            latlongs = self._load_envmaps()
+        fg = load_fg_lut(self.cfg.fg_lut_path)
+        if fg is None:
+            print(f"[dreammat_amd] {self.cfg.fg_lut_path} not found: using the analytic stand-in FG LUT")
+            fg = approx_fg_lut()
+        dev = self.device if torch.cuda.is_available() else torch.device("cpu")
+        self.atlas = EnvAtlas(latlongs, scale=self.cfg.environment_scale, min_res=self.cfg.env_min_res,
+                              max_res=self.cfg.env_max_res, fg_lut=fg, device=dev)
+        self.register_buffer("FG_LUT", fg.reshape(1, *fg.shape), persistent=False)
+        self.mat = _lib.MatCfgStruct(self.cfg.min_metallic, self.cfg.max_metallic, self.cfg.min_roughness,
+                                     self.cfg.max_roughness)
+
+    def _load_envmaps(self):
+        """dreammat_material.py:378-386: <environment_texture>/map{i}/map{i}.hdr for i=1..5; a single
+        .hdr file is also accepted (replicated), like the Config default suggests."""
+        root = self.cfg.environment_texture
+        out = []
+        if os.path.isdir(root):
+            for i in range(1, self.cfg.n_envs + 1):
+                out.append(torch.from_numpy(read_hdr(os.path.join(root, f"map{i}", f"map{i}.hdr"))))
+        else:
+            img = torch.from_numpy(read_hdr(root))
+            out = [img for _ in range(self.cfg.n_envs)]
+        return out
+
+    def set_raytracer(self, ray_trace_fun):
+        self.ray_trace_fun = ray_trace_fun
+
+    def forward(self, pts, features, features_jitter, viewdirs, normals, env_id, pix_idx=None, n_dev=None,
+                hw=None, want_debug=True, **kwargs):
+        if self.cfg.use_raytracing:
+            raise NotImplementedError(
+                "use_raytracing=true (Monte-Carlo shading, dreammat_material.py:615-677) is not built yet "
+                "(SURVEY row f-1); set system.material.use_raytracing=false for the split-sum path")
+        N = features.shape[0]
+        dev = features.device
+        if n_dev is None:
+            n_dev = torch.full((1,), N, dtype=torch.int32, device=dev)
+        env_id = torch.as_tensor(env_id, device=dev).to(torch.int32).reshape(-1)
+        if pix_idx is None:
+            # reference call style: one env for all rows (B=1 semantics)
+            pix_idx = torch.zeros(N, dtype=torch.int32, device=dev)
+            hw = 1 << 30
+            env_id = env_id[:1].contiguous()
+        outs = hipops.shade(features, normals, viewdirs, pix_idx, n_dev, env_id.contiguous(), self.atlas, self.mat,
+                            int(hw), want_debug)
+        mat_reg = hipops.material_smoothness(features, features_jitter, n_dev)
+        out = {"color": outs[0]}
+        if want_debug:
+            out.update({"albedo": outs[1], "specular_lights": outs[2], "diffuse_lights": outs[3],
+                        "specular_colors": outs[4], "diffuse_colors": outs[5], "metalness": outs[6],
+                        "roughness": outs[7]})
+        return out, mat_reg
+
+    def export(self, features, **kwargs):
+        """dreammat_material.py:765-797 (note: uses the *squared* roughness range there)."""
+        material = torch.sigmoid(features)
+        albedo = material[..., :3]
+        metallic = material[..., 3:4] * (self.cfg.max_metallic - self.cfg.min_metallic) + self.cfg.min_metallic
+        roughness = material[..., 4:5] * (self.cfg.max_roughness_squre - self.cfg.min_roughness_squre) \
+            + self.cfg.min_roughness_squre
+        return {"albedo": albedo, "metallic": metallic, "roughness": torch.sqrt(roughness + 1e-7)}

@@ -1,0 +1,180 @@
+/*
+ * dreammat_hip.h -- C ABI of libdreammat_hip.so (gfx950 / MI355X only).
+ *
+ * The reference (zzzyuqing/DreamMat) has NO native code and no FFI of its own: every kernel on
+ * its SDS hot path lives in CUDA-only pip dependencies that it calls through their Python API.
+ * Each entry point below replaces one of those calls; the citation names the reference call site
+ * (paths relative to threestudio_dreammat/threestudio/).  INTEGRATION.md shows the ctypes stubs a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in _host
+ *   - sizes are explicit; nothing is allocated inside: outputs and scratch come from the caller
+ *     (scratch sizes from the *_workspace_bytes queries)
+ *   - `stream` is the hipStream_t the work is enqueued on (0 = null stream); calls are async
+ *   - return: 0 = ok, negative = DM_ERR_* argument/workspace/unsupported, positive = hipError_t
+ *   - "row tensors" [N,C] are addressed as p[i*row_stride + c*col_stride] (strides in elements) so
+ *     the reference's [N,C] layout and the internal coalesced [C,N] layout both work copy-free
+ *   - `n_dev` arguments are DEVICE int32 row counts (produced by dm_gbuffer_compact) so that no
+ *     host synchronisation is needed between kernels; `n_max` only sizes the launch
+ */
+#ifndef DREAMMAT_HIP_H
+#define DREAMMAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* dm_stream_t; /* == hipStream_t */
+
+#define DM_OK 0
+#define DM_ERR_ARG (-1)
+#define DM_ERR_WORKSPACE (-2)
+#define DM_ERR_UNSUPPORTED (-3)
+
+int dm_abi_version(void);
+
+/* ---- mesh (host) ------------------------------------------------------------------------- */
+/* Edge -> opposite-vertex table used by the antialias kernels.  nvdiffrast rebuilds this hash
+ * inside every dr.antialias call (utils/rasterize.py:56); the DreamMat mesh is fixed
+ * (models/renderers/raytracing_renderer.py:101), so it is built once.  tri_host/opp_host: [n_tri,3]. */
+int dm_mesh_build_topology(const int32_t* tri_host, int32_t n_tri, int32_t* opp_host);
+
+/* ---- rasterize ---------------------------------------------------------------------------- */
+/* NVDiffRasterizerContext.vertex_transform (utils/rasterize.py:22-28):
+ * pos_clip[B,n_vert,4] = [v_pos,1] @ mvp[b]^T.  v_pos [n_vert,3], mvp [B,4,4] row-major. */
+int dm_vertex_transform(const float* v_pos, int n_vert, const float* mvp, int B, float* pos_clip,
+                        dm_stream_t stream);
+
+/* dr.rasterize(ctx, pos, tri, (H,W)) (utils/rasterize.py:37 <- raytracing_renderer.py:124).
+ * rast[B,H,W,4] = (u, v, z/w, tri_id+1), zeros where empty.  ws from dm_raster_workspace_bytes
+ * (a larger ws gives more bin capacity). */
+size_t dm_raster_workspace_bytes(int B, int n_tri, int H, int W);
+int dm_rasterize(const float* pos_clip, int B, int n_vert, const int32_t* tri, int n_tri, int H, int W,
+                 float* rast, void* ws, size_t ws_bytes, dm_stream_t stream);
+/* Blocking: *overflow_host = 1 if the last dm_rasterize on `ws` ran out of triangle-bin capacity
+ * (result then incomplete: retry with a larger workspace). */
+int dm_raster_overflowed(const void* ws, dm_stream_t stream, int* overflow_host);
+
+/* dr.interpolate(attr[None], rast, tri) (utils/rasterize.py:66-68 <- raytracing_renderer.py:136,150,178).
+ * attr [n_vert,C] shared by all views; out [n_pix,C], zeros where empty. */
+int dm_interpolate(const float* attr, int n_vert, int C, const int32_t* tri, const float* rast, long long n_pix,
+                   float* out, dm_stream_t stream);
+
+/* ---- antialias ---------------------------------------------------------------------------- */
+/* dr.antialias(color, rast, pos, tri) (utils/rasterize.py:56 <- raytracing_renderer.py:127,147,199)
+ * split into the per-step pair analysis (plan[B,H,W,2]) and its application, so the three calls of
+ * one step and the backward pass share one analysis.  Only the colour gradient exists (fixed mesh). */
+int dm_antialias_plan(const float* pos_clip, int B, int n_vert, const int32_t* tri, const int32_t* opp,
+                      const float* rast, int H, int W, float* plan, dm_stream_t stream);
+int dm_antialias_apply(const float* color, const float* plan, int B, int H, int W, int C, float* out,
+                       dm_stream_t stream); /* C in {1,3,4} */
+int dm_antialias_grad(const float* dout, const float* plan, int B, int H, int W, int C, float* dcolor,
+                      dm_stream_t stream);
+
+/* ---- G-buffer ----------------------------------------------------------------------------- */
+/* The `x[selector]` compaction + interpolate + normalize + tangent-plane jitter of
+ * raytracing_renderer.py:136-173 (get_orthogonal_directions :306-316) in one pass.
+ * Outputs are SoA with pitch `cap` rows: pix_idx[cap], pos[3,cap], pos_jitter[3,cap], nrm[3,cap],
+ * view[3,cap] (= -rays_d); *n_out = number of covered pixels (row-major order).
+ * jitter_u in [0,1), jitter_n ~ N(0,1), both [n_pix] (pass NULL for both to skip the jitter). */
+size_t dm_gbuffer_workspace_bytes(long long n_pix);
+int dm_gbuffer_compact(const float* rast, long long n_pix, const int32_t* tri, const float* v_pos,
+                       const float* v_nrm, const float* rays_d, const float* jitter_u, const float* jitter_n,
+                       float jitter_eps, long long cap, int32_t* pix_idx, float* pos, float* pos_jitter, float* nrm,
+                       float* view, int32_t* n_out, void* ws, size_t ws_bytes, dm_stream_t stream);
+
+/* ControlNet depth [B,H,W,1] / view-normal [B,H,W,3] maps before antialias
+ * (raytracing_renderer.py:129-147, compute_controlnet_normals :326-331).  minmax_ws: >= 8*B bytes. */
+int dm_control_maps(const float* rast, int B, int H, int W, const int32_t* tri, const float* v_nrm,
+                    const float* w2c, float* depth, float* normal, void* minmax_ws, dm_stream_t stream);
+
+/* color[selector] = values / values = dense[selector] (raytracing_renderer.py:198,201-207) */
+int dm_scatter_rows(const int32_t* pix_idx, const int32_t* n_dev, long long n_max, const float* src,
+                    long long src_row_stride, long long src_col_stride, int C, float* dst, dm_stream_t stream);
+int dm_gather_rows(const int32_t* pix_idx, const int32_t* n_dev, long long n_max, const float* src, int C,
+                   float* dst, long long dst_row_stride, long long dst_col_stride, dm_stream_t stream);
+
+/* ---- feature field ------------------------------------------------------------------------ */
+/* tcnn.Encoding(3, HashGrid...)(contract_to_unisphere(x)) (models/networks.py:55-64 <-
+ * models/geometry/dreammat_mesh.py:239-254; geometry/base.py:20-32 bounded branch with bbox +-radius).
+ * table [sum(lv_size), 2] fp32; enc [M, 2*n_levels]. Level tables are host arrays. */
+int dm_hashgrid_fwd(const float* x, long long x_rs, long long x_cs, const int32_t* m_dev, long long m_max,
+                    const float* table, int n_levels, const float* lv_scale_host, const uint32_t* lv_res_host,
+                    const uint32_t* lv_size_host, const uint32_t* lv_offset_host, float radius, float* enc,
+                    long long enc_rs, long long enc_cs, dm_stream_t stream);
+/* Backward of the above wrt the table; ADDS into dtable (caller zeroes it once per step). */
+int dm_hashgrid_bwd(const float* x, long long x_rs, long long x_cs, const int32_t* m_dev, long long m_max,
+                    const float* denc, long long denc_rs, long long denc_cs, int n_levels,
+                    const float* lv_scale_host, const uint32_t* lv_res_host, const uint32_t* lv_size_host,
+                    const uint32_t* lv_offset_host, float radius, float* dtable, dm_stream_t stream);
+
+/* ---- material / shading ------------------------------------------------------------------- */
+/* Pre-filtered environment atlas (envlight.EnvLight equivalents for all env maps, built once at
+ * configure time) + the FG LUT of models/materials/dreammat_material.py:399-404.  Texels are RGBA
+ * fp32; every cube face carries a 1-texel border.  Passed by pointer to a HOST struct. */
+typedef struct dm_env_atlas {
+    const float* spec;         /* [n_env][mips][6][(R+2)][(R+2)][4] */
+    const float* diff;         /* [n_env][6][(Rd+2)][(Rd+2)][4] */
+    const float* fg_lut;       /* [lut_res][lut_res][2] */
+    long long spec_env_stride; /* in texels */
+    long long diff_env_stride;
+    long long mip_off[8];      /* texel offset of each mip inside one env */
+    int mip_res[8];
+    int n_mips, diff_res, lut_res;
+    float min_rough_mip, max_rough_mip; /* envlight's 0.08 / 0.5 */
+} dm_env_atlas;
+typedef struct dm_mat_cfg { float min_metallic, max_metallic, min_roughness, max_roughness; } dm_mat_cfg;
+
+/* DreamMatMaterial.forward, use_raytracing=False branch (dreammat_material.py:746-762) fused with
+ * shade_splitsum (:679-711): sigmoid activation -> albedo/metallic/roughness -> FG LUT fetch ->
+ * diffuse + specular env lookups -> clamp.  One thread per covered pixel, all views in one launch.
+ * The 7 dbg_* outputs (dense [N,3]/[N,1]) are the reference's logging buffers; pass all NULL to skip. */
+int dm_shade_fwd(const dm_env_atlas* atlas_host, const dm_mat_cfg* mat_host, const float* nrm, long long nrm_rs,
+                 long long nrm_cs, const float* view, long long view_rs, long long view_cs, const float* feat,
+                 long long feat_rs, long long feat_cs, const int32_t* pix_idx, const int32_t* env_of_view,
+                 const int32_t* n_dev, long long n_max, int HW, float* color, long long color_rs,
+                 long long color_cs, float* dbg_albedo, float* dbg_spec_light, float* dbg_diff_light,
+                 float* dbg_spec_color, float* dbg_diff_color, float* dbg_metallic, float* dbg_roughness,
+                 dm_stream_t stream);
+/* d loss/d features from d loss/d color (recomputes the forward; nothing is saved). */
+int dm_shade_bwd(const dm_env_atlas* atlas_host, const dm_mat_cfg* mat_host, const float* nrm, long long nrm_rs,
+                 long long nrm_cs, const float* view, long long view_rs, long long view_cs, const float* feat,
+                 long long feat_rs, long long feat_cs, const int32_t* pix_idx, const int32_t* env_of_view,
+                 const int32_t* n_dev, long long n_max, int HW, const float* dcolor, long long dcolor_rs,
+                 long long dcolor_cs, float* dfeat, long long dfeat_rs, long long dfeat_cs, dm_stream_t stream);
+
+/* material_smoothness_grad (dreammat_material.py:110-123) on sigmoid(features) / sigmoid(features_jitter).
+ * fwd ADDS the loss into *loss_out (device float, caller zeroes); bwd writes both feature gradients. */
+int dm_matreg_fwd(const float* feat, long long f_rs, long long f_cs, const float* featj, long long j_rs,
+                  long long j_cs, const int32_t* n_dev, long long n_max, float* loss_out, dm_stream_t stream);
+int dm_matreg_bwd(const float* feat, long long f_rs, long long f_cs, const float* featj, long long j_rs,
+                  long long j_cs, const int32_t* n_dev, long long n_max, float grad_scale, float* dfeat,
+                  long long df_rs, long long df_cs, float* dfeatj, long long dj_rs, long long dj_cs,
+                  dm_stream_t stream);
+
+/* ---- attention ---------------------------------------------------------------------------- */
+/* The QK^T.softmax.V of every transformer block diffusers runs inside ControlNetModel /
+ * UNet2DConditionModel (models/guidance/dreammat_guidance.py:205-241, 261-282), bf16, MFMA.
+ * q [B,Sq,Hh,D], k [B,Skv,Hh,D], out [B,Sq,Hh,D] by strides (d contiguous);
+ * vt = V transposed [B,Hh,D,Skv_pad] by strides (kv contiguous, rows zero-padded to a multiple of 8).
+ * D % 8 == 0, D <= 160; pointers 16 B aligned; strides multiples of 8 (out: 4) elements. */
+int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* out, int B, int Hh, int Sq, int Skv,
+                          int D, long long q_bs, long long q_ss, long long q_hs, long long k_bs, long long k_ss,
+                          long long k_hs, long long vt_bs, long long vt_hs, long long vt_ds, long long o_bs,
+                          long long o_ss, long long o_hs, float scale, dm_stream_t stream);
+
+/* ---- optimiser ---------------------------------------------------------------------------- */
+/* torch.optim.Adam step (configs/dreammat.yaml:110-115 via systems/utils.py:34-53) over one flat
+ * fp32 buffer; grad is multiplied by grad_scale first (1/world after a sum all-reduce) and
+ * optionally zeroed for the next step.  n % 4 == 0, 16 B aligned. */
+int dm_adam_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, long long n, int step, float lr,
+                 float beta1, float beta2, float eps, float grad_scale, int zero_grad, dm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DREAMMAT_HIP_H */

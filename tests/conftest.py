@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def hostemu():
+    """TEST-ONLY host build of the product's __host__ __device__ kernel cores."""
+    import ctypes
+
+    from tests.hostemu import build as hb
+    return ctypes.CDLL(hb.build())

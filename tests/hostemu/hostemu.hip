@@ -1,0 +1,109 @@
+// TEST INFRASTRUCTURE: runs the product's per-thread __host__ __device__ arithmetic
+// (dreammat_amd/csrc/raster_core.h, shade_core.h) in plain host loops so the CPU-only test suite
+// can check it against the oracle without a GPU.  Never loaded by the product.
+#include <cstring>
+#include <vector>
+
+#include "../../dreammat_amd/csrc/raster_core.h"
+#include "../../dreammat_amd/csrc/shade_core.h"
+
+#pragma clang fp contract(off)
+using namespace dm;
+
+extern "C" {
+
+int emu_rasterize(const float* pos, int B, int Nv, const int* tri, int Nf, int H, int W, float* rast) {
+    size_t npix = (size_t)H * W;
+    std::vector<float> best(npix);
+    std::vector<int> bt(npix);
+    for (int b = 0; b < B; ++b) {
+        const float4* P = (const float4*)pos + (size_t)b * Nv;
+        float4* R = (float4*)rast + (size_t)b * npix;
+        for (size_t i = 0; i < npix; ++i) { best[i] = 2.0f; bt[i] = 0x7fffffff; R[i] = make_float4(0, 0, 0, 0); }
+        // reversed triangle order on purpose: the result must not depend on bin order
+        for (int t = Nf - 1; t >= 0; --t) {
+            float4 p0 = P[tri[3 * t]], p1 = P[tri[3 * t + 1]], p2 = P[tri[3 * t + 2]];
+            TriSetup s;
+            if (!tri_setup(p0, p1, p2, H, W, s)) continue;
+            EdgeEq e0 = edge_eq(s.x[1], s.y[1], s.x[2], s.y[2], s.sgn);
+            EdgeEq e1 = edge_eq(s.x[2], s.y[2], s.x[0], s.y[0], s.sgn);
+            EdgeEq e2 = edge_eq(s.x[0], s.y[0], s.x[1], s.y[1], s.sgn);
+            for (int py = s.py0; py <= s.py1; ++py)
+                for (int px = s.px0; px <= s.px1; ++px) {
+                    int cx = (2 * px + 1 - W) * kSubpix, cy = (2 * py + 1 - H) * kSubpix;
+                    if (edge_eval(e0, cx, cy) <= 0 || edge_eval(e1, cx, cy) <= 0 || edge_eval(e2, cx, cy) <= 0) continue;
+                    float b0, b1, zw;
+                    if (!frag_bary(p0, p1, p2, px, py, H, W, b0, b1, zw)) continue;
+                    size_t pi = (size_t)py * W + px;
+                    if (zw < best[pi] || (zw == best[pi] && t < bt[pi])) {
+                        best[pi] = zw; bt[pi] = t;
+                        R[pi] = make_float4(clamp01(b0), clamp01(b1), zw, (float)(t + 1));
+                    }
+                }
+        }
+    }
+    return 0;
+}
+
+int emu_aa_plan(const float* pos, int B, int Nv, const int* tri, const int* opp, const float* rast, int H, int W,
+                float* plan) {
+    for (int b = 0; b < B; ++b) {
+        const float4* P = (const float4*)pos + (size_t)b * Nv;
+        const float4* R = (const float4*)rast + (size_t)b * H * W;
+        float2* A = (float2*)plan + (size_t)b * H * W;
+        for (int py = 0; py < H; ++py)
+            for (int px = 0; px < W; ++px) {
+                size_t pi = (size_t)py * W + px;
+                float2 a = make_float2(0.f, 0.f);
+                if (px + 1 < W && R[pi].w != R[pi + 1].w) a.x = aa_pair(P, tri, opp, R[pi], R[pi + 1], H, W, px, py, 0);
+                if (py + 1 < H && R[pi].w != R[pi + W].w) a.y = aa_pair(P, tri, opp, R[pi], R[pi + W], H, W, px, py, 1);
+                A[pi] = a;
+            }
+    }
+    return 0;
+}
+
+struct emu_atlas {
+    const float* spec; const float* diff; const float* fg_lut;
+    long long spec_env_stride, diff_env_stride;
+    long long mip_off[8];
+    int mip_res[8];
+    int n_mips, diff_res, lut_res;
+    float min_rough_mip, max_rough_mip;
+};
+
+static EnvAtlas conv(const emu_atlas* in) {
+    EnvAtlas A;
+    A.spec = (const float4*)in->spec; A.diff = (const float4*)in->diff; A.fg_lut = (const float2*)in->fg_lut;
+    A.spec_env_stride = in->spec_env_stride; A.diff_env_stride = in->diff_env_stride;
+    for (int i = 0; i < 8; ++i) { A.mip_off[i] = in->mip_off[i]; A.mip_res[i] = in->mip_res[i]; }
+    A.n_mips = in->n_mips; A.diff_res = in->diff_res; A.lut_res = in->lut_res;
+    A.min_rough_mip = in->min_rough_mip; A.max_rough_mip = in->max_rough_mip;
+    return A;
+}
+
+// nrm/view [N,3], feat [N,5], env [N]; outputs color [N,3], dbg [N,17] = albedo3 spec_light3 diff_light3
+// spec_color3 diff_color3 metallic roughness; if dcolor != null also dfeat [N,5].
+int emu_shade(const emu_atlas* atlas, const float* matcfg, const float* nrm, const float* view, const float* feat,
+              const int* env, long long N, float* color, float* dbg, const float* dcolor, float* dfeat) {
+    EnvAtlas A = conv(atlas);
+    MatCfg M = {matcfg[0], matcfg[1], matcfg[2], matcfg[3]};
+    for (long long i = 0; i < N; ++i) {
+        ShadeCtx c;
+        shade_eval(A, M, env[i], f3(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]),
+                   f3(view[3 * i], view[3 * i + 1], view[3 * i + 2]), feat + 5 * i, c);
+        color[3 * i] = sat(c.pre.x); color[3 * i + 1] = sat(c.pre.y); color[3 * i + 2] = sat(c.pre.z);
+        if (dbg) {
+            float* d = dbg + 17 * i;
+            F3 sl = lin2srgb(c.spec), dl = lin2srgb(c.diff), sc = lin2srgb(c.spec_albedo), dc = lin2srgb(c.albedo);
+            d[0] = c.albedo.x; d[1] = c.albedo.y; d[2] = c.albedo.z;
+            d[3] = sl.x; d[4] = sl.y; d[5] = sl.z; d[6] = dl.x; d[7] = dl.y; d[8] = dl.z;
+            d[9] = sc.x; d[10] = sc.y; d[11] = sc.z; d[12] = dc.x; d[13] = dc.y; d[14] = dc.z;
+            d[15] = c.metallic; d[16] = c.roughness;
+        }
+        if (dcolor) shade_backward(M, c, f3(dcolor[3 * i], dcolor[3 * i + 1], dcolor[3 * i + 2]), dfeat + 5 * i);
+    }
+    return 0;
+}
+
+}  // extern "C"

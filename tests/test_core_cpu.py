@@ -1,0 +1,201 @@
+"""CPU suite (-m "not gpu"): oracle self-checks and parity of the product's per-thread
+kernel cores (compiled for the host by tests/hostemu) against the oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from dreammat_amd import _lib, envlight as penv, mesh as pmesh
+from oracle import camera, envlight as oenv, field as ofield, raster as oraster, shading as oshade
+from tests import util
+from tests.util import P
+
+
+def _scene(kind, B, H, W, seed=1):
+    if kind == "quad":
+        m = pmesh.quad_mesh()
+        batch = camera.camera_batch(torch.tensor([80.0]), torch.tensor([10.0]), torch.tensor([3.5]),
+                                    torch.tensor([35.0]), H, W)
+    else:
+        m = pmesh.displaced_sphere(*kind)
+        batch = util.make_views(B, H, W, seed)
+    md = util.mesh_dict(m)
+    pos = oraster.vertex_transform(md["v_pos"], batch["mvp_mtx"]).numpy()
+    return md, batch, np.ascontiguousarray(pos, np.float32)
+
+
+@pytest.mark.parametrize("kind,B,H,W", [("quad", 1, 64, 64), ((48, 40), 3, 128, 128), ((160, 160), 2, 256, 256),
+                                        ((24, 16), 2, 67, 45)])
+def test_raster_core_bit_exact_vs_oracle(hostemu, kind, B, H, W):
+    md, batch, pos = _scene(kind, B, H, W)
+    tri = md["t_pos_idx"]
+    ro = oraster.rasterize(pos, tri, H, W)
+    re = np.empty_like(ro)
+    hostemu.emu_rasterize(P(pos), B, pos.shape[1], P(tri), tri.shape[0], H, W, P(re))
+    assert (ro[..., 3] > 0).mean() > 0.05
+    assert np.array_equal(ro[..., 3], re[..., 3]), "coverage ids differ"
+    assert np.array_equal(ro.view(np.uint32), re.view(np.uint32)), "u/v/zw not bit-identical"
+    po = oraster.antialias_plan(pos, tri, md["opp"], ro)
+    pe = np.empty_like(po)
+    hostemu.emu_aa_plan(P(pos), B, pos.shape[1], P(tri), P(md["opp"]), P(ro), H, W, P(pe))
+    assert np.array_equal(po.view(np.uint32), pe.view(np.uint32))
+    assert (po != 0).sum() > 10
+
+
+def test_oracle_raster_vs_bruteforce_float64():
+    """away from edges the snapped integer rasterizer equals a float64 point-in-triangle."""
+    md, batch, pos = _scene((32, 24), 2, 96, 96)
+    tri = md["t_pos_idx"]
+    ro = oraster.rasterize(pos, tri, 96, 96)
+    ids, margin, _ = oraster.brute_force_cover(pos, tri, 96, 96)
+    rid = ro[..., 3].astype(np.int64)
+    safe = (ids > 0) & (margin > 0.08)
+    assert safe.mean() > 0.2
+    assert np.array_equal(rid[safe], ids[safe])
+    # and the silhouette agrees within a 1-pixel band
+    assert abs((rid > 0).mean() - (ids > 0).mean()) < 0.01
+
+
+def test_oracle_raster_shared_edge_partition():
+    """Top-left rule: a full-screen quad covers every pixel exactly once, including the diagonal."""
+    pos = np.array([[[-1, -1, 0, 1], [1, -1, 0, 1], [1, 1, 0, 1], [-1, 1, 0, 1]]], np.float32)
+    for tri in ([[0, 1, 2], [0, 2, 3]], [[2, 1, 0], [0, 2, 3]]):
+        r = oraster.rasterize(pos, np.array(tri, np.int32), 32, 32)
+        assert (r[..., 3] > 0).all()
+        # each triangle owns a strict half minus/plus the diagonal, never both
+        assert set(np.unique(r[..., 3])) == {1.0, 2.0}
+
+
+def test_interpolate_and_antialias_identities():
+    md, batch, pos = _scene((32, 24), 1, 64, 64)
+    tri = md["t_pos_idx"]
+    ro = oraster.rasterize(pos, tri, 64, 64)
+    ones = np.ones((pos.shape[1], 1), np.float32)
+    it = oraster.interpolate(ones, ro, tri)
+    m = ro[..., 3] > 0
+    assert np.allclose(it[m], 1.0, atol=1e-6) and np.all(it[~m] == 0)
+    plan = oraster.antialias_plan(pos, tri, md["opp"], ro)
+    const = np.full((1, 64, 64, 3), 0.37, np.float32)
+    assert np.allclose(oraster.antialias_apply(const, plan), const)      # AA of a constant image is identity
+    op = oraster.antialias_apply(m[..., None].astype(np.float32), plan)
+    assert op.min() >= -1e-6 and op.max() <= 1 + 1e-6 and ((op > 0.01) & (op < 0.99)).sum() > 20
+    # gradient is the exact transpose of the (linear) forward
+    x = torch.randn(1, 64, 64, 3, dtype=torch.float32)
+    y = torch.randn(1, 64, 64, 3, dtype=torch.float32)
+    lhs = (torch.from_numpy(oraster.antialias_apply(x.numpy(), plan)) * y).sum()
+    rhs = (x * torch.from_numpy(oraster.antialias_grad(y.numpy(), plan))).sum()
+    assert abs(lhs - rhs) < 1e-3 * abs(lhs)
+
+
+@pytest.fixture(scope="module")
+def env_pair():
+    lat = [util.synthetic_latlong(i) * 0.02 for i in range(2)]
+    fg = penv.approx_fg_lut()
+    atlas = penv.EnvAtlas(lat, scale=2.0, min_res=8, max_res=32, fg_lut=fg)
+    oenvs = [oenv.EnvLight(l, scale=2.0, min_res=8, max_res=32) for l in lat]
+    return lat, fg, atlas, oenvs
+
+
+def test_env_prefilter_product_vs_oracle(env_pair):
+    lat, fg, atlas, oenvs = env_pair
+    for e in range(2):
+        for k in range(3):
+            a, b = atlas.specular[e][k], oenvs[e].specular[k]
+            assert (a - b).abs().max() <= 1e-4 * b.abs().max()
+        assert (atlas.diffuse[e] - oenvs[e].diffuse).abs().max() < 1e-5
+    c = oenv.EnvLight(torch.full((16, 32, 3), 0.5), min_res=8, max_res=16)
+    d = torch.nn.functional.normalize(torch.randn(500, 3), dim=-1)
+    assert (c(d, torch.rand(500, 1)) - 0.5).abs().max() < 1e-5      # specular prefilter is normalised
+
+
+def test_shade_core_vs_oracle(hostemu, env_pair):
+    lat, fg, atlas, oenvs = env_pair
+    torch.manual_seed(0)
+    N = 20000
+    n = torch.nn.functional.normalize(torch.randn(N, 3), dim=-1)
+    v = torch.nn.functional.normalize(n + 0.8 * torch.randn(N, 3), dim=-1)
+    feat = (torch.randn(N, 5) * 1.5).requires_grad_()
+    env = torch.randint(0, 2, (N,))
+    out, _ = oshade.material_forward(feat, feat.detach() + 0.1, v, n, oenvs, env, fg)
+    dcol = torch.randn(N, 3)
+    (out["color"] * dcol).sum().backward()
+    color = np.empty((N, 3), np.float32); dbg = np.empty((N, 17), np.float32); dfeat = np.empty((N, 5), np.float32)
+    mat = np.array([0.0, 0.9, 0.1, 0.95], np.float32)
+    arrs = [np.ascontiguousarray(t.detach().numpy()) for t in (n, v, feat, dcol)]
+    ee = env.numpy().astype(np.int32)
+    hostemu.emu_shade(ctypes.byref(atlas.struct), P(mat), P(arrs[0]), P(arrs[1]), P(arrs[2]), P(ee),
+                      ctypes.c_longlong(N), P(color), P(dbg), P(arrs[3]), P(dfeat))
+    oc = out["color"].detach().numpy()
+    assert 0.2 < ((oc > 0) & (oc < 1)).mean()          # not everything is clamped
+    assert np.abs(color - oc).max() < 1e-5
+    names = [("albedo", 0, 3), ("specular_lights", 3, 6), ("diffuse_lights", 6, 9), ("specular_colors", 9, 12),
+             ("diffuse_colors", 12, 15), ("metalness", 15, 16), ("roughness", 16, 17)]
+    for k, a, b in names:
+        assert np.abs(dbg[:, a:b] - out[k].detach().numpy()).max() < 1e-5, k
+    g = feat.grad.numpy()
+    assert np.abs(dfeat - g).max() < 1e-4 * np.abs(g).max()
+
+
+def test_white_furnace():
+    """constant env L, albedo=1, metallic=0 -> color = L_d + (0.04 fg0 + fg1) L_s."""
+    env = oenv.EnvLight(torch.full((16, 32, 3), 0.2), min_res=8, max_res=16)
+    fg = penv.approx_fg_lut()
+    n = torch.nn.functional.normalize(torch.randn(100, 3), dim=-1)
+    feat = torch.tensor([[20.0, 20.0, 20.0, -20.0, 0.3]]).expand(100, 5)
+    out, _ = oshade.material_forward(feat, feat, n, n, [env], torch.zeros(100, dtype=torch.long), fg)
+    _, alb, met, rough = oshade.material_params(feat)
+    f = oenv.texture2d_linear_clamp(fg, torch.cat([torch.ones(100, 1), rough], -1))
+    expect = env(n) + (0.04 * f[:, :1] + f[:, 1:]) * 0.2
+    assert (out["color"] - expect.clamp(0, 1)).abs().max() < 1e-5
+
+
+def test_lin2srgb_knots():
+    x = torch.tensor([0.0, 0.0031308, 1.0, 2.0, -1.0])
+    y = oshade.lin2srgb(x)
+    assert y[0] == 0 and abs(y[1] - 12.92 * 0.0031308) < 1e-6 and abs(y[2] - 1.0) < 1e-6 and y[3] == 1 and y[4] == 0
+
+
+def test_hashgrid_layout():
+    lv, tot = ofield.grid_levels()
+    assert tot * 2 == 12599920                      # tcnn parameter count of dreammat.yaml:43-49
+    from dreammat_amd import hipops
+    spec = hipops.GridSpec()
+    assert spec.n_params == 12599920
+    assert [l["res"] for l in lv] == [l["res"] for l in spec.levels]
+    assert [l["size"] for l in lv] == [l["size"] for l in spec.levels]
+    # trilinear weights sum to one: a constant table encodes to that constant
+    lv4, tot4 = ofield.grid_levels(n_levels=4, log2_hashmap_size=10)
+    enc = ofield.hash_encode(torch.rand(64, 3), torch.full((tot4, 2), 0.7), lv4)
+    assert (enc - 0.7).abs().max() < 1e-6
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The library loads on a GPU-less box and exports exactly what include/dreammat_hip.h declares."""
+    import os, re
+    L = _lib.lib()
+    assert L.dm_abi_version() == 1
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "dreammat_hip.h")).read()
+    declared = set(re.findall(r"\b(dm_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
+    for name in declared:
+        assert hasattr(L, name)
+
+
+def test_topology_native_vs_oracle():
+    m = pmesh.displaced_sphere(24, 16)
+    tri = m.t_pos_idx.numpy().astype(np.int32)
+    from dreammat_amd import hipops
+    opp = hipops.build_topology(m.t_pos_idx).numpy()
+    assert np.array_equal(opp, oraster.build_topology(tri))
+    assert (opp >= 0).all()                         # closed manifold
+
+
+def test_attention_index_math_on_mfma_model():
+    from tests.mfma_sim import attention_wave_sim
+    rng = np.random.default_rng(0)
+    for D, Skv in ((64, 128), (64, 77), (32, 200)):
+        Q = rng.standard_normal((32, D)); K = rng.standard_normal((Skv, D)); V = rng.standard_normal((Skv, D))
+        S = Q @ K.T * D ** -0.5
+        Pm = np.exp(S - S.max(1, keepdims=True)); Pm /= Pm.sum(1, keepdims=True)
+        assert np.abs(attention_wave_sim(Q, K, V, D ** -0.5) - Pm @ V).max() < 1e-12
