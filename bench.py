@@ -1,0 +1,232 @@
+#!/usr/bin/env python
+"""Benchmark of the SDS material-fitting step (BASELINE.json metric: "SDS steps/sec (512^2, 8 views)").
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one optimizer step over ALL `--views` views (default 8): render (rasterize -> G-buffer ->
+hash-grid field -> split-sum shade -> antialias) -> VAE encode -> ControlNet + UNet (3 branches) ->
+SDS gradient -> backward into hash grid + MLP -> all-reduce (RCCL) -> fused Adam.  The 8 views are
+sharded over the N ranks (strong scaling: total work per step is fixed), config = BASELINE configs[2]:
+50 880-triangle displaced sphere, 512^2, 5 synthetic env maps, SD-2.1-base shaped nets (the reference's
+model, dreammat.yaml:60; --sd sd15 selects the SD-1.5 shapes), bf16, seeded random weights and
+synthetic condition maps (no checkpoints / Blender on this box).  Inputs of every step are resident in
+HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--views", type=int, default=8, help="total views per optimizer step (all ranks)")
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--sd", default="sd21-base", choices=["sd21-base", "sd15", "tiny"])
+    ap.add_argument("--mesh", default="sphere:160:160")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--env-res", type=int, default=128)
+    return ap.parse_args()
+
+
+def synthetic_latlong(seed, h=256, w=512):
+    """seeded log-normal sky + one Gaussian sun lobe (map1..5 are missing large blobs)."""
+    import math
+    g = torch.Generator().manual_seed(1000 + seed)
+    sky = torch.exp(torch.randn(h // 8, w // 8, 3, generator=g))
+    sky = torch.nn.functional.interpolate(sky.permute(2, 0, 1)[None], (h, w), mode="bilinear", align_corners=False)[0].permute(1, 2, 0)
+    d = torch.nn.functional.normalize(torch.randn(3, generator=g), dim=0)
+    v = torch.linspace(0, math.pi, h)[:, None].expand(h, w)
+    u = torch.linspace(-math.pi, math.pi, w)[None, :].expand(h, w)
+    dirs = torch.stack([torch.sin(v) * torch.sin(u), torch.cos(v), -torch.sin(v) * torch.cos(u)], -1)
+    lobe = 50.0 * torch.exp(-(1 - (dirs * d).sum(-1)) / 0.01)
+    return (sky * 0.5 + lobe[..., None]).contiguous()
+
+
+def system_config(a, views_per_rank):
+    return {
+        "geometry": {"shape_init": a.mesh, "shape_init_params": 0.8},
+        "material": {"use_raytracing": False, "environment_scale": 2.0, "env_max_res": a.env_res, "env_min_res": 16,
+                     "n_envs": 5},
+        "guidance": {"use_controlnet": True, "control_types": ["light"], "condition_scales": [1.0],
+                     "condition_scales_anneal": [0.8], "control_anneal_start_step": 700, "width": a.res,
+                     "height": a.res, "pretrained_model_name_or_path": a.sd, "cond_scale": 1.05,
+                     "uncond_scale": [0, -1.0, -0.5, 2000], "null_scale": [0, 0.0, -0.5, 2000], "noise_scale": 0.0,
+                     "min_step_percent": [500, 0.2, 0.02, 501], "max_step_percent": [500, 0.8, 0.5, 501]},
+        "prompt_processor": {"prompt": "a DSLR photo of a ceramic vase", "negative_prompt": "ugly, low resolution",
+                             "pretrained_model_name_or_path": a.sd,
+                             "cache_dir": os.path.join("/tmp", f"dm_text_cache_{os.getpid()}")},
+        "loss": {"lambda_sds": 1.0, "lambda_mat_reg": 1.0},
+        "optimizer": {"name": "Adam", "args": {"lr": 0.01, "betas": [0.9, 0.99], "eps": 1e-15}},
+    }
+
+
+def cpu_baseline(a, system, max_threads=None):
+    """The oracle (fp32 torch + C rasterizer) timed on this box's host cores on a bounded sample of the
+    SAME workload: 1 view of the render path fwd+bwd, 1 VAE encode fwd+bwd, 1 branch-item of
+    ControlNet+UNet; scaled to the full step (x views, x views, x 3*views)."""
+    import numpy as np
+    from oracle import envlight as oenv, field as ofield, raster as oraster, render as orender, sd_nets as osd
+    from oracle import camera as ocam
+    cores = os.cpu_count()
+    torch.set_num_threads(max_threads or cores)
+    H = W = a.res
+    mesh = system.geometry.mesh
+    md = dict(v_pos=mesh.v_pos.cpu().numpy(), v_nrm=mesh.v_nrm.cpu().numpy(),
+              t_pos_idx=mesh.t_pos_idx.cpu().numpy().astype(np.int32))
+    md["opp"] = oraster.build_topology(md["t_pos_idx"])
+    batch = ocam.camera_batch(torch.tensor([20.0]), torch.tensor([30.0]), torch.tensor([3.5]), torch.tensor([35.0]), H, W)
+    batch["env_id"] = torch.tensor([0])
+    # small env (the prefilter is init-time work, not part of a step)
+    env = oenv.EnvLight(synthetic_latlong(0, 32, 64), scale=2.0, min_res=8, max_res=16)
+    lv, tot = ofield.grid_levels()
+    geo = system.geometry
+    table = geo.encoding.encoding.params.detach().float().cpu().reshape(-1, 2).clone().requires_grad_()
+    w1 = geo.feature_network.layers[0].weight.detach().float().cpu().clone().requires_grad_()
+    w2 = geo.feature_network.layers[2].weight.detach().float().cpu().clone().requires_grad_()
+    fg = system.material.atlas.fg_lut.cpu()
+    g = torch.Generator().manual_seed(0)
+    t0 = time.time()
+    out = orender.render(md, batch, dict(table=table, w1=w1, w2=w2, levels=lv, radius=1.0), [env], fg,
+                         torch.rand(1, H, W, generator=g), torch.randn(1, H, W, generator=g))
+    (out["comp_rgb"].sum() + out["loss_mat_reg"]).backward()
+    t_render = time.time() - t0
+    gd = system.guidance
+    arch = gd.arch
+    sd_vae = {k: v.float().cpu() for k, v in gd.vae.state_dict().items()}
+    img = torch.rand(1, 3, H, W, generator=g).requires_grad_()
+    t0 = time.time()
+    mean, logvar = osd.vae_encode_moments(sd_vae, img * 2 - 1)
+    (mean + torch.exp(0.5 * logvar)).sum().backward()
+    t_vae = time.time() - t0
+    del sd_vae
+    sd_u = {k: v.float().cpu() for k, v in gd.unet.state_dict().items()}
+    sd_c = {k: v.float().cpu() for k, v in gd.controlnets[0].state_dict().items()}
+    lat = torch.randn(1, 4, H // 8, W // 8, generator=g)
+    ctx = torch.randn(1, 77, arch.cross_dim, generator=g)
+    cond = torch.rand(1, 22, H, W, generator=g)
+    tt = torch.tensor([500])
+    with torch.no_grad():
+        t0 = time.time()
+        d, m = osd.controlnet_forward(sd_c, lat, tt, ctx, cond, 1.0, arch.heads, arch.use_linear_projection)
+        osd.unet_forward(sd_u, lat, tt, ctx, arch.heads, arch.use_linear_projection, d, m)
+        t_nets = time.time() - t0
+    step_s = a.views * (t_render + t_vae) + 3 * a.views * t_nets
+    return {"value": 1.0 / step_s, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle fp32 on host: 1 view render fwd+bwd {t_render:.2f}s, 1 VAE-enc fwd+bwd {t_vae:.2f}s, "
+                      f"1 branch-item ControlNet+UNet fwd {t_nets:.2f}s; step = {a.views}x(render+vae) + {3 * a.views}x nets",
+            "host_cpus": cores}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert a.views % world == 0, "views must divide over ranks"
+    vpr = a.views // world
+
+    import dreammat_amd
+    from dreammat_amd import hipops
+    from dreammat_amd.data import RandomCameraDataModule
+    from dreammat_amd.system import Trainer, to_device
+    dreammat_amd._import_plugins()
+    torch.manual_seed(0)          # identical initial parameters on every rank (DDP broadcast equivalent)
+    lat = [synthetic_latlong(i) for i in range(5)]
+    system = dreammat_amd.find("dreammat-system")(system_config(a, vpr), material_kwargs={"latlongs": lat})
+    system.renderer.debug_outputs = False       # the 7 logging buffers are written every 1000 steps only
+    dm = RandomCameraDataModule(cfg={"height": a.res, "width": a.res, "batch_size": vpr, "use_fix_views": True,
+                                     "camera_distance_range": [3.0, 4.0], "fovy_range": [25, 45], "camera_perturb": 0.0,
+                                     "center_perturb": 0.0, "up_perturb": 0.0, "elevation_range": [-20, 45],
+                                     "azimuth_range": [-180, 180], "condition_source": "synthetic", "seed": 0},
+                                rank=rank, device=dev)
+    dm.setup("fit")
+    system.on_fit_start()
+    system.configure_optimizers()
+    trainer = Trainer(system, dm, max_steps=10 ** 9)
+    total = a.warmup + a.steps
+    batches = [to_device(dm.train_dataset.collate(), dev) for _ in range(total)]     # resident in HBM
+    torch.cuda.synchronize()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        trainer.train_one_step(batches[i])
+    sync()
+    hipops.enable_kernel_timing(True)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss, logs = trainer.train_one_step(batches[a.warmup + i])
+    sync()
+    elapsed = time.perf_counter() - t0
+    hipops.enable_kernel_timing(False)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kt = hipops.kernel_times()
+
+    if rank == 0:
+        ms = elapsed / a.steps * 1e3
+        res = {"metric": "SDS steps/sec (512^2, 8 views)", "value": a.steps / elapsed, "unit": "steps/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"BASELINE configs[2]: {system.geometry.mesh.t_pos_idx.shape[0]}-tri displaced sphere, "
+                                      f"{a.res}^2, {a.views} views/step, 5 synthetic env maps, {a.sd} UNet+22ch ControlNet "
+                                      f"(random init), split-sum shading, hash-grid field 16x2 2^19",
+                          "views_per_step": a.views, "views_per_rank": vpr, "resolution": a.res, "sd_arch": a.sd,
+                          "parallelism": f"dp{world} (views sharded, 1 all-reduce of {system.flat.numel * 4 / 1e6:.1f} MB fp32 grads)",
+                          "final_loss": float(loss)}}
+        # ---- roofline of the dominant hand-written kernel (attention, S=4096 self-attention launches)
+        attn = {k: v for k, v in kt.items() if k.startswith("attention")}
+        if attn:
+            key = max(attn, key=lambda k: attn[k]["avg_ms"] * attn[k]["launches"])
+            r = attn[key]
+            tf = r["work_per_launch"] / (r["avg_ms"] * 1e-3) / 1e12
+            res["roofline"] = {"kernel": "k_attn_fwd " + key, "bound": "mfma", "achieved": tf, "peak": 2500.0,
+                               "unit": "TFLOP/s", "frac": tf / 2500.0, "traffic": None,
+                               "launches_timed": r["launches"], "avg_us": r["avg_ms"] * 1e3}
+            tot_fl = sum(v["work_per_launch"] * v["launches"] for v in attn.values())
+            tot_ms = sum(v["avg_ms"] * v["launches"] for v in attn.values())
+            res["roofline_attention_all_shapes"] = {"TFLOP/s": tot_fl / (tot_ms * 1e-3) / 1e12, "frac": tot_fl / (tot_ms * 1e-3) / 2.5e15,
+                                                    "ms_per_step": tot_ms / a.steps, "launches_per_step": sum(v["launches"] for v in attn.values()) / a.steps}
+        for nm, key in (("roofline_shade_fwd", "shade_fwd"), ("roofline_shade_bwd", "shade_bwd")):
+            if key in kt:
+                r = kt[key]
+                gbs = r["work_per_launch"] / (r["avg_ms"] * 1e-3) / 1e9
+                res[nm] = {"kernel": "k_" + key, "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
+                           "frac": gbs / 8000.0, "traffic": None, "avg_us": r["avg_ms"] * 1e3,
+                           "covered_pixels": r["work_per_launch"] / (56.0 if key == "shade_fwd" else 76.0)}
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(a, system)
+            except Exception as e:   # the baseline is reporting only; never let it kill the bench line
+                res["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

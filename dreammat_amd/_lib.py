@@ -5,6 +5,9 @@ for any of these ops.
 """
 import ctypes
 import os
+
+import torch  # noqa: F401  -- MUST precede CDLL: PyTorch-ROCm bundles its own libamdhip64; loading ours first
+#                              binds the process to the system runtime and every launch fails with hipErrorNoDevice
 from ctypes import POINTER, c_float, c_int, c_int32, c_longlong, c_size_t, c_uint32, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -34,6 +34,7 @@ extern "C" int dm_adam_step(float* param, float* grad, float* exp_avg, float* ex
     double bc2 = 1.0 - pow((double)beta2, (double)step);
     long long n4 = n / 4;
     int blocks = (int)std::min<long long>((n4 + 255) / 256, 256 * 8);
+    DM_ENTER();
     hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, stream, (float4*)param, (float4*)grad, (float4*)exp_avg,
                        (float4*)exp_avg_sq, n4, lr, beta1, beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale,
                        zero_grad);

@@ -233,6 +233,7 @@ int launch_attn(const AttnArgs& a, hipStream_t stream) {
         attr_set = true;
     }
     dim3 grid(dm_div_up(a.Sq, kWaves * kQRowsPerWave), a.B * a.Hh);
+    DM_ENTER();
     hipLaunchKernelGGL(k_attn_fwd<DP>, grid, dim3(256), LDS, stream, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? DM_OK : (int)e;

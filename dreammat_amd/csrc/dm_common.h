@@ -10,6 +10,11 @@
 
 #define DM_HD __host__ __device__ __forceinline__
 
+// hipGetLastError() is per-thread and sticky across libraries: a benign error left behind by another
+// component of the process (PyTorch probing a feature, ...) must not be reported as ours, so every
+// entry point clears it first (DM_ENTER) and checks only its own launches (DM_LAUNCH_CHECK).
+#define DM_ENTER() do { (void)hipGetLastError(); } while (0)
+
 // Launch-check: positive return = hipError_t.
 #define DM_LAUNCH_CHECK()                          \
     do {                                           \

@@ -118,6 +118,7 @@ int dm_hashgrid_fwd(const float* x, long long x_rs, long long x_cs, const int32_
     a.x = x; a.x_rs = x_rs; a.x_cs = x_cs; a.table = (const float2*)table; a.out = enc; a.out_rs = enc_rs;
     a.out_cs = enc_cs; a.m_dev = m_dev; a.m_max = m_max; a.radius = radius; a.inv_2r = 1.0f / (2.0f * radius);
     dim3 grid(dm_div_up(m_max, 256), n_levels);
+    DM_ENTER();
     hipLaunchKernelGGL(k_hashgrid<false>, grid, dim3(256), 0, stream, a);
     DM_LAUNCH_CHECK();
     return DM_OK;
@@ -134,6 +135,7 @@ int dm_hashgrid_bwd(const float* x, long long x_rs, long long x_cs, const int32_
     a.x = x; a.x_rs = x_rs; a.x_cs = x_cs; a.dout = denc; a.dout_rs = denc_rs; a.dout_cs = denc_cs;
     a.dtable = dtable; a.m_dev = m_dev; a.m_max = m_max; a.radius = radius; a.inv_2r = 1.0f / (2.0f * radius);
     dim3 grid(dm_div_up(m_max, 256), n_levels);
+    DM_ENTER();
     hipLaunchKernelGGL(k_hashgrid<true>, grid, dim3(256), 0, stream, a);
     DM_LAUNCH_CHECK();
     return DM_OK;

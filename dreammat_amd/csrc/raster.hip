@@ -526,6 +526,7 @@ int dm_vertex_transform(const float* v_pos, int n_vert, const float* mvp, int B,
                         hipStream_t stream) {
     if (!v_pos || !mvp || !pos_clip || n_vert <= 0 || B <= 0) return DM_ERR_ARG;
     dim3 grid(dm_div_up(n_vert, 256), B);
+    DM_ENTER();
     hipLaunchKernelGGL(k_vertex_transform, grid, dim3(256), 0, stream, v_pos, n_vert, mvp, B, (float4*)pos_clip);
     DM_LAUNCH_CHECK();
     return DM_OK;
@@ -542,6 +543,7 @@ int dm_rasterize(const float* pos_clip, int B, int n_vert, const int32_t* tri, i
     int ntiles = (int)ntiles_ll;
     RasterWs w = carve_ws(ws, ws_bytes, ntiles);
     if (w.capacity < 64) return DM_ERR_WORKSPACE;
+    DM_ENTER();
     DM_HIP(hipMemsetAsync(ws, 0, 256 + align_up((size_t)ntiles * 4, 256), stream));  // header + tile_cnt
     dim3 tg(dm_div_up(n_tri, 256), B);
     hipLaunchKernelGGL(k_bin<false>, tg, dim3(256), 0, stream, (const float4*)pos_clip, B, n_vert, tri, n_tri, H, W,
@@ -568,6 +570,7 @@ int dm_raster_overflowed(const void* ws, hipStream_t stream, int* overflow_host)
 int dm_interpolate(const float* attr, int n_vert, int C, const int32_t* tri, const float* rast, long long n_pix,
                    float* out, hipStream_t stream) {
     if (!attr || !tri || !rast || !out || C <= 0 || n_pix <= 0 || n_vert <= 0) return DM_ERR_ARG;
+    DM_ENTER();
     hipLaunchKernelGGL(k_interpolate, dim3(dm_div_up(n_pix, 256)), dim3(256), 0, stream, attr, C, tri,
                        (const float4*)rast, n_pix, out);
     DM_LAUNCH_CHECK();
@@ -578,6 +581,7 @@ int dm_antialias_plan(const float* pos_clip, int B, int n_vert, const int32_t* t
                       const float* rast, int H, int W, float* plan, hipStream_t stream) {
     if (!pos_clip || !tri || !opp || !rast || !plan || B <= 0 || H <= 0 || W <= 0) return DM_ERR_ARG;
     dim3 block(64, 4), grid(dm_div_up(W, 64), dm_div_up(H, 4), B);
+    DM_ENTER();
     hipLaunchKernelGGL(k_aa_plan, grid, block, 0, stream, (const float4*)pos_clip, n_vert, tri, opp,
                        (const float4*)rast, H, W, (float2*)plan);
     DM_LAUNCH_CHECK();
@@ -588,6 +592,7 @@ int dm_antialias_apply(const float* color, const float* plan, int B, int H, int 
                        hipStream_t stream) {
     if (!color || !plan || !out || B <= 0 || H <= 0 || W <= 0) return DM_ERR_ARG;
     dim3 block(64, 4), grid(dm_div_up(W, 64), dm_div_up(H, 4), B);
+    DM_ENTER();
     if (C == 1) hipLaunchKernelGGL(k_aa_apply<1>, grid, block, 0, stream, color, (const float2*)plan, H, W, out);
     else if (C == 3) hipLaunchKernelGGL(k_aa_apply<3>, grid, block, 0, stream, color, (const float2*)plan, H, W, out);
     else if (C == 4) hipLaunchKernelGGL(k_aa_apply<4>, grid, block, 0, stream, color, (const float2*)plan, H, W, out);
@@ -600,6 +605,7 @@ int dm_antialias_grad(const float* dout, const float* plan, int B, int H, int W,
                       hipStream_t stream) {
     if (!dout || !plan || !dcolor || B <= 0 || H <= 0 || W <= 0) return DM_ERR_ARG;
     dim3 block(64, 4), grid(dm_div_up(W, 64), dm_div_up(H, 4), B);
+    DM_ENTER();
     if (C == 1) hipLaunchKernelGGL(k_aa_grad<1>, grid, block, 0, stream, dout, (const float2*)plan, H, W, dcolor);
     else if (C == 3) hipLaunchKernelGGL(k_aa_grad<3>, grid, block, 0, stream, dout, (const float2*)plan, H, W, dcolor);
     else if (C == 4) hipLaunchKernelGGL(k_aa_grad<4>, grid, block, 0, stream, dout, (const float2*)plan, H, W, dcolor);
@@ -626,6 +632,7 @@ int dm_gbuffer_compact(const float* rast, long long n_pix, const int32_t* tri, c
     int nblocks = dm_div_up(n_pix, kCompactBlock);
     if (ws_bytes < (size_t)nblocks * 4) return DM_ERR_WORKSPACE;
     int* block_cnt = (int*)ws;
+    DM_ENTER();
     hipLaunchKernelGGL(k_cover_count, dim3(nblocks), dim3(kCompactBlock), 0, stream, (const float4*)rast, n_pix,
                        block_cnt);
     hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, stream, block_cnt, nblocks, n_out);
@@ -643,6 +650,7 @@ int dm_control_maps(const float* rast, int B, int H, int W, const int32_t* tri, 
                     const float* w2c, float* depth, float* normal, void* minmax_ws, hipStream_t stream) {
     if (!rast || !tri || !v_nrm || !w2c || !depth || !normal || !minmax_ws || B <= 0) return DM_ERR_ARG;
     int HW = H * W;
+    DM_ENTER();
     hipLaunchKernelGGL(k_minmax_init, dim3(dm_div_up(B, 64)), dim3(64), 0, stream, (unsigned*)minmax_ws, B);
     dim3 grid(dm_div_up(HW, 256), B);
     hipLaunchKernelGGL(k_depth_minmax, grid, dim3(256), 0, stream, (const float4*)rast, HW, (unsigned*)minmax_ws);
@@ -655,6 +663,7 @@ int dm_control_maps(const float* rast, int B, int H, int W, const int32_t* tri, 
 int dm_scatter_rows(const int32_t* pix_idx, const int32_t* n_dev, long long n_max, const float* src,
                     long long src_row_stride, long long src_col_stride, int C, float* dst, hipStream_t stream) {
     if (!pix_idx || !n_dev || !src || !dst || n_max <= 0 || C <= 0) return DM_ERR_ARG;
+    DM_ENTER();
     hipLaunchKernelGGL(k_scatter_rows, dim3(dm_div_up(n_max, 256)), dim3(256), 0, stream, pix_idx, n_dev, src,
                        src_row_stride, src_col_stride, C, dst);
     DM_LAUNCH_CHECK();
@@ -664,6 +673,7 @@ int dm_scatter_rows(const int32_t* pix_idx, const int32_t* n_dev, long long n_ma
 int dm_gather_rows(const int32_t* pix_idx, const int32_t* n_dev, long long n_max, const float* src, int C,
                    float* dst, long long dst_row_stride, long long dst_col_stride, hipStream_t stream) {
     if (!pix_idx || !n_dev || !src || !dst || n_max <= 0 || C <= 0) return DM_ERR_ARG;
+    DM_ENTER();
     hipLaunchKernelGGL(k_gather_rows, dim3(dm_div_up(n_max, 256)), dim3(256), 0, stream, pix_idx, n_dev, src, C, dst,
                        dst_row_stride, dst_col_stride);
     DM_LAUNCH_CHECK();

@@ -171,6 +171,7 @@ int dm_shade_fwd(const dm_env_atlas* atlas, const dm_mat_cfg* mat, const float* 
     a.albedo = dbg_albedo; a.spec_light = dbg_spec_light; a.diff_light = dbg_diff_light;
     a.spec_color = dbg_spec_color; a.diff_color = dbg_diff_color; a.metallic = dbg_metallic;
     a.roughness = dbg_roughness;
+    DM_ENTER();
     hipLaunchKernelGGL(k_shade_fwd, dim3(dm_div_up(n_max, 256)), dim3(256), 0, stream, a);
     DM_LAUNCH_CHECK();
     return DM_OK;
@@ -190,6 +191,7 @@ int dm_shade_bwd(const dm_env_atlas* atlas, const dm_mat_cfg* mat, const float* 
     a.pix_idx = pix_idx; a.env_of_view = env_of_view; a.n_dev = n_dev; a.HW = HW;
     a.dcolor = {dcolor, dcolor_rs, dcolor_cs};
     a.dfeat = {dfeat, dfeat_rs, dfeat_cs};
+    DM_ENTER();
     hipLaunchKernelGGL(k_shade_bwd, dim3(dm_div_up(n_max, 256)), dim3(256), 0, stream, a);
     DM_LAUNCH_CHECK();
     return DM_OK;
@@ -201,6 +203,7 @@ int dm_matreg_fwd(const float* feat, long long f_rs, long long f_cs, const float
     if (!feat || !featj || !n_dev || !loss_out || n_max <= 0) return DM_ERR_ARG;
     Strided f = {feat, f_rs, f_cs}, j = {featj, j_rs, j_cs};
     StridedOut z = {nullptr, 0, 0};
+    DM_ENTER();
     hipLaunchKernelGGL(k_matreg, dim3(dm_div_up(n_max, 256)), dim3(256), 0, stream, f, j, n_dev, 0.f, loss_out, z, z, 0);
     DM_LAUNCH_CHECK();
     return DM_OK;
@@ -213,6 +216,7 @@ int dm_matreg_bwd(const float* feat, long long f_rs, long long f_cs, const float
     if (!feat || !featj || !n_dev || !dfeat || !dfeatj || n_max <= 0) return DM_ERR_ARG;
     Strided f = {feat, f_rs, f_cs}, j = {featj, j_rs, j_cs};
     StridedOut df = {dfeat, df_rs, df_cs}, dj = {dfeatj, dj_rs, dj_cs};
+    DM_ENTER();
     hipLaunchKernelGGL(k_matreg, dim3(dm_div_up(n_max, 256)), dim3(256), 0, stream, f, j, n_dev, grad_scale, nullptr,
                        df, dj, 1);
     DM_LAUNCH_CHECK();

@@ -41,7 +41,11 @@ class HashGridEncoding(nn.Module):
 
     def forward(self, x_world):
         """x_world [M,3] in world space; contract_to_unisphere is fused into the kernel."""
-        return hipops.hashgrid_encode(x_world, self.encoding.params, self.spec, self.radius)
+        p = self.encoding.params
+        # when the trainer has re-homed the parameters into its flat buffer (system.FlatParams), the
+        # backward kernel accumulates straight into that gradient slice
+        sink = p.grad if (p.grad is not None and torch.is_grad_enabled() and p.requires_grad) else None
+        return hipops.hashgrid_encode(x_world, p, self.spec, self.radius, grad_sink=sink)
 
 
 class VanillaMLP(nn.Module):

@@ -1,0 +1,252 @@
+"""`stable-diffusion-dreammat-guidance` plugin
+(threestudio/models/guidance/dreammat_guidance.py:43-627, class StableDiffusionLightGuidance).
+
+Same Config keys, same __call__ / update_step contract, same arithmetic:
+  encode_images (:284-292) -> compute_grad_sds (:440-497) with compute_without_perpneg (:388-438):
+  3 branches (text / negative / null) through ControlNet then UNet -> grad = (1-abar_t)(c e_text +
+  u e_uncond + n e_null + s e) -> nan_to_num -> loss_sds = 0.5*||latents - (latents-grad)||^2 / B.
+Differences, all forced by SURVEY D4 (the reference only works at B=1 per process):
+  * the ControlNet conditioning is repeated for the 3 branches (the reference relies on a [3]+[1]
+    broadcast that breaks for B>1);
+  * all random draws (t, noise, VAE posterior noise) can be injected (`rng=` dict) for parity tests.
+Nets run in bf16 on the MI355X (reference: fp16, `half_precision_weights`), attention in the MFMA kernel.
+"""
+from dataclasses import dataclass, field
+from typing import Any, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+import dreammat_amd
+from .base import BaseObject
+from .config import C
+from .sd import (AutoencoderKLEncoder, ControlNetModel, DDIMScheduler, PaddedContext, UNet2DConditionModel,
+                 arch_for, load_component)
+
+
+@dreammat_amd.register("stable-diffusion-dreammat-guidance")
+class StableDiffusionLightGuidance(BaseObject):
+    @dataclass
+    class Config(BaseObject.Config):
+        width: int = 512
+        height: int = 512
+        cache_dir: Optional[str] = None
+        pretrained_model_name_or_path: str = "stabilityai/stable-diffusion-2-1-base"
+        controlnet_path: Optional[str] = None
+        enable_memory_efficient_attention: bool = False
+        enable_sequential_cpu_offload: bool = False
+        enable_attention_slicing: bool = False
+        enable_channels_last_format: bool = False
+        half_precision_weights: bool = True
+        use_controlnet: bool = False
+        condition_scale: float = 1.5
+        control_anneal_start_step: Optional[int] = None
+        control_anneal_end_scale: Optional[float] = None
+        control_types: List = field(default_factory=lambda: ["depth", "canny"])
+        condition_scales: List = field(default_factory=lambda: [1.0, 1.0])
+        condition_scales_anneal: List = field(default_factory=lambda: [1.0, 1.0])
+        p2p_condition_type: str = "p2p"
+        canny_lower_bound: int = 50
+        canny_upper_bound: int = 100
+        min_step_percent: Any = 0.02
+        max_step_percent: Any = 0.98
+        cond_scale: Any = 1
+        uncond_scale: Any = 0
+        null_scale: Any = -1
+        noise_scale: Any = 0
+        perpneg_scale: Any = 0.0
+        view_dependent_prompting: bool = True
+        grad_clip_val: Optional[float] = None
+        grad_normalize: Optional[bool] = False
+        # additions: compute dtype on the accelerator and the init seed used when no weights are on disk
+        weights_dtype: str = "bfloat16"
+        synthetic_seed: int = 1234
+
+    cfg: Config
+
+    def configure(self) -> None:
+        self.use_controlnet = self.cfg.use_controlnet
+        on_gpu = torch.cuda.is_available()
+        self.device = self.device if on_gpu else torch.device("cpu")
+        if self.cfg.half_precision_weights and on_gpu:
+            self.weights_dtype = getattr(torch, self.cfg.weights_dtype)
+        else:
+            self.weights_dtype = torch.float32
+        arch = arch_for(self.cfg.pretrained_model_name_or_path)
+        self.arch = arch
+        root = self._model_root()
+        gen_state = torch.random.get_rng_state()
+        torch.manual_seed(self.cfg.synthetic_seed)
+        with torch.device(self.device):           # parameters are created (and randomly initialised) on the GPU
+            self.vae = AutoencoderKLEncoder(arch)
+            self.unet = UNet2DConditionModel(arch)
+        self.real_weights = {"vae": load_component(self.vae, root, "vae"),
+                             "unet": load_component(self.unet, root, "unet")}
+        self.controlnets = []
+        if self.use_controlnet:
+            for ct in self.cfg.control_types:
+                if ct != "light":
+                    # 'depth' / 'normal' name sd15 ControlNets in the reference (:103-106): 3-channel cond
+                    raise NotImplementedError(f"control type '{ct}': only the 22-channel 'light' ControlNet is built")
+                with torch.device(self.device):
+                    cn = ControlNetModel.from_unet(self.unet)
+                loaded = load_component(cn, self.cfg.controlnet_path, "controlnet")
+                if not loaded:
+                    # zero-convs would make a random-init ControlNet a no-op: give the synthetic one signal
+                    for conv in list(cn.controlnet_down_blocks) + [cn.controlnet_mid_block, cn.controlnet_cond_embedding.conv_out]:
+                        torch.nn.init.normal_(conv.weight, std=0.02)
+                self.real_weights["controlnet"] = loaded
+                self.controlnets.append(cn)
+        torch.random.set_rng_state(gen_state)
+        for m in [self.vae, self.unet] + self.controlnets:
+            m.to(device=self.device, dtype=self.weights_dtype).eval()
+            for p in m.parameters():
+                p.requires_grad_(False)
+            if self.cfg.enable_channels_last_format:
+                m.to(memory_format=torch.channels_last)
+        self.scheduler = DDIMScheduler()
+        self.num_train_timesteps = self.scheduler.num_train_timesteps
+        self.set_min_max_steps()
+        self.alphas = self.scheduler.alphas_cumprod.to(self.device)
+        self.noise_scale, self.cond_scale, self.uncond_scale, self.null_scale, self.perpneg_scale = 0.0, 1.0, -0.0, -1.0, 0.0
+        self.condition_scales = list(self.cfg.condition_scales)
+
+    def _model_root(self):
+        import os
+        name = self.cfg.pretrained_model_name_or_path
+        for cand in (name, os.path.join(self.cfg.cache_dir or "", name),
+                     os.path.join(self.cfg.cache_dir or "", "models--" + name.replace("/", "--"))):
+            if cand and os.path.isdir(cand):
+                return cand
+        return os.environ.get("DREAMMAT_SD_DIR")
+
+    # ---------------------------------------------------------------- net wrappers (:205-292)
+    def multi_control_forward(self, sample, timestep, ctx, controlnet_cond, conditioning_scale):
+        down, mid = None, None
+        for i, (image, scale, cn) in enumerate(zip(controlnet_cond, conditioning_scale, self.controlnets)):
+            d, m = cn(sample.to(self.weights_dtype), timestep, ctx, image.to(self.weights_dtype), scale)
+            if i == 0:
+                down, mid = d, m
+            else:
+                down = [a + b for a, b in zip(down, d)]
+                mid = mid + m
+        return down, mid
+
+    def forward_unet(self, latents, t, ctx, down=None, mid=None):
+        return self.unet(latents.to(self.weights_dtype), t, ctx, down_block_additional_residuals=down,
+                         mid_block_additional_residual=mid).to(latents.dtype)
+
+    def encode_images(self, imgs, posterior_noise=None):
+        input_dtype = imgs.dtype
+        imgs = imgs * 2.0 - 1.0
+        B = imgs.shape[0]
+        lh, lw = imgs.shape[2] // 8, imgs.shape[3] // 8
+        if posterior_noise is None:
+            posterior_noise = torch.randn(B, 4, lh, lw, device=imgs.device)
+        latents = self.vae.sample(imgs.to(self.weights_dtype), posterior_noise) * self.vae.scaling_factor
+        return latents.to(input_dtype)
+
+    def get_latents(self, rgb_BCHW, rgb_as_latents=False, posterior_noise=None):
+        if rgb_as_latents:
+            return F.interpolate(rgb_BCHW, (64, 64), mode="bilinear", align_corners=False)
+        if rgb_BCHW.shape[2] != self.cfg.height:
+            rgb_BCHW = F.interpolate(rgb_BCHW, (self.cfg.width, self.cfg.height), mode="bilinear", align_corners=False)
+        return self.encode_images(rgb_BCHW, posterior_noise)
+
+    def prepare_image_cond(self, control_type, cond):
+        control = cond.permute(0, 3, 1, 2)
+        if control_type == "depth":
+            control = control.repeat(1, 3, 1, 1)
+        if control.shape[2] != self.cfg.height:
+            # the reference hard-codes (512,512) here (:530-532); generalised to the configured size
+            control = F.interpolate(control, (self.cfg.height, self.cfg.width), mode="bilinear", align_corners=False)
+        return control
+
+    # ---------------------------------------------------------------- SDS (:388-497)
+    def compute_without_perpneg(self, condition_scales, prompt_utils, latents_noisy, t, elevation, azimuth,
+                                camera_distances, image_cond):
+        text_embeddings = prompt_utils.get_text_embeddings(elevation, azimuth, camera_distances,
+                                                           self.cfg.view_dependent_prompting,
+                                                           return_null_text_embeddings=True)
+        with torch.no_grad():
+            ctx = PaddedContext(text_embeddings.to(self.weights_dtype))
+            latent_model_input = torch.cat([latents_noisy] * 3, dim=0)
+            t3 = torch.cat([t] * 3)
+            if self.use_controlnet and not all(s == 0 for s in condition_scales):
+                cond3 = [torch.cat([c] * 3, dim=0) for c in image_cond]
+                down, mid = self.multi_control_forward(latent_model_input, t3, ctx, cond3, condition_scales)
+                noise_pred = self.forward_unet(latent_model_input, t3, ctx, down, mid)
+            else:
+                noise_pred = self.forward_unet(latent_model_input, t3, ctx)
+        return noise_pred.chunk(3)
+
+    def compute_grad_sds(self, prompt_utils, condition_scales, latents, image_cond, elevation, azimuth,
+                         camera_distances, rng=None):
+        B = latents.shape[0]
+        rng = rng or {}
+        t = rng.get("t")
+        if t is None:
+            t = torch.randint(self.min_step, self.max_step + 1, [B], dtype=torch.long, device=latents.device)
+        noise = rng.get("noise")
+        if noise is None:
+            noise = torch.randn_like(latents)
+        latents_noisy = self.scheduler.add_noise(latents, noise, t)
+        if getattr(prompt_utils, "use_perp_neg", False):
+            raise NotImplementedError("perp-neg prompting (dreammat_guidance.py:319-386) is not on the default path")
+        e_text, e_uncond, e_null = self.compute_without_perpneg(condition_scales, prompt_utils, latents_noisy, t,
+                                                                elevation, azimuth, camera_distances, image_cond)
+        w = (1 - self.alphas[t]).view(-1, 1, 1, 1)
+        grad = w * (self.cond_scale * e_text + self.uncond_scale * e_uncond + self.null_scale * e_null
+                    + self.noise_scale * noise)
+        ev = {"uncond_m_noise_norm": (e_uncond - noise).norm(), "text_m_noise_norm": (e_text - noise).norm(),
+              "text_m_uncond_norm": (e_text - e_uncond).norm(), "text_m_null_norm": (e_text - e_null).norm(),
+              "null_m_uncond_norm": (e_null - e_uncond).norm(), "noise_norm": noise.norm(),
+              "uncond_norm": e_uncond.norm(), "text_norm": e_text.norm()}
+        self._last = {"t": t, "noise": noise, "e_text": e_text, "e_uncond": e_uncond, "e_null": e_null}
+        return grad, ev
+
+    def __call__(self, rgb, prompt_utils, elevation, azimuth, camera_distances, env_id=None,
+                 rgb_as_latents=False, rng=None, **kwargs):
+        batch_size = rgb.shape[0]
+        rng = rng or {}
+        latents = self.get_latents(rgb.permute(0, 3, 1, 2), rgb_as_latents, rng.get("posterior_noise"))
+        image_cond, condition_scales = [], []
+        if self.use_controlnet:
+            for k, ct in enumerate(self.cfg.control_types):
+                src = {"depth": kwargs.get("cond_depth"), "normal": kwargs.get("cond_normal"),
+                       "light": kwargs.get("condition_map")}.get(ct, kwargs.get("cond_rgb"))
+                image_cond.append(self.prepare_image_cond(ct, src))
+                condition_scales.append(self.condition_scales[k])
+        else:
+            condition_scales = [0]
+        grad, ev = self.compute_grad_sds(prompt_utils, condition_scales, latents, image_cond, elevation, azimuth,
+                                         camera_distances, rng)
+        grad = torch.nan_to_num(grad)
+        if self.cfg.grad_clip_val is not None:
+            grad = grad.clamp(-self.cfg.grad_clip_val, self.cfg.grad_clip_val)
+        if self.cfg.grad_normalize:
+            grad = grad / (grad.norm(2) + 1e-8)
+        target = (latents - grad).detach()
+        loss_sds = 0.5 * F.mse_loss(latents, target, reduction="sum") / batch_size
+        out = {"loss_sds": loss_sds, "grad_norm": grad.norm()}
+        out.update(ev)
+        self._last["latents"] = latents
+        self._last["grad"] = grad
+        return out
+
+    # ---------------------------------------------------------------- schedules (:603-626)
+    def set_min_max_steps(self, min_step_percent=0.02, max_step_percent=0.98):
+        self.min_step = int(self.num_train_timesteps * min_step_percent)
+        self.max_step = int(self.num_train_timesteps * max_step_percent)
+
+    def update_step(self, epoch: int, global_step: int, on_load_weights: bool = False):
+        self.noise_scale = C(self.cfg.noise_scale, epoch, global_step)
+        self.cond_scale = C(self.cfg.cond_scale, epoch, global_step)
+        self.uncond_scale = C(self.cfg.uncond_scale, epoch, global_step)
+        self.null_scale = C(self.cfg.null_scale, epoch, global_step)
+        self.perpneg_scale = C(self.cfg.perpneg_scale, epoch, global_step)
+        self.set_min_max_steps(min_step_percent=C(self.cfg.min_step_percent, epoch, global_step),
+                               max_step_percent=C(self.cfg.max_step_percent, epoch, global_step))
+        if (self.use_controlnet and self.cfg.control_anneal_start_step is not None
+                and global_step > self.cfg.control_anneal_start_step):
+            self.condition_scales = list(self.cfg.condition_scales_anneal)

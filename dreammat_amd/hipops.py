@@ -17,6 +17,43 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ---- optional per-kernel HIP-event timing (bench.py's live roofline numbers) --------------------
+_TIMING = {"on": False, "events": {}}
+
+
+def enable_kernel_timing(on=True):
+    _TIMING["on"] = on
+    _TIMING["events"] = {}
+
+
+class _Timed:
+    """Brackets one launch with HIP events on the stream it is enqueued on (torch's current stream)."""
+
+    def __init__(self, key, work=0.0):
+        self.key, self.work = key, work
+
+    def __enter__(self):
+        if _TIMING["on"]:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if _TIMING["on"]:
+            self.e1.record()
+            _TIMING["events"].setdefault(self.key, []).append((self.e0, self.e1, self.work))
+
+
+def kernel_times():
+    """{key: {"launches", "avg_ms", "work_per_launch"}} -- call after torch.cuda.synchronize()."""
+    out = {}
+    for k, evs in _TIMING["events"].items():
+        ms = [a.elapsed_time(b) for a, b, _ in evs]
+        out[k] = {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "work_per_launch": sum(w for _, _, w in evs) / len(evs)}
+    return out
+
+
 def _need_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -243,10 +280,12 @@ class GridSpec:
 
 
 class _HashGrid(torch.autograd.Function):
-    """x [M,3] (any strides) -> enc, returned as an [M,2L] VIEW of a feature-major [2L,M] buffer."""
+    """x [M,3] (any strides) -> enc, returned as an [M,2L] VIEW of a feature-major [2L,M] buffer.
+    `grad_sink`: optional pre-allocated gradient buffer of `table` (the flat all-reduce buffer); the
+    backward kernel then scatter-adds straight into it instead of materialising a 50 MB temporary."""
 
     @staticmethod
-    def forward(ctx, x, table, spec, radius):
+    def forward(ctx, x, table, spec, radius, grad_sink):
         _need_cuda(x, table)
         assert table.dtype == torch.float32 and table.is_contiguous()
         M = x.shape[0]
@@ -258,7 +297,7 @@ class _HashGrid(torch.autograd.Function):
                                              spec.c_scale, spec.c_res, spec.c_size, spec.c_offset, float(radius),
                                              enc.data_ptr(), 1, M, _stream()), "dm_hashgrid_fwd")
         ctx.save_for_backward(x, table)
-        ctx.spec, ctx.radius = spec, radius
+        ctx.spec, ctx.radius, ctx.grad_sink = spec, radius, grad_sink
         return enc.t()
 
     @staticmethod
@@ -266,20 +305,22 @@ class _HashGrid(torch.autograd.Function):
         x, table = ctx.saved_tensors
         spec = ctx.spec
         M = x.shape[0]
-        dtable = torch.zeros_like(table)
+        sink = ctx.grad_sink
+        direct = sink is not None and sink.is_contiguous() and sink.numel() == table.numel()
+        dtable = sink if direct else torch.zeros_like(table)
         if M > 0:
             rs, cs = _rs_cs(x)
             grs, gcs = _rs_cs(g)
             check(_lib.lib().dm_hashgrid_bwd(x.data_ptr(), rs, cs, None, M, g.data_ptr(), grs, gcs, spec.n_levels,
                                              spec.c_scale, spec.c_res, spec.c_size, spec.c_offset, float(ctx.radius),
                                              dtable.data_ptr(), _stream()), "dm_hashgrid_bwd")
-        return None, dtable, None, None
+        return None, (None if direct else dtable), None, None, None
 
 
-def hashgrid_encode(x, table, spec, radius=1.0):
+def hashgrid_encode(x, table, spec, radius=1.0, grad_sink=None):
     if x.dtype != torch.float32:
         x = x.float()
-    return _HashGrid.apply(x, table, spec, radius)
+    return _HashGrid.apply(x, table, spec, radius, grad_sink)
 
 
 # ------------------------------------------------------------------------------------------ shading
@@ -294,12 +335,13 @@ class _Shade(torch.autograd.Function):
         if want_debug:
             dbg = [torch.empty(N, 3, device=dev) for _ in range(5)] + [torch.empty(N, 1, device=dev) for _ in range(2)]
         if N > 0:
-            check(_lib.lib().dm_shade_fwd(ctypes.byref(atlas.struct), ctypes.byref(mat), nrm.data_ptr(), *_rs_cs(nrm),
-                                          view.data_ptr(), *_rs_cs(view), feat.data_ptr(), *_rs_cs(feat),
-                                          pix_idx.data_ptr(), env_of_view.data_ptr(), n_dev.data_ptr(), N, HW,
-                                          color.data_ptr(), 1, N,
-                                          *[d.data_ptr() if d is not None else None for d in dbg], _stream()),
-                  "dm_shade_fwd")
+            with _Timed("shade_fwd" + ("+dbg" if want_debug else ""), 56.0 * N):
+                check(_lib.lib().dm_shade_fwd(ctypes.byref(atlas.struct), ctypes.byref(mat), nrm.data_ptr(),
+                                              *_rs_cs(nrm), view.data_ptr(), *_rs_cs(view), feat.data_ptr(),
+                                              *_rs_cs(feat), pix_idx.data_ptr(), env_of_view.data_ptr(),
+                                              n_dev.data_ptr(), N, HW, color.data_ptr(), 1, N,
+                                              *[d.data_ptr() if d is not None else None for d in dbg], _stream()),
+                      "dm_shade_fwd")
         ctx.save_for_backward(feat, nrm, view, pix_idx, n_dev, env_of_view)
         ctx.atlas, ctx.mat, ctx.HW = atlas, mat, HW
         outs = (color.t(),) + tuple(d for d in dbg if d is not None)
@@ -312,10 +354,12 @@ class _Shade(torch.autograd.Function):
         N = feat.shape[0]
         dfeat = torch.zeros(5, N, device=feat.device)
         if N > 0:
-            check(_lib.lib().dm_shade_bwd(ctypes.byref(ctx.atlas.struct), ctypes.byref(ctx.mat), nrm.data_ptr(),
-                                          *_rs_cs(nrm), view.data_ptr(), *_rs_cs(view), feat.data_ptr(), *_rs_cs(feat),
-                                          pix_idx.data_ptr(), env_of_view.data_ptr(), n_dev.data_ptr(), N, ctx.HW,
-                                          g.data_ptr(), *_rs_cs(g), dfeat.data_ptr(), 1, N, _stream()), "dm_shade_bwd")
+            with _Timed("shade_bwd", 76.0 * N):
+                check(_lib.lib().dm_shade_bwd(ctypes.byref(ctx.atlas.struct), ctypes.byref(ctx.mat), nrm.data_ptr(),
+                                              *_rs_cs(nrm), view.data_ptr(), *_rs_cs(view), feat.data_ptr(),
+                                              *_rs_cs(feat), pix_idx.data_ptr(), env_of_view.data_ptr(),
+                                              n_dev.data_ptr(), N, ctx.HW, g.data_ptr(), *_rs_cs(g), dfeat.data_ptr(),
+                                              1, N, _stream()), "dm_shade_bwd")
         return (dfeat.t(),) + (None,) * 9
 
 
@@ -365,10 +409,11 @@ def attention(q, k, vt, heads, scale=None):
     assert q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1
     out = torch.empty(B, Sq, C, device=q.device, dtype=torch.bfloat16)
     sc = float(scale) if scale is not None else float(D) ** -0.5
-    check(_lib.lib().dm_attention_fwd_bf16(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, heads, Sq,
-                                           Skv, D, q.stride(0), q.stride(1), D, k.stride(0), k.stride(1), D,
-                                           vt.stride(0), D * vt.stride(1), vt.stride(1), out.stride(0), out.stride(1),
-                                           D, sc, _stream()), "dm_attention_fwd_bf16")
+    with _Timed(f"attention_fwd_bf16[Sq={Sq},Skv={Skv},h={heads},D={D}]", 4.0 * B * Sq * Skv * C):
+        check(_lib.lib().dm_attention_fwd_bf16(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, heads,
+                                               Sq, Skv, D, q.stride(0), q.stride(1), D, k.stride(0), k.stride(1), D,
+                                               vt.stride(0), D * vt.stride(1), vt.stride(1), out.stride(0),
+                                               out.stride(1), D, sc, _stream()), "dm_attention_fwd_bf16")
     return out
 
 

@@ -1,0 +1,175 @@
+"""`stable-diffusion-prompt-processor` plugin (threestudio/models/prompt_processors/base.py:187-543 and
+stable_diffusion_prompt_processor.py:15-106): CLIP text-encodes the prompt, the negative prompt and
+"" once, with the 4 view-dependent variants (", side view" / ", front view" / ", back view" /
+", overhead view", base.py:281-312), caches them by md5 (base.py:19-23,364-412) and hands out
+[3B,77,D] (text, negative, null) batches (base.py:52-85).
+
+The CLIP weights are not on this box: when `<model dir>/{tokenizer,text_encoder}` cannot be found the
+processor emits deterministic pseudo-embeddings seeded by the md5 of each prompt (synthetic benchmark
+mode, announced on stdout) -- shapes, caching and view-dependent selection are unchanged.
+"""
+import hashlib
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+import dreammat_amd
+from .base import BaseObject, barrier, get_rank
+from .sd import arch_for
+
+
+def shift_azimuth_deg(azimuth):
+    return (azimuth + 180) % 360 - 180
+
+
+def hash_prompt(model: str, prompt: str) -> str:
+    return hashlib.md5(f"{model}-{prompt}".encode()).hexdigest()
+
+
+@dataclass
+class DirectionConfig:
+    name: str
+    prompt: callable
+    negative_prompt: callable
+    condition: callable
+
+
+@dataclass
+class PromptProcessorOutput:
+    text_embeddings: torch.Tensor
+    uncond_text_embeddings: torch.Tensor
+    null_text_embeddings: torch.Tensor
+    text_embeddings_vd: torch.Tensor
+    uncond_text_embeddings_vd: torch.Tensor
+    directions: list
+    direction2idx: dict
+    use_perp_neg: bool = False
+
+    def get_text_embeddings(self, elevation, azimuth, camera_distances, view_dependent_prompting=True,
+                            return_null_text_embeddings=False):
+        batch_size = elevation.shape[0]
+        if view_dependent_prompting:
+            direction_idx = torch.zeros_like(elevation, dtype=torch.long)
+            for d in self.directions:
+                direction_idx[d.condition(elevation, azimuth, camera_distances)] = self.direction2idx[d.name]
+            text = self.text_embeddings_vd[direction_idx]
+            uncond = self.uncond_text_embeddings_vd[direction_idx]
+        else:
+            text = self.text_embeddings.expand(batch_size, -1, -1)
+            uncond = self.uncond_text_embeddings.expand(batch_size, -1, -1)
+        null = self.null_text_embeddings.expand(batch_size, -1, -1)
+        if return_null_text_embeddings:
+            return torch.cat([text, uncond, null], dim=0)
+        return torch.cat([text, uncond], dim=0)
+
+
+@dreammat_amd.register("stable-diffusion-prompt-processor")
+class StableDiffusionPromptProcessor(BaseObject):
+    @dataclass
+    class Config(BaseObject.Config):
+        prompt: str = "a hamburger"
+        prompt_front: Optional[str] = None
+        prompt_side: Optional[str] = None
+        prompt_back: Optional[str] = None
+        prompt_overhead: Optional[str] = None
+        negative_prompt: str = ""
+        pretrained_model_name_or_path: str = "runwayml/stable-diffusion-v1-5"
+        pretrained_model_cache_dir: str = "../../model/SD"
+        overhead_threshold: float = 60.0
+        front_threshold: float = 45.0
+        back_threshold: float = 45.0
+        view_dependent_prompt_front: bool = False
+        use_cache: bool = True
+        spawn: bool = True
+        use_perp_neg: bool = False
+        cache_dir: str = ".threestudio_cache/text_embeddings"
+
+    cfg: Config
+
+    def configure(self) -> None:
+        if self.cfg.use_perp_neg:
+            raise NotImplementedError("perp-neg prompting is not on DreamMat's default path")
+        if not torch.cuda.is_available():
+            self.device = torch.device("cpu")
+        c = self.cfg
+        if c.view_dependent_prompt_front:
+            fmt = lambda v: (lambda s: f"{v} view of {s}")
+        else:
+            fmt = lambda v: (lambda s: f"{s}, {v} view")
+        ident = lambda s: s
+        self.directions = [
+            DirectionConfig("side", fmt("side"), ident, lambda ele, azi, dis: torch.ones_like(ele, dtype=torch.bool)),
+            DirectionConfig("front", fmt("front"), ident,
+                            lambda ele, azi, dis: (shift_azimuth_deg(azi) > -c.front_threshold) & (shift_azimuth_deg(azi) < c.front_threshold)),
+            DirectionConfig("back", fmt("back"), ident,
+                            lambda ele, azi, dis: (shift_azimuth_deg(azi) > 180 - c.back_threshold) | (shift_azimuth_deg(azi) < -180 + c.back_threshold)),
+            DirectionConfig("overhead", fmt("overhead"), ident, lambda ele, azi, dis: ele > c.overhead_threshold),
+        ]
+        self.direction2idx = {d.name: i for i, d in enumerate(self.directions)}
+        self.prompt = c.prompt
+        self.negative_prompt = c.negative_prompt
+        manual = {"front": c.prompt_front, "side": c.prompt_side, "back": c.prompt_back, "overhead": c.prompt_overhead}
+        self.prompts_vd = [manual[d.name] or d.prompt(self.prompt) for d in self.directions]
+        self.negative_prompts_vd = [d.negative_prompt(self.negative_prompt) for d in self.directions]
+        self.embed_dim = arch_for(c.pretrained_model_name_or_path).cross_dim
+        self.prepare_text_embeddings()
+        self.load_text_embeddings()
+
+    # ---------------------------------------------------------------- encode + cache
+    def _model_dir(self):
+        name = self.cfg.pretrained_model_name_or_path
+        for cand in (name, os.path.join(self.cfg.pretrained_model_cache_dir, name),
+                     os.environ.get("DREAMMAT_SD_DIR") or ""):
+            if cand and os.path.isdir(os.path.join(cand, "text_encoder")):
+                return cand
+        return None
+
+    def _encode(self, prompts):
+        root = self._model_dir()
+        if root is None:
+            print("[dreammat_amd] CLIP text encoder not found: using md5-seeded pseudo text embeddings (synthetic mode)")
+            outs = []
+            for p in prompts:
+                g = torch.Generator().manual_seed(int(hash_prompt(self.cfg.pretrained_model_name_or_path, p)[:8], 16))
+                outs.append(torch.randn(77, self.embed_dim, generator=g))
+            return torch.stack(outs)
+        from transformers import AutoTokenizer, CLIPTextModel
+        tok = AutoTokenizer.from_pretrained(os.path.join(root, "tokenizer"))
+        enc = CLIPTextModel.from_pretrained(os.path.join(root, "text_encoder")).to(self.device)
+        with torch.no_grad():
+            ids = tok(prompts, padding="max_length", max_length=tok.model_max_length, return_tensors="pt")
+            emb = enc(ids.input_ids.to(self.device))[0]
+        del enc
+        return emb.float().cpu()
+
+    def prepare_text_embeddings(self):
+        os.makedirs(self.cfg.cache_dir, exist_ok=True)
+        all_prompts = [self.prompt, self.negative_prompt, ""] + self.prompts_vd + self.negative_prompts_vd
+        todo = []
+        for p in dict.fromkeys(all_prompts):
+            path = os.path.join(self.cfg.cache_dir, hash_prompt(self.cfg.pretrained_model_name_or_path, p) + ".pt")
+            if not (self.cfg.use_cache and os.path.exists(path)):
+                todo.append(p)
+        if todo and get_rank() == 0:
+            emb = self._encode(todo)
+            for p, e in zip(todo, emb):
+                torch.save(e, os.path.join(self.cfg.cache_dir, hash_prompt(self.cfg.pretrained_model_name_or_path, p) + ".pt"))
+        barrier()   # other ranks wait for rank 0's cache (base.py:416)
+
+    def _load(self, p):
+        path = os.path.join(self.cfg.cache_dir, hash_prompt(self.cfg.pretrained_model_name_or_path, p) + ".pt")
+        return torch.load(path, map_location=self.device)
+
+    def load_text_embeddings(self):
+        self.text_embeddings = self._load(self.prompt)[None]
+        self.uncond_text_embeddings = self._load(self.negative_prompt)[None]
+        self.null_text_embeddings = self._load("")[None]
+        self.text_embeddings_vd = torch.stack([self._load(p) for p in self.prompts_vd])
+        self.uncond_text_embeddings_vd = torch.stack([self._load(p) for p in self.negative_prompts_vd])
+
+    def __call__(self) -> PromptProcessorOutput:
+        return PromptProcessorOutput(self.text_embeddings, self.uncond_text_embeddings, self.null_text_embeddings,
+                                     self.text_embeddings_vd, self.uncond_text_embeddings_vd, self.directions,
+                                     self.direction2idx, False)

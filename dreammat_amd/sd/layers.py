@@ -1,0 +1,228 @@
+"""Building blocks of the Stable-Diffusion nets (UNet2DConditionModel / ControlNetModel / AutoencoderKL
+encoder) with diffusers-compatible parameter names, so `from_pretrained` checkpoints of
+`stabilityai/stable-diffusion-2-1-base` (dreammat.yaml:60), `runwayml/stable-diffusion-v1-5` and the
+22-channel `zzzyuqing/light-geo-controlnet` (README.md:26) load with `load_state_dict(strict=True)`.
+
+diffusers is an un-vendored dependency of the reference (requirements.txt:7); it is used through
+threestudio/models/guidance/dreammat_guidance.py:110-154, 205-292.  Convs / linears / norms stay on
+PyTorch-ROCm (MIOpen, hipBLASLt); the QK^T.softmax.V of every transformer block runs in the MFMA
+kernel of csrc/attention.hip (bf16 on the GPU).  fp32 / CPU execution (BASELINE config 1: fp32
+plumbing run) uses the plain matmul-softmax path below; a CUDA bf16 call NEVER falls back.
+"""
+import math
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import hipops
+
+
+# Convolution backend.  MIOpen ships no gfx950 kernel database in this ROCm image (no *.kdb / gfx950
+# perf-db), so every new conv shape JIT-compiles its kernel on first use: ~25 minutes of cold start for
+# UNet + ControlNet + VAE on a fresh box.  "gemm" lowers every conv to im2col (torch's native unfold
+# kernel) + one batched hipBLASLt GEMM whose kernels are precompiled: no JIT, ~20 % extra HBM traffic.
+CONV_BACKEND = os.environ.get("DREAMMAT_CONV", "gemm")
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d (same parameters / state_dict keys) with a JIT-free GEMM lowering on the GPU."""
+
+    def forward(self, x):
+        if CONV_BACKEND != "gemm" or not x.is_cuda:
+            return super().forward(x)
+        B, Cin, H, W = x.shape
+        Cout, _, kh, kw = self.weight.shape
+        sh, sw = self.stride
+        ph, pw = self.padding
+        if kh == 1 and kw == 1 and sh == 1 and sw == 1 and ph == 0 and pw == 0:
+            y = torch.matmul(self.weight.view(Cout, Cin), x.reshape(B, Cin, H * W))
+            Ho, Wo = H, W
+        else:
+            cols = F.unfold(x, (kh, kw), padding=(ph, pw), stride=(sh, sw))          # [B, Cin*kh*kw, L]
+            y = torch.matmul(self.weight.view(Cout, Cin * kh * kw), cols)
+            Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+        y = y.view(B, Cout, Ho, Wo)
+        if self.bias is not None:
+            y = y + self.bias.view(1, Cout, 1, 1)
+        return y
+
+
+def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0.0, max_period=10000):
+    half = dim // 2
+    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / (half - freq_shift)
+    emb = t[:, None].float() * torch.exp(exponent)[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+    return emb
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_ch, dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_ch, dim)
+        self.linear_2 = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        return self.linear_2(F.silu(self.linear_1(x)))
+
+
+class PaddedContext:
+    """encoder_hidden_states zero-padded to a multiple of 8 tokens (16 B rows for V^T) + true length."""
+
+    def __init__(self, ctx):
+        B, S, C = ctx.shape
+        self.len = S
+        pad = (-S) % 8
+        self.t = F.pad(ctx, (0, 0, 0, pad)) if pad else ctx
+
+
+def attention_core(q, k, v_weight, v_bias, kv_src, heads, kv_len):
+    """softmax(QK^T/sqrt(d)) V with V = kv_src @ v_weight^T (+bias).  q [B,Sq,C], k [B,Skv,C].
+    CUDA+bf16 -> MFMA kernel (V produced directly transposed by the projection GEMM);
+    otherwise plain fp32-style math (autograd-capable)."""
+    B, Sq, C = q.shape
+    D = C // heads
+    if q.is_cuda and q.dtype == torch.bfloat16:
+        if kv_src.shape[1] % 8:                                       # V^T rows must be 16 B multiples
+            kv_src = F.pad(kv_src, (0, 0, 0, (-kv_src.shape[1]) % 8))
+        vt = torch.matmul(v_weight, kv_src.transpose(1, 2))           # [B, C, Skv_pad]: V^T for free
+        if v_bias is not None:
+            vt = vt + v_bias[None, :, None]
+            if kv_len < vt.shape[2]:
+                vt[:, :, kv_len:] = 0
+        return hipops.attention(q, k[:, :kv_len], vt, heads)
+    v = F.linear(kv_src, v_weight, v_bias)
+    qh = q.view(B, Sq, heads, D).transpose(1, 2)
+    kh = k[:, :kv_len].reshape(B, kv_len, heads, D).transpose(1, 2)
+    vh = v[:, :kv_len].reshape(B, kv_len, heads, D).transpose(1, 2)
+    s = torch.matmul(qh, kh.transpose(-1, -2)) * (D ** -0.5)
+    p = torch.softmax(s.float(), dim=-1).to(q.dtype)
+    return torch.matmul(p, vh).transpose(1, 2).reshape(B, Sq, C)
+
+
+class Attention(nn.Module):
+    """diffusers `Attention` (to_q/to_k/to_v without bias, to_out.0 with bias)."""
+
+    def __init__(self, query_dim, heads, cross_dim=None, bias=False):
+        super().__init__()
+        self.heads = heads
+        cross_dim = cross_dim or query_dim
+        self.to_q = nn.Linear(query_dim, query_dim, bias=bias)
+        self.to_k = nn.Linear(cross_dim, query_dim, bias=bias)
+        self.to_v = nn.Linear(cross_dim, query_dim, bias=bias)
+        self.to_out = nn.ModuleList([nn.Linear(query_dim, query_dim), nn.Identity()])
+
+    def forward(self, x, context=None):
+        if context is None:
+            src, kv_len = x, x.shape[1]
+        else:
+            src, kv_len = context.t, context.len
+        q = self.to_q(x)
+        k = self.to_k(src)
+        o = attention_core(q, k, self.to_v.weight, self.to_v.bias, src, self.heads, kv_len)
+        return self.to_out[0](o)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+    def forward(self, x):
+        x, gate = self.proj(x).chunk(2, dim=-1)
+        return x * F.gelu(gate)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Identity(), nn.Linear(dim * 4, dim)])
+
+    def forward(self, x):
+        return self.net[2](self.net[0](x))
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, heads, cross_dim):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn1 = Attention(dim, heads)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn2 = Attention(dim, heads, cross_dim)
+        self.norm3 = nn.LayerNorm(dim)
+        self.ff = FeedForward(dim)
+
+    def forward(self, x, context):
+        x = self.attn1(self.norm1(x)) + x
+        x = self.attn2(self.norm2(x), context) + x
+        return self.ff(self.norm3(x)) + x
+
+
+class Transformer2DModel(nn.Module):
+    def __init__(self, ch, heads, cross_dim, use_linear_projection):
+        super().__init__()
+        self.use_linear = use_linear_projection
+        self.norm = nn.GroupNorm(32, ch, eps=1e-6)
+        self.proj_in = nn.Linear(ch, ch) if use_linear_projection else Conv2d(ch, ch, 1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(ch, heads, cross_dim)])
+        self.proj_out = nn.Linear(ch, ch) if use_linear_projection else Conv2d(ch, ch, 1)
+
+    def forward(self, x, context):
+        B, C, H, W = x.shape
+        res = x
+        h = self.norm(x)
+        if self.use_linear:
+            h = self.proj_in(h.permute(0, 2, 3, 1).reshape(B, H * W, C))
+        else:
+            h = self.proj_in(h).permute(0, 2, 3, 1).reshape(B, H * W, C)
+        for blk in self.transformer_blocks:
+            h = blk(h, context)
+        if self.use_linear:
+            h = self.proj_out(h).reshape(B, H, W, C).permute(0, 3, 1, 2)
+        else:
+            h = self.proj_out(h.reshape(B, H, W, C).permute(0, 3, 1, 2))
+        return h + res
+
+
+class ResnetBlock2D(nn.Module):
+    def __init__(self, in_ch, out_ch, temb_ch=1280, eps=1e-5):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(32, in_ch, eps=eps)
+        self.conv1 = Conv2d(in_ch, out_ch, 3, padding=1)
+        self.time_emb_proj = nn.Linear(temb_ch, out_ch) if temb_ch else None
+        self.norm2 = nn.GroupNorm(32, out_ch, eps=eps)
+        self.conv2 = Conv2d(out_ch, out_ch, 3, padding=1)
+        self.conv_shortcut = Conv2d(in_ch, out_ch, 1) if in_ch != out_ch else None
+
+    def forward(self, x, temb=None):
+        h = self.conv1(F.silu(self.norm1(x)))
+        if self.time_emb_proj is not None:
+            h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
+        h = self.conv2(F.silu(self.norm2(h)))
+        if self.conv_shortcut is not None:
+            x = self.conv_shortcut(x)
+        return x + h
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, ch, asymmetric_pad=False):
+        super().__init__()
+        self.asym = asymmetric_pad
+        self.conv = Conv2d(ch, ch, 3, stride=2, padding=0 if asymmetric_pad else 1)
+
+    def forward(self, x):
+        if self.asym:
+            x = F.pad(x, (0, 1, 0, 1))
+        return self.conv(x)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, ch):
+        super().__init__()
+        self.conv = Conv2d(ch, ch, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))

@@ -308,3 +308,129 @@ def test_renderer_end_to_end_vs_oracle(dev, envs):
         assert rel < 1e-3, (nm, rel)
     with open(os.path.join(OUT, "render_parity.json"), "w") as fh:
         json.dump({"psnr_db": psnr, "coverage_ids_equal": True}, fh)
+
+
+def test_unet_controlnet_gpu_fp32_and_bf16_hip_attention(dev):
+    """fp32 on the GPU vs the CPU functional oracle (north_star: noise-pred within 1e-3 rel), and the
+    bf16 + MFMA-attention production path vs that fp32 result (bf16 rounding only)."""
+    from dreammat_amd.sd import ARCHS, ControlNetModel, UNet2DConditionModel
+    from oracle import sd_nets as osd
+    for arch_name in ("tiny", "tiny15"):
+        a = ARCHS[arch_name]
+        torch.manual_seed(0)
+        unet = UNet2DConditionModel(a).eval()
+        cn = ControlNetModel.from_unet(unet).eval()
+        for conv in list(cn.controlnet_down_blocks) + [cn.controlnet_mid_block, cn.controlnet_cond_embedding.conv_out]:
+            torch.nn.init.normal_(conv.weight, std=0.05)
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(3, 4, 32, 32, generator=g); t = torch.tensor([37, 801, 500])
+        ctx = torch.randn(3, 77, a.cross_dim, generator=g); cond = torch.rand(3, 22, 256, 256, generator=g)
+        with torch.no_grad():
+            od, om = osd.controlnet_forward(cn.state_dict(), x, t, ctx, cond, 1.0, a.heads, a.use_linear_projection)
+            oy = osd.unet_forward(unet.state_dict(), x, t, ctx, a.heads, a.use_linear_projection, od, om)
+            unet.to(dev); cn.to(dev)
+            d, m = cn(x.to(dev), t.to(dev), ctx.to(dev), cond.to(dev), 1.0)
+            y = unet(x.to(dev), t.to(dev), ctx.to(dev), d, m).cpu()
+            assert (y - oy).abs().max() <= 1e-3 * oy.abs().max(), arch_name
+            unet.bfloat16(); cn.bfloat16()
+            hipops.enable_kernel_timing(True)
+            d, m = cn(x.to(dev).bfloat16(), t.to(dev), ctx.to(dev).bfloat16(), cond.to(dev).bfloat16(), 1.0)
+            yb = unet(x.to(dev).bfloat16(), t.to(dev), ctx.to(dev).bfloat16(), d, m).float().cpu()
+            torch.cuda.synchronize()
+            n_attn = sum(v["launches"] for k, v in hipops.kernel_times().items() if k.startswith("attention"))
+            hipops.enable_kernel_timing(False)
+        assert n_attn == 46, n_attn                    # 2x(16 UNet + 7 ControlNet) attention launches, all on MFMA
+        rel = ((yb - oy).abs().max() / oy.abs().max()).item()
+        assert rel < 6e-2, (arch_name, rel)
+
+
+def test_full_sds_step_vs_oracle(dev, tmp_path, monkeypatch):
+    """BASELINE config 1 shape (2-triangle quad, 1 view, constant env, fp32 nets): one complete optimizer
+    step through the plugin API vs the oracle's step: loss, parameter gradients, Adam-updated parameters."""
+    monkeypatch.chdir(tmp_path)
+    import dreammat_amd
+    from dreammat_amd.data import RandomCameraDataModule
+    from dreammat_amd.system import Trainer, to_device
+    from oracle import sd_nets as osd
+    dreammat_amd._import_plugins()
+    torch.manual_seed(0)
+    H = W = 256
+    lat = [torch.full((16, 32, 3), 0.25) for _ in range(5)]
+    enc = {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 2, "log2_hashmap_size": 14,
+           "base_resolution": 16, "per_level_scale": 1.447269237440378}
+    cfg = {"geometry": {"shape_init": "quad", "shape_init_params": 1.0, "pos_encoding_config": enc},
+           "material": {"use_raytracing": False, "environment_scale": 2.0, "env_max_res": 32, "env_min_res": 8},
+           "guidance": {"use_controlnet": True, "control_types": ["light"], "condition_scales": [1.0], "width": W,
+                        "height": H, "pretrained_model_name_or_path": "tiny15", "half_precision_weights": False,
+                        "cond_scale": 1.05, "uncond_scale": -0.6, "null_scale": -0.3},
+           "prompt_processor": {"prompt": "a checkered tile", "negative_prompt": "ugly",
+                                "pretrained_model_name_or_path": "tiny15"},
+           "loss": {"lambda_sds": 1.0, "lambda_mat_reg": 1.0},
+           "optimizer": {"name": "Adam", "args": {"lr": 0.01, "betas": [0.9, 0.99], "eps": 1e-15}}}
+    system = dreammat_amd.find("dreammat-system")(cfg, material_kwargs={"latlongs": lat})
+    with torch.no_grad():
+        system.geometry.encoding.encoding.params.uniform_(-1, 1)
+        system.geometry.feature_network.layers[0].weight.normal_(0, 0.5)
+        system.geometry.feature_network.layers[2].weight.normal_(0, 0.3)
+    dm = RandomCameraDataModule(cfg={"height": H, "width": W, "batch_size": 1, "use_fix_views": True,
+                                     "camera_distance_range": [3.0, 3.5], "fovy_range": [30, 40], "camera_perturb": 0.0,
+                                     "center_perturb": 0.0, "up_perturb": 0.0, "elevation_range": [50, 80]}, device=dev)
+    dm.setup("fit")
+    system.on_fit_start()
+    system.configure_optimizers()
+    trainer = Trainer(system, dm, max_steps=1)
+    batch = to_device(dm.train_dataset.collate(), dev)
+    g = torch.Generator().manual_seed(1)
+    ju, jn = torch.rand(1, H, W, generator=g), torch.randn(1, H, W, generator=g)
+    batch["jitter_u"], batch["jitter_n"] = ju.to(dev), jn.to(dev)
+    rng = {"t": torch.tensor([400]), "noise": torch.randn(1, 4, H // 8, W // 8, generator=g),
+           "posterior_noise": torch.randn(1, 4, H // 8, W // 8, generator=g)}
+    rng_d = {k: v.to(dev) for k, v in rng.items()}
+    # ---- oracle step
+    geo, gd = system.geometry, None
+    m = geo.mesh
+    md = dict(v_pos=m.v_pos.cpu().numpy(), v_nrm=m.v_nrm.cpu().numpy(), t_pos_idx=m.t_pos_idx.cpu().numpy().astype(np.int32))
+    md["opp"] = oraster.build_topology(md["t_pos_idx"])
+    lv, _ = ofield.grid_levels(n_levels=8, log2_hashmap_size=14)
+    table = geo.encoding.encoding.params.detach().cpu().reshape(-1, 2).clone().requires_grad_()
+    w1 = geo.feature_network.layers[0].weight.detach().cpu().clone().requires_grad_()
+    w2 = geo.feature_network.layers[2].weight.detach().cpu().clone().requires_grad_()
+    opt = torch.optim.Adam([table, w1, w2], lr=0.01, betas=(0.9, 0.99), eps=1e-15)
+    cb = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    oenvs = [oenv.EnvLight(l, scale=2.0, min_res=8, max_res=32) for l in lat]
+    ref = orender.render(md, cb, dict(table=table, w1=w1, w2=w2, levels=lv, radius=1.0), oenvs,
+                         system.material.atlas.fg_lut.cpu(), ju, jn)
+    gd = system.guidance
+    assert gd.weights_dtype == torch.float32
+    nets = {"vae": {k: v.cpu() for k, v in gd.vae.state_dict().items()},
+            "unet": {k: v.cpu() for k, v in gd.unet.state_dict().items()},
+            "controlnet": {k: v.cpu() for k, v in gd.controlnets[0].state_dict().items()}}
+    emb = system.prompt_processor().get_text_embeddings(cb["elevation"].to(dev), cb["azimuth"].to(dev),
+                                                        cb["camera_distances"].to(dev), True, True).cpu()
+    a = gd.arch
+    loss_sds, grad, eps, _ = osd.sds_loss(ref["comp_rgb"], nets, emb, cb["condition_map"], rng["t"], rng["noise"],
+                                          rng["posterior_noise"], (1.05, -0.6, -0.3, 0.0), a.heads,
+                                          a.use_linear_projection, 1.0)
+    loss_ref = loss_sds + ref["loss_mat_reg"]
+    loss_ref.backward()
+    g_ref = [t.grad.clone() for t in (table, w1, w2)]
+    opt.step()
+    # ---- product step
+    system.do_update()
+    loss, logs = system.training_step(batch, rng=rng_d)
+    loss.backward()
+    geo_p = [geo.encoding.encoding.params, geo.feature_network.layers[0].weight, geo.feature_network.layers[2].weight]
+    assert abs(float(loss) - float(loss_ref)) <= 1e-3 * abs(float(loss_ref)), (float(loss), float(loss_ref))
+    e3 = torch.cat([gd._last["e_text"], gd._last["e_uncond"], gd._last["e_null"]]).cpu()
+    assert (e3 - eps).abs().max() <= 1e-3 * eps.abs().max()
+    for p, r, nm in zip(geo_p, g_ref, ("table", "w1", "w2")):
+        rel = ((p.grad.cpu().reshape(r.shape) - r).abs().max() / r.abs().max()).item()
+        assert rel < 2e-3, (nm, rel)
+    system.optimizer.step(1)
+    for p, r, nm in zip(geo_p, (table, w1, w2), ("table", "w1", "w2")):
+        # Adam with eps=1e-15 turns any non-zero gradient into a +-lr step: compare where |g| is not tiny
+        gr = g_ref[("table", "w1", "w2").index(nm)]
+        gmask = gr.abs() > 1e-2 * gr.abs().max()          # sign of the gradient is certain there
+        diff = (p.detach().cpu().reshape(r.shape) - r.detach()).abs()
+        assert diff[gmask].max() < 1e-4, (nm, float(diff[gmask].max()))
+    assert float(system.flat.grad.abs().max()) == 0.0       # zeroed by the fused kernel for the next step

@@ -1,0 +1,104 @@
+"""CPU suite: the product's SD modules (fp32, plain-math attention path) against the oracle's functional
+restatement on identical seeded state_dicts; guidance arithmetic against oracle.sd_nets.sds_loss."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dreammat_amd.sd import ARCHS, AutoencoderKLEncoder, ControlNetModel, UNet2DConditionModel
+from oracle import sd_nets as osd
+
+
+def _nets(arch_name, seed=0):
+    a = ARCHS[arch_name]
+    torch.manual_seed(seed)
+    unet = UNet2DConditionModel(a).eval()
+    cn = ControlNetModel.from_unet(unet).eval()
+    for conv in list(cn.controlnet_down_blocks) + [cn.controlnet_mid_block, cn.controlnet_cond_embedding.conv_out]:
+        torch.nn.init.normal_(conv.weight, std=0.05)
+    vae = AutoencoderKLEncoder(a).eval()
+    return a, unet, cn, vae
+
+
+@pytest.mark.parametrize("arch_name", ["tiny", "tiny15"])
+def test_unet_controlnet_vae_match_functional_oracle(arch_name):
+    a, unet, cn, vae = _nets(arch_name)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 4, 16, 16, generator=g)
+    t = torch.tensor([37, 801])
+    ctx = torch.randn(2, 77, a.cross_dim, generator=g)
+    cond = torch.rand(2, 22, 128, 128, generator=g)
+    with torch.no_grad():
+        d, m = cn(x, t, ctx, cond, 0.8)
+        y = unet(x, t, ctx, d, m)
+        od, om = osd.controlnet_forward(cn.state_dict(), x, t, ctx, cond, 0.8, a.heads, a.use_linear_projection)
+        oy = osd.unet_forward(unet.state_dict(), x, t, ctx, a.heads, a.use_linear_projection, od, om)
+        assert len(d) == 12
+        for p, q in zip(d + [m], od + [om]):
+            assert (p - q).abs().max() <= 1e-4 * max(1.0, q.abs().max())
+        assert (y - oy).abs().max() <= 1e-3 * oy.abs().max()          # north_star: noise-pred within 1e-3 rel
+        img = torch.rand(2, 3, 128, 128, generator=g) * 2 - 1
+        mean, logvar = vae.encode_moments(img)
+        omean, ologvar = osd.vae_encode_moments(vae.state_dict(), img)
+        assert (mean - omean).abs().max() < 1e-4 and (logvar - ologvar).abs().max() < 1e-4
+
+
+def test_full_size_parameter_counts_match_diffusers():
+    """The only externally known constants: parameter counts of the published checkpoints."""
+    with torch.device("meta"):
+        assert sum(p.numel() for p in UNet2DConditionModel(ARCHS["sd21-base"]).parameters()) == 865910724
+        assert sum(p.numel() for p in UNet2DConditionModel(ARCHS["sd15"]).parameters()) == 859520964
+        assert sum(p.numel() for p in AutoencoderKLEncoder(ARCHS["sd21-base"]).parameters()) == 34163664
+
+
+def test_ddim_alphas_and_sds_identity():
+    from dreammat_amd.sd import DDIMScheduler
+    s = DDIMScheduler()
+    assert torch.allclose(s.alphas_cumprod, osd.alphas_cumprod())
+    assert abs(float(s.alphas_cumprod[0]) - 0.99915) < 1e-5 and abs(float(s.alphas_cumprod[-1]) - 0.0047) < 1e-4
+    # eps_text = eps_uncond = eps, scales (1,-1,0,0) -> grad = 0
+    e = torch.randn(2, 4, 8, 8)
+    w = (1 - s.alphas_cumprod[torch.tensor([10, 500])]).view(-1, 1, 1, 1)
+    assert (w * (1.0 * e + -1.0 * e + 0 * e + 0 * e)).abs().max() == 0
+
+
+def test_guidance_call_matches_oracle_sds(tmp_path, monkeypatch):
+    """StableDiffusionLightGuidance.__call__ (plugin API, CPU fp32) vs oracle.sd_nets.sds_loss with the
+    same weights and injected randomness: loss, SDS grad, eps-pred and d loss / d rgb."""
+    monkeypatch.chdir(tmp_path)
+    import dreammat_amd
+    from dreammat_amd.guidance import StableDiffusionLightGuidance
+    from dreammat_amd.prompt import StableDiffusionPromptProcessor
+    gd = StableDiffusionLightGuidance({"pretrained_model_name_or_path": "tiny", "use_controlnet": True,
+                                       "control_types": ["light"], "condition_scales": [0.9], "width": 128,
+                                       "height": 128, "cond_scale": 1.05, "uncond_scale": [0, -1.0, -0.5, 2000],
+                                       "null_scale": [0, 0.0, -0.5, 2000], "half_precision_weights": True})
+    assert gd.weights_dtype == torch.float32            # no GPU here: fp32 plumbing path
+    gd.update_step(0, 1000)
+    assert abs(gd.uncond_scale - (-0.75)) < 1e-9 and abs(gd.null_scale - (-0.25)) < 1e-9
+    pp = StableDiffusionPromptProcessor({"prompt": "a wooden chair", "negative_prompt": "ugly",
+                                         "pretrained_model_name_or_path": "tiny"})
+    B = 2
+    g = torch.Generator().manual_seed(3)
+    rgb = torch.rand(B, 128, 128, 3, generator=g).requires_grad_()
+    cond = torch.rand(B, 128, 128, 22, generator=g)
+    elev, azim, dist = torch.tensor([10.0, 70.0]), torch.tensor([5.0, 170.0]), torch.tensor([3.5, 3.2])
+    rng = {"t": torch.tensor([400, 77]), "noise": torch.randn(B, 4, 16, 16, generator=g),
+           "posterior_noise": torch.randn(B, 4, 16, 16, generator=g)}
+    out = gd(rgb, pp(), elev, azim, dist, env_id=torch.tensor([0, 1]), condition_map=cond, rng=rng)
+    out["loss_sds"].backward()
+    emb = pp().get_text_embeddings(elev, azim, dist, True, True)
+    # view-dependent selection: elev 70 > 60 -> overhead; az 5 -> front
+    assert torch.equal(emb[0], pp.text_embeddings_vd[1]) and torch.equal(emb[1], pp.text_embeddings_vd[3])
+    rgb2 = rgb.detach().clone().requires_grad_()
+    nets = {"vae": gd.vae.state_dict(), "unet": gd.unet.state_dict(), "controlnet": gd.controlnets[0].state_dict()}
+    a = gd.arch
+    loss, grad, eps, lat = osd.sds_loss(rgb2, nets, emb, cond, rng["t"], rng["noise"], rng["posterior_noise"],
+                                        (1.05, -0.75, -0.25, 0.0), a.heads, a.use_linear_projection, 0.9)
+    loss.backward()
+    assert abs(float(out["loss_sds"]) - float(loss)) <= 1e-4 * abs(float(loss))
+    assert (gd._last["grad"] - grad).abs().max() <= 1e-3 * grad.abs().max()
+    e3 = torch.cat([gd._last["e_text"], gd._last["e_uncond"], gd._last["e_null"]])
+    assert (e3 - eps).abs().max() <= 1e-3 * eps.abs().max()
+    assert (rgb.grad - rgb2.grad).abs().max() <= 1e-3 * rgb2.grad.abs().max()
