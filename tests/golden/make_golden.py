@@ -1,0 +1,194 @@
+"""Generates tests/golden/*.npz by EXECUTING THE REFERENCE'S OWN FUNCTION BODIES on seeded inputs.
+
+The reference package cannot be imported here (pytorch_lightning / omegaconf / nvdiffrast / tcnn / ...
+are absent), so the pure-PyTorch functions on the hot path are AST-extracted from the files under
+/root/reference and exec'd in a namespace that only provides torch/numpy/math (and, for the two class
+methods that call un-vendored ops, stubs backed by the oracle's restatement of those ops).  No reference
+source is copied into this repository: only the numeric outputs are stored.
+
+Run in the build container (needs /root/reference):  python tests/golden/make_golden.py
+"""
+import ast
+import math
+import os
+import sys
+import textwrap
+import types
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/threestudio_dreammat/threestudio"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def extract(path, names, cls=None):
+    """source of top-level functions (or methods of `cls`) named in `names`."""
+    src = open(path).read()
+    tree = ast.parse(src)
+    body = tree.body
+    if cls is not None:
+        body = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls).body
+    out = {}
+    for n in body:
+        if isinstance(n, ast.FunctionDef) and n.name in names:
+            n.decorator_list = []
+            n.returns = None
+            for a in n.args.args + n.args.kwonlyargs:
+                a.annotation = None
+            out[n.name] = ast.unparse(n)
+    # drop variable annotations inside bodies (jaxtyping names are not available)
+    cleaned = {}
+    for k, v in out.items():
+        t = ast.parse(v)
+        for node in ast.walk(t):
+            for field, val in ast.iter_fields(node):
+                if isinstance(val, list):
+                    for i, item in enumerate(val):
+                        if isinstance(item, ast.AnnAssign) and item.value is not None:
+                            val[i] = ast.copy_location(ast.Assign(targets=[item.target], value=item.value), item)
+        ast.fix_missing_locations(t)
+        cleaned[k] = ast.unparse(t)
+    return cleaned
+
+
+def ns(**extra):
+    d = {"torch": torch, "np": np, "math": math, "F": F, "Tensor": torch.Tensor}
+    d.update(extra)
+    return d
+
+
+def main():
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(0)
+    # ---------------------------------------------------------------- utils/ops.py
+    fns = extract(f"{REF}/utils/ops.py", ["get_ray_directions", "get_rays", "get_projection_matrix", "get_mvp_matrix",
+                                          "get_activation", "scale_tensor"])
+    env = ns(Union=None, Tuple=None, Optional=None)
+    for s in fns.values():
+        exec(s, env)
+    H = W = 16
+    B = 3
+    fovy = torch.tensor([0.5, 0.7, 0.9])
+    dirs = env["get_ray_directions"](H, W, 1.0)
+    c2w = torch.eye(4)[None].repeat(B, 1, 1)
+    q = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))[0]
+    c2w[:, :3, :3] = q
+    c2w[:, :3, 3] = torch.randn(B, 3, generator=g)
+    focal = 0.5 * H / torch.tan(0.5 * fovy)
+    d = dirs[None].repeat(B, 1, 1, 1)
+    d[..., :2] = d[..., :2] / focal[:, None, None, None]
+    rays_o, rays_d = env["get_rays"](d, c2w, keepdim=True)
+    proj = env["get_projection_matrix"](fovy, W / H, 0.1, 1000.0)
+    mvp, w2c = env["get_mvp_matrix"](c2w, proj)
+    x = torch.linspace(-0.5, 2.0, 101)
+    np.savez(os.path.join(OUT, "camera.npz"), fovy=fovy, c2w=c2w, dirs=dirs, rays_o=rays_o, rays_d=rays_d, proj=proj,
+             mvp=mvp, w2c=w2c, lin2srgb_x=x, lin2srgb_y=env["get_activation"]("lin2srgb")(x),
+             scale_in=x, scale_out=env["scale_tensor"](x[:, None].repeat(1, 3), (-1.0, 1.0), (0, 1)))
+    # ---------------------------------------------------------------- utils/misc.py: C()
+    fns = extract(f"{REF}/utils/misc.py", ["C"])
+    env = ns(config_to_primitive=lambda v: v, Any=None)
+    exec(fns["C"], env)
+    specs = [[0, -1.0, -0.5, 2000], [0, 0.0, -0.5, 2000], [500, 0.2, 0.02, 501], [500, 0.8, 0.5, 501], 1.05, [0.1, 0.9, 10.0]]
+    steps = [0, 1, 250, 500, 501, 1000, 2000, 5000]
+    table = np.array([[env["C"](s, 3, st) for st in steps] for s in specs], dtype=np.float64)
+    np.savez(os.path.join(OUT, "schedule.npz"), steps=np.array(steps), values=table)
+    # ---------------------------------------------------------------- materials/dreammat_material.py
+    path = f"{REF}/models/materials/dreammat_material.py"
+    fns = extract(path, ["material_smoothness_grad", "sample_sphere", "az_el_to_points"])
+    env = ns()
+    for s in fns.values():
+        exec(s, env)
+    mat = torch.rand(200, 5, generator=g)
+    matj = torch.rand(200, 5, generator=g)
+    reg = env["material_smoothness_grad"](mat, matj)
+    az, el = env["sample_sphere"](128, 0)
+    # shade_splitsum + forward(split-sum branch) with the un-vendored ops stubbed by the oracle's restatement
+    from oracle import envlight as oenv
+    from dreammat_amd.envlight import approx_fg_lut
+    meth = extract(path, ["shade_splitsum", "forward"], cls="DreamMatMaterial")
+    fg = approx_fg_lut(64)
+    latlong = torch.rand(16, 32, 3, generator=g)
+    oe = oenv.EnvLight(latlong, scale=2.0, min_res=8, max_res=16)
+    dr = types.SimpleNamespace(texture=lambda tex, uv, filter_mode, boundary_mode:
+                               oenv.texture2d_linear_clamp(tex[0], uv.reshape(-1, 2)).reshape(1, -1, 1, tex.shape[-1]))
+    env = ns(dr=dr, get_activation=ns_get_activation(), material_smoothness_grad=env["material_smoothness_grad"])
+    exec(meth["shade_splitsum"], env)
+    exec(meth["forward"], env)
+    cfg = types.SimpleNamespace(use_raytracing=False, material_activation="sigmoid", min_metallic=0.0, max_metallic=0.9,
+                                min_roughness=0.1, max_roughness=0.95, min_roughness_squre=0.01, max_roughness_squre=0.9)
+    selfobj = types.SimpleNamespace(cfg=cfg, FG_LUT=fg[None], envlight=[oe])
+    selfobj.shade_splitsum = types.MethodType(env["shade_splitsum"], selfobj)
+    N = 300
+    feats = torch.randn(N, 5, generator=g) * 1.5
+    featsj = feats + 0.2 * torch.randn(N, 5, generator=g)
+    nrm = F.normalize(torch.randn(N, 3, generator=g), dim=-1)
+    view = F.normalize(nrm + 0.7 * torch.randn(N, 3, generator=g), dim=-1)
+    outs, mat_reg = env["forward"](selfobj, None, feats, featsj, view, nrm, 0)
+    np.savez(os.path.join(OUT, "shading.npz"), mat=mat, matj=matj, reg=reg, sphere_az=az, sphere_el=el,
+             fg=fg, latlong=latlong, feats=feats, featsj=featsj, nrm=nrm, view=view, mat_reg=mat_reg,
+             **{"out_" + k: v for k, v in outs.items()})
+    # ---------------------------------------------------------------- renderers/raytracing_renderer.py
+    path = f"{REF}/models/renderers/raytracing_renderer.py"
+    top = extract(path, ["xfm_vectors"])
+    meth = extract(path, ["get_orthogonal_directions", "compute_controlnet_normals"], cls="RaytraceRender")
+    env = ns()
+    exec(top["xfm_vectors"], env)
+    for s in meth.values():
+        exec(s, env)
+    selfobj = types.SimpleNamespace(device="cpu")
+    n = F.normalize(torch.randn(500, 3, generator=g), dim=-1)
+    n[:4] = torch.tensor([[0, 0, 1.0], [1.0, 0, 0], [0, 1.0, 0], [0.6, 0, 0.8]])
+    ortho = env["get_orthogonal_directions"](selfobj, n)
+    mv = torch.eye(4)[None].clone()
+    mv[0, :3, :3] = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+    cn = env["compute_controlnet_normals"](selfobj, n, mv, 1)
+    np.savez(os.path.join(OUT, "renderer.npz"), normals=n, ortho=ortho, w2c=mv, cn_normals=cn)
+    # ---------------------------------------------------------------- guidance: SDS composition
+    path = f"{REF}/models/guidance/dreammat_guidance.py"
+    meth = extract(path, ["compute_grad_sds", "set_min_max_steps"], cls="StableDiffusionLightGuidance")
+    env = ns(Float=None)
+    for s in meth.values():
+        exec(s.replace("@torch.cuda.amp.autocast(enabled=False)", ""), env)
+    from oracle import sd_nets as osd
+    ac = osd.alphas_cumprod()
+    Bq = 2
+    lat = torch.randn(Bq, 4, 8, 8, generator=g)
+    eps3 = [torch.randn(Bq, 4, 8, 8, generator=g) for _ in range(3)]
+    sched = types.SimpleNamespace(add_noise=lambda x, n, t: ac[t].sqrt().view(-1, 1, 1, 1) * x + (1 - ac[t]).sqrt().view(-1, 1, 1, 1) * n)
+    so = types.SimpleNamespace(min_step=200, max_step=800, device="cpu", scheduler=sched, alphas=ac, cond_scale=1.05,
+                               uncond_scale=-0.75, null_scale=-0.25, noise_scale=0.1, perpneg_scale=0.0,
+                               compute_without_perpneg=lambda *a, **k: tuple(eps3))
+    pu = types.SimpleNamespace(use_perp_neg=False)
+    torch.manual_seed(123)
+    grad, ev = env["compute_grad_sds"](so, pu, [1.0], lat, [], None, None, None)
+    torch.manual_seed(123)          # replay the two draws the method made: randint then randn_like
+    t = torch.randint(200, 801, [Bq], dtype=torch.long)
+    noise = torch.randn_like(lat)
+    so2 = types.SimpleNamespace(num_train_timesteps=1000)
+    env["set_min_max_steps"](so2, 0.2, 0.8)
+    np.savez(os.path.join(OUT, "sds.npz"), lat=lat, eps_text=eps3[0], eps_uncond=eps3[1], eps_null=eps3[2], t=t,
+             noise=noise, grad=grad, alphas=ac, min_step=so2.min_step, max_step=so2.max_step,
+             **{"ev_" + k: v for k, v in ev.items()})
+    # ---------------------------------------------------------------- prompt processor view selection
+    path = f"{REF}/models/prompt_processors/base.py"
+    top = extract(path, ["shift_azimuth_deg"])
+    env = ns()
+    exec(top["shift_azimuth_deg"], env)
+    az = torch.linspace(-400, 400, 81)
+    np.savez(os.path.join(OUT, "prompt.npz"), az=az, shifted=env["shift_azimuth_deg"](az))
+    print("golden fixtures written to", OUT)
+
+
+def ns_get_activation():
+    fns = extract(f"{REF}/utils/ops.py", ["get_activation"])
+    env = ns()
+    exec(fns["get_activation"], env)
+    return env["get_activation"]
+
+
+if __name__ == "__main__":
+    main()
