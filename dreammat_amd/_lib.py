@@ -73,6 +73,7 @@ _SIGS = {
                               c_void_p, _LL, _LL, c_void_p]),
     "dm_attention_fwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]
                               + [_LL] * 12 + [c_float, c_void_p]),
+    "dm_conv3x3_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "dm_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _LL, c_int, c_float, c_float, c_float, c_float,
                              c_float, c_int, c_void_p]),
 }

@@ -15,6 +15,7 @@ SOURCES = {
     "shade.hip": ["-munsafe-fp-atomics"],
     "hashgrid.hip": ["-munsafe-fp-atomics"],
     "attention.hip": [],
+    "conv.hip": [],
     "adam.hip": [],
     "host.cpp": [],
 }

@@ -93,6 +93,67 @@ __global__ __launch_bounds__(256) void k_hashgrid(HashArgs a) {
     }
 }
 
+// Backward, second formulation.  Device-scope fp32 atomics retire at only ~20 G/s on MI355X (measured,
+// profiles/r01_hashgrid_bwd_per_level_v0.json: every level costs ~1.7-6.7 ms regardless of table size),
+// so the kernel is organised around ISSUING FEWER OF THEM:
+//  * lane pair (2i, 2i+1) = the two features of ONE point, so the pair's atomics hit one 8-byte
+//    slot of one cache line (half the line requests per wave-instruction);
+//  * DEDUP (coarse / mid levels): consecutive lanes are consecutive covered pixels of an image row, whose
+//    samples fall into the same grid cell for long runs; a segmented wave scan sums each run and only
+//    the run's last lane issues the atomic (level 0: ~30x fewer atomics).
+template <bool DEDUP>
+__global__ __launch_bounds__(256) void k_hashgrid_bwd2(HashArgs a, int level_base) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long M = a.m_dev ? (long long)*a.m_dev : a.m_max;
+    const long long m = gid >> 1;
+    const int f = (int)(gid & 1);
+    const int lane = threadIdx.x & 63;
+    const bool valid = m < M;
+    const int l = level_base + blockIdx.y;
+    const float scale = a.lv.scale[l];
+    const unsigned res = a.lv.res[l], size = a.lv.size[l], off = a.lv.offset[l];
+    float w[3];
+    unsigned cell[3];
+    const long long mc = valid ? m : 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        float xn = (a.x[mc * a.x_rs + d * a.x_cs] + a.radius) * a.inv_2r;
+        float p = xn * scale + 0.5f;
+        float fl = floorf(p);
+        w[d] = p - fl;
+        cell[d] = (unsigned)(int)fl;
+    }
+    const float g = valid ? a.dout[mc * a.dout_rs + (2 * l + f) * a.dout_cs] : 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        unsigned cx = cell[0] + (c & 1), cy = cell[1] + ((c >> 1) & 1), cz = cell[2] + ((c >> 2) & 1);
+        float wt = ((c & 1) ? w[0] : 1.f - w[0]) * (((c >> 1) & 1) ? w[1] : 1.f - w[1]) *
+                   (((c >> 2) & 1) ? w[2] : 1.f - w[2]);
+        unsigned idx = valid ? grid_index(cx, cy, cz, res, size) : 0xffffffffu;
+        float v = g * wt;
+        if (DEDUP) {
+            // run start of this lane's key among same-feature lanes (stride 2)
+            unsigned prev = (unsigned)__shfl_up((int)idx, 2);
+            int start = (lane < 2 || prev != idx) ? lane : 0;
+#pragma unroll
+            for (int ofs = 2; ofs < 64; ofs <<= 1) {
+                int s2 = __shfl_up(start, ofs);
+                if (lane >= ofs) start = max(start, s2);
+            }
+#pragma unroll
+            for (int ofs = 2; ofs < 64; ofs <<= 1) {
+                float v2 = __shfl_up(v, ofs);
+                if (lane - ofs >= start) v += v2;
+            }
+            unsigned nxt = (unsigned)__shfl_down((int)idx, 2);
+            bool tail = (lane >= 62) || (nxt != idx);
+            if (tail && valid) atomicAdd(a.dtable + 2 * (size_t)(off + idx) + f, v);
+        } else {
+            if (valid) atomicAdd(a.dtable + 2 * (size_t)(off + idx) + f, v);
+        }
+    }
+}
+
 bool fill_levels(GridLevels& lv, int n_levels, const float* scale, const uint32_t* res, const uint32_t* size,
                  const uint32_t* offset) {
     if (n_levels <= 0 || n_levels > kMaxLevels || !scale || !res || !size || !offset) return false;
@@ -134,9 +195,15 @@ int dm_hashgrid_bwd(const float* x, long long x_rs, long long x_cs, const int32_
         return DM_ERR_ARG;
     a.x = x; a.x_rs = x_rs; a.x_cs = x_cs; a.dout = denc; a.dout_rs = denc_rs; a.dout_cs = denc_cs;
     a.dtable = dtable; a.m_dev = m_dev; a.m_max = m_max; a.radius = radius; a.inv_2r = 1.0f / (2.0f * radius);
-    dim3 grid(dm_div_up(m_max, 256), n_levels);
+    // levels whose cells span several pixels get the run-combining variant (see k_hashgrid_bwd2)
+    int n_dedup = 0;
+    while (n_dedup < n_levels && lv_res[n_dedup] <= 512) ++n_dedup;
     DM_ENTER();
-    hipLaunchKernelGGL(k_hashgrid<true>, grid, dim3(256), 0, stream, a);
+    if (n_dedup > 0)
+        hipLaunchKernelGGL(k_hashgrid_bwd2<true>, dim3(dm_div_up(2 * m_max, 256), n_dedup), dim3(256), 0, stream, a, 0);
+    if (n_levels > n_dedup)
+        hipLaunchKernelGGL(k_hashgrid_bwd2<false>, dim3(dm_div_up(2 * m_max, 256), n_levels - n_dedup), dim3(256), 0,
+                           stream, a, n_dedup);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }

@@ -23,7 +23,8 @@ _TIMING = {"on": False, "events": {}}
 
 def enable_kernel_timing(on=True):
     _TIMING["on"] = on
-    _TIMING["events"] = {}
+    if on:
+        _TIMING["events"] = {}
 
 
 class _Timed:
@@ -415,6 +416,42 @@ def attention(q, k, vt, heads, scale=None):
                                                vt.stride(0), D * vt.stride(1), vt.stride(1), out.stride(0),
                                                out.stride(1), D, sc, _stream()), "dm_attention_fwd_bf16")
     return out
+
+
+# ------------------------------------------------------------------------------------------ convolution
+def conv3x3_nhwc(x_nhwc, w_tap_major, bias, stride=1, pad=(1, 1), out_hw=None):
+    """x [B,H,W,Cin] bf16 contiguous, w [Cout, 9*Cin] bf16 (tap-major) -> y [B,Ho,Wo,Cout] bf16."""
+    _need_cuda(x_nhwc, w_tap_major)
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous() and w_tap_major.is_contiguous()
+    B, H, W, Cin = x_nhwc.shape
+    Cout = w_tap_major.shape[0]
+    if out_hw is None:
+        out_hw = ((H + 2 * pad[0] - 3) // stride + 1, (W + 2 * pad[1] - 3) // stride + 1)
+    Ho, Wo = out_hw
+    y = torch.empty(B, Ho, Wo, Cout, device=x_nhwc.device, dtype=torch.bfloat16)
+    with _Timed(f"conv3x3[{Cin}->{Cout}@{Ho}x{Wo},s{stride}]", 2.0 * B * Ho * Wo * Cout * 9 * Cin):
+        check(_lib.lib().dm_conv3x3_nhwc_bf16(x_nhwc.data_ptr(), w_tap_major.data_ptr(),
+                                              bias.data_ptr() if bias is not None else None, y.data_ptr(), B, H, W,
+                                              Cin, Ho, Wo, Cout, stride, pad[0], pad[1], _stream()),
+              "dm_conv3x3_nhwc_bf16")
+    return y
+
+
+class _Conv3x3S1(torch.autograd.Function):
+    """stride-1, pad-1 3x3 conv with frozen weights: backward = the same kernel on the flipped weights."""
+
+    @staticmethod
+    def forward(ctx, x_nhwc, w_fwd, w_dgrad, bias):
+        ctx.w_dgrad = w_dgrad
+        return conv3x3_nhwc(x_nhwc, w_fwd, bias, 1, (1, 1))
+
+    @staticmethod
+    def backward(ctx, g):
+        return conv3x3_nhwc(g.contiguous(), ctx.w_dgrad, None, 1, (1, 1)), None, None, None
+
+
+def conv3x3_s1_autograd(x_nhwc, w_fwd, w_dgrad, bias):
+    return _Conv3x3S1.apply(x_nhwc, w_fwd, w_dgrad, bias)
 
 
 # ------------------------------------------------------------------------------------------ optimiser

@@ -19,34 +19,66 @@ import torch.nn.functional as F
 from .. import hipops
 
 
-# Convolution backend.  MIOpen ships no gfx950 kernel database in this ROCm image (no *.kdb / gfx950
-# perf-db), so every new conv shape JIT-compiles its kernel on first use: ~25 minutes of cold start for
-# UNet + ControlNet + VAE on a fresh box.  "gemm" lowers every conv to im2col (torch's native unfold
-# kernel) + one batched hipBLASLt GEMM whose kernels are precompiled: no JIT, ~20 % extra HBM traffic.
-CONV_BACKEND = os.environ.get("DREAMMAT_CONV", "gemm")
+# Convolution backends on the GPU (bf16):
+#   "mfma"   (default) 3x3 convs run in the hand-written implicit-GEMM MFMA kernel (csrc/conv.hip) on NHWC
+#            activations; 1x1 convs are plain GEMMs on the NHWC view; the few shapes the kernel does not
+#            cover (Cin % 32 != 0: conv_in / conditioning stem; strided convs that need a gradient) use "gemm".
+#   "gemm"   im2col (torch's unfold) + one batched hipBLASLt GEMM: no JIT, 9x activation traffic.
+#   "miopen" torch's default.  MIOpen ships no gfx950 kernel database in this ROCm image, so every new
+#            conv shape JIT-compiles on first use: ~25 minutes of cold start on a fresh box.
+CONV_BACKEND = os.environ.get("DREAMMAT_CONV", "mfma")
 
 
 class Conv2d(nn.Conv2d):
-    """nn.Conv2d (same parameters / state_dict keys) with a JIT-free GEMM lowering on the GPU."""
+    """nn.Conv2d (same parameters / state_dict keys) with JIT-free GPU lowerings."""
 
-    def forward(self, x):
-        if CONV_BACKEND != "gemm" or not x.is_cuda:
-            return super().forward(x)
+    def _prepared(self):
+        w = self.weight
+        key = (w.data_ptr(), w._version, w.dtype)
+        if getattr(self, "_prep_key", None) != key:
+            Cout, Cin = w.shape[0], w.shape[1]
+            self._w_fwd = w.detach().permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+            self._w_dgrad = w.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous()
+            self._prep_key = key
+        return self._w_fwd, self._w_dgrad
+
+    def _forward_gemm(self, x):
         B, Cin, H, W = x.shape
         Cout, _, kh, kw = self.weight.shape
         sh, sw = self.stride
         ph, pw = self.padding
         if kh == 1 and kw == 1 and sh == 1 and sw == 1 and ph == 0 and pw == 0:
-            y = torch.matmul(self.weight.view(Cout, Cin), x.reshape(B, Cin, H * W))
-            Ho, Wo = H, W
-        else:
-            cols = F.unfold(x, (kh, kw), padding=(ph, pw), stride=(sh, sw))          # [B, Cin*kh*kw, L]
-            y = torch.matmul(self.weight.view(Cout, Cin * kh * kw), cols)
-            Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+            xn = x.permute(0, 2, 3, 1)                                   # free for channels-last activations
+            y = F.linear(xn, self.weight.view(Cout, Cin), self.bias)     # [B,H,W,Cout]
+            return y.permute(0, 3, 1, 2)
+        cols = F.unfold(x, (kh, kw), padding=(ph, pw), stride=(sh, sw))  # [B, Cin*kh*kw, L]
+        y = torch.matmul(self.weight.view(Cout, Cin * kh * kw), cols)
+        Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
         y = y.view(B, Cout, Ho, Wo)
         if self.bias is not None:
             y = y + self.bias.view(1, Cout, 1, 1)
         return y
+
+    def forward(self, x):
+        if CONV_BACKEND == "miopen" or not x.is_cuda:
+            return super().forward(x)
+        Cout, Cin, kh, kw = self.weight.shape
+        needs_grad = torch.is_grad_enabled() and x.requires_grad
+        ok = (CONV_BACKEND == "mfma" and x.dtype == torch.bfloat16 and kh == 3 and kw == 3 and Cin % 32 == 0
+              and Cout % 64 == 0 and self.stride[0] == self.stride[1] and not self.weight.requires_grad
+              and (not needs_grad or (self.stride[0] == 1 and self.padding == (1, 1) and Cin % 64 == 0)))
+        if not ok:
+            return self._forward_gemm(x)
+        w_fwd, w_dgrad = self._prepared()
+        xn = x.permute(0, 2, 3, 1).contiguous()                          # no-op when already NHWC
+        if needs_grad:
+            y = hipops.conv3x3_s1_autograd(xn, w_fwd, w_dgrad, self.bias)
+        else:
+            H, W = x.shape[2], x.shape[3]
+            s = self.stride[0]
+            ph, pw = self.padding
+            y = hipops.conv3x3_nhwc(xn, w_fwd, self.bias, s, (ph, pw), ((H + 2 * ph - 3) // s + 1, (W + 2 * pw - 3) // s + 1))
+        return y.permute(0, 3, 1, 2)
 
 
 def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0.0, max_period=10000):

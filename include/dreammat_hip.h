@@ -167,6 +167,16 @@ int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* ou
                           long long k_hs, long long vt_bs, long long vt_hs, long long vt_ds, long long o_bs,
                           long long o_ss, long long o_hs, float scale, dm_stream_t stream);
 
+/* ---- convolution ------------------------------------------------------------------------- */
+/* 3x3 convolutions of UNet2DConditionModel / ControlNetModel / AutoencoderKL (the F.conv2d calls diffusers
+ * makes under models/guidance/dreammat_guidance.py:205-292) as an implicit GEMM on MFMA: NHWC bf16,
+ * x [B,Hin,Win,Cin], w [Cout,3,3,Cin] (tap-major, K contiguous), bias [Cout] or NULL, y [B,Hout,Wout,Cout].
+ * pad_y/pad_x = leading zero padding, trailing padding implied by Hout/Wout.  Cin % 32 == 0, Cout % 64 == 0.
+ * The data gradient (the VAE encoder is differentiated through) is the same call with w' = taps flipped and
+ * Cin/Cout swapped. */
+int dm_conv3x3_nhwc_bf16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin,
+                         int Hout, int Wout, int Cout, int stride, int pad_y, int pad_x, dm_stream_t stream);
+
 /* ---- optimiser ---------------------------------------------------------------------------- */
 /* torch.optim.Adam step (configs/dreammat.yaml:110-115 via systems/utils.py:34-53) over one flat
  * fp32 buffer; grad is multiplied by grad_scale first (1/world after a sum all-reduce) and

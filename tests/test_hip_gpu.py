@@ -434,3 +434,61 @@ def test_full_sds_step_vs_oracle(dev, tmp_path, monkeypatch):
         diff = (p.detach().cpu().reshape(r.shape) - r.detach()).abs()
         assert diff[gmask].max() < 1e-4, (nm, float(diff[gmask].max()))
     assert float(system.flat.grad.abs().max()) == 0.0       # zeroed by the fused kernel for the next step
+
+
+CONV_CASES = [  # (B, Cin, Cout, H, W, stride)
+    (2, 64, 128, 16, 16, 1), (3, 320, 320, 32, 32, 1), (1, 32, 64, 10, 10, 1), (2, 128, 256, 17, 23, 1),
+    (2, 320, 320, 32, 32, 2), (1, 640, 1280, 8, 8, 1), (1, 96, 192, 9, 9, 2)]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,stride", CONV_CASES)
+def test_conv3x3_mfma_vs_fp32_reference(dev, B, Cin, Cout, H, W, stride):
+    from dreammat_amd.sd import layers
+    torch.manual_seed(0)
+    conv = layers.Conv2d(Cin, Cout, 3, stride=stride, padding=1)
+    x = torch.randn(B, Cin, H, W)
+    xb = x.bfloat16()
+    conv_b = layers.Conv2d(Cin, Cout, 3, stride=stride, padding=1)
+    conv_b.load_state_dict(conv.state_dict())
+    conv_b.to(dev, torch.bfloat16)
+    for p in conv_b.parameters():
+        p.requires_grad_(False)
+    wref = conv_b.weight.float().cpu(); bref = conv_b.bias.float().cpu()
+    xg = xb.to(dev).requires_grad_(stride == 1)
+    assert layers.CONV_BACKEND == "mfma"
+    hipops.enable_kernel_timing(True)
+    y = conv_b(xg)
+    torch.cuda.synchronize()
+    assert any(k.startswith("conv3x3") for k in hipops.kernel_times()), "MFMA conv kernel was not used"
+    hipops.enable_kernel_timing(False)
+    xr = xb.float().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xr, wref, bref, stride=stride, padding=1)
+    assert y.shape == ref.shape
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err < 2e-2 * ref.abs().max().item() + 1e-2, err          # bf16 output rounding
+    if stride == 1:
+        dy = torch.randn_like(ref)
+        y.backward(dy.to(dev).bfloat16())
+        ref.backward(dy.bfloat16().float())
+        gerr = (xg.grad.float().cpu() - xr.grad).abs().max().item()
+        assert gerr < 2e-2 * xr.grad.abs().max().item() + 1e-2, gerr
+
+
+def test_hashgrid_backward_coherent_points(dev):
+    """pixel-coherent sample points (long runs of identical cells per wave) exercise the run-combining
+    backward; result must equal the oracle's autograd."""
+    torch.manual_seed(2)
+    spec = hipops.GridSpec(n_levels=12, log2_hashmap_size=15)
+    lv, tot = ofield.grid_levels(n_levels=12, log2_hashmap_size=15)
+    t = torch.linspace(0, 1, 6000)[:, None]
+    x = torch.cat([-0.6 + 1.2 * t, 0.3 * torch.sin(6 * t), 0.1 + 0.002 * torch.randn(6000, 1)], dim=1)
+    table = torch.rand(tot * 2) * 2 - 1
+    tg = table.to(dev).requires_grad_()
+    enc = hipops.hashgrid_encode(x.t().contiguous().to(dev).t(), tg, spec, 1.0)
+    to = table.reshape(-1, 2).clone().requires_grad_()
+    ref = ofield.hash_encode(ofield.contract_to_unisphere(x), to, lv)
+    dy = torch.randn(6000, 24)
+    enc.backward(dy.to(dev))
+    ref.backward(dy)
+    err = (tg.grad.cpu().reshape(-1, 2) - to.grad).abs().max()
+    assert err < 1e-3 * to.grad.abs().max(), float(err)

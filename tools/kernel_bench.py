@@ -127,6 +127,16 @@ def main():
             vt = torch.randn(Bq, C, pad, device=dev, dtype=torch.bfloat16)
             rec(f"attention B{Bq} h{h} Sq{Sq} Skv{Skv} D{D}", timeit(lambda: hipops.attention(q, k, vt, h), a.iters),
                 flops=4.0 * Bq * Sq * Skv * C)
+    if not a.skip_attn:
+        from dreammat_amd.sd import layers
+        for (Bq, Cin, Cout, Hh, Ww) in [(24, 320, 320, 64, 64), (24, 640, 640, 32, 32), (24, 1280, 1280, 16, 16),
+                                        (24, 960, 320, 64, 64), (8, 128, 128, 512, 512), (8, 256, 256, 256, 256),
+                                        (8, 512, 512, 64, 64)]:
+            x = torch.randn(Bq, Hh, Ww, Cin, device=dev, dtype=torch.bfloat16)
+            w = torch.randn(Cout, 9 * Cin, device=dev, dtype=torch.bfloat16) * 0.02
+            b = torch.zeros(Cout, device=dev, dtype=torch.bfloat16)
+            rec(f"conv3x3 B{Bq} {Cin}->{Cout} @{Hh}x{Ww}", timeit(lambda: hipops.conv3x3_nhwc(x, w, b), max(3, a.iters // 3), 2),
+                flops=2.0 * Bq * Hh * Ww * Cout * 9 * Cin)
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/kernel_bench.json", "w") as fh:
         json.dump(res, fh, indent=1)
