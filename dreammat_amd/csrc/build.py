@@ -16,6 +16,7 @@ SOURCES = {
     "hashgrid.hip": ["-munsafe-fp-atomics"],
     "attention.hip": [],
     "conv.hip": [],
+    "groupnorm.hip": [],
     "adam.hip": [],
     "host.cpp": [],
 }

@@ -33,28 +33,47 @@ struct ConvArgs {
     long long M;         // B*Hout*Wout
 };
 
-constexpr int BM = 128, BK = 32;
-constexpr int ROWB = BK * 2 + 16;     // LDS bytes per tile row (32 bf16 + 16 B pad)
+constexpr int BM = 128;
 
-template <int BN>
-__global__ __launch_bounds__(256) void k_conv3x3(ConvArgs a) {
+// (m-tile, n-tile) of this workgroup.  Consecutive tile ids share the activation (A) tile and walk the
+// Cout tiles; since the dispatcher places block b on XCD b % 8 (private L2 per XCD), each XCD gets a
+// CONTIGUOUS range of tile ids so that the re-used A tile and the weight panel stay in ITS L2.
+__device__ __forceinline__ bool tile_of_block(long long n_mt, int n_nt, long long& mt, int& nt) {
+    const long long total = n_mt * n_nt;
+    const long long lin = (long long)blockIdx.x;
+    const long long per_xcd = (total + 7) / 8;
+    const long long id = (lin & 7) * per_xcd + (lin >> 3);
+    if ((lin >> 3) >= per_xcd || id >= total) return false;
+    mt = id / n_nt;
+    nt = (int)(id - mt * n_nt);
+    return true;
+}
+
+template <int BN, int BK>
+__global__ __launch_bounds__(256) void k_conv3x3(ConvArgs a, long long n_mt, int n_nt) {
+    constexpr int ROWB = BK * 2 + 16;                  // LDS bytes per tile row (BK bf16 + 16 B pad)
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
-    constexpr int NT = BN / 64;                       // 32-wide n tiles per wave (wave tile = 64 x BN/2)
-    constexpr int B_CHUNKS = BN * 4 / 256;            // 16 B chunks of the B tile per thread (BN=128: 2, 64: 1)
-    __shared__ __attribute__((aligned(16))) char smem[2 * (A_BYTES + B_BYTES)];
+    constexpr int NT = BN / 64;                        // 32-wide n tiles per wave (wave tile = 64 x BN/2)
+    constexpr int CPR = BK / 8;                        // 16 B chunks per tile row
+    constexpr int A_CHUNKS = BM * CPR / 256;           // per thread
+    constexpr int B_CHUNKS = BN * CPR / 256;
+    constexpr int RPI = 256 / CPR;                     // rows covered per chunk-iteration
+    extern __shared__ __attribute__((aligned(16))) char smem[];
 
+    long long mt; int nt;
+    if (!tile_of_block(n_mt, n_nt, mt, nt)) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
-    const int wm = wave >> 1, wn = wave & 1;          // 2 x 2 waves
-    const long long m0 = (long long)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    const int wm = wave >> 1, wn = wave & 1;           // 2 x 2 waves
+    const long long m0 = mt * BM;
+    const int n0 = nt * BN;
 
-    // ---- per-thread gather coordinates of its two A rows (row = tid/4 and 64 + tid/4), chunk = tid%4
-    const int a_chunk = tid & 3;
-    int a_b[2], a_y[2], a_x[2];
-    bool a_ok[2];
+    // ---- per-thread gather coordinates of its A rows (row = tid/CPR + RPI*i), chunk = tid%CPR
+    const int a_chunk = tid % CPR;
+    int a_b[A_CHUNKS], a_y[A_CHUNKS], a_x[A_CHUNKS];
+    bool a_ok[A_CHUNKS];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        long long m = m0 + (tid >> 2) + 64 * i;
+    for (int i = 0; i < A_CHUNKS; ++i) {
+        long long m = m0 + tid / CPR + RPI * i;
         a_ok[i] = m < a.M;
         long long mm = a_ok[i] ? m : 0;
         int hw = a.Hout * a.Wout;
@@ -68,13 +87,13 @@ __global__ __launch_bounds__(256) void k_conv3x3(ConvArgs a) {
     const int n_steps = 9 * kt_per_tap;
     const long long Kw = 9LL * a.Cin;
 
-    uint4 areg[2], breg[B_CHUNKS];
+    uint4 areg[A_CHUNKS], breg[B_CHUNKS];
     auto load_step = [&](int s) {
         int tap = s / kt_per_tap;
         int c0 = (s - tap * kt_per_tap) * BK + a_chunk * 8;
         int dy = tap / 3, dx = tap - dy * 3;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < A_CHUNKS; ++i) {
             int yy = a_y[i] + dy, xx = a_x[i] + dx;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (a_ok[i] && (unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)a.Win)
@@ -83,22 +102,19 @@ __global__ __launch_bounds__(256) void k_conv3x3(ConvArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < B_CHUNKS; ++i) {
-            int c = tid + 256 * i;
-            int row = c >> 2, ch = c & 3;
-            breg[i] = *reinterpret_cast<const uint4*>(a.w + (long long)(n0 + row) * Kw + (long long)s * BK + ch * 8);
+            int row = tid / CPR + RPI * i;
+            breg[i] = *reinterpret_cast<const uint4*>(a.w + (long long)(n0 + row) * Kw + (long long)s * BK + a_chunk * 8);
         }
     };
     auto write_step = [&](int buf) {
         char* ab = smem + buf * (A_BYTES + B_BYTES);
         char* bb = ab + A_BYTES;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<uint4*>(ab + ((tid >> 2) + 64 * i) * ROWB + a_chunk * 16) = areg[i];
+        for (int i = 0; i < A_CHUNKS; ++i)
+            *reinterpret_cast<uint4*>(ab + (tid / CPR + RPI * i) * ROWB + a_chunk * 16) = areg[i];
 #pragma unroll
-        for (int i = 0; i < B_CHUNKS; ++i) {
-            int c = tid + 256 * i;
-            *reinterpret_cast<uint4*>(bb + (c >> 2) * ROWB + (c & 3) * 16) = breg[i];
-        }
+        for (int i = 0; i < B_CHUNKS; ++i)
+            *reinterpret_cast<uint4*>(bb + (tid / CPR + RPI * i) * ROWB + a_chunk * 16) = breg[i];
     };
 
     f32x16 acc[2][NT];
@@ -118,7 +134,7 @@ __global__ __launch_bounds__(256) void k_conv3x3(ConvArgs a) {
         const char* ab = smem + buf * (A_BYTES + B_BYTES);
         const char* bb = ab + A_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BK / 16; ++kk) {
             bf16x8 af[2], bf[NT];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -151,6 +167,27 @@ __global__ __launch_bounds__(256) void k_conv3x3(ConvArgs a) {
     }
 }
 
+template <int BN, int BK>
+int launch_conv(const ConvArgs& a, hipStream_t stream) {
+    constexpr int LDS = 2 * (BM + BN) * (BK * 2 + 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<BN, BK>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    long long n_mt = (a.M + BM - 1) / BM;
+    int n_nt = a.Cout / BN;
+    long long total = n_mt * n_nt;
+    long long blocks = ((total + 7) / 8) * 8;
+    if (blocks > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
+    DM_ENTER();
+    hipLaunchKernelGGL((k_conv3x3<BN, BK>), dim3((unsigned)blocks), dim3(256), LDS, stream, a, n_mt, n_nt);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DM_OK : (int)e;
+}
+
 }  // namespace
 
 extern "C" {
@@ -168,16 +205,8 @@ int dm_conv3x3_nhwc_bf16(const void* x, const void* w, const void* bias, void* y
     a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
     a.stride = stride; a.pad_y = pad_y; a.pad_x = pad_x;
     a.M = (long long)B * Hout * Wout;
-    long long mt = (a.M + BM - 1) / BM;
-    if (mt > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
-    DM_ENTER();
-    if (Cout % 128 == 0) {
-        hipLaunchKernelGGL(k_conv3x3<128>, dim3((unsigned)mt, Cout / 128), dim3(256), 0, stream, a);
-    } else {
-        hipLaunchKernelGGL(k_conv3x3<64>, dim3((unsigned)mt, Cout / 64), dim3(256), 0, stream, a);
-    }
-    DM_LAUNCH_CHECK();
-    return DM_OK;
+    if (Cout % 128 == 0) return (Cin % 64 == 0) ? launch_conv<128, 64>(a, stream) : launch_conv<128, 32>(a, stream);
+    return (Cin % 64 == 0) ? launch_conv<64, 64>(a, stream) : launch_conv<64, 32>(a, stream);
 }
 
 }  // extern "C"

@@ -454,6 +454,47 @@ def conv3x3_s1_autograd(x_nhwc, w_fwd, w_dgrad, bias):
     return _Conv3x3S1.apply(x_nhwc, w_fwd, w_dgrad, bias)
 
 
+# ------------------------------------------------------------------------------------------ group norm
+def _gn_fwd(x_nhwc, gamma, beta, eps, act):
+    B, H, W, C = x_nhwc.shape
+    y = torch.empty_like(x_nhwc)
+    ws = torch.empty(int(_lib.lib().dm_groupnorm_workspace_floats(B, C)), device=x_nhwc.device, dtype=torch.float32)
+    with _Timed(f"groupnorm_fwd[C={C},HW={H * W}]", 6.0 * B * H * W * C):
+        check(_lib.lib().dm_groupnorm_nhwc_fwd(x_nhwc.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                               ws.data_ptr(), B, H * W, C, float(eps), int(act), _stream()),
+              "dm_groupnorm_nhwc_fwd")
+    return y, ws
+
+
+class _GroupNormAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_nhwc, gamma, beta, eps, act):
+        y, ws = _gn_fwd(x_nhwc, gamma, beta, eps, act)
+        ctx.save_for_backward(x_nhwc, gamma, beta, ws)
+        ctx.eps, ctx.act = eps, act
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, beta, ws = ctx.saved_tensors
+        B, H, W, C = x.shape
+        g = g.contiguous()
+        dx = torch.empty_like(x)
+        check(_lib.lib().dm_groupnorm_nhwc_bwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), g.data_ptr(),
+                                               dx.data_ptr(), ws.data_ptr(), B, H * W, C, float(ctx.eps), int(ctx.act),
+                                               _stream()), "dm_groupnorm_nhwc_bwd")
+        return dx, None, None, None, None
+
+
+def groupnorm_nhwc(x_nhwc, gamma, beta, eps, act):
+    """x [B,H,W,C] bf16 contiguous -> act(GroupNorm32(x)) [B,H,W,C]; differentiable wrt x."""
+    _need_cuda(x_nhwc, gamma, beta)
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous() and gamma.dtype == torch.bfloat16
+    if torch.is_grad_enabled() and x_nhwc.requires_grad:
+        return _GroupNormAct.apply(x_nhwc, gamma, beta, eps, act)
+    return _gn_fwd(x_nhwc, gamma, beta, eps, act)[0]
+
+
 # ------------------------------------------------------------------------------------------ optimiser
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, grad_scale=1.0, zero_grad=True):
     _need_cuda(param, grad, exp_avg, exp_avg_sq)

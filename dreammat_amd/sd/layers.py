@@ -81,6 +81,18 @@ class Conv2d(nn.Conv2d):
         return y.permute(0, 3, 1, 2)
 
 
+def group_norm_act(norm: nn.GroupNorm, x, silu: bool):
+    """act(GroupNorm(x)) for a logical-NCHW tensor.  GPU bf16 (32 groups) -> fused NHWC HIP kernel (the
+    activation stays channels-last, which is what the implicit-GEMM conv consumes); otherwise torch."""
+    if (x.is_cuda and x.dtype == torch.bfloat16 and norm.num_groups == 32 and CONV_BACKEND == "mfma"
+            and not norm.weight.requires_grad):
+        xn = x.permute(0, 2, 3, 1).contiguous()                  # no-op for channels-last activations
+        y = hipops.groupnorm_nhwc(xn, norm.weight, norm.bias, norm.eps, 1 if silu else 0)
+        return y.permute(0, 3, 1, 2)
+    y = norm(x)
+    return F.silu(y) if silu else y
+
+
 def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0.0, max_period=10000):
     half = dim // 2
     exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / (half - freq_shift)
@@ -205,7 +217,7 @@ class Transformer2DModel(nn.Module):
     def forward(self, x, context):
         B, C, H, W = x.shape
         res = x
-        h = self.norm(x)
+        h = group_norm_act(self.norm, x, False)
         if self.use_linear:
             h = self.proj_in(h.permute(0, 2, 3, 1).reshape(B, H * W, C))
         else:
@@ -230,10 +242,10 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = Conv2d(in_ch, out_ch, 1) if in_ch != out_ch else None
 
     def forward(self, x, temb=None):
-        h = self.conv1(F.silu(self.norm1(x)))
+        h = self.conv1(group_norm_act(self.norm1, x, True))
         if self.time_emb_proj is not None:
             h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
-        h = self.conv2(F.silu(self.norm2(h)))
+        h = self.conv2(group_norm_act(self.norm2, h, True))
         if self.conv_shortcut is not None:
             x = self.conv_shortcut(x)
         return x + h

@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .layers import (Attention, Conv2d, Downsample2D, PaddedContext, ResnetBlock2D, TimestepEmbedding,
+from .layers import (Attention, Conv2d, Downsample2D, group_norm_act, PaddedContext, ResnetBlock2D, TimestepEmbedding,
                      Transformer2DModel, Upsample2D, attention_core, timestep_embedding)
 
 
@@ -171,7 +171,7 @@ class UNet2DConditionModel(_Encoder):
             x = x + mid_block_additional_residual
         for blk in self.up_blocks:
             x = blk(x, skips, temb, ctx)
-        return self.conv_out(F.silu(self.conv_norm_out(x)))
+        return self.conv_out(group_norm_act(self.conv_norm_out, x, True))
 
 
 class ControlNetConditioningEmbedding(nn.Module):
@@ -249,12 +249,12 @@ class VaeAttention(nn.Module):
 
     def forward(self, x):
         B, C, H, W = x.shape
-        h = self.group_norm(x).reshape(B, C, H * W).transpose(1, 2)
+        h = group_norm_act(self.group_norm, x, False).permute(0, 2, 3, 1).reshape(B, H * W, C)
         q, k, v = self.to_q(h), self.to_k(h), self.to_v(h)
         s = torch.matmul(q, k.transpose(1, 2)) * (C ** -0.5)
         p = torch.softmax(s.float(), dim=-1).to(q.dtype)
         o = self.to_out[0](torch.matmul(p, v))
-        return o.transpose(1, 2).reshape(B, C, H, W) + x
+        return o.reshape(B, H, W, C).permute(0, 3, 1, 2) + x
 
 
 class VaeEncoder(nn.Module):
@@ -288,7 +288,7 @@ class VaeEncoder(nn.Module):
         x = self.mid_block.resnets[0](x)
         x = self.mid_block.attentions[0](x)
         x = self.mid_block.resnets[1](x)
-        return self.conv_out(F.silu(self.conv_norm_out(x)))
+        return self.conv_out(group_norm_act(self.conv_norm_out, x, True))
 
 
 class AutoencoderKLEncoder(nn.Module):

@@ -177,6 +177,16 @@ int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* ou
 int dm_conv3x3_nhwc_bf16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin,
                          int Hout, int Wout, int Cout, int stride, int pad_y, int pad_x, dm_stream_t stream);
 
+/* ---- normalisation ----------------------------------------------------------------------- */
+/* GroupNorm(32) [+ SiLU] of the ResnetBlock2D / Transformer2DModel / conv_norm_out layers of the same nets,
+ * NHWC bf16: x,y [B,HW,C], gamma/beta [C] bf16.  ws: dm_groupnorm_workspace_floats(B,C) fp32, kept by the caller
+ * between fwd and bwd.  act: 0 = none, 1 = SiLU.  bwd returns dx only (weights are frozen on this path). */
+size_t dm_groupnorm_workspace_floats(int B, int C);
+int dm_groupnorm_nhwc_fwd(const void* x, const void* gamma, const void* beta, void* y, float* ws, int B, int HW,
+                          int C, float eps, int act, dm_stream_t stream);
+int dm_groupnorm_nhwc_bwd(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* ws,
+                          int B, int HW, int C, float eps, int act, dm_stream_t stream);
+
 /* ---- optimiser ---------------------------------------------------------------------------- */
 /* torch.optim.Adam step (configs/dreammat.yaml:110-115 via systems/utils.py:34-53) over one flat
  * fp32 buffer; grad is multiplied by grad_scale first (1/world after a sum all-reduce) and
