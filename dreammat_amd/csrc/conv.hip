@@ -14,6 +14,9 @@
 // (conflict-free ds_read_b128), one barrier per K-step.  The same kernel computes the data gradient
 // (the VAE encoder is differentiated through): dx = conv(dy, w') with w' = taps flipped, Cin<->Cout
 // swapped (prepared once on the host side).  Requirements: Cin % 32 == 0, Cout % 64 == 0.
+#include <cstdlib>
+#include <cstring>
+
 #include "dm_common.h"
 
 namespace {
@@ -167,6 +170,166 @@ __global__ __launch_bounds__(256) void k_conv3x3(ConvArgs a, long long n_mt, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Variant 2: LDS-DMA pipeline.  Same tiling (128 x BN x 64, 4 waves), but the tiles travel
+// HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR staging) through a 3-stage ring, so two
+// K-steps of loads are in flight behind the MFMAs instead of one: the kernel above is latency-bound
+// (~16 % of MFMA peak) because a single staged tile cannot cover an L2/HBM round trip.
+//  * LDS rows are unpadded 128 B (the DMA writes wave-uniform base + lane*16); bank conflicts are
+//    avoided by XOR-swizzling the 16 B chunk index with (row>>1)&7 -- applied to the per-lane SOURCE
+//    address on the way in and to the ds_read address on the way out (same involution both sides).
+//  * out-of-image taps read from a 16-byte zero page instead of being predicated.
+//  * counted s_waitcnt vmcnt(L) + raw s_barrier: one barrier per K-step, loads span the barrier.
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0, 0, 0, 0};
+
+template <int BN>
+__global__ __launch_bounds__(256) void k_conv3x3_dma(ConvArgs a, long long n_mt, int n_nt) {
+    constexpr int BK = 64;
+    constexpr int ROWB = 128;                          // bytes per tile row (64 bf16), unpadded
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int NT = BN / 64;
+    constexpr int A_INSTR = BM / 8 / 4;                // wave-instructions (8 rows each) per wave: 4
+    constexpr int B_INSTR = BN / 8 / 4;                // 4 (BN=128) or 2 (BN=64)
+    constexpr int L = A_INSTR + B_INSTR;               // DMA instructions per wave per tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 * STAGE
+
+    long long mt; int nt;
+    if (!tile_of_block(n_mt, n_nt, mt, nt)) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long m0 = mt * BM;
+    const int n0 = nt * BN;
+    const int lrow = lane >> 3, lslot = lane & 7;      // this lane's row / 16 B slot inside one DMA instruction
+
+    // A rows of this lane: wave*32 + 8*i + lrow
+    int a_b[A_INSTR], a_y[A_INSTR], a_x[A_INSTR];
+    bool a_ok[A_INSTR];
+    int a_chunk[A_INSTR];
+#pragma unroll
+    for (int i = 0; i < A_INSTR; ++i) {
+        int row = wave * (BM / 4) + 8 * i + lrow;
+        long long m = m0 + row;
+        a_ok[i] = m < a.M;
+        long long mm = a_ok[i] ? m : 0;
+        int hw = a.Hout * a.Wout;
+        a_b[i] = (int)(mm / hw);
+        int rem = (int)(mm - (long long)a_b[i] * hw);
+        int yo = rem / a.Wout;
+        a_y[i] = yo * a.stride - a.pad_y;
+        a_x[i] = (rem - yo * a.Wout) * a.stride - a.pad_x;
+        a_chunk[i] = lslot ^ ((row >> 1) & 7);         // source chunk that must land in slot lslot
+    }
+    const __bf16* b_src[B_INSTR];
+#pragma unroll
+    for (int i = 0; i < B_INSTR; ++i) {
+        int row = wave * (BN / 4) + 8 * i + lrow;
+        b_src[i] = a.w + (long long)(n0 + row) * 9LL * a.Cin + (lslot ^ ((row >> 1) & 7)) * 8;
+    }
+    const int kt_per_tap = a.Cin / BK;
+    const int n_steps = 9 * kt_per_tap;
+
+    auto issue = [&](int s, int stage) {
+        int tap = s / kt_per_tap;
+        int c0 = (s - tap * kt_per_tap) * BK;
+        int dy = tap / 3, dx = tap - dy * 3;
+        char* ab = smem + stage * STAGE;
+        char* bb = ab + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_INSTR; ++i) {
+            int yy = a_y[i] + dy, xx = a_x[i] + dx;
+            bool inb = a_ok[i] && (unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)a.Win;
+            int yc = min(max(yy, 0), a.Hin - 1), xc = min(max(xx, 0), a.Win - 1);   // always a legal address
+            unsigned long long real = (unsigned long long)(a.x + (((long long)a_b[i] * a.Hin + yc) * a.Win + xc) * a.Cin + c0 + a_chunk[i] * 8);
+            unsigned long long zero = (unsigned long long)g_zero_page;
+            const void* src = (const void*)(inb ? real : zero);                      // select, never a branch:
+            // the DMA must execute with ALL lanes active (an inactive lane would leave its LDS slot stale)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(ab + (wave * (BM / 4) + 8 * i) * ROWB),
+                                             16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_INSTR; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + (long long)s * BK),
+                                             (__attribute__((address_space(3))) void*)(bb + (wave * (BN / 4) + 8 * i) * ROWB),
+                                             16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    issue(0, 0);
+    if (n_steps > 1) issue(1, 1);
+    int stage = 0;
+    for (int s = 0; s < n_steps; ++s) {
+        if (s + 1 < n_steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int st2 = stage + 2; if (st2 >= 3) st2 -= 3;
+        if (s + 2 < n_steps) issue(s + 2, st2);
+        const char* ab = smem + stage * STAGE;
+        const char* bb = ab + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            bf16x8 af[2], bf[NT];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int r = 64 * wm + 32 * i + l31;
+                af[i] = *reinterpret_cast<const bf16x8*>(ab + r * ROWB + (((2 * kk + hi) ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                int r = (BN / 2) * wn + 32 * j + l31;
+                bf[j] = *reinterpret_cast<const bf16x8*>(bb + r * ROWB + (((2 * kk + hi) ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        stage = stage + 1; if (stage >= 3) stage = 0;
+    }
+
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        int n = n0 + (BN / 2) * wn + 32 * j + l31;
+        float bv = a.bias ? (float)a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                long long m = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (m < a.M) a.y[m * a.Cout + n] = (__bf16)(acc[i][j][r] + bv);
+            }
+    }
+}
+
+template <int BN>
+int launch_conv_dma(const ConvArgs& a, hipStream_t stream) {
+    constexpr int LDS = 3 * (BM + BN) * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_dma<BN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    long long n_mt = (a.M + BM - 1) / BM;
+    int n_nt = a.Cout / BN;
+    long long blocks = ((n_mt * n_nt + 7) / 8) * 8;
+    if (blocks > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
+    DM_ENTER();
+    hipLaunchKernelGGL((k_conv3x3_dma<BN>), dim3((unsigned)blocks), dim3(256), LDS, stream, a, n_mt, n_nt);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DM_OK : (int)e;
+}
+
 template <int BN, int BK>
 int launch_conv(const ConvArgs& a, hipStream_t stream) {
     constexpr int LDS = 2 * (BM + BN) * (BK * 2 + 16);
@@ -205,6 +368,10 @@ int dm_conv3x3_nhwc_bf16(const void* x, const void* w, const void* bias, void* y
     a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
     a.stride = stride; a.pad_y = pad_y; a.pad_x = pad_x;
     a.M = (long long)B * Hout * Wout;
+    // DREAMMAT_CONV_KERNEL=staged selects the register-staged variant everywhere (A/B measurements)
+    static const bool use_dma = !(getenv("DREAMMAT_CONV_KERNEL") && !strcmp(getenv("DREAMMAT_CONV_KERNEL"), "staged"));
+    if (use_dma && Cin % 64 == 0)
+        return (Cout % 128 == 0) ? launch_conv_dma<128>(a, stream) : launch_conv_dma<64>(a, stream);
     if (Cout % 128 == 0) return (Cin % 64 == 0) ? launch_conv<128, 64>(a, stream) : launch_conv<128, 32>(a, stream);
     return (Cin % 64 == 0) ? launch_conv<64, 64>(a, stream) : launch_conv<64, 32>(a, stream);
 }
