@@ -66,30 +66,32 @@ def system_config(a, views_per_rank):
                      "min_step_percent": [500, 0.2, 0.02, 501], "max_step_percent": [500, 0.8, 0.5, 501]},
         "prompt_processor": {"prompt": "a DSLR photo of a ceramic vase", "negative_prompt": "ugly, low resolution",
                              "pretrained_model_name_or_path": a.sd,
-                             "cache_dir": os.path.join("/tmp", f"dm_text_cache_{os.getpid()}")},
+                             # shared by all ranks of one job (rank 0 writes, the others read after the barrier)
+                             "cache_dir": os.path.join("/tmp", f"dm_text_cache_{os.environ.get('MASTER_PORT', os.getpid())}")},
         "loss": {"lambda_sds": 1.0, "lambda_mat_reg": 1.0},
         "optimizer": {"name": "Adam", "args": {"lr": 0.01, "betas": [0.9, 0.99], "eps": 1e-15}},
     }
 
 
 def cpu_baseline(a, system, max_threads=None):
-    """The oracle (fp32 torch + C rasterizer) timed on this box's host cores on a bounded sample of the
-    SAME workload: 1 view of the render path fwd+bwd, 1 VAE encode fwd+bwd, 1 branch-item of
-    ControlNet+UNet; scaled to the full step (x views, x views, x 3*views)."""
+    """The oracle (fp32 torch + C rasterizer) timed on this box's host cores on a BOUNDED sample of the same
+    workload (~10-40 s of CPU work): everything at HALF resolution (256^2 image, 32^2 latents) for ONE view --
+    render fwd+bwd on the full 50k-triangle mesh and the full 16-level hash grid, VAE-encoder fwd+bwd, one
+    branch-item of ControlNet+UNet -- scaled x4 to 512^2 (convs/linears/field are linear in pixels; the S^2
+    self-attention part is under-counted, which favours the CPU) and to the full step (x views, x 3*views)."""
     import numpy as np
     from oracle import envlight as oenv, field as ofield, raster as oraster, render as orender, sd_nets as osd
     from oracle import camera as ocam
     cores = os.cpu_count()
     torch.set_num_threads(max_threads or cores)
-    H = W = a.res
+    H = W = a.res // 2
     mesh = system.geometry.mesh
     md = dict(v_pos=mesh.v_pos.cpu().numpy(), v_nrm=mesh.v_nrm.cpu().numpy(),
               t_pos_idx=mesh.t_pos_idx.cpu().numpy().astype(np.int32))
     md["opp"] = oraster.build_topology(md["t_pos_idx"])
     batch = ocam.camera_batch(torch.tensor([20.0]), torch.tensor([30.0]), torch.tensor([3.5]), torch.tensor([35.0]), H, W)
     batch["env_id"] = torch.tensor([0])
-    # small env (the prefilter is init-time work, not part of a step)
-    env = oenv.EnvLight(synthetic_latlong(0, 32, 64), scale=2.0, min_res=8, max_res=16)
+    env = oenv.EnvLight(synthetic_latlong(0, 32, 64), scale=2.0, min_res=8, max_res=16)   # prefilter = init-time work
     lv, tot = ofield.grid_levels()
     geo = system.geometry
     table = geo.encoding.encoding.params.detach().float().cpu().reshape(-1, 2).clone().requires_grad_()
@@ -122,10 +124,12 @@ def cpu_baseline(a, system, max_threads=None):
         d, m = osd.controlnet_forward(sd_c, lat, tt, ctx, cond, 1.0, arch.heads, arch.use_linear_projection)
         osd.unet_forward(sd_u, lat, tt, ctx, arch.heads, arch.use_linear_projection, d, m)
         t_nets = time.time() - t0
-    step_s = a.views * (t_render + t_vae) + 3 * a.views * t_nets
+    scale = (a.res / H) ** 2
+    step_s = scale * (a.views * (t_render + t_vae) + 3 * a.views * t_nets)
     return {"value": 1.0 / step_s, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle fp32 on host: 1 view render fwd+bwd {t_render:.2f}s, 1 VAE-enc fwd+bwd {t_vae:.2f}s, "
-                      f"1 branch-item ControlNet+UNet fwd {t_nets:.2f}s; step = {a.views}x(render+vae) + {3 * a.views}x nets",
+            "sample": f"oracle fp32 on host at {H}^2 (x{scale:.0f} to {a.res}^2): 1 view render fwd+bwd {t_render:.2f}s, "
+                      f"1 VAE-enc fwd+bwd {t_vae:.2f}s, 1 branch-item ControlNet+UNet fwd {t_nets:.2f}s; "
+                      f"step = {scale:.0f} x ({a.views} x (render+vae) + {3 * a.views} x nets)",
             "host_cpus": cores}
 
 

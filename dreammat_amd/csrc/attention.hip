@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
 
         // ---- S^T = K . Q^T
         f32x16 s[2];
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -139,6 +140,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
                 s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[t], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         // ---- mask the ragged tail (cross-attention: Skv = 77)
         if (kv0 + kKvTile > a.Skv) {
 #pragma unroll
@@ -155,9 +157,17 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float m_new = fmaxf(m_run, mx * a.scale_log2);
-        float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        mx = fmaxf(mx, __shfl_xor(mx, 32)) * a.scale_log2;
+        // deferred rescale: while no row of this wave outgrows its running max by more than 2^8 the
+        // accumulators keep their old scale (P <= 256, harmless for the fp32 accumulation and for bf16 P,
+        // whose relative precision does not depend on magnitude) and the O-wide multiply is skipped.
+        // The branch is wave-uniform; the previous tile's P.V is already complete at this point.
+        float m_new = m_run, alpha = 1.0f;
+        const bool rescale = !__all(mx <= m_run + 8.0f);
+        if (rescale) {
+            m_new = fmaxf(m_run, mx);
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        }
         float psum = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -167,12 +177,15 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
                 s[t][r] = p;
                 psum += p;
             }
-        l_run = l_run * alpha + psum;
+        if (rescale) {
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        }
+        l_run += psum;
         m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < DT; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
 
         // ---- P -> bf16 B-operand fragments (no data movement: accumulator order == k-slot order)
         bf16x8 pf[4];
@@ -188,6 +201,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
             }
         }
         // ---- O^T += V^T . P^T
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -196,6 +210,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[dt], 0, 0, 0);
             }
 
+        __builtin_amdgcn_s_setprio(0);
         if (j + 1 < n_tiles) write_tile(buf ^ 1);
         __syncthreads();
     }

@@ -173,8 +173,9 @@ class StableDiffusionLightGuidance(BaseObject):
             latent_model_input = torch.cat([latents_noisy] * 3, dim=0)
             t3 = torch.cat([t] * 3)
             if self.use_controlnet and not all(s == 0 for s in condition_scales):
-                cond3 = [torch.cat([c] * 3, dim=0) for c in image_cond]
-                down, mid = self.multi_control_forward(latent_model_input, t3, ctx, cond3, condition_scales)
+                # the reference relies on a [3]+[1] broadcast here (B=1 only); the ControlNet tiles the
+                # conditioning EMBEDDING over the three branches (branch-major, like torch.cat([x]*3))
+                down, mid = self.multi_control_forward(latent_model_input, t3, ctx, image_cond, condition_scales)
                 noise_pred = self.forward_unet(latent_model_input, t3, ctx, down, mid)
             else:
                 noise_pred = self.forward_unet(latent_model_input, t3, ctx)

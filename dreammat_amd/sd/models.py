@@ -212,7 +212,12 @@ class ControlNetModel(_Encoder):
         ctx = encoder_hidden_states if isinstance(encoder_hidden_states, PaddedContext) else PaddedContext(encoder_hidden_states)
         temb = self._temb(timestep, sample.dtype)
         x = self.conv_in(sample)
-        x = x + self.controlnet_cond_embedding(controlnet_cond)
+        emb = self.controlnet_cond_embedding(controlnet_cond)
+        if emb.shape[0] != x.shape[0]:
+            # the conditioning stem depends on the image only: embed the B views once and tile the result over
+            # the (text / negative / null) branches instead of embedding the same image three times
+            emb = emb.repeat(x.shape[0] // emb.shape[0], 1, 1, 1)
+        x = x + emb
         outs = [x]
         for blk in self.down_blocks:
             x, o = blk(x, temb, ctx)
