@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--sd", default="sd21-base", choices=["sd21-base", "sd15", "tiny"])
     ap.add_argument("--mesh", default="sphere:160:160")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-timeout", type=int, default=150)
     ap.add_argument("--env-res", type=int, default=128)
     return ap.parse_args()
 
@@ -73,6 +74,26 @@ def system_config(a, views_per_rank):
     }
 
 
+def effective_cores():
+    """CPU cores this process may actually use (affinity mask and cgroup quota), capped at 64: os.cpu_count()
+    reports the host's cores even inside a small container and oversubscribing torch's thread pool by 10x
+    makes the fp32 oracle crawl."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(a, system, max_threads=None):
     """The oracle (fp32 torch + C rasterizer) timed on this box's host cores on a BOUNDED sample of the same
     workload (~10-40 s of CPU work): everything at HALF resolution (256^2 image, 32^2 latents) for ONE view --
@@ -82,7 +103,7 @@ def cpu_baseline(a, system, max_threads=None):
     import numpy as np
     from oracle import envlight as oenv, field as ofield, raster as oraster, render as orender, sd_nets as osd
     from oracle import camera as ocam
-    cores = os.cpu_count()
+    cores = effective_cores()
     torch.set_num_threads(max_threads or cores)
     H = W = a.res // 2
     mesh = system.geometry.mesh
@@ -130,7 +151,7 @@ def cpu_baseline(a, system, max_threads=None):
             "sample": f"oracle fp32 on host at {H}^2 (x{scale:.0f} to {a.res}^2): 1 view render fwd+bwd {t_render:.2f}s, "
                       f"1 VAE-enc fwd+bwd {t_vae:.2f}s, 1 branch-item ControlNet+UNet fwd {t_nets:.2f}s; "
                       f"step = {scale:.0f} x ({a.views} x (render+vae) + {3 * a.views} x nets)",
-            "host_cpus": cores}
+            "host_cpus": os.cpu_count()}
 
 
 def main():
@@ -223,10 +244,19 @@ def main():
                            "frac": gbs / 8000.0, "traffic": None, "avg_us": r["avg_ms"] * 1e3,
                            "covered_pixels": r["work_per_launch"] / (56.0 if key == "shade_fwd" else 76.0)}
         if world == 1 and not a.no_cpu_baseline:
-            try:
+            import signal
+
+            def _alarm(signum, frame):
+                raise TimeoutError(f"cpu baseline exceeded {a.cpu_baseline_timeout}s on {effective_cores()} cores")
+            try:   # the baseline is reporting only: bounded, and never allowed to kill the bench line
+                signal.signal(signal.SIGALRM, _alarm)
+                signal.alarm(a.cpu_baseline_timeout)
                 res["cpu_baseline"] = cpu_baseline(a, system)
-            except Exception as e:   # the baseline is reporting only; never let it kill the bench line
-                res["cpu_baseline"] = {"value": None, "error": repr(e)}
+            except BaseException as e:
+                res["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": effective_cores(), "kind": "port",
+                                       "sample": "not completed", "error": repr(e)}
+            finally:
+                signal.alarm(0)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

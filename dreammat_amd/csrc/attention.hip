@@ -17,6 +17,9 @@
 //    per KV tile.
 //  * head_dim D <= DP (template: 64/96/128/160), D % 8 == 0: SD-2.1 (64) and SD-1.5 (40/80/160)
 //    shapes are both covered, the pad columns are zero-filled in registers, never in memory.
+#include <cstdlib>
+#include <cstring>
+
 #include "dm_common.h"
 
 namespace {
@@ -236,6 +239,235 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Variant 2 (DP = 64 or 128): K and V^T tiles travel HBM/L2 -> LDS by DMA (global_load_lds, 16 B per lane)
+// through a 3-stage ring with counted s_waitcnt vmcnt(L) + one raw s_barrier per KV tile, so two tiles of
+// loads are in flight behind the MFMAs and no VGPRs / ds_write instructions are spent on staging.
+// LDS rows are unpadded (DMA writes base + lane*16); the 16 B chunk index is XOR-swizzled with
+// (row>>1)&7 (128 B rows) or row&15 (256 B rows) -- on the per-lane SOURCE address on the way in and on
+// the ds_read address on the way out.  V^T keeps the natural kv order; the k-slot permutation of the
+// P.V product is folded into two 8-byte ds_reads per k-step instead.  Out-of-range rows / chunks read
+// a 16-byte zero page (the DMA must run with all lanes active).
+__device__ __attribute__((aligned(16))) unsigned int g_attn_zero_page[4] = {0, 0, 0, 0};
+
+template <int DP>
+__global__ __launch_bounds__(256) void k_attn_fwd_dma(AttnArgs a) {
+    static_assert(DP == 64 || DP == 128, "DMA variant: power-of-two row sizes only");
+    constexpr int KSTEPS = DP / 16, DT = DP / 32;
+    constexpr int KROW = DP * 2;                       // K row bytes
+    constexpr int VROW = kKvTile * 2;                  // V^T row bytes (128)
+    constexpr int KBYTES = kKvTile * KROW, VBYTES = DP * VROW, STAGE = KBYTES + VBYTES;
+    constexpr int KCH = KROW / 16;                     // chunks per K row: 8 or 16
+    constexpr int KRPI = 64 / KCH;                     // K rows per DMA instruction: 8 or 4
+    constexpr int K_INSTR = kKvTile / KRPI / 4;        // per wave: 2 or 4
+    constexpr int V_INSTR = DP / 8 / 4;                // per wave: 2 or 4
+    constexpr int L = K_INSTR + V_INSTR;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int bh = blockIdx.y, b = bh / a.Hh, h = bh - b * a.Hh;
+    const int q_row = blockIdx.x * (kWaves * kQRowsPerWave) + wave * kQRowsPerWave + l31;
+    const bool q_ok = q_row < a.Sq;
+    const int skv_pad8 = (a.Skv + 7) & ~7;
+    auto kswz = [](int r) { return KCH == 8 ? ((r >> 1) & 7) : (r & 15); };
+
+    bf16x8 qf[KSTEPS];
+    {
+        const __bf16* qp = a.q + (long long)b * a.q_bs + (long long)q_row * a.q_ss + (long long)h * a.q_hs;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            int d = 16 * kk + 8 * hi;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q_ok && d < a.D) v = ld16(qp + d);
+            qf[kk] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+    const __bf16* kp = a.k + (long long)b * a.k_bs + (long long)h * a.k_hs;
+    const __bf16* vp = a.vt + (long long)b * a.vt_bs + (long long)h * a.vt_hs;
+    const unsigned long long zero = (unsigned long long)g_attn_zero_page;
+
+    // per-lane constants of its DMA slots
+    int k_row[K_INSTR], k_col[K_INSTR];
+#pragma unroll
+    for (int i = 0; i < K_INSTR; ++i) {
+        int r = (wave * K_INSTR + i) * KRPI + lane / KCH;
+        k_row[i] = r;
+        k_col[i] = ((lane % KCH) ^ kswz(r)) * 8;       // source element offset that lands in this lane's slot
+    }
+    int v_row[V_INSTR], v_col[V_INSTR];
+#pragma unroll
+    for (int i = 0; i < V_INSTR; ++i) {
+        int d = (wave * V_INSTR + i) * 8 + (lane >> 3);
+        v_row[i] = d;
+        v_col[i] = ((lane & 7) ^ ((d >> 1) & 7)) * 8;
+    }
+    auto issue = [&](int kv0, int stage) {
+        char* kb = smem + stage * STAGE;
+        char* vb = kb + KBYTES;
+#pragma unroll
+        for (int i = 0; i < K_INSTR; ++i) {
+            int kv = kv0 + k_row[i];
+            bool ok = kv < a.Skv && k_col[i] < a.D;
+            int kvc = min(kv, a.Skv - 1);
+            int colc = min(k_col[i], a.D - 8);
+            unsigned long long real = (unsigned long long)(kp + (long long)kvc * a.k_ss + colc);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ok ? real : zero),
+                                             (__attribute__((address_space(3))) void*)(kb + (wave * K_INSTR + i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < V_INSTR; ++i) {
+            int kvc0 = kv0 + v_col[i];
+            bool ok = v_row[i] < a.D && kvc0 < skv_pad8;
+            int dc = min(v_row[i], a.D - 1);
+            int kc = min(kvc0, skv_pad8 - 8);
+            unsigned long long real = (unsigned long long)(vp + (long long)dc * a.vt_ds + kc);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ok ? real : zero),
+                                             (__attribute__((address_space(3))) void*)(vb + (wave * V_INSTR + i) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int n_tiles = (a.Skv + kKvTile - 1) / kKvTile;
+    issue(0, 0);
+    if (n_tiles > 1) issue(kKvTile, 1);
+    int stage = 0;
+    for (int j = 0; j < n_tiles; ++j) {
+        const int kv0 = j * kKvTile;
+        if (j + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int st2 = stage + 2; if (st2 >= 3) st2 -= 3;
+        if (j + 2 < n_tiles) issue(kv0 + 2 * kKvTile, st2);
+        const char* kb = smem + stage * STAGE;
+        const char* vb = kb + KBYTES;
+
+        f32x16 s[2];
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+            const int row = 32 * t + l31;
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + row * KROW + (((2 * kk + hi) ^ kswz(row)) << 4));
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[t], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (kv0 + kKvTile > a.Skv) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int kv = kv0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (kv >= a.Skv) s[t][r] = -INFINITY;
+                }
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32)) * a.scale_log2;
+        float m_new = m_run, alpha = 1.0f;
+        const bool rescale = !__all(mx <= m_run + 8.0f);
+        if (rescale) {
+            m_new = fmaxf(m_run, mx);
+            alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        }
+        float psum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = __builtin_amdgcn_exp2f(s[t][r] * a.scale_log2 - m_new);
+                s[t][r] = p;
+                psum += p;
+            }
+        if (rescale) {
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        }
+        l_run += psum;
+        m_run = m_new;
+
+        bf16x8 pf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int t = ks >> 1, u = ks & 1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f32x2 two = {s[t][8 * u + 2 * e], s[t][8 * u + 2 * e + 1]};
+                bf16x2 pk = __builtin_convertvector(two, bf16x2);
+                pf[ks][2 * e] = pk[0];
+                pf[ks][2 * e + 1] = pk[1];
+            }
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int row = 32 * dt + l31;
+            const char* rb = vb + row * VROW + 8 * hi;
+            const int sw = (row >> 1) & 7;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                // k-slots (hi, j') <-> kv 16ks + (j'&3) + 8(j'>>2) + 4hi: two 8-byte pieces of chunks 2ks and 2ks+1
+                uint2 lo = *reinterpret_cast<const uint2*>(rb + (((2 * ks) ^ sw) << 4));
+                uint2 hi2 = *reinterpret_cast<const uint2*>(rb + (((2 * ks + 1) ^ sw) << 4));
+                uint4 both = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), pf[ks], o[dt], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        stage = stage + 1; if (stage >= 3) stage = 0;
+    }
+
+    float l_tot = l_run + __shfl_xor(l_run, 32);
+    float inv = 1.0f / l_tot;
+    if (q_ok) {
+        __bf16* op = a.out + (long long)b * a.o_bs + (long long)q_row * a.o_ss + (long long)h * a.o_hs;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int d = 32 * dt + 8 * g + 4 * hi;
+                if (d < a.D) {
+                    f32x2 x0 = {o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv};
+                    f32x2 x1 = {o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
+                    bf16x2 y0 = __builtin_convertvector(x0, bf16x2), y1 = __builtin_convertvector(x1, bf16x2);
+                    bf16x4 y = {y0[0], y0[1], y1[0], y1[1]};
+                    *reinterpret_cast<bf16x4*>(op + d) = y;
+                }
+            }
+    }
+}
+
+template <int DP>
+int launch_attn_dma(const AttnArgs& a, hipStream_t stream) {
+    constexpr int LDS = 3 * (kKvTile * DP * 2 + DP * kKvTile * 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_fwd_dma<DP>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid(dm_div_up(a.Sq, kWaves * kQRowsPerWave), a.B * a.Hh);
+    DM_ENTER();
+    hipLaunchKernelGGL(k_attn_fwd_dma<DP>, grid, dim3(256), LDS, stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DM_OK : (int)e;
+}
+
 template <int DP>
 int launch_attn(const AttnArgs& a, hipStream_t stream) {
     constexpr int KROW = DP * 2 + 16, VROW = kKvTile * 2 + 16;
@@ -280,9 +512,11 @@ int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* ou
     a.vt_bs = vt_bs; a.vt_hs = vt_hs; a.vt_ds = vt_ds; a.o_bs = o_bs; a.o_ss = o_ss; a.o_hs = o_hs;
     a.B = B; a.Hh = Hh; a.Sq = Sq; a.Skv = Skv; a.D = D;
     a.scale_log2 = scale * 1.4426950408889634f;
-    if (D <= 64) return launch_attn<64>(a, stream);
+    // DREAMMAT_ATTN_KERNEL=staged selects the register-staged variant everywhere (A/B measurements)
+    static const bool use_dma = !(getenv("DREAMMAT_ATTN_KERNEL") && !strcmp(getenv("DREAMMAT_ATTN_KERNEL"), "staged"));
+    if (D <= 64) return use_dma ? launch_attn_dma<64>(a, stream) : launch_attn<64>(a, stream);
     if (D <= 96) return launch_attn<96>(a, stream);
-    if (D <= 128) return launch_attn<128>(a, stream);
+    if (D <= 128) return use_dma ? launch_attn_dma<128>(a, stream) : launch_attn<128>(a, stream);
     return launch_attn<160>(a, stream);
 }
 
