@@ -182,32 +182,45 @@ __global__ __launch_bounds__(256) void k_conv3x3(ConvArgs a, long long n_mt, int
 //  * counted s_waitcnt vmcnt(L) + raw s_barrier: one barrier per K-step, loads span the barrier.
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0, 0, 0, 0};
 
-template <int BN>
-__global__ __launch_bounds__(256) void k_conv3x3_dma(ConvArgs a, long long n_mt, int n_nt) {
+template <int BMT, int BN>
+__global__ __launch_bounds__(BMT * 2) void k_conv3x3_dma(ConvArgs a, long long n_mt, int n_nt) {
+    // BMT x BN x 64 tile; BMT/32 waves as (BMT/64) x 2, each wave a 64 x BN/2 sub-tile.
+    // 128 x {64,128}: 4 waves, 2-5 workgroups per CU.  256 x 128: 8 waves, one workgroup per CU, twice the
+    // FLOP per byte pulled through L2 (the 128-row tiles are L2-bandwidth bound: ~13 TB/s at 570 TF/s).
     constexpr int BK = 64;
     constexpr int ROWB = 128;                          // bytes per tile row (64 bf16), unpadded
-    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int NW = BMT / 32;                       // waves
+    constexpr int A_BYTES = BMT * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
     constexpr int NT = BN / 64;
-    constexpr int A_INSTR = BM / 8 / 4;                // wave-instructions (8 rows each) per wave: 4
-    constexpr int B_INSTR = BN / 8 / 4;                // 4 (BN=128) or 2 (BN=64)
+    constexpr int A_INSTR = BMT / 8 / NW;              // wave-instructions (8 rows each) per wave: 4
+    constexpr int B_INSTR = BN / 8 / NW;               // 4 / 2 (128-row tile), 2 (256-row tile)
     constexpr int L = A_INSTR + B_INSTR;               // DMA instructions per wave per tile
     extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 * STAGE
 
     long long mt; int nt;
-    if (!tile_of_block(n_mt, n_nt, mt, nt)) return;
+    {
+        const long long total = n_mt * n_nt;
+        const long long lin = (long long)blockIdx.x;
+        const long long per_xcd = (total + 7) / 8;
+        const long long id = (lin & 7) * per_xcd + (lin >> 3);
+        if ((lin >> 3) >= per_xcd || id >= total) return;
+        mt = id / n_nt;
+        nt = (int)(id - mt * n_nt);
+    }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
-    const long long m0 = mt * BM;
+    const long long m0 = mt * BMT;
     const int n0 = nt * BN;
     const int lrow = lane >> 3, lslot = lane & 7;      // this lane's row / 16 B slot inside one DMA instruction
+    const unsigned long long zero = (unsigned long long)g_zero_page;
 
-    // A rows of this lane: wave*32 + 8*i + lrow
+    // A rows of this lane: wave*(BMT/NW) + 8*i + lrow
     int a_b[A_INSTR], a_y[A_INSTR], a_x[A_INSTR];
     bool a_ok[A_INSTR];
     int a_chunk[A_INSTR];
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i) {
-        int row = wave * (BM / 4) + 8 * i + lrow;
+        int row = wave * (BMT / NW) + 8 * i + lrow;
         long long m = m0 + row;
         a_ok[i] = m < a.M;
         long long mm = a_ok[i] ? m : 0;
@@ -219,11 +232,14 @@ __global__ __launch_bounds__(256) void k_conv3x3_dma(ConvArgs a, long long n_mt,
         a_x[i] = (rem - yo * a.Wout) * a.stride - a.pad_x;
         a_chunk[i] = lslot ^ ((row >> 1) & 7);         // source chunk that must land in slot lslot
     }
-    const __bf16* b_src[B_INSTR];
+    unsigned long long b_src[B_INSTR];
+    bool b_ok[B_INSTR];
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) {
-        int row = wave * (BN / 4) + 8 * i + lrow;
-        b_src[i] = a.w + (long long)(n0 + row) * 9LL * a.Cin + (lslot ^ ((row >> 1) & 7)) * 8;
+        int row = wave * (BN / NW) + 8 * i + lrow;
+        b_ok[i] = n0 + row < a.Cout;                   // ragged last Cout tile (e.g. 320 = 2.5 x 128)
+        int rc = min(n0 + row, a.Cout - 1);
+        b_src[i] = (unsigned long long)(a.w + (long long)rc * 9LL * a.Cin + (lslot ^ ((row >> 1) & 7)) * 8);
     }
     const int kt_per_tap = a.Cin / BK;
     const int n_steps = 9 * kt_per_tap;
@@ -240,17 +256,17 @@ __global__ __launch_bounds__(256) void k_conv3x3_dma(ConvArgs a, long long n_mt,
             bool inb = a_ok[i] && (unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)a.Win;
             int yc = min(max(yy, 0), a.Hin - 1), xc = min(max(xx, 0), a.Win - 1);   // always a legal address
             unsigned long long real = (unsigned long long)(a.x + (((long long)a_b[i] * a.Hin + yc) * a.Win + xc) * a.Cin + c0 + a_chunk[i] * 8);
-            unsigned long long zero = (unsigned long long)g_zero_page;
             const void* src = (const void*)(inb ? real : zero);                      // select, never a branch:
             // the DMA must execute with ALL lanes active (an inactive lane would leave its LDS slot stale)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(ab + (wave * (BM / 4) + 8 * i) * ROWB),
+                                             (__attribute__((address_space(3))) void*)(ab + (wave * (BMT / NW) + 8 * i) * ROWB),
                                              16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + (long long)s * BK),
-                                             (__attribute__((address_space(3))) void*)(bb + (wave * (BN / 4) + 8 * i) * ROWB),
+            const void* src = (const void*)(b_ok[i] ? b_src[i] + (unsigned long long)s * BK * 2 : zero);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(bb + (wave * (BN / NW) + 8 * i) * ROWB),
                                              16, 0, 0);
         }
     };
@@ -299,6 +315,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_dma(ConvArgs a, long long n_mt,
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         int n = n0 + (BN / 2) * wn + 32 * j + l31;
+        if (n >= a.Cout) continue;
         float bv = a.bias ? (float)a.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -310,22 +327,22 @@ __global__ __launch_bounds__(256) void k_conv3x3_dma(ConvArgs a, long long n_mt,
     }
 }
 
-template <int BN>
+template <int BMT, int BN>
 int launch_conv_dma(const ConvArgs& a, hipStream_t stream) {
-    constexpr int LDS = 3 * (BM + BN) * 128;
+    constexpr int LDS = 3 * (BMT + BN) * 128;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_dma<BN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_dma<BMT, BN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    long long n_mt = (a.M + BM - 1) / BM;
-    int n_nt = a.Cout / BN;
+    long long n_mt = (a.M + BMT - 1) / BMT;
+    int n_nt = (a.Cout + BN - 1) / BN;
     long long blocks = ((n_mt * n_nt + 7) / 8) * 8;
     if (blocks > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
     DM_ENTER();
-    hipLaunchKernelGGL((k_conv3x3_dma<BN>), dim3((unsigned)blocks), dim3(256), LDS, stream, a, n_mt, n_nt);
+    hipLaunchKernelGGL((k_conv3x3_dma<BMT, BN>), dim3((unsigned)blocks), dim3(BMT * 2), LDS, stream, a, n_mt, n_nt);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? DM_OK : (int)e;
 }
@@ -370,8 +387,15 @@ int dm_conv3x3_nhwc_bf16(const void* x, const void* w, const void* bias, void* y
     a.M = (long long)B * Hout * Wout;
     // DREAMMAT_CONV_KERNEL=staged selects the register-staged variant everywhere (A/B measurements)
     static const bool use_dma = !(getenv("DREAMMAT_CONV_KERNEL") && !strcmp(getenv("DREAMMAT_CONV_KERNEL"), "staged"));
-    if (use_dma && Cin % 64 == 0)
-        return (Cout % 128 == 0) ? launch_conv_dma<128>(a, stream) : launch_conv_dma<64>(a, stream);
+    if (use_dma && Cin % 64 == 0) {
+        // 256 x 128 tiles (8 waves, 1 workgroup per CU) win on every measured UNet / ControlNet / VAE shape
+        // (profiles/r01_kernel_bench_v4.json: 624-793 TF/s vs 502-598) -- used unless the problem is tiny;
+        // DREAMMAT_CONV_TILE=128|256 forces a choice (tests / A-B measurements)
+        const char* tile_env = getenv("DREAMMAT_CONV_TILE");   // read per call: tests toggle it
+        bool big = tile_env ? !strcmp(tile_env, "256") : (Cout >= 128 && a.M >= 2048);
+        if (big) return launch_conv_dma<256, 128>(a, stream);
+        return (Cout % 128 == 0) ? launch_conv_dma<128, 128>(a, stream) : launch_conv_dma<128, 64>(a, stream);
+    }
     if (Cout % 128 == 0) return (Cin % 64 == 0) ? launch_conv<128, 64>(a, stream) : launch_conv<128, 32>(a, stream);
     return (Cin % 64 == 0) ? launch_conv<64, 64>(a, stream) : launch_conv<64, 32>(a, stream);
 }

@@ -52,22 +52,31 @@ DM_HD int cube_index(F3 d, float& u, float& v) {
     return face;
 }
 
-// bilinear fetch from one padded cube mip
-DM_HD F3 cube_bilinear(const float4* __restrict__ tex, int R, F3 d) {
-    float u, v;
-    int face = cube_index(d, u, v);
-    float x = u * (float)R - 0.5f, y = v * (float)R - 0.5f;
+// Cube lookup split in two so that the (branchy) direction -> face/uv step is shared by the two mip
+// levels of the specular fetch.  All texel indexing is 32-bit (an atlas is far below 2^31 texels).
+struct CubeCoord { int face; float u, v; };
+
+DM_HD CubeCoord cube_coord(F3 d) {
+    CubeCoord c;
+    c.face = cube_index(d, c.u, c.v);
+    return c;
+}
+
+// bilinear fetch from one padded cube mip (texel (ix,iy) of face f at ((f*(R+2) + iy+1)*(R+2) + ix+1))
+DM_HD F3 cube_fetch(const float4* __restrict__ tex, int R, CubeCoord cc) {
+    float x = cc.u * (float)R - 0.5f, y = cc.v * (float)R - 0.5f;
     float x0 = floorf(x), y0 = floorf(y);
     float fx = x - x0, fy = y - y0;
-    int ix = (int)x0 + 1, iy = (int)y0 + 1;       // +1: border
     int P = R + 2;
-    const float4* base = tex + ((size_t)face * P + iy) * P + ix;
-    float4 t00 = base[0], t10 = base[1], t01 = base[P], t11 = base[P + 1];
+    int idx = (cc.face * P + (int)y0 + 1) * P + (int)x0 + 1;       // +1: border
+    float4 t00 = tex[idx], t10 = tex[idx + 1], t01 = tex[idx + P], t11 = tex[idx + P + 1];
     float w00 = (1.f - fx) * (1.f - fy), w10 = fx * (1.f - fy), w01 = (1.f - fx) * fy, w11 = fx * fy;
     return f3(t00.x * w00 + t10.x * w10 + t01.x * w01 + t11.x * w11,
               t00.y * w00 + t10.y * w10 + t01.y * w01 + t11.y * w11,
               t00.z * w00 + t10.z * w10 + t01.z * w01 + t11.z * w11);
 }
+
+DM_HD F3 cube_bilinear(const float4* __restrict__ tex, int R, F3 d) { return cube_fetch(tex, R, cube_coord(d)); }
 
 // envlight.get_mip: roughness -> (fractional) mip level, and d level / d roughness
 DM_HD float mip_level(const EnvAtlas& A, float rough, float& dlevel) {
@@ -143,8 +152,9 @@ DM_HD void shade_eval(const EnvAtlas& A, const MatCfg& M, int env, F3 n, F3 v, c
         int l1 = min(l0 + 1, A.n_mips - 1);
         float f = level - (float)l0;
         const float4* envb = A.spec + (size_t)env * A.spec_env_stride;
-        F3 s0 = cube_bilinear(envb + A.mip_off[l0], A.mip_res[l0], refl);
-        F3 s1 = (l1 != l0) ? cube_bilinear(envb + A.mip_off[l1], A.mip_res[l1], refl) : s0;
+        CubeCoord rc = cube_coord(refl);
+        F3 s0 = cube_fetch(envb + A.mip_off[l0], A.mip_res[l0], rc);
+        F3 s1 = (l1 != l0) ? cube_fetch(envb + A.mip_off[l1], A.mip_res[l1], rc) : s0;
         c.spec = s0 * (1.f - f) + s1 * f;
         c.dspec_dlevel = s1 - s0;
     }

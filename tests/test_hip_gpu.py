@@ -517,3 +517,19 @@ def test_groupnorm_silu_nhwc_vs_fp32_reference(dev, B, C, H, W, act):
     ref.backward(dy.float())
     gerr = (xg.grad.permute(0, 3, 1, 2).float().cpu() - xr.grad).abs().max().item()
     assert gerr < 3e-2 * max(1.0, xr.grad.abs().max().item()), gerr
+
+
+@pytest.mark.parametrize("tile", ["128", "256"])
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 320, 320, 32, 32), (1, 128, 128, 40, 24), (3, 64, 192, 16, 16)])
+def test_conv3x3_dma_tile_variants(dev, monkeypatch, tile, B, Cin, Cout, H, W):
+    """both tile shapes of the LDS-DMA conv kernel (incl. the ragged last Cout tile: 320 = 2.5 x 128, 192 = 1.5 x 128)."""
+    monkeypatch.setenv("DREAMMAT_CONV_TILE", tile)
+    torch.manual_seed(1)
+    x = torch.randn(B, H, W, Cin).bfloat16()
+    w = (torch.randn(Cout, Cin, 3, 3) * 0.05).bfloat16()
+    bias = torch.randn(Cout).bfloat16()
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    y = hipops.conv3x3_nhwc(x.to(dev), wt.to(dev), bias.to(dev)).float().cpu()
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias.float(), padding=1).permute(0, 2, 3, 1)
+    err = (y - ref).abs().max().item()
+    assert err < 2e-2 * ref.abs().max().item() + 1e-2, err
