@@ -163,8 +163,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("DREAMMAT_FORCE_DIST"))   # FORCE_DIST: exercise RCCL at world 1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     assert a.views % world == 0, "views must divide over ranks"
     vpr = a.views // world
@@ -192,7 +196,7 @@ def main():
     torch.cuda.synchronize()
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -206,7 +210,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     hipops.enable_kernel_timing(False)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -267,7 +271,7 @@ def main():
             finally:
                 signal.alarm(0)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -34,49 +34,84 @@ struct ShadeArgs {
     StridedOut dfeat;
 };
 
-__global__ __launch_bounds__(256) void k_shade_fwd(ShadeArgs a) {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= *a.n_dev) return;
-    F3 n = f3(a.nrm.p[i * a.nrm.rs], a.nrm.p[i * a.nrm.rs + a.nrm.cs], a.nrm.p[i * a.nrm.rs + 2 * a.nrm.cs]);
-    F3 v = f3(a.view.p[i * a.view.rs], a.view.p[i * a.view.rs + a.view.cs], a.view.p[i * a.view.rs + 2 * a.view.cs]);
+// Both kernels are persistent grid-stride loops with a one-pixel software prefetch: the 11 input floats
+// (+ pixel index) of the NEXT pixel are requested before the current pixel's ~600 VALU instructions and 16
+// texel gathers run.  A one-thread-per-pixel launch has all waves streaming inputs, then all computing, then
+// all gathering at the same time (measured: runtime ~ sum of the three phases); the prefetch overlaps them.
+struct ShadeIn {
+    F3 n, v;
     float f[5];
+    F3 dc;
+    int pix;
+};
+
+template <bool BWD>
+__device__ __forceinline__ void shade_load(const ShadeArgs& a, long long i, ShadeIn& in) {
+    in.n = f3(a.nrm.p[i * a.nrm.rs], a.nrm.p[i * a.nrm.rs + a.nrm.cs], a.nrm.p[i * a.nrm.rs + 2 * a.nrm.cs]);
+    in.v = f3(a.view.p[i * a.view.rs], a.view.p[i * a.view.rs + a.view.cs], a.view.p[i * a.view.rs + 2 * a.view.cs]);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) f[k] = a.feat.p[i * a.feat.rs + k * a.feat.cs];
-    int env = a.env_of_view[a.pix_idx[i] / a.HW];
-    ShadeCtx c;
-    shade_eval(a.atlas, a.mat, env, n, v, f, c);
-    a.color.p[i * a.color.rs] = sat(c.pre.x);
-    a.color.p[i * a.color.rs + a.color.cs] = sat(c.pre.y);
-    a.color.p[i * a.color.rs + 2 * a.color.cs] = sat(c.pre.z);
-    if (a.albedo) {
-        F3 sl = lin2srgb(c.spec), dl = lin2srgb(c.diff), sc = lin2srgb(c.spec_albedo), dc = lin2srgb(c.albedo);
-        a.albedo[3 * i] = c.albedo.x; a.albedo[3 * i + 1] = c.albedo.y; a.albedo[3 * i + 2] = c.albedo.z;
-        a.spec_light[3 * i] = sl.x; a.spec_light[3 * i + 1] = sl.y; a.spec_light[3 * i + 2] = sl.z;
-        a.diff_light[3 * i] = dl.x; a.diff_light[3 * i + 1] = dl.y; a.diff_light[3 * i + 2] = dl.z;
-        a.spec_color[3 * i] = sc.x; a.spec_color[3 * i + 1] = sc.y; a.spec_color[3 * i + 2] = sc.z;
-        a.diff_color[3 * i] = dc.x; a.diff_color[3 * i + 1] = dc.y; a.diff_color[3 * i + 2] = dc.z;
-        a.metallic[i] = c.metallic;
-        a.roughness[i] = c.roughness;
+    for (int k = 0; k < 5; ++k) in.f[k] = a.feat.p[i * a.feat.rs + k * a.feat.cs];
+    if (BWD)
+        in.dc = f3(a.dcolor.p[i * a.dcolor.rs], a.dcolor.p[i * a.dcolor.rs + a.dcolor.cs],
+                   a.dcolor.p[i * a.dcolor.rs + 2 * a.dcolor.cs]);
+    in.pix = a.pix_idx[i];
+}
+
+__global__ __launch_bounds__(256) void k_shade_fwd(ShadeArgs a) {
+    const long long N = *a.n_dev;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    ShadeIn cur, nxt;
+    shade_load<false>(a, i, cur);
+    for (; i < N; i += stride) {
+        const bool more = i + stride < N;
+        if (more) shade_load<false>(a, i + stride, nxt);
+        int env = a.env_of_view[cur.pix / a.HW];
+        ShadeCtx c;
+        shade_eval(a.atlas, a.mat, env, cur.n, cur.v, cur.f, c);
+        a.color.p[i * a.color.rs] = sat(c.pre.x);
+        a.color.p[i * a.color.rs + a.color.cs] = sat(c.pre.y);
+        a.color.p[i * a.color.rs + 2 * a.color.cs] = sat(c.pre.z);
+        if (a.albedo) {
+            F3 sl = lin2srgb(c.spec), dl = lin2srgb(c.diff), sc = lin2srgb(c.spec_albedo), dc = lin2srgb(c.albedo);
+            a.albedo[3 * i] = c.albedo.x; a.albedo[3 * i + 1] = c.albedo.y; a.albedo[3 * i + 2] = c.albedo.z;
+            a.spec_light[3 * i] = sl.x; a.spec_light[3 * i + 1] = sl.y; a.spec_light[3 * i + 2] = sl.z;
+            a.diff_light[3 * i] = dl.x; a.diff_light[3 * i + 1] = dl.y; a.diff_light[3 * i + 2] = dl.z;
+            a.spec_color[3 * i] = sc.x; a.spec_color[3 * i + 1] = sc.y; a.spec_color[3 * i + 2] = sc.z;
+            a.diff_color[3 * i] = dc.x; a.diff_color[3 * i + 1] = dc.y; a.diff_color[3 * i + 2] = dc.z;
+            a.metallic[i] = c.metallic;
+            a.roughness[i] = c.roughness;
+        }
+        if (more) cur = nxt;
     }
 }
 
 __global__ __launch_bounds__(256) void k_shade_bwd(ShadeArgs a) {
+    const long long N = *a.n_dev;
+    const long long stride = (long long)gridDim.x * blockDim.x;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= *a.n_dev) return;
-    F3 n = f3(a.nrm.p[i * a.nrm.rs], a.nrm.p[i * a.nrm.rs + a.nrm.cs], a.nrm.p[i * a.nrm.rs + 2 * a.nrm.cs]);
-    F3 v = f3(a.view.p[i * a.view.rs], a.view.p[i * a.view.rs + a.view.cs], a.view.p[i * a.view.rs + 2 * a.view.cs]);
-    float f[5];
+    if (i >= N) return;
+    ShadeIn cur, nxt;
+    shade_load<true>(a, i, cur);
+    for (; i < N; i += stride) {
+        const bool more = i + stride < N;
+        if (more) shade_load<true>(a, i + stride, nxt);
+        int env = a.env_of_view[cur.pix / a.HW];
+        ShadeCtx c;
+        shade_eval(a.atlas, a.mat, env, cur.n, cur.v, cur.f, c);
+        float df[5];
+        shade_backward(a.mat, c, cur.dc, df);
 #pragma unroll
-    for (int k = 0; k < 5; ++k) f[k] = a.feat.p[i * a.feat.rs + k * a.feat.cs];
-    F3 dc = f3(a.dcolor.p[i * a.dcolor.rs], a.dcolor.p[i * a.dcolor.rs + a.dcolor.cs],
-               a.dcolor.p[i * a.dcolor.rs + 2 * a.dcolor.cs]);
-    int env = a.env_of_view[a.pix_idx[i] / a.HW];
-    ShadeCtx c;
-    shade_eval(a.atlas, a.mat, env, n, v, f, c);
-    float df[5];
-    shade_backward(a.mat, c, dc, df);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) a.dfeat.p[i * a.dfeat.rs + k * a.dfeat.cs] = df[k];
+        for (int k = 0; k < 5; ++k) a.dfeat.p[i * a.dfeat.rs + k * a.dfeat.cs] = df[k];
+        if (more) cur = nxt;
+    }
+}
+
+// persistent launch: enough workgroups to fill every CU at the kernels' occupancy, never more than needed
+static inline int shade_blocks(long long n_max) {
+    long long need = (n_max + 255) / 256;
+    return (int)std::min<long long>(need, 256 * 4);   // 106-108 VGPRs -> 4 waves per SIMD = 4 workgroups per CU
 }
 
 // Material smoothness regulariser (dreammat_material.py:110-123) fused: forward partial sums and
@@ -172,7 +207,7 @@ int dm_shade_fwd(const dm_env_atlas* atlas, const dm_mat_cfg* mat, const float* 
     a.spec_color = dbg_spec_color; a.diff_color = dbg_diff_color; a.metallic = dbg_metallic;
     a.roughness = dbg_roughness;
     DM_ENTER();
-    hipLaunchKernelGGL(k_shade_fwd, dim3(dm_div_up(n_max, 256)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(k_shade_fwd, dim3(shade_blocks(n_max)), dim3(256), 0, stream, a);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
@@ -192,7 +227,7 @@ int dm_shade_bwd(const dm_env_atlas* atlas, const dm_mat_cfg* mat, const float* 
     a.dcolor = {dcolor, dcolor_rs, dcolor_cs};
     a.dfeat = {dfeat, dfeat_rs, dfeat_cs};
     DM_ENTER();
-    hipLaunchKernelGGL(k_shade_bwd, dim3(dm_div_up(n_max, 256)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(k_shade_bwd, dim3(shade_blocks(n_max)), dim3(256), 0, stream, a);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }

@@ -47,7 +47,7 @@ class FlatParams:
 def allreduce_sum_(flat_grad):
     """The step's only data-path collective: SUM over ranks of the flat gradient (mean is folded into
     the Adam kernel as grad_scale = 1/world)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
         return dist.get_world_size()
     return 1
