@@ -230,9 +230,10 @@ class _ScatterRows(torch.autograd.Function):
         _need_cuda(rows, pix_idx, dense_init)
         C = rows.shape[1]
         out = dense_init.clone()
-        rs, cs = _rs_cs(rows)
-        check(_lib.lib().dm_scatter_rows(pix_idx.data_ptr(), n_dev.data_ptr(), max(rows.shape[0], 1), rows.data_ptr(),
-                                         rs, cs, C, out.data_ptr(), _stream()), "dm_scatter_rows")
+        if rows.shape[0] > 0:                        # nothing covered (all views empty): the init IS the result
+            rs, cs = _rs_cs(rows)
+            check(_lib.lib().dm_scatter_rows(pix_idx.data_ptr(), n_dev.data_ptr(), rows.shape[0], rows.data_ptr(),
+                                             rs, cs, C, out.data_ptr(), _stream()), "dm_scatter_rows")
         ctx.save_for_backward(pix_idx, n_dev)
         ctx.n = rows.shape[0]
         return out
@@ -243,8 +244,9 @@ class _ScatterRows(torch.autograd.Function):
         g = _f32c(g)
         C = g.shape[-1]
         d = torch.empty(C, ctx.n, device=g.device)     # SoA
-        check(_lib.lib().dm_gather_rows(pix_idx.data_ptr(), n_dev.data_ptr(), max(ctx.n, 1), g.data_ptr(), C,
-                                        d.data_ptr(), 1, ctx.n, _stream()), "dm_gather_rows")
+        if ctx.n > 0:
+            check(_lib.lib().dm_gather_rows(pix_idx.data_ptr(), n_dev.data_ptr(), ctx.n, g.data_ptr(), C,
+                                            d.data_ptr(), 1, ctx.n, _stream()), "dm_gather_rows")
         return d.t(), None, None, None
 
 

@@ -533,3 +533,78 @@ def test_conv3x3_dma_tile_variants(dev, monkeypatch, tile, B, Cin, Cout, H, W):
     ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias.float(), padding=1).permute(0, 2, 3, 1)
     err = (y - ref).abs().max().item()
     assert err < 2e-2 * ref.abs().max().item() + 1e-2, err
+
+
+def test_raster_edge_cases_bit_exact(dev):
+    """object partly off-screen, behind the camera (discarded), degenerate and sub-pixel triangles, and a
+    camera that sees nothing (empty coverage) -- ids/barycentrics stay bit-identical to the oracle."""
+    m = pmesh.displaced_sphere(32, 24)
+    md = util.mesh_dict(m)
+    H = W = 96
+    # view 0: very close (object larger than the frame, some vertices behind the near plane / camera)
+    # view 1: looking away (nothing visible)   view 2: far away (sub-pixel triangles)
+    b0 = camera.camera_batch(torch.tensor([10.0, 0.0, 25.0]), torch.tensor([30.0, 0.0, -60.0]),
+                             torch.tensor([0.9, 3.0, 40.0]), torch.tensor([60.0, 30.0, 25.0]), H, W)
+    mvp = b0["mvp_mtx"].clone()
+    flip = torch.eye(4); flip[2, 2] = -1; flip[0, 0] = -1
+    mvp[1] = mvp[1] @ torch.diag(torch.tensor([1.0, 1.0, 1.0, 1.0]))
+    c2w = b0["c2w"][1].clone(); c2w[:3, 0] *= -1; c2w[:3, 2] *= -1          # turn the camera around
+    proj = camera.get_projection_matrix(b0["fovy"][1:2], 1.0, 0.1, 1000.0)
+    mvp[1] = camera.get_mvp_matrix(c2w[None], proj)[0][0]
+    v = torch.cat([m.v_pos, m.v_pos[:3] * 0 + m.v_pos[:1]])                 # 3 coincident vertices
+    tri = torch.cat([m.t_pos_idx, torch.tensor([[v.shape[0] - 3, v.shape[0] - 2, v.shape[0] - 1], [0, 0, 1]], dtype=torch.int32)])
+    pos_o = oraster.vertex_transform(v.numpy(), mvp).numpy()
+    ro = oraster.rasterize(pos_o, tri.numpy().astype(np.int32), H, W)
+    pos = hipops.vertex_transform(v.to(dev), mvp.to(dev))
+    rg = hipops.RasterContext(dev).rasterize(pos, tri.to(dev).int().contiguous(), H, W, check_overflow=True).cpu().numpy()
+    assert np.array_equal(rg.view(np.uint32), ro.view(np.uint32))
+    cov = (ro[..., 3] > 0).reshape(3, -1).mean(1)
+    assert cov[1] == 0.0 and cov[0] > 0.3 and 0 < cov[2] < 0.01, cov
+
+
+def test_raster_full_size_1024_and_bin_overflow_retry(dev):
+    """BASELINE config 5 size (1024^2) on the 50k mesh, and the workspace-overflow detection + retry path."""
+    m = pmesh.displaced_sphere(160, 160)
+    md = util.mesh_dict(m)
+    batch = util.make_views(2, 1024, 1024, seed=4)
+    tri = m.t_pos_idx.to(dev).int().contiguous()
+    pos = hipops.vertex_transform(m.v_pos.to(dev), batch["mvp_mtx"].to(dev))
+    ctx = hipops.RasterContext(dev)
+    ctx.ws = torch.empty(256 + 3 * 2 * 128 * 128 * 4 + 4096 * 4, dtype=torch.uint8, device=dev)   # far too small
+    ctx._workspace = lambda B, Nf, H, W, _o=ctx._workspace: (ctx.ws if ctx.ws is not None else _o(B, Nf, H, W))
+    rast = ctx.rasterize(pos, tri, 1024, 1024, check_overflow=True)           # first try overflows, retry succeeds
+    assert ctx.ws_mult >= 2
+    ro = oraster.rasterize(pos.cpu().numpy(), md["t_pos_idx"], 1024, 1024)
+    assert np.array_equal(rast.cpu().numpy().view(np.uint32), ro.view(np.uint32))
+
+
+def test_renderer_empty_view_and_determinism(dev, envs):
+    """a batch containing a view that sees nothing still renders (white background, zero opacity) and the
+    forward pass is deterministic (no atomics on the forward path)."""
+    from dreammat_amd.geometry import DreamMatMesh
+    from dreammat_amd.material import DreamMatMaterial
+    from dreammat_amd.renderer import RaytraceRender
+    from dreammat_amd.background import SolidColorBackground
+    lat, fg, oenvs = envs
+    torch.manual_seed(0)
+    geom = DreamMatMesh({"shape_init": "sphere:32:24", "shape_init_params": 0.7}).to(dev)
+    mat = DreamMatMaterial({"use_raytracing": False, "environment_scale": 2.0, "env_max_res": 32, "env_min_res": 8,
+                            "n_envs": 3}, latlongs=lat).to(dev)
+    rend = RaytraceRender({}, geometry=geom, material=mat, background=SolidColorBackground({}))
+    B, H, W = 2, 64, 64
+    batch = util.make_views(B, H, W, seed=2)
+    c2w = batch["c2w"][1].clone(); c2w[:3, 0] *= -1; c2w[:3, 2] *= -1
+    proj = camera.get_projection_matrix(batch["fovy"][1:2], 1.0, 0.1, 1000.0)
+    batch["mvp_mtx"][1] = camera.get_mvp_matrix(c2w[None], proj)[0][0]
+    batch["env_id"] = torch.tensor([0, 2])
+    gb = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    ju, jn = torch.rand(B, H, W, device=dev), torch.randn(B, H, W, device=dev)
+    o1 = rend(**gb, light_positions=None, jitter_u=ju, jitter_n=jn)
+    o2 = rend(**gb, light_positions=None, jitter_u=ju, jitter_n=jn)
+    assert torch.equal(o1["comp_rgb"], o2["comp_rgb"])
+    assert float(o1["opacity"][1].abs().max()) == 0.0 and float((o1["comp_rgb"][1] - 1).abs().max()) == 0.0
+    assert float(o1["opacity"][0].max()) == 1.0
+    # all-empty batch: N = 0 everywhere
+    gb["mvp_mtx"] = gb["mvp_mtx"][1:2].repeat(2, 1, 1)
+    o3 = rend(**gb, light_positions=None, jitter_u=ju, jitter_n=jn)
+    assert float((o3["comp_rgb"] - 1).abs().max()) == 0.0 and float(o3["loss_mat_reg"]) == 0.0
