@@ -456,6 +456,33 @@ def conv3x3_s1_autograd(x_nhwc, w_fwd, w_dgrad, bias):
     return _Conv3x3S1.apply(x_nhwc, w_fwd, w_dgrad, bias)
 
 
+class _Conv3x3S2(torch.autograd.Function):
+    """stride-2 3x3 conv with leading pad p (0: AutoencoderKL's F.pad(0,1,0,1) downsampler; 1: UNet's) and frozen
+    weights.  Backward = transposed conv, computed by the SAME stride-1 kernel on the zero-inserted gradient
+    (G_up[2i,2j] = g[i,j]) with leading pad 2-p and the flipped / channel-swapped weights: 4x the minimal MFMA
+    work on three small layers instead of an im2col + col2im round trip through HBM."""
+
+    @staticmethod
+    def forward(ctx, x_nhwc, w_fwd, w_dgrad, bias, p):
+        B, H, W, _ = x_nhwc.shape
+        Ho, Wo = (H + 2 * p - 3 + (1 - p)) // 2 + 1, (W + 2 * p - 3 + (1 - p)) // 2 + 1   # p=0: trailing pad 1
+        ctx.w_dgrad, ctx.p, ctx.hw = w_dgrad, p, (H, W)
+        return conv3x3_nhwc(x_nhwc, w_fwd, bias, 2, (p, p), (Ho, Wo))
+
+    @staticmethod
+    def backward(ctx, g):
+        B, Ho, Wo, C = g.shape
+        H, W = ctx.hw
+        g_up = torch.zeros(B, H, W, C, device=g.device, dtype=g.dtype)
+        g_up[:, 0:2 * Ho:2, 0:2 * Wo:2] = g
+        q = 2 - ctx.p
+        return conv3x3_nhwc(g_up, ctx.w_dgrad, None, 1, (q, q), (H, W)), None, None, None, None
+
+
+def conv3x3_s2_autograd(x_nhwc, w_fwd, w_dgrad, bias, lead_pad):
+    return _Conv3x3S2.apply(x_nhwc, w_fwd, w_dgrad, bias, lead_pad)
+
+
 # ------------------------------------------------------------------------------------------ group norm
 def _gn_fwd(x_nhwc, gamma, beta, eps, act):
     B, H, W, C = x_nhwc.shape

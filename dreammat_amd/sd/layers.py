@@ -52,12 +52,28 @@ class Conv2d(nn.Conv2d):
             y = F.linear(xn, self.weight.view(Cout, Cin), self.bias)     # [B,H,W,Cout]
             return y.permute(0, 3, 1, 2)
         cols = F.unfold(x, (kh, kw), padding=(ph, pw), stride=(sh, sw))  # [B, Cin*kh*kw, L]
-        y = torch.matmul(self.weight.view(Cout, Cin * kh * kw), cols)
-        Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
-        y = y.view(B, Cout, Ho, Wo)
+        # [B, L, K] @ [K, Cout]: the result is produced directly in NHWC, like every other layer of the nets
+        y = torch.matmul(cols.transpose(1, 2), self.weight.view(Cout, Cin * kh * kw).t())
         if self.bias is not None:
-            y = y + self.bias.view(1, Cout, 1, 1)
-        return y
+            y = y + self.bias
+        Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
+        return y.view(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
+
+    def mfma_ok(self, x):
+        Cout, Cin, kh, kw = self.weight.shape
+        return (CONV_BACKEND == "mfma" and x.is_cuda and x.dtype == torch.bfloat16 and kh == 3 and kw == 3
+                and Cin % 32 == 0 and Cout % 64 == 0 and not self.weight.requires_grad)
+
+    def forward_strided_asym(self, x):
+        """stride-2 conv over F.pad(x, (0,1,0,1)) (AutoencoderKL downsampler) without materialising the pad."""
+        w_fwd, w_dgrad = self._prepared()
+        xn = x.permute(0, 2, 3, 1).contiguous()
+        if torch.is_grad_enabled() and x.requires_grad:
+            y = hipops.conv3x3_s2_autograd(xn, w_fwd, w_dgrad, self.bias, 0)
+        else:
+            H, W = x.shape[2], x.shape[3]
+            y = hipops.conv3x3_nhwc(xn, w_fwd, self.bias, 2, (0, 0), (H // 2, W // 2))
+        return y.permute(0, 3, 1, 2)
 
     def forward(self, x):
         if CONV_BACKEND == "miopen" or not x.is_cuda:
@@ -259,6 +275,9 @@ class Downsample2D(nn.Module):
 
     def forward(self, x):
         if self.asym:
+            Cout, Cin = self.conv.weight.shape[:2]
+            if self.conv.mfma_ok(x) and Cin % 64 == 0 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0:
+                return self.conv.forward_strided_asym(x)
             x = F.pad(x, (0, 1, 0, 1))
         return self.conv(x)
 

@@ -1,0 +1,36 @@
+"""One benchmark step under torch.profiler, grouped by op + input shapes: finds where the elementwise /
+copy time of the step comes from (diagnostic)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+import dreammat_amd
+from dreammat_amd.data import RandomCameraDataModule
+from dreammat_amd.system import Trainer, to_device
+from torch.profiler import profile, ProfilerActivity
+
+a = bench.parse() if len(sys.argv) > 1 else None
+import argparse
+a = argparse.Namespace(gpus=1, steps=1, warmup=2, views=8, res=512, sd="sd21-base", mesh="sphere:160:160", env_res=128)
+dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+dreammat_amd._import_plugins()
+torch.manual_seed(0)
+lat = [bench.synthetic_latlong(i) for i in range(5)]
+system = dreammat_amd.find("dreammat-system")(bench.system_config(a, 8), material_kwargs={"latlongs": lat})
+system.renderer.debug_outputs = False
+dm = RandomCameraDataModule(cfg={"height": 512, "width": 512, "batch_size": 8, "use_fix_views": True,
+                                 "camera_distance_range": [3.0, 4.0], "fovy_range": [25, 45], "camera_perturb": 0.0,
+                                 "center_perturb": 0.0, "up_perturb": 0.0, "elevation_range": [-20, 45]}, device=dev)
+dm.setup("fit"); system.on_fit_start(); system.configure_optimizers()
+tr = Trainer(system, dm, max_steps=10 ** 9)
+batches = [to_device(dm.train_dataset.collate(), dev) for _ in range(3)]
+for i in range(2):
+    tr.train_one_step(batches[i])
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    tr.train_one_step(batches[2])
+    torch.cuda.synchronize()
+tab = prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=60, max_name_column_width=40, max_shapes_column_width=90)
+open("gpurun_out/trace_ops.txt", "w").write(tab)
+print(tab[:200])
