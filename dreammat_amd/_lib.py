@@ -74,11 +74,14 @@ _SIGS = {
     "dm_attention_fwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]
                               + [_LL] * 12 + [c_float, c_void_p]),
     "dm_conv3x3_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
+    "dm_conv3x3_nhwc_bf16_fused": (c_int, [c_void_p] * 6 + [c_int] * 10 + [c_void_p]),
     "dm_groupnorm_workspace_floats": (c_size_t, [c_int, c_int]),
     "dm_groupnorm_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                       c_int, c_void_p]),
     "dm_groupnorm_nhwc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                       c_float, c_int, c_void_p]),
+    "dm_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _LL, c_int, c_float, c_void_p]),
+    "dm_geglu_bf16": (c_int, [c_void_p, c_void_p, _LL, c_int, c_void_p]),
     "dm_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _LL, c_int, c_float, c_float, c_float, c_float,
                              c_float, c_int, c_void_p]),
 }

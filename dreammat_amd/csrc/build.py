@@ -18,6 +18,7 @@ SOURCES = {
     "attention.hip": [],
     "conv.hip": [],
     "groupnorm.hip": [],
+    "transformer.hip": [],
     "adam.hip": [],
     "host.cpp": [],
 }

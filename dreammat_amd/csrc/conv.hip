@@ -30,6 +30,8 @@ struct ConvArgs {
     const __bf16* x;     // [B, Hin, Win, Cin]
     const __bf16* w;     // [Cout, 9, Cin]
     const __bf16* bias;  // [Cout] or null
+    const __bf16* rowbias;   // [B, Cout] or null: per-image channel bias (the ResnetBlock2D time embedding)
+    const __bf16* res;       // [B, Hout, Wout, Cout] or null: residual added in the epilogue
     __bf16* y;           // [B, Hout, Wout, Cout]
     int B, Hin, Win, Cin, Hout, Wout, Cout;
     int stride, pad_y, pad_x;
@@ -182,20 +184,26 @@ __global__ __launch_bounds__(256) void k_conv3x3(ConvArgs a, long long n_mt, int
 //  * counted s_waitcnt vmcnt(L) + raw s_barrier: one barrier per K-step, loads span the barrier.
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0, 0, 0, 0};
 
-template <int BMT, int BN>
-__global__ __launch_bounds__(BMT * 2) void k_conv3x3_dma(ConvArgs a, long long n_mt, int n_nt) {
-    // BMT x BN x 64 tile; BMT/32 waves as (BMT/64) x 2, each wave a 64 x BN/2 sub-tile.
-    // 128 x {64,128}: 4 waves, 2-5 workgroups per CU.  256 x 128: 8 waves, one workgroup per CU, twice the
-    // FLOP per byte pulled through L2 (the 128-row tiles are L2-bandwidth bound: ~13 TB/s at 570 TF/s).
+template <int BMT, int BN, int NW, int WMW, int NSTAGE>
+__global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n_mt, int n_nt) {
+    // BMT x BN x 64 workgroup tile, NW waves laid out WMW (along M) x NW/WMW (along N), NSTAGE-deep LDS ring.
+    //   <128, 64|128, 4, 2, 3>  wave tile 64 x 32|64, 2-5 workgroups per CU (small problems)
+    //   <256, 128, 8, 4, 3>     wave tile 64 x 64, one workgroup per CU
+    //   <256, 256, 8, 2, 2>     wave tile 128 x 64: 24 ds_read_b128 per 32 MFMA instead of 16 per 16, and half the
+    //   <256, 320, 8, 4, 2>     wave tile 64 x 160    DMA bytes per FLOP (Cout = 320 without a ragged N tile)
+    //   <512, 128, 8, 4, 2>     wave tile 128 x 64 for Cout = 128 (the 512^2 VAE layers)
     constexpr int BK = 64;
     constexpr int ROWB = 128;                          // bytes per tile row (64 bf16), unpadded
-    constexpr int NW = BMT / 32;                       // waves
+    constexpr int WNW = NW / WMW;
+    constexpr int TM = BMT / WMW, TN = BN / WNW;       // wave tile
+    constexpr int MT = TM / 32, NT = TN / 32;          // 32x32 accumulator fragments per wave
     constexpr int A_BYTES = BMT * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
-    constexpr int NT = BN / 64;
-    constexpr int A_INSTR = BMT / 8 / NW;              // wave-instructions (8 rows each) per wave: 4
-    constexpr int B_INSTR = BN / 8 / NW;               // 4 / 2 (128-row tile), 2 (256-row tile)
+    constexpr int A_INSTR = BMT / 8 / NW;              // wave-instructions (8 rows each) per wave
+    constexpr int B_INSTR = BN / 8 / NW;
     constexpr int L = A_INSTR + B_INSTR;               // DMA instructions per wave per tile
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // 3 * STAGE
+    static_assert(TM % 32 == 0 && TN % 32 == 0 && BMT % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile shape");
+    static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // NSTAGE * STAGE
 
     long long mt; int nt;
     {
@@ -208,131 +216,167 @@ __global__ __launch_bounds__(BMT * 2) void k_conv3x3_dma(ConvArgs a, long long n
         nt = (int)(id - mt * n_nt);
     }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WNW, wn = wave % WNW;
     const long long m0 = mt * BMT;
     const int n0 = nt * BN;
     const int lrow = lane >> 3, lslot = lane & 7;      // this lane's row / 16 B slot inside one DMA instruction
     const unsigned long long zero = (unsigned long long)g_zero_page;
 
-    // A rows of this lane: wave*(BMT/NW) + 8*i + lrow
-    int a_b[A_INSTR], a_y[A_INSTR], a_x[A_INSTR];
-    bool a_ok[A_INSTR];
-    int a_chunk[A_INSTR];
+    // A rows of this lane: wave*(BMT/NW) + 8*i + lrow.  Everything that depends on the row is computed ONCE:
+    // a pointer to tap (0,0) / channel 0 of the row's receptive field (pre-swizzled chunk; it may lie outside
+    // the image and is only dereferenced for taps whose bit is set in a_mask) and a 9-bit tap-validity mask.
+    // The K-loop then needs one 64-bit add and one select per DMA instruction (the first version recomputed
+    // ((b*Hin + y)*Win + x)*Cin per tap: ~110 VALU / 24 quarter-rate multiplies per K-step per wave, more
+    // issue time than the 16 MFMAs they feed).
+    const __bf16* a_ptr[A_INSTR];
+    unsigned a_mask[A_INSTR];
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i) {
         int row = wave * (BMT / NW) + 8 * i + lrow;
         long long m = m0 + row;
-        a_ok[i] = m < a.M;
-        long long mm = a_ok[i] ? m : 0;
+        bool ok = m < a.M;
+        long long mm = ok ? m : 0;
         int hw = a.Hout * a.Wout;
-        a_b[i] = (int)(mm / hw);
-        int rem = (int)(mm - (long long)a_b[i] * hw);
+        int b = (int)(mm / hw);
+        int rem = (int)(mm - (long long)b * hw);
         int yo = rem / a.Wout;
-        a_y[i] = yo * a.stride - a.pad_y;
-        a_x[i] = (rem - yo * a.Wout) * a.stride - a.pad_x;
-        a_chunk[i] = lslot ^ ((row >> 1) & 7);         // source chunk that must land in slot lslot
+        int y0 = yo * a.stride - a.pad_y;
+        int x0 = (rem - yo * a.Wout) * a.stride - a.pad_x;
+        a_ptr[i] = a.x + (((long long)b * a.Hin + y0) * a.Win + x0) * a.Cin + (lslot ^ ((row >> 1) & 7)) * 8;
+        unsigned mk = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            int yy = y0 + t / 3, xx = x0 + t % 3;
+            if (ok && (unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)a.Win) mk |= 1u << t;
+        }
+        a_mask[i] = mk;
     }
-    unsigned long long b_src[B_INSTR];
-    bool b_ok[B_INSTR];
+    // weight rows past Cout (ragged last tile, e.g. 320 = 2.5 x 128) re-read row Cout-1: finite values that
+    // only reach accumulator columns the epilogue never stores
+    const __bf16* b_ptr[B_INSTR];
 #pragma unroll
     for (int i = 0; i < B_INSTR; ++i) {
         int row = wave * (BN / NW) + 8 * i + lrow;
-        b_ok[i] = n0 + row < a.Cout;                   // ragged last Cout tile (e.g. 320 = 2.5 x 128)
         int rc = min(n0 + row, a.Cout - 1);
-        b_src[i] = (unsigned long long)(a.w + (long long)rc * 9LL * a.Cin + (lslot ^ ((row >> 1) & 7)) * 8);
+        b_ptr[i] = a.w + (long long)rc * 9LL * a.Cin + (lslot ^ ((row >> 1) & 7)) * 8;
     }
     const int kt_per_tap = a.Cin / BK;
     const int n_steps = 9 * kt_per_tap;
 
-    auto issue = [&](int s, int stage) {
-        int tap = s / kt_per_tap;
-        int c0 = (s - tap * kt_per_tap) * BK;
-        int dy = tap / 3, dx = tap - dy * 3;
+    // issue cursor (wave-uniform => SGPRs): K-step i_s = (tap i_tap, channel block i_kc)
+    int i_s = 0, i_tap = 0, i_kc = 0;
+    auto issue = [&](int stage) {
+        const int dy = (i_tap * 11) >> 5, dx = i_tap - 3 * dy;                      // tap / 3, tap % 3 for tap < 9
+        const long long toff = (long long)(dy * a.Win + dx) * a.Cin + i_kc * BK;     // elements from a_ptr
+        const long long woff = (long long)i_s * BK;
+        const unsigned bit = 1u << i_tap;
         char* ab = smem + stage * STAGE;
         char* bb = ab + A_BYTES;
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
-            int yy = a_y[i] + dy, xx = a_x[i] + dx;
-            bool inb = a_ok[i] && (unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)a.Win;
-            int yc = min(max(yy, 0), a.Hin - 1), xc = min(max(xx, 0), a.Win - 1);   // always a legal address
-            unsigned long long real = (unsigned long long)(a.x + (((long long)a_b[i] * a.Hin + yc) * a.Win + xc) * a.Cin + c0 + a_chunk[i] * 8);
-            const void* src = (const void*)(inb ? real : zero);                      // select, never a branch:
-            // the DMA must execute with ALL lanes active (an inactive lane would leave its LDS slot stale)
+            // select, never a branch: the DMA must execute with ALL lanes active (an inactive lane would
+            // leave its LDS slot stale); out-of-image taps read the 16-byte zero page
+            const void* src = (a_mask[i] & bit) ? (const void*)(a_ptr[i] + toff) : (const void*)zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(ab + (wave * (BMT / NW) + 8 * i) * ROWB),
                                              16, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < B_INSTR; ++i) {
-            const void* src = (const void*)(b_ok[i] ? b_src[i] + (unsigned long long)s * BK * 2 : zero);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+        for (int i = 0; i < B_INSTR; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[i] + woff),
                                              (__attribute__((address_space(3))) void*)(bb + (wave * (BN / NW) + 8 * i) * ROWB),
                                              16, 0, 0);
-        }
+        ++i_s;
+        if (++i_kc == kt_per_tap) { i_kc = 0; ++i_tap; }
     };
 
-    f32x16 acc[2][NT];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    issue(0, 0);
-    if (n_steps > 1) issue(1, 1);
+    // ring protocol: at the top of step s every wave waits for ITS OWN step-s DMAs (counted vmcnt leaves the
+    // NSTAGE-2 younger steps in flight), then the barrier makes all waves' step-s data visible and proves
+    // everybody has finished reading stage (s-1) % NSTAGE, which is the stage the next issue overwrites.
+    issue(0);
+    if (NSTAGE == 3 && n_steps > 1) issue(1);
     int stage = 0;
     for (int s = 0; s < n_steps; ++s) {
-        if (s + 1 < n_steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        if (NSTAGE == 3 && s + 1 < n_steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        int st2 = stage + 2; if (st2 >= 3) st2 -= 3;
-        if (s + 2 < n_steps) issue(s + 2, st2);
+        int st2 = stage + NSTAGE - 1; if (st2 >= NSTAGE) st2 -= NSTAGE;
+        if (s + NSTAGE - 1 < n_steps) issue(st2);
         const char* ab = smem + stage * STAGE;
         const char* bb = ab + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8 af[2], bf[NT];
+            bf16x8 af[MT], bf[NT];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int r = 64 * wm + 32 * i + l31;
+            for (int i = 0; i < MT; ++i) {
+                int r = TM * wm + 32 * i + l31;
                 af[i] = *reinterpret_cast<const bf16x8*>(ab + r * ROWB + (((2 * kk + hi) ^ ((r >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                int r = (BN / 2) * wn + 32 * j + l31;
+                int r = TN * wn + 32 * j + l31;
                 bf[j] = *reinterpret_cast<const bf16x8*>(bb + r * ROWB + (((2 * kk + hi) ^ ((r >> 1) & 7)) << 4));
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        stage = stage + 1; if (stage >= 3) stage = 0;
+        stage = stage + 1; if (stage >= NSTAGE) stage = 0;
     }
 
+    // ---- epilogue: y = acc + bias[n] (+ rowbias[image(m), n]) (+ res[m, n]), one rounding to bf16.
+    // D layout: lane holds column n = l31 of each 32x32 fragment, rows (r&3) + 8*(r>>2) + 4*hi.
+    float bv[NT];
+    int ncol[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        int n = n0 + (BN / 2) * wn + 32 * j + l31;
-        if (n >= a.Cout) continue;
-        float bv = a.bias ? (float)a.bias[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                long long m = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (m < a.M) a.y[m * a.Cout + n] = (__bf16)(acc[i][j][r] + bv);
-            }
+        ncol[j] = n0 + TN * wn + 32 * j + l31;
+        bv[j] = (a.bias && ncol[j] < a.Cout) ? (float)a.bias[ncol[j]] : 0.f;
     }
+    const int hw = a.Hout * a.Wout;
+    const int img0 = (int)(m0 / hw);                   // image of the tile's first row (wave-uniform)
+    const int rem0 = (int)(m0 - (long long)img0 * hw);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = TM * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const long long m = m0 + d;
+            if (m >= a.M) continue;
+            const __bf16* rb = nullptr;
+            if (a.rowbias) {
+                int img = img0, t = rem0 + d;
+                while (t >= hw) { t -= hw; ++img; }    // a tile spans at most BMT / hw + 1 images
+                rb = a.rowbias + (long long)img * a.Cout;
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (ncol[j] >= a.Cout) continue;
+                float v = acc[i][j][r] + bv[j];
+                if (rb) v += (float)rb[ncol[j]];
+                if (a.res) v += (float)a.res[m * a.Cout + ncol[j]];
+                a.y[m * a.Cout + ncol[j]] = (__bf16)v;
+            }
+        }
 }
 
-template <int BMT, int BN>
+template <int BMT, int BN, int NW, int WMW, int NSTAGE>
 int launch_conv_dma(const ConvArgs& a, hipStream_t stream) {
-    constexpr int LDS = 3 * (BMT + BN) * 128;
+    constexpr int LDS = NSTAGE * (BMT + BN) * 128;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_dma<BMT, BN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_dma<BMT, BN, NW, WMW, NSTAGE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -342,7 +386,8 @@ int launch_conv_dma(const ConvArgs& a, hipStream_t stream) {
     long long blocks = ((n_mt * n_nt + 7) / 8) * 8;
     if (blocks > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
     DM_ENTER();
-    hipLaunchKernelGGL((k_conv3x3_dma<BMT, BN>), dim3((unsigned)blocks), dim3(BMT * 2), LDS, stream, a, n_mt, n_nt);
+    hipLaunchKernelGGL((k_conv3x3_dma<BMT, BN, NW, WMW, NSTAGE>), dim3((unsigned)blocks), dim3(NW * 64), LDS, stream, a,
+                       n_mt, n_nt);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? DM_OK : (int)e;
 }
@@ -375,29 +420,62 @@ extern "C" {
 // x [B,Hin,Win,Cin] NHWC bf16; w [Cout,3,3,Cin] (= [Cout, 9*Cin], tap-major) bf16; bias [Cout] bf16 or NULL;
 // y [B,Hout,Wout,Cout] NHWC bf16 with Hout = (Hin + pad_y + pad_y_end - 3)/stride + 1 chosen by the caller
 // (pad_y / pad_x are the leading pads; trailing pads are implied by Hout/Wout and zero-filled).
-int dm_conv3x3_nhwc_bf16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin,
-                         int Hout, int Wout, int Cout, int stride, int pad_y, int pad_x, hipStream_t stream) {
+// rowbias [B,Cout] / residual [B,Hout,Wout,Cout] (bf16, either may be NULL) are added in the epilogue
+// (LDS-DMA kernels only: Cin % 64 == 0).
+int dm_conv3x3_nhwc_bf16_fused(const void* x, const void* w, const void* bias, const void* rowbias, const void* residual,
+                               void* y, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int stride,
+                               int pad_y, int pad_x, hipStream_t stream) {
     if (!x || !w || !y || B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || stride <= 0) return DM_ERR_ARG;
     if (Cin % 32 != 0 || Cout % 64 != 0) return DM_ERR_UNSUPPORTED;
     if (((uintptr_t)x | (uintptr_t)w) & 15) return DM_ERR_ARG;
     ConvArgs a;
     a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const __bf16*)bias; a.y = (__bf16*)y;
+    a.rowbias = (const __bf16*)rowbias; a.res = (const __bf16*)residual;
     a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
     a.stride = stride; a.pad_y = pad_y; a.pad_x = pad_x;
     a.M = (long long)B * Hout * Wout;
     // DREAMMAT_CONV_KERNEL=staged selects the register-staged variant everywhere (A/B measurements)
     static const bool use_dma = !(getenv("DREAMMAT_CONV_KERNEL") && !strcmp(getenv("DREAMMAT_CONV_KERNEL"), "staged"));
     if (use_dma && Cin % 64 == 0) {
-        // 256 x 128 tiles (8 waves, 1 workgroup per CU) win on every measured UNet / ControlNet / VAE shape
-        // (profiles/r01_kernel_bench_v4.json: 624-793 TF/s vs 502-598) -- used unless the problem is tiny;
-        // DREAMMAT_CONV_TILE=128|256 forces a choice (tests / A-B measurements)
+        // Tile choice from profiles/r01_kernel_bench_conv_tiles.json (TF/s, MI355X):
+        //   Cout=320 @64x64 B24: 256x128 632 | 256x320 839      960->320: 750 | 952      640 @32x32: 897 | 950
+        //   Cout=256 @256x256 B8: 256x128 888 | 256x256 1023    512 @64x64: 951 | 1107
+        //   1280 @16x16 B24 (M = 6144): 256x128 925 | 256x256 629 | 256x320 531   (too few workgroups for 256 CUs)
+        // => the widest tile that divides Cout, as long as it still yields enough workgroups to fill the chip.
+        // DREAMMAT_CONV_TILE=128|256|512|320|640 forces a variant (tests / A-B measurements).
         const char* tile_env = getenv("DREAMMAT_CONV_TILE");   // read per call: tests toggle it
-        bool big = tile_env ? !strcmp(tile_env, "256") : (Cout >= 128 && a.M >= 2048);
-        if (big) return launch_conv_dma<256, 128>(a, stream);
-        return (Cout % 128 == 0) ? launch_conv_dma<128, 128>(a, stream) : launch_conv_dma<128, 64>(a, stream);
+        int tile = tile_env ? atoi(tile_env) : 0;
+        auto n_wg = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
+        if (!tile) {
+            if (!(Cout >= 128 && a.M >= 2048)) tile = 128;
+            else if (Cout % 320 == 0 && Cout % 256 != 0 && n_wg(256, 320) >= 160) tile = 320;
+            else if (Cout % 256 == 0 && n_wg(256, 256) >= 200) tile = 512;
+            else if (Cout == 128 && n_wg(512, 128) >= 256) tile = 640;
+            else tile = 256;
+        }
+        switch (tile) {
+        case 640: {                                                          // wave tile 128 x 64, all 160 KB of LDS
+            int rc = launch_conv_dma<512, 128, 8, 4, 2>(a, stream);
+            if (rc <= 0 || tile_env) return rc;
+            return launch_conv_dma<256, 128, 8, 4, 3>(a, stream);            // runtime refused the full-LDS variant
+        }
+        case 320: return launch_conv_dma<256, 320, 8, 4, 2>(a, stream);      // wave tile 64 x 160
+        case 512: return launch_conv_dma<256, 256, 8, 2, 2>(a, stream);      // wave tile 128 x 64
+        case 256: return launch_conv_dma<256, 128, 8, 4, 3>(a, stream);      // wave tile 64 x 64
+        default:
+            return (Cout % 128 == 0) ? launch_conv_dma<128, 128, 4, 2, 3>(a, stream)
+                                     : launch_conv_dma<128, 64, 4, 2, 3>(a, stream);
+        }
     }
+    if (rowbias || residual) return DM_ERR_UNSUPPORTED;
     if (Cout % 128 == 0) return (Cin % 64 == 0) ? launch_conv<128, 64>(a, stream) : launch_conv<128, 32>(a, stream);
     return (Cin % 64 == 0) ? launch_conv<64, 64>(a, stream) : launch_conv<64, 32>(a, stream);
+}
+
+int dm_conv3x3_nhwc_bf16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin,
+                         int Hout, int Wout, int Cout, int stride, int pad_y, int pad_x, hipStream_t stream) {
+    return dm_conv3x3_nhwc_bf16_fused(x, w, bias, nullptr, nullptr, y, B, Hin, Win, Cin, Hout, Wout, Cout, stride, pad_y,
+                                      pad_x, stream);
 }
 
 }  // extern "C"

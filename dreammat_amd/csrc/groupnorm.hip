@@ -5,7 +5,9 @@
 // of the activation (statistics pass + apply pass), all 16 B vector accesses; keeping the activations
 // NHWC end-to-end removes the NCHW<->NHWC copies around the implicit-GEMM convolutions (csrc/conv.hip).
 //   x [B, HW, C] bf16, gamma/beta [C] bf16, G = 32 groups of C/32 contiguous channels, eps.
-// stats[b][g] = (sum, sumsq) fp32 accumulated with atomics (caller zeroes), then
+// Group statistics (sum, sumsq) are reduced WITHOUT atomics: every workgroup writes one fp32 partial per group,
+// the coefficient kernel adds the partials in a fixed order (deterministic, no memset, no same-address
+// atomic traffic across the 8 XCDs -- the first version spent most of its time there), then
 //   y = act((x - mean) * rstd * gamma + beta),  act = identity | SiLU.
 // Backward (the VAE encoder is differentiated through; weights are frozen => only dx):
 //   dz = dy * act'(z);  dxhat = dz * gamma;  dx = rstd * (dxhat - mean_g(dxhat) - xhat * mean_g(dxhat * xhat)).
@@ -15,14 +17,14 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// workspace (fp32): stats [B,32,2] | bstats [B,32,2] | coef [B,7,C]
+// workspace (fp32): coef [B,7,C] | part [B*nblk,32,2] | bpart [B*nblk,32,2]   (nblk = workgroups per batch item)
 //   coef rows: 0 A = rstd*gamma   1 S = beta - mean*rstd*gamma   2 rstd   3 mean*rstd   4 gamma
 //              5 rstd*mean_g(dxhat)   6 rstd*mean_g(dxhat*xhat)
 struct GnArgs {
     const __bf16* x; const __bf16* gamma; const __bf16* beta; const __bf16* dy;
     __bf16* y;            // forward output / backward dx
-    float* stats; float* bstats; float* coef;
-    int B, HW, C, act;
+    float* part; float* bpart; float* coef;
+    int B, HW, C, act, nblk;
     float eps;
     int rows_per_block;
 };
@@ -45,33 +47,35 @@ __global__ void k_gn_coef(GnArgs a) {
     if (c >= a.C) return;
     const int cpg = a.C / 32, g = c / cpg;
     const float n = (float)a.HW * cpg;
-    float m = a.stats[((long long)b * 32 + g) * 2] / n;
-    float var = a.stats[((long long)b * 32 + g) * 2 + 1] / n - m * m;
-    float rs = rsqrtf(fmaxf(var, 0.f) + a.eps);
+    const float* pp = (PASS == 0 ? a.part : a.bpart) + (long long)b * a.nblk * 64 + g * 2;
+    float t0 = 0.f, t1 = 0.f;
+    for (int k = 0; k < a.nblk; ++k) { t0 += pp[(long long)k * 64]; t1 += pp[(long long)k * 64 + 1]; }
     float* co = a.coef + (long long)b * 7 * a.C;
     if (PASS == 0) {
+        float m = t0 / n;
+        float var = t1 / n - m * m;
+        float rs = rsqrtf(fmaxf(var, 0.f) + a.eps);
         float gm = (float)a.gamma[c], bt = (float)a.beta[c];
         co[c] = rs * gm; co[a.C + c] = bt - m * rs * gm; co[2 * a.C + c] = rs; co[3 * a.C + c] = m * rs;
         co[4 * a.C + c] = gm;
     } else {
-        co[5 * a.C + c] = rs * a.bstats[((long long)b * 32 + g) * 2] / n;
-        co[6 * a.C + c] = rs * a.bstats[((long long)b * 32 + g) * 2 + 1] / n;
+        float rs = co[2 * a.C + c];
+        co[5 * a.C + c] = rs * t0 / n;
+        co[6 * a.C + c] = rs * t1 / n;
     }
 }
 
 // MODE 0: forward statistics (sum x, sum x^2).  MODE 1: backward statistics (sum dxhat, sum dxhat*xhat).
 template <int MODE>
 __global__ __launch_bounds__(256) void k_gn_stats(GnArgs a) {
-    extern __shared__ float sh[];          // [2*C] per-channel partial sums
+    extern __shared__ float sh[];          // [row_par][2*C] per-thread partial sums (each slot written once)
     const int b = blockIdx.y;
     const int C = a.C, cpg = C / 32;
     const int chunks = C / 8;              // 16 B chunks per pixel row
-    for (int i = threadIdx.x; i < 2 * C; i += 256) sh[i] = 0.f;
-    __syncthreads();
     const long long row0 = (long long)blockIdx.x * a.rows_per_block;
     const long long row1 = min((long long)a.HW, row0 + a.rows_per_block);
-    const __bf16* xb = a.x + (long long)b * a.HW * C;
-    const __bf16* dyb = MODE ? a.dy + (long long)b * a.HW * C : nullptr;
+    const __bf16* __restrict__ xb = a.x + (long long)b * a.HW * C;
+    const __bf16* __restrict__ dyb = MODE ? a.dy + (long long)b * a.HW * C : nullptr;
     const float* co = a.coef + (long long)b * 7 * C;
     // thread -> fixed channel chunk(s); rows are strided over the threads that share a chunk
     const int lanes_per_row = min(chunks, 256);
@@ -86,39 +90,56 @@ __global__ __launch_bounds__(256) void k_gn_stats(GnArgs a) {
                 load8(co + ch * 8, A); load8(co + C + ch * 8, S); load8(co + 2 * C + ch * 8, rs);
                 load8(co + 3 * C + ch * 8, mrs); load8(co + 4 * C + ch * 8, gm);
             }
-            for (long long r = row0 + my_row; r < row1; r += row_par) {
-                bf16x8 v = *reinterpret_cast<const bf16x8*>(xb + r * C + ch * 8);
-                if (!MODE) {
+            // 4 rows per trip: four independent 16 B loads in flight per thread (the single-load loop was
+            // latency-bound at ~1.3 TB/s on the UNet-sized tensors)
+            for (long long r = row0 + my_row; r < row1; r += 4LL * row_par) {
+                bf16x8 v[4], d[4];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { float f = (float)v[k]; s0[k] += f; s1[k] += f * f; }
-                } else {
-                    bf16x8 d = *reinterpret_cast<const bf16x8*>(dyb + r * C + ch * 8);
+                for (int u = 0; u < 4; ++u) {
+                    long long rr = r + (long long)u * row_par;
+                    bool ok = rr < row1;
+                    long long rc = ok ? rr : row0;
+                    v[u] = *reinterpret_cast<const bf16x8*>(xb + rc * C + ch * 8);
+                    if (MODE) d[u] = *reinterpret_cast<const bf16x8*>(dyb + rc * C + ch * 8);
+                    if (!ok) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        float xf = (float)v[k];
-                        float xh = xf * rs[k] - mrs[k];
-                        float dz = (float)d[k];
-                        if (a.act) dz *= silu_grad(xf * A[k] + S[k]);
-                        float dxh = dz * gm[k];
-                        s0[k] += dxh; s1[k] += dxh * xh;
+                        for (int k = 0; k < 8; ++k) { v[u][k] = (__bf16)0.f; if (MODE) d[u][k] = (__bf16)0.f; }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (!MODE) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) { float f = (float)v[u][k]; s0[k] += f; s1[k] += f * f; }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            float xf = (float)v[u][k];
+                            float xh = xf * rs[k] - mrs[k];
+                            float dz = (float)d[u][k];
+                            if (a.act) dz *= silu_grad(xf * A[k] + S[k]);
+                            float dxh = dz * gm[k];
+                            s0[k] += dxh; s1[k] += dxh * xh;
+                        }
                     }
                 }
             }
+            float* o = sh + (long long)my_row * 2 * C + ch * 8;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                atomicAdd(&sh[ch * 8 + k], s0[k]);
-                atomicAdd(&sh[C + ch * 8 + k], s1[k]);
-            }
+            for (int k = 0; k < 8; ++k) { o[k] = s0[k]; o[C + k] = s1[k]; }
         }
     }
     __syncthreads();
-    float* out = MODE ? a.bstats : a.stats;
-    if (threadIdx.x < 32) {
-        int g = threadIdx.x;
-        float t0 = 0.f, t1 = 0.f;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { t0 += sh[c]; t1 += sh[C + c]; }
-        atomicAdd(&out[((long long)b * 32 + g) * 2], t0);
-        atomicAdd(&out[((long long)b * 32 + g) * 2 + 1], t1);
+    // fixed-order reduction: thread t < 64 -> (group t>>1, statistic t&1)
+    if (threadIdx.x < 64) {
+        const int g = threadIdx.x >> 1, which = threadIdx.x & 1;
+        float t = 0.f;
+        for (int rp = 0; rp < row_par; ++rp) {
+            const float* src = sh + (long long)rp * 2 * C + which * C + g * cpg;
+            for (int c = 0; c < cpg; ++c) t += src[c];
+        }
+        float* out = MODE ? a.bpart : a.part;
+        out[((long long)b * a.nblk + blockIdx.x) * 64 + g * 2 + which] = t;
     }
 }
 
@@ -127,9 +148,9 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_gn_apply(GnArgs a) {
     const int b = blockIdx.y;
     const int C = a.C, chunks = C / 8;
-    const __bf16* xb = a.x + (long long)b * a.HW * C;
-    const __bf16* dyb = MODE ? a.dy + (long long)b * a.HW * C : nullptr;
-    __bf16* yb = a.y + (long long)b * a.HW * C;
+    const __bf16* __restrict__ xb = a.x + (long long)b * a.HW * C;
+    const __bf16* __restrict__ dyb = MODE ? a.dy + (long long)b * a.HW * C : nullptr;
+    __bf16* __restrict__ yb = a.y + (long long)b * a.HW * C;
     const float* co = a.coef + (long long)b * 7 * C;
     const int lanes_per_row = min(chunks, 256);
     const int row_par = 256 / lanes_per_row;
@@ -144,6 +165,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnArgs a) {
             load8(co + 2 * C + ch * 8, rs); load8(co + 3 * C + ch * 8, mrs); load8(co + 4 * C + ch * 8, gm);
             load8(co + 5 * C + ch * 8, c1); load8(co + 6 * C + ch * 8, c2);
         }
+#pragma unroll 4
         for (long long r = row0 + my_row; r < row1; r += row_par) {
             bf16x8 v = *reinterpret_cast<const bf16x8*>(xb + r * C + ch * 8);
             bf16x8 o;
@@ -171,18 +193,32 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnArgs a) {
 
 bool check_args(int B, int HW, int C) { return B > 0 && HW > 0 && C > 0 && C % 32 == 0 && C <= 8192; }
 
+constexpr int GN_MAX_BLOCKS = 2048;      // workgroups over the chip (all batch items together), at least 8 rows each
+
 void launch_cfg(int B, int HW, int C, dim3& grid, int& rows_per_block) {
-    // ~2048 workgroups over the chip, at least 8 rows each
-    int blocks_per_b = (int)std::max<long long>(1, std::min<long long>((HW + 7) / 8, 2048 / std::max(1, B) + 1));
+    int blocks_per_b = (int)std::max<long long>(1, std::min<long long>((HW + 7) / 8, GN_MAX_BLOCKS / std::max(1, B) + 1));
     rows_per_block = (HW + blocks_per_b - 1) / blocks_per_b;
     grid = dim3((unsigned)((HW + rows_per_block - 1) / rows_per_block), B);
+}
+
+size_t part_floats(int B) { return ((size_t)GN_MAX_BLOCKS + (size_t)B) * 64; }      // >= B * blocks_per_b * 64
+
+size_t stats_lds_bytes(int C) {
+    int chunks = C / 8, lanes_per_row = std::min(chunks, 256), row_par = 256 / lanes_per_row;
+    return (size_t)row_par * 2 * C * sizeof(float);
+}
+
+void bind_ws(GnArgs& a, float* ws, int B, int C) {
+    a.coef = ws;
+    a.part = ws + (size_t)B * 7 * C;
+    a.bpart = a.part + part_floats(B);
 }
 
 }  // namespace
 
 extern "C" {
 
-size_t dm_groupnorm_workspace_floats(int B, int C) { return (size_t)B * (128 + 7 * (size_t)C); }
+size_t dm_groupnorm_workspace_floats(int B, int C) { return (size_t)B * 7 * (size_t)C + 2 * part_floats(B); }
 
 // ws: dm_groupnorm_workspace_floats(B,C) fp32 (kept by the caller for the backward).  act: 0 none, 1 SiLU.
 int dm_groupnorm_nhwc_fwd(const void* x, const void* gamma, const void* beta, void* y, float* ws, int B, int HW,
@@ -190,13 +226,13 @@ int dm_groupnorm_nhwc_fwd(const void* x, const void* gamma, const void* beta, vo
     if (!x || !gamma || !beta || !y || !ws || !check_args(B, HW, C)) return DM_ERR_ARG;
     GnArgs a = {};
     a.x = (const __bf16*)x; a.gamma = (const __bf16*)gamma; a.beta = (const __bf16*)beta; a.y = (__bf16*)y;
-    a.stats = ws; a.bstats = ws + (size_t)B * 64; a.coef = ws + (size_t)B * 128;
+    bind_ws(a, ws, B, C);
     a.B = B; a.HW = HW; a.C = C; a.act = act; a.eps = eps;
     dim3 g;
     launch_cfg(B, HW, C, g, a.rows_per_block);
+    a.nblk = (int)g.x;
     DM_ENTER();
-    DM_HIP(hipMemsetAsync(ws, 0, (size_t)B * 128 * sizeof(float), stream));
-    hipLaunchKernelGGL(k_gn_stats<0>, g, dim3(256), 2 * C * sizeof(float), stream, a);
+    hipLaunchKernelGGL(k_gn_stats<0>, g, dim3(256), stats_lds_bytes(C), stream, a);
     hipLaunchKernelGGL(k_gn_coef<0>, dim3(dm_div_up(C, 256), B), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(k_gn_apply<0>, g, dim3(256), 0, stream, a);
     DM_LAUNCH_CHECK();
@@ -209,13 +245,14 @@ int dm_groupnorm_nhwc_bwd(const void* x, const void* gamma, const void* beta, co
     if (!x || !gamma || !beta || !dy || !dx || !ws || !check_args(B, HW, C)) return DM_ERR_ARG;
     GnArgs a = {};
     a.x = (const __bf16*)x; a.gamma = (const __bf16*)gamma; a.beta = (const __bf16*)beta; a.dy = (const __bf16*)dy;
-    a.y = (__bf16*)dx; a.stats = ws; a.bstats = ws + (size_t)B * 64; a.coef = ws + (size_t)B * 128;
+    a.y = (__bf16*)dx;
+    bind_ws(a, ws, B, C);
     a.B = B; a.HW = HW; a.C = C; a.act = act; a.eps = eps;
     dim3 g;
     launch_cfg(B, HW, C, g, a.rows_per_block);
+    a.nblk = (int)g.x;
     DM_ENTER();
-    DM_HIP(hipMemsetAsync(a.bstats, 0, (size_t)B * 64 * sizeof(float), stream));
-    hipLaunchKernelGGL(k_gn_stats<1>, g, dim3(256), 2 * C * sizeof(float), stream, a);
+    hipLaunchKernelGGL(k_gn_stats<1>, g, dim3(256), stats_lds_bytes(C), stream, a);
     hipLaunchKernelGGL(k_gn_coef<1>, dim3(dm_div_up(C, 256), B), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(k_gn_apply<1>, g, dim3(256), 0, stream, a);
     DM_LAUNCH_CHECK();

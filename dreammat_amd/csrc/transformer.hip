@@ -1,0 +1,139 @@
+// Row-wise pieces of the UNet / ControlNet transformer blocks on bf16 token matrices for gfx950:
+// LayerNorm and the GEGLU gate.  diffusers runs them as separate ATen kernels inside BasicTransformerBlock
+// (reached from threestudio/models/guidance/dreammat_guidance.py:205-292); both are pure bandwidth
+// (LayerNorm: 1 read + 1 write, GEGLU: 2 reads + 1 write of [tokens, C] bf16), so each is one pass with 16 B
+// accesses.  Forward only: the diffusion nets run without autograd in score distillation (the SDS gradient is
+// injected at the latents, dreammat_guidance.py:385-397).
+#include "dm_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// One wave per row, NCH 16-byte chunks per lane held in registers between the two passes (mean, then the
+// centred second moment: the same two-pass arithmetic as ATen's fp32-accumulating kernel).
+template <int NCH>
+__global__ __launch_bounds__(256) void k_layernorm(const __bf16* __restrict__ x, const __bf16* __restrict__ gamma,
+                                                   const __bf16* __restrict__ beta, __bf16* __restrict__ y,
+                                                   long long rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * 4;
+    const int chunks = C / 8;
+    float g[NCH][8], b[NCH][8];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        int ch = lane + 64 * c;
+        bool ok = ch < chunks;
+        bf16x8 gv = *reinterpret_cast<const bf16x8*>(gamma + (ok ? ch : 0) * 8);
+        bf16x8 bv = *reinterpret_cast<const bf16x8*>(beta + (ok ? ch : 0) * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { g[c][k] = (float)gv[k]; b[c][k] = (float)bv[k]; }
+    }
+    const float inv_c = 1.f / (float)C;
+    for (long long r = wave0; r < rows; r += nwaves) {
+        const __bf16* xr = x + r * C;
+        float v[NCH][8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            int ch = lane + 64 * c;
+            bool ok = ch < chunks;
+            bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + (ok ? ch : 0) * 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[c][k] = ok ? (float)xv[k] : 0.f; s += v[c][k]; }
+        }
+        const float mean = wave_sum(s) * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            bool ok = lane + 64 * c < chunks;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { float d = v[c][k] - mean; q += ok ? d * d : 0.f; }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * inv_c + eps);
+        __bf16* yr = y + r * C;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            int ch = lane + 64 * c;
+            if (ch < chunks) {
+                bf16x8 o;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = (__bf16)((v[c][k] - mean) * rstd * g[c][k] + b[c][k]);
+                *reinterpret_cast<bf16x8*>(yr + ch * 8) = o;
+            }
+        }
+    }
+}
+
+// y[r, c] = h[r, c] * gelu(h[r, inner + c])  (exact erf GELU).  The gate is rounded to bf16 before the product,
+// which is what the two-kernel ATen sequence F.gelu(gate) -> mul produces.
+__global__ __launch_bounds__(256) void k_geglu(const __bf16* __restrict__ h, __bf16* __restrict__ y, long long rows,
+                                               int inner) {
+    const int cpr = inner / 8;
+    const long long total = rows * cpr;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        long long r = i / cpr;
+        int c = (int)(i - r * cpr);
+        const __bf16* hr = h + r * 2LL * inner;
+        bf16x8 xv = *reinterpret_cast<const bf16x8*>(hr + c * 8);
+        bf16x8 gv = *reinterpret_cast<const bf16x8*>(hr + inner + c * 8);
+        bf16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float gf = (float)gv[k];
+            float ge = (float)(__bf16)(0.5f * gf * (1.f + erff(gf * 0.70710678118654752440f)));
+            o[k] = (__bf16)((float)xv[k] * ge);
+        }
+        *reinterpret_cast<bf16x8*>(y + r * inner + c * 8) = o;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// x, y [rows, C] bf16 (row-contiguous), gamma/beta [C] bf16; C % 8 == 0, C <= 2048.
+int dm_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, long long rows, int C, float eps,
+                      hipStream_t stream) {
+    if (!x || !gamma || !beta || !y || rows < 0 || C <= 0) return DM_ERR_ARG;
+    if (C % 8 != 0 || C > 2048) return DM_ERR_UNSUPPORTED;
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) return DM_ERR_ARG;
+    if (rows == 0) return DM_OK;
+    const int nch = (C / 8 + 63) / 64;
+    const unsigned grid = (unsigned)std::min<long long>((rows + 3) / 4, 256 * 16);
+    DM_ENTER();
+#define DM_LN(N) hipLaunchKernelGGL(k_layernorm<N>, dim3(grid), dim3(256), 0, stream, (const __bf16*)x, \
+                                    (const __bf16*)gamma, (const __bf16*)beta, (__bf16*)y, rows, C, eps)
+    switch (nch) {
+    case 1: DM_LN(1); break;
+    case 2: DM_LN(2); break;
+    case 3: DM_LN(3); break;
+    default: DM_LN(4); break;
+    }
+#undef DM_LN
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+// h [rows, 2*inner] bf16 (value half | gate half), y [rows, inner] bf16; inner % 8 == 0.
+int dm_geglu_bf16(const void* h, void* y, long long rows, int inner, hipStream_t stream) {
+    if (!h || !y || rows < 0 || inner <= 0) return DM_ERR_ARG;
+    if (inner % 8 != 0) return DM_ERR_UNSUPPORTED;
+    if (((uintptr_t)h | (uintptr_t)y) & 15) return DM_ERR_ARG;
+    if (rows == 0) return DM_OK;
+    const long long total = rows * (inner / 8);
+    const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 256 * 32);
+    DM_ENTER();
+    hipLaunchKernelGGL(k_geglu, dim3(grid), dim3(256), 0, stream, (const __bf16*)h, (__bf16*)y, rows, inner);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+}  // extern "C"

@@ -48,6 +48,41 @@ class HashGridEncoding(nn.Module):
         return hipops.hashgrid_encode(x_world, p, self.spec, self.radius, grad_sink=sink)
 
 
+def _wgrad_splitk(g, h, n_split=512):
+    """dW = g @ h^T for feature-major g [out, N], h [in, N] with N in the millions: one GEMM with K = N runs as a
+    single skinny tile (2.2 ms for 64x32xN=2.6M on MI355X); split the points into `n_split` slabs, one batched
+    GEMM over strided views (no copies), and add the slab results."""
+    N = g.shape[1]
+    n = N // n_split
+    if n < 64:
+        return g @ h.t()
+    g = g.contiguous()
+    h = h.contiguous()
+    Np = n * n_split
+    gp = g[:, :Np].view(g.shape[0], n_split, n).transpose(0, 1)          # [S, out, n]  (row stride N)
+    hp = h[:, :Np].view(h.shape[0], n_split, n).permute(1, 2, 0)         # [S, n, in]   (column stride N)
+    dW = torch.bmm(gp, hp).sum(0)
+    if Np < N:
+        dW = dW + g[:, Np:] @ h[:, Np:].t()
+    return dW
+
+
+class _FeatureMajorLinear(torch.autograd.Function):
+    """y = W @ h for feature-major activations h [in, N]."""
+
+    @staticmethod
+    def forward(ctx, W, h):
+        ctx.save_for_backward(W, h)
+        return W @ h
+
+    @staticmethod
+    def backward(ctx, g):
+        W, h = ctx.saved_tensors
+        dW = _wgrad_splitk(g, h) if ctx.needs_input_grad[0] else None
+        dh = W.t() @ g if ctx.needs_input_grad[1] else None
+        return dW, dh
+
+
 class VanillaMLP(nn.Module):
     def __init__(self, dim_in, dim_out, config):
         super().__init__()
@@ -65,7 +100,7 @@ class VanillaMLP(nn.Module):
             # feature-major (W @ X^T) and hand back an [M, out] view -- same numbers, no transposes
             h = x.t()
             for layer in self.layers:
-                h = layer.weight @ h if isinstance(layer, nn.Linear) else torch.relu(h)
+                h = _FeatureMajorLinear.apply(layer.weight, h) if isinstance(layer, nn.Linear) else torch.relu(h)
             return h.t()
         return self.layers(x)
 

@@ -421,9 +421,10 @@ def attention(q, k, vt, heads, scale=None):
 
 
 # ------------------------------------------------------------------------------------------ convolution
-def conv3x3_nhwc(x_nhwc, w_tap_major, bias, stride=1, pad=(1, 1), out_hw=None):
-    """x [B,H,W,Cin] bf16 contiguous, w [Cout, 9*Cin] bf16 (tap-major) -> y [B,Ho,Wo,Cout] bf16."""
-    _need_cuda(x_nhwc, w_tap_major)
+def conv3x3_nhwc(x_nhwc, w_tap_major, bias, stride=1, pad=(1, 1), out_hw=None, rowbias=None, residual=None):
+    """x [B,H,W,Cin] bf16 contiguous, w [Cout, 9*Cin] bf16 (tap-major) -> y [B,Ho,Wo,Cout] bf16.
+    rowbias [B,Cout] / residual [B,Ho,Wo,Cout] (bf16) are added in the kernel epilogue (Cin % 64 == 0)."""
+    _need_cuda(x_nhwc, w_tap_major, rowbias, residual)
     assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous() and w_tap_major.is_contiguous()
     B, H, W, Cin = x_nhwc.shape
     Cout = w_tap_major.shape[0]
@@ -431,11 +432,15 @@ def conv3x3_nhwc(x_nhwc, w_tap_major, bias, stride=1, pad=(1, 1), out_hw=None):
         out_hw = ((H + 2 * pad[0] - 3) // stride + 1, (W + 2 * pad[1] - 3) // stride + 1)
     Ho, Wo = out_hw
     y = torch.empty(B, Ho, Wo, Cout, device=x_nhwc.device, dtype=torch.bfloat16)
+    if rowbias is not None:
+        assert rowbias.dtype == torch.bfloat16 and rowbias.is_contiguous() and tuple(rowbias.shape) == (B, Cout)
+    if residual is not None:
+        assert residual.dtype == torch.bfloat16 and residual.is_contiguous() and residual.shape == y.shape
     with _Timed(f"conv3x3[{Cin}->{Cout}@{Ho}x{Wo},s{stride}]", 2.0 * B * Ho * Wo * Cout * 9 * Cin):
-        check(_lib.lib().dm_conv3x3_nhwc_bf16(x_nhwc.data_ptr(), w_tap_major.data_ptr(),
-                                              bias.data_ptr() if bias is not None else None, y.data_ptr(), B, H, W,
-                                              Cin, Ho, Wo, Cout, stride, pad[0], pad[1], _stream()),
-              "dm_conv3x3_nhwc_bf16")
+        check(_lib.lib().dm_conv3x3_nhwc_bf16_fused(
+            x_nhwc.data_ptr(), w_tap_major.data_ptr(), bias.data_ptr() if bias is not None else None,
+            rowbias.data_ptr() if rowbias is not None else None, residual.data_ptr() if residual is not None else None,
+            y.data_ptr(), B, H, W, Cin, Ho, Wo, Cout, stride, pad[0], pad[1], _stream()), "dm_conv3x3_nhwc_bf16_fused")
     return y
 
 
@@ -522,6 +527,32 @@ def groupnorm_nhwc(x_nhwc, gamma, beta, eps, act):
     if torch.is_grad_enabled() and x_nhwc.requires_grad:
         return _GroupNormAct.apply(x_nhwc, gamma, beta, eps, act)
     return _gn_fwd(x_nhwc, gamma, beta, eps, act)[0]
+
+
+# ------------------------------------------------------------------------------------------ transformer rows
+def layernorm_rows(x, gamma, beta, eps):
+    """LayerNorm over the last dim of a contiguous bf16 tensor [..., C] (forward only)."""
+    _need_cuda(x, gamma, beta)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and gamma.dtype == torch.bfloat16
+    C = x.shape[-1]
+    rows = x.numel() // C
+    y = torch.empty_like(x)
+    with _Timed(f"layernorm[C={C}]", 4.0 * rows * C):
+        check(_lib.lib().dm_layernorm_bf16(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), rows, C,
+                                           float(eps), _stream()), "dm_layernorm_bf16")
+    return y
+
+
+def geglu_rows(h):
+    """h [..., 2*inner] bf16 contiguous -> h[..., :inner] * gelu(h[..., inner:]) (forward only)."""
+    _need_cuda(h)
+    assert h.dtype == torch.bfloat16 and h.is_contiguous() and h.shape[-1] % 2 == 0
+    inner = h.shape[-1] // 2
+    rows = h.numel() // (2 * inner)
+    y = torch.empty(*h.shape[:-1], inner, device=h.device, dtype=h.dtype)
+    with _Timed(f"geglu[inner={inner}]", 6.0 * rows * inner):
+        check(_lib.lib().dm_geglu_bf16(h.data_ptr(), y.data_ptr(), rows, inner, _stream()), "dm_geglu_bf16")
+    return y
 
 
 # ------------------------------------------------------------------------------------------ optimiser

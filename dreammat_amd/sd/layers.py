@@ -59,10 +59,26 @@ class Conv2d(nn.Conv2d):
         Ho, Wo = (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1
         return y.view(B, Ho, Wo, Cout).permute(0, 3, 1, 2)
 
+    def _frozen(self):
+        return not (torch.is_grad_enabled() and self.weight.requires_grad)
+
     def mfma_ok(self, x):
         Cout, Cin, kh, kw = self.weight.shape
         return (CONV_BACKEND == "mfma" and x.is_cuda and x.dtype == torch.bfloat16 and kh == 3 and kw == 3
-                and Cin % 32 == 0 and Cout % 64 == 0 and not self.weight.requires_grad)
+                and Cin % 32 == 0 and Cout % 64 == 0 and self._frozen())
+
+    def fused_ok(self, x):
+        """conv + per-image channel bias + residual in one kernel: stride-1 LDS-DMA path, nothing needs autograd."""
+        return (self.mfma_ok(x) and self.weight.shape[1] % 64 == 0 and self.stride == (1, 1) and self.padding == (1, 1)
+                and not (torch.is_grad_enabled() and x.requires_grad))
+
+    def forward_fused(self, x, rowbias=None, residual=None):
+        """y = conv(x) + bias + rowbias[:, :, None, None] + residual (logical NCHW in / out, NHWC in memory)."""
+        w_fwd, _ = self._prepared()
+        xn = x.permute(0, 2, 3, 1).contiguous()
+        rn = residual.permute(0, 2, 3, 1).contiguous() if residual is not None else None
+        rb = rowbias.contiguous() if rowbias is not None else None
+        return hipops.conv3x3_nhwc(xn, w_fwd, self.bias, 1, (1, 1), None, rb, rn).permute(0, 3, 1, 2)
 
     def forward_strided_asym(self, x):
         """stride-2 conv over F.pad(x, (0,1,0,1)) (AutoencoderKL downsampler) without materialising the pad."""
@@ -81,7 +97,7 @@ class Conv2d(nn.Conv2d):
         Cout, Cin, kh, kw = self.weight.shape
         needs_grad = torch.is_grad_enabled() and x.requires_grad
         ok = (CONV_BACKEND == "mfma" and x.dtype == torch.bfloat16 and kh == 3 and kw == 3 and Cin % 32 == 0
-              and Cout % 64 == 0 and self.stride[0] == self.stride[1] and not self.weight.requires_grad
+              and Cout % 64 == 0 and self.stride[0] == self.stride[1] and self._frozen()
               and (not needs_grad or (self.stride[0] == 1 and self.padding == (1, 1) and Cin % 64 == 0)))
         if not ok:
             return self._forward_gemm(x)
@@ -101,12 +117,26 @@ def group_norm_act(norm: nn.GroupNorm, x, silu: bool):
     """act(GroupNorm(x)) for a logical-NCHW tensor.  GPU bf16 (32 groups) -> fused NHWC HIP kernel (the
     activation stays channels-last, which is what the implicit-GEMM conv consumes); otherwise torch."""
     if (x.is_cuda and x.dtype == torch.bfloat16 and norm.num_groups == 32 and CONV_BACKEND == "mfma"
-            and not norm.weight.requires_grad):
+            and not (torch.is_grad_enabled() and norm.weight.requires_grad)):
         xn = x.permute(0, 2, 3, 1).contiguous()                  # no-op for channels-last activations
         y = hipops.groupnorm_nhwc(xn, norm.weight, norm.bias, norm.eps, 1 if silu else 0)
         return y.permute(0, 3, 1, 2)
     y = norm(x)
     return F.silu(y) if silu else y
+
+
+def _rows_kernel_ok(x, *params):
+    """token-matrix HIP kernels (LayerNorm, GEGLU) are forward-only: used when nothing on this path needs autograd
+    (the diffusion nets in score distillation); otherwise the ATen ops run on the same device."""
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+    return x.is_cuda and x.dtype == torch.bfloat16 and CONV_BACKEND == "mfma" and not needs_grad
+
+
+def layer_norm(norm: nn.LayerNorm, x):
+    C = x.shape[-1]
+    if _rows_kernel_ok(x, norm.weight) and C % 8 == 0 and C <= 2048:
+        return hipops.layernorm_rows(x.contiguous(), norm.weight, norm.bias, norm.eps)
+    return norm(x)
 
 
 def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0.0, max_period=10000):
@@ -192,7 +222,10 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        x, gate = self.proj(x).chunk(2, dim=-1)
+        h = self.proj(x)
+        if _rows_kernel_ok(h) and h.shape[-1] % 16 == 0:
+            return hipops.geglu_rows(h.contiguous())
+        x, gate = h.chunk(2, dim=-1)
         return x * F.gelu(gate)
 
 
@@ -216,9 +249,9 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, x, context):
-        x = self.attn1(self.norm1(x)) + x
-        x = self.attn2(self.norm2(x), context) + x
-        return self.ff(self.norm3(x)) + x
+        x = self.attn1(layer_norm(self.norm1, x)) + x
+        x = self.attn2(layer_norm(self.norm2, x), context) + x
+        return self.ff(layer_norm(self.norm3, x)) + x
 
 
 class Transformer2DModel(nn.Module):
@@ -258,9 +291,18 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = Conv2d(in_ch, out_ch, 1) if in_ch != out_ch else None
 
     def forward(self, x, temb=None):
-        h = self.conv1(group_norm_act(self.norm1, x, True))
-        if self.time_emb_proj is not None:
-            h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
+        h = group_norm_act(self.norm1, x, True)
+        tproj = self.time_emb_proj(F.silu(temb)) if self.time_emb_proj is not None else None
+        if self.conv1.fused_ok(h) and self.conv2.fused_ok(h):
+            # inference path (diffusion nets in SDS): both adds ride in the conv epilogues
+            h = self.conv1.forward_fused(h, rowbias=tproj)
+            h = group_norm_act(self.norm2, h, True)
+            if self.conv_shortcut is not None:
+                x = self.conv_shortcut(x)
+            return self.conv2.forward_fused(h, residual=x)
+        h = self.conv1(h)
+        if tproj is not None:
+            h = h + tproj[:, :, None, None]
         h = self.conv2(group_norm_act(self.norm2, h, True))
         if self.conv_shortcut is not None:
             x = self.conv_shortcut(x)

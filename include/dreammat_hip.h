@@ -176,6 +176,12 @@ int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* ou
  * Cin/Cout swapped. */
 int dm_conv3x3_nhwc_bf16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin,
                          int Hout, int Wout, int Cout, int stride, int pad_y, int pad_x, dm_stream_t stream);
+/* Same convolution with the two adds diffusers' ResnetBlock2D performs around it folded into the epilogue:
+ * rowbias [B,Cout] bf16 or NULL (`hidden_states + temb[:, :, None, None]`), residual [B,Hout,Wout,Cout] bf16 or
+ * NULL (`input_tensor + hidden_states`); y = conv + bias + rowbias + residual, rounded once.  Cin % 64 == 0. */
+int dm_conv3x3_nhwc_bf16_fused(const void* x, const void* w, const void* bias, const void* rowbias, const void* residual,
+                               void* y, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int stride,
+                               int pad_y, int pad_x, dm_stream_t stream);
 
 /* ---- normalisation ----------------------------------------------------------------------- */
 /* GroupNorm(32) [+ SiLU] of the ResnetBlock2D / Transformer2DModel / conv_norm_out layers of the same nets,
@@ -186,6 +192,14 @@ int dm_groupnorm_nhwc_fwd(const void* x, const void* gamma, const void* beta, vo
                           int C, float eps, int act, dm_stream_t stream);
 int dm_groupnorm_nhwc_bwd(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* ws,
                           int B, int HW, int C, float eps, int act, dm_stream_t stream);
+
+/* LayerNorm and the GEGLU gate of diffusers' BasicTransformerBlock (norm1/2/3, ff.net.0) inside the same nets,
+ * forward only (the diffusion nets run without autograd in SDS, dreammat_guidance.py:385-397).
+ * layernorm: x,y [rows,C] bf16, gamma/beta [C] bf16, C % 8 == 0, C <= 2048.
+ * geglu:     h [rows, 2*inner] bf16 = (value | gate), y [rows, inner] = value * gelu_erf(gate), inner % 8 == 0. */
+int dm_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, long long rows, int C, float eps,
+                      dm_stream_t stream);
+int dm_geglu_bf16(const void* h, void* y, long long rows, int inner, dm_stream_t stream);
 
 /* ---- optimiser ---------------------------------------------------------------------------- */
 /* torch.optim.Adam step (configs/dreammat.yaml:110-115 via systems/utils.py:34-53) over one flat

@@ -337,9 +337,13 @@ def test_unet_controlnet_gpu_fp32_and_bf16_hip_attention(dev):
             d, m = cn(x.to(dev).bfloat16(), t.to(dev), ctx.to(dev).bfloat16(), cond.to(dev).bfloat16(), 1.0)
             yb = unet(x.to(dev).bfloat16(), t.to(dev), ctx.to(dev).bfloat16(), d, m).float().cpu()
             torch.cuda.synchronize()
-            n_attn = sum(v["launches"] for k, v in hipops.kernel_times().items() if k.startswith("attention"))
+            kt = hipops.kernel_times()
+            n_attn = sum(v["launches"] for k, v in kt.items() if k.startswith("attention"))
+            n_ln = sum(v["launches"] for k, v in kt.items() if k.startswith("layernorm"))
+            n_gg = sum(v["launches"] for k, v in kt.items() if k.startswith("geglu"))
             hipops.enable_kernel_timing(False)
         assert n_attn == 46, n_attn                    # 2x(16 UNet + 7 ControlNet) attention launches, all on MFMA
+        assert n_ln == 69 and n_gg == 23, (n_ln, n_gg)  # 3 LayerNorms + 1 GEGLU per transformer block, HIP kernels
         rel = ((yb - oy).abs().max() / oy.abs().max()).item()
         assert rel < 6e-2, (arch_name, rel)
 
@@ -519,10 +523,12 @@ def test_groupnorm_silu_nhwc_vs_fp32_reference(dev, B, C, H, W, act):
     assert gerr < 3e-2 * max(1.0, xr.grad.abs().max().item()), gerr
 
 
-@pytest.mark.parametrize("tile", ["128", "256"])
-@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 320, 320, 32, 32), (1, 128, 128, 40, 24), (3, 64, 192, 16, 16)])
+@pytest.mark.parametrize("tile", ["128", "256", "512", "320", "640"])
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 320, 320, 32, 32), (1, 128, 128, 40, 24), (3, 64, 192, 16, 16),
+                                            (1, 64, 640, 24, 24)])
 def test_conv3x3_dma_tile_variants(dev, monkeypatch, tile, B, Cin, Cout, H, W):
-    """both tile shapes of the LDS-DMA conv kernel (incl. the ragged last Cout tile: 320 = 2.5 x 128, 192 = 1.5 x 128)."""
+    """every tile shape of the LDS-DMA conv kernel (128x{64,128}, 256x128, 256x256 / 256x320 / 512x128 [2-stage ring]), incl.
+    ragged last Cout tiles (320 = 2.5 x 128, 192 = 1.5 x 128, 640 = 2.5 x 256 = 2 x 320) and ragged M."""
     monkeypatch.setenv("DREAMMAT_CONV_TILE", tile)
     torch.manual_seed(1)
     x = torch.randn(B, H, W, Cin).bfloat16()
@@ -660,3 +666,54 @@ def test_vae_encoder_bf16_gradient_vs_fp32_oracle(dev):
     rel_f = ((mg.float().cpu() - mean).abs().max() / mean.abs().max()).item()
     rel_g = ((xg.grad.cpu() - xr.grad).abs().max() / xr.grad.abs().max()).item()
     assert rel_f < 5e-2 and rel_g < 8e-2, (rel_f, rel_g)
+
+
+@pytest.mark.parametrize("rows,C", [(1000, 320), (77, 640), (513, 1280), (5, 2048), (64, 8)])
+def test_layernorm_rows_vs_torch(dev, rows, C):
+    torch.manual_seed(0)
+    x = (torch.randn(rows, C) * 3 + 1.5).bfloat16()
+    g = torch.randn(C).bfloat16(); b = torch.randn(C).bfloat16()
+    y = hipops.layernorm_rows(x.to(dev), g.to(dev), b.to(dev), 1e-5).float().cpu()
+    ref = torch.nn.functional.layer_norm(x.float(), (C,), g.float(), b.float(), 1e-5)
+    assert (y - ref).abs().max() <= 2e-2 * ref.abs().max()              # one bf16 rounding of the output
+    ref_bf = torch.nn.functional.layer_norm(x.to(dev), (C,), g.to(dev), b.to(dev), 1e-5).float().cpu()
+    assert ((y - ref_bf).abs() > 1e-6).float().mean() < 0.15           # ATen's bf16 kernel: same up to 1-ulp ties
+    assert (y - ref_bf).abs().max() <= 1.6e-2 * ref.abs().max()
+
+
+@pytest.mark.parametrize("rows,inner", [(4096, 1280), (77, 2560), (3, 8)])
+def test_geglu_rows_vs_torch(dev, rows, inner):
+    torch.manual_seed(0)
+    h = (torch.randn(rows, 2 * inner) * 2).bfloat16()
+    y = hipops.geglu_rows(h.to(dev)).float().cpu()
+    xv, gate = h.float().chunk(2, dim=-1)
+    ref = xv * torch.nn.functional.gelu(gate)
+    assert (y - ref).abs().max() <= 2e-2 * ref.abs().max()
+    hb = h.to(dev)
+    xb, gb = hb.chunk(2, dim=-1)
+    ref_bf = (xb * torch.nn.functional.gelu(gb)).float().cpu()
+    assert ((y - ref_bf).abs() > 1e-6).float().mean() < 0.05
+    assert (y - ref_bf).abs().max() <= 1.6e-2 * ref.abs().max()
+
+
+@pytest.mark.parametrize("tile", ["", "256", "512", "320", "640"])
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(12, 64, 128, 8, 8), (3, 128, 320, 20, 12)])
+def test_conv3x3_fused_epilogue(dev, monkeypatch, tile, B, Cin, Cout, H, W):
+    """ResnetBlock2D's `+ temb[:, :, None, None]` and `+ input_tensor` folded into the conv epilogue; workgroup tiles
+    that span several images (8x8 images, 256/512-row tiles) exercise the per-row image lookup."""
+    if tile:
+        monkeypatch.setenv("DREAMMAT_CONV_TILE", tile)
+    torch.manual_seed(2)
+    x = torch.randn(B, H, W, Cin).bfloat16()
+    w = (torch.randn(Cout, Cin, 3, 3) * 0.05).bfloat16()
+    bias = torch.randn(Cout).bfloat16()
+    rowbias = torch.randn(B, Cout).bfloat16()
+    res = torch.randn(B, H, W, Cout).bfloat16()
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    y = hipops.conv3x3_nhwc(x.to(dev), wt.to(dev), bias.to(dev), 1, (1, 1), None, rowbias.to(dev), res.to(dev)).float().cpu()
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias.float(), padding=1).permute(0, 2, 3, 1)
+    ref = ref + rowbias.float()[:, None, None, :] + res.float()
+    err = (y - ref).abs().max().item()
+    assert err < 2e-2 * ref.abs().max().item() + 1e-2, err
+    y1 = hipops.conv3x3_nhwc(x.to(dev), wt.to(dev), bias.to(dev), 1, (1, 1), None, rowbias.to(dev), None).float().cpu()
+    assert (y1 - (ref - res.float())).abs().max().item() < 2e-2 * ref.abs().max().item() + 1e-2

@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--skip-attn", action="store_true")
+    ap.add_argument("--conv-tiles", action="store_true", help="time every conv tile variant per shape")
+    ap.add_argument("--only-conv", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -52,6 +54,31 @@ def main():
         r.update(kw)
         res.append(r)
         print(json.dumps(r), flush=True)
+
+    def conv_section():
+        from dreammat_amd.sd import layers
+        for (Bq, Cin, Cout, Hh, Ww) in [(24, 320, 320, 64, 64), (24, 640, 640, 32, 32), (24, 1280, 1280, 16, 16),
+                                        (24, 960, 320, 64, 64), (8, 128, 128, 512, 512), (8, 256, 256, 256, 256),
+                                        (8, 512, 512, 64, 64)]:
+            x = torch.randn(Bq, Hh, Ww, Cin, device=dev, dtype=torch.bfloat16)
+            w = torch.randn(Cout, 9 * Cin, device=dev, dtype=torch.bfloat16) * 0.02
+            b = torch.zeros(Cout, device=dev, dtype=torch.bfloat16)
+            for tile in (["default"] + (["256", "512", "320", "640"] if a.conv_tiles else [])):
+                if tile == "default":
+                    os.environ.pop("DREAMMAT_CONV_TILE", None)
+                else:
+                    os.environ["DREAMMAT_CONV_TILE"] = tile
+                rec(f"conv3x3 B{Bq} {Cin}->{Cout} @{Hh}x{Ww}" + ("" if tile == "default" else f" tile{tile}"),
+                    timeit(lambda: hipops.conv3x3_nhwc(x, w, b), max(3, a.iters // 3), 2),
+                    flops=2.0 * Bq * Hh * Ww * Cout * 9 * Cin)
+            os.environ.pop("DREAMMAT_CONV_TILE", None)
+
+    if a.only_conv:
+        conv_section()
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/kernel_bench_conv.json", "w") as fh:
+            json.dump(res, fh, indent=1)
+        return
 
     pos = hipops.vertex_transform(v, mvp)
     ctx = hipops.RasterContext(dev)
@@ -128,15 +155,7 @@ def main():
             rec(f"attention B{Bq} h{h} Sq{Sq} Skv{Skv} D{D}", timeit(lambda: hipops.attention(q, k, vt, h), a.iters),
                 flops=4.0 * Bq * Sq * Skv * C)
     if not a.skip_attn:
-        from dreammat_amd.sd import layers
-        for (Bq, Cin, Cout, Hh, Ww) in [(24, 320, 320, 64, 64), (24, 640, 640, 32, 32), (24, 1280, 1280, 16, 16),
-                                        (24, 960, 320, 64, 64), (8, 128, 128, 512, 512), (8, 256, 256, 256, 256),
-                                        (8, 512, 512, 64, 64)]:
-            x = torch.randn(Bq, Hh, Ww, Cin, device=dev, dtype=torch.bfloat16)
-            w = torch.randn(Cout, 9 * Cin, device=dev, dtype=torch.bfloat16) * 0.02
-            b = torch.zeros(Cout, device=dev, dtype=torch.bfloat16)
-            rec(f"conv3x3 B{Bq} {Cin}->{Cout} @{Hh}x{Ww}", timeit(lambda: hipops.conv3x3_nhwc(x, w, b), max(3, a.iters // 3), 2),
-                flops=2.0 * Bq * Hh * Ww * Cout * 9 * Cin)
+        conv_section()
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/kernel_bench.json", "w") as fh:
         json.dump(res, fh, indent=1)

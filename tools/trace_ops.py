@@ -33,4 +33,16 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     torch.cuda.synchronize()
 tab = prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=60, max_name_column_width=40, max_shapes_column_width=90)
 open("gpurun_out/trace_ops.txt", "w").write(tab)
-print(tab[:200])
+rows = []
+for e in prof.key_averages(group_by_input_shape=True):
+    t = getattr(e, "self_device_time_total", None)
+    if t is None:
+        t = e.self_cuda_time_total
+    if t > 0:
+        rows.append((t, e.count, e.key, str(e.input_shapes)))
+rows.sort(reverse=True)
+with open("gpurun_out/trace_ops.csv", "w") as f:
+    f.write("self_device_us,calls,name,shapes\n")
+    for t, c, k, sh in rows[:500]:
+        f.write(f"{t:.0f},{c},\"{k[:90]}\",\"{sh[:160]}\"\n")
+print("total device us", sum(r[0] for r in rows))
