@@ -16,6 +16,7 @@
 // swapped (prepared once on the host side).  Requirements: Cin % 32 == 0, Cout % 64 == 0.
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "dm_common.h"
 
@@ -36,6 +37,9 @@ struct ConvArgs {
     int B, Hin, Win, Cin, Hout, Wout, Cout;
     int stride, pad_y, pad_x;
     long long M;         // B*Hout*Wout
+    // LDS-DMA kernels: an M tile is a 2-D patch of TW x (BMT/TW) output pixels of the "tall image" [B*Hout, Wout]
+    int tw_log2;         // log2(TW)
+    int tiles_x;         // ceil(Wout / TW)
 };
 
 constexpr int BM = 128;
@@ -217,7 +221,14 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     }
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int wm = wave / WNW, wn = wave % WNW;
-    const long long m0 = mt * BMT;
+    // M tile = patch of TW x TH output pixels: rows Y0.. of the tall image [B*Hout, Wout], columns X0..
+    // (tile row r -> pixel (Y0 + r / TW, X0 + r % TW)).  A 1-D run of BMT pixels re-reads 3 full image rows per
+    // tile; the patch re-reads a one-pixel halo: (TH+2)(TW+2)/(TH*TW) = 1.2-1.3x.
+    const int TWm = (1 << a.tw_log2) - 1;
+    const long long tile_y = mt / a.tiles_x;
+    const long long Y0 = tile_y * (BMT >> a.tw_log2);
+    const int X0 = (int)(mt - tile_y * a.tiles_x) << a.tw_log2;
+    const long long rows_total = (long long)a.B * a.Hout;
     const int n0 = nt * BN;
     const int lrow = lane >> 3, lslot = lane & 7;      // this lane's row / 16 B slot inside one DMA instruction
     const unsigned long long zero = (unsigned long long)g_zero_page;
@@ -233,15 +244,14 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i) {
         int row = wave * (BMT / NW) + 8 * i + lrow;
-        long long m = m0 + row;
-        bool ok = m < a.M;
-        long long mm = ok ? m : 0;
-        int hw = a.Hout * a.Wout;
-        int b = (int)(mm / hw);
-        int rem = (int)(mm - (long long)b * hw);
-        int yo = rem / a.Wout;
+        long long Y = Y0 + (row >> a.tw_log2);
+        int xo = X0 + (row & TWm);
+        bool ok = Y < rows_total && xo < a.Wout;
+        long long Yc = ok ? Y : 0;
+        int b = (int)(Yc / a.Hout);
+        int yo = (int)(Yc - (long long)b * a.Hout);
         int y0 = yo * a.stride - a.pad_y;
-        int x0 = (rem - yo * a.Wout) * a.stride - a.pad_x;
+        int x0 = (ok ? xo : 0) * a.stride - a.pad_x;
         a_ptr[i] = a.x + (((long long)b * a.Hin + y0) * a.Win + x0) * a.Cin + (lslot ^ ((row >> 1) & 7)) * 8;
         unsigned mk = 0;
 #pragma unroll
@@ -263,31 +273,43 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     const int kt_per_tap = a.Cin / BK;
     const int n_steps = 9 * kt_per_tap;
 
-    // issue cursor (wave-uniform => SGPRs): K-step i_s = (tap i_tap, channel block i_kc)
-    int i_s = 0, i_tap = 0, i_kc = 0;
-    auto issue = [&](int stage) {
+    // issue cursor (wave-uniform => SGPRs).  K order = channel block OUTER, tap INNER: the 9 taps of one 64-channel
+    // block re-read the same 128-byte line of every halo pixel back to back, so the per-CU L2 working set is
+    // (TH+2)(TW+2) lines (41 KB for 16x16) whatever Cin is.  Tap-outer order swept all Cin between re-reads
+    // (83 KB-830 KB per CU, x32 CUs per 4 MB L2): rocprofv3 FETCH_SIZE showed 2.1x (Cin=128) to 6.3x (Cin=320)
+    // the compulsory bytes and a 66-76 % L2 hit rate (profiles/r01_pmc_conv_v0.json).
+    int i_tap = 0, i_kc = 0;
+    long long toff = 0, woff = 0;                      // element offsets of the step being issued
+    unsigned bit = 1u;
+    auto cursor_set = [&]() {
         const int dy = (i_tap * 11) >> 5, dx = i_tap - 3 * dy;                      // tap / 3, tap % 3 for tap < 9
-        const long long toff = (long long)(dy * a.Win + dx) * a.Cin + i_kc * BK;     // elements from a_ptr
-        const long long woff = (long long)i_s * BK;
-        const unsigned bit = 1u << i_tap;
+        toff = (long long)(dy * a.Win + dx) * a.Cin + i_kc * BK;                     // from a_ptr
+        woff = (long long)i_tap * a.Cin + i_kc * BK;                                 // weights are [Cout][tap][Cin]
+        bit = 1u << i_tap;
+    };
+    auto cursor_next = [&]() { if (++i_tap == 9) { i_tap = 0; ++i_kc; } };
+    // DMA piece p of the step at the cursor (p < A_INSTR: 8 activation rows, else 8 weight rows) into `stage`
+    auto piece = [&](int p, int stage) {
         char* ab = smem + stage * STAGE;
-        char* bb = ab + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < A_INSTR; ++i) {
+        if (p < A_INSTR) {
             // select, never a branch: the DMA must execute with ALL lanes active (an inactive lane would
             // leave its LDS slot stale); out-of-image taps read the 16-byte zero page
-            const void* src = (a_mask[i] & bit) ? (const void*)(a_ptr[i] + toff) : (const void*)zero;
+            const void* src = (a_mask[p] & bit) ? (const void*)(a_ptr[p] + toff) : (const void*)zero;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(ab + (wave * (BMT / NW) + 8 * i) * ROWB),
+                                             (__attribute__((address_space(3))) void*)(ab + (wave * (BMT / NW) + 8 * p) * ROWB),
+                                             16, 0, 0);
+        } else {
+            const int q = p - A_INSTR;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[q] + woff),
+                                             (__attribute__((address_space(3))) void*)(ab + A_BYTES + (wave * (BN / NW) + 8 * q) * ROWB),
                                              16, 0, 0);
         }
+    };
+    auto issue = [&](int stage) {
+        cursor_set();
 #pragma unroll
-        for (int i = 0; i < B_INSTR; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[i] + woff),
-                                             (__attribute__((address_space(3))) void*)(bb + (wave * (BN / NW) + 8 * i) * ROWB),
-                                             16, 0, 0);
-        ++i_s;
-        if (++i_kc == kt_per_tap) { i_kc = 0; ++i_tap; }
+        for (int p = 0; p < L; ++p) piece(p, stage);
+        cursor_next();
     };
 
     f32x16 acc[MT][NT];
@@ -303,34 +325,69 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     // everybody has finished reading stage (s-1) % NSTAGE, which is the stage the next issue overwrites.
     issue(0);
     if (NSTAGE == 3 && n_steps > 1) issue(1);
-    int stage = 0;
-    for (int s = 0; s < n_steps; ++s) {
-        if (NSTAGE == 3 && s + 1 < n_steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int st2 = stage + NSTAGE - 1; if (st2 >= NSTAGE) st2 -= NSTAGE;
-        if (s + NSTAGE - 1 < n_steps) issue(st2);
+    // One K-step: 4 chunks of 16 K.  Chunk kk (a) reads the fragments of chunk kk+1 into the other register set,
+    // (b) issues its quarter of the NEXT stage's DMA pieces, (c) runs its MT*NT MFMAs on fragments that were read
+    // one chunk earlier -- so LDS latency and the DMA issue time (60-180 cycles per 1 KB piece) sit under MFMA
+    // execution instead of in front of it (the first version issued all pieces, then read, then multiplied:
+    // SQ_WAIT_ANY 39 %, MFMA busy 29 %, profiles/r01_pmc_conv_v0.json).
+    auto read_frags = [&](int stage, int kk, bf16x8 (&af)[MT], bf16x8 (&bf)[NT]) {
         const char* ab = smem + stage * STAGE;
         const char* bb = ab + A_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8 af[MT], bf[NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                int r = TM * wm + 32 * i + l31;
-                af[i] = *reinterpret_cast<const bf16x8*>(ab + r * ROWB + (((2 * kk + hi) ^ ((r >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                int r = TN * wn + 32 * j + l31;
-                bf[j] = *reinterpret_cast<const bf16x8*>(bb + r * ROWB + (((2 * kk + hi) ^ ((r >> 1) & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < MT; ++i) {
+            int r = TM * wm + 32 * i + l31;
+            af[i] = *reinterpret_cast<const bf16x8*>(ab + r * ROWB + (((2 * kk + hi) ^ ((r >> 1) & 7)) << 4));
         }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            int r = TN * wn + 32 * j + l31;
+            bf[j] = *reinterpret_cast<const bf16x8*>(bb + r * ROWB + (((2 * kk + hi) ^ ((r >> 1) & 7)) << 4));
+        }
+    };
+    auto mma = [&](const bf16x8 (&af)[MT], const bf16x8 (&bf)[NT]) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    };
+    auto kstep = [&](int stage, int st_next, auto issue_tag) {
+        constexpr bool ISSUE = decltype(issue_tag)::value;
+        // 3-deep ring: the pieces have a whole extra step to land, spread them over all 4 chunks.  2-deep ring:
+        // they are needed at the next barrier, so the last chunk issues nothing (>= a quarter step of lead time)
+        constexpr int NCH = (NSTAGE == 2) ? 3 : 4;
+        auto pieces = [&](int kk) {
+            if (ISSUE && kk < NCH) {
+#pragma unroll
+                for (int p = kk; p < L; p += NCH) piece(p, st_next);
+            }
+        };
+        bf16x8 a0[MT], b0[NT], a1[MT], b1[NT];         // two fragment sets, used alternately (named, not indexed:
+        if (ISSUE) cursor_set();                       // a parity-indexed array is not promoted to registers)
+        read_frags(stage, 0, a0, b0);
+        read_frags(stage, 1, a1, b1); pieces(0); mma(a0, b0); __builtin_amdgcn_sched_barrier(0);
+        read_frags(stage, 2, a0, b0); pieces(1); mma(a1, b1); __builtin_amdgcn_sched_barrier(0);
+        read_frags(stage, 3, a1, b1); pieces(2); mma(a0, b0); __builtin_amdgcn_sched_barrier(0);
+        pieces(3); mma(a1, b1);
+        if (ISSUE) cursor_next();
+    };
+    // main loop (every step issues the DMAs of step s + NSTAGE - 1) and drain (nothing left to issue) are SEPARATE
+    // loops: with both bodies under one loop the register allocator gave each its own accumulator set
+    int stage = 0, s = 0;
+    const int n_main = n_steps - (NSTAGE - 1);
+    for (; s < n_main; ++s) {
+        if (NSTAGE == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int st2 = stage + NSTAGE - 1; if (st2 >= NSTAGE) st2 -= NSTAGE;
+        kstep(stage, st2, std::true_type{});
+        stage = stage + 1; if (stage >= NSTAGE) stage = 0;
+    }
+    for (; s < n_steps; ++s) {
+        if (NSTAGE == 3 && s + 1 < n_steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        kstep(stage, 0, std::false_type{});
         stage = stage + 1; if (stage >= NSTAGE) stage = 0;
     }
 
@@ -343,20 +400,22 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
         ncol[j] = n0 + TN * wn + 32 * j + l31;
         bv[j] = (a.bias && ncol[j] < a.Cout) ? (float)a.bias[ncol[j]] : 0.f;
     }
-    const int hw = a.Hout * a.Wout;
-    const int img0 = (int)(m0 / hw);                   // image of the tile's first row (wave-uniform)
-    const int rem0 = (int)(m0 - (long long)img0 * hw);
+    const int img0 = (int)(Y0 / a.Hout);               // image of the patch's first row (wave-uniform)
+    const int rem0 = (int)(Y0 - (long long)img0 * a.Hout);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int d = TM * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const long long m = m0 + d;
-            if (m >= a.M) continue;
+            const int ty = d >> a.tw_log2;
+            const long long Y = Y0 + ty;
+            const int xo = X0 + (d & TWm);
+            if (Y >= rows_total || xo >= a.Wout) continue;
+            const long long m = Y * a.Wout + xo;       // = (b*Hout + yo)*Wout + xo
             const __bf16* rb = nullptr;
             if (a.rowbias) {
-                int img = img0, t = rem0 + d;
-                while (t >= hw) { t -= hw; ++img; }    // a tile spans at most BMT / hw + 1 images
+                int img = img0, t = rem0 + ty;
+                while (t >= a.Hout) { t -= a.Hout; ++img; }     // a patch spans at most TH / Hout + 1 images
                 rb = a.rowbias + (long long)img * a.Cout;
             }
 #pragma unroll
@@ -371,7 +430,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
 }
 
 template <int BMT, int BN, int NW, int WMW, int NSTAGE>
-int launch_conv_dma(const ConvArgs& a, hipStream_t stream) {
+int launch_conv_dma(const ConvArgs& a_in, hipStream_t stream) {
     constexpr int LDS = NSTAGE * (BMT + BN) * 128;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
@@ -381,7 +440,14 @@ int launch_conv_dma(const ConvArgs& a, hipStream_t stream) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    long long n_mt = (a.M + BMT - 1) / BMT;
+    ConvArgs a = a_in;
+    // patch width: 16 output pixels (or the next power of two >= Wout for narrower maps), height BMT / TW
+    int tw_log2 = 4;
+    while (tw_log2 > 0 && (1 << (tw_log2 - 1)) >= a.Wout) --tw_log2;
+    a.tw_log2 = tw_log2;
+    a.tiles_x = (a.Wout + (1 << tw_log2) - 1) >> tw_log2;
+    const int TH = BMT >> tw_log2;
+    long long n_mt = (((long long)a.B * a.Hout + TH - 1) / TH) * a.tiles_x;
     int n_nt = (a.Cout + BN - 1) / BN;
     long long blocks = ((n_mt * n_nt + 7) / 8) * 8;
     if (blocks > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
@@ -448,9 +514,9 @@ int dm_conv3x3_nhwc_bf16_fused(const void* x, const void* w, const void* bias, c
         auto n_wg = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
         if (!tile) {
             if (!(Cout >= 128 && a.M >= 2048)) tile = 128;
-            else if (Cout % 320 == 0 && Cout % 256 != 0 && n_wg(256, 320) >= 160) tile = 320;
             else if (Cout % 256 == 0 && n_wg(256, 256) >= 200) tile = 512;
-            else if (Cout == 128 && n_wg(512, 128) >= 256) tile = 640;
+            else if ((Cout == 128 || Cout == 640) && n_wg(512, 128) >= 200) tile = 640;
+            else if (Cout % 320 == 0 && Cout % 256 != 0 && n_wg(256, 320) >= 160) tile = 320;
             else tile = 256;
         }
         switch (tile) {

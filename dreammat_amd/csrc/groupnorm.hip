@@ -42,14 +42,26 @@ __device__ __forceinline__ void load8(const float* p, float* o) {
 
 // per-(b, channel) coefficients from the group statistics.  PASS 0: rows 0-4, PASS 1: rows 5-6.
 template <int PASS>
-__global__ void k_gn_coef(GnArgs a) {
+__global__ __launch_bounds__(256) void k_gn_coef(GnArgs a) {
+    // the 64 group statistics of this batch item: 256 threads = 64 statistics x 4 interleaved slices of the
+    // per-workgroup partials, combined in a fixed order (a per-channel serial walk over up to 257 partials cost
+    // 26 us per call)
+    __shared__ float red[4][64];
     const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    {
+        const int st = threadIdx.x & 63, sl = threadIdx.x >> 6;
+        const float* pp = (PASS == 0 ? a.part : a.bpart) + (long long)b * a.nblk * 64 + st;
+        float t = 0.f;
+#pragma unroll 4
+        for (int k = sl; k < a.nblk; k += 4) t += pp[(long long)k * 64];
+        red[sl][st] = t;
+    }
+    __syncthreads();
     if (c >= a.C) return;
     const int cpg = a.C / 32, g = c / cpg;
     const float n = (float)a.HW * cpg;
-    const float* pp = (PASS == 0 ? a.part : a.bpart) + (long long)b * a.nblk * 64 + g * 2;
-    float t0 = 0.f, t1 = 0.f;
-    for (int k = 0; k < a.nblk; ++k) { t0 += pp[(long long)k * 64]; t1 += pp[(long long)k * 64 + 1]; }
+    const float t0 = (red[0][2 * g] + red[1][2 * g]) + (red[2][2 * g] + red[3][2 * g]);
+    const float t1 = (red[0][2 * g + 1] + red[1][2 * g + 1]) + (red[2][2 * g + 1] + red[3][2 * g + 1]);
     float* co = a.coef + (long long)b * 7 * a.C;
     if (PASS == 0) {
         float m = t0 / n;
@@ -193,7 +205,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnArgs a) {
 
 bool check_args(int B, int HW, int C) { return B > 0 && HW > 0 && C > 0 && C % 32 == 0 && C <= 8192; }
 
-constexpr int GN_MAX_BLOCKS = 2048;      // workgroups over the chip (all batch items together), at least 8 rows each
+constexpr int GN_MAX_BLOCKS = 1536;      // workgroups over the chip (all batch items together), at least 8 rows each
 
 void launch_cfg(int B, int HW, int C, dim3& grid, int& rows_per_block) {
     int blocks_per_b = (int)std::max<long long>(1, std::min<long long>((HW + 7) / 8, GN_MAX_BLOCKS / std::max(1, B) + 1));

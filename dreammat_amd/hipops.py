@@ -448,17 +448,20 @@ class _Conv3x3S1(torch.autograd.Function):
     """stride-1, pad-1 3x3 conv with frozen weights: backward = the same kernel on the flipped weights."""
 
     @staticmethod
-    def forward(ctx, x_nhwc, w_fwd, w_dgrad, bias):
+    def forward(ctx, x_nhwc, w_fwd, w_dgrad, bias, residual):
         ctx.w_dgrad = w_dgrad
-        return conv3x3_nhwc(x_nhwc, w_fwd, bias, 1, (1, 1))
+        return conv3x3_nhwc(x_nhwc, w_fwd, bias, 1, (1, 1), None, None, residual)
 
     @staticmethod
     def backward(ctx, g):
-        return conv3x3_nhwc(g.contiguous(), ctx.w_dgrad, None, 1, (1, 1)), None, None, None
+        g = g.contiguous()
+        dx = conv3x3_nhwc(g, ctx.w_dgrad, None, 1, (1, 1)) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None, (g if ctx.needs_input_grad[4] else None)
 
 
-def conv3x3_s1_autograd(x_nhwc, w_fwd, w_dgrad, bias):
-    return _Conv3x3S1.apply(x_nhwc, w_fwd, w_dgrad, bias)
+def conv3x3_s1_autograd(x_nhwc, w_fwd, w_dgrad, bias, residual=None):
+    """y = conv(x) + bias (+ residual, folded into the kernel epilogue); differentiable wrt x and residual."""
+    return _Conv3x3S1.apply(x_nhwc, w_fwd, w_dgrad, bias, residual)
 
 
 class _Conv3x3S2(torch.autograd.Function):

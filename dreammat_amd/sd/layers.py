@@ -37,8 +37,16 @@ class Conv2d(nn.Conv2d):
         key = (w.data_ptr(), w._version, w.dtype)
         if getattr(self, "_prep_key", None) != key:
             Cout, Cin = w.shape[0], w.shape[1]
-            self._w_fwd = w.detach().permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
-            self._w_dgrad = w.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous()
+            wd, bd = w.detach(), (self.bias.detach() if self.bias is not None else None)
+            if Cout < 64:
+                # narrow heads (UNet conv_out 320->4, VAE conv_out 512->8): zero-pad Cout to one 64-wide MFMA tile
+                # instead of an im2col + GEMM lowering; callers slice the first Cout channels back out
+                wd = torch.cat([wd, wd.new_zeros(64 - Cout, Cin, 3, 3)], dim=0)
+                bd = torch.cat([bd, bd.new_zeros(64 - Cout)]) if bd is not None else None
+            Cp = wd.shape[0]
+            self._w_fwd = wd.permute(0, 2, 3, 1).reshape(Cp, 9 * Cin).contiguous()
+            self._w_dgrad = wd.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9 * Cp).contiguous()
+            self._bias_p = bd
             self._prep_key = key
         return self._w_fwd, self._w_dgrad
 
@@ -78,17 +86,33 @@ class Conv2d(nn.Conv2d):
         xn = x.permute(0, 2, 3, 1).contiguous()
         rn = residual.permute(0, 2, 3, 1).contiguous() if residual is not None else None
         rb = rowbias.contiguous() if rowbias is not None else None
-        return hipops.conv3x3_nhwc(xn, w_fwd, self.bias, 1, (1, 1), None, rb, rn).permute(0, 3, 1, 2)
+        return hipops.conv3x3_nhwc(xn, w_fwd, self._bias_p, 1, (1, 1), None, rb, rn).permute(0, 3, 1, 2)
+
+    def forward_residual(self, x, residual):
+        """conv(x) + residual; the add rides in the kernel epilogue on the stride-1 LDS-DMA path (also under
+        autograd: the VAE encoder's ResnetBlock2D), otherwise a separate add."""
+        Cout, Cin = self.weight.shape[:2]
+        if not (self.mfma_ok(x) and Cin % 64 == 0 and self.stride == (1, 1) and self.padding == (1, 1)
+                and residual.dtype == x.dtype):
+            return self.forward(x) + residual
+        w_fwd, w_dgrad = self._prepared()
+        xn = x.permute(0, 2, 3, 1).contiguous()
+        rn = residual.permute(0, 2, 3, 1).contiguous()
+        if torch.is_grad_enabled() and (x.requires_grad or residual.requires_grad):
+            y = hipops.conv3x3_s1_autograd(xn, w_fwd, w_dgrad, self._bias_p, rn)
+        else:
+            y = hipops.conv3x3_nhwc(xn, w_fwd, self._bias_p, 1, (1, 1), None, None, rn)
+        return y.permute(0, 3, 1, 2)
 
     def forward_strided_asym(self, x):
         """stride-2 conv over F.pad(x, (0,1,0,1)) (AutoencoderKL downsampler) without materialising the pad."""
         w_fwd, w_dgrad = self._prepared()
         xn = x.permute(0, 2, 3, 1).contiguous()
         if torch.is_grad_enabled() and x.requires_grad:
-            y = hipops.conv3x3_s2_autograd(xn, w_fwd, w_dgrad, self.bias, 0)
+            y = hipops.conv3x3_s2_autograd(xn, w_fwd, w_dgrad, self._bias_p, 0)
         else:
             H, W = x.shape[2], x.shape[3]
-            y = hipops.conv3x3_nhwc(xn, w_fwd, self.bias, 2, (0, 0), (H // 2, W // 2))
+            y = hipops.conv3x3_nhwc(xn, w_fwd, self._bias_p, 2, (0, 0), (H // 2, W // 2))
         return y.permute(0, 3, 1, 2)
 
     def forward(self, x):
@@ -96,20 +120,24 @@ class Conv2d(nn.Conv2d):
             return super().forward(x)
         Cout, Cin, kh, kw = self.weight.shape
         needs_grad = torch.is_grad_enabled() and x.requires_grad
+        narrow = Cout < 64 and Cin % 64 == 0                              # zero-padded to 64 outputs (_prepared)
         ok = (CONV_BACKEND == "mfma" and x.dtype == torch.bfloat16 and kh == 3 and kw == 3 and Cin % 32 == 0
-              and Cout % 64 == 0 and self.stride[0] == self.stride[1] and self._frozen()
+              and (Cout % 64 == 0 or narrow) and self.stride[0] == self.stride[1] and self._frozen()
               and (not needs_grad or (self.stride[0] == 1 and self.padding == (1, 1) and Cin % 64 == 0)))
         if not ok:
             return self._forward_gemm(x)
         w_fwd, w_dgrad = self._prepared()
+        bias = self._bias_p
         xn = x.permute(0, 2, 3, 1).contiguous()                          # no-op when already NHWC
         if needs_grad:
-            y = hipops.conv3x3_s1_autograd(xn, w_fwd, w_dgrad, self.bias)
+            y = hipops.conv3x3_s1_autograd(xn, w_fwd, w_dgrad, bias)
         else:
             H, W = x.shape[2], x.shape[3]
             s = self.stride[0]
             ph, pw = self.padding
-            y = hipops.conv3x3_nhwc(xn, w_fwd, self.bias, s, (ph, pw), ((H + 2 * ph - 3) // s + 1, (W + 2 * pw - 3) // s + 1))
+            y = hipops.conv3x3_nhwc(xn, w_fwd, bias, s, (ph, pw), ((H + 2 * ph - 3) // s + 1, (W + 2 * pw - 3) // s + 1))
+        if narrow:
+            y = y[..., :Cout]
         return y.permute(0, 3, 1, 2)
 
 
@@ -303,10 +331,10 @@ class ResnetBlock2D(nn.Module):
         h = self.conv1(h)
         if tproj is not None:
             h = h + tproj[:, :, None, None]
-        h = self.conv2(group_norm_act(self.norm2, h, True))
+        h = group_norm_act(self.norm2, h, True)
         if self.conv_shortcut is not None:
             x = self.conv_shortcut(x)
-        return x + h
+        return self.conv2.forward_residual(h, x)
 
 
 class Downsample2D(nn.Module):

@@ -717,3 +717,31 @@ def test_conv3x3_fused_epilogue(dev, monkeypatch, tile, B, Cin, Cout, H, W):
     assert err < 2e-2 * ref.abs().max().item() + 1e-2, err
     y1 = hipops.conv3x3_nhwc(x.to(dev), wt.to(dev), bias.to(dev), 1, (1, 1), None, rowbias.to(dev), None).float().cpu()
     assert (y1 - (ref - res.float())).abs().max().item() < 2e-2 * ref.abs().max().item() + 1e-2
+
+
+def test_narrow_head_conv_zero_padded_to_mfma_tile(dev):
+    """UNet conv_out (320->4) / VAE conv_out (512->8): Cout zero-padded to 64 for the MFMA kernel, forward + dgrad."""
+    from dreammat_amd.sd import layers
+    torch.manual_seed(3)
+    for (Cin, Cout) in [(128, 4), (64, 8)]:
+        conv = layers.Conv2d(Cin, Cout, 3, padding=1).to(dev, torch.bfloat16)
+        for p in conv.parameters():
+            p.requires_grad_(False)
+        x = torch.randn(2, Cin, 24, 16).bfloat16()
+        hipops.enable_kernel_timing(True)
+        xg = x.to(dev).requires_grad_()
+        y = conv(xg)
+        with torch.no_grad():
+            y2 = conv(x.to(dev))
+        torch.cuda.synchronize()
+        n_conv = sum(v["launches"] for k, v in hipops.kernel_times().items() if k.startswith("conv3x3"))
+        hipops.enable_kernel_timing(False)
+        assert n_conv == 2 and tuple(y.shape) == (2, Cout, 24, 16)
+        xr = x.float().requires_grad_()
+        ref = torch.nn.functional.conv2d(xr, conv.weight.float().cpu(), conv.bias.float().cpu(), padding=1)
+        assert (y.float().cpu() - ref).abs().max() < 2e-2 * ref.abs().max() + 1e-2
+        assert torch.equal(y2, y.detach())
+        dy = torch.randn_like(ref).bfloat16()
+        y.backward(dy.to(dev))
+        ref.backward(dy.float())
+        assert (xg.grad.float().cpu() - xr.grad).abs().max() < 2e-2 * xr.grad.abs().max() + 1e-2
