@@ -74,6 +74,33 @@ def system_config(a, views_per_rank):
     }
 
 
+def pmc_traffic(kernel_key, batch):
+    """HBM traffic per launch of the conv kernel named by `kernel_key` ("... conv3x3[Cin->Cout@HxW,s1]") from the newest
+    committed counter profile (profiles/r*_pmc_conv_*.json), if that shape was profiled at this batch size."""
+    import glob
+    import re
+    m = re.search(r"conv3x3\[(\d+)->(\d+)@(\d+)x(\d+),s1\]", kernel_key)
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_conv_*.json")))
+    if not m or not files:
+        return None
+    cin, cout, h, w = (int(g) for g in m.groups())
+    tag = f"{batch}_{h}_{w}_{cin}_{cout}"
+    try:
+        ctr = json.load(open(files[-1]))["counters"]
+        fetch = next(iter(ctr["fetch_" + tag].values()))["FETCH_SIZE"]
+        write = next(iter(ctr["write_" + tag].values()))["WRITE_SIZE"]
+    except (KeyError, StopIteration, ValueError, OSError):
+        return None
+    alg = 2.0 * (batch * h * w * (cin + cout) + 9 * cin * cout)
+    out = {"traffic": (2.0 * fetch + write) * 1024.0, "traffic_unit": "bytes/launch", "algorithmic_bytes": alg,
+           "traffic_source": "profiles/" + os.path.basename(files[-1])}
+    hit = ctr.get("tcc_" + tag)
+    if hit:
+        c = next(iter(hit.values()))
+        out["l2_hit_rate"] = c["TCC_HIT_sum"] / max(1.0, c["TCC_REQ_sum"])
+    return out
+
+
 def effective_cores():
     """CPU cores this process may actually use (affinity mask and cgroup quota), capped at 64: os.cpu_count()
     reports the host's cores even inside a small container and oversubscribing torch's thread pool by 10x
@@ -247,8 +274,14 @@ def main():
             res["roofline_attention"] = mfma_entry("k_attn_fwd_dma", attn)
             if "roofline" not in res:
                 res["roofline"] = res["roofline_attention"]
-        res["roofline_note"] = ("traffic=null: `rocprofv3 --pmc` segfaults under this image's python+torch "
-                                "(profiles/r01_pmc_attempt_segfault.log); kernel-trace stats are in profiles/")
+        if conv:
+            tr = pmc_traffic(res["roofline"]["kernel"], vpr)
+            if tr:
+                res["roofline"].update(tr)
+        res["roofline_note"] = ("traffic: HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB from `rocprofv3 --pmc` on the "
+                                "same kernel and shape through the C ABI driver tools/conv_pmc.cpp (tools/pmc_conv.sh; FETCH_SIZE "
+                                "doubled per MI355X_MICROARCH.md); not collected live because rocprofv3 --pmc segfaults "
+                                "under python+torch in this image (profiles/r01_pmc_attempt_segfault.log)")
         for nm, key in (("roofline_shade_fwd", "shade_fwd"), ("roofline_shade_bwd", "shade_bwd")):
             if key in kt:
                 r = kt[key]

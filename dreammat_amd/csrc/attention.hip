@@ -20,6 +20,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <type_traits>
+
 #include "dm_common.h"
 
 namespace {
@@ -335,39 +337,67 @@ __global__ __launch_bounds__(256) void k_attn_fwd_dma(AttnArgs a) {
     const int n_tiles = (a.Skv + kKvTile - 1) / kKvTile;
     issue(0, 0);
     if (n_tiles > 1) issue(kKvTile, 1);
-    int stage = 0;
-    for (int j = 0; j < n_tiles; ++j) {
-        const int kv0 = j * kKvTile;
-        if (j + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int st2 = stage + 2; if (st2 >= 3) st2 -= 3;
-        if (j + 2 < n_tiles) issue(kv0 + 2 * kKvTile, st2);
+    // One KV tile.  MASKED is only instantiated for the drain iterations (the last tile may be ragged): with the
+    // bounds test in the main loop the compiler if-converted it into 32 compares + 32 selects per tile.
+    static_assert(DT % 2 == 0, "PV loop is unrolled by two row blocks");
+    auto read_v = [&](const char* vb, int dt, bf16x8 (&vf)[4]) {
+        const int row = 32 * dt + l31;
+        const char* rb = vb + row * VROW + 8 * hi;
+        const int sw = (row >> 1) & 7;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            // k-slots (hi, j') <-> kv 16ks + (j'&3) + 8(j'>>2) + 4hi: two 8-byte pieces of chunks 2ks and 2ks+1
+            // read as bf16 vectors, like the K fragments: an `unsigned`-typed LDS read after the LDS-DMA issue makes
+            // hipcc insert s_waitcnt vmcnt(0) (it may alias the DMA's destination under TBAA), which drained the
+            // whole 3-deep ring every tile
+            bf16x4 lo = *reinterpret_cast<const bf16x4*>(rb + (((2 * ks) ^ sw) << 4));
+            bf16x4 hi2 = *reinterpret_cast<const bf16x4*>(rb + (((2 * ks + 1) ^ sw) << 4));
+            vf[ks] = __builtin_shufflevector(lo, hi2, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+    };
+    bf16x8 pf[4];
+    auto pv = [&](int dt, const bf16x8 (&vf)[4]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks], pf[ks], o[dt], 0, 0, 0);
+    };
+    auto tile = [&](int kv0, int stage, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         const char* kb = smem + stage * STAGE;
         const char* vb = kb + KBYTES;
+        bf16x8 v0[4], v1[4];
 
+        // S^T = K Q^T: all K fragments first (one LDS latency per tile, not one per MFMA), then the MFMAs
+        bf16x8 kf[2][KSTEPS];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int row = 32 * t + l31;
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk)
+                kf[t][kk] = *reinterpret_cast<const bf16x8*>(kb + row * KROW + (((2 * kk + hi) ^ kswz(row)) << 4));
+        }
         f32x16 s[2];
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-            const int row = 32 * t + l31;
 #pragma unroll
-            for (int kk = 0; kk < KSTEPS; ++kk) {
-                bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + row * KROW + (((2 * kk + hi) ^ kswz(row)) << 4));
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[t], 0, 0, 0);
-            }
+            for (int kk = 0; kk < KSTEPS; ++kk)
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][kk], qf[kk], s[t], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
-        if (kv0 + kKvTile > a.Skv) {
+        read_v(vb, 0, v0);                             // first V^T block: its LDS latency hides under the softmax
+        if (MASKED) {
+            if (kv0 + kKvTile > a.Skv) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int kv = kv0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (kv >= a.Skv) s[t][r] = -INFINITY;
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        int kv = kv0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (kv >= a.Skv) s[t][r] = -INFINITY;
+                    }
+            }
         }
         float mx = s[0][0];
 #pragma unroll
@@ -400,7 +430,6 @@ __global__ __launch_bounds__(256) void k_attn_fwd_dma(AttnArgs a) {
         l_run += psum;
         m_run = m_new;
 
-        bf16x8 pf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int t = ks >> 1, u = ks & 1;
@@ -412,22 +441,34 @@ __global__ __launch_bounds__(256) void k_attn_fwd_dma(AttnArgs a) {
                 pf[ks][2 * e + 1] = pk[1];
             }
         }
+        // O^T += V^T P^T, 32 output rows (dt) at a time; the fragments of block dt+1 are read while block dt multiplies
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const int row = 32 * dt + l31;
-            const char* rb = vb + row * VROW + 8 * hi;
-            const int sw = (row >> 1) & 7;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                // k-slots (hi, j') <-> kv 16ks + (j'&3) + 8(j'>>2) + 4hi: two 8-byte pieces of chunks 2ks and 2ks+1
-                uint2 lo = *reinterpret_cast<const uint2*>(rb + (((2 * ks) ^ sw) << 4));
-                uint2 hi2 = *reinterpret_cast<const uint2*>(rb + (((2 * ks + 1) ^ sw) << 4));
-                uint4 both = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, both), pf[ks], o[dt], 0, 0, 0);
-            }
+        for (int dt = 0; dt < DT; dt += 2) {
+            read_v(vb, dt + 1, v1);
+            pv(dt, v0);
+            if (dt + 2 < DT) read_v(vb, dt + 2, v0);
+            pv(dt + 1, v1);
         }
         __builtin_amdgcn_s_setprio(0);
+    };
+
+    // main loop: full tiles, each issuing the DMAs of tile j+2; drain: the last (up to) two tiles, nothing to issue.
+    // Separate loops so that each body gets one accumulator register set (see conv.hip).
+    int stage = 0, j = 0;
+    for (; j + 2 < n_tiles; ++j) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        __builtin_amdgcn_s_barrier();
+        int st2 = stage + 2; if (st2 >= 3) st2 -= 3;
+        issue((j + 2) * kKvTile, st2);
+        tile(j * kKvTile, stage, std::false_type{});
+        stage = stage + 1; if (stage >= 3) stage = 0;
+    }
+    for (; j < n_tiles; ++j) {
+        if (j + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        tile(j * kKvTile, stage, std::true_type{});
         stage = stage + 1; if (stage >= 3) stage = 0;
     }
 

@@ -154,6 +154,105 @@ __global__ __launch_bounds__(256) void k_hashgrid_bwd2(HashArgs a, int level_bas
     }
 }
 
+// Backward, coarse levels (cells several pixels wide): each workgroup accumulates its 1024 consecutive points --
+// a strip a few image rows tall -- in an LDS hash table keyed by the level-local entry index and only then
+// issues ONE global atomic pair per distinct entry.  The run-combining variant above merges along an image row
+// only; the strip also shares entries between rows.  Open addressing, linear probing; a point that cannot find a
+// slot within LH_PROBES falls back to the direct global atomic, so a full table costs time, never correctness.
+constexpr int LH_SLOTS = 2048;                 // 8 KB keys + 16 KB values => 6 workgroups per CU
+constexpr int LH_THREADS = 256;
+constexpr int LH_PTS = 4;                      // points per thread (1024 consecutive points per workgroup)
+constexpr int LH_PROBES = 8;
+constexpr unsigned LH_EMPTY = 0xffffffffu;
+constexpr unsigned LH_INVALID = 0xfffffffeu;   // key of lanes past the end of the point list (never inserted)
+
+__global__ __launch_bounds__(LH_THREADS) void k_hashgrid_bwd_lds(HashArgs a, int level_base) {
+    __shared__ unsigned keys[LH_SLOTS];
+    __shared__ float vals[2 * LH_SLOTS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < LH_SLOTS; i += LH_THREADS) { keys[i] = LH_EMPTY; vals[2 * i] = 0.f; vals[2 * i + 1] = 0.f; }
+    __syncthreads();
+    const long long M = a.m_dev ? (long long)*a.m_dev : a.m_max;
+    const int l = level_base + blockIdx.y;
+    const float scale = a.lv.scale[l];
+    const unsigned res = a.lv.res[l], size = a.lv.size[l], off = a.lv.offset[l];
+    // cells >= ~7 pixels wide: whole runs of lanes share a corner, and 64 LDS atomics on one address serialise --
+    // combine each run with a segmented wave scan first (as k_hashgrid_bwd2<true>) and insert once per run
+    const bool premerge = res <= 64;
+#pragma unroll 1
+    for (int q = 0; q < LH_PTS; ++q) {
+        const long long m = ((long long)blockIdx.x * LH_PTS + q) * LH_THREADS + tid;
+        const bool valid = m < M;
+        const long long mc = valid ? m : 0;
+        float w[3];
+        unsigned cell[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float xn = (a.x[mc * a.x_rs + d * a.x_cs] + a.radius) * a.inv_2r;
+            float p = xn * scale + 0.5f;
+            float fl = floorf(p);
+            w[d] = p - fl;
+            cell[d] = (unsigned)(int)fl;
+        }
+        const float g0 = valid ? a.dout[mc * a.dout_rs + (2 * l) * a.dout_cs] : 0.f;
+        const float g1 = valid ? a.dout[mc * a.dout_rs + (2 * l + 1) * a.dout_cs] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            unsigned cx = cell[0] + (c & 1), cy = cell[1] + ((c >> 1) & 1), cz = cell[2] + ((c >> 2) & 1);
+            float wt = ((c & 1) ? w[0] : 1.f - w[0]) * (((c >> 1) & 1) ? w[1] : 1.f - w[1]) *
+                       (((c >> 2) & 1) ? w[2] : 1.f - w[2]);
+            const unsigned idx = valid ? grid_index(cx, cy, cz, res, size) : LH_INVALID;
+            float v0 = g0 * wt, v1 = g1 * wt;
+            bool emit = valid;
+            if (premerge) {                            // wave-uniform branch: every lane takes part in the shuffles
+                unsigned prev = (unsigned)__shfl_up((int)idx, 1);
+                int start = (lane == 0 || prev != idx) ? lane : 0;
+#pragma unroll
+                for (int ofs = 1; ofs < 64; ofs <<= 1) {
+                    int s2 = __shfl_up(start, ofs);
+                    if (lane >= ofs) start = max(start, s2);
+                }
+#pragma unroll
+                for (int ofs = 1; ofs < 64; ofs <<= 1) {
+                    float t0 = __shfl_up(v0, ofs), t1 = __shfl_up(v1, ofs);
+                    if (lane - ofs >= start) { v0 += t0; v1 += t1; }
+                }
+                unsigned nxt = (unsigned)__shfl_down((int)idx, 1);
+                emit = valid && (lane == 63 || nxt != idx);
+            }
+            if (emit) {
+                unsigned h = (idx * 2654435761u) >> 21;                  // 11 bits = LH_SLOTS
+                bool placed = false;
+#pragma unroll 1
+                for (int pr = 0; pr < LH_PROBES; ++pr) {
+                    unsigned old = atomicCAS(&keys[h], LH_EMPTY, idx);
+                    if (old == LH_EMPTY || old == idx) {
+                        atomicAdd(&vals[2 * h], v0);
+                        atomicAdd(&vals[2 * h + 1], v1);
+                        placed = true;
+                        break;
+                    }
+                    h = (h + 1) & (LH_SLOTS - 1);
+                }
+                if (!placed) {
+                    float* dst = a.dtable + 2 * (size_t)(off + idx);
+                    atomicAdd(dst, v0);
+                    atomicAdd(dst + 1, v1);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < LH_SLOTS; i += LH_THREADS) {
+        const unsigned k = keys[i];
+        if (k != LH_EMPTY) {
+            float* dst = a.dtable + 2 * (size_t)(off + k);
+            atomicAdd(dst, vals[2 * i]);
+            atomicAdd(dst + 1, vals[2 * i + 1]);
+        }
+    }
+}
+
 bool fill_levels(GridLevels& lv, int n_levels, const float* scale, const uint32_t* res, const uint32_t* size,
                  const uint32_t* offset) {
     if (n_levels <= 0 || n_levels > kMaxLevels || !scale || !res || !size || !offset) return false;
@@ -195,12 +294,19 @@ int dm_hashgrid_bwd(const float* x, long long x_rs, long long x_cs, const int32_
         return DM_ERR_ARG;
     a.x = x; a.x_rs = x_rs; a.x_cs = x_cs; a.dout = denc; a.dout_rs = denc_rs; a.dout_cs = denc_cs;
     a.dtable = dtable; a.m_dev = m_dev; a.m_max = m_max; a.radius = radius; a.inv_2r = 1.0f / (2.0f * radius);
-    // levels whose cells span several pixels get the run-combining variant (see k_hashgrid_bwd2)
-    int n_dedup = 0;
+    // coarsest levels: LDS hash accumulation per 1024-point strip; mid levels (cells ~1-3 pixels): run combining
+    // along the image row; fine levels: one atomic pair per corner (nothing to share)
+    int n_lds = 0;
+    while (n_lds < n_levels && lv_res[n_lds] <= 110) ++n_lds;
+    int n_dedup = n_lds;
     while (n_dedup < n_levels && lv_res[n_dedup] <= 512) ++n_dedup;
     DM_ENTER();
-    if (n_dedup > 0)
-        hipLaunchKernelGGL(k_hashgrid_bwd2<true>, dim3(dm_div_up(2 * m_max, 256), n_dedup), dim3(256), 0, stream, a, 0);
+    if (n_lds > 0)
+        hipLaunchKernelGGL(k_hashgrid_bwd_lds, dim3(dm_div_up(m_max, LH_THREADS * LH_PTS), n_lds), dim3(LH_THREADS), 0,
+                           stream, a, 0);
+    if (n_dedup > n_lds)
+        hipLaunchKernelGGL(k_hashgrid_bwd2<true>, dim3(dm_div_up(2 * m_max, 256), n_dedup - n_lds), dim3(256), 0, stream,
+                           a, n_lds);
     if (n_levels > n_dedup)
         hipLaunchKernelGGL(k_hashgrid_bwd2<false>, dim3(dm_div_up(2 * m_max, 256), n_levels - n_dedup), dim3(256), 0,
                            stream, a, n_dedup);
