@@ -75,23 +75,32 @@ def system_config(a, views_per_rank):
 
 
 def pmc_traffic(kernel_key, batch):
-    """HBM traffic per launch of the conv kernel named by `kernel_key` ("... conv3x3[Cin->Cout@HxW,s1]") from the newest
-    committed counter profile (profiles/r*_pmc_conv_*.json), if that shape was profiled at this batch size."""
+    """HBM traffic per launch of the kernel named by `kernel_key` ("... conv3x3[Cin->Cout@HxW,s1]" at batch `batch`, or
+    "... attention_fwd_bf16[Sq=..,Skv=..,h=..,D=..]" at batch 3*`batch`) from the newest committed counter profile
+    (profiles/r*_pmc_conv_*.json), if exactly that shape was profiled."""
     import glob
     import re
-    m = re.search(r"conv3x3\[(\d+)->(\d+)@(\d+)x(\d+),s1\]", kernel_key)
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_conv_*.json")))
-    if not m or not files:
+    if not files:
         return None
-    cin, cout, h, w = (int(g) for g in m.groups())
-    tag = f"{batch}_{h}_{w}_{cin}_{cout}"
+    m = re.search(r"conv3x3\[(\d+)->(\d+)@(\d+)x(\d+),s1\]", kernel_key)
+    m2 = re.search(r"attention_fwd_bf16\[Sq=(\d+),Skv=(\d+),h=(\d+),D=(\d+)\]", kernel_key)
+    if m:
+        cin, cout, h, w = (int(g) for g in m.groups())
+        tag = f"{batch}_{h}_{w}_{cin}_{cout}"
+        alg = 2.0 * (batch * h * w * (cin + cout) + 9 * cin * cout)
+    elif m2:
+        sq, skv, heads, d = (int(g) for g in m2.groups())
+        tag = f"attn_{3 * batch}_{heads}_{sq}_{skv}_{d}"
+        alg = 2.0 * 3 * batch * heads * d * (2 * sq + 2 * skv)
+    else:
+        return None
     try:
         ctr = json.load(open(files[-1]))["counters"]
         fetch = next(iter(ctr["fetch_" + tag].values()))["FETCH_SIZE"]
         write = next(iter(ctr["write_" + tag].values()))["WRITE_SIZE"]
     except (KeyError, StopIteration, ValueError, OSError):
         return None
-    alg = 2.0 * (batch * h * w * (cin + cout) + 9 * cin * cout)
     out = {"traffic": (2.0 * fetch + write) * 1024.0, "traffic_unit": "bytes/launch", "algorithmic_bytes": alg,
            "traffic_source": "profiles/" + os.path.basename(files[-1])}
     hit = ctr.get("tcc_" + tag)
@@ -274,12 +283,12 @@ def main():
             res["roofline_attention"] = mfma_entry("k_attn_fwd_dma", attn)
             if "roofline" not in res:
                 res["roofline"] = res["roofline_attention"]
-        if conv:
-            tr = pmc_traffic(res["roofline"]["kernel"], vpr)
+        for nm in ("roofline", "roofline_attention"):
+            tr = pmc_traffic(res[nm]["kernel"], vpr) if nm in res else None
             if tr:
-                res["roofline"].update(tr)
+                res[nm].update(tr)
         res["roofline_note"] = ("traffic: HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB from `rocprofv3 --pmc` on the "
-                                "same kernel and shape through the C ABI driver tools/conv_pmc.cpp (tools/pmc_conv.sh; FETCH_SIZE "
+                                "same kernel and shape (conv, attention) through the C ABI driver tools/abi_pmc.cpp (tools/pmc_abi.sh; FETCH_SIZE "
                                 "doubled per MI355X_MICROARCH.md); not collected live because rocprofv3 --pmc segfaults "
                                 "under python+torch in this image (profiles/r01_pmc_attempt_segfault.log)")
         for nm, key in (("roofline_shade_fwd", "shade_fwd"), ("roofline_shade_bwd", "shade_bwd")):

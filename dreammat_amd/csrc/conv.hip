@@ -225,10 +225,10 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     // (tile row r -> pixel (Y0 + r / TW, X0 + r % TW)).  A 1-D run of BMT pixels re-reads 3 full image rows per
     // tile; the patch re-reads a one-pixel halo: (TH+2)(TW+2)/(TH*TW) = 1.2-1.3x.
     const int TWm = (1 << a.tw_log2) - 1;
-    const long long tile_y = mt / a.tiles_x;
-    const long long Y0 = tile_y * (BMT >> a.tw_log2);
-    const int X0 = (int)(mt - tile_y * a.tiles_x) << a.tw_log2;
-    const long long rows_total = (long long)a.B * a.Hout;
+    const int tile_y = (int)(mt / a.tiles_x);          // B*Hout < 2^31 (checked by the launcher): 32-bit row math
+    const int Y0 = tile_y * (BMT >> a.tw_log2);
+    const int X0 = (int)(mt - (long long)tile_y * a.tiles_x) << a.tw_log2;
+    const int rows_total = a.B * a.Hout;
     const int n0 = nt * BN;
     const int lrow = lane >> 3, lslot = lane & 7;      // this lane's row / 16 B slot inside one DMA instruction
     const unsigned long long zero = (unsigned long long)g_zero_page;
@@ -244,12 +244,12 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
 #pragma unroll
     for (int i = 0; i < A_INSTR; ++i) {
         int row = wave * (BMT / NW) + 8 * i + lrow;
-        long long Y = Y0 + (row >> a.tw_log2);
+        int Y = Y0 + (row >> a.tw_log2);
         int xo = X0 + (row & TWm);
         bool ok = Y < rows_total && xo < a.Wout;
-        long long Yc = ok ? Y : 0;
-        int b = (int)(Yc / a.Hout);
-        int yo = (int)(Yc - (long long)b * a.Hout);
+        int Yc = ok ? Y : 0;
+        int b = Yc / a.Hout;
+        int yo = Yc - b * a.Hout;
         int y0 = yo * a.stride - a.pad_y;
         int x0 = (ok ? xo : 0) * a.stride - a.pad_x;
         a_ptr[i] = a.x + (((long long)b * a.Hin + y0) * a.Win + x0) * a.Cin + (lslot ^ ((row >> 1) & 7)) * 8;
@@ -400,18 +400,18 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
         ncol[j] = n0 + TN * wn + 32 * j + l31;
         bv[j] = (a.bias && ncol[j] < a.Cout) ? (float)a.bias[ncol[j]] : 0.f;
     }
-    const int img0 = (int)(Y0 / a.Hout);               // image of the patch's first row (wave-uniform)
-    const int rem0 = (int)(Y0 - (long long)img0 * a.Hout);
+    const int img0 = Y0 / a.Hout;                      // image of the patch's first row (wave-uniform)
+    const int rem0 = Y0 - img0 * a.Hout;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int d = TM * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
             const int ty = d >> a.tw_log2;
-            const long long Y = Y0 + ty;
+            const int Y = Y0 + ty;
             const int xo = X0 + (d & TWm);
             if (Y >= rows_total || xo >= a.Wout) continue;
-            const long long m = Y * a.Wout + xo;       // = (b*Hout + yo)*Wout + xo
+            const long long m = (long long)Y * a.Wout + xo;       // = (b*Hout + yo)*Wout + xo
             const __bf16* rb = nullptr;
             if (a.rowbias) {
                 int img = img0, t = rem0 + ty;
@@ -447,6 +447,7 @@ int launch_conv_dma(const ConvArgs& a_in, hipStream_t stream) {
     a.tw_log2 = tw_log2;
     a.tiles_x = (a.Wout + (1 << tw_log2) - 1) >> tw_log2;
     const int TH = BMT >> tw_log2;
+    if ((long long)a.B * a.Hout + 512 > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
     long long n_mt = (((long long)a.B * a.Hout + TH - 1) / TH) * a.tiles_x;
     int n_nt = (a.Cout + BN - 1) / BN;
     long long blocks = ((n_mt * n_nt + 7) / 8) * 8;

@@ -1,0 +1,139 @@
+// Stand-alone C-ABI driver for hardware-counter / kernel-trace runs (no python, no torch in the process):
+//   hipcc --offload-arch=gfx950 -O2 tools/abi_pmc.cpp -o tools/_abi_pmc -Ldreammat_amd -ldreammat_hip -Wl,-rpath,'$ORIGIN/../dreammat_amd'
+//   tools/_abi_pmc conv  B H W Cin Cout iters        3x3 conv, stride 1, pad 1, NHWC bf16
+//   tools/_abi_pmc attn  B heads Sq Skv D iters      attention forward, bf16
+//   tools/_abi_pmc shade N n_env iters               split-sum shade forward + backward over N covered pixels
+// Prints one JSON line with the HIP-event time per launch.  See tools/pmc_abi.sh for the rocprofv3 passes.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../include/dreammat_hip.h"
+
+#define CK(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { printf("hip error %d at %s:%d\n", (int)r_, __FILE__, __LINE__); return 2; } } while (0)
+#define DM(e) do { int r_ = (e); if (r_) { printf("dm error %d at %s:%d\n", r_, __FILE__, __LINE__); return 3; } } while (0)
+
+static unsigned g_seed = 12345u;
+static unsigned rnd() { g_seed = g_seed * 1664525u + 1013904223u; return g_seed; }
+static float frand() { return (rnd() >> 8) * (1.0f / 16777216.0f); }                       // [0,1)
+static unsigned short bf16_small() { unsigned r = rnd(); return (unsigned short)(0x3c00u + ((r >> 16) & 0x1ffu) + ((r >> 31) << 15)); }
+static unsigned short bf16_of(float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x8000u) >> 16); }
+
+template <class T> static int upload(void** d, const std::vector<T>& h) {
+    CK(hipMalloc(d, h.size() * sizeof(T)));
+    CK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+template <class F> static int timed(int iters, float* ms_per, F&& f) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    DM(f());                                             // warm-up
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters; ++i) f();
+    CK(hipEventRecord(e1, nullptr));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    *ms_per = ms / iters;
+    return 0;
+}
+
+static int run_conv(int B, int H, int W, int Cin, int Cout, int iters) {
+    const size_t nx = (size_t)B * H * W * Cin, nw = (size_t)Cout * 9 * Cin, ny = (size_t)B * H * W * Cout;
+    std::vector<unsigned short> hx(nx), hw(nw);
+    for (auto& v : hx) v = bf16_small();
+    for (auto& v : hw) v = bf16_small();
+    void *dx, *dw, *dy;
+    if (upload(&dx, hx) || upload(&dw, hw)) return 2;
+    CK(hipMalloc(&dy, ny * 2));
+    float ms;
+    int rc = timed(iters, &ms, [&] { return dm_conv3x3_nhwc_bf16(dx, dw, nullptr, dy, B, H, W, Cin, H, W, Cout, 1, 1, 1, nullptr); });
+    if (rc) return rc;
+    const double flops = 2.0 * B * H * W * Cout * 9.0 * Cin;
+    printf("{\"op\":\"conv\",\"B\":%d,\"H\":%d,\"W\":%d,\"Cin\":%d,\"Cout\":%d,\"ms\":%.4f,\"TFLOPs\":%.1f,\"alg_in_MB\":%.1f,\"alg_out_MB\":%.1f}\n",
+           B, H, W, Cin, Cout, ms, flops / (ms * 1e-3) / 1e12, (nx + nw) * 2 / 1e6, ny * 2 / 1e6);
+    return 0;
+}
+
+static int run_attn(int B, int Hh, int Sq, int Skv, int D, int iters) {
+    const int C = Hh * D, Sp = (Skv + 7) / 8 * 8;
+    std::vector<unsigned short> hq((size_t)B * Sq * C), hk((size_t)B * Skv * C), hv((size_t)B * C * Sp);
+    for (auto& v : hq) v = bf16_of(frand() * 2.f - 1.f);
+    for (auto& v : hk) v = bf16_of(frand() * 2.f - 1.f);
+    for (auto& v : hv) v = bf16_of(frand() * 2.f - 1.f);
+    void *dq, *dk, *dv, *dout;
+    if (upload(&dq, hq) || upload(&dk, hk) || upload(&dv, hv)) return 2;
+    CK(hipMalloc(&dout, hq.size() * 2));
+    float ms;
+    int rc = timed(iters, &ms, [&] {
+        return dm_attention_fwd_bf16(dq, dk, dv, dout, B, Hh, Sq, Skv, D, (long long)Sq * C, C, D, (long long)Skv * C, C, D,
+                                     (long long)C * Sp, (long long)D * Sp, Sp, (long long)Sq * C, C, D, 1.0f / sqrtf((float)D), nullptr);
+    });
+    if (rc) return rc;
+    const double flops = 4.0 * B * Sq * (double)Skv * C;
+    printf("{\"op\":\"attn\",\"B\":%d,\"heads\":%d,\"Sq\":%d,\"Skv\":%d,\"D\":%d,\"ms\":%.4f,\"TFLOPs\":%.1f,\"alg_MB\":%.1f}\n", B, Hh, Sq, Skv, D,
+           ms, flops / (ms * 1e-3) / 1e12, (2.0 * hq.size() + hk.size() + hv.size()) * 2 / 1e6);
+    return 0;
+}
+
+static int run_shade(long long N, int n_env, int iters) {
+    // atlas: envlight geometry (max_res 128 -> min_res 16, diffuse 16), every face with a 1-texel border, RGBA fp32
+    dm_env_atlas at;
+    memset(&at, 0, sizeof(at));
+    const int res[4] = {128, 64, 32, 16};
+    long long off = 0;
+    for (int m = 0; m < 4; ++m) { at.mip_off[m] = off; at.mip_res[m] = res[m]; off += 6LL * (res[m] + 2) * (res[m] + 2); }
+    at.n_mips = 4; at.spec_env_stride = off; at.diff_res = 16; at.diff_env_stride = 6LL * 18 * 18; at.lut_res = 256;
+    at.min_rough_mip = 0.08f; at.max_rough_mip = 0.5f;
+    std::vector<float> hspec((size_t)n_env * off * 4), hdiff((size_t)n_env * at.diff_env_stride * 4), hlut(256 * 256 * 2);
+    for (auto& v : hspec) v = frand() * 2.f;
+    for (auto& v : hdiff) v = frand();
+    for (auto& v : hlut) v = frand();
+    void *dspec, *ddiff, *dlut;
+    if (upload(&dspec, hspec) || upload(&ddiff, hdiff) || upload(&dlut, hlut)) return 2;
+    at.spec = (const float*)dspec; at.diff = (const float*)ddiff; at.fg_lut = (const float*)dlut;
+    dm_mat_cfg mc = {0.0f, 0.9f, 0.08f, 0.9f};
+    const int views = 8, HW = 512 * 512;
+    std::vector<float> hn(3 * N), hv(3 * N), hf(5 * N), hg(3 * N);
+    std::vector<int> hp(N), henv(views);
+    for (long long i = 0; i < N; ++i) {
+        float n[3] = {frand() - .5f, frand() - .5f, frand() + .2f}, v[3] = {frand() - .5f, frand() - .5f, frand() + .2f};
+        float ln = 1.f / sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), lv = 1.f / sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        for (int c = 0; c < 3; ++c) { hn[c * N + i] = n[c] * ln; hv[c * N + i] = v[c] * lv; hg[c * N + i] = frand() - .5f; }
+        for (int c = 0; c < 5; ++c) hf[c * N + i] = frand() * 4.f - 2.f;
+        hp[i] = (int)((double)i * views * HW / N);
+    }
+    for (int v = 0; v < views; ++v) henv[v] = v % n_env;
+    std::vector<int> hcount(1, (int)N);
+    void *dn, *dv, *df, *dg, *dp, *denv, *dcount, *dcol, *ddf;
+    if (upload(&dn, hn) || upload(&dv, hv) || upload(&df, hf) || upload(&dg, hg) || upload(&dp, hp) || upload(&denv, henv) || upload(&dcount, hcount)) return 2;
+    CK(hipMalloc(&dcol, 3 * N * 4)); CK(hipMalloc(&ddf, 5 * N * 4));
+    float ms_f, ms_b;
+    int rc = timed(iters, &ms_f, [&] {
+        return dm_shade_fwd(&at, &mc, (float*)dn, 1, N, (float*)dv, 1, N, (float*)df, 1, N, (int*)dp, (int*)denv, (int*)dcount, N, HW,
+                            (float*)dcol, 1, N, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    });
+    if (rc) return rc;
+    rc = timed(iters, &ms_b, [&] {
+        return dm_shade_bwd(&at, &mc, (float*)dn, 1, N, (float*)dv, 1, N, (float*)df, 1, N, (int*)dp, (int*)denv, (int*)dcount, N, HW,
+                            (float*)dg, 1, N, (float*)ddf, 1, N, nullptr);
+    });
+    if (rc) return rc;
+    printf("{\"op\":\"shade\",\"N\":%lld,\"n_env\":%d,\"fwd_ms\":%.4f,\"bwd_ms\":%.4f,\"fwd_GBps\":%.0f,\"bwd_GBps\":%.0f,\"alg_fwd_MB\":%.1f,\"alg_bwd_MB\":%.1f}\n",
+           N, n_env, ms_f, ms_b, 56.0 * N / (ms_f * 1e-3) / 1e9, 76.0 * N / (ms_b * 1e-3) / 1e9, 56.0 * N / 1e6, 76.0 * N / 1e6);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc >= 8 && !strcmp(argv[1], "conv")) return run_conv(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]));
+    if (argc >= 8 && !strcmp(argv[1], "attn")) return run_attn(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]));
+    if (argc >= 5 && !strcmp(argv[1], "shade")) return run_shade(atoll(argv[2]), atoi(argv[3]), atoi(argv[4]));
+    printf("usage: %s conv B H W Cin Cout iters | attn B heads Sq Skv D iters | shade N n_env iters\n", argv[0]);
+    return 1;
+}
