@@ -1,0 +1,160 @@
+"""Host-side algebra around the conv C ABI, checked on CPU: the weight layouts `Conv2d._prepared()` hands to the
+kernel (tap-major forward weights, flipped / channel-swapped data-gradient weights, zero-padded narrow heads) and
+the autograd wrappers in `hipops` (fused residual, stride-2 forward with an implied trailing pad, zero-insert data
+gradient).  `hipops.conv3x3_nhwc` is replaced by a torch emulation of the `dm_conv3x3_nhwc_bf16_fused` CONTRACT
+(include/dreammat_hip.h) -- the kernel itself is covered by tests/test_hip_gpu.py."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from dreammat_amd import hipops
+from dreammat_amd.geometry import VanillaMLP, _wgrad_splitk
+from dreammat_amd.sd import layers
+
+
+def conv3x3_contract(x_nhwc, w_tap_major, bias, stride=1, pad=(1, 1), out_hw=None, rowbias=None, residual=None):
+    """y[b,yo,xo,n] = bias[n] + rowbias[b,n] + residual[b,yo,xo,n] + sum_{dy,dx,c} x[b, yo*s-py+dy, xo*s-px+dx, c] *
+    w[n, (dy*3+dx)*Cin + c], zero outside the image; the output size is the caller's (trailing pad implied)."""
+    B, H, W, Cin = x_nhwc.shape
+    Cout = w_tap_major.shape[0]
+    if out_hw is None:
+        out_hw = ((H + 2 * pad[0] - 3) // stride + 1, (W + 2 * pad[1] - 3) // stride + 1)
+    Ho, Wo = out_hw
+    need_h, need_w = (Ho - 1) * stride + 3, (Wo - 1) * stride + 3
+    x = x_nhwc.permute(0, 3, 1, 2)
+    x = F.pad(x, (pad[1], max(0, need_w - W - pad[1]), pad[0], max(0, need_h - H - pad[0])))[:, :, :need_h, :need_w]
+    w = w_tap_major.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    y = F.conv2d(x, w, bias, stride=stride).permute(0, 2, 3, 1)
+    assert y.shape[1:3] == (Ho, Wo)
+    if rowbias is not None:
+        y = y + rowbias[:, None, None, :]
+    if residual is not None:
+        y = y + residual
+    return y.contiguous()
+
+
+@pytest.fixture
+def contract(monkeypatch):
+    monkeypatch.setattr(hipops, "conv3x3_nhwc", conv3x3_contract)
+
+
+def test_prepared_weights_forward_and_data_gradient(contract):
+    torch.manual_seed(0)
+    conv = layers.Conv2d(6, 64, 3, padding=1).double()
+    w_fwd, w_dgrad = conv._prepared()
+    x = torch.randn(2, 6, 9, 7, dtype=torch.float64, requires_grad=True)
+    ref = F.conv2d(x, conv.weight, conv.bias, padding=1)
+    y = conv3x3_contract(x.detach().permute(0, 2, 3, 1).contiguous(), w_fwd, conv._bias_p)
+    assert torch.allclose(y.permute(0, 3, 1, 2), ref.detach(), atol=1e-12)
+    dy = torch.randn_like(ref)
+    ref.backward(dy)
+    dx = conv3x3_contract(dy.permute(0, 2, 3, 1).contiguous(), w_dgrad, None)       # same kernel, flipped weights
+    assert torch.allclose(dx.permute(0, 3, 1, 2), x.grad, atol=1e-12)
+
+
+def test_narrow_head_is_zero_padded_to_one_mfma_tile(contract):
+    """Cout < 64 (UNet conv_out 320->4, VAE conv_out 512->8): 64 output rows, the extra ones exactly zero, and a
+    data gradient that ignores whatever arrives in the padded channels."""
+    torch.manual_seed(1)
+    conv = layers.Conv2d(8, 4, 3, padding=1).double()
+    w_fwd, w_dgrad = conv._prepared()
+    assert w_fwd.shape == (64, 72) and w_dgrad.shape == (8, 9 * 64) and conv._bias_p.shape == (64,)
+    x = torch.randn(1, 8, 5, 6, dtype=torch.float64, requires_grad=True)
+    y = conv3x3_contract(x.detach().permute(0, 2, 3, 1).contiguous(), w_fwd, conv._bias_p)
+    ref = F.conv2d(x, conv.weight, conv.bias, padding=1)
+    assert torch.allclose(y[..., :4].permute(0, 3, 1, 2), ref.detach(), atol=1e-12)
+    assert y[..., 4:].abs().max() == 0
+    dy = torch.randn_like(ref)
+    ref.backward(dy)
+    dy64 = torch.randn(1, 5, 6, 64, dtype=torch.float64)                              # garbage in the padded channels
+    dy64[..., :4] = dy.permute(0, 2, 3, 1)
+    dx = conv3x3_contract(dy64, w_dgrad, None)
+    assert torch.allclose(dx.permute(0, 3, 1, 2), x.grad, atol=1e-12)
+
+
+def test_stride1_autograd_with_fused_residual(contract):
+    torch.manual_seed(2)
+    conv = layers.Conv2d(5, 64, 3, padding=1).double()
+    w_fwd, w_dgrad = conv._prepared()
+    x = torch.randn(2, 6, 8, 5, dtype=torch.float64, requires_grad=True)
+    r = torch.randn(2, 6, 8, 64, dtype=torch.float64, requires_grad=True)
+    y = hipops.conv3x3_s1_autograd(x, w_fwd, w_dgrad, conv._bias_p, r)
+    xr, rr = x.detach().clone().requires_grad_(), r.detach().clone().requires_grad_()
+    ref = F.conv2d(xr.permute(0, 3, 1, 2), conv.weight, conv.bias, padding=1).permute(0, 2, 3, 1) + rr
+    assert torch.allclose(y, ref, atol=1e-12)
+    g = torch.randn_like(ref)
+    y.backward(g)
+    ref.backward(g)
+    assert torch.allclose(x.grad, xr.grad, atol=1e-12) and torch.allclose(r.grad, rr.grad, atol=1e-12)
+
+
+@pytest.mark.parametrize("lead_pad,H,W", [(0, 8, 12), (1, 8, 12), (1, 7, 9)])
+def test_stride2_forward_and_zero_insert_data_gradient(contract, lead_pad, H, W):
+    """lead_pad 0 = AutoencoderKL's downsampler over F.pad(x, (0,1,0,1)); lead_pad 1 = the UNet's padding=1 one.
+    Backward = stride-1 conv of the zero-inserted gradient with leading pad 2 - lead_pad."""
+    torch.manual_seed(3)
+    conv = layers.Conv2d(4, 64, 3, stride=2, padding=lead_pad).double()
+    w_fwd, w_dgrad = conv._prepared()
+    x = torch.randn(2, H, W, 4, dtype=torch.float64, requires_grad=True)
+    y = hipops.conv3x3_s2_autograd(x, w_fwd, w_dgrad, conv._bias_p, lead_pad)
+    xr = x.detach().clone().requires_grad_()
+    xin = xr.permute(0, 3, 1, 2)
+    xin = F.pad(xin, (0, 1, 0, 1)) if lead_pad == 0 else xin
+    ref = F.conv2d(xin, conv.weight, conv.bias, stride=2, padding=lead_pad).permute(0, 2, 3, 1)
+    if lead_pad == 1 and (H % 2 or W % 2):
+        assert y.shape == ref.shape
+    assert torch.allclose(y, ref, atol=1e-12)
+    g = torch.randn_like(ref)
+    y.backward(g)
+    ref.backward(g)
+    assert torch.allclose(x.grad, xr.grad, atol=1e-12)
+
+
+def test_fused_epilogue_contract_matches_resnet_block_math(contract):
+    """ResnetBlock2D inference path: conv1(+temb row bias) and conv2(+residual) through the fused entry point equal
+    the unfused module arithmetic."""
+    torch.manual_seed(4)
+    blk = layers.ResnetBlock2D(64, 64, temb_ch=32).double().eval()
+    x = torch.randn(2, 64, 6, 6, dtype=torch.float64)
+    temb = torch.randn(2, 32, dtype=torch.float64)
+    with torch.no_grad():
+        ref = blk(x, temb)                                                          # CPU: unfused torch path
+        h = layers.group_norm_act(blk.norm1, x, True).permute(0, 2, 3, 1).contiguous()
+        tproj = blk.time_emb_proj(F.silu(temb))
+        h = conv3x3_contract(h, blk.conv1._prepared()[0], blk.conv1._bias_p, rowbias=tproj)
+        h = layers.group_norm_act(blk.norm2, h.permute(0, 3, 1, 2), True).permute(0, 2, 3, 1).contiguous()
+        y = conv3x3_contract(h, blk.conv2._prepared()[0], blk.conv2._bias_p, residual=x.permute(0, 2, 3, 1).contiguous())
+    assert torch.allclose(y.permute(0, 3, 1, 2), ref, atol=1e-10)
+
+
+def test_splitk_weight_gradient_of_the_feature_major_mlp():
+    torch.manual_seed(5)
+    g = torch.randn(5, 70001, dtype=torch.float64)
+    h = torch.randn(64, 70001, dtype=torch.float64)
+    assert torch.allclose(_wgrad_splitk(g, h), g @ h.t(), atol=1e-9)
+    gt = torch.randn(70001, 5, dtype=torch.float64).t()                              # non-contiguous, as autograd delivers it
+    assert torch.allclose(_wgrad_splitk(gt, h), gt @ h.t(), atol=1e-9)
+    assert torch.allclose(_wgrad_splitk(g[:, :100], h[:, :100]), g[:, :100] @ h[:, :100].t(), atol=1e-12)   # tiny: plain GEMM
+    mlp = VanillaMLP(32, 5, {"n_neurons": 64, "n_hidden_layers": 1})
+    xf = torch.randn(32, 40000).t()                                                  # feature-major [N, 32] view
+    assert xf.stride(0) == 1
+    xa = xf.detach().requires_grad_()
+    mlp(xa).square().sum().backward()
+    ga = [p.grad.clone() for p in mlp.parameters()]
+    gxa = xa.grad.clone()
+    for p in mlp.parameters():
+        p.grad = None
+    xb = xf.contiguous().detach().requires_grad_()
+    mlp.layers(xb).square().sum().backward()
+    for a, p in zip(ga, mlp.parameters()):
+        assert (a - p.grad).abs().max() <= 1e-5 * p.grad.abs().max()
+    assert (gxa - xb.grad).abs().max() <= 1e-5 * xb.grad.abs().max()
+
+
+def test_bench_reads_counter_profiles():
+    import bench
+    tr = bench.pmc_traffic("k_conv3x3_dma conv3x3[128->128@512x512,s1]", 8)
+    assert tr and tr["traffic_unit"] == "bytes/launch" and tr["traffic_source"].startswith("profiles/")
+    assert 0.9 * tr["algorithmic_bytes"] < tr["traffic"] < 3.0 * tr["algorithmic_bytes"]
+    assert bench.pmc_traffic("k_conv3x3_dma conv3x3[128->128@512x512,s1]", 3) is None      # shape not profiled
+    assert bench.pmc_traffic("k_unknown foo", 8) is None
