@@ -97,7 +97,7 @@ def main():
     table = np.array([[env["C"](s, 3, st) for st in steps] for s in specs], dtype=np.float64)
     np.savez(os.path.join(OUT, "schedule.npz"), steps=np.array(steps), values=table)
     # ---------------------------------------------------------------- materials/dreammat_material.py
-    path = f"{REF}/models/materials/dreammat_material.py"
+    path = path_mat = f"{REF}/models/materials/dreammat_material.py"
     fns = extract(path, ["material_smoothness_grad", "sample_sphere", "az_el_to_points"])
     env = ns()
     for s in fns.values():
@@ -131,6 +131,64 @@ def main():
     np.savez(os.path.join(OUT, "shading.npz"), mat=mat, matj=matj, reg=reg, sphere_az=az, sphere_el=el,
              fg=fg, latlong=latlong, feats=feats, featsj=featsj, nrm=nrm, view=view, mat_reg=mat_reg,
              **{"out_" + k: v for k, v in outs.items()})
+    # ---------------------------------------------------------------- MC ray-traced shading (row f-1 groundwork)
+    # the reference's own method bodies; only the BVH ray tracer (un-vendored CUDA package) is stubbed, by the
+    # oracle's brute-force any-hit test, so the hit mask is an INPUT of the pinned arithmetic
+    from oracle import mc_shading as omc
+    g_mc = torch.Generator().manual_seed(20240)      # own stream: the fixtures generated after this section keep theirs
+    from dreammat_amd import mesh as pmesh
+    mc_names = ["get_orthogonal_directions", "sample_diffuse_directions", "sample_specular_directions", "distribution_ggx",
+                "geometry_schlick_ggx", "geometry_schlick", "geometry_ggx_smith_correlated", "geometry", "fresnel_schlick",
+                "fresnel_schlick_directions", "get_envirmentlight_blender", "get_lights", "shade_raytracing", "forward"]
+    meth = extract(path_mat, mc_names, cls="DreamMatMaterial")
+    top = extract(path_mat, ["saturate_dot", "sample_sphere", "material_smoothness_grad"])
+    env = ns(get_activation=ns_get_activation())
+    for s_ in top.values():
+        exec(s_, env)
+    for s_ in meth.values():
+        exec(s_, env)
+    msh = pmesh.displaced_sphere(12, 8)
+    mv, mf = msh.v_pos.float(), msh.t_pos_idx.long()
+    tri_pts = mv[mf]                                                     # [Nf,3,3]
+    fn = F.normalize(torch.cross(tri_pts[:, 1] - tri_pts[:, 0], tri_pts[:, 2] - tri_pts[:, 0], dim=-1), dim=-1)
+    pick = torch.randperm(mf.shape[0], generator=g_mc)[:40]
+    nrm_mc = fn[pick]
+    pts_mc = tri_pts[pick].mean(1) + 1e-4 * nrm_mc
+    view_mc = F.normalize(nrm_mc + 0.8 * torch.randn(40, 3, generator=g_mc), dim=-1)
+    light_mc = torch.rand(8, 16, 3, generator=g_mc) * 2.0
+
+    def trace_stub(o, d):
+        hit = omc.trace_any_hit(mv, mf, o, d)
+        depth = torch.where(hit, torch.ones(o.shape[0]), torch.full((o.shape[0],), 100.0))
+        return o.clone(), d.clone(), depth, hit
+    golden_mc = {}
+    for gname, nd, nsp, rnd in (("schlick", 16, 8, True), ("ggx_smith", 12, 12, False)):
+        az, el = env["sample_sphere"](nd, 0)
+        dsamp = torch.from_numpy(np.stack([az * 0.5 / np.pi, 1 - 2 * el / np.pi], -1).astype(np.float32))
+        az, el = env["sample_sphere"](nsp, 0)
+        ssamp = torch.from_numpy(np.stack([az * 0.5 / np.pi, 1 - 2 * el / np.pi], -1).astype(np.float32))
+        cfg = types.SimpleNamespace(use_raytracing=True, material_activation="sigmoid", min_metallic=0.0, max_metallic=0.9,
+                                    min_roughness=0.1, max_roughness=0.95, min_roughness_squre=0.01, max_roughness_squre=0.9,
+                                    random_azimuth=rnd, geometry_type=gname)
+        so = types.SimpleNamespace(cfg=cfg, diffuse_direction_samples=dsamp, specular_direction_samples=ssamp,
+                                   light=[light_mc], ray_trace_fun=trace_stub)
+        for nm in mc_names:
+            setattr(so, nm, types.MethodType(env[nm], so))
+        feats_mc = (torch.randn(40, 5, generator=g_mc) * 1.5).requires_grad_()
+        featsj_mc = (feats_mc.detach() + 0.2 * torch.randn(40, 5, generator=g_mc)).requires_grad_()
+        torch.manual_seed(77)
+        outs, mat_reg = env["forward"](so, pts_mc, feats_mc, featsj_mc, view_mc, nrm_mc, 0)
+        torch.manual_seed(77)           # replay the two azimuth draws (diffuse first, then specular)
+        ra_d, ra_s = torch.rand((40, 1, 1)), torch.rand((40, 1, 1))
+        wgt = torch.rand(40, 3, generator=g_mc)
+        ((outs["color"] * wgt).sum() + 3.0 * mat_reg).backward()
+        golden_mc.update({f"{gname}_dsamp": dsamp, f"{gname}_ssamp": ssamp, f"{gname}_feats": feats_mc.detach(),
+                          f"{gname}_featsj": featsj_mc.detach(), f"{gname}_rand_d": ra_d.view(-1), f"{gname}_rand_s": ra_s.view(-1),
+                          f"{gname}_wgt": wgt, f"{gname}_mat_reg": mat_reg.detach(), f"{gname}_dfeats": feats_mc.grad,
+                          f"{gname}_dfeatsj": featsj_mc.grad, f"{gname}_random": np.array(rnd)})
+        golden_mc.update({f"{gname}_out_{k}": v.detach() for k, v in outs.items()})
+    np.savez(os.path.join(OUT, "mc_shading.npz"), v_pos=mv, tri=mf, pts=pts_mc, nrm=nrm_mc, view=view_mc, light=light_mc,
+             **golden_mc)
     # ---------------------------------------------------------------- renderers/raytracing_renderer.py
     path = f"{REF}/models/renderers/raytracing_renderer.py"
     top = extract(path, ["xfm_vectors"])

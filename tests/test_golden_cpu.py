@@ -127,3 +127,35 @@ def test_reference_assets_loaders():
     assert np.array_equal(hdr, oenv.load_hdr(os.path.join(root, "lights/mud_road_puresky_1k.hdr")))
     m = pmesh.load_obj(os.path.join(root, "shapes/objs/apple.obj"))
     assert m.t_pos_idx.shape[0] == 4164
+
+
+@pytest.mark.parametrize("variant", ["schlick", "ggx_smith"])
+def test_mc_raytraced_shading_oracle_vs_reference(variant):
+    """SURVEY row f-1 groundwork: the oracle's restatement of the reference's default (Monte-Carlo, ray-traced)
+    material branch against the reference's own shade_raytracing / forward bodies -- outputs AND the gradients wrt
+    the material features (autograd through sample directions, pdfs, BRDF terms)."""
+    from oracle import mc_shading as omc
+    g = L("mc_shading.npz")
+    nd, nsp = g[f"{variant}_dsamp"].shape[0], g[f"{variant}_ssamp"].shape[0]
+    assert torch.equal(omc.direction_samples(nd), g[f"{variant}_dsamp"])            # Fibonacci tables of configure()
+    assert torch.equal(omc.direction_samples(nsp), g[f"{variant}_ssamp"])
+    random_az = bool(g[f"{variant}_random"])
+    feats = g[f"{variant}_feats"].clone().requires_grad_()
+    featsj = g[f"{variant}_featsj"].clone().requires_grad_()
+    trace = lambda o, d: omc.trace_any_hit(g["v_pos"], g["tri"], o, d)
+    out, reg = omc.material_forward_mc(g["pts"], feats, featsj, g["view"], g["nrm"], g["light"], g[f"{variant}_dsamp"],
+                                       g[f"{variant}_ssamp"], trace,
+                                       g[f"{variant}_rand_d"] if random_az else None,
+                                       g[f"{variant}_rand_s"] if random_az else None, geometry_type=variant)
+    assert abs(float(reg) - float(g[f"{variant}_mat_reg"])) < 1e-7
+    for k in ["color", "albedo", "roughness", "metalness", "specular_lights", "diffuse_lights", "specular_colors",
+              "diffuse_colors"]:
+        ref = g[f"{variant}_out_{k}"]
+        assert (out[k] - ref).abs().max() <= 1e-5 * max(1.0, ref.abs().max().item()), k
+    ((out["color"] * g[f"{variant}_wgt"]).sum() + 3.0 * reg).backward()
+    for got, ref in ((feats.grad, g[f"{variant}_dfeats"]), (featsj.grad, g[f"{variant}_dfeatsj"])):
+        assert (got - ref).abs().max() <= 1e-4 * max(1e-3, ref.abs().max().item())
+    # sanity of the stubbed scene: some directions are occluded by the mesh, most are not
+    dirs = omc.sample_diffuse_directions(g["nrm"], g[f"{variant}_dsamp"], None)
+    hit = trace((g["pts"][:, None] + 1e-5 * dirs).reshape(-1, 3), dirs.reshape(-1, 3))
+    assert 0 < int(hit.sum()) < hit.numel() // 2
