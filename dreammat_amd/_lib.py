@@ -71,6 +71,8 @@ _SIGS = {
     "dm_matreg_fwd": (c_int, [c_void_p, _LL, _LL, c_void_p, _LL, _LL, c_void_p, _LL, c_void_p, c_void_p]),
     "dm_matreg_bwd": (c_int, [c_void_p, _LL, _LL, c_void_p, _LL, _LL, c_void_p, _LL, c_float, c_void_p, _LL, _LL,
                               c_void_p, _LL, _LL, c_void_p]),
+    "dm_bvh_build": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dm_bvh_any_hit_rays": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _LL, c_float, c_void_p, c_void_p]),
     "dm_attention_fwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]
                               + [_LL] * 12 + [c_float, c_void_p]),
     "dm_conv3x3_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),

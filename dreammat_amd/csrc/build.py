@@ -22,9 +22,10 @@ SOURCES = {
     "groupnorm.hip": [],
     "transformer.hip": [],
     "adam.hip": [],
+    "bvh.hip": [],
     "host.cpp": [],
 }
-HEADERS = ["dm_common.h", "raster_core.h", "shade_core.h"]
+HEADERS = ["dm_common.h", "raster_core.h", "shade_core.h", "bvh_core.h"]
 
 
 def _newer(src, dst):

@@ -2,10 +2,83 @@
 // kernels (nvdiffrast builds this edge->opposite-vertex hash inside dr.antialias on every call;
 // the DreamMat mesh is fixed, so it is built once per mesh) and library introspection.
 #include <algorithm>
+#include <cfloat>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
+#include "bvh_core.h"
 #include "dm_common.h"
+
+namespace {
+
+struct Aabb {
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    void grow(const float* p) { for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); } }
+    void grow(const Aabb& o) { grow(o.lo); grow(o.hi); }
+    float area() const {
+        float d[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+        if (d[0] < 0.f) return 0.f;
+        return 2.f * (d[0] * d[1] + d[1] * d[2] + d[2] * d[0]);
+    }
+};
+
+struct BvhBuilder {
+    const float* v; const int32_t* tri; int n;
+    std::vector<Aabb> box;            // per triangle
+    std::vector<float> cen;           // per triangle centroid [n][3]
+    std::vector<int32_t> order;       // triangle ids, partitioned in place
+    std::vector<DmBvhNode> nodes;
+    static constexpr int kLeaf = 4, kBins = 16;
+
+    void set_box(int node, const Aabb& b) {
+        for (int k = 0; k < 3; ++k) { nodes[node].bmin[k] = b.lo[k]; nodes[node].bmax[k] = b.hi[k]; }
+    }
+    // binned surface-area heuristic; falls back to a median split when no bin boundary separates the centroids
+    void build(int node, int first, int count) {
+        Aabb bb, cb;
+        for (int i = first; i < first + count; ++i) { bb.grow(box[order[i]]); cb.grow(&cen[3 * (size_t)order[i]]); }
+        set_box(node, bb);
+        if (count <= kLeaf) { nodes[node].a = first; nodes[node].b = count; return; }
+        int axis = 0;
+        float ext[3] = {cb.hi[0] - cb.lo[0], cb.hi[1] - cb.lo[1], cb.hi[2] - cb.lo[2]};
+        if (ext[1] > ext[axis]) axis = 1;
+        if (ext[2] > ext[axis]) axis = 2;
+        int mid = first + count / 2;
+        if (ext[axis] > 0.f) {
+            Aabb bin_box[kBins]; int bin_cnt[kBins] = {0};
+            const float scale = kBins / ext[axis];
+            auto bin_of = [&](int t) { return std::min(kBins - 1, (int)((cen[3 * (size_t)t + axis] - cb.lo[axis]) * scale)); };
+            for (int i = first; i < first + count; ++i) { int b = bin_of(order[i]); bin_box[b].grow(box[order[i]]); ++bin_cnt[b]; }
+            float right_area[kBins]; Aabb acc; int best = -1; float best_cost = FLT_MAX;
+            for (int b = kBins - 1; b > 0; --b) { acc.grow(bin_box[b]); right_area[b] = acc.area(); }
+            Aabb left; int nl = 0;
+            for (int b = 0; b + 1 < kBins; ++b) {
+                left.grow(bin_box[b]); nl += bin_cnt[b];
+                if (nl == 0 || nl == count) continue;
+                float cost = left.area() * nl + right_area[b + 1] * (count - nl);
+                if (cost < best_cost) { best_cost = cost; best = b; }
+            }
+            if (best >= 0) {
+                auto it = std::partition(order.begin() + first, order.begin() + first + count,
+                                         [&](int32_t t) { return bin_of(t) <= best; });
+                mid = (int)(it - order.begin());
+            }
+        }
+        if (mid == first || mid == first + count || ext[axis] <= 0.f) {        // degenerate: split the list in half
+            mid = first + count / 2;
+            std::nth_element(order.begin() + first, order.begin() + mid, order.begin() + first + count,
+                             [&](int32_t x, int32_t y) { return cen[3 * (size_t)x + axis] < cen[3 * (size_t)y + axis]; });
+        }
+        const int left_node = (int)nodes.size();
+        nodes.emplace_back(); nodes.emplace_back();
+        nodes[node].a = left_node; nodes[node].b = 0;
+        build(left_node, first, mid - first);
+        build(left_node + 1, mid, first + count - mid);
+    }
+};
+
+}  // namespace
 
 extern "C" {
 
@@ -43,6 +116,47 @@ int dm_mesh_build_topology(const int32_t* tri, int32_t n_tri, int32_t* opp) {
         }
         i = j;
     }
+    return DM_OK;
+}
+
+// Bounding-volume hierarchy over the (fixed) DreamMat mesh for the Monte-Carlo shading branch: the host-side
+// counterpart of `_raytracing.create_raytracer(vertices, triangles)` (raytracing_renderer.py:31).  Host pointers.
+//   nodes_out [2*n_tri] DmBvhNode (32 B each), tris_out [n_tri*12] floats in leaf order, order_out [n_tri] (or NULL) =
+//   original triangle id of each leaf slot, *n_nodes_out = nodes used.  Layout: csrc/bvh_core.h.
+int dm_bvh_build(const float* v_pos, int32_t n_vert, const int32_t* tri, int32_t n_tri, void* nodes_out, float* tris_out,
+                 int32_t* order_out, int32_t* n_nodes_out) {
+    if (!v_pos || !tri || !nodes_out || !tris_out || !n_nodes_out || n_vert <= 0 || n_tri <= 0) return DM_ERR_ARG;
+    for (size_t i = 0; i < (size_t)n_tri * 3; ++i)
+        if (tri[i] < 0 || tri[i] >= n_vert) return DM_ERR_ARG;
+    BvhBuilder b;
+    b.v = v_pos; b.tri = tri; b.n = n_tri;
+    b.box.resize(n_tri); b.cen.resize((size_t)n_tri * 3); b.order.resize(n_tri);
+    for (int32_t t = 0; t < n_tri; ++t) {
+        b.order[t] = t;
+        float c[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < 3; ++k) {
+            const float* p = v_pos + 3 * (size_t)tri[3 * (size_t)t + k];
+            b.box[t].grow(p);
+            for (int d = 0; d < 3; ++d) c[d] += p[d] * (1.0f / 3.0f);
+        }
+        for (int d = 0; d < 3; ++d) b.cen[3 * (size_t)t + d] = c[d];
+    }
+    b.nodes.reserve((size_t)2 * n_tri);
+    b.nodes.emplace_back();
+    b.build(0, 0, n_tri);
+    if (b.nodes.size() > (size_t)2 * n_tri) return DM_ERR_WORKSPACE;
+    std::memcpy(nodes_out, b.nodes.data(), b.nodes.size() * sizeof(DmBvhNode));
+    for (int32_t j = 0; j < n_tri; ++j) {
+        const int32_t t = b.order[j];
+        const float* p0 = v_pos + 3 * (size_t)tri[3 * (size_t)t];
+        const float* p1 = v_pos + 3 * (size_t)tri[3 * (size_t)t + 1];
+        const float* p2 = v_pos + 3 * (size_t)tri[3 * (size_t)t + 2];
+        float* o = tris_out + 12 * (size_t)j;
+        for (int d = 0; d < 3; ++d) { o[d] = p0[d]; o[4 + d] = p1[d] - p0[d]; o[8 + d] = p2[d] - p0[d]; }
+        o[3] = o[7] = o[11] = 0.f;
+        if (order_out) order_out[j] = t;
+    }
+    *n_nodes_out = (int32_t)b.nodes.size();
     return DM_OK;
 }
 

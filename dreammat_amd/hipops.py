@@ -532,6 +532,39 @@ def groupnorm_nhwc(x_nhwc, gamma, beta, eps, act):
     return _gn_fwd(x_nhwc, gamma, beta, eps, act)[0]
 
 
+# ------------------------------------------------------------------------------------------ ray queries (row f-1)
+class MeshBvh:
+    """BVH of a fixed mesh (dm_bvh_build, host) with device copies of the node / triangle arrays; the counterpart of
+    `RayTracer(vertices, triangles)` (raytracing_renderer.py:20-31)."""
+
+    def __init__(self, v_pos, tri, device=None):
+        v = v_pos.detach().float().cpu().contiguous()
+        t = tri.detach().to(torch.int32).cpu().contiguous()
+        n_tri = t.shape[0]
+        nodes = torch.zeros(2 * n_tri, 8, dtype=torch.int32)                    # 32 B per node
+        tris = torch.empty(n_tri, 12, dtype=torch.float32)
+        order = torch.empty(n_tri, dtype=torch.int32)
+        n_nodes = ctypes.c_int32(0)
+        check(_lib.lib().dm_bvh_build(v.data_ptr(), v.shape[0], t.data_ptr(), n_tri, nodes.data_ptr(), tris.data_ptr(),
+                                      order.data_ptr(), ctypes.addressof(n_nodes)), "dm_bvh_build")
+        self.n_nodes = int(n_nodes.value)
+        self.nodes_host, self.tris_host, self.order = nodes[:self.n_nodes].contiguous(), tris, order
+        self.nodes = self.tris = None
+        if device is not None:
+            self.nodes, self.tris = self.nodes_host.to(device), self.tris_host.to(device)
+
+    def any_hit(self, origins, dirs, t_max=10.0):
+        """hit mask [n] (bool) of rays origins + t*dirs, 0 < t < t_max (miss <=> the reference's depth >= 10)."""
+        _need_cuda(origins, dirs)
+        if self.nodes is None:
+            raise _lib.DmError("MeshBvh was built without a device")
+        o, d = _f32c(origins.reshape(-1, 3)), _f32c(dirs.reshape(-1, 3))
+        hit = torch.empty(o.shape[0], dtype=torch.uint8, device=o.device)
+        check(_lib.lib().dm_bvh_any_hit_rays(self.nodes.data_ptr(), self.tris.data_ptr(), o.data_ptr(), d.data_ptr(),
+                                             o.shape[0], float(t_max), hit.data_ptr(), _stream()), "dm_bvh_any_hit_rays")
+        return hit.bool().reshape(origins.shape[:-1])
+
+
 # ------------------------------------------------------------------------------------------ transformer rows
 def layernorm_rows(x, gamma, beta, eps):
     """LayerNorm over the last dim of a contiguous bf16 tensor [..., C] (forward only)."""

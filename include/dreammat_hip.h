@@ -156,6 +156,19 @@ int dm_matreg_bwd(const float* feat, long long f_rs, long long f_cs, const float
                   long long df_rs, long long df_cs, float* dfeatj, long long dj_rs, long long dj_cs,
                   dm_stream_t stream);
 
+/* ---- ray queries for the Monte-Carlo shading branch (groundwork) ------------------- */
+/* `_raytracing.create_raytracer(vertices, triangles)` (models/renderers/raytracing_renderer.py:31): HOST function,
+ * host pointers.  nodes_out: 2*n_tri nodes of 32 B {bmin.xyz, a, bmax.xyz, b} (leaf when b > 0: triangles [a, a+b) of
+ * tris_out; else children a and a+1); tris_out [n_tri*12] = {v0,0,e1,0,e2,0} in leaf order; order_out [n_tri] (may be
+ * NULL) = original triangle id per leaf slot; *n_nodes_out = nodes used.  Copy nodes / tris to the device once. */
+int dm_bvh_build(const float* v_pos_host, int32_t n_vert, const int32_t* tri_host, int32_t n_tri, void* nodes_out,
+                 float* tris_out, int32_t* order_out, int32_t* n_nodes_out);
+/* `RayTracer.trace` as DreamMatMaterial.get_lights consumes it (dreammat_material.py:490-507,
+ * raytracing_renderer.py:318-324): hit[i] = 1 iff ray origins[i] + t*dirs[i] meets the mesh for some 0 < t < t_max
+ * (double-sided).  Device pointers; origins, dirs [n,3] fp32. */
+int dm_bvh_any_hit_rays(const void* nodes, const float* tris, const float* origins, const float* dirs, long long n,
+                        float t_max, unsigned char* hit, dm_stream_t stream);
+
 /* ---- attention ---------------------------------------------------------------------------- */
 /* The QK^T.softmax.V of every transformer block diffusers runs inside ControlNetModel /
  * UNet2DConditionModel (models/guidance/dreammat_guidance.py:205-241, 261-282), bf16, MFMA.

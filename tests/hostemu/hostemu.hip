@@ -1,9 +1,11 @@
 // TEST INFRASTRUCTURE: runs the product's per-thread __host__ __device__ arithmetic
-// (dreammat_amd/csrc/raster_core.h, shade_core.h) in plain host loops so the CPU-only test suite
+// (dreammat_amd/csrc/raster_core.h, shade_core.h, bvh_core.h, mc_shade_core.h) in plain host loops so the CPU-only test suite
 // can check it against the oracle without a GPU.  Never loaded by the product.
 #include <cstring>
 #include <vector>
 
+#include "../../dreammat_amd/csrc/bvh_core.h"
+#include "../../dreammat_amd/csrc/mc_shade_core.h"
 #include "../../dreammat_amd/csrc/raster_core.h"
 #include "../../dreammat_amd/csrc/shade_core.h"
 
@@ -102,6 +104,50 @@ int emu_shade(const emu_atlas* atlas, const float* matcfg, const float* nrm, con
             d[15] = c.metallic; d[16] = c.roughness;
         }
         if (dcolor) shade_backward(M, c, f3(dcolor[3 * i], dcolor[3 * i + 1], dcolor[3 * i + 2]), dfeat + 5 * i);
+    }
+    return 0;
+}
+
+// any-hit BVH traversal (bvh_core.h) over host copies of dm_bvh_build's outputs
+int emu_bvh_any_hit(const void* nodes, const float* tris, const float* org, const float* dir, long long n, float t_max,
+                    unsigned char* hit) {
+    for (long long i = 0; i < n; ++i)
+        hit[i] = dm_bvh_any_hit((const DmBvhNode*)nodes, tris, org[3 * i], org[3 * i + 1], org[3 * i + 2], dir[3 * i],
+                                dir[3 * i + 1], dir[3 * i + 2], t_max) ? 1 : 0;
+    return 0;
+}
+
+// Monte-Carlo shading (mc_shade_core.h): forward = shade_pixel<float, true> (traces, records the hit bits), backward =
+// shade_pixel<Dual, false> on the recorded bits + finish_backward.  out [N,25] = color3 albedo3 roughness1 metalness1
+// specular_lights3 diffuse_lights3 specular_colors3 diffuse_colors3 pre3 (linear colour) alpha1 pad1.
+int emu_mc_shade(const float* cfg4, int nd, int ns, int ggx_smith, const void* nodes, const float* tris, const float* light,
+                 int lh, int lw, const float* samples_d, const float* samples_s, long long N, const float* p, const float* n,
+                 const float* v, const float* feat, const float* rand_d, const float* rand_s, unsigned* hit_bits, float* out,
+                 const float* dcolor, float* dfeat) {
+    using namespace dm::mc;
+    McCfg cfg = {cfg4[0], cfg4[1], cfg4[2], cfg4[3], nd, ns, ggx_smith};
+    McScene sc = {(const DmBvhNode*)nodes, tris, light, lh, lw, samples_d, samples_s};
+    const int words = kMaxSamples / 32;
+    if (nd + ns > kMaxSamples) return -1;
+    for (long long i = 0; i < N; ++i) {
+        unsigned* hb = hit_bits + (size_t)i * words;
+        McPixel px;
+        const float rd = rand_d ? rand_d[i] : -1.f, rs = rand_s ? rand_s[i] : -1.f;
+        if (!dcolor) {
+            std::memset(hb, 0, words * sizeof(unsigned));
+            shade_pixel<float, true>(cfg, sc, p + 3 * i, n + 3 * i, v + 3 * i, feat + 5 * i, rd, rs, hb, px);
+            float* o = out + 25 * i;
+            for (int c = 0; c < 3; ++c) {
+                o[c] = lin2srgb_mc(px.pre[c]); o[3 + c] = lin2srgb_mc(px.albedo[c]);
+                o[8 + c] = lin2srgb_mc(px.Ls_mean[c]); o[11 + c] = lin2srgb_mc(px.Ld_mean[c]);
+                o[14 + c] = lin2srgb_mc(px.specular[c]); o[17 + c] = lin2srgb_mc(px.diffuse[c]);
+                o[20 + c] = px.pre[c];
+            }
+            o[6] = sqrtf(px.alpha + 1e-7f); o[7] = px.metallic; o[23] = px.alpha; o[24] = 0.f;
+        } else {
+            shade_pixel<Dual, false>(cfg, sc, p + 3 * i, n + 3 * i, v + 3 * i, feat + 5 * i, rd, rs, hb, px);
+            finish_backward(cfg, px, dcolor + 3 * i, dfeat + 5 * i);
+        }
     }
     return 0;
 }

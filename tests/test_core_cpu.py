@@ -199,3 +199,53 @@ def test_attention_index_math_on_mfma_model():
         S = Q @ K.T * D ** -0.5
         Pm = np.exp(S - S.max(1, keepdims=True)); Pm /= Pm.sum(1, keepdims=True)
         assert np.abs(attention_wave_sim(Q, K, V, D ** -0.5) - Pm @ V).max() < 1e-12
+
+
+def test_bvh_build_and_traversal_core_vs_brute_force(hostemu):
+    """SURVEY row f-1 groundwork: the host BVH builder of the product library (dm_bvh_build) and the traversal core
+    the HIP kernels share (csrc/bvh_core.h, run here through tests/hostemu) against the oracle's brute-force
+    double-sided any-hit test."""
+    import ctypes
+
+    from dreammat_amd import hipops, mesh as pmesh
+    from oracle import mc_shading as omc
+    torch.manual_seed(0)
+    for (n_lon, n_lat) in [(12, 8), (48, 40)]:
+        m = pmesh.displaced_sphere(n_lon, n_lat)
+        bvh = hipops.MeshBvh(m.v_pos, m.t_pos_idx)
+        n_tri = m.t_pos_idx.shape[0]
+        nodes = bvh.nodes_host
+        assert 1 <= bvh.n_nodes <= 2 * n_tri and sorted(bvh.order.tolist()) == list(range(n_tri))
+        # structure: every leaf slot used exactly once; children boxes inside the parent box; triangles inside leaves
+        fl = nodes.view(torch.float32)
+        covered = torch.zeros(n_tri, dtype=torch.int32)
+        tv = m.v_pos.float()[m.t_pos_idx.long()[bvh.order.long()]]                    # [n_tri,3,3] in leaf order
+        assert torch.allclose(bvh.tris_host[:, 0:3], tv[:, 0]) and torch.allclose(bvh.tris_host[:, 4:7], tv[:, 1] - tv[:, 0])
+        for i in range(bvh.n_nodes):
+            a, b = int(nodes[i, 3]), int(nodes[i, 7])
+            lo, hi = fl[i, 0:3], fl[i, 4:7]
+            if b > 0:
+                covered[a:a + b] += 1
+                pts = tv[a:a + b].reshape(-1, 3)
+                assert (pts >= lo - 1e-6).all() and (pts <= hi + 1e-6).all() and b <= 4
+            else:
+                for c in (a, a + 1):
+                    assert (fl[c, 0:3] >= lo - 1e-6).all() and (fl[c, 4:7] <= hi + 1e-6).all()
+        assert (covered == 1).all()
+        # rays: from surface points along random directions (the shading pattern) + from outside towards the object
+        tri_c = tv.mean(1)
+        fn = torch.nn.functional.normalize(torch.cross(tv[:, 1] - tv[:, 0], tv[:, 2] - tv[:, 0], dim=-1), dim=-1)
+        pick = torch.randint(0, n_tri, (1500,))
+        d1 = torch.nn.functional.normalize(torch.randn(1500, 3), dim=-1)
+        o1 = tri_c[pick] + 1e-4 * fn[pick] + 1e-5 * d1
+        o2 = torch.nn.functional.normalize(torch.randn(500, 3), dim=-1) * 3.0
+        d2 = torch.nn.functional.normalize(-o2 + 0.6 * torch.randn(500, 3), dim=-1)
+        o, d = torch.cat([o1, o2]).contiguous(), torch.cat([d1, d2]).contiguous()
+        hit = torch.zeros(o.shape[0], dtype=torch.uint8)
+        hostemu.emu_bvh_any_hit(ctypes.c_void_p(nodes.data_ptr()), ctypes.c_void_p(bvh.tris_host.data_ptr()),
+                                ctypes.c_void_p(o.data_ptr()), ctypes.c_void_p(d.data_ptr()), ctypes.c_longlong(o.shape[0]),
+                                ctypes.c_float(10.0), ctypes.c_void_p(hit.data_ptr()))
+        ref = omc.trace_any_hit(m.v_pos.float(), m.t_pos_idx, o, d)
+        mism = int((hit.bool() != ref).sum())
+        assert mism <= 2, (mism, o.shape[0])                                          # fp32 vs fp64 on edge-grazing rays
+        assert 0.2 < ref.float().mean() < 0.95

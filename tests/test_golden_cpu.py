@@ -159,3 +159,54 @@ def test_mc_raytraced_shading_oracle_vs_reference(variant):
     dirs = omc.sample_diffuse_directions(g["nrm"], g[f"{variant}_dsamp"], None)
     hit = trace((g["pts"][:, None] + 1e-5 * dirs).reshape(-1, 3), dirs.reshape(-1, 3))
     assert 0 < int(hit.sum()) < hit.numel() // 2
+
+
+def _emu_mc_shade(hostemu, bvh, light, dsamp, ssamp, pts, nrm, view, feats, rand_d, rand_s, ggx_smith, dcolor=None, hit_bits=None):
+    import ctypes
+    N = pts.shape[0]
+    cp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    f = lambda t: t.detach().float().contiguous() if t is not None else None
+    cfg4 = torch.tensor([0.0, 0.9, 0.01, 0.9])
+    light, dsamp, ssamp, pts, nrm, view, feats = map(f, (light, dsamp, ssamp, pts, nrm, view, feats))
+    rand_d, rand_s, dcolor = f(rand_d), f(rand_s), f(dcolor)
+    if hit_bits is None:
+        hit_bits = torch.zeros(N, 32, dtype=torch.int32)
+    out = torch.zeros(N, 25)
+    dfeat = torch.zeros(N, 5)
+    rc = hostemu.emu_mc_shade(cp(cfg4), dsamp.shape[0], ssamp.shape[0], int(ggx_smith), cp(bvh.nodes_host), cp(bvh.tris_host),
+                              cp(light), light.shape[0], light.shape[1], cp(dsamp), cp(ssamp), ctypes.c_longlong(N), cp(pts),
+                              cp(nrm), cp(view), cp(feats), cp(rand_d), cp(rand_s), cp(hit_bits), cp(out), cp(dcolor), cp(dfeat))
+    assert rc == 0
+    return out, dfeat, hit_bits
+
+
+@pytest.mark.parametrize("variant", ["schlick", "ggx_smith"])
+def test_mc_shading_product_core_vs_reference(hostemu, variant):
+    """the product's Monte-Carlo shading core (csrc/mc_shade_core.h: BVH any-hit + sampling + BRDF + forward-mode
+    d/d(alpha)), run on the CPU through tests/hostemu, against the REFERENCE's outputs and autograd gradients."""
+    from dreammat_amd import hipops
+    g = L("mc_shading.npz")
+    bvh = hipops.MeshBvh(g["v_pos"], g["tri"])
+    random_az = bool(g[f"{variant}_random"])
+    rd = g[f"{variant}_rand_d"] if random_az else None
+    rs = g[f"{variant}_rand_s"] if random_az else None
+    args = (hostemu, bvh, g["light"], g[f"{variant}_dsamp"], g[f"{variant}_ssamp"], g["pts"], g["nrm"], g["view"],
+            g[f"{variant}_feats"], rd, rs, variant == "ggx_smith")
+    out, _, bits = _emu_mc_shade(*args)
+    cols = {"color": (0, 3), "albedo": (3, 6), "roughness": (6, 7), "metalness": (7, 8), "specular_lights": (8, 11),
+            "diffuse_lights": (11, 14), "specular_colors": (14, 17), "diffuse_colors": (17, 20)}
+    for k, (a, b) in cols.items():
+        ref = g[f"{variant}_out_{k}"]
+        err = (out[:, a:b] - ref).abs().max().item()
+        assert err <= 2e-4 * max(1.0, ref.abs().max().item()), (k, err)
+    # backward on the recorded hit bits: d(sum(color * wgt)) / d features  (mat_reg's share is subtracted: it has its
+    # own kernel, k_matreg)
+    from oracle import shading as oshade
+    feats = g[f"{variant}_feats"].clone().requires_grad_()
+    featsj = g[f"{variant}_featsj"].clone()
+    (3.0 * oshade.material_smoothness_grad(torch.sigmoid(feats), torch.sigmoid(featsj))).backward()
+    ref_grad = g[f"{variant}_dfeats"] - feats.grad
+    _, dfeat, _ = _emu_mc_shade(*args, dcolor=g[f"{variant}_wgt"], hit_bits=bits)
+    scale = ref_grad.abs().max().item()
+    assert (dfeat - ref_grad).abs().max().item() <= 2e-3 * scale, ((dfeat - ref_grad).abs().max().item(), scale)
+    assert (dfeat[:, 4].abs() > 0).any() and (dfeat[:, 3].abs() > 0).any()           # roughness / metallic do get gradient
