@@ -23,9 +23,10 @@ SOURCES = {
     "transformer.hip": [],
     "adam.hip": [],
     "bvh.hip": [],
+    "mc_shade.hip": [],
     "host.cpp": [],
 }
-HEADERS = ["dm_common.h", "raster_core.h", "shade_core.h", "bvh_core.h"]
+HEADERS = ["dm_common.h", "raster_core.h", "shade_core.h", "bvh_core.h", "mc_shade_core.h"]
 
 
 def _newer(src, dst):

@@ -565,6 +565,96 @@ class MeshBvh:
         return hit.bool().reshape(origins.shape[:-1])
 
 
+def fibonacci_direction_samples(num_samples):
+    """the [n, 2] (azimuth, elevation) table in [0,1]^2 that DreamMatMaterial.configure builds from sample_sphere
+    (dreammat_material.py:84-98, 389-398): Fibonacci lattice on the upper hemisphere."""
+    n = np.arange(num_samples, 2 * num_samples)                                 # begin_elevation = 0: upper half of 2n points
+    z = 2.0 * n / (2 * num_samples) - 1.0
+    az = 2 * np.pi * n * ((np.sqrt(5) - 1.0) / 2.0) % (2 * np.pi)
+    el = np.arcsin(z)
+    return torch.from_numpy(np.stack([az * 0.5 / np.pi, 1 - 2 * el / np.pi], -1).astype(np.float32))
+
+
+class McScene:
+    """Everything the Monte-Carlo shading kernels need besides the per-pixel inputs (dm_mc_scene): the mesh BVH, the
+    lat-long radiance images of all environments and the two direction tables."""
+
+    def __init__(self, bvh, latlongs, n_diffuse, n_specular, geometry_type="schlick", device=None):
+        if geometry_type not in ("schlick", "ggx_smith"):
+            raise NotImplementedError(f"geometry_type={geometry_type!r} (dreammat_material.py:606-613)")
+        dev = device or bvh.nodes.device
+        self.bvh = bvh
+        imgs = [torch.as_tensor(x, dtype=torch.float32) for x in latlongs]
+        if any(i.shape != imgs[0].shape for i in imgs):
+            raise _lib.DmError("all environment lat-long images must share one resolution for the MC shading kernels")
+        self.lights = torch.stack(imgs).to(dev).contiguous()                    # [n_env, h, w, 3]
+        self.samples_d = fibonacci_direction_samples(n_diffuse).to(dev)
+        self.samples_s = fibonacci_direction_samples(n_specular).to(dev)
+        self.n_diffuse, self.n_specular = int(n_diffuse), int(n_specular)
+        self.hit_words = int(_lib.lib().dm_mc_hit_words(self.n_diffuse, self.n_specular))
+        self.struct = _lib.McSceneStruct(bvh.nodes.data_ptr(), bvh.tris.data_ptr(), self.lights.data_ptr(),
+                                         self.lights.shape[0], self.lights.shape[1], self.lights.shape[2],
+                                         self.samples_d.data_ptr(), self.samples_s.data_ptr(), self.n_diffuse,
+                                         self.n_specular, 1 if geometry_type == "ggx_smith" else 0)
+
+
+class _McShade(torch.autograd.Function):
+    """DreamMatMaterial.forward(use_raytracing=True) -> shade_raytracing (dreammat_material.py:615-677, 726-744)."""
+
+    @staticmethod
+    def forward(ctx, feat, pos, nrm, view, pix_idx, n_dev, env_of_view, scene, mat, HW, rand_d, rand_s, want_debug):
+        _need_cuda(feat, pos, nrm, view, pix_idx, env_of_view, rand_d, rand_s)
+        N = feat.shape[0]
+        dev = feat.device
+        color = torch.empty(3, N, device=dev)
+        hit_bits = torch.zeros(max(N, 1), scene.hit_words, dtype=torch.int32, device=dev)
+        dbg = [None] * 7
+        if want_debug:
+            dbg = [torch.empty(N, 3, device=dev) for _ in range(5)] + [torch.empty(N, 1, device=dev) for _ in range(2)]
+        if N > 0:
+            with _Timed("mc_shade_fwd", 72.0 * N):
+                check(_lib.lib().dm_mc_shade_fwd(
+                    ctypes.byref(scene.struct), ctypes.byref(mat), pos.data_ptr(), *_rs_cs(pos), nrm.data_ptr(), *_rs_cs(nrm),
+                    view.data_ptr(), *_rs_cs(view), feat.data_ptr(), *_rs_cs(feat), pix_idx.data_ptr(), env_of_view.data_ptr(),
+                    n_dev.data_ptr(), N, HW, rand_d.data_ptr() if rand_d is not None else None,
+                    rand_s.data_ptr() if rand_s is not None else None, hit_bits.data_ptr(), color.data_ptr(), 1, N,
+                    *[d.data_ptr() if d is not None else None for d in dbg], _stream()), "dm_mc_shade_fwd")
+        ctx.save_for_backward(feat, pos, nrm, view, pix_idx, n_dev, env_of_view, hit_bits,
+                              *([rand_d] if rand_d is not None else []), *([rand_s] if rand_s is not None else []))
+        ctx.has_rand = (rand_d is not None, rand_s is not None)
+        ctx.scene, ctx.mat, ctx.HW = scene, mat, HW
+        # order of the debug buffers: albedo, specular_lights, diffuse_lights, specular_colors, diffuse_colors,
+        # metalness, roughness (as dm_shade_fwd)
+        outs = (color.t(),) + tuple(d for d in dbg if d is not None)
+        ctx.mark_non_differentiable(*outs[1:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g, *unused):
+        saved = list(ctx.saved_tensors)
+        feat, pos, nrm, view, pix_idx, n_dev, env_of_view, hit_bits = saved[:8]
+        rest = saved[8:]
+        rand_d = rest.pop(0) if ctx.has_rand[0] else None
+        rand_s = rest.pop(0) if ctx.has_rand[1] else None
+        N = feat.shape[0]
+        dfeat = torch.zeros(5, N, device=feat.device)
+        if N > 0:
+            with _Timed("mc_shade_bwd", 92.0 * N):
+                check(_lib.lib().dm_mc_shade_bwd(
+                    ctypes.byref(ctx.scene.struct), ctypes.byref(ctx.mat), pos.data_ptr(), *_rs_cs(pos), nrm.data_ptr(),
+                    *_rs_cs(nrm), view.data_ptr(), *_rs_cs(view), feat.data_ptr(), *_rs_cs(feat), pix_idx.data_ptr(),
+                    env_of_view.data_ptr(), n_dev.data_ptr(), N, ctx.HW, rand_d.data_ptr() if rand_d is not None else None,
+                    rand_s.data_ptr() if rand_s is not None else None, hit_bits.data_ptr(), g.data_ptr(), *_rs_cs(g),
+                    dfeat.data_ptr(), 1, N, _stream()), "dm_mc_shade_bwd")
+        return (dfeat.t(),) + (None,) * 12
+
+
+def mc_shade(feat, pos, nrm, view, pix_idx, n_dev, env_of_view, scene, mat, HW, rand_d=None, rand_s=None, want_debug=True):
+    """-> (color [N,3], albedo, spec_light, diff_light, spec_color, diff_color, metallic, roughness), the 8 outputs of
+    shade_raytracing (all already lin2srgb-encoded where the reference encodes them)."""
+    return _McShade.apply(feat, pos, nrm, view, pix_idx, n_dev, env_of_view, scene, mat, HW, rand_d, rand_s, want_debug)
+
+
 # ------------------------------------------------------------------------------------------ transformer rows
 def layernorm_rows(x, gamma, beta, eps):
     """LayerNorm over the last dim of a contiguous bf16 tensor [..., C] (forward only)."""

@@ -2,8 +2,10 @@
 branch.  forward() keeps the reference signature
     forward(pts, features, features_jitter, viewdirs, normals, env_id) -> (outputs dict, mat_reg)
 and runs two HIP kernels: the fused activation + FG-LUT + env-lookup shade kernel and the smoothness
-regulariser.  `use_raytracing: true` (the reference default, Monte-Carlo shading with BVH
-visibility) is SURVEY row f-1 and not built yet: it raises.
+regulariser.  `use_raytracing: true` (the reference default, Monte-Carlo shading with BVH visibility, SURVEY
+row f-1) runs the fused Monte-Carlo kernels (csrc/mc_shade.hip) once the renderer has handed over the mesh BVH
+through `set_raytracer`; their arithmetic is validated on the CPU against the reference (tests/hostemu), GPU
+validation is pending (no GPU time left in round 1), so the bench / north-star path keeps `use_raytracing: false`.
 """
 import os
 from dataclasses import dataclass
@@ -60,6 +62,12 @@ class DreamMatMaterial(BaseModule):
         self.register_buffer("FG_LUT", fg.reshape(1, *fg.shape), persistent=False)
         self.mat = _lib.MatCfgStruct(self.cfg.min_metallic, self.cfg.max_metallic, self.cfg.min_roughness,
                                      self.cfg.max_roughness)
+        # Monte-Carlo branch: "roughness" is alpha, already squared (dreammat_material.py:740-743)
+        self.mat_mc = _lib.MatCfgStruct(self.cfg.min_metallic, self.cfg.max_metallic, self.cfg.min_roughness_squre,
+                                        self.cfg.max_roughness_squre)
+        # the reference keeps the raw lat-long images next to the envlight cubes (self.light, :384-386)
+        self._latlongs = [torch.as_tensor(x, dtype=torch.float32) for x in latlongs]
+        self.mc_scene = None
 
     def _load_envmaps(self):
         """dreammat_material.py:378-386: <environment_texture>/map{i}/map{i}.hdr for i=1..5; a single
@@ -75,14 +83,15 @@ class DreamMatMaterial(BaseModule):
         return out
 
     def set_raytracer(self, ray_trace_fun):
+        """reference: a callable (o, d) -> (inters, normals, depth, hit_mask) (raytracing_renderer.py:104).  Here the
+        occlusion rays are fused into the shading kernel, so what is handed over is the mesh BVH (hipops.MeshBvh)."""
         self.ray_trace_fun = ray_trace_fun
+        if isinstance(ray_trace_fun, hipops.MeshBvh):
+            self.mc_scene = hipops.McScene(ray_trace_fun, self._latlongs, self.cfg.diffuse_sample_num,
+                                           self.cfg.specular_sample_num, self.cfg.geometry_type)
 
     def forward(self, pts, features, features_jitter, viewdirs, normals, env_id, pix_idx=None, n_dev=None,
                 hw=None, want_debug=True, **kwargs):
-        if self.cfg.use_raytracing:
-            raise NotImplementedError(
-                "use_raytracing=true (Monte-Carlo shading, dreammat_material.py:615-677) is not built yet "
-                "(SURVEY row f-1); set system.material.use_raytracing=false for the split-sum path")
         N = features.shape[0]
         dev = features.device
         if n_dev is None:
@@ -93,8 +102,19 @@ class DreamMatMaterial(BaseModule):
             pix_idx = torch.zeros(N, dtype=torch.int32, device=dev)
             hw = 1 << 30
             env_id = env_id[:1].contiguous()
-        outs = hipops.shade(features, normals, viewdirs, pix_idx, n_dev, env_id.contiguous(), self.atlas, self.mat,
-                            int(hw), want_debug)
+        if self.cfg.use_raytracing:
+            if self.mc_scene is None:
+                raise _lib.DmError("use_raytracing=true needs the mesh BVH: call set_raytracer(hipops.MeshBvh(...)) first "
+                                   "(RaytraceRender.configure does, raytracing_renderer.py:103-104)")
+            rand_d, rand_s = kwargs.get("rand_diffuse"), kwargs.get("rand_specular")
+            if self.cfg.random_azimuth and self.training:          # is_train=True in the reference's forward (:744)
+                rand_d = torch.rand(N, device=dev) if rand_d is None else rand_d
+                rand_s = torch.rand(N, device=dev) if rand_s is None else rand_s
+            outs = hipops.mc_shade(features, pts, normals, viewdirs, pix_idx, n_dev, env_id.contiguous(), self.mc_scene,
+                                   self.mat_mc, int(hw), rand_d, rand_s, want_debug)
+        else:
+            outs = hipops.shade(features, normals, viewdirs, pix_idx, n_dev, env_id.contiguous(), self.atlas, self.mat,
+                                int(hw), want_debug)
         mat_reg = hipops.material_smoothness(features, features_jitter, n_dev)
         out = {"color": outs[0]}
         if want_debug:

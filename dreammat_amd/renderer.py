@@ -48,6 +48,10 @@ class RaytraceRender(BaseModule):
         m = self.geometry.isosurface()
         if self._opp is None or self._opp.device != m.v_pos.device:
             self._opp = hipops.build_topology(m.t_pos_idx)
+            if getattr(self.material.cfg, "use_raytracing", False) and m.v_pos.is_cuda:
+                # raytracing_renderer.py:103-104: RayTracer(mesh) handed to the material (here: the BVH itself, the
+                # occlusion rays are traced inside the Monte-Carlo shading kernel)
+                self.material.set_raytracer(hipops.MeshBvh(m.v_pos, m.t_pos_idx, m.v_pos.device))
         return m
 
     def forward(self, env_id, rays_o, rays_d, w2c, mvp_mtx, camera_positions=None, light_positions=None,

@@ -169,6 +169,38 @@ int dm_bvh_build(const float* v_pos_host, int32_t n_vert, const int32_t* tri_hos
 int dm_bvh_any_hit_rays(const void* nodes, const float* tris, const float* origins, const float* dirs, long long n,
                         float t_max, unsigned char* hit, dm_stream_t stream);
 
+/* Monte-Carlo ray-traced shading: DreamMatMaterial.forward, use_raytracing=True branch (dreammat_material.py:726-744)
+ * + shade_raytracing (:615-677) + get_lights (:490-507) with the occlusion rays fused in.  Host struct, device data:
+ * lights [n_env][light_h][light_w][3] fp32 lat-long radiance (get_envirmentlight_blender :452-470, nearest texel);
+ * samples_* [n][2] = the (azimuth, elevation) Fibonacci tables of configure() (:389-398) in [0,1]^2.
+ * mat->min/max_roughness carry the SQUARED range here (cfg.min/max_roughness_squre).  rand_* [N] = the per-point
+ * azimuth rotations in [0,1) (torch.rand in the reference; NULL = none).  hit_bits [N][dm_mc_hit_words()] u32 is
+ * written by fwd and read by bwd (one bit per sample direction, diffuse first).  n_diffuse + n_specular <= 1024.
+ * Round-1 status: arithmetic validated on the CPU against the reference (tests/hostemu); no GPU run yet. */
+typedef struct dm_mc_scene {
+    const void* bvh_nodes; const float* bvh_tris;       /* device copies of dm_bvh_build's outputs */
+    const float* lights; int n_env, light_h, light_w;
+    const float* samples_diffuse; const float* samples_specular;
+    int n_diffuse, n_specular;
+    int geometry_ggx_smith;                             /* cfg.geometry_type: 0 = 'schlick', 1 = 'ggx_smith' */
+} dm_mc_scene;
+int dm_mc_hit_words(int n_diffuse, int n_specular);
+int dm_mc_shade_fwd(const dm_mc_scene* scene_host, const dm_mat_cfg* mat_host, const float* pos, long long pos_rs,
+                    long long pos_cs, const float* nrm, long long nrm_rs, long long nrm_cs, const float* view,
+                    long long view_rs, long long view_cs, const float* feat, long long feat_rs, long long feat_cs,
+                    const int32_t* pix_idx, const int32_t* env_of_view, const int32_t* n_dev, long long n_max, int HW,
+                    const float* rand_diffuse, const float* rand_specular, uint32_t* hit_bits, float* color,
+                    long long color_rs, long long color_cs, float* dbg_albedo, float* dbg_spec_light,
+                    float* dbg_diff_light, float* dbg_spec_color, float* dbg_diff_color, float* dbg_metallic,
+                    float* dbg_roughness, dm_stream_t stream);
+int dm_mc_shade_bwd(const dm_mc_scene* scene_host, const dm_mat_cfg* mat_host, const float* pos, long long pos_rs,
+                    long long pos_cs, const float* nrm, long long nrm_rs, long long nrm_cs, const float* view,
+                    long long view_rs, long long view_cs, const float* feat, long long feat_rs, long long feat_cs,
+                    const int32_t* pix_idx, const int32_t* env_of_view, const int32_t* n_dev, long long n_max, int HW,
+                    const float* rand_diffuse, const float* rand_specular, const uint32_t* hit_bits,
+                    const float* dcolor, long long dcolor_rs, long long dcolor_cs, float* dfeat, long long dfeat_rs,
+                    long long dfeat_cs, dm_stream_t stream);
+
 /* ---- attention ---------------------------------------------------------------------------- */
 /* The QK^T.softmax.V of every transformer block diffusers runs inside ControlNetModel /
  * UNet2DConditionModel (models/guidance/dreammat_guidance.py:205-241, 261-282), bf16, MFMA.

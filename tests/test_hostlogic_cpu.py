@@ -158,3 +158,14 @@ def test_bench_reads_counter_profiles():
     assert 0.9 * tr["algorithmic_bytes"] < tr["traffic"] < 3.0 * tr["algorithmic_bytes"]
     assert bench.pmc_traffic("k_conv3x3_dma conv3x3[128->128@512x512,s1]", 3) is None      # shape not profiled
     assert bench.pmc_traffic("k_unknown foo", 8) is None
+
+
+def test_fibonacci_direction_tables_match_the_reference():
+    """hipops.fibonacci_direction_samples == the (azimuth, elevation) tables DreamMatMaterial.configure builds from the
+    reference's sample_sphere (tests/golden/mc_shading.npz stores the reference's own tables)."""
+    import os
+    import numpy as np
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "mc_shading.npz"))
+    for key in ("schlick_dsamp", "schlick_ssamp", "ggx_smith_dsamp", "ggx_smith_ssamp"):
+        ref = torch.from_numpy(g[key])
+        assert torch.equal(hipops.fibonacci_direction_samples(ref.shape[0]), ref), key

@@ -1,0 +1,90 @@
+"""GPU checks of the SURVEY row f-1 groundwork (Monte-Carlo ray-traced shading).  The arithmetic of these kernels is
+validated on the CPU (tests/test_golden_cpu.py::test_mc_shading_product_core_vs_reference, tests/test_core_cpu.py::
+test_bvh_build_and_traversal_core_vs_brute_force); the kernels themselves were written after round 1's GPU budget was
+spent, so these tests are marked xfail(strict=False): a pass is reported as XPASS, a failure does not break the suite
+and tells round 2 where to start.  The file sorts last on purpose."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="row f-1 kernels: no GPU time in round 1")]
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def L(name):
+    return {k: torch.from_numpy(v) if v.ndim else v for k, v in np.load(os.path.join(G, name)).items()}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    return torch.device("cuda:0")
+
+
+def test_bvh_any_hit_kernel_vs_brute_force(dev):
+    from dreammat_amd import hipops, mesh as pmesh
+    from oracle import mc_shading as omc
+    torch.manual_seed(0)
+    m = pmesh.displaced_sphere(48, 40)
+    bvh = hipops.MeshBvh(m.v_pos, m.t_pos_idx, dev)
+    tv = m.v_pos.float()[m.t_pos_idx.long()]
+    fn = torch.nn.functional.normalize(torch.cross(tv[:, 1] - tv[:, 0], tv[:, 2] - tv[:, 0], dim=-1), dim=-1)
+    pick = torch.randint(0, tv.shape[0], (4000,))
+    d = torch.nn.functional.normalize(torch.randn(4000, 3), dim=-1)
+    o = tv.mean(1)[pick] + 1e-4 * fn[pick] + 1e-5 * d
+    hit = bvh.any_hit(o.to(dev), d.to(dev)).cpu()
+    ref = omc.trace_any_hit(m.v_pos.float(), m.t_pos_idx, o, d)
+    assert int((hit != ref).sum()) <= 4
+
+
+@pytest.mark.parametrize("variant", ["schlick", "ggx_smith"])
+def test_mc_shade_kernels_vs_reference(dev, variant):
+    from dreammat_amd import _lib, hipops
+    from oracle import shading as oshade
+    g = L("mc_shading.npz")
+    bvh = hipops.MeshBvh(g["v_pos"], g["tri"], dev)
+    nd, nsp = g[f"{variant}_dsamp"].shape[0], g[f"{variant}_ssamp"].shape[0]
+    scene = hipops.McScene(bvh, [g["light"]], nd, nsp, variant)
+    assert torch.equal(scene.samples_d.cpu(), g[f"{variant}_dsamp"]) and torch.equal(scene.samples_s.cpu(), g[f"{variant}_ssamp"])
+    mat = _lib.MatCfgStruct(0.0, 0.9, 0.01, 0.9)
+    N = g["pts"].shape[0]
+    random_az = bool(g[f"{variant}_random"])
+    rd = g[f"{variant}_rand_d"].to(dev).contiguous() if random_az else None
+    rs = g[f"{variant}_rand_s"].to(dev).contiguous() if random_az else None
+    feats = g[f"{variant}_feats"].to(dev).requires_grad_()
+    outs = hipops.mc_shade(feats, g["pts"].to(dev), g["nrm"].to(dev), g["view"].to(dev),
+                           torch.zeros(N, dtype=torch.int32, device=dev), torch.full((1,), N, dtype=torch.int32, device=dev),
+                           torch.zeros(1, dtype=torch.int32, device=dev), scene, mat, 1 << 30, rd, rs, True)
+    names = ["color", "albedo", "specular_lights", "diffuse_lights", "specular_colors", "diffuse_colors", "metalness", "roughness"]
+    for k, o in zip(names, outs):
+        ref = g[f"{variant}_out_{k}"]
+        assert (o.detach().cpu() - ref).abs().max() <= 2e-4 * max(1.0, ref.abs().max().item()), k
+    (outs[0] * g[f"{variant}_wgt"].to(dev)).sum().backward()
+    fr = g[f"{variant}_feats"].clone().requires_grad_()
+    (3.0 * oshade.material_smoothness_grad(torch.sigmoid(fr), torch.sigmoid(g[f"{variant}_featsj"]))).backward()
+    ref_grad = g[f"{variant}_dfeats"] - fr.grad
+    assert (feats.grad.cpu() - ref_grad).abs().max() <= 2e-3 * ref_grad.abs().max()
+
+
+def test_material_plugin_raytracing_branch_runs(dev):
+    import dreammat_amd
+    from dreammat_amd import hipops, mesh as pmesh
+    dreammat_amd._import_plugins()
+    lat = [torch.rand(16, 32, 3) for _ in range(5)]
+    mat = dreammat_amd.find("dreammat-material")({"use_raytracing": True, "diffuse_sample_num": 32, "specular_sample_num": 16,
+                                                  "env_max_res": 32, "env_min_res": 8}, latlongs=lat).to(dev)
+    m = pmesh.displaced_sphere(24, 16)
+    mat.set_raytracer(hipops.MeshBvh(m.v_pos, m.t_pos_idx, dev))
+    tv = m.v_pos.float()[m.t_pos_idx.long()]
+    n = torch.nn.functional.normalize(torch.cross(tv[:, 1] - tv[:, 0], tv[:, 2] - tv[:, 0], dim=-1), dim=-1)[:200].to(dev)
+    p = (tv.mean(1)[:200].to(dev) + 1e-4 * n).contiguous()
+    v = torch.nn.functional.normalize(n + 0.5 * torch.randn(200, 3, device=dev), dim=-1)
+    f = torch.randn(200, 5, device=dev, requires_grad=True)
+    out, reg = mat(p, f, f.detach() + 0.1, v, n, torch.zeros(1, dtype=torch.int32, device=dev))
+    assert out["color"].shape == (200, 3) and torch.isfinite(out["color"]).all() and 0 <= float(out["color"].min())
+    (out["color"].sum() + reg).backward()
+    assert torch.isfinite(f.grad).all() and f.grad.abs().sum() > 0
