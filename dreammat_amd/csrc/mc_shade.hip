@@ -7,8 +7,8 @@
 // one hit bit, kept so that the backward pass does not have to trace again.
 //   forward : shade_pixel<float, trace + record hit bits>
 //   backward: shade_pixel<Dual, reuse hit bits> (forward-mode d/d alpha) + analytic albedo / metallic terms
-// STATUS: the per-pixel arithmetic is validated on the CPU (tests/hostemu) against the reference's own outputs and
-// autograd gradients; these kernels had no GPU time in round 1.
+// STATUS: parity-tested against the reference's own outputs and autograd gradients on the CPU (tests/hostemu) and on
+// the MI355X (tests/test_mc_gpu.py); one thread per pixel, 0.27 G rays/s -- correct, not yet fast.
 #include "mc_shade_core.h"
 
 extern "C" {

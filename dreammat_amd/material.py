@@ -4,8 +4,9 @@ branch.  forward() keeps the reference signature
 and runs two HIP kernels: the fused activation + FG-LUT + env-lookup shade kernel and the smoothness
 regulariser.  `use_raytracing: true` (the reference default, Monte-Carlo shading with BVH visibility, SURVEY
 row f-1) runs the fused Monte-Carlo kernels (csrc/mc_shade.hip) once the renderer has handed over the mesh BVH
-through `set_raytracer`; their arithmetic is validated on the CPU against the reference (tests/hostemu), GPU
-validation is pending (no GPU time left in round 1), so the bench / north-star path keeps `use_raytracing: false`.
+through `set_raytracer`; parity-tested against the reference on the CPU (tests/hostemu) and on the GPU
+(tests/test_mc_gpu.py) but not yet optimised (0.27 G rays/s), so the bench / north-star path keeps
+`use_raytracing: false`.
 """
 import os
 from dataclasses import dataclass

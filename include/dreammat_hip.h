@@ -176,7 +176,7 @@ int dm_bvh_any_hit_rays(const void* nodes, const float* tris, const float* origi
  * mat->min/max_roughness carry the SQUARED range here (cfg.min/max_roughness_squre).  rand_* [N] = the per-point
  * azimuth rotations in [0,1) (torch.rand in the reference; NULL = none).  hit_bits [N][dm_mc_hit_words()] u32 is
  * written by fwd and read by bwd (one bit per sample direction, diffuse first).  n_diffuse + n_specular <= 1024.
- * Round-1 status: arithmetic validated on the CPU against the reference (tests/hostemu); no GPU run yet. */
+ * Round-1 status: parity-tested on CPU and GPU against the reference, not yet optimised. */
 typedef struct dm_mc_scene {
     const void* bvh_nodes; const float* bvh_tris;       /* device copies of dm_bvh_build's outputs */
     const float* lights; int n_env, light_h, light_w;
