@@ -23,4 +23,4 @@ def find(name):
 def _import_plugins():
     # importing the modules runs their @register decorators (threestudio/__init__.py:37)
     from . import data, geometry, guidance, material, prompt, renderer, system  # noqa: F401
-    from . import background  # noqa: F401
+    from . import background, exporter  # noqa: F401

@@ -22,6 +22,7 @@ def main(argv=None):
     g.add_argument("--train", action="store_true")
     g.add_argument("--validate", action="store_true")
     g.add_argument("--test", action="store_true")
+    g.add_argument("--export", action="store_true")
     ap.add_argument("--verbose", action="store_true")
     args, extras = ap.parse_known_args(argv)
     cfg = load_config(args.config, cli_args=extras)
@@ -51,6 +52,12 @@ def main(argv=None):
         if cfg.get("resume"):
             trainer.load_checkpoint(cfg["resume"])
         trainer.validate()
+    elif args.export:
+        system.configure_optimizers()
+        if cfg.get("resume"):
+            trainer.load_checkpoint(cfg["resume"])
+        for p in trainer.export():
+            print("[dreammat_amd] wrote", p)
     else:
         system.configure_optimizers()
         if cfg.get("resume"):

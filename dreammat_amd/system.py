@@ -263,6 +263,22 @@ class Trainer:
                              out["metalness"][0].expand(-1, -1, 3), out["comp_normal"][0]])
 
     @torch.no_grad()
+    def export(self):
+        """systems/base.py:309-334 (`--export`): run the configured exporter and write its outputs under
+        <trial>/save/it<N>-export/."""
+        from .saving import save_obj
+        s = self.system
+        exporter = dreammat_amd.find(s.cfg.exporter_type)(s.cfg.exporter, geometry=s.geometry, material=s.material,
+                                                            background=s.background)
+        base = os.path.join(self.trial_dir, "save", f"it{s.true_global_step}-export")
+        written = []
+        for out in exporter():
+            if out.save_type != "obj":
+                raise ValueError(f"{out.save_type} export not supported yet.")
+            written += save_obj(os.path.join(base, out.save_name), **out.params)
+        return written
+
+    @torch.no_grad()
     def test(self):
         """systems/dreammat.py:247-300: per-view albedo / roughness / metallic / render RGBA PNGs."""
         from .saving import save_rgba

@@ -3,6 +3,8 @@ kernel (tap-major forward weights, flipped / channel-swapped data-gradient weigh
 the autograd wrappers in `hipops` (fused residual, stride-2 forward with an implied trailing pad, zero-insert data
 gradient).  `hipops.conv3x3_nhwc` is replaced by a torch emulation of the `dm_conv3x3_nhwc_bf16_fused` CONTRACT
 (include/dreammat_hip.h) -- the kernel itself is covered by tests/test_hip_gpu.py."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -169,3 +171,86 @@ def test_fibonacci_direction_tables_match_the_reference():
     for key in ("schlick_dsamp", "schlick_ssamp", "ggx_smith_dsamp", "ggx_smith_ssamp"):
         ref = torch.from_numpy(g[key])
         assert torch.equal(hipops.fibonacci_direction_samples(ref.shape[0]), ref), key
+
+
+def test_mesh_exporter_bakes_textures_and_writes_obj_mtl(monkeypatch, tmp_path):
+    """`mesh-exporter` (threestudio/models/exporters/mesh_exporter.py).  The GPU rasterize /
+    interpolate entry points are replaced by the oracle's CPU restatement of the same contracts, so the test covers
+    the baking recipe (UV clip transform, position interpolation with the POSITION triangles, field queries, chart
+    padding) and the OBJ / MTL / texture writers."""
+    import numpy as np
+    from PIL import Image
+
+    import dreammat_amd
+    from dreammat_amd import mesh as pmesh, saving
+    from dreammat_amd.exporter import MeshExporter, dilate_charts
+    from oracle import raster as oraster
+
+    class CpuRaster:
+        def __init__(self, device):
+            pass
+
+        def rasterize(self, pos, tri, H, W, check_overflow=False):
+            return torch.from_numpy(oraster.rasterize(pos, tri, H, W))
+    monkeypatch.setattr(hipops, "RasterContext", CpuRaster)
+    monkeypatch.setattr(hipops, "interpolate", lambda attr, rast, tri: torch.from_numpy(oraster.interpolate(attr, rast, tri)))
+
+    m = pmesh.quad_mesh()
+    m.v_tex = m.v_tex * 0.5 + 0.125                       # chart covers [0.125, 0.625]^2: the rest of the atlas is holes
+
+    class Geo:
+        def isosurface(self):
+            return m
+
+        def export(self, points, **kw):
+            return {"features": torch.cat([points * 4.0, points[:, :2] * 2.0], dim=-1)}     # 5 "features"
+
+    class Mat:
+        def export(self, features, **kw):
+            s = torch.sigmoid(features)
+            return {"albedo": s[..., :3], "metallic": s[..., 3:4], "roughness": s[..., 4:5]}
+    S = 32
+    ex = MeshExporter({"texture_size": S, "texture_format": "png", "xatlas_pack_options": {"padding": 3}},
+                      geometry=Geo(), material=Mat(), background=None)
+    maps, holes = ex.bake_textures(m)
+    assert maps["albedo"].shape == (S, S, 3) and maps["metallic"].shape == (S, S, 1)
+    jj, ii = torch.meshgrid(torch.arange(S), torch.arange(S), indexing="ij")
+    u, v = (ii + 0.5) / S, (jj + 0.5) / S                 # texel centres; image row 0 = v near 0 (clip y = -1)
+    inside = (u > 0.125) & (u < 0.625) & (v > 0.125) & (v < 0.625)
+    assert torch.equal(~holes, inside)
+    pos = torch.stack([(u - 0.125) / 0.5 - 0.5, (v - 0.125) / 0.5 - 0.5, torch.zeros_like(u)], -1)   # quad: x = u' - .5
+    ref = torch.sigmoid(pos * 4.0)
+    assert (maps["albedo"][inside] - ref[inside]).abs().max() < 1e-5
+    ring = dilate_charts(torch.ones(S, S, 1), holes, 3)[..., 0]
+    assert int((ring > 0).sum()) == int((((u > 0.125 - 3 / S) & (u < 0.625 + 3 / S) & (v > 0.125 - 3 / S) & (v < 0.625 + 3 / S))).sum())
+    far = ~((u > 0.125 - 3.5 / S) & (u < 0.625 + 3.5 / S) & (v > 0.125 - 3.5 / S) & (v < 0.625 + 3.5 / S))
+    assert maps["albedo"][far].abs().max() == 0 and maps["albedo"][~holes].min() > 0
+    # padded texels continue the chart: values within the range of the chart border
+    border = maps["albedo"][(ring > 0) & holes]
+    assert border.min() > 0 and border.max() < 1
+
+    outs = ex()
+    assert len(outs) == 1 and outs[0].save_name == "model.obj" and outs[0].save_type == "obj"
+    paths = saving.save_obj(str(tmp_path / "exp" / outs[0].save_name), **outs[0].params)
+    names = sorted(os.path.basename(p) for p in paths)
+    assert names == ["model.mtl", "model.obj", "texture_kd.png", "texture_metallic.png", "texture_roughness.png"]
+    mtl = open(tmp_path / "exp" / "model.mtl").read()
+    assert "newmtl default" in mtl and "map_Kd texture_kd.png" in mtl and "map_Pm texture_metallic.png" in mtl
+    obj = open(tmp_path / "exp" / "model.obj").read().splitlines()
+    assert obj[0] == "mtllib model.mtl" and obj[2] == "usemtl default"
+    vts = [l for l in obj if l.startswith("vt ")]
+    assert len(vts) == 4 and vts[0] == f"vt {float(m.v_tex[0, 0])} {1.0 - float(m.v_tex[0, 1])}"
+    assert [l for l in obj if l.startswith("f ")][0] == "f 1/1/ 2/2/ 3/3/"
+    kd = np.asarray(Image.open(tmp_path / "exp" / "texture_kd.png"))
+    assert kd.shape == (S, S, 3) and np.abs(kd.astype(np.float32) / 255 - maps["albedo"].numpy()).max() < 1 / 255 + 1e-6
+    re = pmesh.load_obj(str(tmp_path / "exp" / "model.obj"))
+    assert torch.allclose(re.v_pos, m.v_pos) and torch.equal(re.t_pos_idx, m.t_pos_idx)
+    # vertex-colour variant and the no-UV error
+    ex2 = MeshExporter({"fmt": "obj", "save_uv": False}, geometry=Geo(), material=Mat(), background=None)
+    p2 = saving.save_obj(str(tmp_path / "exp2" / "m"), **ex2()[0].params)
+    first_v = [l for l in open(p2[0]).read().splitlines() if l.startswith("v ")][0].split()
+    assert len(first_v) == 7                                # x y z r g b
+    m.v_tex = None
+    with pytest.raises(NotImplementedError):
+        ex()
+    assert "mesh-exporter" in dreammat_amd.__modules__ or dreammat_amd.find("mesh-exporter") is MeshExporter
