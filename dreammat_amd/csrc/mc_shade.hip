@@ -9,6 +9,11 @@
 //   backward: shade_pixel<Dual, reuse hit bits> (forward-mode d/d alpha) + analytic albedo / metallic terms
 // STATUS: parity-tested against the reference's own outputs and autograd gradients on the CPU (tests/hostemu) and on
 // the MI355X (tests/test_mc_gpu.py); one thread per pixel, 0.27 G rays/s -- correct, not yet fast.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
 #include "mc_shade_core.h"
 
 extern "C" {
@@ -95,6 +100,106 @@ __global__ __launch_bounds__(128) void k_mc_shade(McArgs a) {
     }
 }
 
+// ---- one WAVE per pixel: the nd + ns sample directions are spread over the 64 lanes (6 rounds for 200 + 128), each
+// lane traces its own occlusion rays and accumulates its share of A / B / Ld / Ls; a butterfly reduction combines the
+// lanes, lane 0 finishes the pixel.  All rays of a wave start at the same surface point, so the top of the BVH is
+// shared; the hit bits of a round are exactly one __ballot.  Opt-in (DREAMMAT_MC_KERNEL=wave) until it has been
+// validated and timed on the GPU; the decomposition itself (strided samples, bit packing, finish on the combined sums)
+// is checked on the CPU by tests/hostemu (emu_mc_shade with lanes > 1).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ void wave_sum_inplace(float& v) { v = wave_sum(v); }
+__device__ __forceinline__ void wave_sum_inplace(Dual& v) { v.v = wave_sum(v.v); v.d = wave_sum(v.d); }
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_mc_shade_wave(McArgs a) {
+    using S = typename std::conditional<BWD, Dual, float>::type;
+    const long long N = *a.n_dev;
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const int sn = a.cfg.n_diffuse + a.cfg.n_specular;
+    for (long long i = wave0; i < N; i += nwaves) {
+        float p[3], n[3], v[3], f[5];
+        load3(a.pos, i, p); load3(a.nrm, i, n); load3(a.view, i, v);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) f[k] = a.feat.p[i * a.feat.rs + k * a.feat.cs];
+        const int env = a.env_of_view[a.pix_idx[i] / a.HW];
+        McScene sc;
+        sc.nodes = a.nodes; sc.tris = a.tris;
+        sc.light = a.lights + (size_t)env * a.light_h * a.light_w * 3; sc.light_h = a.light_h; sc.light_w = a.light_w;
+        sc.samples_d = a.samples_d; sc.samples_s = a.samples_s;
+        McFrame fr;
+        McPixel px;
+        pixel_setup(a.cfg, p, n, v, f, a.rand_d ? a.rand_d[i] : -1.f, a.rand_s ? a.rand_s[i] : -1.f, fr, px);
+        const S al = seed(S(), px.alpha);
+        McAcc<S> acc;
+        acc_clear(al, acc);
+        unsigned* gb = a.hit_bits + (size_t)i * a.hit_words;
+        for (int base = 0; base < sn; base += 64) {
+            const int s = base + lane;
+            const bool active = s < sn;
+            bool hit = false;
+            if (BWD && active) hit = (gb[s >> 5] >> (s & 31)) & 1u;
+            if (active) sample_eval<S, !BWD>(a.cfg, sc, fr, al, s, hit, acc);
+            if (!BWD) {
+                const unsigned long long m = __ballot(active && hit);
+                if (lane == 0) {
+                    gb[base >> 5] = (unsigned)m;
+                    if ((base >> 5) + 1 < a.hit_words) gb[(base >> 5) + 1] = (unsigned)(m >> 32);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            wave_sum_inplace(acc.A[c]); wave_sum_inplace(acc.B[c]);
+            acc.Ld[c] = wave_sum(acc.Ld[c]); acc.Ls[c] = wave_sum(acc.Ls[c]);
+        }
+        if (lane != 0) continue;
+        pixel_finish(a.cfg, acc, px);
+        if (!BWD) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a.color.p[i * a.color.rs + c * a.color.cs] = lin2srgb_mc(px.pre[c]);
+            if (a.albedo) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    a.albedo[3 * i + c] = lin2srgb_mc(px.albedo[c]);
+                    a.spec_light[3 * i + c] = lin2srgb_mc(px.Ls_mean[c]);
+                    a.diff_light[3 * i + c] = lin2srgb_mc(px.Ld_mean[c]);
+                    a.spec_color[3 * i + c] = lin2srgb_mc(px.specular[c]);
+                    a.diff_color[3 * i + c] = lin2srgb_mc(px.diffuse[c]);
+                }
+                a.metallic[i] = px.metallic;
+                a.roughness[i] = sqrtf(px.alpha + 1e-7f);
+            }
+        } else {
+            float dc[3], df[5];
+            load3(a.dcolor, i, dc);
+            finish_backward(a.cfg, px, dc, df);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) a.dfeat.p[i * a.dfeat.rs + k * a.dfeat.cs] = df[k];
+        }
+    }
+}
+
+bool use_wave_kernel() {
+    const char* e = getenv("DREAMMAT_MC_KERNEL");      // read per call: tests toggle it
+    return e && !strcmp(e, "wave");
+}
+
+template <bool BWD>
+void launch_mc(const McArgs& a, long long n_max, hipStream_t stream) {
+    if (use_wave_kernel()) {
+        const unsigned grid = (unsigned)std::min<long long>((n_max + 3) / 4, 256 * 8);
+        hipLaunchKernelGGL(k_mc_shade_wave<BWD>, dim3(grid), dim3(256), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(k_mc_shade<BWD>, dim3(dm_div_up(n_max, 128)), dim3(128), 0, stream, a);
+    }
+}
+
 bool fill(McArgs& a, const dm_mc_scene* s, const dm_mat_cfg* mat) {
     if (!s || !mat || !s->bvh_nodes || !s->bvh_tris || !s->lights || !s->samples_diffuse || !s->samples_specular) return false;
     if (s->n_env <= 0 || s->light_h <= 0 || s->light_w <= 0 || s->n_diffuse <= 0 || s->n_specular <= 0) return false;
@@ -135,7 +240,7 @@ int dm_mc_shade_fwd(const dm_mc_scene* scene, const dm_mat_cfg* mat, const float
     a.albedo = dbg_albedo; a.spec_light = dbg_spec_light; a.diff_light = dbg_diff_light; a.spec_color = dbg_spec_color;
     a.diff_color = dbg_diff_color; a.metallic = dbg_metallic; a.roughness = dbg_roughness;
     DM_ENTER();
-    hipLaunchKernelGGL(k_mc_shade<false>, dim3(dm_div_up(n_max, 128)), dim3(128), 0, stream, a);
+    launch_mc<false>(a, n_max, stream);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
@@ -157,7 +262,7 @@ int dm_mc_shade_bwd(const dm_mc_scene* scene, const dm_mat_cfg* mat, const float
     a.dcolor = {dcolor, dcolor_rs, dcolor_cs};
     a.dfeat = {dfeat, dfeat_rs, dfeat_cs};
     DM_ENTER();
-    hipLaunchKernelGGL(k_mc_shade<true>, dim3(dm_div_up(n_max, 128)), dim3(128), 0, stream, a);
+    launch_mc<true>(a, n_max, stream);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }

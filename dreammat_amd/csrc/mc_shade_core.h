@@ -162,79 +162,87 @@ struct McPixel {
     float dpre_dalbedo[3], dpre_dmetallic[3], dpre_dalpha[3];   // per colour channel (dalpha only when S = Dual)
 };
 
-// S = float: values.  S = Dual: additionally d(pre)/d(alpha).
-// hit_bits: one bit per sample (diffuse first, kMaxSamples/32 words, zeroed by the caller when WRITE_HITS).
-// rand_d / rand_s: the per-point azimuth rotations in [0,1) (torch.rand in the reference); < 0 = no rotation.
-template <class S, bool WRITE_HITS>
-DM_HD void shade_pixel(const McCfg& cfg, const McScene& sc, const float* p, const float* n, const float* v, const float* feat,
-                       float rand_d, float rand_s, unsigned* hit_bits, McPixel& out) {
+// ---- a pixel in three pieces, so that the samples can be walked serially by one thread (shade_pixel) or spread over
+// the lanes of a wave (mc_shade.hip, k_mc_shade_wave): setup (material activation, frames) / one sample / finish.
+struct McFrame {
+    float n[3], v[3], p[3], r[3];                 // normal, view direction, surface point, mirror direction
+    float xd[3], yd[3], xs[3], ys[3];             // tangent frames of n and r
+    float NoV, rand_d, rand_s;
+};
+
+DM_HD void pixel_setup(const McCfg& cfg, const float* p, const float* n, const float* v, const float* feat, float rand_d,
+                       float rand_s, McFrame& fr, McPixel& out) {
 #pragma unroll
     for (int k = 0; k < 5; ++k) out.m[k] = 1.0f / (1.0f + expf(-feat[k]));
 #pragma unroll
     for (int c = 0; c < 3; ++c) out.albedo[c] = sat_(out.m[c]);
     out.metallic = out.m[3] * (cfg.max_metallic - cfg.min_metallic) + cfg.min_metallic;
     out.alpha = out.m[4] * (cfg.max_rough_sq - cfg.min_rough_sq) + cfg.min_rough_sq;
-    const S a = seed(S(), out.alpha);
-
     const float ndv = n[0] * v[0] + n[1] * v[1] + n[2] * v[2];
-    const float NoV = sat_(ndv);
-    const float r[3] = {ndv * n[0] * 2.f - v[0], ndv * n[1] * 2.f - v[1], ndv * n[2] * 2.f - v[2]};
-    float xd[3], yd[3], xs[3], ys[3];
-    ortho_frame(n, xd, yd);
-    ortho_frame(r, xs, ys);
-    const int nd = cfg.n_diffuse, ns = cfg.n_specular, sn = nd + ns;
-    McAcc<S> acc;
+    fr.NoV = sat_(ndv);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { fr.n[c] = n[c]; fr.v[c] = v[c]; fr.p[c] = p[c]; fr.r[c] = ndv * n[c] * 2.f - v[c]; }
+    ortho_frame(fr.n, fr.xd, fr.yd);
+    ortho_frame(fr.r, fr.xs, fr.ys);
+    fr.rand_d = rand_d; fr.rand_s = rand_s;
+}
+
+template <class S> DM_HD void acc_clear(S a, McAcc<S>& acc) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) { acc.A[c] = cst(a, 0.f); acc.B[c] = cst(a, 0.f); acc.Ld[c] = 0.f; acc.Ls[c] = 0.f; }
+}
 
-    // ---- cosine-weighted directions around the normal (:554-573); pdf = NoL / pi * nd / sn
-    for (int i = 0; i < nd; ++i) {
-        float az = sc.samples_d[2 * i] * kPi * 2.f;
-        const float el = sc.samples_d[2 * i + 1];
-        if (rand_d >= 0.f) az = fmodf(az + rand_d * kPi * 2.f, 2.f * kPi);
+// sample s of the pixel: s < nd = cosine-weighted direction s around the normal (:554-573, pdf NoL/pi * nd/sn), else GGX
+// direction s - nd around the mirror direction (:575-596, pdf D NoH / (4 VoH + 1e-5) * ns/sn).
+// TRACE: shoot the occlusion ray and return the result in `hit`; else take `hit` as given (recorded by the forward).
+template <class S, bool TRACE>
+DM_HD void sample_eval(const McCfg& cfg, const McScene& sc, const McFrame& fr, S a, int s, bool& hit, McAcc<S>& acc) {
+    const int nd = cfg.n_diffuse, ns = cfg.n_specular, sn = nd + ns;
+    if (s < nd) {
+        float az = sc.samples_d[2 * s] * kPi * 2.f;
+        const float el = sc.samples_d[2 * s + 1];
+        if (fr.rand_d >= 0.f) az = fmodf(az + fr.rand_d * kPi * 2.f, 2.f * kPi);
         const float el_sqrt = sqrtf(el + 1e-7f), cz = sqrtf(1.f - el + 1e-7f);
         const float cx = el_sqrt * cosf(az), cy = el_sqrt * sinf(az);
         float d[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) d[c] = cx * xd[c] + cy * yd[c] + cz * n[c];
-        bool hit;
-        if (WRITE_HITS) { hit = occluded(sc, p, d[0], d[1], d[2]); if (hit) hit_bits[i >> 5] |= 1u << (i & 31); }
-        else hit = (hit_bits[i >> 5] >> (i & 31)) & 1u;
+        for (int c = 0; c < 3; ++c) d[c] = cx * fr.xd[c] + cy * fr.yd[c] + cz * fr.n[c];
+        if (TRACE) hit = occluded(sc, fr.p, d[0], d[1], d[2]);
         float L[3] = {0.f, 0.f, 0.f};
         if (!hit) env_lookup(sc, d[0], d[1], d[2], L);
 #pragma unroll
         for (int c = 0; c < 3; ++c) acc.Ld[c] += L[c];
-        const float NoL_d = sat_(d[0] * n[0] + d[1] * n[1] + d[2] * n[2]);
+        const float NoL_d = sat_(d[0] * fr.n[0] + d[1] * fr.n[1] + d[2] * fr.n[2]);
         V3<S> ds;
         ds.x = cst(a, d[0]); ds.y = cst(a, d[1]); ds.z = cst(a, d[2]);
-        add_sample<S>(cfg, n, v, NoV, a, ds, half_vector(ds, v), cst(a, NoL_d / kPi * ((float)nd / (float)sn)), L, acc);
-    }
-    // ---- GGX directions around the mirror direction (:575-596); pdf = D NoH / (4 VoH + 1e-5) * ns / sn
-    for (int j = 0; j < ns; ++j) {
+        add_sample<S>(cfg, fr.n, fr.v, fr.NoV, a, ds, half_vector(ds, fr.v), cst(a, NoL_d / kPi * ((float)nd / (float)sn)), L, acc);
+    } else {
+        const int j = s - nd;
         float phi = kPi * 2.f * sc.samples_s[2 * j];
         const float el = sc.samples_s[2 * j + 1];
-        if (rand_s >= 0.f) phi = fmodf(phi + rand_s * kPi * 2.f, 2.f * kPi);
+        if (fr.rand_s >= 0.f) phi = fmodf(phi + fr.rand_s * kPi * 2.f, 2.f * kPi);
         S cos_t = sqrt_((1.0f - el + 1e-6f) / (1.0f + (a * a - 1.0f) * el + 1e-6f) + 1e-6f);
         S sin_t = sqrt_(1.0f - cos_t * cos_t + 1e-6f);
         const float cph = cosf(phi), sph = sinf(phi);
         V3<S> d;
-        d.x = (cph * sin_t) * xs[0] + (sph * sin_t) * ys[0] + cos_t * r[0];
-        d.y = (cph * sin_t) * xs[1] + (sph * sin_t) * ys[1] + cos_t * r[1];
-        d.z = (cph * sin_t) * xs[2] + (sph * sin_t) * ys[2] + cos_t * r[2];
-        const int bit = nd + j;
-        bool hit;
-        if (WRITE_HITS) { hit = occluded(sc, p, val(d.x), val(d.y), val(d.z)); if (hit) hit_bits[bit >> 5] |= 1u << (bit & 31); }
-        else hit = (hit_bits[bit >> 5] >> (bit & 31)) & 1u;
+        d.x = (cph * sin_t) * fr.xs[0] + (sph * sin_t) * fr.ys[0] + cos_t * fr.r[0];
+        d.y = (cph * sin_t) * fr.xs[1] + (sph * sin_t) * fr.ys[1] + cos_t * fr.r[1];
+        d.z = (cph * sin_t) * fr.xs[2] + (sph * sin_t) * fr.ys[2] + cos_t * fr.r[2];
+        if (TRACE) hit = occluded(sc, fr.p, val(d.x), val(d.y), val(d.z));
         float L[3] = {0.f, 0.f, 0.f};
         if (!hit) env_lookup(sc, val(d.x), val(d.y), val(d.z), L);
 #pragma unroll
         for (int c = 0; c < 3; ++c) acc.Ls[c] += L[c];
-        const V3<S> h = half_vector(d, v);
-        S NoH = sat_(dotf(h, n)), VoH = sat_(dotf(h, v));
+        const V3<S> h = half_vector(d, fr.v);
+        S NoH = sat_(dotf(h, fr.n)), VoH = sat_(dotf(h, fr.v));
         S prob = ggx_d(NoH, a * a) * NoH / (4.0f * VoH + 1e-5f) * ((float)ns / (float)sn);
-        add_sample<S>(cfg, n, v, NoV, a, d, h, prob, L, acc);
+        add_sample<S>(cfg, fr.n, fr.v, fr.NoV, a, d, h, prob, L, acc);
     }
+}
 
+// sums over all samples -> colours and their sensitivities (out.m / albedo / metallic / alpha set by pixel_setup)
+template <class S> DM_HD void pixel_finish(const McCfg& cfg, const McAcc<S>& acc, McPixel& out) {
+    const int nd = cfg.n_diffuse, ns = cfg.n_specular, sn = nd + ns;
     const float inv_sn = 1.0f / (float)sn, inv_nd = 1.0f / (float)nd, inv_ns = 1.0f / (float)ns;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -249,6 +257,26 @@ DM_HD void shade_pixel(const McCfg& cfg, const McScene& sc, const float* p, cons
         out.dpre_dmetallic[c] = A * (out.albedo[c] - 0.04f);
         out.dpre_dalpha[c] = (F0 * der(acc.A[c]) + der(acc.B[c])) * inv_sn;
     }
+}
+
+// One thread walks all samples.  S = float: values.  S = Dual: additionally d(pre)/d(alpha).
+// hit_bits: one bit per sample (diffuse first, kMaxSamples/32 words, zeroed by the caller when WRITE_HITS).
+// rand_d / rand_s: the per-point azimuth rotations in [0,1) (torch.rand in the reference); < 0 = no rotation.
+template <class S, bool WRITE_HITS>
+DM_HD void shade_pixel(const McCfg& cfg, const McScene& sc, const float* p, const float* n, const float* v, const float* feat,
+                       float rand_d, float rand_s, unsigned* hit_bits, McPixel& out) {
+    McFrame fr;
+    pixel_setup(cfg, p, n, v, feat, rand_d, rand_s, fr, out);
+    const S a = seed(S(), out.alpha);
+    McAcc<S> acc;
+    acc_clear(a, acc);
+    const int sn = cfg.n_diffuse + cfg.n_specular;
+    for (int s = 0; s < sn; ++s) {
+        bool hit = WRITE_HITS ? false : ((hit_bits[s >> 5] >> (s & 31)) & 1u);
+        sample_eval<S, WRITE_HITS>(cfg, sc, fr, a, s, hit, acc);
+        if (WRITE_HITS && hit) hit_bits[s >> 5] |= 1u << (s & 31);
+    }
+    pixel_finish(cfg, acc, out);
 }
 
 DM_HD float lin2srgb_mc(float x) {

@@ -117,25 +117,68 @@ int emu_bvh_any_hit(const void* nodes, const float* tris, const float* org, cons
     return 0;
 }
 
-// Monte-Carlo shading (mc_shade_core.h): forward = shade_pixel<float, true> (traces, records the hit bits), backward =
-// shade_pixel<Dual, false> on the recorded bits + finish_backward.  out [N,25] = color3 albedo3 roughness1 metalness1
-// specular_lights3 diffuse_lights3 specular_colors3 diffuse_colors3 pre3 (linear colour) alpha1 pad1.
+// Monte-Carlo shading (mc_shade_core.h).  lanes == 1: the serial kernel's path -- forward = shade_pixel<float, true>
+// (traces, records the hit bits), backward = shade_pixel<Dual, false> on the recorded bits + finish_backward.
+// lanes == 64: the wave kernel's decomposition (k_mc_shade_wave) replayed lane by lane -- sample s of a round goes to
+// lane s % 64, each lane keeps its own partial sums, the hit bits of a round are packed like __ballot, the partial
+// sums are combined before pixel_finish.  out [N,25] = color3 albedo3 roughness1 metalness1 specular_lights3
+// diffuse_lights3 specular_colors3 diffuse_colors3 pre3 (linear colour) alpha1 pad1.
+}  // extern "C"
+
+template <class S, bool TRACE>
+static void emu_pixel_lanes(const dm::mc::McCfg& cfg, const dm::mc::McScene& sc, const float* p, const float* n, const float* v,
+                            const float* f, float rd, float rs, unsigned* hb, int words, int lanes, dm::mc::McPixel& px) {
+    using namespace dm::mc;
+    McFrame fr;
+    pixel_setup(cfg, p, n, v, f, rd, rs, fr, px);
+    const S al = seed(S(), px.alpha);
+    std::vector<McAcc<S>> part(lanes);
+    for (auto& a : part) acc_clear(al, a);
+    const int sn = cfg.n_diffuse + cfg.n_specular;
+    for (int base = 0; base < sn; base += lanes) {
+        unsigned long long ballot = 0;
+        for (int lane = 0; lane < lanes; ++lane) {
+            const int s = base + lane;
+            if (s >= sn) continue;
+            bool hit = TRACE ? false : ((hb[s >> 5] >> (s & 31)) & 1u);
+            sample_eval<S, TRACE>(cfg, sc, fr, al, s, hit, part[lane]);
+            if (TRACE && hit) ballot |= 1ull << lane;
+        }
+        if (TRACE) {
+            hb[base >> 5] = (unsigned)ballot;
+            if ((base >> 5) + 1 < words) hb[(base >> 5) + 1] = (unsigned)(ballot >> 32);
+        }
+    }
+    McAcc<S> acc;
+    acc_clear(al, acc);
+    for (auto& a : part)
+        for (int c = 0; c < 3; ++c) {
+            acc.A[c] = acc.A[c] + a.A[c]; acc.B[c] = acc.B[c] + a.B[c];
+            acc.Ld[c] += a.Ld[c]; acc.Ls[c] += a.Ls[c];
+        }
+    pixel_finish(cfg, acc, px);
+}
+
+extern "C" {
+
 int emu_mc_shade(const float* cfg4, int nd, int ns, int ggx_smith, const void* nodes, const float* tris, const float* light,
                  int lh, int lw, const float* samples_d, const float* samples_s, long long N, const float* p, const float* n,
                  const float* v, const float* feat, const float* rand_d, const float* rand_s, unsigned* hit_bits, float* out,
-                 const float* dcolor, float* dfeat) {
+                 const float* dcolor, float* dfeat, int lanes) {
     using namespace dm::mc;
     McCfg cfg = {cfg4[0], cfg4[1], cfg4[2], cfg4[3], nd, ns, ggx_smith};
     McScene sc = {(const DmBvhNode*)nodes, tris, light, lh, lw, samples_d, samples_s};
     const int words = kMaxSamples / 32;
-    if (nd + ns > kMaxSamples) return -1;
+    if (nd + ns > kMaxSamples || (lanes != 1 && lanes != 64)) return -1;
+    const int used_words = (nd + ns + 31) / 32;
     for (long long i = 0; i < N; ++i) {
         unsigned* hb = hit_bits + (size_t)i * words;
         McPixel px;
         const float rd = rand_d ? rand_d[i] : -1.f, rs = rand_s ? rand_s[i] : -1.f;
         if (!dcolor) {
             std::memset(hb, 0, words * sizeof(unsigned));
-            shade_pixel<float, true>(cfg, sc, p + 3 * i, n + 3 * i, v + 3 * i, feat + 5 * i, rd, rs, hb, px);
+            if (lanes == 1) shade_pixel<float, true>(cfg, sc, p + 3 * i, n + 3 * i, v + 3 * i, feat + 5 * i, rd, rs, hb, px);
+            else emu_pixel_lanes<float, true>(cfg, sc, p + 3 * i, n + 3 * i, v + 3 * i, feat + 5 * i, rd, rs, hb, used_words, lanes, px);
             float* o = out + 25 * i;
             for (int c = 0; c < 3; ++c) {
                 o[c] = lin2srgb_mc(px.pre[c]); o[3 + c] = lin2srgb_mc(px.albedo[c]);
@@ -145,7 +188,8 @@ int emu_mc_shade(const float* cfg4, int nd, int ns, int ggx_smith, const void* n
             }
             o[6] = sqrtf(px.alpha + 1e-7f); o[7] = px.metallic; o[23] = px.alpha; o[24] = 0.f;
         } else {
-            shade_pixel<Dual, false>(cfg, sc, p + 3 * i, n + 3 * i, v + 3 * i, feat + 5 * i, rd, rs, hb, px);
+            if (lanes == 1) shade_pixel<Dual, false>(cfg, sc, p + 3 * i, n + 3 * i, v + 3 * i, feat + 5 * i, rd, rs, hb, px);
+            else emu_pixel_lanes<Dual, false>(cfg, sc, p + 3 * i, n + 3 * i, v + 3 * i, feat + 5 * i, rd, rs, hb, used_words, lanes, px);
             finish_backward(cfg, px, dcolor + 3 * i, dfeat + 5 * i);
         }
     }

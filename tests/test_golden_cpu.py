@@ -161,7 +161,8 @@ def test_mc_raytraced_shading_oracle_vs_reference(variant):
     assert 0 < int(hit.sum()) < hit.numel() // 2
 
 
-def _emu_mc_shade(hostemu, bvh, light, dsamp, ssamp, pts, nrm, view, feats, rand_d, rand_s, ggx_smith, dcolor=None, hit_bits=None):
+def _emu_mc_shade(hostemu, bvh, light, dsamp, ssamp, pts, nrm, view, feats, rand_d, rand_s, ggx_smith, dcolor=None, hit_bits=None,
+                  lanes=1):
     import ctypes
     N = pts.shape[0]
     cp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
@@ -175,7 +176,7 @@ def _emu_mc_shade(hostemu, bvh, light, dsamp, ssamp, pts, nrm, view, feats, rand
     dfeat = torch.zeros(N, 5)
     rc = hostemu.emu_mc_shade(cp(cfg4), dsamp.shape[0], ssamp.shape[0], int(ggx_smith), cp(bvh.nodes_host), cp(bvh.tris_host),
                               cp(light), light.shape[0], light.shape[1], cp(dsamp), cp(ssamp), ctypes.c_longlong(N), cp(pts),
-                              cp(nrm), cp(view), cp(feats), cp(rand_d), cp(rand_s), cp(hit_bits), cp(out), cp(dcolor), cp(dfeat))
+                              cp(nrm), cp(view), cp(feats), cp(rand_d), cp(rand_s), cp(hit_bits), cp(out), cp(dcolor), cp(dfeat), int(lanes))
     assert rc == 0
     return out, dfeat, hit_bits
 
@@ -210,3 +211,9 @@ def test_mc_shading_product_core_vs_reference(hostemu, variant):
     scale = ref_grad.abs().max().item()
     assert (dfeat - ref_grad).abs().max().item() <= 2e-3 * scale, ((dfeat - ref_grad).abs().max().item(), scale)
     assert (dfeat[:, 4].abs() > 0).any() and (dfeat[:, 3].abs() > 0).any()           # roughness / metallic do get gradient
+    # the wave kernel's decomposition (samples strided over 64 lanes, ballot-packed hit bits, sums combined before the
+    # finish) gives the same pixel: identical hit bits, values equal up to fp32 summation order
+    out64, _, bits64 = _emu_mc_shade(*args, lanes=64)
+    assert torch.equal(bits64, bits) and (out64 - out).abs().max() < 1e-5
+    _, dfeat64, _ = _emu_mc_shade(*args, dcolor=g[f"{variant}_wgt"], hit_bits=bits64, lanes=64)
+    assert (dfeat64 - dfeat).abs().max() <= 1e-5 * max(1.0, scale)

@@ -1,0 +1,76 @@
+"""First GPU contact of code written after round 1 ran out of GPU budget: SURVEY row f-3 (`mesh-exporter`: texture
+baking through the real HIP rasterize / interpolate / hash-grid kernels) and the opt-in wave-parallel Monte-Carlo kernel.
+Both are CPU-tested (tests/test_hostlogic_cpu.py, tests/test_golden_cpu.py); this file had no GPU time in round 1, hence
+xfail(strict=False): XPASS on success, no red mark if the first contact finds something.  Sorts last on purpose."""
+import os
+
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="first GPU contact pending (written after the round-1 GPU budget was spent)")]
+
+
+def test_exporter_bakes_the_fitted_field_on_the_gpu(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    import dreammat_amd
+    from dreammat_amd import saving
+    dreammat_amd._import_plugins()
+    dev = torch.device("cuda:0")
+    enc = {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 2, "log2_hashmap_size": 14, "base_resolution": 16,
+           "per_level_scale": 1.447269237440378}
+    geo = dreammat_amd.find("dreammat-mesh")({"shape_init": "quad", "shape_init_params": 1.0, "pos_encoding_config": enc}).to(dev)
+    with torch.no_grad():
+        geo.encoding.encoding.params.uniform_(-1, 1)
+    lat = [torch.full((16, 32, 3), 0.25) for _ in range(5)]
+    mat = dreammat_amd.find("dreammat-material")({"use_raytracing": False, "env_max_res": 32, "env_min_res": 8}, latlongs=lat).to(dev)
+    ex = dreammat_amd.find("mesh-exporter")({"texture_size": 64, "texture_format": "png"}, geometry=geo, material=mat,
+                                            background=None)
+    mesh = geo.isosurface()
+    maps, holes = ex.bake_textures(mesh)
+    assert not bool(holes.any())                                             # the quad's UVs cover the whole atlas
+    # texel (j, i) <-> uv ((i+.5)/S, (j+.5)/S) <-> quad position (u-.5, v-.5, 0): query the field there directly
+    S = 64
+    jj, ii = torch.meshgrid(torch.arange(S, device=dev), torch.arange(S, device=dev), indexing="ij")
+    pts = torch.stack([(ii + 0.5) / S - 0.5, (jj + 0.5) / S - 0.5, torch.zeros_like(ii, dtype=torch.float32)], -1).reshape(-1, 3)
+    with torch.no_grad():
+        ref = mat.export(**geo.export(points=pts.float()))
+    for k in ("albedo", "metallic", "roughness"):
+        assert (maps[k].reshape(ref[k].shape) - ref[k]).abs().max() < 1e-4, k
+    paths = saving.save_obj(str(tmp_path / "model.obj"), **ex()[0].params)
+    assert sorted(os.path.basename(p) for p in paths) == ["model.mtl", "model.obj", "texture_kd.png", "texture_metallic.png",
+                                                         "texture_roughness.png"]
+
+
+@pytest.mark.parametrize("variant", ["schlick", "ggx_smith"])
+def test_mc_wave_kernel_matches_the_serial_kernel(variant, monkeypatch):
+    """the opt-in one-wave-per-pixel Monte-Carlo kernel (DREAMMAT_MC_KERNEL=wave; samples over the 64 lanes, ballot hit
+    bits, butterfly reduction) against the validated one-thread-per-pixel kernel; its decomposition is CPU-checked in
+    tests/test_golden_cpu.py, the kernel itself has not run on a GPU yet (hence the file-level xfail(strict=False))."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    import numpy as np
+    from dreammat_amd import _lib, hipops
+    dev = torch.device("cuda:0")
+    g = {k: torch.from_numpy(v) if v.ndim else v
+         for k, v in np.load(os.path.join(os.path.dirname(__file__), "golden", "mc_shading.npz")).items()}
+    bvh = hipops.MeshBvh(g["v_pos"], g["tri"], dev)
+    scene = hipops.McScene(bvh, [g["light"]], g[f"{variant}_dsamp"].shape[0], g[f"{variant}_ssamp"].shape[0], variant)
+    mat = _lib.MatCfgStruct(0.0, 0.9, 0.01, 0.9)
+    N = g["pts"].shape[0]
+    rd, rs = g[f"{variant}_rand_d"].to(dev).contiguous(), g[f"{variant}_rand_s"].to(dev).contiguous()
+
+    def run():
+        feats = g[f"{variant}_feats"].to(dev).requires_grad_()
+        outs = hipops.mc_shade(feats, g["pts"].to(dev), g["nrm"].to(dev), g["view"].to(dev),
+                               torch.zeros(N, dtype=torch.int32, device=dev), torch.full((1,), N, dtype=torch.int32, device=dev),
+                               torch.zeros(1, dtype=torch.int32, device=dev), scene, mat, 1 << 30, rd, rs, True)
+        (outs[0] * g[f"{variant}_wgt"].to(dev)).sum().backward()
+        return [o.detach().cpu() for o in outs], feats.grad.cpu()
+    monkeypatch.delenv("DREAMMAT_MC_KERNEL", raising=False)
+    ref_out, ref_grad = run()
+    monkeypatch.setenv("DREAMMAT_MC_KERNEL", "wave")
+    out, grad = run()
+    for a, b in zip(out, ref_out):
+        assert (a - b).abs().max() < 1e-5
+    assert (grad - ref_grad).abs().max() <= 1e-5 * max(1.0, ref_grad.abs().max().item())
