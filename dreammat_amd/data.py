@@ -6,6 +6,8 @@ ControlNet condition maps come from one of
   * `condition_source: prerender` -- the reference's Blender/Cycles PNG tree under `pre_render_dir`
     (depth/%03d.png 16-bit, normal/%03d.png, light/%03d_m{0.0,1.0}r{0.0,0.5,1.0}_env{1..5}.png),
     decoded like uncond.py:532-582;
+  * `condition_source: render` -- rendered on the fly by this repo's kernels (dreammat_amd/condition.py: depth,
+    Blender-convention view normal, 6 probe-material split-sum light maps); needs `attach_renderer(mesh, atlas)`;
   * `condition_source: synthetic` -- seeded U[0,1] maps (Blender is not available on this box;
     SURVEY 8d cfg3), generated per (view, env) on the fly instead of holding the reference's
     [128,5,H,W,18] float table (12.9 GB at 512^2) in host memory.
@@ -97,8 +99,16 @@ class FixCameraIterableDataset:
         self.fovy_degs = torch.rand(n, generator=g) * (fr[1] - fr[0]) + fr[0]
         self.gen = torch.Generator().manual_seed(cfg.seed + 1000003 * (rank + 1))   # per-rank draws
         self._prerender = None
+        self._cond_renderer = None
         if cfg.condition_source == "prerender":
             self._prerender = _PreRendered(cfg.pre_render_dir, n, cfg.fix_env_num, self.height, self.width)
+        elif cfg.condition_source not in ("synthetic", "render"):
+            raise ValueError(f"condition_source={cfg.condition_source!r}: expected synthetic | prerender | render")
+
+    def attach_renderer(self, mesh, atlas):
+        """condition_source: render -- the mesh and the material's environment atlas the maps are rendered with."""
+        from .condition import ConditionMapRenderer
+        self._cond_renderer = ConditionMapRenderer(mesh, atlas, self.device)
 
     def camera_for(self, view_id):
         elevation_deg = self.elevation_degs[view_id]
@@ -124,9 +134,15 @@ class FixCameraIterableDataset:
                 "light_positions": None, "elevation": elevation_deg, "azimuth": azimuth_deg, "camera_distances": dist,
                 "height": self.height, "width": self.width}
 
-    def condition_map(self, view_id, env_id):
+    def condition_map(self, view_id, env_id, cam=None):
         if self._prerender is not None:
             return self._prerender.get(view_id, env_id)
+        if self.cfg.condition_source == "render":
+            if self._cond_renderer is None:
+                raise RuntimeError("condition_source=render: call attach_renderer(mesh, material.atlas) first "
+                                   "(RandomCameraDataModule.setup does when it was given the mesh and the atlas)")
+            cam = cam or self.camera_for(view_id)
+            return self._cond_renderer(cam["mvp_mtx"], cam["c2w"], cam["rays_d"], env_id)
         out = []
         for v, e in zip(view_id.tolist(), env_id.tolist()):
             g = torch.Generator(device=self.device).manual_seed(7919 * v + e + 17)
@@ -138,7 +154,7 @@ class FixCameraIterableDataset:
         view_id = (torch.rand(B, generator=self.gen) * self.cfg.fix_view_num).floor().long()
         env_id = (torch.rand(B, generator=self.gen) * self.cfg.fix_env_num).floor().long()
         out = self.camera_for(view_id)
-        out.update({"view_id": view_id, "env_id": env_id, "condition_map": self.condition_map(view_id, env_id)})
+        out.update({"view_id": view_id, "env_id": env_id, "condition_map": self.condition_map(view_id, env_id, out)})
         return out
 
     def __iter__(self):
@@ -217,17 +233,20 @@ class RandomCameraDataset:
 
 @dreammat_amd.register("random-camera-datamodule")
 class RandomCameraDataModule:
-    def __init__(self, mesh=None, prerender_dir=None, cfg=None, rank=0, device="cpu"):
+    def __init__(self, mesh=None, prerender_dir=None, cfg=None, rank=0, device="cpu", atlas=None):
         self.device = device
         self.cfg = parse_structured(RandomCameraDataModuleConfig, cfg)
         if prerender_dir is not None and self.cfg.pre_render_dir is None:
             self.cfg.pre_render_dir = prerender_dir
         self.mesh = mesh
+        self.atlas = atlas          # the material's EnvAtlas: needed by condition_source=render only
         self.rank = rank
 
     def setup(self, stage=None):
         if stage in (None, "fit"):
             self.train_dataset = FixCameraIterableDataset(self.cfg, self.rank, self.device)
+            if self.cfg.condition_source == "render" and self.mesh is not None and self.atlas is not None:
+                self.train_dataset.attach_renderer(self.mesh, self.atlas)
         if stage in (None, "fit", "validate"):
             self.val_dataset = RandomCameraDataset(self.cfg, "val")
         if stage in (None, "test", "predict"):

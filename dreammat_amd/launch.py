@@ -37,7 +37,8 @@ def main(argv=None):
     system = dreammat_amd.find(cfg["system_type"])(cfg["system"])
     data_cfg = dict(cfg.get("data", {}))
     data_cfg.setdefault("seed", cfg.get("seed", 0))
-    dm = dreammat_amd.find(cfg["data_type"])(mesh=system.geometry.isosurface(), cfg=data_cfg, rank=rank)
+    dm = dreammat_amd.find(cfg["data_type"])(mesh=system.geometry.isosurface(), cfg=data_cfg, rank=rank,
+                                             device=system.device_, atlas=getattr(system.material, "atlas", None))
     tr = cfg.get("trainer", {})
     ck = cfg.get("checkpoint", {})
     trial_dir = os.path.join(cfg.get("exp_root_dir", "outputs"), cfg.get("name", "dream_mat"), str(cfg.get("tag", "run")))

@@ -74,3 +74,58 @@ def test_mc_wave_kernel_matches_the_serial_kernel(variant, monkeypatch):
     for a, b in zip(out, ref_out):
         assert (a - b).abs().max() < 1e-5
     assert (grad - ref_grad).abs().max() <= 1e-5 * max(1.0, ref_grad.abs().max().item())
+
+
+def test_condition_map_producer_vs_oracle_composition():
+    """SURVEY row f-2 (`condition_source: render`): depth / Blender-convention view normal / 6 probe-material light maps
+    from the HIP kernels, against the same recipe composed from the oracle's CPU pieces (C rasterizer + interpolate,
+    EnvLight split-sum shading with the probe material)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    import numpy as np
+    from dreammat_amd import envlight as penv, mesh as pmesh
+    from dreammat_amd.condition import PROBE_MATERIALS, ConditionMapRenderer, lin2srgb
+    from oracle import envlight as oenv, raster as oraster, shading as oshade
+    from tests import util
+    dev = torch.device("cuda:0")
+    lat = [util.synthetic_latlong(i) * 0.02 for i in range(3)]
+    fg = penv.approx_fg_lut()
+    atlas = penv.EnvAtlas(lat, scale=2.0, min_res=8, max_res=32, fg_lut=fg, device=dev)
+    oenvs = [oenv.EnvLight(l, scale=2.0, min_res=8, max_res=32) for l in lat]
+    m = pmesh.displaced_sphere(48, 40)
+    B, H, W = 2, 96, 96
+    batch = util.make_views(B, H, W, seed=5)
+    env_id = torch.tensor([2, 0])
+    cond = ConditionMapRenderer(m, atlas, dev)(batch["mvp_mtx"], batch["c2w"], batch["rays_d"], env_id).cpu()
+    assert cond.shape == (B, H, W, 22)
+    # ---- oracle composition
+    tri = m.t_pos_idx.numpy().astype(np.int32)
+    pos_clip = oraster.vertex_transform(m.v_pos.numpy(), batch["mvp_mtx"].numpy())
+    rast = torch.from_numpy(oraster.rasterize(pos_clip, tri, H, W))
+    mask = rast[..., 3] > 0
+    gpos = torch.from_numpy(oraster.interpolate(m.v_pos.numpy(), rast.numpy(), tri))
+    gnrm = torch.nn.functional.normalize(torch.from_numpy(oraster.interpolate(m.v_nrm.numpy(), rast.numpy(), tri)), dim=-1)
+    ref = torch.zeros(B, H, W, 22)
+    ref[..., 1:4] = torch.tensor([0.5, 0.5, 1.0])
+    c2w = batch["c2w"]
+    for b in range(B):
+        mk = mask[b]
+        right, up, back, cam = c2w[b, :3, 0], c2w[b, :3, 1], c2w[b, :3, 2], c2w[b, :3, 3]
+        inv = 1.0 / (((cam - gpos[b][mk]) * back).sum(-1) + 1e-6)
+        ref[b][mk, 0] = 0.7 * (inv - inv.min()) / (inv.max() - inv.min() + 1e-6) + 0.3
+        n = gnrm[b][mk]
+        ref[b][mk, 1] = 0.5 * (n * right).sum(-1) + 0.5
+        ref[b][mk, 2] = -0.5 * (n * up).sum(-1) + 0.5
+        ref[b][mk, 3] = -0.5 * (n * back).sum(-1) + 0.5
+        view = -torch.nn.functional.normalize(batch["rays_d"][b][mk], dim=-1)
+        for k, (met, rough) in enumerate(PROBE_MATERIALS):
+            one = torch.ones(n.shape[0], 1)
+            out = oshade.shade_splitsum(n, view, oenvs[int(env_id[b])], fg, met * one, rough * one, one.expand(-1, 3))
+            ref[b][mk, 4 + 3 * k:7 + 3 * k] = lin2srgb(out["color"])
+    assert torch.equal(cond[..., 0] > 0, mask)                              # same coverage as the bit-exact rasterizer
+    assert (cond[..., :4] - ref[..., :4]).abs().max() < 2e-4
+    assert (cond[..., 4:] - ref[..., 4:]).abs().max() < 3e-3
+    fgpix = cond[mask]
+    assert fgpix[:, 0].min() >= 0.3 - 1e-6 and fgpix[:, 0].max() <= 1 + 1e-6 and (cond[~mask][:, 4:] == 0).all()
+    assert (cond[~mask][:, 1:4] - torch.tensor([0.5, 0.5, 1.0])).abs().max() == 0
+    assert (fgpix[:, 4:7] - fgpix[:, 10:13]).abs().max() > 0.02             # the probes do look different
