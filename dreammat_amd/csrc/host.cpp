@@ -3,6 +3,7 @@
 // the DreamMat mesh is fixed, so it is built once per mesh) and library introspection.
 #include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -29,7 +30,8 @@ struct BvhBuilder {
     std::vector<float> cen;           // per triangle centroid [n][3]
     std::vector<int32_t> order;       // triangle ids, partitioned in place
     std::vector<DmBvhNode> nodes;
-    static constexpr int kLeaf = 4, kBins = 16;
+    int kLeaf = 4;                    // max triangles per leaf (bvh_core.h assumes nothing about it)
+    static constexpr int kBins = 16;
 
     void set_box(int node, const Aabb& b) {
         for (int k = 0; k < 3; ++k) { nodes[node].bmin[k] = b.lo[k]; nodes[node].bmax[k] = b.hi[k]; }
@@ -130,6 +132,7 @@ int dm_bvh_build(const float* v_pos, int32_t n_vert, const int32_t* tri, int32_t
         if (tri[i] < 0 || tri[i] >= n_vert) return DM_ERR_ARG;
     BvhBuilder b;
     b.v = v_pos; b.tri = tri; b.n = n_tri;
+    if (const char* e = getenv("DREAMMAT_BVH_LEAF")) b.kLeaf = std::max(1, std::min(16, atoi(e)));   // tuning knob (tools/bvh_stats.py)
     b.box.resize(n_tri); b.cen.resize((size_t)n_tri * 3); b.order.resize(n_tri);
     for (int32_t t = 0; t < n_tri; ++t) {
         b.order[t] = t;

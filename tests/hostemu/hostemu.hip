@@ -196,4 +196,39 @@ int emu_mc_shade(const float* cfg4, int nd, int ns, int ggx_smith, const void* n
     return 0;
 }
 
+// traversal statistics of the any-hit query (same control flow as dm_bvh_any_hit): nodes popped and triangles tested per
+// ray -- a CPU-measurable proxy for the GPU traversal cost, used to tune the builder (tools/bvh_stats.py)
+int emu_bvh_stats(const void* nodes_v, const float* tris, const float* org, const float* dir, long long n, float t_max,
+                  long long* nodes_visited, long long* tris_tested, long long* hits) {
+    const DmBvhNode* nodes = (const DmBvhNode*)nodes_v;
+    long long nv = 0, tt = 0, nh = 0;
+    for (long long i = 0; i < n; ++i) {
+        const float ox = org[3 * i], oy = org[3 * i + 1], oz = org[3 * i + 2], dx = dir[3 * i], dy = dir[3 * i + 1], dz = dir[3 * i + 2];
+        const float big = 3.0e38f;
+        const float ix = fabsf(dx) > 1e-30f ? 1.0f / dx : (dx < 0.f ? -big : big);
+        const float iy = fabsf(dy) > 1e-30f ? 1.0f / dy : (dy < 0.f ? -big : big);
+        const float iz = fabsf(dz) > 1e-30f ? 1.0f / dz : (dz < 0.f ? -big : big);
+        int stack[64], sp = 0;
+        stack[sp++] = 0;
+        bool hit = false;
+        while (sp > 0 && !hit) {
+            const DmBvhNode nd = nodes[stack[--sp]];
+            ++nv;
+            float t0 = (nd.bmin[0] - ox) * ix, t1 = (nd.bmax[0] - ox) * ix;
+            float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+            t0 = (nd.bmin[1] - oy) * iy; t1 = (nd.bmax[1] - oy) * iy;
+            tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+            t0 = (nd.bmin[2] - oz) * iz; t1 = (nd.bmax[2] - oz) * iz;
+            tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+            if (!(tf >= fmaxf(tn, 0.f)) || tn > t_max) continue;
+            if (nd.b > 0) {
+                for (int k = 0; k < nd.b && !hit; ++k) { ++tt; hit = dm_bvh_ray_triangle(tris + 12 * (size_t)(nd.a + k), ox, oy, oz, dx, dy, dz, t_max); }
+            } else if (sp + 2 <= 64) { stack[sp++] = nd.a; stack[sp++] = nd.a + 1; }
+        }
+        nh += hit;
+    }
+    *nodes_visited = nv; *tris_tested = tt; *hits = nh;
+    return 0;
+}
+
 }  // extern "C"
