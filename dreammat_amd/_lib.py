@@ -39,7 +39,7 @@ class McSceneStruct(ctypes.Structure):
     """dm_mc_scene (include/dreammat_hip.h): host struct with device pointers for the Monte-Carlo shading kernels."""
     _fields_ = [("bvh_nodes", c_void_p), ("bvh_tris", c_void_p), ("lights", c_void_p), ("n_env", c_int),
                 ("light_h", c_int), ("light_w", c_int), ("samples_diffuse", c_void_p), ("samples_specular", c_void_p),
-                ("n_diffuse", c_int), ("n_specular", c_int), ("geometry_ggx_smith", c_int)]
+                ("n_diffuse", c_int), ("n_specular", c_int), ("geometry_ggx_smith", c_int), ("bvh_nodes4", c_void_p)]
 
 
 _LL = c_longlong
@@ -79,6 +79,7 @@ _SIGS = {
     "dm_matreg_bwd": (c_int, [c_void_p, _LL, _LL, c_void_p, _LL, _LL, c_void_p, _LL, c_float, c_void_p, _LL, _LL,
                               c_void_p, _LL, _LL, c_void_p]),
     "dm_bvh_build": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "dm_bvh_collapse4": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "dm_bvh_any_hit_rays": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _LL, c_float, c_void_p, c_void_p]),
     "dm_mc_hit_words": (c_int, [c_int, c_int]),
     "dm_mc_shade_fwd": (c_int, [POINTER(McSceneStruct), POINTER(MatCfgStruct)] + [c_void_p, _LL, _LL] * 4

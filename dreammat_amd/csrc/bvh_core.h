@@ -66,3 +66,47 @@ DM_HD bool dm_bvh_any_hit(const DmBvhNode* __restrict__ nodes, const float* __re
     }
     return false;
 }
+
+// ---- 4-wide variant (opt-in, DREAMMAT_BVH=4): the binary tree collapsed two levels at a time, the four child boxes
+// stored IN the parent (SoA, 128 B = 8 x 16 B loads).  One node fetch decides four subtrees, so a ray makes a quarter to
+// a third of the DEPENDENT memory round trips of the pop-then-test binary layout (tools/bvh_stats.py counts them on
+// the CPU).  child k: b[k] > 0 leaf = triangles [a[k], a[k]+b[k]); b[k] == 0 internal node a[k]; b[k] < 0 empty slot.
+struct DmBvhNode4 {
+    float lo[3][4];
+    float hi[3][4];
+    int a[4];
+    int b[4];
+};
+
+DM_HD bool dm_bvh4_any_hit(const DmBvhNode4* __restrict__ nodes, const float* __restrict__ tris, float ox, float oy, float oz,
+                           float dx, float dy, float dz, float t_max) {
+    const float big = 3.0e38f;
+    const float ix = fabsf(dx) > 1e-30f ? 1.0f / dx : (dx < 0.f ? -big : big);
+    const float iy = fabsf(dy) > 1e-30f ? 1.0f / dy : (dy < 0.f ? -big : big);
+    const float iz = fabsf(dz) > 1e-30f ? 1.0f / dz : (dz < 0.f ? -big : big);
+    int stack[48];
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp > 0) {
+        const DmBvhNode4 nd = nodes[stack[--sp]];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (nd.b[k] < 0) continue;
+            float t0 = (nd.lo[0][k] - ox) * ix, t1 = (nd.hi[0][k] - ox) * ix;
+            float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+            t0 = (nd.lo[1][k] - oy) * iy; t1 = (nd.hi[1][k] - oy) * iy;
+            tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+            t0 = (nd.lo[2][k] - oz) * iz; t1 = (nd.hi[2][k] - oz) * iz;
+            tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+            if (!(tf >= fmaxf(tn, 0.f)) || tn > t_max) continue;
+            if (nd.b[k] > 0) {
+                for (int j = 0; j < nd.b[k]; ++j)
+                    if (dm_bvh_ray_triangle(tris + 12 * (size_t)(nd.a[k] + j), ox, oy, oz, dx, dy, dz, t_max)) return true;
+            } else if (sp < 48) {
+                stack[sp++] = nd.a[k];
+            }
+        }
+    }
+    return false;
+}
+

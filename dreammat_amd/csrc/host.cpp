@@ -163,4 +163,55 @@ int dm_bvh_build(const float* v_pos, int32_t n_vert, const int32_t* tri, int32_t
     return DM_OK;
 }
 
+// 4-wide collapse of dm_bvh_build's binary tree (csrc/bvh_core.h, DmBvhNode4): nodes2 = the n_nodes2 binary nodes,
+// nodes4_out must hold n_nodes2 entries (upper bound), *n_nodes4_out = entries used.  Triangle order is unchanged.
+int dm_bvh_collapse4(const void* nodes2_v, int32_t n_nodes2, void* nodes4_out, int32_t* n_nodes4_out) {
+    if (!nodes2_v || !nodes4_out || !n_nodes4_out || n_nodes2 <= 0) return DM_ERR_ARG;
+    const DmBvhNode* n2 = (const DmBvhNode*)nodes2_v;
+    std::vector<DmBvhNode4> out;
+    out.reserve(n_nodes2);
+    // work list of (binary node -> wide node) pairs; children of a wide node = grandchildren of the binary node where
+    // possible (a binary child that is a leaf stays one slot)
+    struct Item { int bin, wide; };
+    std::vector<Item> todo;
+    out.emplace_back();
+    todo.push_back({0, 0});
+    auto set_child = [&](DmBvhNode4& w, int k, const DmBvhNode& c, int a, int b) {
+        for (int d = 0; d < 3; ++d) { w.lo[d][k] = c.bmin[d]; w.hi[d][k] = c.bmax[d]; }
+        w.a[k] = a; w.b[k] = b;
+    };
+    while (!todo.empty()) {
+        Item it = todo.back();
+        todo.pop_back();
+        DmBvhNode4 w;
+        for (int k = 0; k < 4; ++k) { w.a[k] = 0; w.b[k] = -1; for (int d = 0; d < 3; ++d) { w.lo[d][k] = 1.f; w.hi[d][k] = -1.f; } }
+        const DmBvhNode& root = n2[it.bin];
+        int slots[4], ns = 0;
+        if (root.b > 0) {
+            slots[ns++] = it.bin;                                   // a leaf root (tiny mesh): one slot
+        } else {
+            for (int c = 0; c < 2; ++c) {
+                const int ci = root.a + c;
+                if (n2[ci].b > 0) slots[ns++] = ci;                 // leaf child
+                else { slots[ns++] = n2[ci].a; slots[ns++] = n2[ci].a + 1; }   // its two children
+            }
+        }
+        for (int k = 0; k < ns; ++k) {
+            const DmBvhNode& c = n2[slots[k]];
+            if (c.b > 0) set_child(w, k, c, c.a, c.b);
+            else {
+                const int wi = (int)out.size();
+                out.emplace_back();
+                set_child(w, k, c, wi, 0);
+                todo.push_back({slots[k], wi});
+            }
+        }
+        out[it.wide] = w;
+    }
+    if ((int32_t)out.size() > n_nodes2) return DM_ERR_WORKSPACE;
+    std::memcpy(nodes4_out, out.data(), out.size() * sizeof(DmBvhNode4));
+    *n_nodes4_out = (int32_t)out.size();
+    return DM_OK;
+}
+
 }  // extern "C"

@@ -25,6 +25,7 @@ struct dm_mc_scene {
     const float* samples_diffuse; const float* samples_specular;
     int n_diffuse, n_specular;
     int geometry_ggx_smith;
+    const void* bvh_nodes4;
 };
 }
 
@@ -37,7 +38,7 @@ struct StrOut { float* p; long long rs, cs; };
 
 struct McArgs {
     McCfg cfg;
-    const DmBvhNode* nodes; const float* tris;
+    const DmBvhNode* nodes; const float* tris; const DmBvhNode4* nodes4;
     const float* lights; int n_env, light_h, light_w;
     const float* samples_d; const float* samples_s;
     Str pos, nrm, view, feat, dcolor;
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(128) void k_mc_shade(McArgs a) {
     for (int k = 0; k < 5; ++k) f[k] = a.feat.p[i * a.feat.rs + k * a.feat.cs];
     const int env = a.env_of_view[a.pix_idx[i] / a.HW];
     McScene sc;
-    sc.nodes = a.nodes; sc.tris = a.tris;
+    sc.nodes = a.nodes; sc.tris = a.tris; sc.nodes4 = a.nodes4;
     sc.light = a.lights + (size_t)env * a.light_h * a.light_w * 3; sc.light_h = a.light_h; sc.light_w = a.light_w;
     sc.samples_d = a.samples_d; sc.samples_s = a.samples_s;
     const float rd = a.rand_d ? a.rand_d[i] : -1.f, rs = a.rand_s ? a.rand_s[i] : -1.f;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void k_mc_shade_wave(McArgs a) {
         for (int k = 0; k < 5; ++k) f[k] = a.feat.p[i * a.feat.rs + k * a.feat.cs];
         const int env = a.env_of_view[a.pix_idx[i] / a.HW];
         McScene sc;
-        sc.nodes = a.nodes; sc.tris = a.tris;
+        sc.nodes = a.nodes; sc.tris = a.tris; sc.nodes4 = a.nodes4;
         sc.light = a.lights + (size_t)env * a.light_h * a.light_w * 3; sc.light_h = a.light_h; sc.light_w = a.light_w;
         sc.samples_d = a.samples_d; sc.samples_s = a.samples_s;
         McFrame fr;
@@ -206,7 +207,7 @@ bool fill(McArgs& a, const dm_mc_scene* s, const dm_mat_cfg* mat) {
     if (s->n_diffuse + s->n_specular > kMaxSamples) return false;
     a.cfg = {mat->min_metallic, mat->max_metallic, mat->min_roughness, mat->max_roughness, s->n_diffuse, s->n_specular,
              s->geometry_ggx_smith ? 1 : 0};
-    a.nodes = (const DmBvhNode*)s->bvh_nodes; a.tris = s->bvh_tris;
+    a.nodes = (const DmBvhNode*)s->bvh_nodes; a.tris = s->bvh_tris; a.nodes4 = (const DmBvhNode4*)s->bvh_nodes4;
     a.lights = s->lights; a.n_env = s->n_env; a.light_h = s->light_h; a.light_w = s->light_w;
     a.samples_d = s->samples_diffuse; a.samples_s = s->samples_specular;
     return true;

@@ -79,6 +79,7 @@ struct McCfg {
 
 struct McScene {
     const DmBvhNode* nodes; const float* tris;                       // dm_bvh_build outputs
+    const DmBvhNode4* nodes4;                                        // optional 4-wide form (dm_bvh_collapse4), else null
     const float* light; int light_h, light_w;                        // lat-long radiance [h][w][3] of this pixel's env
     const float* samples_d; const float* samples_s;                  // [n][2] (azimuth, elevation) tables in [0,1]^2
 };
@@ -114,6 +115,7 @@ DM_HD void env_lookup(const McScene& sc, float dx, float dy, float dz, float* rg
 // get_lights (:490-507): the ray starts 1e-5 along the direction; miss <=> no hit closer than 10
 DM_HD bool occluded(const McScene& sc, const float* p, float dx, float dy, float dz) {
     const float eps = 1e-5f;
+    if (sc.nodes4) return dm_bvh4_any_hit(sc.nodes4, sc.tris, p[0] + dx * eps, p[1] + dy * eps, p[2] + dz * eps, dx, dy, dz, 10.0f);
     return dm_bvh_any_hit(sc.nodes, sc.tris, p[0] + dx * eps, p[1] + dy * eps, p[2] + dz * eps, dx, dy, dz, 10.0f);
 }
 

@@ -5,6 +5,7 @@ PyTorch is plumbing here (memory, streams, autograd graph) -- all arithmetic of 
 hand-written gfx950 kernels.  There is no fallback: CPU tensors or a missing library raise.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -549,6 +550,13 @@ class MeshBvh:
                                       order.data_ptr(), ctypes.addressof(n_nodes)), "dm_bvh_build")
         self.n_nodes = int(n_nodes.value)
         self.nodes_host, self.tris_host, self.order = nodes[:self.n_nodes].contiguous(), tris, order
+        # 4-wide collapse of the same tree (128 B nodes, csrc/bvh_core.h DmBvhNode4): opt-in for the kernels
+        nodes4 = torch.zeros(self.n_nodes, 32, dtype=torch.int32)
+        n4 = ctypes.c_int32(0)
+        check(_lib.lib().dm_bvh_collapse4(self.nodes_host.data_ptr(), self.n_nodes, nodes4.data_ptr(), ctypes.addressof(n4)),
+              "dm_bvh_collapse4")
+        self.n_nodes4 = int(n4.value)
+        self.nodes4_host = nodes4[:self.n_nodes4].contiguous()
         self.nodes = self.tris = None
         if device is not None:
             self.nodes, self.tris = self.nodes_host.to(device), self.tris_host.to(device)
@@ -592,10 +600,13 @@ class McScene:
         self.samples_s = fibonacci_direction_samples(n_specular).to(dev)
         self.n_diffuse, self.n_specular = int(n_diffuse), int(n_specular)
         self.hit_words = int(_lib.lib().dm_mc_hit_words(self.n_diffuse, self.n_specular))
+        # DREAMMAT_BVH=4: trace through the 4-wide nodes (opt-in until timed on the GPU; same hits by construction)
+        self.nodes4 = bvh.nodes4_host.to(dev) if os.environ.get("DREAMMAT_BVH") == "4" else None
         self.struct = _lib.McSceneStruct(bvh.nodes.data_ptr(), bvh.tris.data_ptr(), self.lights.data_ptr(),
                                          self.lights.shape[0], self.lights.shape[1], self.lights.shape[2],
                                          self.samples_d.data_ptr(), self.samples_s.data_ptr(), self.n_diffuse,
-                                         self.n_specular, 1 if geometry_type == "ggx_smith" else 0)
+                                         self.n_specular, 1 if geometry_type == "ggx_smith" else 0,
+                                         self.nodes4.data_ptr() if self.nodes4 is not None else None)
 
 
 class _McShade(torch.autograd.Function):

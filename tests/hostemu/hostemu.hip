@@ -161,13 +161,13 @@ static void emu_pixel_lanes(const dm::mc::McCfg& cfg, const dm::mc::McScene& sc,
 
 extern "C" {
 
-int emu_mc_shade(const float* cfg4, int nd, int ns, int ggx_smith, const void* nodes, const float* tris, const float* light,
+int emu_mc_shade(const float* cfg4, int nd, int ns, int ggx_smith, const void* nodes, const void* nodes4, const float* tris, const float* light,
                  int lh, int lw, const float* samples_d, const float* samples_s, long long N, const float* p, const float* n,
                  const float* v, const float* feat, const float* rand_d, const float* rand_s, unsigned* hit_bits, float* out,
                  const float* dcolor, float* dfeat, int lanes) {
     using namespace dm::mc;
     McCfg cfg = {cfg4[0], cfg4[1], cfg4[2], cfg4[3], nd, ns, ggx_smith};
-    McScene sc = {(const DmBvhNode*)nodes, tris, light, lh, lw, samples_d, samples_s};
+    McScene sc = {(const DmBvhNode*)nodes, tris, (const DmBvhNode4*)nodes4, light, lh, lw, samples_d, samples_s};
     const int words = kMaxSamples / 32;
     if (nd + ns > kMaxSamples || (lanes != 1 && lanes != 64)) return -1;
     const int used_words = (nd + ns + 31) / 32;
@@ -224,6 +224,51 @@ int emu_bvh_stats(const void* nodes_v, const float* tris, const float* org, cons
             if (nd.b > 0) {
                 for (int k = 0; k < nd.b && !hit; ++k) { ++tt; hit = dm_bvh_ray_triangle(tris + 12 * (size_t)(nd.a + k), ox, oy, oz, dx, dy, dz, t_max); }
             } else if (sp + 2 <= 64) { stack[sp++] = nd.a; stack[sp++] = nd.a + 1; }
+        }
+        nh += hit;
+    }
+    *nodes_visited = nv; *tris_tested = tt; *hits = nh;
+    return 0;
+}
+
+int emu_bvh4_any_hit(const void* nodes4, const float* tris, const float* org, const float* dir, long long n, float t_max,
+                     unsigned char* hit) {
+    for (long long i = 0; i < n; ++i)
+        hit[i] = dm_bvh4_any_hit((const DmBvhNode4*)nodes4, tris, org[3 * i], org[3 * i + 1], org[3 * i + 2], dir[3 * i],
+                                 dir[3 * i + 1], dir[3 * i + 2], t_max) ? 1 : 0;
+    return 0;
+}
+
+// node fetches / triangle tests per ray of the 4-wide traversal (same control flow as dm_bvh4_any_hit)
+int emu_bvh4_stats(const void* nodes_v, const float* tris, const float* org, const float* dir, long long n, float t_max,
+                   long long* nodes_visited, long long* tris_tested, long long* hits) {
+    const DmBvhNode4* nodes = (const DmBvhNode4*)nodes_v;
+    long long nv = 0, tt = 0, nh = 0;
+    for (long long i = 0; i < n; ++i) {
+        const float ox = org[3 * i], oy = org[3 * i + 1], oz = org[3 * i + 2], dx = dir[3 * i], dy = dir[3 * i + 1], dz = dir[3 * i + 2];
+        const float big = 3.0e38f;
+        const float ix = fabsf(dx) > 1e-30f ? 1.0f / dx : (dx < 0.f ? -big : big);
+        const float iy = fabsf(dy) > 1e-30f ? 1.0f / dy : (dy < 0.f ? -big : big);
+        const float iz = fabsf(dz) > 1e-30f ? 1.0f / dz : (dz < 0.f ? -big : big);
+        int stack[48], sp = 0;
+        stack[sp++] = 0;
+        bool hit = false;
+        while (sp > 0 && !hit) {
+            const DmBvhNode4 nd = nodes[stack[--sp]];
+            ++nv;
+            for (int k = 0; k < 4 && !hit; ++k) {
+                if (nd.b[k] < 0) continue;
+                float t0 = (nd.lo[0][k] - ox) * ix, t1 = (nd.hi[0][k] - ox) * ix;
+                float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+                t0 = (nd.lo[1][k] - oy) * iy; t1 = (nd.hi[1][k] - oy) * iy;
+                tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+                t0 = (nd.lo[2][k] - oz) * iz; t1 = (nd.hi[2][k] - oz) * iz;
+                tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+                if (!(tf >= fmaxf(tn, 0.f)) || tn > t_max) continue;
+                if (nd.b[k] > 0) {
+                    for (int j = 0; j < nd.b[k] && !hit; ++j) { ++tt; hit = dm_bvh_ray_triangle(tris + 12 * (size_t)(nd.a[k] + j), ox, oy, oz, dx, dy, dz, t_max); }
+                } else if (sp < 48) stack[sp++] = nd.a[k];
+            }
         }
         nh += hit;
     }

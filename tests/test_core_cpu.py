@@ -248,4 +248,10 @@ def test_bvh_build_and_traversal_core_vs_brute_force(hostemu):
         ref = omc.trace_any_hit(m.v_pos.float(), m.t_pos_idx, o, d)
         mism = int((hit.bool() != ref).sum())
         assert mism <= 2, (mism, o.shape[0])                                          # fp32 vs fp64 on edge-grazing rays
+        # the 4-wide collapse (dm_bvh_collapse4 + dm_bvh4_any_hit): same triangles, same tests => identical answers
+        hit4 = torch.zeros(o.shape[0], dtype=torch.uint8)
+        hostemu.emu_bvh4_any_hit(ctypes.c_void_p(bvh.nodes4_host.data_ptr()), ctypes.c_void_p(bvh.tris_host.data_ptr()),
+                                 ctypes.c_void_p(o.data_ptr()), ctypes.c_void_p(d.data_ptr()), ctypes.c_longlong(o.shape[0]),
+                                 ctypes.c_float(10.0), ctypes.c_void_p(hit4.data_ptr()))
+        assert torch.equal(hit4, hit) and 1 <= bvh.n_nodes4 <= bvh.n_nodes
         assert 0.2 < ref.float().mean() < 0.95

@@ -162,7 +162,7 @@ def test_mc_raytraced_shading_oracle_vs_reference(variant):
 
 
 def _emu_mc_shade(hostemu, bvh, light, dsamp, ssamp, pts, nrm, view, feats, rand_d, rand_s, ggx_smith, dcolor=None, hit_bits=None,
-                  lanes=1):
+                  lanes=1, wide=False):
     import ctypes
     N = pts.shape[0]
     cp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
@@ -174,7 +174,8 @@ def _emu_mc_shade(hostemu, bvh, light, dsamp, ssamp, pts, nrm, view, feats, rand
         hit_bits = torch.zeros(N, 32, dtype=torch.int32)
     out = torch.zeros(N, 25)
     dfeat = torch.zeros(N, 5)
-    rc = hostemu.emu_mc_shade(cp(cfg4), dsamp.shape[0], ssamp.shape[0], int(ggx_smith), cp(bvh.nodes_host), cp(bvh.tris_host),
+    rc = hostemu.emu_mc_shade(cp(cfg4), dsamp.shape[0], ssamp.shape[0], int(ggx_smith), cp(bvh.nodes_host),
+                              cp(bvh.nodes4_host) if wide else None, cp(bvh.tris_host),
                               cp(light), light.shape[0], light.shape[1], cp(dsamp), cp(ssamp), ctypes.c_longlong(N), cp(pts),
                               cp(nrm), cp(view), cp(feats), cp(rand_d), cp(rand_s), cp(hit_bits), cp(out), cp(dcolor), cp(dfeat), int(lanes))
     assert rc == 0
@@ -217,3 +218,6 @@ def test_mc_shading_product_core_vs_reference(hostemu, variant):
     assert torch.equal(bits64, bits) and (out64 - out).abs().max() < 1e-5
     _, dfeat64, _ = _emu_mc_shade(*args, dcolor=g[f"{variant}_wgt"], hit_bits=bits64, lanes=64)
     assert (dfeat64 - dfeat).abs().max() <= 1e-5 * max(1.0, scale)
+    # tracing through the 4-wide collapse of the BVH finds the same occlusions
+    out4, _, bits4 = _emu_mc_shade(*args, wide=True)
+    assert torch.equal(bits4, bits) and torch.equal(out4, out)

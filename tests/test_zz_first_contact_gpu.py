@@ -42,8 +42,9 @@ def test_exporter_bakes_the_fitted_field_on_the_gpu(tmp_path):
                                                          "texture_roughness.png"]
 
 
+@pytest.mark.parametrize("bvh_width", ["2", "4"])
 @pytest.mark.parametrize("variant", ["schlick", "ggx_smith"])
-def test_mc_wave_kernel_matches_the_serial_kernel(variant, monkeypatch):
+def test_mc_wave_kernel_matches_the_serial_kernel(variant, bvh_width, monkeypatch):
     """the opt-in one-wave-per-pixel Monte-Carlo kernel (DREAMMAT_MC_KERNEL=wave; samples over the 64 lanes, ballot hit
     bits, butterfly reduction) against the validated one-thread-per-pixel kernel; its decomposition is CPU-checked in
     tests/test_golden_cpu.py, the kernel itself has not run on a GPU yet (hence the file-level xfail(strict=False))."""
@@ -55,12 +56,16 @@ def test_mc_wave_kernel_matches_the_serial_kernel(variant, monkeypatch):
     g = {k: torch.from_numpy(v) if v.ndim else v
          for k, v in np.load(os.path.join(os.path.dirname(__file__), "golden", "mc_shading.npz")).items()}
     bvh = hipops.MeshBvh(g["v_pos"], g["tri"], dev)
-    scene = hipops.McScene(bvh, [g["light"]], g[f"{variant}_dsamp"].shape[0], g[f"{variant}_ssamp"].shape[0], variant)
+    monkeypatch.delenv("DREAMMAT_BVH", raising=False)
+    scene_ref = hipops.McScene(bvh, [g["light"]], g[f"{variant}_dsamp"].shape[0], g[f"{variant}_ssamp"].shape[0], variant)
+    monkeypatch.setenv("DREAMMAT_BVH", bvh_width)          # "4": trace through the 4-wide collapse of the same tree
+    scene_new = hipops.McScene(bvh, [g["light"]], g[f"{variant}_dsamp"].shape[0], g[f"{variant}_ssamp"].shape[0], variant)
+    assert (scene_new.nodes4 is not None) == (bvh_width == "4")
     mat = _lib.MatCfgStruct(0.0, 0.9, 0.01, 0.9)
     N = g["pts"].shape[0]
     rd, rs = g[f"{variant}_rand_d"].to(dev).contiguous(), g[f"{variant}_rand_s"].to(dev).contiguous()
 
-    def run():
+    def run(scene):
         feats = g[f"{variant}_feats"].to(dev).requires_grad_()
         outs = hipops.mc_shade(feats, g["pts"].to(dev), g["nrm"].to(dev), g["view"].to(dev),
                                torch.zeros(N, dtype=torch.int32, device=dev), torch.full((1,), N, dtype=torch.int32, device=dev),
@@ -68,9 +73,9 @@ def test_mc_wave_kernel_matches_the_serial_kernel(variant, monkeypatch):
         (outs[0] * g[f"{variant}_wgt"].to(dev)).sum().backward()
         return [o.detach().cpu() for o in outs], feats.grad.cpu()
     monkeypatch.delenv("DREAMMAT_MC_KERNEL", raising=False)
-    ref_out, ref_grad = run()
+    ref_out, ref_grad = run(scene_ref)
     monkeypatch.setenv("DREAMMAT_MC_KERNEL", "wave")
-    out, grad = run()
+    out, grad = run(scene_new)
     for a, b in zip(out, ref_out):
         assert (a - b).abs().max() < 1e-5
     assert (grad - ref_grad).abs().max() <= 1e-5 * max(1.0, ref_grad.abs().max().item())

@@ -26,6 +26,10 @@ nv, tt, nh = ctypes.c_longlong(0), ctypes.c_longlong(0), ctypes.c_longlong(0)
 p = lambda t: ctypes.c_void_p(t.data_ptr())
 emu.emu_bvh_stats(p(bvh.nodes_host), p(bvh.tris_host), p(o), p(d), ctypes.c_longlong(N), ctypes.c_float(10.0),
                   ctypes.byref(nv), ctypes.byref(tt), ctypes.byref(nh))
-depth = 0
-print(json.dumps({"tris": int(tv.shape[0]), "nodes": bvh.n_nodes, "rays": N, "nodes_per_ray": nv.value / N,
-                  "tris_per_ray": tt.value / N, "hit_frac": nh.value / N}))
+res = {"tris": int(tv.shape[0]), "rays": N, "hit_frac": nh.value / N,
+       "bvh2": {"nodes": bvh.n_nodes, "node_bytes": 32, "node_fetches_per_ray": nv.value / N, "tris_per_ray": tt.value / N}}
+emu.emu_bvh4_stats(p(bvh.nodes4_host), p(bvh.tris_host), p(o), p(d), ctypes.c_longlong(N), ctypes.c_float(10.0),
+                   ctypes.byref(nv), ctypes.byref(tt), ctypes.byref(nh))
+res["bvh4"] = {"nodes": bvh.n_nodes4, "node_bytes": 128, "node_fetches_per_ray": nv.value / N, "tris_per_ray": tt.value / N,
+               "hit_frac": nh.value / N}
+print(json.dumps(res))

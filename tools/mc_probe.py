@@ -10,7 +10,6 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 m = pmesh.displaced_sphere(160, 160)
 bvh = hipops.MeshBvh(m.v_pos, m.t_pos_idx, dev)
-scene = hipops.McScene(bvh, [torch.rand(512, 1024, 3) for _ in range(5)], 200, 128, "schlick")
 mat = _lib.MatCfgStruct(0.0, 0.9, 0.01, 0.9)
 tv = m.v_pos.float()[m.t_pos_idx.long()]
 fn = torch.nn.functional.normalize(torch.cross(tv[:, 1] - tv[:, 0], tv[:, 2] - tv[:, 0], dim=-1), dim=-1)
@@ -23,15 +22,23 @@ pix = (torch.arange(N, device=dev, dtype=torch.int32) % 8) * (512 * 512)
 env = torch.tensor([0, 1, 2, 3, 4, 0, 1, 2], dtype=torch.int32, device=dev)
 nd = torch.full((1,), N, dtype=torch.int32, device=dev)
 rd, rs = torch.rand(N, device=dev), torch.rand(N, device=dev)
-def run():
-    out = hipops.mc_shade(f, p, n, v, pix, nd, env, scene, mat, 512 * 512, rd, rs, False)
-    return out[0]
-c = run(); torch.cuda.synchronize()
-e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-e[0].record(); c = run(); e[1].record(); c.sum().backward(); e[2].record(); torch.cuda.synchronize()
-tf, tb = e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])
-res = {"N": N, "samples": 328, "tris": int(m.t_pos_idx.shape[0]), "bvh_nodes": bvh.n_nodes, "fwd_ms": tf, "bwd_ms": tb,
-       "fwd_Grays_per_s": N * 328 / tf / 1e6, "occluded_frac_color_mean": float(c.mean())}
-print(json.dumps(res))
+lights = [torch.rand(512, 1024, 3) for _ in range(5)]
+results = []
+for kernel in ("serial", "wave"):
+    for width in ("2", "4"):
+        os.environ["DREAMMAT_BVH"] = width
+        os.environ["DREAMMAT_MC_KERNEL"] = kernel
+        scene = hipops.McScene(bvh, lights, 200, 128, "schlick")
+
+        def run():
+            return hipops.mc_shade(f, p, n, v, pix, nd, env, scene, mat, 512 * 512, rd, rs, False)[0]
+        c = run(); torch.cuda.synchronize()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record(); c = run(); e[1].record(); c.sum().backward(); e[2].record(); torch.cuda.synchronize()
+        tf, tb = e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])
+        res = {"kernel": kernel, "bvh_width": int(width), "N": N, "samples": 328, "tris": int(m.t_pos_idx.shape[0]),
+               "fwd_ms": tf, "bwd_ms": tb, "fwd_Grays_per_s": N * 328 / tf / 1e6, "color_mean": float(c.mean())}
+        print(json.dumps(res), flush=True)
+        results.append(res)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(res, open("gpurun_out/mc_probe.json", "w"))
+json.dump(results, open("gpurun_out/mc_probe.json", "w"), indent=1)
