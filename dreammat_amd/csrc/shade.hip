@@ -170,6 +170,7 @@ struct dm_env_atlas {
     int mip_res[8];
     int n_mips, diff_res, lut_res;
     float min_rough_mip, max_rough_mip;
+    int texel_fp16;
 };
 struct dm_mat_cfg { float min_metallic, max_metallic, min_roughness, max_roughness; };
 
@@ -180,6 +181,7 @@ static bool conv_atlas(const dm_env_atlas* in, EnvAtlas& A) {
     for (int i = 0; i < kMaxMips; ++i) { A.mip_off[i] = in->mip_off[i]; A.mip_res[i] = in->mip_res[i]; }
     A.n_mips = in->n_mips; A.diff_res = in->diff_res; A.lut_res = in->lut_res;
     A.min_rough_mip = in->min_rough_mip; A.max_rough_mip = in->max_rough_mip;
+    A.half_texels = in->texel_fp16 ? 1 : 0;
     return true;
 }
 

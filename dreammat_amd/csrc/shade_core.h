@@ -23,6 +23,7 @@ struct EnvAtlas {
     int diff_res;
     int lut_res;
     float min_rough_mip, max_rough_mip;   // envlight MIN/MAX_ROUGHNESS (0.08, 0.5)
+    int half_texels;             // 1: spec / diff texels are RGBA fp16 (8 B): one 16 B load per bilinear ROW (opt-in)
 };
 
 struct MatCfg {
@@ -74,6 +75,29 @@ DM_HD F3 cube_fetch(const float4* __restrict__ tex, int R, CubeCoord cc) {
     return f3(t00.x * w00 + t10.x * w10 + t01.x * w01 + t11.x * w11,
               t00.y * w00 + t10.y * w10 + t01.y * w01 + t11.y * w11,
               t00.z * w00 + t10.z * w10 + t01.z * w01 + t11.z * w11);
+}
+
+// fp16 atlas (opt-in): texel = 4 halves, so the two texels of a bilinear row are ONE 16-byte load (8-byte aligned).
+// The shade kernels are bound by the number of scattered gather instructions per pixel (16 with fp32 texels, rocprofv3:
+// SQ_WAIT_INST_ANY 54 %, VALU 9 %); this halves the cube-map gathers (12 -> 6).  Values are clamped to +-65504 when the
+// atlas is packed; relative texel error <= 2^-11.
+typedef unsigned int HalfRowBits __attribute__((ext_vector_type(4), aligned(4)));   // 8 halves = one 16 B load
+DM_HD float half_lo(unsigned w) { unsigned short b = (unsigned short)(w & 0xffffu); _Float16 h; __builtin_memcpy(&h, &b, 2); return (float)h; }
+DM_HD float half_hi(unsigned w) { unsigned short b = (unsigned short)(w >> 16); _Float16 h; __builtin_memcpy(&h, &b, 2); return (float)h; }
+DM_HD F3 cube_fetch_half(const void* __restrict__ tex, long long texel_base, int R, CubeCoord cc) {
+    float x = cc.u * (float)R - 0.5f, y = cc.v * (float)R - 0.5f;
+    float x0 = floorf(x), y0 = floorf(y);
+    float fx = x - x0, fy = y - y0;
+    int P = R + 2;
+    long long idx = texel_base + (long long)(cc.face * P + (int)y0 + 1) * P + (int)x0 + 1;
+    const char* base = (const char*)tex;
+    // texel x0 = words 0,1 (r g | b a), texel x0+1 = words 2,3
+    const HalfRowBits r0 = *reinterpret_cast<const HalfRowBits*>(base + idx * 8);
+    const HalfRowBits r1 = *reinterpret_cast<const HalfRowBits*>(base + (idx + P) * 8);
+    float w00 = (1.f - fx) * (1.f - fy), w10 = fx * (1.f - fy), w01 = (1.f - fx) * fy, w11 = fx * fy;
+    return f3(half_lo(r0.x) * w00 + half_lo(r0.z) * w10 + half_lo(r1.x) * w01 + half_lo(r1.z) * w11,
+              half_hi(r0.x) * w00 + half_hi(r0.z) * w10 + half_hi(r1.x) * w01 + half_hi(r1.z) * w11,
+              half_lo(r0.y) * w00 + half_lo(r0.w) * w10 + half_lo(r1.y) * w01 + half_lo(r1.w) * w11);
 }
 
 DM_HD F3 cube_bilinear(const float4* __restrict__ tex, int R, F3 d) { return cube_fetch(tex, R, cube_coord(d)); }
@@ -144,7 +168,8 @@ DM_HD void shade_eval(const EnvAtlas& A, const MatCfg& M, int env, F3 n, F3 v, c
               0.04f * (1.f - c.metallic) + c.metallic * c.albedo.y,
               0.04f * (1.f - c.metallic) + c.metallic * c.albedo.z);
     c.spec_albedo = f3(c.F0.x * c.fg0 + c.fg1, c.F0.y * c.fg0 + c.fg1, c.F0.z * c.fg0 + c.fg1);
-    c.diff = cube_bilinear(A.diff + (size_t)env * A.diff_env_stride, A.diff_res, n);
+    if (A.half_texels) c.diff = cube_fetch_half(A.diff, (long long)env * A.diff_env_stride, A.diff_res, cube_coord(n));
+    else c.diff = cube_bilinear(A.diff + (size_t)env * A.diff_env_stride, A.diff_res, n);
     {
         float level = mip_level(A, c.roughness, c.dlevel_drough);
         level = fminf(fmaxf(level, 0.f), (float)(A.n_mips - 1));
@@ -152,9 +177,16 @@ DM_HD void shade_eval(const EnvAtlas& A, const MatCfg& M, int env, F3 n, F3 v, c
         int l1 = min(l0 + 1, A.n_mips - 1);
         float f = level - (float)l0;
         const float4* envb = A.spec + (size_t)env * A.spec_env_stride;
+        const long long envt = (long long)env * A.spec_env_stride;
         CubeCoord rc = cube_coord(refl);
-        F3 s0 = cube_fetch(envb + A.mip_off[l0], A.mip_res[l0], rc);
-        F3 s1 = (l1 != l0) ? cube_fetch(envb + A.mip_off[l1], A.mip_res[l1], rc) : s0;
+        F3 s0, s1;
+        if (A.half_texels) {
+            s0 = cube_fetch_half(A.spec, envt + A.mip_off[l0], A.mip_res[l0], rc);
+            s1 = (l1 != l0) ? cube_fetch_half(A.spec, envt + A.mip_off[l1], A.mip_res[l1], rc) : s0;
+        } else {
+            s0 = cube_fetch(envb + A.mip_off[l0], A.mip_res[l0], rc);
+            s1 = (l1 != l0) ? cube_fetch(envb + A.mip_off[l1], A.mip_res[l1], rc) : s0;
+        }
         c.spec = s0 * (1.f - f) + s1 * f;
         c.dspec_dlevel = s1 - s0;
     }

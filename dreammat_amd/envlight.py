@@ -184,8 +184,13 @@ def _pad_faces(cube):
 class EnvAtlas:
     """All environment maps of a DreamMatMaterial, pre-filtered and packed for the shade kernel."""
 
-    def __init__(self, latlongs, scale=1.0, min_res=16, max_res=128, fg_lut=None, device="cpu"):
+    def __init__(self, latlongs, scale=1.0, min_res=16, max_res=128, fg_lut=None, device="cpu", texel=None):
         self.device = torch.device(device)
+        # texel storage of the packed cube maps: "fp32" (default) or "fp16" (opt-in, DREAMMAT_ATLAS=fp16: one 16 B load
+        # per bilinear row in the shade kernels, values clamped to +-65504, relative texel error <= 2^-11)
+        self.texel = texel or os.environ.get("DREAMMAT_ATLAS", "fp32")
+        if self.texel not in ("fp32", "fp16"):
+            raise ValueError(f"atlas texel format {self.texel!r}: expected fp32 | fp16")
         self.n_env = len(latlongs)
         spec_all, diff_all = [], []
         self.mip_res = []
@@ -222,6 +227,9 @@ class EnvAtlas:
         self.diff_res = self.diffuse[0].shape[1]
         self.diff_packed = torch.stack([_pad_faces(d).reshape(-1, 4) for d in self.diffuse]).contiguous()
         self.diff_env_stride = self.diff_packed.shape[1]
+        if self.texel == "fp16":
+            self.spec_packed = self.spec_packed.clamp(-65504.0, 65504.0).half().contiguous()
+            self.diff_packed = self.diff_packed.clamp(-65504.0, 65504.0).half().contiguous()
         s = _lib.EnvAtlasStruct()
         s.spec = self.spec_packed.data_ptr()
         s.diff = self.diff_packed.data_ptr()
@@ -236,6 +244,7 @@ class EnvAtlas:
         s.lut_res = self.fg_lut.shape[0]
         s.min_rough_mip = MIN_ROUGHNESS
         s.max_rough_mip = MAX_ROUGHNESS
+        s.texel_fp16 = 1 if self.texel == "fp16" else 0
         self.struct = s
 
     def to(self, device):

@@ -126,6 +126,7 @@ typedef struct dm_env_atlas {
     int mip_res[8];
     int n_mips, diff_res, lut_res;
     float min_rough_mip, max_rough_mip; /* envlight's 0.08 / 0.5 */
+    int texel_fp16;            /* 0: spec / diff texels are RGBA fp32 (default); 1: RGBA fp16, 8 B per texel (opt-in) */
 } dm_env_atlas;
 typedef struct dm_mat_cfg { float min_metallic, max_metallic, min_roughness, max_roughness; } dm_mat_cfg;
 

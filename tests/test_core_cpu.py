@@ -137,6 +137,36 @@ def test_shade_core_vs_oracle(hostemu, env_pair):
     assert np.abs(dfeat - g).max() < 1e-4 * np.abs(g).max()
 
 
+def test_shade_core_fp16_atlas_stays_inside_the_parity_budget(hostemu, env_pair):
+    """opt-in atlas format (DREAMMAT_ATLAS=fp16: RGBA fp16 texels, one 16-byte load per bilinear row): the shaded colour
+    stays within the north-star's 1e-3 relative budget of the fp32 oracle, and the default atlas is untouched."""
+    lat, fg, atlas, oenvs = env_pair
+    assert atlas.texel == "fp32" and atlas.struct.texel_fp16 == 0 and atlas.spec_packed.dtype == torch.float32
+    half = penv.EnvAtlas(lat, scale=2.0, min_res=8, max_res=32, fg_lut=fg, texel="fp16")
+    assert half.struct.texel_fp16 == 1 and half.spec_packed.dtype == torch.float16 and half.diff_packed.dtype == torch.float16
+    assert half.spec_packed.shape == atlas.spec_packed.shape
+    torch.manual_seed(1)
+    N = 20000
+    n = torch.nn.functional.normalize(torch.randn(N, 3), dim=-1)
+    v = torch.nn.functional.normalize(n + 0.8 * torch.randn(N, 3), dim=-1)
+    feat = (torch.randn(N, 5) * 1.5).requires_grad_()
+    env = torch.randint(0, 2, (N,))
+    out, _ = oshade.material_forward(feat, feat.detach() + 0.1, v, n, oenvs, env, fg)
+    dcol = torch.randn(N, 3)
+    (out["color"] * dcol).sum().backward()
+    color = np.empty((N, 3), np.float32); dbg = np.empty((N, 17), np.float32); dfeat = np.empty((N, 5), np.float32)
+    mat = np.array([0.0, 0.9, 0.1, 0.95], np.float32)
+    arrs = [np.ascontiguousarray(t.detach().numpy()) for t in (n, v, feat, dcol)]
+    ee = env.numpy().astype(np.int32)
+    hostemu.emu_shade(ctypes.byref(half.struct), P(mat), P(arrs[0]), P(arrs[1]), P(arrs[2]), P(ee),
+                      ctypes.c_longlong(N), P(color), P(dbg), P(arrs[3]), P(dfeat))
+    oc = out["color"].detach().numpy()
+    err = np.abs(color - oc).max()
+    assert 1e-7 < err < 1e-3 * max(1.0, np.abs(oc).max()), err            # different from fp32, inside the budget
+    g = feat.grad.numpy()
+    assert np.abs(dfeat - g).max() < 2e-3 * np.abs(g).max()
+
+
 def test_white_furnace():
     """constant env L, albedo=1, metallic=0 -> color = L_d + (0.04 fg0 + fg1) L_s."""
     env = oenv.EnvLight(torch.full((16, 32, 3), 0.2), min_res=8, max_res=16)

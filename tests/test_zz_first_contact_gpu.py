@@ -134,3 +134,36 @@ def test_condition_map_producer_vs_oracle_composition():
     assert fgpix[:, 0].min() >= 0.3 - 1e-6 and fgpix[:, 0].max() <= 1 + 1e-6 and (cond[~mask][:, 4:] == 0).all()
     assert (cond[~mask][:, 1:4] - torch.tensor([0.5, 0.5, 1.0])).abs().max() == 0
     assert (fgpix[:, 4:7] - fgpix[:, 10:13]).abs().max() > 0.02             # the probes do look different
+
+
+def test_shade_kernels_with_the_fp16_atlas():
+    """opt-in DREAMMAT_ATLAS=fp16 (RGBA fp16 texels: 6 instead of 12 cube-map gathers per pixel): forward within the 1e-3
+    budget of the fp32 oracle, backward within 2e-3; CPU-checked through tests/hostemu, first GPU contact here."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    from dreammat_amd import _lib, envlight as penv, hipops
+    from oracle import envlight as oenv, shading as oshade
+    from tests import util
+    dev = torch.device("cuda:0")
+    lat = [util.synthetic_latlong(i) * 0.02 for i in range(3)]
+    fg = penv.approx_fg_lut()
+    oenvs = [oenv.EnvLight(l, scale=2.0, min_res=8, max_res=32) for l in lat]
+    atlas = penv.EnvAtlas(lat, scale=2.0, min_res=8, max_res=32, fg_lut=fg, device=dev, texel="fp16")
+    assert atlas.spec_packed.dtype == torch.float16
+    torch.manual_seed(0)
+    N, HW = 30000, 10000
+    n = torch.nn.functional.normalize(torch.randn(N, 3), dim=-1)
+    v = torch.nn.functional.normalize(n + 0.8 * torch.randn(N, 3), dim=-1)
+    feat = (torch.randn(N, 5) * 1.5).requires_grad_()
+    pix = torch.randint(0, 3 * HW, (N,), dtype=torch.int32)
+    env_of_view = torch.tensor([2, 0, 1], dtype=torch.int32)
+    ref, _ = oshade.material_forward(feat, feat.detach() + 0.1, v, n, oenvs, env_of_view[(pix // HW).long()].long(), fg)
+    dcol = torch.randn(N, 3)
+    (ref["color"] * dcol).sum().backward()
+    fg_ = feat.detach().to(dev).requires_grad_()
+    mat = _lib.MatCfgStruct(0.0, 0.9, 0.1, 0.95)
+    out = hipops.shade(fg_, n.to(dev), v.to(dev), pix.to(dev), torch.full((1,), N, dtype=torch.int32, device=dev),
+                       env_of_view.to(dev), atlas, mat, HW, False)
+    (out[0] * dcol.to(dev)).sum().backward()
+    assert (out[0].detach().cpu() - ref["color"].detach()).abs().max() < 1e-3
+    assert (fg_.grad.cpu() - feat.grad).abs().max() < 2e-3 * feat.grad.abs().max()
