@@ -203,7 +203,9 @@ def attention_core(q, k, v_weight, v_bias, kv_src, heads, kv_len):
     otherwise plain fp32-style math (autograd-capable)."""
     B, Sq, C = q.shape
     D = C // heads
-    if q.is_cuda and q.dtype == torch.bfloat16:
+    needs_grad = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or kv_src.requires_grad
+                                              or v_weight.requires_grad)
+    if q.is_cuda and q.dtype == torch.bfloat16 and not needs_grad:     # the MFMA kernel is forward-only
         if kv_src.shape[1] % 8:                                       # V^T rows must be 16 B multiples
             kv_src = F.pad(kv_src, (0, 0, 0, (-kv_src.shape[1]) % 8))
         vt = torch.matmul(v_weight, kv_src.transpose(1, 2))           # [B, C, Skv_pad]: V^T for free

@@ -102,3 +102,57 @@ def test_guidance_call_matches_oracle_sds(tmp_path, monkeypatch):
     e3 = torch.cat([gd._last["e_text"], gd._last["e_uncond"], gd._last["e_null"]])
     assert (e3 - eps).abs().max() <= 1e-3 * eps.abs().max()
     assert (rgb.grad - rgb2.grad).abs().max() <= 1e-3 * rgb2.grad.abs().max()
+
+
+def test_controlnet_training_step_and_cfg_dropout():
+    """the ControlNet training loss / step of controlnet_train/diffusers_train_controlnet.py:858-915 on
+    the tiny architecture -- zero-initialised ControlNet == plain UNet prediction, only ControlNet parameters receive
+    gradients (frozen UNet / VAE), the loss goes down on a fixed batch, and the dataset's CFG dropout rates."""
+    from dreammat_amd import controlnet_train as ct
+    from dreammat_amd.sd import ARCHS, AutoencoderKLEncoder, UNet2DConditionModel
+    from dreammat_amd.sd.layers import PaddedContext
+    torch.manual_seed(0)
+    a = ARCHS["tiny"]
+    unet, vae = UNet2DConditionModel(a), AutoencoderKLEncoder(a)
+    tr = ct.ControlNetTrainer(vae, unet, lr=2e-3)
+    assert all(not p.requires_grad for p in list(unet.parameters()) + list(vae.parameters()))
+    assert all(p.requires_grad for p in tr.controlnet.parameters())
+    g = torch.Generator().manual_seed(1)
+    B = 2
+    img = torch.rand(B, 3, 64, 64, generator=g) * 2 - 1
+    cond = torch.rand(B, 22, 64, 64, generator=g)
+    text = torch.randn(B, 77, a.cross_dim, generator=g)
+    t = torch.tensor([300, 700])
+    noise = torch.randn(B, 4, 8, 8, generator=g)
+    pn = torch.randn(B, 4, 8, 8, generator=g)
+    fixed = dict(timesteps=t, noise=noise, posterior_noise=pn)
+    # zero convs: the ControlNet contributes nothing at initialisation
+    loss0 = ct.controlnet_training_loss(vae, unet, tr.controlnet, tr.scheduler, img, cond, text, **fixed)
+    with torch.no_grad():
+        lat = vae.sample(img, pn) * vae.scaling_factor
+        noisy = tr.scheduler.add_noise(lat, noise, t)
+        plain = unet(noisy, t, PaddedContext(text))
+    assert abs(float(loss0) - float(torch.nn.functional.mse_loss(plain, noise))) < 1e-6
+    loss0.backward()
+    assert all(p.grad is None for p in unet.parameters())
+    got = [n for n, p in tr.controlnet.named_parameters() if p.grad is not None and p.grad.abs().sum() > 0]
+    assert any(n.startswith("controlnet_down_blocks") for n in got) and any(n.startswith("controlnet_mid_block") for n in got)
+    tr.opt.zero_grad(set_to_none=True)
+    losses = [float(tr.step(img, cond, text, **fixed)) for _ in range(12)]
+    assert losses[-1] < losses[0] and tr.global_step == 12
+    assert set(tr.state_dict()) == set(tr.controlnet.state_dict())
+    # CFG dropout of the dataset: 5 % all conditions, 5 % depth, 5 % normal, 5 % light maps, 30 % empty prompt
+    n = 40000
+    te, ne = torch.ones(n, 1, 1), torch.zeros(1, 1, 1)
+    cd = torch.ones(n, 22, 1, 1)
+    t2, c2 = ct.cfg_dropout(te, ne, cd, torch.Generator().manual_seed(3))
+    z = (c2[:, :, 0, 0] == 0)
+    all0 = z.all(1)
+    depth0 = z[:, 0] & ~z[:, 1] & ~z[:, 4]
+    normal0 = ~z[:, 0] & z[:, 1:4].all(1) & ~z[:, 4]
+    light0 = ~z[:, 0] & ~z[:, 1] & z[:, 4:].all(1)
+    for m in (all0, depth0, normal0, light0):
+        assert abs(float(m.float().mean()) - 0.05) < 0.006
+    assert int((z.any(1) & ~(all0 | depth0 | normal0 | light0)).sum()) == 0
+    dt = (t2.view(-1) == 0)
+    assert abs(float(dt.float().mean()) - 0.30) < 0.01 and int((dt & z.any(1)).sum()) == 0   # never both
