@@ -62,11 +62,11 @@ def system_config(a, views_per_rank):
                      "n_envs": 5},
         "guidance": {"use_controlnet": True, "control_types": ["light"], "condition_scales": [1.0],
                      "condition_scales_anneal": [0.8], "control_anneal_start_step": 700, "width": a.res,
-                     "height": a.res, "pretrained_model_name_or_path": a.sd, "cond_scale": 1.05,
+                     "height": a.res, "pretrained_model_name_or_path": a.sd, "synthetic": True, "cond_scale": 1.05,
                      "uncond_scale": [0, -1.0, -0.5, 2000], "null_scale": [0, 0.0, -0.5, 2000], "noise_scale": 0.0,
                      "min_step_percent": [500, 0.2, 0.02, 501], "max_step_percent": [500, 0.8, 0.5, 501]},
         "prompt_processor": {"prompt": "a DSLR photo of a ceramic vase", "negative_prompt": "ugly, low resolution",
-                             "pretrained_model_name_or_path": a.sd,
+                             "pretrained_model_name_or_path": a.sd, "synthetic": True,
                              # shared by all ranks of one job (rank 0 writes, the others read after the barrier)
                              "cache_dir": os.path.join("/tmp", f"dm_text_cache_{os.environ.get('MASTER_PORT', os.getpid())}")},
         "loss": {"lambda_sds": 1.0, "lambda_mat_reg": 1.0},
@@ -226,7 +226,8 @@ def main():
     dm.setup("fit")
     system.on_fit_start()
     system.configure_optimizers()
-    trainer = Trainer(system, dm, max_steps=10 ** 9)
+    trainer = Trainer(system, dm, max_steps=10 ** 9, seed=0)
+    trainer.seed_rank_streams()   # parameters are identical (seed 0 build + rank-0 broadcast); t / noise / jitter are per rank
     total = a.warmup + a.steps
     batches = [to_device(dm.train_dataset.collate(), dev) for _ in range(total)]     # resident in HBM
     torch.cuda.synchronize()

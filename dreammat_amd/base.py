@@ -82,7 +82,12 @@ class BaseModule(nn.Module, Updateable):
             path, module_name = self.cfg.weights.split(":")
             ckpt = torch.load(path, map_location="cpu")
             sd = {k[len(module_name) + 1:]: v for k, v in ckpt["state_dict"].items() if k.startswith(module_name + ".")}
-            self.load_state_dict(sd)
+            # reference checkpoints carry keys this repo does not instantiate (the never-used predictor heads of
+            # dreammat_mesh.py:136-139, inner-light MLPs): skipped and reported, like Trainer.load_checkpoint
+            res = self.load_state_dict(sd, strict=False)
+            if res.missing_keys or res.unexpected_keys:
+                print(f"[dreammat_amd] weights '{self.cfg.weights}': missing {list(res.missing_keys)}, "
+                      f"ignored {list(res.unexpected_keys)}")
             self.do_update_step(ckpt.get("epoch", 0), ckpt.get("global_step", 0), on_load_weights=True)
         self._dummy: torch.Tensor
         self.register_buffer("_dummy", torch.zeros(0).float(), persistent=False)

@@ -160,11 +160,13 @@ class DreamMatMesh(BaseModule):
         self.register_buffer("v_buffer", m.v_pos)
         self.register_buffer("t_buffer", m.t_pos_idx)
         self.register_buffer("vnrm_buffer", m.v_nrm)
+        if m.v_tex is not None:       # dreammat_mesh.py:211-214: the exporter rasterizes in UV space on the device
+            self.register_buffer("vtex_buffer", m.v_tex.contiguous())
         return m
 
     def isosurface(self):
         # buffers follow .to(device); rebuild the view lazily (dreammat_mesh.py:230-237)
-        m = meshlib.Mesh(self.v_buffer, self.t_buffer, self.vnrm_buffer, self.mesh.v_tex)
+        m = meshlib.Mesh(self.v_buffer, self.t_buffer, self.vnrm_buffer, getattr(self, "vtex_buffer", None))
         return m
 
     def forward(self, points, output_normal: bool = False):

@@ -61,6 +61,9 @@ class StableDiffusionLightGuidance(BaseObject):
         # additions: compute dtype on the accelerator and the init seed used when no weights are on disk
         weights_dtype: str = "bfloat16"
         synthetic_seed: int = 1234
+        # seeded random UNet / VAE / ControlNet when no checkpoint is on disk: allowed only when asked for (bench, tests;
+        # the 'tiny*' architectures have no checkpoints at all) -- a 30k-step run on random nets must not start silently
+        synthetic: bool = False
 
     cfg: Config
 
@@ -98,6 +101,12 @@ class StableDiffusionLightGuidance(BaseObject):
                 self.real_weights["controlnet"] = loaded
                 self.controlnets.append(cn)
         torch.random.set_rng_state(gen_state)
+        missing = [k for k, ok in self.real_weights.items() if not ok]
+        if missing and not (self.cfg.synthetic or self.cfg.pretrained_model_name_or_path.lower().startswith("tiny")):
+            raise FileNotFoundError(
+                f"no checkpoint found for {missing} (pretrained_model_name_or_path='{self.cfg.pretrained_model_name_or_path}', "
+                f"cache_dir='{self.cfg.cache_dir}', controlnet_path='{getattr(self.cfg, 'controlnet_path', None)}', "
+                f"$DREAMMAT_SD_DIR); set guidance.synthetic=true to run on seeded random weights (benchmark / test mode)")
         for m in [self.vae, self.unet] + self.controlnets:
             m.to(device=self.device, dtype=self.weights_dtype).eval()
             for p in m.parameters():

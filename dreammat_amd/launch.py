@@ -1,7 +1,9 @@
 """CLI entry (threestudio_dreammat/launch.py:42-246 without Lightning):
     python -m dreammat_amd.launch --config configs/dreammat.yaml --train system.prompt_processor.prompt="a chair" ...
 One process per GPU; under torchrun the RANK/LOCAL_RANK/WORLD_SIZE env is honoured and gradients are
-all-reduced over RCCL.  Seeds: cfg.seed + rank (launch.py:102)."""
+all-reduced over RCCL.  Seeding (reference launch.py:102 + Lightning DDP): the system is BUILT under the
+rank-independent cfg.seed (hash-grid table and MLP initialisers draw from the global RNG) and rank 0's parameters are
+broadcast in `configure_optimizers`; only then does each rank switch to `cfg.seed + rank` for its per-step draws."""
 import argparse
 import os
 
@@ -9,9 +11,16 @@ import torch
 import torch.distributed as dist
 
 import dreammat_amd
-from .base import get_local_rank, get_rank
+from .base import barrier, get_local_rank, get_rank
 from .config import load_config
 from .system import Trainer
+
+
+def seed_for_build(seed):
+    """Rank-INDEPENDENT seed for everything that initialises parameters or shared tables."""
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
 
 
 def main(argv=None):
@@ -32,7 +41,8 @@ def main(argv=None):
         torch.cuda.set_device(get_local_rank())
         dist.init_process_group("nccl")
     rank = get_rank()
-    torch.manual_seed(cfg.get("seed", 0) + rank)
+    seed = int(cfg.get("seed", 0))
+    seed_for_build(seed)
     dreammat_amd._import_plugins()
     system = dreammat_amd.find(cfg["system_type"])(cfg["system"])
     data_cfg = dict(cfg.get("data", {}))
@@ -44,26 +54,26 @@ def main(argv=None):
     trial_dir = os.path.join(cfg.get("exp_root_dir", "outputs"), cfg.get("name", "dream_mat"), str(cfg.get("tag", "run")))
     trainer = Trainer(system, dm, max_steps=tr.get("max_steps", 30000), trial_dir=trial_dir,
                       val_check_interval=tr.get("val_check_interval", 100),
-                      checkpoint_every=ck.get("every_n_train_steps", 3999), resume=cfg.get("resume"))
+                      checkpoint_every=ck.get("every_n_train_steps", 3999), resume=cfg.get("resume"), seed=seed)
     if args.train:
         trainer.fit()
-        trainer.test()
-    elif args.validate:
-        system.configure_optimizers()
-        if cfg.get("resume"):
-            trainer.load_checkpoint(cfg["resume"])
-        trainer.validate()
-    elif args.export:
-        system.configure_optimizers()
-        if cfg.get("resume"):
-            trainer.load_checkpoint(cfg["resume"])
-        for p in trainer.export():
-            print("[dreammat_amd] wrote", p)
+        if rank == 0:                 # every rank holds the same model: one writer for the test renders
+            trainer.test()
     else:
-        system.configure_optimizers()
+        system.configure_optimizers()                 # all ranks: it contains the parameter broadcast
         if cfg.get("resume"):
             trainer.load_checkpoint(cfg["resume"])
-        trainer.test()
+        if rank == 0:                 # validate / export / test are single-writer jobs
+            if args.validate:
+                trainer.validate()
+            elif args.export:
+                for p in trainer.export():
+                    print("[dreammat_amd] wrote", p)
+            else:
+                trainer.test()
+    barrier()
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -80,11 +80,12 @@ def load_obj(path):
 
 
 def normalize_mesh(mesh, scale):
-    """dreammat_mesh.py:163-199: centre the bbox at the origin and scale the longest half-extent to `scale`."""
+    """dreammat_mesh.py:161-193: subtract the vertex CENTROID (`vertices.mean(0)`, not the bbox centre) and divide by
+    the largest absolute coordinate, then multiply by `shape_init_params`.  The reference hands this normalised mesh
+    to Blender for the pre-rendered condition maps, so any other convention misaligns `condition_source: prerender`."""
     v = mesh.v_pos
-    lo, hi = v.min(0).values, v.max(0).values
-    v = v - (lo + hi) / 2
-    v = v / (hi - lo).max() * 2.0 * scale
+    v = v - v.mean(0, keepdim=True)
+    v = v / v.abs().max() * scale
     mesh.v_pos = v.contiguous()
     return mesh
 

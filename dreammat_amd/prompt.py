@@ -85,6 +85,10 @@ class StableDiffusionPromptProcessor(BaseObject):
         spawn: bool = True
         use_perp_neg: bool = False
         cache_dir: str = ".threestudio_cache/text_embeddings"
+        # addition: md5-seeded pseudo embeddings when the CLIP text encoder is not on disk.  Off by default: a run with
+        # a real model name and no encoder is an error, not a silent stand-in ('tiny*' architectures are synthetic by
+        # definition).  Synthetic embeddings are cached under their own suffix and never read back as real ones.
+        synthetic: bool = False
 
     cfg: Config
 
@@ -129,6 +133,11 @@ class StableDiffusionPromptProcessor(BaseObject):
     def _encode(self, prompts):
         root = self._model_dir()
         if root is None:
+            if not self._synthetic_allowed():
+                raise FileNotFoundError(
+                    f"CLIP text encoder for '{self.cfg.pretrained_model_name_or_path}' not found under "
+                    f"'{self.cfg.pretrained_model_cache_dir}' or $DREAMMAT_SD_DIR; set prompt_processor.synthetic=true to "
+                    f"run on md5-seeded pseudo embeddings (benchmark / test mode)")
             print("[dreammat_amd] CLIP text encoder not found: using md5-seeded pseudo text embeddings (synthetic mode)")
             outs = []
             for p in prompts:
@@ -144,23 +153,29 @@ class StableDiffusionPromptProcessor(BaseObject):
         del enc
         return emb.float().cpu()
 
+    def _synthetic_allowed(self):
+        return bool(self.cfg.synthetic) or self.cfg.pretrained_model_name_or_path.lower().startswith("tiny")
+
+    def _cache_path(self, p):
+        suffix = ".pt" if self._model_dir() is not None else ".synthetic.pt"
+        return os.path.join(self.cfg.cache_dir, hash_prompt(self.cfg.pretrained_model_name_or_path, p) + suffix)
+
     def prepare_text_embeddings(self):
         os.makedirs(self.cfg.cache_dir, exist_ok=True)
         all_prompts = [self.prompt, self.negative_prompt, ""] + self.prompts_vd + self.negative_prompts_vd
         todo = []
         for p in dict.fromkeys(all_prompts):
-            path = os.path.join(self.cfg.cache_dir, hash_prompt(self.cfg.pretrained_model_name_or_path, p) + ".pt")
+            path = self._cache_path(p)
             if not (self.cfg.use_cache and os.path.exists(path)):
                 todo.append(p)
         if todo and get_rank() == 0:
             emb = self._encode(todo)
             for p, e in zip(todo, emb):
-                torch.save(e, os.path.join(self.cfg.cache_dir, hash_prompt(self.cfg.pretrained_model_name_or_path, p) + ".pt"))
+                torch.save(e, self._cache_path(p))
         barrier()   # other ranks wait for rank 0's cache (base.py:416)
 
     def _load(self, p):
-        path = os.path.join(self.cfg.cache_dir, hash_prompt(self.cfg.pretrained_model_name_or_path, p) + ".pt")
-        return torch.load(path, map_location=self.device)
+        return torch.load(self._cache_path(p), map_location=self.device)
 
     def load_text_embeddings(self):
         self.text_embeddings = self._load(self.prompt)[None]

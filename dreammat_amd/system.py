@@ -53,6 +53,28 @@ def allreduce_sum_(flat_grad):
     return 1
 
 
+def sync_parameters_(flat):
+    """Replica start-up: every rank adopts rank 0's parameters (what Lightning's DDP wrapper does when it wraps the
+    module, threestudio_dreammat/launch.py:172-179).  Construction is already seeded rank-independently
+    (launch.seed_for_build), so this is a guard against any non-deterministic initialiser, not the mechanism."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(flat, src=0)
+    return flat
+
+
+def replicas_in_sync(flat):
+    """True when every rank holds bit-identical parameters (one 2-float all-reduce; used by tests and by
+    DREAMMAT_CHECK_REPLICAS=1 every checkpoint interval)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return True
+    c = flat.double()
+    sig = torch.stack([c.sum(), (c * torch.arange(1, c.numel() + 1, device=c.device, dtype=c.dtype)).sum()])
+    lo, hi = sig.clone(), sig.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return bool(torch.equal(lo, hi))
+
+
 class FusedAdam:
     """torch.optim.Adam(lr, betas, eps) semantics (systems/utils.py:34-53; dreammat.yaml:110-115)."""
 
@@ -144,6 +166,7 @@ class DreamMat(nn.Module, Updateable):
         if opt.get("name", "Adam") != "Adam":
             raise NotImplementedError("only the Adam of dreammat.yaml:110-115 is implemented (fused HIP kernel)")
         self.flat = FlatParams(list(self.parameters()))
+        sync_parameters_(self.flat.flat)
         args = opt.get("args", {})
         self.optimizer = FusedAdam(self.flat, lr=args.get("lr", 0.01), betas=args.get("betas", (0.9, 0.99)),
                                    eps=args.get("eps", 1e-15))
@@ -189,8 +212,9 @@ class Trainer:
     (every_n_train_steps, dreammat.yaml:125-128) and rank-0 CSV metrics + PNG grids."""
 
     def __init__(self, system: DreamMat, datamodule, max_steps=30000, trial_dir="outputs/dream_mat/run",
-                 val_check_interval=100, checkpoint_every=3999, log_every=1, resume=None):
+                 val_check_interval=100, checkpoint_every=3999, log_every=1, resume=None, seed=0):
         self.system, self.dm = system, datamodule
+        self.seed = seed
         self.max_steps, self.trial_dir = max_steps, trial_dir
         self.val_check_interval, self.checkpoint_every, self.log_every = val_check_interval, checkpoint_every, log_every
         self.resume = resume
@@ -214,6 +238,14 @@ class Trainer:
         s.optimizer.load_state_dict(ck["optimizer"])
         s.true_global_step, s.true_current_epoch = ck["global_step"], ck["epoch"]
 
+    def seed_rank_streams(self):
+        """threestudio_dreammat/launch.py:102 `pl.seed_everything(cfg.seed + get_rank())`: the parameters are identical
+        on every rank (seed_for_build + sync_parameters_), the per-step draws (timestep t, noise, VAE posterior noise,
+        tangent jitter; the view draws have their own per-rank generator in data.py) must NOT be."""
+        torch.manual_seed(self.seed + self.rank)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed(self.seed + self.rank)
+
     def train_one_step(self, batch=None, rng=None):
         s = self.system
         s.do_update()
@@ -233,6 +265,7 @@ class Trainer:
         s.configure_optimizers()
         if self.resume:
             self.load_checkpoint(self.resume)
+        self.seed_rank_streams()
         if self.rank == 0:
             os.makedirs(os.path.join(self.trial_dir, "ckpts"), exist_ok=True)
             self.csv = open(os.path.join(self.trial_dir, "metrics.csv"), "a")
@@ -249,6 +282,8 @@ class Trainer:
                 self.save_checkpoint(os.path.join(self.trial_dir, "ckpts", f"step={step}.ckpt"))
             if self.rank == 0 and self.val_check_interval and step % self.val_check_interval == 0:
                 self.validate()
+            if self.checkpoint_every and step % self.checkpoint_every == 0 and os.environ.get("DREAMMAT_CHECK_REPLICAS"):
+                assert replicas_in_sync(s.flat.flat), f"replicas diverged by step {step}"
         return s
 
     @torch.no_grad()

@@ -59,3 +59,106 @@ def test_two_rank_sharding_and_flat_allreduce(tmp_path):
     q = torch.randn(1000)
     q = q - (0.01 / (1 - 0.9)) * (m / (v.sqrt() / (1 - 0.99) ** 0.5 + 1e-15))
     assert torch.allclose(q, p.detach(), atol=1e-6)
+
+
+# ---- replica start-up and per-rank streams through the launcher's own code path (launch.seed_for_build ->
+#      configure_optimizers -> sync_parameters_ -> Trainer.fit -> seed_rank_streams -> train_one_step x N)
+class _CpuAdam:
+    """torch.optim.Adam semantics with the mean folded in (what dm_adam_step does on the GPU)."""
+
+    def __init__(self, fp):
+        self.fp, self.m, self.v, self.t = fp, torch.zeros_like(fp.flat), torch.zeros_like(fp.flat), 0
+
+    def step(self, world=1):
+        self.t += 1
+        g = self.fp.grad / world
+        self.m.mul_(0.9).add_(g, alpha=0.1)
+        self.v.mul_(0.99).addcmul_(g, g, value=0.01)
+        mh, vh = self.m / (1 - 0.9 ** self.t), self.v / (1 - 0.99 ** self.t)
+        self.fp.flat.sub_(0.01 * mh / (vh.sqrt() + 1e-15))
+        self.fp.grad.zero_()
+
+
+def _stub_system(build_seed_offset=0):
+    """A CPU stand-in for DreamMat with the REAL initialisers of dreammat_amd/geometry.py (hash table U(-1e-4,1e-4) and
+    the bias-free MLP, both drawing from the global RNG) and the real FlatParams / sync_parameters_ / Trainer; only the
+    HIP kernels (render, nets, fused Adam) are replaced by a toy loss and a CPU Adam."""
+    import torch.nn as nn
+    from dreammat_amd.geometry import HashGridEncoding, VanillaMLP
+    from dreammat_amd.system import FlatParams, sync_parameters_
+
+    class Stub(nn.Module):
+        def __init__(self):
+            super().__init__()
+            enc = {"otype": "HashGrid", "n_levels": 4, "n_features_per_level": 2, "log2_hashmap_size": 10,
+                   "base_resolution": 4, "per_level_scale": 1.5}
+            self.encoding = HashGridEncoding(3, enc)
+            self.feature_network = VanillaMLP(self.encoding.n_output_dims, 5, {"n_neurons": 16, "n_hidden_layers": 1})
+            self.device_ = torch.device("cpu")
+            self.true_global_step = self.true_current_epoch = 0
+            self.draws = []
+
+        def on_fit_start(self):
+            pass
+
+        def do_update(self):
+            pass
+
+        def configure_optimizers(self):
+            self.flat = FlatParams(list(self.parameters()))
+            sync_parameters_(self.flat.flat)
+            self.optimizer = _CpuAdam(self.flat)
+
+        def training_step(self, batch, rng=None):
+            B = batch["azimuth"].shape[0]
+            t = torch.randint(20, 981, [B])                      # guidance.py: the timestep draw
+            noise = torch.randn(B, 8)                            # guidance.py: the noise draw (global RNG as well)
+            self.draws.append((t.clone(), noise.clone()))
+            x = self.feature_network(torch.tanh(self.encoding.encoding.params[:8 * B].view(B, 8)).repeat(1, 1))
+            loss = ((x.sum(-1) - noise.sum(-1)) ** 2 * (1 + t / 1000.0) * torch.cos(batch["azimuth"] * 0.01)).mean()
+            return loss, {"train/loss_sds": loss.detach()}
+    return Stub()
+
+
+def _replica_worker(rank, world, port, out_dir, divergent_build):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dreammat_amd import launch
+    from dreammat_amd.data import RandomCameraDataModule
+    from dreammat_amd.system import Trainer, replicas_in_sync
+    seed = 3
+    # `divergent_build` reproduces round 1's bug (construction under seed + rank): the broadcast alone must repair it
+    launch.seed_for_build(seed + (rank if divergent_build else 0))
+    system = _stub_system()
+    built = torch.cat([p.detach().reshape(-1) for p in system.parameters()]).clone()
+    dm = RandomCameraDataModule(cfg={"height": 8, "width": 8, "batch_size": 2, "use_fix_views": True, "seed": seed}, rank=rank)
+    trainer = Trainer(system, dm, max_steps=4, trial_dir=os.path.join(out_dir, f"trial{rank}"), val_check_interval=0,
+                      checkpoint_every=0, seed=seed)
+    system_params_before = []
+    orig = trainer.train_one_step
+
+    def spy(*a, **k):
+        if not system_params_before:
+            system_params_before.append(system.flat.flat.clone())
+            assert replicas_in_sync(system.flat.flat)
+        return orig(*a, **k)
+    trainer.train_one_step = spy
+    trainer.fit()
+    assert replicas_in_sync(system.flat.flat)
+    torch.save({"built": built, "before": system_params_before[0], "after": system.flat.flat.clone(),
+                "t": torch.stack([d[0] for d in system.draws]), "noise": torch.stack([d[1] for d in system.draws])},
+               os.path.join(out_dir, f"rep{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("divergent_build", [False, True])
+def test_replicas_start_identical_stay_identical_and_draw_different_noise(tmp_path, divergent_build):
+    """ranks were built under seed + rank and never synchronised."""
+    port = _free_port()
+    mp.spawn(_replica_worker, args=(2, port, str(tmp_path), divergent_build), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "rep0.pt"), torch.load(tmp_path / "rep1.pt")
+    assert torch.equal(r0["built"], r1["built"]) == (not divergent_build)     # rank-independent build seed
+    assert torch.equal(r0["before"], r1["before"])                            # (i) identical before step 1 ...
+    assert torch.equal(r0["before"][:r0["built"].numel()], r0["built"])       #     ... and they are rank 0's
+    assert torch.equal(r0["after"], r1["after"]) and not torch.equal(r0["after"], r0["before"])   # ... and after N
+    assert not torch.equal(r0["t"], r1["t"]) and not torch.equal(r0["noise"], r1["noise"])       # (ii) per-rank draws

@@ -254,3 +254,82 @@ def test_mesh_exporter_bakes_textures_and_writes_obj_mtl(monkeypatch, tmp_path):
     with pytest.raises(NotImplementedError):
         ex()
     assert "mesh-exporter" in dreammat_amd.__modules__ or dreammat_amd.find("mesh-exporter") is MeshExporter
+
+
+def test_normalize_mesh_follows_the_reference_on_an_asymmetric_mesh(tmp_path):
+    """dreammat_mesh.py:161-193 subtracts the vertex centroid and divides by the largest absolute
+    coordinate (NOT bbox centre / longest extent); restated here in numpy on an L-shaped, off-centre OBJ."""
+    import numpy as np
+    import dreammat_amd
+    from dreammat_amd import mesh as pmesh
+    obj = tmp_path / "ell.obj"
+    verts = np.array([[0, 0, 0], [4, 0, 0], [4, 1, 0], [1, 1, 0], [1, 3, 0], [0, 3, 0], [0, 0, 2.5], [4, 0, 0.5]], dtype=np.float64) + [10, -2, 1]
+    faces = [[1, 2, 3], [1, 3, 4], [1, 4, 5], [1, 5, 6], [1, 2, 8], [1, 8, 7]]
+    with open(obj, "w") as fh:
+        for v in verts:
+            fh.write(f"v {v[0]} {v[1]} {v[2]}\n")
+        for k in range(len(verts)):
+            fh.write(f"vt {k / 8.0} {1 - k / 8.0}\n")
+        for f in faces:
+            fh.write("f " + " ".join(f"{i}/{i}" for i in f) + "\n")
+    dreammat_amd._import_plugins()
+    enc = {"otype": "HashGrid", "n_levels": 2, "n_features_per_level": 2, "log2_hashmap_size": 8, "base_resolution": 4,
+           "per_level_scale": 1.5}
+    geo = dreammat_amd.find("dreammat-mesh")({"shape_init": f"mesh:{obj}", "shape_init_params": 0.7, "shape_init_mesh_up": "+y",
+                                              "shape_init_mesh_front": "+z", "pos_encoding_config": enc})
+    # the reference's arithmetic (centroid, abs-max scale, then std2mesh^-1 with z_=up, x_=front)
+    v = verts - verts.mean(0)
+    v = v / np.abs(v).max() * 0.7
+    z_, x_ = np.array([0, 1, 0.0]), np.array([0, 0, 1.0])
+    std2mesh = np.stack([x_, np.cross(z_, x_), z_], 0).T
+    ref = (np.linalg.inv(std2mesh) @ v.T).T
+    got = geo.v_buffer.numpy().astype(np.float64)       # the loader numbers corners by first use in a face: compare as sets
+    key = lambda a: a[np.lexsort(np.round(a, 4).T[::-1])]
+    assert np.abs(key(got) - key(ref)).max() < 1e-6
+    lo, hi = ref.min(0), ref.max(0)
+    assert np.abs((lo + hi) / 2).max() > 0.05            # the bbox centre is NOT at the origin: the two conventions differ
+    assert geo.vtex_buffer.shape == (8, 2)               # registered like the reference's vtex_buffer (device-resident)
+    assert geo.isosurface().v_tex is geo.vtex_buffer
+
+
+def test_missing_weights_are_an_error_unless_synthetic_is_requested(tmp_path, monkeypatch):
+    """pseudo embeddings / random nets must never stand in silently for a real model name, and
+    synthetic embeddings must not land in the cache slot real ones are read from."""
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv("DREAMMAT_SD_DIR", raising=False)
+    from dreammat_amd.prompt import StableDiffusionPromptProcessor
+    real = {"prompt": "a chair", "pretrained_model_name_or_path": "stabilityai/stable-diffusion-2-1-base",
+            "pretrained_model_cache_dir": str(tmp_path / "nope"), "cache_dir": str(tmp_path / "cache")}
+    with pytest.raises(FileNotFoundError):
+        StableDiffusionPromptProcessor(dict(real))
+    pp = StableDiffusionPromptProcessor(dict(real, synthetic=True))
+    files = os.listdir(tmp_path / "cache")
+    assert files and all(f.endswith(".synthetic.pt") for f in files)
+    assert pp.text_embeddings.shape == (1, 77, 1024)
+    from dreammat_amd.sd.models import ARCHS
+    import dreammat_amd.guidance as G
+    monkeypatch.setattr(G, "arch_for", lambda name: ARCHS["tiny"])       # keep the construction small
+    cfg = {"pretrained_model_name_or_path": "stabilityai/stable-diffusion-2-1-base", "use_controlnet": True,
+           "control_types": ["light"], "condition_scales": [1.0], "cache_dir": str(tmp_path / "nope")}
+    with pytest.raises(FileNotFoundError):
+        G.StableDiffusionLightGuidance(dict(cfg))
+    gd = G.StableDiffusionLightGuidance(dict(cfg, synthetic=True))
+    assert gd.real_weights == {"vae": False, "unet": False, "controlnet": False}
+
+
+def test_partial_weight_load_skips_reference_only_keys(tmp_path):
+    """`weights: path:module` must accept a reference checkpoint that carries the predictor
+    heads this repo does not instantiate."""
+    import dreammat_amd
+    dreammat_amd._import_plugins()
+    enc = {"otype": "HashGrid", "n_levels": 2, "n_features_per_level": 2, "log2_hashmap_size": 8, "base_resolution": 4,
+           "per_level_scale": 1.5}
+    cfg = {"shape_init": "quad", "shape_init_params": 1.0, "pos_encoding_config": enc}
+    g0 = dreammat_amd.find("dreammat-mesh")(dict(cfg))
+    with torch.no_grad():
+        g0.encoding.encoding.params.uniform_(-1, 1)
+    sd = {"geometry." + k: v for k, v in g0.state_dict().items()}
+    sd["geometry.albedo_predictor.layers.0.weight"] = torch.zeros(4, 4)   # reference-only head
+    torch.save({"state_dict": sd, "epoch": 0, "global_step": 7}, tmp_path / "ref.ckpt")
+    g1 = dreammat_amd.find("dreammat-mesh")(dict(cfg, weights=f"{tmp_path / 'ref.ckpt'}:geometry"))
+    assert torch.equal(g1.encoding.encoding.params, g0.encoding.encoding.params)

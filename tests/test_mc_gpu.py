@@ -88,3 +88,42 @@ def test_material_plugin_raytracing_branch_runs(dev):
     assert out["color"].shape == (200, 3) and torch.isfinite(out["color"]).all() and 0 <= float(out["color"].min())
     (out["color"].sum() + reg).backward()
     assert torch.isfinite(f.grad).all() and f.grad.abs().sum() > 0
+
+
+@pytest.mark.parametrize("bvh_width", ["2", "4"])
+@pytest.mark.parametrize("variant", ["schlick", "ggx_smith"])
+def test_mc_wave_kernel_matches_the_serial_kernel(variant, bvh_width, monkeypatch):
+    """the opt-in one-wave-per-pixel Monte-Carlo kernel (DREAMMAT_MC_KERNEL=wave; samples over the 64 lanes, ballot hit
+    bits, butterfly reduction) against the validated one-thread-per-pixel kernel; its decomposition is CPU-checked in
+    tests/test_golden_cpu.py."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs the MI355X")
+    import numpy as np
+    from dreammat_amd import _lib, hipops
+    dev = torch.device("cuda:0")
+    g = {k: torch.from_numpy(v) if v.ndim else v
+         for k, v in np.load(os.path.join(os.path.dirname(__file__), "golden", "mc_shading.npz")).items()}
+    bvh = hipops.MeshBvh(g["v_pos"], g["tri"], dev)
+    monkeypatch.delenv("DREAMMAT_BVH", raising=False)
+    scene_ref = hipops.McScene(bvh, [g["light"]], g[f"{variant}_dsamp"].shape[0], g[f"{variant}_ssamp"].shape[0], variant)
+    monkeypatch.setenv("DREAMMAT_BVH", bvh_width)          # "4": trace through the 4-wide collapse of the same tree
+    scene_new = hipops.McScene(bvh, [g["light"]], g[f"{variant}_dsamp"].shape[0], g[f"{variant}_ssamp"].shape[0], variant)
+    assert (scene_new.nodes4 is not None) == (bvh_width == "4")
+    mat = _lib.MatCfgStruct(0.0, 0.9, 0.01, 0.9)
+    N = g["pts"].shape[0]
+    rd, rs = g[f"{variant}_rand_d"].to(dev).contiguous(), g[f"{variant}_rand_s"].to(dev).contiguous()
+
+    def run(scene):
+        feats = g[f"{variant}_feats"].to(dev).requires_grad_()
+        outs = hipops.mc_shade(feats, g["pts"].to(dev), g["nrm"].to(dev), g["view"].to(dev),
+                               torch.zeros(N, dtype=torch.int32, device=dev), torch.full((1,), N, dtype=torch.int32, device=dev),
+                               torch.zeros(1, dtype=torch.int32, device=dev), scene, mat, 1 << 30, rd, rs, True)
+        (outs[0] * g[f"{variant}_wgt"].to(dev)).sum().backward()
+        return [o.detach().cpu() for o in outs], feats.grad.cpu()
+    monkeypatch.delenv("DREAMMAT_MC_KERNEL", raising=False)
+    ref_out, ref_grad = run(scene_ref)
+    monkeypatch.setenv("DREAMMAT_MC_KERNEL", "wave")
+    out, grad = run(scene_new)
+    for a, b in zip(out, ref_out):
+        assert (a - b).abs().max() < 1e-5
+    assert (grad - ref_grad).abs().max() <= 1e-5 * max(1.0, ref_grad.abs().max().item())
