@@ -27,7 +27,8 @@ class EnvAtlasStruct(ctypes.Structure):
                 ("spec_env_stride", c_longlong), ("diff_env_stride", c_longlong),
                 ("mip_off", c_longlong * 8), ("mip_res", c_int * 8),
                 ("n_mips", c_int), ("diff_res", c_int), ("lut_res", c_int),
-                ("min_rough_mip", c_float), ("max_rough_mip", c_float), ("texel_fp16", c_int)]
+                ("min_rough_mip", c_float), ("max_rough_mip", c_float), ("texel_format", c_int),
+                ("fg_pairs", c_void_p)]
 
 
 class MatCfgStruct(ctypes.Structure):

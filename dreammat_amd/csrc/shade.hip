@@ -1,8 +1,10 @@
 // Fused G-buffer -> split-sum PBR shade kernel (forward + backward) for gfx950.
 // One thread per covered pixel; all views of the step in ONE launch.  HBM-bound by design:
 // algorithmic traffic = n(12) + v(12) + features(20) in, colour(12) out = 56 B / covered pixel
-// forward, 76 B backward; LUT / cubemap taps (RGBA fp32, 16 B aligned, 1-texel face borders so a
-// bilinear footprint never branches) are served by L2/MALL.
+// forward, 76 B backward; LUT / cubemap taps (1-texel face borders so a bilinear footprint never branches)
+// are served by L2/MALL.  What bounds the kernel is the number of scattered cache lines per wave the texture
+// address unit visits: 16 gather instructions per pixel with RGBA-fp32 texels and plain LUT taps, 8 with 8-byte
+// texels (one 16 B load per bilinear row) and the FG x-pair table -- see shade_core.h.
 // Reference: threestudio/models/materials/dreammat_material.py:679-711, 746-762.
 #include "shade_core.h"
 
@@ -57,6 +59,7 @@ __device__ __forceinline__ void shade_load(const ShadeArgs& a, long long i, Shad
     in.pix = a.pix_idx[i];
 }
 
+template <int FMT>
 __global__ __launch_bounds__(256) void k_shade_fwd(ShadeArgs a) {
     const long long N = *a.n_dev;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256) void k_shade_fwd(ShadeArgs a) {
         if (more) shade_load<false>(a, i + stride, nxt);
         int env = a.env_of_view[cur.pix / a.HW];
         ShadeCtx c;
-        shade_eval(a.atlas, a.mat, env, cur.n, cur.v, cur.f, c);
+        shade_eval_t<FMT>(a.atlas, a.mat, env, cur.n, cur.v, cur.f, c);
         a.color.p[i * a.color.rs] = sat(c.pre.x);
         a.color.p[i * a.color.rs + a.color.cs] = sat(c.pre.y);
         a.color.p[i * a.color.rs + 2 * a.color.cs] = sat(c.pre.z);
@@ -87,6 +90,7 @@ __global__ __launch_bounds__(256) void k_shade_fwd(ShadeArgs a) {
     }
 }
 
+template <int FMT>
 __global__ __launch_bounds__(256) void k_shade_bwd(ShadeArgs a) {
     const long long N = *a.n_dev;
     const long long stride = (long long)gridDim.x * blockDim.x;
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(256) void k_shade_bwd(ShadeArgs a) {
         if (more) shade_load<true>(a, i + stride, nxt);
         int env = a.env_of_view[cur.pix / a.HW];
         ShadeCtx c;
-        shade_eval(a.atlas, a.mat, env, cur.n, cur.v, cur.f, c);
+        shade_eval_t<FMT>(a.atlas, a.mat, env, cur.n, cur.v, cur.f, c);
         float df[5];
         shade_backward(a.mat, c, cur.dc, df);
 #pragma unroll
@@ -170,7 +174,8 @@ struct dm_env_atlas {
     int mip_res[8];
     int n_mips, diff_res, lut_res;
     float min_rough_mip, max_rough_mip;
-    int texel_fp16;
+    int texel_format;
+    const float* fg_pairs;
 };
 struct dm_mat_cfg { float min_metallic, max_metallic, min_roughness, max_roughness; };
 
@@ -181,7 +186,9 @@ static bool conv_atlas(const dm_env_atlas* in, EnvAtlas& A) {
     for (int i = 0; i < kMaxMips; ++i) { A.mip_off[i] = in->mip_off[i]; A.mip_res[i] = in->mip_res[i]; }
     A.n_mips = in->n_mips; A.diff_res = in->diff_res; A.lut_res = in->lut_res;
     A.min_rough_mip = in->min_rough_mip; A.max_rough_mip = in->max_rough_mip;
-    A.half_texels = in->texel_fp16 ? 1 : 0;
+    if (in->texel_format < 0 || in->texel_format > 2) return false;
+    A.texel_format = in->texel_format;
+    A.fg_pairs = (const float4*)in->fg_pairs;
     return true;
 }
 
@@ -209,7 +216,12 @@ int dm_shade_fwd(const dm_env_atlas* atlas, const dm_mat_cfg* mat, const float* 
     a.spec_color = dbg_spec_color; a.diff_color = dbg_diff_color; a.metallic = dbg_metallic;
     a.roughness = dbg_roughness;
     DM_ENTER();
-    hipLaunchKernelGGL(k_shade_fwd, dim3(shade_blocks(n_max)), dim3(256), 0, stream, a);
+    const dim3 grid(shade_blocks(n_max));
+    switch (a.atlas.texel_format) {
+        case kTexelRgb18e8: hipLaunchKernelGGL(k_shade_fwd<kTexelRgb18e8>, grid, dim3(256), 0, stream, a); break;
+        case kTexelF16: hipLaunchKernelGGL(k_shade_fwd<kTexelF16>, grid, dim3(256), 0, stream, a); break;
+        default: hipLaunchKernelGGL(k_shade_fwd<kTexelF32>, grid, dim3(256), 0, stream, a); break;
+    }
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
@@ -229,7 +241,12 @@ int dm_shade_bwd(const dm_env_atlas* atlas, const dm_mat_cfg* mat, const float* 
     a.dcolor = {dcolor, dcolor_rs, dcolor_cs};
     a.dfeat = {dfeat, dfeat_rs, dfeat_cs};
     DM_ENTER();
-    hipLaunchKernelGGL(k_shade_bwd, dim3(shade_blocks(n_max)), dim3(256), 0, stream, a);
+    const dim3 grid(shade_blocks(n_max));
+    switch (a.atlas.texel_format) {
+        case kTexelRgb18e8: hipLaunchKernelGGL(k_shade_bwd<kTexelRgb18e8>, grid, dim3(256), 0, stream, a); break;
+        case kTexelF16: hipLaunchKernelGGL(k_shade_bwd<kTexelF16>, grid, dim3(256), 0, stream, a); break;
+        default: hipLaunchKernelGGL(k_shade_bwd<kTexelF32>, grid, dim3(256), 0, stream, a); break;
+    }
     DM_LAUNCH_CHECK();
     return DM_OK;
 }

@@ -23,8 +23,12 @@ struct EnvAtlas {
     int diff_res;
     int lut_res;
     float min_rough_mip, max_rough_mip;   // envlight MIN/MAX_ROUGHNESS (0.08, 0.5)
-    int half_texels;             // 1: spec / diff texels are RGBA fp16 (8 B): one 16 B load per bilinear ROW (opt-in)
+    int texel_format;            // spec / diff texels: 0 = RGBA fp32 (16 B), 1 = RGBA fp16 (8 B), 2 = RGB18E8 (8 B, default):
+                                 // with 8-byte texels the two texels of a bilinear ROW are one 16 B load
+    const float4* fg_pairs;      // optional [lut_res][lut_res+1] x-pairs of the FG LUT (see fg_fetch); null = 4 plain taps
 };
+
+enum { kTexelF32 = 0, kTexelF16 = 1, kTexelRgb18e8 = 2 };
 
 struct MatCfg {
     float min_metallic, max_metallic, min_roughness, max_roughness;
@@ -100,6 +104,41 @@ DM_HD F3 cube_fetch_half(const void* __restrict__ tex, long long texel_base, int
               half_lo(r0.y) * w00 + half_lo(r0.w) * w10 + half_lo(r1.y) * w01 + half_lo(r1.w) * w11);
 }
 
+// RGB18E8 atlas: 8-byte texel = three 18-bit mantissas sharing one 8-bit exponent (bits R[0,18) G[18,36) B[36,54) E[54,62);
+// value = mantissa * 2^(E-127)).  Radiance is non-negative, so no sign bits are needed; the largest channel of a texel keeps
+// 18 significant bits (relative error <= 2^-18, the others the same ABSOLUTE error), i.e. fp32-class accuracy at half the
+// bytes and -- the point -- half the gather instructions of RGBA fp32: the shade kernels are bound by the number of
+// scattered cache lines the texture-address unit has to visit per wave, not by bytes or by VALU work.
+DM_HD F3 rgb18e8_decode(unsigned lo, unsigned hi) {
+    const unsigned r = lo & 0x3ffffu, g = ((lo >> 18) | (hi << 14)) & 0x3ffffu, b = (hi >> 4) & 0x3ffffu;
+    const unsigned ebits = (hi >> 22) << 23;             // 2^(E-127) as fp32 bits (E in [1,254], top two bits of hi are 0)
+    float sc;
+    __builtin_memcpy(&sc, &ebits, 4);
+    return f3((float)r * sc, (float)g * sc, (float)b * sc);
+}
+DM_HD F3 cube_fetch_rgbe(const void* __restrict__ tex, long long texel_base, int R, CubeCoord cc) {
+    float x = cc.u * (float)R - 0.5f, y = cc.v * (float)R - 0.5f;
+    float x0 = floorf(x), y0 = floorf(y);
+    float fx = x - x0, fy = y - y0;
+    int P = R + 2;
+    long long idx = texel_base + (long long)(cc.face * P + (int)y0 + 1) * P + (int)x0 + 1;
+    const char* base = (const char*)tex;
+    const HalfRowBits r0 = *reinterpret_cast<const HalfRowBits*>(base + idx * 8);
+    const HalfRowBits r1 = *reinterpret_cast<const HalfRowBits*>(base + (idx + P) * 8);
+    F3 t00 = rgb18e8_decode(r0.x, r0.y), t10 = rgb18e8_decode(r0.z, r0.w);
+    F3 t01 = rgb18e8_decode(r1.x, r1.y), t11 = rgb18e8_decode(r1.z, r1.w);
+    float w00 = (1.f - fx) * (1.f - fy), w10 = fx * (1.f - fy), w01 = (1.f - fx) * fy, w11 = fx * fy;
+    return f3(t00.x * w00 + t10.x * w10 + t01.x * w01 + t11.x * w11,
+              t00.y * w00 + t10.y * w10 + t01.y * w01 + t11.y * w11,
+              t00.z * w00 + t10.z * w10 + t01.z * w01 + t11.z * w11);
+}
+// one bilinear cube lookup in whichever texel format the atlas carries (`texel_off` in texels)
+DM_HD F3 cube_fetch_any(int fmt, const float4* __restrict__ tex, long long texel_off, int R, CubeCoord cc) {
+    if (fmt == kTexelRgb18e8) return cube_fetch_rgbe(tex, texel_off, R, cc);
+    if (fmt == kTexelF16) return cube_fetch_half(tex, texel_off, R, cc);
+    return cube_fetch(tex + texel_off, R, cc);
+}
+
 DM_HD F3 cube_bilinear(const float4* __restrict__ tex, int R, F3 d) { return cube_fetch(tex, R, cube_coord(d)); }
 
 // envlight.get_mip: roughness -> (fractional) mip level, and d level / d roughness
@@ -135,7 +174,10 @@ struct ShadeCtx {
 
 DM_HD float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-DM_HD void shade_eval(const EnvAtlas& A, const MatCfg& M, int env, F3 n, F3 v, const float feat[5], ShadeCtx& c) {
+// FMT >= 0: texel format fixed at compile time (the kernels: one code path, no per-fetch branch); FMT < 0: read from the atlas
+template <int FMT>
+DM_HD void shade_eval_t(const EnvAtlas& A, const MatCfg& M, int env, F3 n, F3 v, const float feat[5], ShadeCtx& c) {
+    const int fmt = FMT >= 0 ? FMT : A.texel_format;
 #pragma unroll
     for (int k = 0; k < 5; ++k) c.s[k] = sigmoidf(feat[k]);
     c.albedo = f3(sat(c.s[0]), sat(c.s[1]), sat(c.s[2]));
@@ -153,8 +195,17 @@ DM_HD void shade_eval(const EnvAtlas& A, const MatCfg& M, int env, F3 n, F3 v, c
         int ix0 = (int)x0, iy0 = (int)y0;
         int ix1 = min(ix0 + 1, L - 1), iy1 = min(iy0 + 1, L - 1);
         ix0 = max(ix0, 0); iy0 = max(iy0, 0);
-        float2 t00 = A.fg_lut[iy0 * L + ix0], t10 = A.fg_lut[iy0 * L + ix1];
-        float2 t01 = A.fg_lut[iy1 * L + ix0], t11 = A.fg_lut[iy1 * L + ix1];
+        float2 t00, t10, t01, t11;
+        if (A.fg_pairs) {
+            // x-pair table: entry (row, x0+1) = {lut[row][max(x0,0)], lut[row][min(x0+1,L-1)]}: the clamped pair of one
+            // bilinear row as ONE aligned 16 B load (2 gathers per pixel instead of 4, same fp32 values)
+            const float4 p0 = A.fg_pairs[iy0 * (L + 1) + (int)x0 + 1], p1 = A.fg_pairs[iy1 * (L + 1) + (int)x0 + 1];
+            t00 = make_float2(p0.x, p0.y); t10 = make_float2(p0.z, p0.w);
+            t01 = make_float2(p1.x, p1.y); t11 = make_float2(p1.z, p1.w);
+        } else {
+            t00 = A.fg_lut[iy0 * L + ix0]; t10 = A.fg_lut[iy0 * L + ix1];
+            t01 = A.fg_lut[iy1 * L + ix0]; t11 = A.fg_lut[iy1 * L + ix1];
+        }
         float r0x = t00.x + (t10.x - t00.x) * fx, r0y = t00.y + (t10.y - t00.y) * fx;
         float r1x = t01.x + (t11.x - t01.x) * fx, r1y = t01.y + (t11.y - t01.y) * fx;
         c.fg0 = r0x + (r1x - r0x) * fy;
@@ -168,29 +219,25 @@ DM_HD void shade_eval(const EnvAtlas& A, const MatCfg& M, int env, F3 n, F3 v, c
               0.04f * (1.f - c.metallic) + c.metallic * c.albedo.y,
               0.04f * (1.f - c.metallic) + c.metallic * c.albedo.z);
     c.spec_albedo = f3(c.F0.x * c.fg0 + c.fg1, c.F0.y * c.fg0 + c.fg1, c.F0.z * c.fg0 + c.fg1);
-    if (A.half_texels) c.diff = cube_fetch_half(A.diff, (long long)env * A.diff_env_stride, A.diff_res, cube_coord(n));
-    else c.diff = cube_bilinear(A.diff + (size_t)env * A.diff_env_stride, A.diff_res, n);
+    c.diff = cube_fetch_any(fmt, A.diff, (long long)env * A.diff_env_stride, A.diff_res, cube_coord(n));
     {
         float level = mip_level(A, c.roughness, c.dlevel_drough);
         level = fminf(fmaxf(level, 0.f), (float)(A.n_mips - 1));
         int l0 = min((int)floorf(level), A.n_mips - 1);
         int l1 = min(l0 + 1, A.n_mips - 1);
         float f = level - (float)l0;
-        const float4* envb = A.spec + (size_t)env * A.spec_env_stride;
         const long long envt = (long long)env * A.spec_env_stride;
         CubeCoord rc = cube_coord(refl);
-        F3 s0, s1;
-        if (A.half_texels) {
-            s0 = cube_fetch_half(A.spec, envt + A.mip_off[l0], A.mip_res[l0], rc);
-            s1 = (l1 != l0) ? cube_fetch_half(A.spec, envt + A.mip_off[l1], A.mip_res[l1], rc) : s0;
-        } else {
-            s0 = cube_fetch(envb + A.mip_off[l0], A.mip_res[l0], rc);
-            s1 = (l1 != l0) ? cube_fetch(envb + A.mip_off[l1], A.mip_res[l1], rc) : s0;
-        }
+        F3 s0 = cube_fetch_any(fmt, A.spec, envt + A.mip_off[l0], A.mip_res[l0], rc);
+        F3 s1 = (l1 != l0) ? cube_fetch_any(fmt, A.spec, envt + A.mip_off[l1], A.mip_res[l1], rc) : s0;
         c.spec = s0 * (1.f - f) + s1 * f;
         c.dspec_dlevel = s1 - s0;
     }
     c.pre = c.albedo * c.diff + c.spec_albedo * c.spec;
+}
+
+DM_HD void shade_eval(const EnvAtlas& A, const MatCfg& M, int env, F3 n, F3 v, const float feat[5], ShadeCtx& c) {
+    shade_eval_t<-1>(A, M, env, n, v, feat, c);
 }
 
 DM_HD float lin2srgb1(float x) {

@@ -181,16 +181,61 @@ def _pad_faces(cube):
     return out
 
 
+TEXEL_FORMATS = {"fp32": 0, "fp16": 1, "rgb18e8": 2}
+
+
+def encode_rgb18e8(rgb):
+    """[..., 3] non-negative fp32 -> [..., 2] int32 words of the 8-byte shared-exponent texel the shade kernels decode
+    (csrc/shade_core.h rgb18e8_decode): bits R[0,18) G[18,36) B[36,54) E[54,62), value = mantissa * 2^(E-127); the exponent is
+    chosen so that the largest channel uses all 18 bits."""
+    rgb = rgb.double().clamp(min=0.0)
+    mx = rgb.amax(-1)
+    _, ex = torch.frexp(mx)                                  # mx = m * 2^ex, m in [0.5, 1)
+    ex = ex.clamp(-100, 127).to(torch.int64)
+    man = torch.round(torch.ldexp(rgb, (18 - ex)[..., None].expand_as(rgb).to(torch.int32)))
+    over = man.amax(-1) >= 2 ** 18                           # rounding carried into bit 18: one exponent up
+    ex = ex + over.to(torch.int64)
+    man = torch.round(torch.ldexp(rgb, (18 - ex)[..., None].expand_as(rgb).to(torch.int32))).clamp(0, 2 ** 18 - 1).to(torch.int64)
+    e = ex - 18 + 127
+    assert int(e.min()) >= 1 and int(e.max()) <= 254
+    word = man[..., 0] | (man[..., 1] << 18) | (man[..., 2] << 36) | (e << 54)
+    lo = word & 0xFFFFFFFF
+    hi = (word >> 32) & 0xFFFFFFFF
+    lo = torch.where(lo >= 2 ** 31, lo - 2 ** 32, lo)
+    hi = torch.where(hi >= 2 ** 31, hi - 2 ** 32, hi)
+    return torch.stack([lo, hi], -1).to(torch.int32).contiguous()
+
+
+def decode_rgb18e8(words):
+    """inverse of encode_rgb18e8 (tests): [..., 2] int32 -> [..., 3] fp32."""
+    lo = words[..., 0].to(torch.int64) & 0xFFFFFFFF
+    hi = words[..., 1].to(torch.int64) & 0xFFFFFFFF
+    word = lo | (hi << 32)
+    man = torch.stack([word & 0x3FFFF, (word >> 18) & 0x3FFFF, (word >> 36) & 0x3FFFF], -1).double()
+    e = ((word >> 54) & 0xFF).to(torch.int32)
+    return torch.ldexp(man, (e - 127)[..., None].expand_as(man)).float()
+
+
+def fg_pair_table(fg_lut):
+    """[L, L, 2] -> [L, L+1, 4]: entry (row, x0+1) = (lut[row, max(x0,0)], lut[row, min(x0+1, L-1)]) for x0 in [-1, L-1], the
+    clamped x-pair of one bilinear row as one aligned 16 B record (same fp32 values, half the gathers)."""
+    L = fg_lut.shape[0]
+    x0 = torch.arange(-1, L, device=fg_lut.device)
+    return torch.cat([fg_lut[:, x0.clamp(min=0)], fg_lut[:, (x0 + 1).clamp(max=L - 1)]], -1).contiguous()
+
+
 class EnvAtlas:
     """All environment maps of a DreamMatMaterial, pre-filtered and packed for the shade kernel."""
 
     def __init__(self, latlongs, scale=1.0, min_res=16, max_res=128, fg_lut=None, device="cpu", texel=None):
         self.device = torch.device(device)
-        # texel storage of the packed cube maps: "fp32" (default) or "fp16" (opt-in, DREAMMAT_ATLAS=fp16: one 16 B load
-        # per bilinear row in the shade kernels, values clamped to +-65504, relative texel error <= 2^-11)
-        self.texel = texel or os.environ.get("DREAMMAT_ATLAS", "fp32")
-        if self.texel not in ("fp32", "fp16"):
-            raise ValueError(f"atlas texel format {self.texel!r}: expected fp32 | fp16")
+        # texel storage of the packed cube maps (DREAMMAT_ATLAS overrides): "rgb18e8" (default: 8-byte shared-exponent
+        # RGB, 18-bit mantissas -- one 16 B load per bilinear row in the shade kernels, relative texel error <= 2^-18),
+        # "fp32" (RGBA fp32, 16 B: the exact reference layout, twice the gathers) or "fp16" (RGBA fp16, 8 B, clamped to
+        # +-65504, relative error <= 2^-11)
+        self.texel = texel or os.environ.get("DREAMMAT_ATLAS", "rgb18e8")
+        if self.texel not in TEXEL_FORMATS:
+            raise ValueError(f"atlas texel format {self.texel!r}: expected one of {sorted(TEXEL_FORMATS)}")
         self.n_env = len(latlongs)
         spec_all, diff_all = [], []
         self.mip_res = []
@@ -230,6 +275,10 @@ class EnvAtlas:
         if self.texel == "fp16":
             self.spec_packed = self.spec_packed.clamp(-65504.0, 65504.0).half().contiguous()
             self.diff_packed = self.diff_packed.clamp(-65504.0, 65504.0).half().contiguous()
+        elif self.texel == "rgb18e8":
+            self.spec_packed = encode_rgb18e8(self.spec_packed[..., :3])
+            self.diff_packed = encode_rgb18e8(self.diff_packed[..., :3])
+        self.fg_pairs = fg_pair_table(self.fg_lut)
         s = _lib.EnvAtlasStruct()
         s.spec = self.spec_packed.data_ptr()
         s.diff = self.diff_packed.data_ptr()
@@ -244,7 +293,8 @@ class EnvAtlas:
         s.lut_res = self.fg_lut.shape[0]
         s.min_rough_mip = MIN_ROUGHNESS
         s.max_rough_mip = MAX_ROUGHNESS
-        s.texel_fp16 = 1 if self.texel == "fp16" else 0
+        s.texel_format = TEXEL_FORMATS[self.texel]
+        s.fg_pairs = self.fg_pairs.data_ptr()
         self.struct = s
 
     def to(self, device):

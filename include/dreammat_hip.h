@@ -114,8 +114,8 @@ int dm_hashgrid_bwd(const float* x, long long x_rs, long long x_cs, const int32_
 
 /* ---- material / shading ------------------------------------------------------------------- */
 /* Pre-filtered environment atlas (envlight.EnvLight equivalents for all env maps, built once at
- * configure time) + the FG LUT of models/materials/dreammat_material.py:399-404.  Texels are RGBA
- * fp32; every cube face carries a 1-texel border.  Passed by pointer to a HOST struct. */
+ * configure time) + the FG LUT of models/materials/dreammat_material.py:399-404.  Texel format per
+ * `texel_format`; every cube face carries a 1-texel border.  Passed by pointer to a HOST struct. */
 typedef struct dm_env_atlas {
     const float* spec;         /* [n_env][mips][6][(R+2)][(R+2)][4] */
     const float* diff;         /* [n_env][6][(Rd+2)][(Rd+2)][4] */
@@ -126,7 +126,10 @@ typedef struct dm_env_atlas {
     int mip_res[8];
     int n_mips, diff_res, lut_res;
     float min_rough_mip, max_rough_mip; /* envlight's 0.08 / 0.5 */
-    int texel_fp16;            /* 0: spec / diff texels are RGBA fp32 (default); 1: RGBA fp16, 8 B per texel (opt-in) */
+    int texel_format;          /* spec / diff texels: 0 = RGBA fp32 (16 B); 1 = RGBA fp16 (8 B); 2 = RGB18E8 (8 B: three 18-bit
+                                * mantissas R[0,18) G[18,36) B[36,54) + shared exponent E[54,62), value = m * 2^(E-127)) */
+    const float* fg_pairs;     /* optional [lut_res][lut_res+1][4]: entry (row, x0+1) = {lut[row][max(x0,0)], lut[row][min(x0+1,
+                                * lut_res-1)]}, the clamped x-pair of a bilinear row as one 16 B load; NULL = plain LUT taps */
 } dm_env_atlas;
 typedef struct dm_mat_cfg { float min_metallic, max_metallic, min_roughness, max_roughness; } dm_mat_cfg;
 

@@ -72,7 +72,8 @@ struct emu_atlas {
     int mip_res[8];
     int n_mips, diff_res, lut_res;
     float min_rough_mip, max_rough_mip;
-    int texel_fp16;
+    int texel_format;
+    const float* fg_pairs;
 };
 
 static EnvAtlas conv(const emu_atlas* in) {
@@ -82,7 +83,8 @@ static EnvAtlas conv(const emu_atlas* in) {
     for (int i = 0; i < 8; ++i) { A.mip_off[i] = in->mip_off[i]; A.mip_res[i] = in->mip_res[i]; }
     A.n_mips = in->n_mips; A.diff_res = in->diff_res; A.lut_res = in->lut_res;
     A.min_rough_mip = in->min_rough_mip; A.max_rough_mip = in->max_rough_mip;
-    A.half_texels = in->texel_fp16 ? 1 : 0;
+    A.texel_format = in->texel_format;
+    A.fg_pairs = (const float4*)in->fg_pairs;
     return A;
 }
 

@@ -141,10 +141,9 @@ def test_shade_core_fp16_atlas_stays_inside_the_parity_budget(hostemu, env_pair)
     """opt-in atlas format (DREAMMAT_ATLAS=fp16: RGBA fp16 texels, one 16-byte load per bilinear row): the shaded colour
     stays within the north-star's 1e-3 relative budget of the fp32 oracle, and the default atlas is untouched."""
     lat, fg, atlas, oenvs = env_pair
-    assert atlas.texel == "fp32" and atlas.struct.texel_fp16 == 0 and atlas.spec_packed.dtype == torch.float32
     half = penv.EnvAtlas(lat, scale=2.0, min_res=8, max_res=32, fg_lut=fg, texel="fp16")
-    assert half.struct.texel_fp16 == 1 and half.spec_packed.dtype == torch.float16 and half.diff_packed.dtype == torch.float16
-    assert half.spec_packed.shape == atlas.spec_packed.shape
+    assert half.struct.texel_format == 1 and half.spec_packed.dtype == torch.float16 and half.diff_packed.dtype == torch.float16
+    assert half.spec_packed.shape[:2] == atlas.spec_packed.shape[:2]
     torch.manual_seed(1)
     N = 20000
     n = torch.nn.functional.normalize(torch.randn(N, 3), dim=-1)
@@ -204,7 +203,7 @@ def test_c_abi_exports_every_declared_symbol():
     """The library loads on a GPU-less box and exports exactly what include/dreammat_hip.h declares."""
     import os, re
     L = _lib.lib()
-    assert L.dm_abi_version() == 1
+    assert L.dm_abi_version() == 2
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "dreammat_hip.h")).read()
     declared = set(re.findall(r"\b(dm_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
@@ -285,3 +284,41 @@ def test_bvh_build_and_traversal_core_vs_brute_force(hostemu):
                                  ctypes.c_float(10.0), ctypes.c_void_p(hit4.data_ptr()))
         assert torch.equal(hit4, hit) and 1 <= bvh.n_nodes4 <= bvh.n_nodes
         assert 0.2 < ref.float().mean() < 0.95
+
+
+def test_rgb18e8_texels_and_fg_pair_table(hostemu, env_pair):
+    """The default atlas texel (8-byte shared-exponent RGB, 18-bit mantissas) and the FG x-pair table: packing round trip
+    within 2^-18 of the largest channel, the pair table holds exactly the clamped bilinear taps, and the shading core gives
+    the same colours with all three texel formats (fp32 exact layout / rgb18e8 / fp16) within their stated budgets."""
+    lat, fg, atlas, oenvs = env_pair
+    assert atlas.texel == "rgb18e8" and atlas.struct.texel_format == 2 and atlas.spec_packed.dtype == torch.int32
+    g = torch.Generator().manual_seed(0)
+    rgb = torch.exp(torch.randn(4000, 3, generator=g) * 4.0)               # 7 decades of dynamic range
+    rgb[::7, 1] = 0.0
+    rgb[5] = 0.0
+    rgb[6] = torch.tensor([1.0 - 2 ** -20, 0.25, 0.5])                    # mantissa rounds up into the next exponent
+    dec = penv.decode_rgb18e8(penv.encode_rgb18e8(rgb))
+    assert ((dec - rgb).abs().amax(-1) <= rgb.amax(-1) * 2.0 ** -18 + 1e-37).all()
+    L = fg.shape[0]
+    pairs = penv.fg_pair_table(fg)
+    assert pairs.shape == (L, L + 1, 4)
+    for x0 in (-1, 0, 100, L - 1):
+        assert torch.equal(pairs[:, x0 + 1, :2], fg[:, max(x0, 0)]) and torch.equal(pairs[:, x0 + 1, 2:], fg[:, min(x0 + 1, L - 1)])
+    torch.manual_seed(3)
+    N = 8000
+    n = torch.nn.functional.normalize(torch.randn(N, 3), dim=-1)
+    v = torch.nn.functional.normalize(n + 0.8 * torch.randn(N, 3), dim=-1)
+    feat = torch.randn(N, 5) * 1.5
+    env = torch.randint(0, 2, (N,)).numpy().astype(np.int32)
+    mat = np.array([0.0, 0.9, 0.1, 0.95], np.float32)
+    arrs = [np.ascontiguousarray(t.numpy()) for t in (n, v, feat, torch.randn(N, 3))]
+    res = {}
+    for texel in ("fp32", "rgb18e8", "fp16"):
+        a = penv.EnvAtlas(lat, scale=2.0, min_res=8, max_res=32, fg_lut=fg, texel=texel)
+        color = np.empty((N, 3), np.float32); dfeat = np.empty((N, 5), np.float32)
+        hostemu.emu_shade(ctypes.byref(a.struct), P(mat), P(arrs[0]), P(arrs[1]), P(arrs[2]), P(env), ctypes.c_longlong(N),
+                          P(color), None, P(arrs[3]), P(dfeat))
+        res[texel] = (color, dfeat)
+    gmax = np.abs(res["fp32"][1]).max()
+    assert np.abs(res["rgb18e8"][0] - res["fp32"][0]).max() < 2e-6 and np.abs(res["rgb18e8"][1] - res["fp32"][1]).max() < 1e-5 * gmax
+    assert np.abs(res["fp16"][0] - res["fp32"][0]).max() < 1e-3

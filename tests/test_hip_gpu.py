@@ -866,3 +866,139 @@ def test_shade_kernels_with_the_fp16_atlas():
     (out[0] * dcol.to(dev)).sum().backward()
     assert (out[0].detach().cpu() - ref["color"].detach()).abs().max() < 1e-3
     assert (fg_.grad.cpu() - feat.grad).abs().max() < 2e-3 * feat.grad.abs().max()
+
+
+# ---- BASELINE configs[1] (cfg2) on the reference's own in-tree assets: apple.obj, the CC0 HDR probe and
+#      the real split-sum FG LUT, copied to tests/golden/assets by tests/golden/make_assets.py
+ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "assets")
+
+
+def _golden_cfg2_env():
+    """oracle EnvLight of the real HDR at the reference's settings (scale 2.0, 16..128), prefiltered once on the CPU by
+    tests/golden/make_cfg2_env.py (O(res^4): minutes) and stored."""
+    gz = np.load(os.path.join(os.path.dirname(ASSETS), "cfg2_env.npz"))
+    env = oenv.EnvLight.__new__(oenv.EnvLight)
+    env.specular = [torch.from_numpy(gz[f"spec{i}"]) for i in range(4)]
+    env.diffuse = torch.from_numpy(gz["diffuse"])
+    env.base = torch.from_numpy(gz["base"])
+    return env
+
+
+def test_cfg2_real_assets_render_vs_oracle(dev):
+    """run_examples.sh:2 (`shape_init=mesh:load/shapes/objs/apple.obj shape_init_params=0.7`) with dreammat.yaml's geometry
+    (+y up, +z front, 16-level 2^19 hash grid), environment_scale 2.0 and the real FG LUT (dreammat_material.py:383,399-404):
+    4 views @512^2 through the plugin API against the oracle -- coverage bit-equal, shaded pixels within 1e-3, gradients
+    within 1e-3; the product's GPU-built environment atlas against the oracle's prefilter of the same HDR."""
+    import hashlib
+    import dreammat_amd
+    from dreammat_amd.geometry import DreamMatMesh
+    from dreammat_amd.material import DreamMatMaterial
+    from dreammat_amd.renderer import RaytraceRender
+    from dreammat_amd.background import SolidColorBackground
+    sums = json.load(open(os.path.join(ASSETS, "SHA256.json")))
+    for name, want in sums.items():
+        assert hashlib.sha256(open(os.path.join(ASSETS, name), "rb").read()).hexdigest() == want, name
+    assert sums["bsdf_256_256.bin"].startswith("aee514f7c7e5")                     # SURVEY 8c
+    torch.manual_seed(0)
+    geom = DreamMatMesh({"shape_init": "mesh:" + os.path.join(ASSETS, "apple.obj"), "shape_init_params": 0.7,
+                         "shape_init_mesh_up": "+y", "shape_init_mesh_front": "+z"}).to(dev)
+    assert geom.t_buffer.shape[0] == 4164 and geom.encoding.spec.n_params == 12599920
+    with torch.no_grad():
+        geom.encoding.encoding.params.copy_(torch.rand_like(geom.encoding.encoding.params) * 2 - 1)
+        geom.feature_network.layers[0].weight.copy_(torch.randn(64, 32) * 0.3)
+        geom.feature_network.layers[2].weight.copy_(torch.randn(5, 64) * 0.3)
+    mat = DreamMatMaterial({"use_raytracing": False, "environment_scale": 2.0, "n_envs": 1,
+                            "environment_texture": os.path.join(ASSETS, "mud_road_puresky_1k.hdr"),
+                            "fg_lut_path": os.path.join(ASSETS, "bsdf_256_256.bin")}).to(dev)
+    fg = penv.load_fg_lut(os.path.join(ASSETS, "bsdf_256_256.bin"))
+    assert torch.equal(mat.FG_LUT[0].cpu(), fg) and abs(float(fg[0, 0, 0]) - 0.00973) < 1e-5
+    golden_env = _golden_cfg2_env()
+    assert mat.atlas.mip_res == [128, 64, 32, 16] and mat.atlas.texel == "rgb18e8"
+    for k in range(4):
+        a, b = mat.atlas.specular[0][k].cpu(), golden_env.specular[k]
+        assert (a - b).abs().max() <= 1e-4 * b.abs().max(), k
+    assert (mat.atlas.diffuse[0].cpu() - golden_env.diffuse).abs().max() < 1e-5 * max(1.0, float(golden_env.diffuse.max()))
+    rend = RaytraceRender({}, geometry=geom, material=mat, background=SolidColorBackground({}))
+    B, H, W = 4, 512, 512
+    batch = util.make_views(B, H, W, seed=4)
+    batch["env_id"] = torch.zeros(B, dtype=torch.long)
+    g = torch.Generator().manual_seed(9)
+    ju, jn = torch.rand(B, H, W, generator=g), torch.randn(B, H, W, generator=g)
+    gbatch = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    out = rend(**gbatch, light_positions=None, jitter_u=ju.to(dev), jitter_n=jn.to(dev), check_overflow=True)
+    m = geom.mesh
+    md = dict(v_pos=geom.v_buffer.cpu().numpy(), v_nrm=geom.vnrm_buffer.cpu().numpy(),
+              t_pos_idx=geom.t_buffer.cpu().numpy().astype(np.int32))
+    md["opp"] = oraster.build_topology(md["t_pos_idx"])
+    lv, tot = ofield.grid_levels()
+    table = geom.encoding.encoding.params.detach().cpu().reshape(-1, 2).clone().requires_grad_()
+    w1 = geom.feature_network.layers[0].weight.detach().cpu().clone().requires_grad_()
+    w2 = geom.feature_network.layers[2].weight.detach().cpu().clone().requires_grad_()
+    ref = orender.render(md, batch, dict(table=table, w1=w1, w2=w2, levels=lv, radius=1.0), [golden_env], fg, ju, jn)
+    assert np.array_equal(out["_internals"]["rast"].cpu().numpy().view(np.uint32), ref["_rast"].numpy().view(np.uint32))
+    cover = float((ref["opacity"] > 0).float().mean())
+    assert 0.1 < cover < 0.6
+    errs = {}
+    for k in ["comp_rgb", "opacity", "comp_depth", "comp_normal", "albedo", "metalness", "roughness", "specular_light",
+              "diffuse_light", "specular_color", "diffuse_color"]:
+        errs[k] = (out[k].detach().cpu() - ref[k].detach()).abs().max().item()
+        assert errs[k] < 1e-3, (k, errs[k])
+    mse = ((out["comp_rgb"].detach().cpu() - ref["comp_rgb"].detach()) ** 2).mean().item()
+    psnr = 10 * np.log10(1.0 / max(mse, 1e-20))
+    assert psnr > 80, psnr
+    dy = torch.randn(B, H, W, 3, generator=g)
+    ((out["comp_rgb"] * dy.to(dev)).sum() + 2.0 * out["loss_mat_reg"]).backward()
+    ((ref["comp_rgb"] * dy).sum() + 2.0 * ref["loss_mat_reg"]).backward()
+    rels = {}
+    for a, b, nm in ((geom.encoding.encoding.params.grad.cpu().reshape(-1, 2), table.grad, "table"),
+                     (geom.feature_network.layers[0].weight.grad.cpu(), w1.grad, "w1"),
+                     (geom.feature_network.layers[2].weight.grad.cpu(), w2.grad, "w2")):
+        rels[nm] = ((a - b).abs().max() / b.abs().max()).item()
+        assert rels[nm] < 1e-3, (nm, rels[nm])
+    with open(os.path.join(OUT, "cfg2_render_parity.json"), "w") as fh:
+        json.dump({"psnr_db": psnr, "coverage_ids_equal": True, "covered_fraction": cover, "max_abs_err": errs,
+                   "grad_rel_err": rels, "assets": sums}, fh)
+
+
+def test_full_size_sd21_unet_controlnet_eps_vs_oracle(dev):
+    """One branch-item of the guidance's frozen stack at the bench's real shapes (SD-2.1-base UNet 865.9 M parameters + the
+    22-channel ControlNet, 64^2 latents, S = 4096 self-attention, 512^2 condition maps; seeded random weights -- no
+    checkpoints on this box): fp32 on the GPU within 1e-3 of the functional CPU oracle (north_star), and the bf16 production
+    path (MFMA attention / conv / GroupNorm kernels) against the same oracle within bf16 rounding."""
+    from dreammat_amd.sd import ARCHS, ControlNetModel, UNet2DConditionModel
+    from oracle import sd_nets as osd
+    a = ARCHS["sd21-base"]
+    torch.manual_seed(0)
+    with torch.device(dev):
+        unet = UNet2DConditionModel(a).eval()
+        cn = ControlNetModel.from_unet(unet).eval()
+    for conv in list(cn.controlnet_down_blocks) + [cn.controlnet_mid_block, cn.controlnet_cond_embedding.conv_out]:
+        torch.nn.init.normal_(conv.weight, std=0.02)
+    for p in list(unet.parameters()) + list(cn.parameters()):
+        p.requires_grad_(False)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 4, 64, 64, generator=g); t = torch.tensor([437])
+    ctx = torch.randn(1, 77, a.cross_dim, generator=g); cond = torch.rand(1, 22, 512, 512, generator=g)
+    with torch.no_grad():
+        d, m = cn(x.to(dev), t.to(dev), ctx.to(dev), cond.to(dev), 1.0)
+        y = unet(x.to(dev), t.to(dev), ctx.to(dev), d, m).cpu()
+        sd_u = {k: v.float().cpu() for k, v in unet.state_dict().items()}
+        sd_c = {k: v.float().cpu() for k, v in cn.state_dict().items()}
+        od, om = osd.controlnet_forward(sd_c, x, t, ctx, cond, 1.0, a.heads, a.use_linear_projection)
+        oy = osd.unet_forward(sd_u, x, t, ctx, a.heads, a.use_linear_projection, od, om)
+        del sd_u, sd_c
+        rel32 = ((y - oy).abs().max() / oy.abs().max()).item()
+        assert rel32 <= 1e-3, rel32
+        unet.bfloat16(); cn.bfloat16()
+        hipops.enable_kernel_timing(True)
+        d, m = cn(x.to(dev).bfloat16(), t.to(dev), ctx.to(dev).bfloat16(), cond.to(dev).bfloat16(), 1.0)
+        yb = unet(x.to(dev).bfloat16(), t.to(dev), ctx.to(dev).bfloat16(), d, m).float().cpu()
+        torch.cuda.synchronize()
+        kt = hipops.kernel_times()
+        hipops.enable_kernel_timing(False)
+    assert sum(v["launches"] for k, v in kt.items() if k.startswith("attention")) == 46
+    assert any(k.startswith("conv3x3") for k in kt)
+    rel16 = ((yb - oy).abs().max() / oy.abs().max()).item()
+    with open(os.path.join(OUT, "full_size_eps_parity.json"), "w") as fh:
+        json.dump({"fp32_rel_max": rel32, "bf16_rel_max": rel16, "eps_abs_max": float(oy.abs().max())}, fh)
+    assert rel16 < 8e-2, rel16
