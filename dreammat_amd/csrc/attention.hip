@@ -508,6 +508,346 @@ __global__ __launch_bounds__(256) void k_attn_fwd_dma(AttnArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Variant 3 (DP = 64 or 128): same decomposition (4 waves x 32 query rows, 64-kv tiles, 3-stage LDS-DMA ring) with
+// the per-tile instruction stream cut from ~290 to ~150 non-MFMA instructions -- the kernel is bound by VALU issue
+// beside the MFMAs (rocprofv3 round 1: 218 M VALU instructions against 503 M MFMA-busy cycles, SQ_WAIT_INST_ANY 46 %):
+//  * DMA through a buffer descriptor (buffer_load ... lds): per-lane offsets are loop-invariant VGPRs, the tile offset
+//    is an SGPR (soffset), rows past the end of K and head-dim columns >= D fall outside num_records and read as zero:
+//    no address arithmetic, clamps, selects or zero page in the loop (was ~50 VALU + 12 SALU per tile);
+//  * K rows land in LDS with bits 2 and 3 of the row index swapped, which makes the accumulator order of S^T the NATURAL
+//    k order of the P.V product: V^T fragments are single ds_read_b128 (was two ds_read_b64 each);
+//  * PRESCALE: Q is multiplied by scale*log2(e) once in the prologue (one extra bf16 rounding of Q) and the running
+//    maximum enters through the MFMA's C operand (S' = K.Q'^T - m), so the softmax numerator is a bare v_exp_f32 per
+//    element: no multiply, no subtract;
+//  * the running maximum is only revised when some row outgrows it by more than 2^8 (as before); the revision path
+//    (rare) re-bases S', O, l and the C-operand vector.
+__device__ __forceinline__ int attn_swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+// VLATE: the V^T fragments are read inside the P.V loop (16 VGPRs at a time) instead of ahead of the softmax (32 VGPRs
+// across it); with PRESCALE that is the difference between 2 and 3 resident waves per SIMD.
+template <int DP, bool PRESCALE, bool VLATE>
+__global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // __amdgpu_buffer_rsrc_t does not exist in the host pass (the stub needs no body)
+    static_assert(DP == 64 || DP == 128, "power-of-two row sizes only");
+    constexpr int KSTEPS = DP / 16, DT = DP / 32;
+    constexpr int KROW = DP * 2, VROW = kKvTile * 2;
+    constexpr int KBYTES = kKvTile * KROW, VBYTES = DP * VROW, STAGE = KBYTES + VBYTES;
+    constexpr int KCH = KROW / 16, KRPI = 64 / KCH, K_INSTR = kKvTile / KRPI / 4, V_INSTR = DP / 8 / 4;
+    constexpr int L = K_INSTR + V_INSTR;
+    constexpr int OOB = 0x40000000;                     // beyond any num_records the launcher admits
+    constexpr float THR = 8.0f;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bh, qb;
+    {
+        const int nq = (a.Sq + kWaves * kQRowsPerWave - 1) / (kWaves * kQRowsPerWave);
+        const int BH = a.B * a.Hh, id = blockIdx.x;
+        if ((BH & 7) == 0) {
+            const int j = id >> 3;
+            bh = (j / nq) * 8 + (id & 7);
+            qb = j - (j / nq) * nq;
+        } else {
+            bh = id / nq;
+            qb = id - bh * nq;
+        }
+    }
+    const int b = bh / a.Hh, h = bh - b * a.Hh;
+    const int q_row = qb * (kWaves * kQRowsPerWave) + wave * kQRowsPerWave + l31;
+    const bool q_ok = q_row < a.Sq;
+    const int skv_pad8 = (a.Skv + 7) & ~7;
+    const int n_tiles = (a.Skv + kKvTile - 1) / kKvTile;
+    auto kswz = [](int r) { return KCH == 8 ? ((r >> 1) & 7) : (r & 15); };
+
+    // ragged sequences: whatever an out-of-range DMA lane does to its LDS slot (writes zero / leaves it), the slot must
+    // hold finite numbers, because masked probabilities are exact zeros and 0 x NaN would poison O
+    if ((a.Skv & (kKvTile - 1)) != 0 || a.D != DP) {
+        for (int o = tid * 16; o < 3 * STAGE; o += 256 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+    }
+
+    bf16x8 qf[KSTEPS];
+    {
+        const __bf16* qp = a.q + (long long)b * a.q_bs + (long long)q_row * a.q_ss + (long long)h * a.q_hs;
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            int d = 16 * kk + 8 * hi;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q_ok && d < a.D) v = ld16(qp + d);
+            qf[kk] = __builtin_bit_cast(bf16x8, v);
+            if (PRESCALE) {
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    f32x2 two = {(float)qf[kk][e] * a.scale_log2, (float)qf[kk][e + 1] * a.scale_log2};
+                    bf16x2 pk = __builtin_convertvector(two, bf16x2);
+                    qf[kk][e] = pk[0];
+                    qf[kk][e + 1] = pk[1];
+                }
+            }
+        }
+    }
+    // ---- DMA descriptors: one per operand, base = this (batch, head)
+    const __bf16* kp = a.k + (long long)b * a.k_bs + (long long)h * a.k_hs;
+    const __bf16* vp = a.vt + (long long)b * a.vt_bs + (long long)h * a.vt_hs;
+    const int k_bytes = (int)((((long long)a.Skv - 1) * a.k_ss + a.D) * 2);
+    const int v_bytes = (int)((((long long)a.D - 1) * a.vt_ds + skv_pad8) * 2);
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, k_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, v_bytes, 0x00020000);
+    int k_voff[K_INSTR], v_voff[V_INSTR], v_kv[V_INSTR];
+#pragma unroll
+    for (int i = 0; i < K_INSTR; ++i) {
+        const int r = (wave * K_INSTR + i) * KRPI + lane / KCH;            // LDS row of this lane's 16 B slot
+        const int col = ((lane % KCH) ^ kswz(r)) * 8;                       // source column (elements) that lands there
+        k_voff[i] = col < a.D ? (int)(((long long)attn_swap23(r) * a.k_ss + col) * 2) : OOB;
+    }
+#pragma unroll
+    for (int i = 0; i < V_INSTR; ++i) {
+        const int d = (wave * V_INSTR + i) * 8 + (lane >> 3);
+        v_kv[i] = ((lane & 7) ^ ((d >> 1) & 7)) * 8;
+        v_voff[i] = d < a.D ? (int)(((long long)d * a.vt_ds + v_kv[i]) * 2) : OOB;
+    }
+    const int k_tile_bytes = (int)(a.k_ss * 2 * kKvTile);
+    auto issue = [&](int j, int stage, auto guard_tag) {
+        constexpr bool GUARD = decltype(guard_tag)::value;
+        char* kb = smem + stage * STAGE;
+        char* vb = kb + KBYTES;
+        const int ks = j * k_tile_bytes, vs = j * (kKvTile * 2);
+#pragma unroll
+        for (int i = 0; i < K_INSTR; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)(kb + (wave * K_INSTR + i) * 1024),
+                                                     16, k_voff[i], ks, 0, 0);
+#pragma unroll
+        for (int i = 0; i < V_INSTR; ++i) {
+            int vo = v_voff[i];
+            // the kv columns of the LAST tile beyond the zero-padded row end belong to the next row (or to nobody)
+            if (GUARD) vo = (j * kKvTile + v_kv[i] < skv_pad8) ? vo : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (__attribute__((address_space(3))) void*)(vb + (wave * V_INSTR + i) * 1024),
+                                                     16, vo, vs, 0, 0);
+        }
+    };
+
+    f32x16 o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    f32x16 cinit;                                        // C operand of the first S^T MFMA: -m (PRESCALE) or 0
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
+    float m_run = 0.f, l_run = 0.f;                      // PRESCALE: cinit == -m_run at all times
+    bf16x8 pf[4];
+
+    auto tile = [&](int j, int stage, bool first, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const char* kb = smem + stage * STAGE;
+        const char* vb = kb + KBYTES;
+        bf16x8 kf[2][KSTEPS];
+        auto read_k = [&](int t) {
+            const int row = 32 * t + l31;
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk)
+                kf[t][kk] = *reinterpret_cast<const bf16x8*>(kb + row * KROW + (((2 * kk + hi) ^ kswz(row)) << 4));
+        };
+        read_k(0);
+        if (!VLATE) read_k(1);
+        f32x16 s[2];
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (VLATE && t == 0) read_k(1);
+            s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][0], qf[0], cinit, 0, 0, 0);
+#pragma unroll
+            for (int kk = 1; kk < KSTEPS; ++kk)
+                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][kk], qf[kk], s[t], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        bf16x8 vf[DT][4];
+        auto read_v = [&](int dt) {
+            const int row = 32 * dt + l31;
+            const int sw = (row >> 1) & 7;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                vf[dt][ks] = *reinterpret_cast<const bf16x8*>(vb + row * VROW + (((2 * ks + hi) ^ sw) << 4));
+        };
+        if (!VLATE) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) read_v(dt);
+        }
+        if (MASKED) {
+            if ((j + 1) * kKvTile > a.Skv) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        // LDS row (r&3) + 8(r>>2) + 4hi of this half holds K row swap23(.) of the tile
+                        const int kv = j * kKvTile + 32 * t + 16 * (r >> 3) + 8 * hi + 4 * ((r >> 2) & 1) + (r & 3);
+                        if (kv >= a.Skv) s[t][r] = -INFINITY;
+                    }
+            }
+        }
+        // ---- row maximum of this tile (relative to the running maximum when PRESCALE)
+        float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float psum = 0.f;
+        if (PRESCALE) {
+            if (first || !__all(mx <= THR)) {            // wave-uniform; the previous tile's P.V is complete
+                const float delta = first ? mx : fmaxf(mx, 0.f);
+                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+                m_run += delta;
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < DT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[0][r] -= delta; s[1][r] -= delta; cinit[r] = -m_run; }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s[t][r]);
+                    s[t][r] = p;
+                    psum += p;
+                }
+        } else {
+            mx *= a.scale_log2;
+            if (first || !__all(mx <= m_run + THR)) {
+                const float m_new = first ? mx : fmaxf(m_run, mx);
+                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_new);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < DT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], a.scale_log2, -m_run));
+                    s[t][r] = p;
+                    psum += p;
+                }
+        }
+        l_run += psum;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int t = ks >> 1, u = ks & 1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                f32x2 two = {s[t][8 * u + 2 * e], s[t][8 * u + 2 * e + 1]};
+                bf16x2 pk = __builtin_convertvector(two, bf16x2);
+                pf[ks][2 * e] = pk[0];
+                pf[ks][2 * e + 1] = pk[1];
+            }
+        }
+        if (VLATE) read_v(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            if (VLATE && dt + 1 < DT) read_v(dt + 1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][ks], pf[ks], o[dt], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // prologue: tiles 0 and 1 (the last tile of the sequence is always issued through the guarded form)
+    if (n_tiles == 1) issue(0, 0, std::true_type{}); else issue(0, 0, std::false_type{});
+    if (n_tiles == 2) issue(1, 1, std::true_type{}); else if (n_tiles > 2) issue(1, 1, std::false_type{});
+    int stage = 0, j = 0;
+    // main loop: tile j computes while tiles j+1, j+2 are in flight; every tile touched here is a full one
+    for (; j + 3 < n_tiles; ++j) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        __builtin_amdgcn_s_barrier();
+        int st2 = stage + 2; if (st2 >= 3) st2 -= 3;
+        issue(j + 2, st2, std::false_type{});
+        tile(j, stage, j == 0, std::false_type{});
+        stage = stage + 1; if (stage >= 3) stage = 0;
+    }
+    // tail: at most three tiles; issues the (possibly ragged) last tile guarded, masks the last tile
+    for (; j < n_tiles; ++j) {
+        if (j + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (j + 2 < n_tiles) {
+            int st2 = stage + 2; if (st2 >= 3) st2 -= 3;
+            issue(j + 2, st2, std::true_type{});
+        }
+        tile(j, stage, j == 0, std::true_type{});
+        stage = stage + 1; if (stage >= 3) stage = 0;
+    }
+
+    float l_tot = l_run + __shfl_xor(l_run, 32);
+    float inv = 1.0f / l_tot;
+    if (q_ok) {
+        __bf16* op = a.out + (long long)b * a.o_bs + (long long)q_row * a.o_ss + (long long)h * a.o_hs;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int d = 32 * dt + 8 * g + 4 * hi;
+                if (d < a.D) {
+                    f32x2 x0 = {o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv};
+                    f32x2 x1 = {o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
+                    bf16x2 y0 = __builtin_convertvector(x0, bf16x2), y1 = __builtin_convertvector(x1, bf16x2);
+                    bf16x4 y = {y0[0], y0[1], y1[0], y1[1]};
+                    *reinterpret_cast<bf16x4*>(op + d) = y;
+                }
+            }
+    }
+#endif
+}
+
+template <int DP, bool PRESCALE, bool VLATE>
+int launch_attn_v3(const AttnArgs& a, hipStream_t stream) {
+    constexpr int LDS = 3 * (kKvTile * DP * 2 + DP * kKvTile * 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_fwd_v3<DP, PRESCALE, VLATE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const long long n_blocks = (long long)dm_div_up(a.Sq, kWaves * kQRowsPerWave) * a.B * a.Hh;
+    if (n_blocks > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
+    DM_ENTER();
+    hipLaunchKernelGGL((k_attn_fwd_v3<DP, PRESCALE, VLATE>), dim3((unsigned)n_blocks), dim3(256), LDS, stream, a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DM_OK : (int)e;
+}
+
+static int g_attn_mode = -1;
+static int attn_mode_from_name(const char* e) {
+    if (!e || !strcmp(e, "v3")) return 3;
+    if (!strcmp(e, "v3l")) return 4;
+    if (!strcmp(e, "v3s")) return 2;
+    if (!strcmp(e, "dma")) return 1;
+    if (!strcmp(e, "staged")) return 0;
+    return -1;
+}
+static int attn_mode() {
+    if (g_attn_mode < 0) {
+        g_attn_mode = attn_mode_from_name(getenv("DREAMMAT_ATTN_KERNEL"));
+        if (g_attn_mode < 0) g_attn_mode = 3;
+    }
+    return g_attn_mode;
+}
+
+// the buffer-descriptor DMA addresses one (batch, head) operand with 32-bit byte offsets
+static bool attn_v3_ok(const AttnArgs& a) {
+    const long long skv_pad8 = (a.Skv + 7) & ~7;
+    const long long kb = (((long long)a.Skv + kKvTile) * a.k_ss + a.D) * 2, vb = (((long long)a.D - 1) * a.vt_ds + skv_pad8 + kKvTile) * 2;
+    return kb < 0x40000000LL && vb < 0x40000000LL && a.k_ss >= a.D && a.vt_ds >= skv_pad8;
+}
+
 template <int DP>
 int launch_attn_dma(const AttnArgs& a, hipStream_t stream) {
     constexpr int LDS = 3 * (kKvTile * DP * 2 + DP * kKvTile * 2);
@@ -548,6 +888,17 @@ int launch_attn(const AttnArgs& a, hipStream_t stream) {
 
 extern "C" {
 
+// Selects the attention kernel variant by name ("v3", "v3l", "v3s", "dma", "staged"; NULL = environment / default) for
+// every later dm_attention_fwd_bf16 call of the process.  Returns DM_OK or DM_ERR_ARG for an unknown name.  Meant for
+// A/B measurements and for the parity tests, which run every variant.
+int dm_attention_select(const char* name) {
+    if (!name) { g_attn_mode = -1; return DM_OK; }
+    const int m = attn_mode_from_name(name);
+    if (m < 0) return DM_ERR_ARG;
+    g_attn_mode = m;
+    return DM_OK;
+}
+
 // q   [B, Sq, Hh, D]  via strides (q_bs, q_ss, q_hs), d contiguous
 // k   [B, Skv, Hh, D] via strides
 // vt  [B, Hh, D, Skv_pad] via strides (vt_bs, vt_hs, vt_ds), kv contiguous, rows zero-padded to a
@@ -570,8 +921,18 @@ int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* ou
     a.vt_bs = vt_bs; a.vt_hs = vt_hs; a.vt_ds = vt_ds; a.o_bs = o_bs; a.o_ss = o_ss; a.o_hs = o_hs;
     a.B = B; a.Hh = Hh; a.Sq = Sq; a.Skv = Skv; a.D = D;
     a.scale_log2 = scale * 1.4426950408889634f;
-    // DREAMMAT_ATTN_KERNEL=staged selects the register-staged variant everywhere (A/B measurements)
-    static const bool use_dma = !(getenv("DREAMMAT_ATTN_KERNEL") && !strcmp(getenv("DREAMMAT_ATTN_KERNEL"), "staged"));
+    // Kernel choice: dm_attention_select() / DREAMMAT_ATTN_KERNEL = v3 (default: prologue Q scaling, 2 waves per SIMD) |
+    // v3l (v3 with late V^T reads, 3 waves per SIMD) | v3s (v3 without the Q scaling) | dma (round-1 kernel) | staged
+    // (register-staged): A/B measurements and regression tests.  D = 40/80/160 heads always use the staged kernel.
+    const int mode = attn_mode();
+    if (mode >= 2 && attn_v3_ok(a) && (D <= 64 || (D > 96 && D <= 128))) {
+        if (D <= 64) {
+            if (mode == 4) return launch_attn_v3<64, true, true>(a, stream);
+            return mode == 3 ? launch_attn_v3<64, true, false>(a, stream) : launch_attn_v3<64, false, false>(a, stream);
+        }
+        return mode == 2 ? launch_attn_v3<128, false, false>(a, stream) : launch_attn_v3<128, true, false>(a, stream);
+    }
+    const bool use_dma = mode >= 1;
     if (D <= 64) return use_dma ? launch_attn_dma<64>(a, stream) : launch_attn<64>(a, stream);
     if (D <= 96) return launch_attn<96>(a, stream);
     if (D <= 128) return use_dma ? launch_attn_dma<128>(a, stream) : launch_attn<128>(a, stream);

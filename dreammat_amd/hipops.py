@@ -402,6 +402,12 @@ def material_smoothness(feat, featj, n_dev):
 
 
 # ------------------------------------------------------------------------------------------ attention
+def attention_select(name=None):
+    """Kernel variant of every later attention() call: "v3" (default) | "v3l" | "v3s" | "dma" | "staged"; None restores the
+    DREAMMAT_ATTN_KERNEL / default choice (dm_attention_select)."""
+    check(_lib.lib().dm_attention_select(name.encode() if name is not None else None), "dm_attention_select")
+
+
 def attention(q, k, vt, heads, scale=None):
     """q [B,Sq,C], k [B,Skv,C] bf16 (C = heads*D, last dim contiguous), vt [B,C,Skv_pad] bf16
     (V transposed, rows zero-padded to a multiple of 8) -> out [B,Sq,C] bf16."""

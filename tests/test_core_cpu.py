@@ -230,6 +230,28 @@ def test_attention_index_math_on_mfma_model():
         assert np.abs(attention_wave_sim(Q, K, V, D ** -0.5) - Pm @ V).max() < 1e-12
 
 
+def test_attention_v3_index_math_and_rebase_logic_on_mfma_model():
+    """k_attn_fwd_v3: swapped-row K image + natural V^T + running maximum through the MFMA C operand + deferred re-base
+    (threshold 8, forced on the first tile), both with and without the prologue Q scaling; spiked keys force the re-base
+    branch at chosen tiles (guide rule 26), ragged tails exercise the permuted mask."""
+    from tests.mfma_sim import attention_wave_sim_v3
+    rng = np.random.default_rng(1)
+    for D, Skv, spike in ((64, 256, True), (64, 77, False), (64, 200, True), (128, 192, False), (64, 64, False), (64, 1, False)):
+        Q = rng.standard_normal((32, D)); K = rng.standard_normal((Skv, D)); V = rng.standard_normal((Skv, D))
+        if spike:
+            K[Skv - 30] = Q[5] * 6.0               # late, large: re-base in the last tile
+            K[70] = Q[9] * 3.0                     # second tile
+            K[3] = -Q[2] * 50.0                    # a row whose FIRST tile is dominated by a very negative score
+        S = Q @ K.T * D ** -0.5
+        Pm = np.exp(S - S.max(1, keepdims=True)); Pm /= Pm.sum(1, keepdims=True)
+        for prescale in (True, False):
+            O, nb = attention_wave_sim_v3(Q, K, V, D ** -0.5, prescale=prescale)
+            assert np.isfinite(O).all() and np.abs(O - Pm @ V).max() < 1e-10, (D, Skv, prescale)
+            assert nb >= (2 if spike and Skv >= 200 else 1)
+        O0, _ = attention_wave_sim_v3(Q, K, V, D ** -0.5, thr=0.0)      # THR = 0 and THR = 8 agree to rounding
+        assert np.abs(O0 - O).max() < 1e-10
+
+
 def test_bvh_build_and_traversal_core_vs_brute_force(hostemu):
     """SURVEY row f-1 groundwork: the host BVH builder of the product library (dm_bvh_build) and the traversal core
     the HIP kernels share (csrc/bvh_core.h, run here through tests/hostemu) against the oracle's brute-force

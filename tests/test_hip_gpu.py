@@ -217,8 +217,19 @@ ATTN_CASES = [  # (B, heads, Sq, Skv, D)
     (1, 2, 100, 130, 128)]
 
 
+ATTN_VARIANTS = ["v3", "v3l", "v3s", "dma", "staged"]
+
+
+@pytest.fixture
+def attn_variant(request):
+    hipops.attention_select(request.param)
+    yield request.param
+    hipops.attention_select(None)
+
+
+@pytest.mark.parametrize("attn_variant", ATTN_VARIANTS, indirect=True)
 @pytest.mark.parametrize("B,h,Sq,Skv,D", ATTN_CASES)
-def test_attention_vs_fp32_reference(dev, B, h, Sq, Skv, D):
+def test_attention_vs_fp32_reference(dev, B, h, Sq, Skv, D, attn_variant):
     torch.manual_seed(0)
     C = h * D
     q = torch.randn(B, Sq, C); k = torch.randn(B, Skv, C); v = torch.randn(B, Skv, C)
@@ -237,13 +248,16 @@ def test_attention_vs_fp32_reference(dev, B, h, Sq, Skv, D):
     assert (out - ref).abs().mean().item() < 2e-3
 
 
-def test_attention_online_softmax_rescale_branch(dev):
-    """spiked keys late in the sequence force large running-max jumps (guide rule 26)."""
+@pytest.mark.parametrize("attn_variant", ATTN_VARIANTS, indirect=True)
+def test_attention_online_softmax_rescale_branch(dev, attn_variant):
+    """spiked keys late in the sequence force large running-max jumps (guide rule 26); a row whose first tile is dominated
+    by a very negative score exercises the forced first-tile re-base of the v3 kernels."""
     torch.manual_seed(1)
     B, h, S, D = 1, 2, 512, 64
     q = torch.randn(B, S, h * D); k = torch.randn(B, S, h * D); v = torch.randn(B, S, h * D)
     k[:, 300] = q[:, 17] * 4.0
     k[:, 450] = q[:, 99] * 8.0
+    k[:, :64] = -q[:, 5:6] * 3.0
     qb, kb, vb = (t.to(dev).bfloat16() for t in (q, k, v))
     out = hipops.attention(qb, kb, vb.transpose(1, 2).contiguous(), h).float().cpu()
     qf, kf, vf = (t.float().cpu().view(B, S, h, D).transpose(1, 2) for t in (qb, kb, vb))

@@ -3,6 +3,9 @@
 //   tools/_abi_pmc conv  B H W Cin Cout iters        3x3 conv, stride 1, pad 1, NHWC bf16
 //   tools/_abi_pmc attn  B heads Sq Skv D iters      attention forward, bf16
 //   tools/_abi_pmc shade N n_env iters               split-sum shade forward + backward over N covered pixels
+//   tools/_abi_pmc shadef FILE iters                 the same on a dumped G-buffer + packed atlas (tools/r2_probe.py writes
+//                                                    gpurun_out/shade_case_*.bin: the step's REAL coherent G-buffer)
+//   (attn takes an optional 8th argument: the kernel variant name for dm_attention_select)
 // Prints one JSON line with the HIP-event time per launch.  See tools/pmc_abi.sh for the rocprofv3 passes.
 #include <hip/hip_runtime.h>
 
@@ -130,8 +133,60 @@ static int run_shade(long long N, int n_env, int iters) {
     return 0;
 }
 
+// File layout (little endian, written by tools/r2_probe.py): int64 header[16] = {magic 0x444d5348, N, views, HW, n_mips, diff_res,
+// lut_res, texel_format, spec_env_stride, diff_env_stride, spec_bytes, diff_bytes, has_pairs, 0, 0, 0}; int64 mip_off[8];
+// int32 mip_res[8]; then nrm[3][N] view[3][N] feat[5][N] dcol[3][N] (f32), pix[N] env_of_view[views] (i32), spec, diff,
+// fg_lut[lut_res^2*2] f32, fg_pairs[lut_res*(lut_res+1)*4] f32 (if has_pairs).
+static int run_shade_file(const char* path, int iters) {
+    FILE* fh = fopen(path, "rb");
+    if (!fh) { printf("cannot open %s\n", path); return 1; }
+    long long hd[16], mip_off[8];
+    int mip_res[8];
+    if (fread(hd, 8, 16, fh) != 16 || hd[0] != 0x444d5348LL || fread(mip_off, 8, 8, fh) != 8 || fread(mip_res, 4, 8, fh) != 8) return 1;
+    const long long N = hd[1];
+    const int views = (int)hd[2], HW = (int)hd[3];
+    auto rd = [&](size_t bytes, void** dptr) -> int {
+        std::vector<char> h(bytes);
+        if (fread(h.data(), 1, bytes, fh) != bytes) { printf("short read\n"); return 1; }
+        return upload(dptr, h);
+    };
+    void *dn, *dv, *df, *dg, *dp, *denv, *dspec, *ddiff, *dlut, *dpairs = nullptr, *dcount, *dcol, *ddf;
+    if (rd(12 * N, &dn) || rd(12 * N, &dv) || rd(20 * N, &df) || rd(12 * N, &dg) || rd(4 * N, &dp) || rd(4 * views, &denv) ||
+        rd(hd[10], &dspec) || rd(hd[11], &ddiff) || rd((size_t)hd[6] * hd[6] * 8, &dlut))
+        return 2;
+    if (hd[12] && rd((size_t)hd[6] * (hd[6] + 1) * 16, &dpairs)) return 2;
+    fclose(fh);
+    dm_env_atlas at;
+    memset(&at, 0, sizeof(at));
+    at.spec = (const float*)dspec; at.diff = (const float*)ddiff; at.fg_lut = (const float*)dlut; at.fg_pairs = (const float*)dpairs;
+    at.spec_env_stride = hd[8]; at.diff_env_stride = hd[9];
+    for (int i = 0; i < 8; ++i) { at.mip_off[i] = mip_off[i]; at.mip_res[i] = mip_res[i]; }
+    at.n_mips = (int)hd[4]; at.diff_res = (int)hd[5]; at.lut_res = (int)hd[6]; at.texel_format = (int)hd[7];
+    at.min_rough_mip = 0.08f; at.max_rough_mip = 0.5f;
+    dm_mat_cfg mc = {0.0f, 0.9f, 0.1f, 0.95f};
+    std::vector<int> hcount(1, (int)N);
+    if (upload(&dcount, hcount)) return 2;
+    CK(hipMalloc(&dcol, 3 * N * 4)); CK(hipMalloc(&ddf, 5 * N * 4));
+    float ms_f, ms_b;
+    int rc = timed(iters, &ms_f, [&] {
+        return dm_shade_fwd(&at, &mc, (float*)dn, 1, N, (float*)dv, 1, N, (float*)df, 1, N, (int*)dp, (int*)denv, (int*)dcount, N, HW,
+                            (float*)dcol, 1, N, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+    });
+    if (rc) return rc;
+    rc = timed(iters, &ms_b, [&] {
+        return dm_shade_bwd(&at, &mc, (float*)dn, 1, N, (float*)dv, 1, N, (float*)df, 1, N, (int*)dp, (int*)denv, (int*)dcount, N, HW,
+                            (float*)dg, 1, N, (float*)ddf, 1, N, nullptr);
+    });
+    if (rc) return rc;
+    printf("{\"op\":\"shadef\",\"N\":%lld,\"texel_format\":%d,\"fg_pairs\":%d,\"fwd_ms\":%.4f,\"bwd_ms\":%.4f,\"fwd_GBps\":%.0f,\"bwd_GBps\":%.0f,\"alg_fwd_MB\":%.1f,\"alg_bwd_MB\":%.1f}\n",
+           N, at.texel_format, dpairs ? 1 : 0, ms_f, ms_b, 56.0 * N / (ms_f * 1e-3) / 1e9, 76.0 * N / (ms_b * 1e-3) / 1e9, 56.0 * N / 1e6, 76.0 * N / 1e6);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc >= 8 && !strcmp(argv[1], "conv")) return run_conv(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]));
+    if (argc >= 9 && !strcmp(argv[1], "attn") && dm_attention_select(argv[8])) { printf("unknown attention variant %s\n", argv[8]); return 1; }
+    if (argc >= 4 && !strcmp(argv[1], "shadef")) return run_shade_file(argv[2], atoi(argv[3]));
     if (argc >= 8 && !strcmp(argv[1], "attn")) return run_attn(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]));
     if (argc >= 5 && !strcmp(argv[1], "shade")) return run_shade(atoll(argv[2]), atoi(argv[3]), atoi(argv[4]));
     printf("usage: %s conv B H W Cin Cout iters | attn B heads Sq Skv D iters | shade N n_env iters\n", argv[0]);
