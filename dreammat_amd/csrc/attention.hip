@@ -526,8 +526,8 @@ __device__ __forceinline__ int attn_swap23(int r) { return (r & ~12) | ((r & 4) 
 
 // VLATE: the V^T fragments are read inside the P.V loop (16 VGPRs at a time) instead of ahead of the softmax (32 VGPRs
 // across it); with PRESCALE that is the difference between 2 and 3 resident waves per SIMD.
-template <int DP, bool PRESCALE, bool VLATE>
-__global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a) {
+template <int DP, bool PRESCALE, bool VLATE, bool PIPE>
+__global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(AttnArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // __amdgpu_buffer_rsrc_t does not exist in the host pass (the stub needs no body)
     static_assert(DP == 64 || DP == 128, "power-of-two row sizes only");
     constexpr int KSTEPS = DP / 16, DT = DP / 32;
@@ -639,10 +639,9 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a) 
     float m_run = 0.f, l_run = 0.f;                      // PRESCALE: cinit == -m_run at all times
     bf16x8 pf[4];
 
-    auto tile = [&](int j, int stage, bool first, auto masked_tag) {
-        constexpr bool MASKED = decltype(masked_tag)::value;
+    // S^T = K.Q^T (+ C operand) of the tile in `stage`
+    auto qk = [&](int stage, f32x16 (&s)[2]) {
         const char* kb = smem + stage * STAGE;
-        const char* vb = kb + KBYTES;
         bf16x8 kf[2][KSTEPS];
         auto read_k = [&](int t) {
             const int row = 32 * t + l31;
@@ -652,8 +651,7 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a) 
         };
         read_k(0);
         if (!VLATE) read_k(1);
-        f32x16 s[2];
-        __builtin_amdgcn_s_setprio(1);
+        if (!PIPE) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (VLATE && t == 0) read_k(1);
@@ -662,7 +660,13 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a) 
             for (int kk = 1; kk < KSTEPS; ++kk)
                 s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][kk], qf[kk], s[t], 0, 0, 0);
         }
-        __builtin_amdgcn_s_setprio(0);
+        if (!PIPE) __builtin_amdgcn_s_setprio(0);
+    };
+    // softmax of tile j (scores in `s`) and O^T += V^T.P^T.  PIPE: `sn` holds the scores of tile j+1, computed against the
+    // C operand as it was BEFORE this tile's possible re-base -- the re-base path shifts them as well.
+    auto softmax_pv = [&](int j, int stage, bool first, f32x16 (&s)[2], f32x16 (&sn)[2], bool have_next, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const char* vb = smem + stage * STAGE + KBYTES;
         bf16x8 vf[DT][4];
         auto read_v = [&](int dt) {
             const int row = 32 * dt + l31;
@@ -687,12 +691,15 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a) 
                     }
             }
         }
-        // ---- row maximum of this tile (relative to the running maximum when PRESCALE)
-        float mx = fmaxf(s[0][0], s[1][0]);
+        // ---- row maximum of this tile (relative to the running maximum when PRESCALE): four independent chains
+        float mq[4];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
+        for (int c = 0; c < 4; ++c) mq[c] = fmaxf(s[0][c], s[1][c]);
+#pragma unroll
+        for (int r = 4; r < 16; ++r) mq[r & 3] = fmaxf(fmaxf(mq[r & 3], s[0][r]), s[1][r]);
+        float mx = fmaxf(fmaxf(mq[0], mq[1]), fmaxf(mq[2], mq[3]));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float psum = 0.f;
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};            // four independent partial row sums (a single chain of 32 dependent adds stalls)
         if (PRESCALE) {
             if (first || !__all(mx <= THR)) {            // wave-uniform; the previous tile's P.V is complete
                 const float delta = first ? mx : fmaxf(mx, 0.f);
@@ -705,6 +712,10 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a) 
                     for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { s[0][r] -= delta; s[1][r] -= delta; cinit[r] = -m_run; }
+                if (PIPE && have_next) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { sn[0][r] -= delta; sn[1][r] -= delta; }
+                }
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -712,7 +723,7 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a) 
                 for (int r = 0; r < 16; ++r) {
                     const float p = __builtin_amdgcn_exp2f(s[t][r]);
                     s[t][r] = p;
-                    psum += p;
+                    ps[r & 3] += p;
                 }
         } else {
             mx *= a.scale_log2;
@@ -732,10 +743,10 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a) 
                 for (int r = 0; r < 16; ++r) {
                     const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], a.scale_log2, -m_run));
                     s[t][r] = p;
-                    psum += p;
+                    ps[r & 3] += p;
                 }
         }
-        l_run += psum;
+        l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int t = ks >> 1, u = ks & 1;
@@ -763,26 +774,177 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a) 
     if (n_tiles == 1) issue(0, 0, std::true_type{}); else issue(0, 0, std::false_type{});
     if (n_tiles == 2) issue(1, 1, std::true_type{}); else if (n_tiles > 2) issue(1, 1, std::false_type{});
     int stage = 0, j = 0;
-    // main loop: tile j computes while tiles j+1, j+2 are in flight; every tile touched here is a full one
-    for (; j + 3 < n_tiles; ++j) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-        __builtin_amdgcn_s_barrier();
-        int st2 = stage + 2; if (st2 >= 3) st2 -= 3;
-        issue(j + 2, st2, std::false_type{});
-        tile(j, stage, j == 0, std::false_type{});
-        stage = stage + 1; if (stage >= 3) stage = 0;
-    }
-    // tail: at most three tiles; issues the (possibly ragged) last tile guarded, masks the last tile
-    for (; j < n_tiles; ++j) {
-        if (j + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+    f32x16 sA[2], sB[2];
+    if (!PIPE) {
+        // main loop: tile j computes while tiles j+1, j+2 are in flight; every tile touched here is a full one
+        for (; j + 3 < n_tiles; ++j) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+            __builtin_amdgcn_s_barrier();
+            int st2 = stage + 2; if (st2 >= 3) st2 -= 3;
+            issue(j + 2, st2, std::false_type{});
+            qk(stage, sA);
+            softmax_pv(j, stage, j == 0, sA, sA, false, std::false_type{});
+            stage = stage + 1; if (stage >= 3) stage = 0;
+        }
+        // tail: at most three tiles; issues the (possibly ragged) last tile guarded, masks the last tile
+        for (; j < n_tiles; ++j) {
+            if (j + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (j + 2 < n_tiles) {
+                int st2 = stage + 2; if (st2 >= 3) st2 -= 3;
+                issue(j + 2, st2, std::true_type{});
+            }
+            qk(stage, sA);
+            softmax_pv(j, stage, j == 0, sA, sA, false, std::true_type{});
+            stage = stage + 1; if (stage >= 3) stage = 0;
+        }
+    } else {
+        // Two-phase software pipeline (PRESCALE only): every MFMA of the loop is issued with independent VALU work behind it.
+        //   phase A:  S^T(j+1) = K(j+1).Q'^T   [8 MFMAs]  beside  exp / row-sum / bf16 convert of tile j   (-> P(j))
+        //   phase B:  O^T += V^T(j).P(j)^T      [8 MFMAs]  beside  the row maximum of tile j+1
+        // so the re-base decision of tile j+1 (needs its maximum) is ready at the top of the next iteration, before that
+        // tile's exponentials and before S^T(j+2) is started against the then-current C operand.  Two named score register
+        // sets alternate (no copies).  `sched_barrier(0)` pins one MFMA + its slice of VALU work per region: an in-order wave
+        // can only overlap the two pipes if they alternate in program order.
+        // K(j+1) must have landed one iteration early: loads are issued K first, V^T second, so waiting for all but the
+        // newest V_INSTR of them leaves only V^T(j+1) in flight.
+        static_assert(!PIPE || (PRESCALE && DP == 64), "pipelined form: D = 64 with the prologue Q scaling");
+        auto mask_tile = [&](int jt, f32x16 (&s)[2]) {
+            if ((jt + 1) * kKvTile > a.Skv) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int kv = jt * kKvTile + 32 * t + 16 * (r >> 3) + 8 * hi + 4 * ((r >> 2) & 1) + (r & 3);
+                        if (kv >= a.Skv) s[t][r] = -INFINITY;
+                    }
+            }
+        };
+        auto row_max = [&](const f32x16 (&s)[2]) {
+            float mq[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mq[c] = fmaxf(s[0][c], s[1][c]);
+#pragma unroll
+            for (int r = 4; r < 16; ++r) mq[r & 3] = fmaxf(fmaxf(mq[r & 3], s[0][r]), s[1][r]);
+            const float mx = fmaxf(fmaxf(mq[0], mq[1]), fmaxf(mq[2], mq[3]));
+            return fmaxf(mx, __shfl_xor(mx, 32));
+        };
+        if (n_tiles > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (j + 2 < n_tiles) {
+        qk(0, sA);
+        if (n_tiles == 1) mask_tile(0, sA);
+        float mx_cur = row_max(sA);
+        auto iter = [&](f32x16 (&cur)[2], f32x16 (&nxt)[2], auto tail_tag) {
+            constexpr bool TAIL = decltype(tail_tag)::value;
+            const bool have_next = !TAIL || j + 1 < n_tiles;
+            if (have_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V_INSTR) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            int st1 = stage + 1; if (st1 >= 3) st1 -= 3;
             int st2 = stage + 2; if (st2 >= 3) st2 -= 3;
-            issue(j + 2, st2, std::true_type{});
+            if (!TAIL) issue(j + 2, st2, std::false_type{});
+            else if (j + 2 < n_tiles) issue(j + 2, st2, std::true_type{});
+            // ---- K fragments of tile j+1 (their LDS latency hides under the re-base test and the first exponentials)
+            const char* kb = smem + st1 * STAGE;
+            const char* vb = smem + stage * STAGE + KBYTES;
+            bf16x8 kf[2][KSTEPS];
+            auto read_k = [&](int t) {
+                const int row = 32 * t + l31;
+#pragma unroll
+                for (int kk = 0; kk < KSTEPS; ++kk)
+                    kf[t][kk] = *reinterpret_cast<const bf16x8*>(kb + row * KROW + (((2 * kk + hi) ^ kswz(row)) << 4));
+            };
+            auto read_v = [&](bf16x8 (&vf)[4], int dt) {
+                const int row = 32 * dt + l31, sw = (row >> 1) & 7;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    vf[ks] = *reinterpret_cast<const bf16x8*>(vb + row * VROW + (((2 * ks + hi) ^ sw) << 4));
+            };
+            if (have_next) read_k(0);
+            // ---- re-base of tile j (rare, wave-uniform): nothing of tile j+1 exists yet, so only tile j's scores move
+            const bool first = j == 0;
+            if (first || !__all(mx_cur <= THR)) {
+                const float delta = first ? mx_cur : fmaxf(mx_cur, 0.f);
+                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+                m_run += delta;
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < DT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { cur[0][r] -= delta; cur[1][r] -= delta; cinit[r] = -m_run; }
+            }
+            // ---- phase A
+            float ps[4] = {0.f, 0.f, 0.f, 0.f};
+            bf16x8 vf0[4], vf1[4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int t = i >> 2, q4 = i & 3;
+                if (have_next) {
+                    if (i == 1) read_k(1);                // second half's fragments: needed from slice 4 on
+                    nxt[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][q4], qf[q4], q4 == 0 ? cinit : nxt[t], 0, 0, 0);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float pexp = __builtin_amdgcn_exp2f(cur[t][4 * q4 + c]);
+                    cur[t][4 * q4 + c] = pexp;
+                    ps[c] += pexp;
+                }
+                {   // registers 4*q4 .. +3 of tile half t are k-slots e = 4*(q4&1) .. +3 of k-step ks = 2t + (q4>>1)
+                    const int ks = 2 * t + (q4 >> 1), e0 = 4 * (q4 & 1);
+                    f32x2 lo = {cur[t][4 * q4], cur[t][4 * q4 + 1]}, hi2 = {cur[t][4 * q4 + 2], cur[t][4 * q4 + 3]};
+                    bf16x2 plo = __builtin_convertvector(lo, bf16x2), phi = __builtin_convertvector(hi2, bf16x2);
+                    pf[ks][e0] = plo[0]; pf[ks][e0 + 1] = plo[1]; pf[ks][e0 + 2] = phi[0]; pf[ks][e0 + 3] = phi[1];
+                }
+                if (i == 6) read_v(vf0, 0);               // V^T fragments of tile j: first 32 output rows
+                // keep the four row-sum chains where they are: left alone, the SLP vectoriser gathers all 32 adds into 16
+                // v_pk_add_f32 behind the last slice, where no MFMA covers them
+                asm volatile("" : "+v"(ps[0]), "+v"(ps[1]), "+v"(ps[2]), "+v"(ps[3]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+            // ---- phase B
+            if (TAIL && have_next) mask_tile(j + 1, nxt);
+            float mq[4];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int dt = i >> 2, ks = i & 3;
+                if (i == 0) read_v(vf1, 1);
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt == 0 ? vf0[ks] : vf1[ks], pf[ks], o[dt], 0, 0, 0);
+                if (have_next) {                          // registers 2i, 2i+1 of both halves per slice; four chains
+                    const int r = 2 * i;
+                    if (i < 2) {
+                        mq[r & 3] = fmaxf(nxt[0][r], nxt[1][r]);
+                        mq[(r + 1) & 3] = fmaxf(nxt[0][r + 1], nxt[1][r + 1]);
+                    } else {
+                        mq[r & 3] = fmaxf(fmaxf(mq[r & 3], nxt[0][r]), nxt[1][r]);
+                        mq[(r + 1) & 3] = fmaxf(fmaxf(mq[(r + 1) & 3], nxt[0][r + 1]), nxt[1][r + 1]);
+                    }
+                    // opaque to the re-association pass, which otherwise rebuilds the max tree behind the last MFMA
+                    asm volatile("" : "+v"(mq[r & 3]), "+v"(mq[(r + 1) & 3]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (have_next) {
+                const float mx = fmaxf(fmaxf(mq[0], mq[1]), fmaxf(mq[2], mq[3]));
+                mx_cur = fmaxf(mx, __shfl_xor(mx, 32));
+            }
+            stage = st1;
+            ++j;
+        };
+        while (j + 4 < n_tiles) {                        // two full tiles per trip (iter advances j): named register sets
+            iter(sA, sB, std::false_type{});
+            iter(sB, sA, std::false_type{});
         }
-        tile(j, stage, j == 0, std::true_type{});
-        stage = stage + 1; if (stage >= 3) stage = 0;
+        bool flip = false;
+        while (j < n_tiles) {
+            if (!flip) iter(sA, sB, std::true_type{});
+            else iter(sB, sA, std::true_type{});
+            flip = !flip;
+        }
     }
 
     float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -806,12 +968,12 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a) 
 #endif
 }
 
-template <int DP, bool PRESCALE, bool VLATE>
+template <int DP, bool PRESCALE, bool VLATE, bool PIPE>
 int launch_attn_v3(const AttnArgs& a, hipStream_t stream) {
     constexpr int LDS = 3 * (kKvTile * DP * 2 + DP * kKvTile * 2);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_fwd_v3<DP, PRESCALE, VLATE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_fwd_v3<DP, PRESCALE, VLATE, PIPE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -819,7 +981,7 @@ int launch_attn_v3(const AttnArgs& a, hipStream_t stream) {
     const long long n_blocks = (long long)dm_div_up(a.Sq, kWaves * kQRowsPerWave) * a.B * a.Hh;
     if (n_blocks > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
     DM_ENTER();
-    hipLaunchKernelGGL((k_attn_fwd_v3<DP, PRESCALE, VLATE>), dim3((unsigned)n_blocks), dim3(256), LDS, stream, a);
+    hipLaunchKernelGGL((k_attn_fwd_v3<DP, PRESCALE, VLATE, PIPE>), dim3((unsigned)n_blocks), dim3(256), LDS, stream, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? DM_OK : (int)e;
 }
@@ -827,6 +989,7 @@ int launch_attn_v3(const AttnArgs& a, hipStream_t stream) {
 static int g_attn_mode = -1;
 static int attn_mode_from_name(const char* e) {
     if (!e || !strcmp(e, "v3")) return 3;
+    if (!strcmp(e, "v3p")) return 5;
     if (!strcmp(e, "v3l")) return 4;
     if (!strcmp(e, "v3s")) return 2;
     if (!strcmp(e, "dma")) return 1;
@@ -921,16 +1084,20 @@ int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* ou
     a.vt_bs = vt_bs; a.vt_hs = vt_hs; a.vt_ds = vt_ds; a.o_bs = o_bs; a.o_ss = o_ss; a.o_hs = o_hs;
     a.B = B; a.Hh = Hh; a.Sq = Sq; a.Skv = Skv; a.D = D;
     a.scale_log2 = scale * 1.4426950408889634f;
-    // Kernel choice: dm_attention_select() / DREAMMAT_ATTN_KERNEL = v3 (default: prologue Q scaling, 2 waves per SIMD) |
-    // v3l (v3 with late V^T reads, 3 waves per SIMD) | v3s (v3 without the Q scaling) | dma (round-1 kernel) | staged
+    // Kernel choice: dm_attention_select() / DREAMMAT_ATTN_KERNEL = v3 (prologue Q scaling, 2 waves per SIMD) |
+    // v3l (v3 with late fragment reads, 3 waves per SIMD) | v3p (two-phase software pipeline for Skv >= 512, v3l below) |
+    // v3s (v3 without the Q scaling) | dma (round-1 kernel) | staged
     // (register-staged): A/B measurements and regression tests.  D = 40/80/160 heads always use the staged kernel.
     const int mode = attn_mode();
     if (mode >= 2 && attn_v3_ok(a) && (D <= 64 || (D > 96 && D <= 128))) {
         if (D <= 64) {
-            if (mode == 4) return launch_attn_v3<64, true, true>(a, stream);
-            return mode == 3 ? launch_attn_v3<64, true, false>(a, stream) : launch_attn_v3<64, false, false>(a, stream);
+            // the pipelined form pays off on long sequences; its (register-starved) tail handles the last four tiles
+            if (mode == 5 && a.Skv >= 8 * kKvTile) return launch_attn_v3<64, true, true, true>(a, stream);
+            if (mode == 5) return launch_attn_v3<64, true, true, false>(a, stream);
+            if (mode == 4) return launch_attn_v3<64, true, true, false>(a, stream);
+            return mode == 3 ? launch_attn_v3<64, true, false, false>(a, stream) : launch_attn_v3<64, false, false, false>(a, stream);
         }
-        return mode == 2 ? launch_attn_v3<128, false, false>(a, stream) : launch_attn_v3<128, true, false>(a, stream);
+        return mode == 2 ? launch_attn_v3<128, false, false, false>(a, stream) : launch_attn_v3<128, true, false, false>(a, stream);
     }
     const bool use_dma = mode >= 1;
     if (D <= 64) return use_dma ? launch_attn_dma<64>(a, stream) : launch_attn<64>(a, stream);

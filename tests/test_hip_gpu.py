@@ -217,7 +217,7 @@ ATTN_CASES = [  # (B, heads, Sq, Skv, D)
     (1, 2, 100, 130, 128)]
 
 
-ATTN_VARIANTS = ["v3", "v3l", "v3s", "dma", "staged"]
+ATTN_VARIANTS = ["v3p", "v3", "v3l", "v3s", "dma", "staged"]
 
 
 @pytest.fixture

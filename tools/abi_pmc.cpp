@@ -4,7 +4,7 @@
 //   tools/_abi_pmc attn  B heads Sq Skv D iters      attention forward, bf16
 //   tools/_abi_pmc shade N n_env iters               split-sum shade forward + backward over N covered pixels
 //   tools/_abi_pmc shadef FILE iters                 the same on a dumped G-buffer + packed atlas (tools/r2_probe.py writes
-//                                                    gpurun_out/shade_case_*.bin: the step's REAL coherent G-buffer)
+//                                                    /tmp/shade_case_*.bin: the step's REAL coherent G-buffer)
 //   (attn takes an optional 8th argument: the kernel variant name for dm_attention_select)
 // Prints one JSON line with the HIP-event time per launch.  See tools/pmc_abi.sh for the rocprofv3 passes.
 #include <hip/hip_runtime.h>

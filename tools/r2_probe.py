@@ -2,7 +2,7 @@
   * attention: every kernel variant (dm_attention_select) x the UNet's shapes, TF/s + max error vs an fp32 reference;
   * shade: every atlas texel format x FG pair table on/off on the bench scene's REAL G-buffer (8 views @512^2 of the
     50 880-triangle sphere, 5 environments), forward + backward, GB/s of the algorithmic 56 / 76 B per pixel; the cases
-    are also dumped to gpurun_out/shade_case_<fmt>.bin for the counter passes of tools/_abi_pmc (`shadef`).
+    are also dumped to $DM_SHADE_CASE_DIR (default /tmp)/shade_case_<fmt>.bin for the counter passes of tools/_abi_pmc (`shadef`).
 Usage: python tools/r2_probe.py [--rounds 5] [--iters 10] [--skip-attn] [--skip-shade]      -> gpurun_out/r2_probe.json
 """
 import argparse
@@ -47,7 +47,7 @@ def ab(fns, rounds, iters):
 
 
 def attention_section(a, res):
-    variants = ["v3", "v3l", "v3s", "dma", "staged"]
+    variants = ["v3p", "v3", "v3l", "v3s", "dma", "staged"]
     shapes = [(24, 5, 4096, 4096, 64), (24, 10, 1024, 1024, 64), (24, 20, 256, 256, 64), (24, 20, 64, 64, 64),
               (24, 5, 4096, 77, 64), (24, 10, 1024, 77, 64), (3, 5, 4096, 4096, 64), (48, 5, 16384, 16384, 64)]
     if a.quick:
@@ -175,7 +175,7 @@ def shade_section(a, res):
         print(json.dumps(r), flush=True)
     for texel in ("fp32", "rgb18e8"):
         at = atlases[texel]
-        dump_shade_case(os.path.join(OUT, f"shade_case_{texel}.bin"), at, gb.nrm, gb.view, feat, dcol, gb.pix_idx[:N],
+        dump_shade_case(os.path.join(os.environ.get("DM_SHADE_CASE_DIR", "/tmp"), f"shade_case_{texel}.bin"), at, gb.nrm, gb.view, feat, dcol, gb.pix_idx[:N],
                         env_of_view, H * W, texel != "fp32")
 
 
