@@ -71,10 +71,10 @@ _SIGS = {
     "dm_hashgrid_bwd": (c_int, [c_void_p, _LL, _LL, c_void_p, _LL, c_void_p, _LL, _LL, c_int, POINTER(c_float),
                                 POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32), c_float, c_void_p, c_void_p]),
     "dm_shade_fwd": (c_int, [POINTER(EnvAtlasStruct), POINTER(MatCfgStruct), c_void_p, _LL, _LL, c_void_p, _LL, _LL,
-                             c_void_p, _LL, _LL, c_void_p, c_void_p, c_void_p, _LL, c_int, c_void_p, _LL, _LL,
+                             c_void_p, _LL, _LL, c_void_p, c_void_p, c_void_p, _LL, c_int, c_int, c_void_p, _LL, _LL,
                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dm_shade_bwd": (c_int, [POINTER(EnvAtlasStruct), POINTER(MatCfgStruct), c_void_p, _LL, _LL, c_void_p, _LL, _LL,
-                             c_void_p, _LL, _LL, c_void_p, c_void_p, c_void_p, _LL, c_int, c_void_p, _LL, _LL,
+                             c_void_p, _LL, _LL, c_void_p, c_void_p, c_void_p, _LL, c_int, c_int, c_void_p, _LL, _LL,
                              c_void_p, _LL, _LL, c_void_p]),
     "dm_matreg_fwd": (c_int, [c_void_p, _LL, _LL, c_void_p, _LL, _LL, c_void_p, _LL, c_void_p, c_void_p]),
     "dm_matreg_bwd": (c_int, [c_void_p, _LL, _LL, c_void_p, _LL, _LL, c_void_p, _LL, c_float, c_void_p, _LL, _LL,

@@ -535,6 +535,7 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
     constexpr int KBYTES = kKvTile * KROW, VBYTES = DP * VROW, STAGE = KBYTES + VBYTES;
     constexpr int KCH = KROW / 16, KRPI = 64 / KCH, K_INSTR = kKvTile / KRPI / 4, V_INSTR = DP / 8 / 4;
     constexpr int L = K_INSTR + V_INSTR;
+    constexpr int NST = PIPE ? 4 : 3;                   // LDS ring depth (the pipelined form needs K one iteration earlier)
     constexpr int OOB = 0x40000000;                     // beyond any num_records the launcher admits
     constexpr float THR = 8.0f;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -564,7 +565,7 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
     // ragged sequences: whatever an out-of-range DMA lane does to its LDS slot (writes zero / leaves it), the slot must
     // hold finite numbers, because masked probabilities are exact zeros and 0 x NaN would poison O
     if ((a.Skv & (kKvTile - 1)) != 0 || a.D != DP) {
-        for (int o = tid * 16; o < 3 * STAGE; o += 256 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
+        for (int o = tid * 16; o < NST * STAGE; o += 256 * 16) *reinterpret_cast<uint4*>(smem + o) = make_uint4(0, 0, 0, 0);
         __syncthreads();
     }
 
@@ -773,6 +774,9 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
     // prologue: tiles 0 and 1 (the last tile of the sequence is always issued through the guarded form)
     if (n_tiles == 1) issue(0, 0, std::true_type{}); else issue(0, 0, std::false_type{});
     if (n_tiles == 2) issue(1, 1, std::true_type{}); else if (n_tiles > 2) issue(1, 1, std::false_type{});
+    if (PIPE) {
+        if (n_tiles == 3) issue(2, 2, std::true_type{}); else if (n_tiles > 3) issue(2, 2, std::false_type{});
+    }
     int stage = 0, j = 0;
     f32x16 sA[2], sB[2];
     if (!PIPE) {
@@ -830,7 +834,8 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
             const float mx = fmaxf(fmaxf(mq[0], mq[1]), fmaxf(mq[2], mq[3]));
             return fmaxf(mx, __shfl_xor(mx, 32));
         };
-        if (n_tiles > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+        if (n_tiles > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");      // tiles 1, 2 may still be in flight
+        else if (n_tiles > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         qk(0, sA);
@@ -839,13 +844,15 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
         auto iter = [&](f32x16 (&cur)[2], f32x16 (&nxt)[2], auto tail_tag) {
             constexpr bool TAIL = decltype(tail_tag)::value;
             const bool have_next = !TAIL || j + 1 < n_tiles;
-            if (have_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V_INSTR) : "memory");
+            // needed now: all of tile j and K(j+1).  Issue order is K, V^T per tile, so in the steady state everything except
+            // V^T(j+1) and tile j+2 (issued one iteration ago) must have landed; the tail waits more than necessary
+            if (!TAIL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V_INSTR + L) : "memory");
+            else if (have_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V_INSTR) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            int st1 = stage + 1; if (st1 >= 3) st1 -= 3;
-            int st2 = stage + 2; if (st2 >= 3) st2 -= 3;
-            if (!TAIL) issue(j + 2, st2, std::false_type{});
-            else if (j + 2 < n_tiles) issue(j + 2, st2, std::true_type{});
+            const int st1 = (stage + 1) & 3, st3 = (stage + 3) & 3;
+            if (!TAIL) issue(j + 3, st3, std::false_type{});
+            else if (j + 3 < n_tiles) issue(j + 3, st3, std::true_type{});
             // ---- K fragments of tile j+1 (their LDS latency hides under the re-base test and the first exponentials)
             const char* kb = smem + st1 * STAGE;
             const char* vb = smem + stage * STAGE + KBYTES;
@@ -935,7 +942,7 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
             stage = st1;
             ++j;
         };
-        while (j + 4 < n_tiles) {                        // two full tiles per trip (iter advances j): named register sets
+        while (j + 5 < n_tiles) {                        // two full tiles per trip (iter advances j): named register sets
             iter(sA, sB, std::false_type{});
             iter(sB, sA, std::false_type{});
         }
@@ -970,7 +977,7 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
 
 template <int DP, bool PRESCALE, bool VLATE, bool PIPE>
 int launch_attn_v3(const AttnArgs& a, hipStream_t stream) {
-    constexpr int LDS = 3 * (kKvTile * DP * 2 + DP * kKvTile * 2);
+    constexpr int LDS = (PIPE ? 4 : 3) * (kKvTile * DP * 2 + DP * kKvTile * 2);
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_fwd_v3<DP, PRESCALE, VLATE, PIPE>),
@@ -1085,14 +1092,14 @@ int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* ou
     a.B = B; a.Hh = Hh; a.Sq = Sq; a.Skv = Skv; a.D = D;
     a.scale_log2 = scale * 1.4426950408889634f;
     // Kernel choice: dm_attention_select() / DREAMMAT_ATTN_KERNEL = v3 (prologue Q scaling, 2 waves per SIMD) |
-    // v3l (v3 with late fragment reads, 3 waves per SIMD) | v3p (two-phase software pipeline for Skv >= 512, v3l below) |
+    // v3l (v3 with late fragment reads, 3 waves per SIMD) | v3p (two-phase software pipeline for Skv >= 1024, v3l below) |
     // v3s (v3 without the Q scaling) | dma (round-1 kernel) | staged
     // (register-staged): A/B measurements and regression tests.  D = 40/80/160 heads always use the staged kernel.
     const int mode = attn_mode();
     if (mode >= 2 && attn_v3_ok(a) && (D <= 64 || (D > 96 && D <= 128))) {
         if (D <= 64) {
             // the pipelined form pays off on long sequences; its (register-starved) tail handles the last four tiles
-            if (mode == 5 && a.Skv >= 8 * kKvTile) return launch_attn_v3<64, true, true, true>(a, stream);
+            if (mode == 5 && a.Skv >= 16 * kKvTile) return launch_attn_v3<64, true, true, true>(a, stream);
             if (mode == 5) return launch_attn_v3<64, true, true, false>(a, stream);
             if (mode == 4) return launch_attn_v3<64, true, true, false>(a, stream);
             return mode == 3 ? launch_attn_v3<64, true, false, false>(a, stream) : launch_attn_v3<64, false, false, false>(a, stream);

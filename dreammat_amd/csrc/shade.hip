@@ -27,6 +27,8 @@ struct ShadeArgs {
     const int* env_of_view;  // [B]
     const int* n_dev;        // device count of rows
     int HW;
+    int n_views;             // entries of env_of_view
+    int offsets32;           // every element offset of the row tensors fits 31 bits (32-bit lane offsets in the fast loop)
     StridedOut color;        // [N,3]
     // optional debug outputs (null => skipped); rows of 3/3/3/3/1/1 floats, dense [N,C]
     float* albedo; float* spec_light; float* diff_light; float* spec_color; float* diff_color;
@@ -36,10 +38,11 @@ struct ShadeArgs {
     StridedOut dfeat;
 };
 
-// Both kernels are persistent grid-stride loops with a one-pixel software prefetch: the 11 input floats
-// (+ pixel index) of the NEXT pixel are requested before the current pixel's ~600 VALU instructions and 16
-// texel gathers run.  A one-thread-per-pixel launch has all waves streaming inputs, then all computing, then
+// Both kernels are persistent grid-stride loops with a software prefetch of the 11 input floats (+ pixel index) of later
+// pixels (see shade_pixel_loop).  A one-thread-per-pixel launch has all waves streaming inputs, then all computing, then
 // all gathering at the same time (measured: runtime ~ sum of the three phases); the prefetch overlaps them.
+constexpr int kMaxViewsLds = 256;
+
 struct ShadeIn {
     F3 n, v;
     float f[5];
@@ -58,25 +61,102 @@ __device__ __forceinline__ void shade_load(const ShadeArgs& a, long long i, Shad
                    a.dcolor.p[i * a.dcolor.rs + 2 * a.dcolor.cs]);
     in.pix = a.pix_idx[i];
 }
+// the same with 32-bit element offsets from the (uniform) base pointers: scalar base + 32-bit lane offset addressing, no
+// 64-bit lane arithmetic and no address VGPR pairs (the launcher checks that every offset fits)
+template <bool BWD>
+__device__ __forceinline__ void shade_load32(const ShadeArgs& a, unsigned i, ShadeIn& in) {
+    const unsigned nr = (unsigned)a.nrm.rs, nc = (unsigned)a.nrm.cs, vr = (unsigned)a.view.rs, vc = (unsigned)a.view.cs;
+    const unsigned fr = (unsigned)a.feat.rs, fc = (unsigned)a.feat.cs;
+    in.n = f3(a.nrm.p[i * nr], a.nrm.p[i * nr + nc], a.nrm.p[i * nr + 2 * nc]);
+    in.v = f3(a.view.p[i * vr], a.view.p[i * vr + vc], a.view.p[i * vr + 2 * vc]);
+#pragma unroll
+    for (unsigned k = 0; k < 5; ++k) in.f[k] = a.feat.p[i * fr + k * fc];
+    if (BWD) {
+        const unsigned dr = (unsigned)a.dcolor.rs, dcs = (unsigned)a.dcolor.cs;
+        in.dc = f3(a.dcolor.p[i * dr], a.dcolor.p[i * dr + dcs], a.dcolor.p[i * dr + 2 * dcs]);
+    }
+    in.pix = a.pix_idx[i];
+}
 
-template <int FMT>
-__global__ __launch_bounds__(256) void k_shade_fwd(ShadeArgs a) {
+// Pixel loop of both kernels.  8-byte texel formats (production): two-stage form with a prefetch distance of TWO pixels,
+// the prefetch issued BETWEEN the gathers of the current pixel and their first use.  vmcnt retires in order, so with the
+// round-1 order (prefetch first, gathers second) the wait in front of the first texel decode also waited for the OLDER HBM
+// input stream of the next pixel, every iteration: the streaming latency was never hidden (rocprofv3 on the real
+// G-buffer: 28 us with an atlas of ONE texel per face, i.e. without any gather divergence at all, against 31 us with the real
+// atlas).  Now the only loads older than the gathers were issued a whole iteration earlier.
+template <int FMT, bool BWD, class Body>
+__device__ __forceinline__ void shade_pixel_loop(const ShadeArgs& a, Body&& body) {
     const long long N = *a.n_dev;
     const long long stride = (long long)gridDim.x * blockDim.x;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    ShadeIn cur, nxt;
-    shade_load<false>(a, i, cur);
-    for (; i < N; i += stride) {
-        const bool more = i + stride < N;
-        if (more) shade_load<false>(a, i + stride, nxt);
-        int env = a.env_of_view[cur.pix / a.HW];
+    if (FMT == kTexelF32 || !a.atlas.fg_pairs || a.n_views > kMaxViewsLds || !a.offsets32) {   // legacy: monolithic, one-pixel prefetch
+        ShadeIn cur, nxt;
+        shade_load<BWD>(a, i, cur);
+        for (; i < N; i += stride) {
+            const bool more = i + stride < N;
+            if (more) shade_load<BWD>(a, i + stride, nxt);
+            int env = a.env_of_view[cur.pix / a.HW];
+            ShadeCtx c;
+            shade_eval_t<FMT>(a.atlas, a.mat, env, cur.n, cur.v, cur.f, c);
+            body(i, cur.dc, c);
+            if (more) cur = nxt;
+        }
+        return;
+    }
+    // per-mip tables and the view -> environment table in LDS: a per-lane index into the kernel-argument copies (or into
+    // env_of_view) is a global load whose latency sits in front of every gather of the pixel
+    __shared__ int s_mip_off[kMaxMips], s_mip_res[kMaxMips], s_env[kMaxViewsLds];
+    if (threadIdx.x < kMaxMips) {
+        s_mip_off[threadIdx.x] = (int)a.atlas.mip_off[threadIdx.x];
+        s_mip_res[threadIdx.x] = a.atlas.mip_res[threadIdx.x];
+    }
+    if ((int)threadIdx.x < a.n_views) s_env[threadIdx.x] = a.env_of_view[threadIdx.x];
+    __syncthreads();
+    const float inv_hw = 1.0f / (float)a.HW;
+    auto env_of = [&](int pix) {
+        int view = (int)((float)pix * inv_hw);           // pix < 2^24 is exact in fp32; one step of correction covers the rounding
+        view -= (view * a.HW > pix) ? 1 : 0;
+        view += ((view + 1) * a.HW <= pix) ? 1 : 0;
+        return s_env[view];                              // (n_views <= kMaxViewsLds on this path)
+    };
+    // Two input register sets, two pixels per trip: the inputs of pixel i + 2*stride are loaded INTO the set whose pixel
+    // has just issued its gathers (everything the second stage needs lives in ShadeCtx / ShadeTaps by then), so no set is
+    // ever copied -- a copy of a freshly requested register is a wait for the whole stream in front of it.
+    // The loop body is branch-free up to the stores: indices past the end are clamped (a redundant load of the last pixel)
+    // instead of skipped, because a conditional load makes the compiler's vmcnt bookkeeping assume the load-free path and
+    // wait for "all but the newest 7" at the first texel use -- which on the taken path includes the prefetch just issued.
+    ShadeIn A, B;
+    const unsigned n32 = (unsigned)N, s32 = (unsigned)stride, last = n32 - 1;
+    unsigned j = (unsigned)i;
+    shade_load32<BWD>(a, j, A);
+    shade_load32<BWD>(a, min(j + s32, last), B);
+    auto step = [&](ShadeIn& cur, unsigned idx) {
+        const int env = env_of(cur.pix);
         ShadeCtx c;
-        shade_eval_t<FMT>(a.atlas, a.mat, env, cur.n, cur.v, cur.f, c);
+        ShadeTaps t;
+        shade_issue_t<FMT>(a.atlas, a.mat, env, cur.n, cur.v, cur.f, c, t, [](int l) { return (long long)s_mip_off[l]; },
+                           [](int l) { return s_mip_res[l]; });
+        const F3 dc = cur.dc;
+        __builtin_amdgcn_sched_barrier(0);
+        shade_load32<BWD>(a, min(idx + 2 * s32, last), cur);
+        __builtin_amdgcn_sched_barrier(0);
+        shade_finish_t<FMT>(a.atlas, a.mat, t, c);
+        if (idx < n32) body(idx, dc, c);
+    };
+    for (; j < n32; j += 2 * s32) {
+        step(A, j);
+        step(B, j + s32);
+    }
+}
+
+template <int FMT, bool DBG>
+__global__ __launch_bounds__(256, 3) void k_shade_fwd(ShadeArgs a) {
+    shade_pixel_loop<FMT, false>(a, [&](long long i, F3, const ShadeCtx& c) {
         a.color.p[i * a.color.rs] = sat(c.pre.x);
         a.color.p[i * a.color.rs + a.color.cs] = sat(c.pre.y);
         a.color.p[i * a.color.rs + 2 * a.color.cs] = sat(c.pre.z);
-        if (a.albedo) {
+        if (DBG) {
             F3 sl = lin2srgb(c.spec), dl = lin2srgb(c.diff), sc = lin2srgb(c.spec_albedo), dc = lin2srgb(c.albedo);
             a.albedo[3 * i] = c.albedo.x; a.albedo[3 * i + 1] = c.albedo.y; a.albedo[3 * i + 2] = c.albedo.z;
             a.spec_light[3 * i] = sl.x; a.spec_light[3 * i + 1] = sl.y; a.spec_light[3 * i + 2] = sl.z;
@@ -86,36 +166,31 @@ __global__ __launch_bounds__(256) void k_shade_fwd(ShadeArgs a) {
             a.metallic[i] = c.metallic;
             a.roughness[i] = c.roughness;
         }
-        if (more) cur = nxt;
-    }
+    });
 }
 
 template <int FMT>
-__global__ __launch_bounds__(256) void k_shade_bwd(ShadeArgs a) {
-    const long long N = *a.n_dev;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    ShadeIn cur, nxt;
-    shade_load<true>(a, i, cur);
-    for (; i < N; i += stride) {
-        const bool more = i + stride < N;
-        if (more) shade_load<true>(a, i + stride, nxt);
-        int env = a.env_of_view[cur.pix / a.HW];
-        ShadeCtx c;
-        shade_eval_t<FMT>(a.atlas, a.mat, env, cur.n, cur.v, cur.f, c);
+__global__ __launch_bounds__(256, 3) void k_shade_bwd(ShadeArgs a) {
+    shade_pixel_loop<FMT, true>(a, [&](long long i, F3 dc, const ShadeCtx& c) {
         float df[5];
-        shade_backward(a.mat, c, cur.dc, df);
+        shade_backward(a.mat, c, dc, df);
 #pragma unroll
         for (int k = 0; k < 5; ++k) a.dfeat.p[i * a.dfeat.rs + k * a.dfeat.cs] = df[k];
-        if (more) cur = nxt;
-    }
+    });
+}
+
+static inline int shade_offsets32(const ShadeArgs& a, long long n_max, bool bwd) {
+    auto fits = [&](long long rs, long long cs, int ch) {
+        return rs >= 0 && cs >= 0 && (n_max - 1) * rs + (ch - 1) * cs < 0x7fffffffLL / 4;
+    };
+    return fits(a.nrm.rs, a.nrm.cs, 3) && fits(a.view.rs, a.view.cs, 3) && fits(a.feat.rs, a.feat.cs, 5) &&
+           (!bwd || fits(a.dcolor.rs, a.dcolor.cs, 3)) && n_max < 0x3fffffffLL;
 }
 
 // persistent launch: enough workgroups to fill every CU at the kernels' occupancy, never more than needed
-static inline int shade_blocks(long long n_max) {
+static inline int shade_blocks(long long n_max, int wg_per_cu) {
     long long need = (n_max + 255) / 256;
-    return (int)std::min<long long>(need, 256 * 4);   // 106-108 VGPRs -> 4 waves per SIMD = 4 workgroups per CU
+    return (int)std::min<long long>(need, 256 * wg_per_cu);
 }
 
 // Material smoothness regulariser (dreammat_material.py:110-123) fused: forward partial sums and
@@ -197,30 +272,41 @@ static bool conv_atlas(const dm_env_atlas* in, EnvAtlas& A) {
 int dm_shade_fwd(const dm_env_atlas* atlas, const dm_mat_cfg* mat, const float* nrm, long long nrm_rs,
                  long long nrm_cs, const float* view, long long view_rs, long long view_cs, const float* feat,
                  long long feat_rs, long long feat_cs, const int32_t* pix_idx, const int32_t* env_of_view,
-                 const int32_t* n_dev, long long n_max, int HW, float* color, long long color_rs,
+                 const int32_t* n_dev, long long n_max, int HW, int n_views, float* color, long long color_rs,
                  long long color_cs, float* dbg_albedo, float* dbg_spec_light, float* dbg_diff_light,
                  float* dbg_spec_color, float* dbg_diff_color, float* dbg_metallic, float* dbg_roughness,
                  hipStream_t stream) {
     ShadeArgs a = {};
     if (!conv_atlas(atlas, a.atlas) || !mat || !nrm || !view || !feat || !pix_idx || !env_of_view || !n_dev ||
-        !color || n_max <= 0 || HW <= 0)
+        !color || n_max <= 0 || HW <= 0 || n_views <= 0)
         return DM_ERR_ARG;
     int ndbg = (dbg_albedo != 0) + (dbg_spec_light != 0) + (dbg_diff_light != 0) + (dbg_spec_color != 0) +
                (dbg_diff_color != 0) + (dbg_metallic != 0) + (dbg_roughness != 0);
     if (ndbg != 0 && ndbg != 7) return DM_ERR_ARG;
     a.mat = {mat->min_metallic, mat->max_metallic, mat->min_roughness, mat->max_roughness};
     a.nrm = {nrm, nrm_rs, nrm_cs}; a.view = {view, view_rs, view_cs}; a.feat = {feat, feat_rs, feat_cs};
-    a.pix_idx = pix_idx; a.env_of_view = env_of_view; a.n_dev = n_dev; a.HW = HW;
+    a.pix_idx = pix_idx; a.env_of_view = env_of_view; a.n_dev = n_dev; a.HW = HW; a.n_views = n_views;
     a.color = {color, color_rs, color_cs};
     a.albedo = dbg_albedo; a.spec_light = dbg_spec_light; a.diff_light = dbg_diff_light;
     a.spec_color = dbg_spec_color; a.diff_color = dbg_diff_color; a.metallic = dbg_metallic;
     a.roughness = dbg_roughness;
     DM_ENTER();
-    const dim3 grid(shade_blocks(n_max));
+    const dim3 grid(shade_blocks(n_max, 4));               // forward: <= 128 VGPRs, 4 workgroups per CU
+    a.offsets32 = shade_offsets32(a, n_max, false);
+    const bool dbg = ndbg != 0;
     switch (a.atlas.texel_format) {
-        case kTexelRgb18e8: hipLaunchKernelGGL(k_shade_fwd<kTexelRgb18e8>, grid, dim3(256), 0, stream, a); break;
-        case kTexelF16: hipLaunchKernelGGL(k_shade_fwd<kTexelF16>, grid, dim3(256), 0, stream, a); break;
-        default: hipLaunchKernelGGL(k_shade_fwd<kTexelF32>, grid, dim3(256), 0, stream, a); break;
+        case kTexelRgb18e8:
+            if (dbg) hipLaunchKernelGGL((k_shade_fwd<kTexelRgb18e8, true>), grid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((k_shade_fwd<kTexelRgb18e8, false>), grid, dim3(256), 0, stream, a);
+            break;
+        case kTexelF16:
+            if (dbg) hipLaunchKernelGGL((k_shade_fwd<kTexelF16, true>), grid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((k_shade_fwd<kTexelF16, false>), grid, dim3(256), 0, stream, a);
+            break;
+        default:
+            if (dbg) hipLaunchKernelGGL((k_shade_fwd<kTexelF32, true>), grid, dim3(256), 0, stream, a);
+            else hipLaunchKernelGGL((k_shade_fwd<kTexelF32, false>), grid, dim3(256), 0, stream, a);
+            break;
     }
     DM_LAUNCH_CHECK();
     return DM_OK;
@@ -229,19 +315,20 @@ int dm_shade_fwd(const dm_env_atlas* atlas, const dm_mat_cfg* mat, const float* 
 int dm_shade_bwd(const dm_env_atlas* atlas, const dm_mat_cfg* mat, const float* nrm, long long nrm_rs,
                  long long nrm_cs, const float* view, long long view_rs, long long view_cs, const float* feat,
                  long long feat_rs, long long feat_cs, const int32_t* pix_idx, const int32_t* env_of_view,
-                 const int32_t* n_dev, long long n_max, int HW, const float* dcolor, long long dcolor_rs,
+                 const int32_t* n_dev, long long n_max, int HW, int n_views, const float* dcolor, long long dcolor_rs,
                  long long dcolor_cs, float* dfeat, long long dfeat_rs, long long dfeat_cs, hipStream_t stream) {
     ShadeArgs a = {};
     if (!conv_atlas(atlas, a.atlas) || !mat || !nrm || !view || !feat || !pix_idx || !env_of_view || !n_dev ||
-        !dcolor || !dfeat || n_max <= 0 || HW <= 0)
+        !dcolor || !dfeat || n_max <= 0 || HW <= 0 || n_views <= 0)
         return DM_ERR_ARG;
     a.mat = {mat->min_metallic, mat->max_metallic, mat->min_roughness, mat->max_roughness};
     a.nrm = {nrm, nrm_rs, nrm_cs}; a.view = {view, view_rs, view_cs}; a.feat = {feat, feat_rs, feat_cs};
-    a.pix_idx = pix_idx; a.env_of_view = env_of_view; a.n_dev = n_dev; a.HW = HW;
+    a.pix_idx = pix_idx; a.env_of_view = env_of_view; a.n_dev = n_dev; a.HW = HW; a.n_views = n_views;
     a.dcolor = {dcolor, dcolor_rs, dcolor_cs};
     a.dfeat = {dfeat, dfeat_rs, dfeat_cs};
     DM_ENTER();
-    const dim3 grid(shade_blocks(n_max));
+    a.offsets32 = shade_offsets32(a, n_max, true);
+    const dim3 grid(shade_blocks(n_max, 3));               // backward: <= 168 VGPRs, 3 workgroups per CU
     switch (a.atlas.texel_format) {
         case kTexelRgb18e8: hipLaunchKernelGGL(k_shade_bwd<kTexelRgb18e8>, grid, dim3(256), 0, stream, a); break;
         case kTexelF16: hipLaunchKernelGGL(k_shade_bwd<kTexelF16>, grid, dim3(256), 0, stream, a); break;

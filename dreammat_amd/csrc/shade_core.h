@@ -132,6 +132,34 @@ DM_HD F3 cube_fetch_rgbe(const void* __restrict__ tex, long long texel_base, int
               t00.y * w00 + t10.y * w10 + t01.y * w01 + t11.y * w11,
               t00.z * w00 + t10.z * w10 + t01.z * w01 + t11.z * w11);
 }
+// Split form of the 8-byte-texel lookups, so that a kernel can put other memory operations BETWEEN the issue of the gathers
+// and their first use: cube_tap_addr -> two 16 B row loads -> cube_tap_blend.
+struct CubeTap { long long idx; int P; float fx, fy; };
+DM_HD CubeTap cube_tap_addr(long long texel_base, int R, CubeCoord cc) {
+    float x = cc.u * (float)R - 0.5f, y = cc.v * (float)R - 0.5f;
+    float x0 = floorf(x), y0 = floorf(y);
+    CubeTap t;
+    t.fx = x - x0; t.fy = y - y0; t.P = R + 2;
+    t.idx = texel_base + (long long)(cc.face * t.P + (int)y0 + 1) * t.P + (int)x0 + 1;
+    return t;
+}
+DM_HD HalfRowBits cube_tap_row(const void* __restrict__ tex, const CubeTap& t, int row) {
+    return *reinterpret_cast<const HalfRowBits*>((const char*)tex + (t.idx + (long long)row * t.P) * 8);
+}
+DM_HD F3 cube_tap_blend(int fmt, HalfRowBits r0, HalfRowBits r1, float fx, float fy) {
+    float w00 = (1.f - fx) * (1.f - fy), w10 = fx * (1.f - fy), w01 = (1.f - fx) * fy, w11 = fx * fy;
+    if (fmt == kTexelRgb18e8) {
+        F3 t00 = rgb18e8_decode(r0.x, r0.y), t10 = rgb18e8_decode(r0.z, r0.w);
+        F3 t01 = rgb18e8_decode(r1.x, r1.y), t11 = rgb18e8_decode(r1.z, r1.w);
+        return f3(t00.x * w00 + t10.x * w10 + t01.x * w01 + t11.x * w11,
+                  t00.y * w00 + t10.y * w10 + t01.y * w01 + t11.y * w11,
+                  t00.z * w00 + t10.z * w10 + t01.z * w01 + t11.z * w11);
+    }
+    return f3(half_lo(r0.x) * w00 + half_lo(r0.z) * w10 + half_lo(r1.x) * w01 + half_lo(r1.z) * w11,
+              half_hi(r0.x) * w00 + half_hi(r0.z) * w10 + half_hi(r1.x) * w01 + half_hi(r1.z) * w11,
+              half_lo(r0.y) * w00 + half_lo(r0.w) * w10 + half_lo(r1.y) * w01 + half_lo(r1.w) * w11);
+}
+
 // one bilinear cube lookup in whichever texel format the atlas carries (`texel_off` in texels)
 DM_HD F3 cube_fetch_any(int fmt, const float4* __restrict__ tex, long long texel_off, int R, CubeCoord cc) {
     if (fmt == kTexelRgb18e8) return cube_fetch_rgbe(tex, texel_off, R, cc);
@@ -174,10 +202,101 @@ struct ShadeCtx {
 
 DM_HD float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// ---- two-stage evaluation (8-byte texel formats + FG pair table: the production configuration) --------------------
+// shade_issue: activations, all addresses, ALL 8 gathers of the pixel issued back to back (raw rows kept in registers);
+// shade_finish: decode, blend, compose.  A kernel puts its next-pixel input prefetch between the two, so that the
+// in-order vmcnt wait in front of the first decode covers only the gathers (L2 hits) and not the younger HBM stream.
+struct ShadeTaps {
+    HalfRowBits s0a, s0b, s1a, s1b, da, db;     // rows y0 / y0+1 of: specular mip l0, specular mip l1, diffuse cube
+    float4 fga, fgb;                             // FG x-pair rows iy0 / iy1
+    float sfx0, sfy0, sfx1, sfy1, dfx, dfy, gfx, gfy, mipf;
+};
+
+// `mip_off` / `mip_res`: the atlas' per-mip tables; the kernels pass LDS copies, because indexing the kernel-argument copy
+// with a per-lane mip level is a global load in front of the gathers that depend on it.
+// (functors, not pointers: a generic pointer to LDS trips a gfx950 code-generation bug in this ROCm release)
+template <int FMT, class MipOff, class MipRes>
+DM_HD void shade_issue_t(const EnvAtlas& A, const MatCfg& M, int env, F3 n, F3 v, const float feat[5], ShadeCtx& c,
+                         ShadeTaps& t, MipOff mip_off, MipRes mip_res) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) c.s[k] = sigmoidf(feat[k]);
+    c.albedo = f3(sat(c.s[0]), sat(c.s[1]), sat(c.s[2]));
+    c.metallic = c.s[3] * (M.max_metallic - M.min_metallic) + M.min_metallic;
+    c.roughness = c.s[4] * (M.max_roughness - M.min_roughness) + M.min_roughness;
+    float ndv = dot3(n, v);
+    F3 refl = n * (2.f * ndv) - v;
+    {
+        int L = A.lut_res;
+        float uu = sat(ndv), vv = sat(c.roughness);
+        float x = uu * (float)L - 0.5f, y = vv * (float)L - 0.5f;
+        float x0 = floorf(x), y0 = floorf(y);
+        t.gfx = x - x0; t.gfy = y - y0;
+        int iy0 = (int)y0;
+        int iy1 = min(iy0 + 1, L - 1);
+        iy0 = max(iy0, 0);
+        t.fga = A.fg_pairs[iy0 * (L + 1) + (int)x0 + 1];
+        t.fgb = A.fg_pairs[iy1 * (L + 1) + (int)x0 + 1];
+    }
+    {
+        CubeTap d = cube_tap_addr((long long)env * A.diff_env_stride, A.diff_res, cube_coord(n));
+        t.da = cube_tap_row(A.diff, d, 0); t.db = cube_tap_row(A.diff, d, 1);
+        t.dfx = d.fx; t.dfy = d.fy;
+    }
+    {
+        float level = mip_level(A, c.roughness, c.dlevel_drough);
+        level = fminf(fmaxf(level, 0.f), (float)(A.n_mips - 1));
+        int l0 = min((int)floorf(level), A.n_mips - 1);
+        int l1 = min(l0 + 1, A.n_mips - 1);
+        t.mipf = level - (float)l0;
+        const long long envt = (long long)env * A.spec_env_stride;
+        CubeCoord rc = cube_coord(refl);
+        CubeTap a0 = cube_tap_addr(envt + mip_off(l0), mip_res(l0), rc);
+        t.s0a = cube_tap_row(A.spec, a0, 0); t.s0b = cube_tap_row(A.spec, a0, 1);
+        t.sfx0 = a0.fx; t.sfy0 = a0.fy;
+        // l1 == l0 (last mip): the same rows are simply fetched twice (an L1 hit); copying the first pair instead would put
+        // a wait for it in the middle of the gather sequence
+        CubeTap a1 = cube_tap_addr(envt + mip_off(l1), mip_res(l1), rc);
+        t.s1a = cube_tap_row(A.spec, a1, 0); t.s1b = cube_tap_row(A.spec, a1, 1);
+        t.sfx1 = a1.fx; t.sfy1 = a1.fy;
+    }
+}
+
+template <int FMT>
+DM_HD void shade_finish_t(const EnvAtlas& A, const MatCfg& M, const ShadeTaps& t, ShadeCtx& c) {
+    const int fmt = FMT >= 0 ? FMT : A.texel_format;
+    {
+        const float fx = t.gfx, fy = t.gfy;
+        float r0x = t.fga.x + (t.fga.z - t.fga.x) * fx, r0y = t.fga.y + (t.fga.w - t.fga.y) * fx;
+        float r1x = t.fgb.x + (t.fgb.z - t.fgb.x) * fx, r1y = t.fgb.y + (t.fgb.w - t.fgb.y) * fx;
+        c.fg0 = r0x + (r1x - r0x) * fy;
+        c.fg1 = r0y + (r1y - r0y) * fy;
+        bool inside = c.roughness > 0.f && c.roughness < 1.f;
+        c.dfg0_dv = inside ? (r1x - r0x) * (float)A.lut_res : 0.f;
+        c.dfg1_dv = inside ? (r1y - r0y) * (float)A.lut_res : 0.f;
+    }
+    c.F0 = f3(0.04f * (1.f - c.metallic) + c.metallic * c.albedo.x,
+              0.04f * (1.f - c.metallic) + c.metallic * c.albedo.y,
+              0.04f * (1.f - c.metallic) + c.metallic * c.albedo.z);
+    c.spec_albedo = f3(c.F0.x * c.fg0 + c.fg1, c.F0.y * c.fg0 + c.fg1, c.F0.z * c.fg0 + c.fg1);
+    c.diff = cube_tap_blend(fmt, t.da, t.db, t.dfx, t.dfy);
+    F3 s0 = cube_tap_blend(fmt, t.s0a, t.s0b, t.sfx0, t.sfy0);
+    F3 s1 = cube_tap_blend(fmt, t.s1a, t.s1b, t.sfx1, t.sfy1);
+    c.spec = s0 * (1.f - t.mipf) + s1 * t.mipf;
+    c.dspec_dlevel = s1 - s0;
+    c.pre = c.albedo * c.diff + c.spec_albedo * c.spec;
+}
+
 // FMT >= 0: texel format fixed at compile time (the kernels: one code path, no per-fetch branch); FMT < 0: read from the atlas
 template <int FMT>
 DM_HD void shade_eval_t(const EnvAtlas& A, const MatCfg& M, int env, F3 n, F3 v, const float feat[5], ShadeCtx& c) {
     const int fmt = FMT >= 0 ? FMT : A.texel_format;
+    if (fmt != kTexelF32 && A.fg_pairs) {                // production configuration: same arithmetic as the kernels' two stages
+        ShadeTaps t;
+        shade_issue_t<FMT>(A, M, env, n, v, feat, c, t, [&](int l) { return (long long)A.mip_off[l]; },
+                           [&](int l) { return A.mip_res[l]; });
+        shade_finish_t<FMT>(A, M, t, c);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 5; ++k) c.s[k] = sigmoidf(feat[k]);
     c.albedo = f3(sat(c.s[0]), sat(c.s[1]), sat(c.s[2]));

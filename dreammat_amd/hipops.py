@@ -343,7 +343,7 @@ class _Shade(torch.autograd.Function):
                 check(_lib.lib().dm_shade_fwd(ctypes.byref(atlas.struct), ctypes.byref(mat), nrm.data_ptr(),
                                               *_rs_cs(nrm), view.data_ptr(), *_rs_cs(view), feat.data_ptr(),
                                               *_rs_cs(feat), pix_idx.data_ptr(), env_of_view.data_ptr(),
-                                              n_dev.data_ptr(), N, HW, color.data_ptr(), 1, N,
+                                              n_dev.data_ptr(), N, HW, env_of_view.numel(), color.data_ptr(), 1, N,
                                               *[d.data_ptr() if d is not None else None for d in dbg], _stream()),
                       "dm_shade_fwd")
         ctx.save_for_backward(feat, nrm, view, pix_idx, n_dev, env_of_view)
@@ -362,7 +362,8 @@ class _Shade(torch.autograd.Function):
                 check(_lib.lib().dm_shade_bwd(ctypes.byref(ctx.atlas.struct), ctypes.byref(ctx.mat), nrm.data_ptr(),
                                               *_rs_cs(nrm), view.data_ptr(), *_rs_cs(view), feat.data_ptr(),
                                               *_rs_cs(feat), pix_idx.data_ptr(), env_of_view.data_ptr(),
-                                              n_dev.data_ptr(), N, ctx.HW, g.data_ptr(), *_rs_cs(g), dfeat.data_ptr(),
+                                              n_dev.data_ptr(), N, ctx.HW, env_of_view.numel(), g.data_ptr(), *_rs_cs(g),
+                                              dfeat.data_ptr(),
                                               1, N, _stream()), "dm_shade_bwd")
         return (dfeat.t(),) + (None,) * 9
 

@@ -133,14 +133,15 @@ typedef struct dm_env_atlas {
 } dm_env_atlas;
 typedef struct dm_mat_cfg { float min_metallic, max_metallic, min_roughness, max_roughness; } dm_mat_cfg;
 
-/* DreamMatMaterial.forward, use_raytracing=False branch (dreammat_material.py:746-762) fused with
+/* pix_idx[i] = view * HW + pixel; env_of_view [n_views] maps the view to its environment map.
+ * DreamMatMaterial.forward, use_raytracing=False branch (dreammat_material.py:746-762) fused with
  * shade_splitsum (:679-711): sigmoid activation -> albedo/metallic/roughness -> FG LUT fetch ->
  * diffuse + specular env lookups -> clamp.  One thread per covered pixel, all views in one launch.
  * The 7 dbg_* outputs (dense [N,3]/[N,1]) are the reference's logging buffers; pass all NULL to skip. */
 int dm_shade_fwd(const dm_env_atlas* atlas_host, const dm_mat_cfg* mat_host, const float* nrm, long long nrm_rs,
                  long long nrm_cs, const float* view, long long view_rs, long long view_cs, const float* feat,
                  long long feat_rs, long long feat_cs, const int32_t* pix_idx, const int32_t* env_of_view,
-                 const int32_t* n_dev, long long n_max, int HW, float* color, long long color_rs,
+                 const int32_t* n_dev, long long n_max, int HW, int n_views, float* color, long long color_rs,
                  long long color_cs, float* dbg_albedo, float* dbg_spec_light, float* dbg_diff_light,
                  float* dbg_spec_color, float* dbg_diff_color, float* dbg_metallic, float* dbg_roughness,
                  dm_stream_t stream);
@@ -148,7 +149,7 @@ int dm_shade_fwd(const dm_env_atlas* atlas_host, const dm_mat_cfg* mat_host, con
 int dm_shade_bwd(const dm_env_atlas* atlas_host, const dm_mat_cfg* mat_host, const float* nrm, long long nrm_rs,
                  long long nrm_cs, const float* view, long long view_rs, long long view_cs, const float* feat,
                  long long feat_rs, long long feat_cs, const int32_t* pix_idx, const int32_t* env_of_view,
-                 const int32_t* n_dev, long long n_max, int HW, const float* dcolor, long long dcolor_rs,
+                 const int32_t* n_dev, long long n_max, int HW, int n_views, const float* dcolor, long long dcolor_rs,
                  long long dcolor_cs, float* dfeat, long long dfeat_rs, long long dfeat_cs, dm_stream_t stream);
 
 /* material_smoothness_grad (dreammat_material.py:110-123) on sigmoid(features) / sigmoid(features_jitter).

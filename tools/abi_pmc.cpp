@@ -119,12 +119,12 @@ static int run_shade(long long N, int n_env, int iters) {
     CK(hipMalloc(&dcol, 3 * N * 4)); CK(hipMalloc(&ddf, 5 * N * 4));
     float ms_f, ms_b;
     int rc = timed(iters, &ms_f, [&] {
-        return dm_shade_fwd(&at, &mc, (float*)dn, 1, N, (float*)dv, 1, N, (float*)df, 1, N, (int*)dp, (int*)denv, (int*)dcount, N, HW,
+        return dm_shade_fwd(&at, &mc, (float*)dn, 1, N, (float*)dv, 1, N, (float*)df, 1, N, (int*)dp, (int*)denv, (int*)dcount, N, HW, views,
                             (float*)dcol, 1, N, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     });
     if (rc) return rc;
     rc = timed(iters, &ms_b, [&] {
-        return dm_shade_bwd(&at, &mc, (float*)dn, 1, N, (float*)dv, 1, N, (float*)df, 1, N, (int*)dp, (int*)denv, (int*)dcount, N, HW,
+        return dm_shade_bwd(&at, &mc, (float*)dn, 1, N, (float*)dv, 1, N, (float*)df, 1, N, (int*)dp, (int*)denv, (int*)dcount, N, HW, views,
                             (float*)dg, 1, N, (float*)ddf, 1, N, nullptr);
     });
     if (rc) return rc;
@@ -169,12 +169,12 @@ static int run_shade_file(const char* path, int iters) {
     CK(hipMalloc(&dcol, 3 * N * 4)); CK(hipMalloc(&ddf, 5 * N * 4));
     float ms_f, ms_b;
     int rc = timed(iters, &ms_f, [&] {
-        return dm_shade_fwd(&at, &mc, (float*)dn, 1, N, (float*)dv, 1, N, (float*)df, 1, N, (int*)dp, (int*)denv, (int*)dcount, N, HW,
+        return dm_shade_fwd(&at, &mc, (float*)dn, 1, N, (float*)dv, 1, N, (float*)df, 1, N, (int*)dp, (int*)denv, (int*)dcount, N, HW, views,
                             (float*)dcol, 1, N, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     });
     if (rc) return rc;
     rc = timed(iters, &ms_b, [&] {
-        return dm_shade_bwd(&at, &mc, (float*)dn, 1, N, (float*)dv, 1, N, (float*)df, 1, N, (int*)dp, (int*)denv, (int*)dcount, N, HW,
+        return dm_shade_bwd(&at, &mc, (float*)dn, 1, N, (float*)dv, 1, N, (float*)df, 1, N, (int*)dp, (int*)denv, (int*)dcount, N, HW, views,
                             (float*)dg, 1, N, (float*)ddf, 1, N, nullptr);
     });
     if (rc) return rc;

@@ -134,7 +134,7 @@ def main():
         import ctypes
         _lib.check(L.dm_shade_bwd(ctypes.byref(atlas.struct), ctypes.byref(mat), gb.nrm.data_ptr(), 1, gb.nrm.stride(0),
                                   gb.view.data_ptr(), 1, gb.view.stride(0), feat.data_ptr(), 1, N, gb.pix_idx.data_ptr(),
-                                  env_of_view.data_ptr(), gb.n_dev.data_ptr(), N, H * W, dcol.data_ptr(), 1, N,
+                                  env_of_view.data_ptr(), gb.n_dev.data_ptr(), N, H * W, B, dcol.data_ptr(), 1, N,
                                   dfe.data_ptr(), 1, N, hipops._stream()))
     rec("shade_bwd(SoA)", timeit(sh_bwd, a.iters), bytes_=N * 76, N=N)
     # adam

@@ -146,37 +146,46 @@ def shade_section(a, res):
                 st.fg_pairs = None
             cases[f"{texel}{'+pairs' if pairs else ''}"] = (at, st, pairs)
     cases = dict(sorted(cases.items(), key=lambda kv: kv[0] != "fp32"))          # "fp32" (round-1 configuration) first
-    fns_f, fns_b, outs = {}, {}, {}
-    for name, (at, st, pairs) in cases.items():
-        out = torch.empty(3, N, device=dev)
+    # bench-like features: the hash-grid field is a smooth function of position, so roughness (= the mip level) and albedo
+    # vary slowly across a wave; `feat` above (white noise) is the incoherent worst case
+    w = torch.randn(5, 3, device=dev) * 2.5
+    feat_smooth = (1.5 * torch.sin(w @ gb.pos + torch.rand(5, 1, device=dev) * 6.28)).contiguous()
+    tiny = penv.EnvAtlas([l[::64, ::64].contiguous() for l in lat], scale=2.0, min_res=1, max_res=2, fg_lut=fg, device=dev,
+                         texel="rgb18e8")            # every gather of a wave lands in one or two cache lines: the no-divergence floor
+    cases["rgb18e8+pairs tiny-atlas"] = (tiny, type(tiny.struct).from_buffer_copy(tiny.struct), True)
+    for fname, ft in (("noise", feat), ("smooth", feat_smooth)):
+        fns_f, fns_b, outs = {}, {}, {}
+        for name, (at, st, pairs) in cases.items():
+            out = torch.empty(3, N, device=dev)
 
-        def fwd(at=at, st=st, out=out):
-            _lib.check(L.dm_shade_fwd(ctypes.byref(st), ctypes.byref(mat), gb.nrm.data_ptr(), 1, gb.nrm.stride(0),
-                                      gb.view.data_ptr(), 1, gb.view.stride(0), feat.data_ptr(), 1, N, gb.pix_idx.data_ptr(),
-                                      env_of_view.data_ptr(), gb.n_dev.data_ptr(), N, H * W, out.data_ptr(), 1, N,
-                                      None, None, None, None, None, None, None, hipops._stream()))
-            return out
+            def fwd(at=at, st=st, out=out, ft=ft):
+                _lib.check(L.dm_shade_fwd(ctypes.byref(st), ctypes.byref(mat), gb.nrm.data_ptr(), 1, gb.nrm.stride(0),
+                                          gb.view.data_ptr(), 1, gb.view.stride(0), ft.data_ptr(), 1, N, gb.pix_idx.data_ptr(),
+                                          env_of_view.data_ptr(), gb.n_dev.data_ptr(), N, H * W, B, out.data_ptr(), 1, N,
+                                          None, None, None, None, None, None, None, hipops._stream()))
+                return out
 
-        def bwd(at=at, st=st):
-            _lib.check(L.dm_shade_bwd(ctypes.byref(st), ctypes.byref(mat), gb.nrm.data_ptr(), 1, gb.nrm.stride(0),
-                                      gb.view.data_ptr(), 1, gb.view.stride(0), feat.data_ptr(), 1, N, gb.pix_idx.data_ptr(),
-                                      env_of_view.data_ptr(), gb.n_dev.data_ptr(), N, H * W, dcol.data_ptr(), 1, N,
-                                      dfe.data_ptr(), 1, N, hipops._stream()))
-        fns_f[name], fns_b[name] = fwd, bwd
-        outs[name] = fwd().clone()
-    base = outs["fp32"]
-    tf, tb = ab(fns_f, a.rounds, a.iters), ab(fns_b, a.rounds, a.iters)
-    for name in cases:
-        r = {"op": "shade", "case": name, "N": N, "fwd_us": tf[name]["median_s"] * 1e6, "bwd_us": tb[name]["median_s"] * 1e6,
-             "fwd_GBps": 56.0 * N / tf[name]["median_s"] / 1e9, "bwd_GBps": 76.0 * N / tb[name]["median_s"] / 1e9,
-             "fwd_frac_8TBs": 56.0 * N / tf[name]["median_s"] / 8e12, "bwd_frac_8TBs": 76.0 * N / tb[name]["median_s"] / 8e12,
-             "max_abs_diff_vs_fp32_atlas": float((outs[name] - base).abs().max())}
-        res.append(r)
-        print(json.dumps(r), flush=True)
+            def bwd(at=at, st=st, ft=ft):
+                _lib.check(L.dm_shade_bwd(ctypes.byref(st), ctypes.byref(mat), gb.nrm.data_ptr(), 1, gb.nrm.stride(0),
+                                          gb.view.data_ptr(), 1, gb.view.stride(0), ft.data_ptr(), 1, N, gb.pix_idx.data_ptr(),
+                                          env_of_view.data_ptr(), gb.n_dev.data_ptr(), N, H * W, B, dcol.data_ptr(), 1, N,
+                                          dfe.data_ptr(), 1, N, hipops._stream()))
+            fns_f[name], fns_b[name] = fwd, bwd
+            outs[name] = fwd().clone()
+        base = outs["fp32"]
+        tf, tb = ab(fns_f, a.rounds, a.iters), ab(fns_b, a.rounds, a.iters)
+        for name in cases:
+            r = {"op": "shade", "features": fname, "case": name, "N": N, "fwd_us": tf[name]["median_s"] * 1e6,
+                 "bwd_us": tb[name]["median_s"] * 1e6, "fwd_GBps": 56.0 * N / tf[name]["median_s"] / 1e9,
+                 "bwd_GBps": 76.0 * N / tb[name]["median_s"] / 1e9, "fwd_frac_8TBs": 56.0 * N / tf[name]["median_s"] / 8e12,
+                 "bwd_frac_8TBs": 76.0 * N / tb[name]["median_s"] / 8e12,
+                 "max_abs_diff_vs_fp32_atlas": float((outs[name] - base).abs().max())}
+            res.append(r)
+            print(json.dumps(r), flush=True)
     for texel in ("fp32", "rgb18e8"):
         at = atlases[texel]
-        dump_shade_case(os.path.join(os.environ.get("DM_SHADE_CASE_DIR", "/tmp"), f"shade_case_{texel}.bin"), at, gb.nrm, gb.view, feat, dcol, gb.pix_idx[:N],
-                        env_of_view, H * W, texel != "fp32")
+        dump_shade_case(os.path.join(os.environ.get("DM_SHADE_CASE_DIR", "/tmp"), f"shade_case_{texel}.bin"), at, gb.nrm, gb.view,
+                        feat_smooth, dcol, gb.pix_idx[:N], env_of_view, H * W, texel != "fp32")
 
 
 def main():
