@@ -28,7 +28,7 @@ struct ShadeArgs {
     const int* n_dev;        // device count of rows
     int HW;
     int n_views;             // entries of env_of_view
-    int offsets32;           // every element offset of the row tensors fits 31 bits (32-bit lane offsets in the fast loop)
+    int offsets32;           // inputs are SoA (unit row stride) and every byte offset fits 31 bits: the fast loop applies
     StridedOut color;        // [N,3]
     // optional debug outputs (null => skipped); rows of 3/3/3/3/1/1 floats, dense [N,C]
     float* albedo; float* spec_light; float* diff_light; float* spec_color; float* diff_color;
@@ -61,23 +61,6 @@ __device__ __forceinline__ void shade_load(const ShadeArgs& a, long long i, Shad
                    a.dcolor.p[i * a.dcolor.rs + 2 * a.dcolor.cs]);
     in.pix = a.pix_idx[i];
 }
-// the same with 32-bit element offsets from the (uniform) base pointers: scalar base + 32-bit lane offset addressing, no
-// 64-bit lane arithmetic and no address VGPR pairs (the launcher checks that every offset fits)
-template <bool BWD>
-__device__ __forceinline__ void shade_load32(const ShadeArgs& a, unsigned i, ShadeIn& in) {
-    const unsigned nr = (unsigned)a.nrm.rs, nc = (unsigned)a.nrm.cs, vr = (unsigned)a.view.rs, vc = (unsigned)a.view.cs;
-    const unsigned fr = (unsigned)a.feat.rs, fc = (unsigned)a.feat.cs;
-    in.n = f3(a.nrm.p[i * nr], a.nrm.p[i * nr + nc], a.nrm.p[i * nr + 2 * nc]);
-    in.v = f3(a.view.p[i * vr], a.view.p[i * vr + vc], a.view.p[i * vr + 2 * vc]);
-#pragma unroll
-    for (unsigned k = 0; k < 5; ++k) in.f[k] = a.feat.p[i * fr + k * fc];
-    if (BWD) {
-        const unsigned dr = (unsigned)a.dcolor.rs, dcs = (unsigned)a.dcolor.cs;
-        in.dc = f3(a.dcolor.p[i * dr], a.dcolor.p[i * dr + dcs], a.dcolor.p[i * dr + 2 * dcs]);
-    }
-    in.pix = a.pix_idx[i];
-}
-
 // Pixel loop of both kernels.  8-byte texel formats (production): two-stage form with a prefetch distance of TWO pixels,
 // the prefetch issued BETWEEN the gathers of the current pixel and their first use.  vmcnt retires in order, so with the
 // round-1 order (prefetch first, gathers second) the wait in front of the first texel decode also waited for the OLDER HBM
@@ -90,7 +73,8 @@ __device__ __forceinline__ void shade_pixel_loop(const ShadeArgs& a, Body&& body
     const long long stride = (long long)gridDim.x * blockDim.x;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
-    if (FMT == kTexelF32 || !a.atlas.fg_pairs || a.n_views > kMaxViewsLds || !a.offsets32) {   // legacy: monolithic, one-pixel prefetch
+    if (FMT == kTexelF32 || !a.atlas.fg_pairs || a.n_views > kMaxViewsLds || !a.offsets32) {   // legacy: monolithic, one-pixel prefetch,
+                                                                                                // any row strides
         ShadeIn cur, nxt;
         shade_load<BWD>(a, i, cur);
         for (; i < N; i += stride) {
@@ -104,6 +88,7 @@ __device__ __forceinline__ void shade_pixel_loop(const ShadeArgs& a, Body&& body
         }
         return;
     }
+#if defined(__HIP_DEVICE_COMPILE__)   // (__amdgpu_buffer_rsrc_t does not exist in the host pass)
     // per-mip tables and the view -> environment table in LDS: a per-lane index into the kernel-argument copies (or into
     // env_of_view) is a global load whose latency sits in front of every gather of the pixel
     __shared__ int s_mip_off[kMaxMips], s_mip_res[kMaxMips], s_env[kMaxViewsLds];
@@ -120,6 +105,34 @@ __device__ __forceinline__ void shade_pixel_loop(const ShadeArgs& a, Body&& body
         view += ((view + 1) * a.HW <= pix) ? 1 : 0;
         return s_env[view];                              // (n_views <= kMaxViewsLds on this path)
     };
+    // Everything is addressed as (uniform buffer descriptor) + (32-bit lane offset) [+ scalar offset]: no 64-bit lane
+    // arithmetic.  The SoA rows of one tensor share ONE lane offset (4*pixel); the channel is a scalar offset.
+    constexpr int kAll = 0x7ffffffc;
+    const __amdgpu_buffer_rsrc_t r_spec = __builtin_amdgcn_make_buffer_rsrc((void*)a.atlas.spec, 0, kAll, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_diff = __builtin_amdgcn_make_buffer_rsrc((void*)a.atlas.diff, 0, kAll, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_fg = __builtin_amdgcn_make_buffer_rsrc((void*)a.atlas.fg_pairs, 0, kAll, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_nrm = __builtin_amdgcn_make_buffer_rsrc((void*)a.nrm.p, 0, kAll, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_view = __builtin_amdgcn_make_buffer_rsrc((void*)a.view.p, 0, kAll, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_feat = __builtin_amdgcn_make_buffer_rsrc((void*)a.feat.p, 0, kAll, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_pix = __builtin_amdgcn_make_buffer_rsrc((void*)a.pix_idx, 0, kAll, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_dcol = __builtin_amdgcn_make_buffer_rsrc((void*)(BWD ? a.dcolor.p : a.nrm.p), 0, kAll, 0x00020000);
+    const int nc = (int)a.nrm.cs * 4, vc = (int)a.view.cs * 4, fc = (int)a.feat.cs * 4, dcs = BWD ? (int)a.dcolor.cs * 4 : 0;
+    auto ldf = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    };
+    auto load_soa = [&](unsigned idx, ShadeIn& in) {
+        const int vo = (int)(idx * 4u);
+        in.n = f3(ldf(r_nrm, vo, 0), ldf(r_nrm, vo, nc), ldf(r_nrm, vo, 2 * nc));
+        in.v = f3(ldf(r_view, vo, 0), ldf(r_view, vo, vc), ldf(r_view, vo, 2 * vc));
+#pragma unroll
+        for (int k = 0; k < 5; ++k) in.f[k] = ldf(r_feat, vo, k * fc);
+        if (BWD) in.dc = f3(ldf(r_dcol, vo, 0), ldf(r_dcol, vo, dcs), ldf(r_dcol, vo, 2 * dcs));
+        in.pix = (int)__builtin_amdgcn_raw_buffer_load_b32(r_pix, vo, 0, 0);
+    };
+    auto rows = [](__amdgpu_buffer_rsrc_t r) {
+        return [r](unsigned off) { return __builtin_bit_cast(HalfRowBits, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0)); };
+    };
+    auto fg_rows = [r_fg](unsigned off) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_fg, (int)off, 0, 0)); };
     // Two input register sets, two pixels per trip: the inputs of pixel i + 2*stride are loaded INTO the set whose pixel
     // has just issued its gathers (everything the second stage needs lives in ShadeCtx / ShadeTaps by then), so no set is
     // ever copied -- a copy of a freshly requested register is a wait for the whole stream in front of it.
@@ -129,17 +142,17 @@ __device__ __forceinline__ void shade_pixel_loop(const ShadeArgs& a, Body&& body
     ShadeIn A, B;
     const unsigned n32 = (unsigned)N, s32 = (unsigned)stride, last = n32 - 1;
     unsigned j = (unsigned)i;
-    shade_load32<BWD>(a, j, A);
-    shade_load32<BWD>(a, min(j + s32, last), B);
+    load_soa(j, A);
+    load_soa(min(j + s32, last), B);
     auto step = [&](ShadeIn& cur, unsigned idx) {
         const int env = env_of(cur.pix);
         ShadeCtx c;
         ShadeTaps t;
-        shade_issue_t<FMT>(a.atlas, a.mat, env, cur.n, cur.v, cur.f, c, t, [](int l) { return (long long)s_mip_off[l]; },
-                           [](int l) { return s_mip_res[l]; });
+        shade_issue_t<FMT>(a.atlas, a.mat, env, cur.n, cur.v, cur.f, c, t, [](int l) { return s_mip_off[l]; },
+                           [](int l) { return s_mip_res[l]; }, rows(r_spec), rows(r_diff), fg_rows);
         const F3 dc = cur.dc;
         __builtin_amdgcn_sched_barrier(0);
-        shade_load32<BWD>(a, min(idx + 2 * s32, last), cur);
+        load_soa(min(idx + 2 * s32, last), cur);
         __builtin_amdgcn_sched_barrier(0);
         shade_finish_t<FMT>(a.atlas, a.mat, t, c);
         if (idx < n32) body(idx, dc, c);
@@ -148,6 +161,7 @@ __device__ __forceinline__ void shade_pixel_loop(const ShadeArgs& a, Body&& body
         step(A, j);
         step(B, j + s32);
     }
+#endif
 }
 
 template <int FMT, bool DBG>
@@ -180,8 +194,8 @@ __global__ __launch_bounds__(256, 3) void k_shade_bwd(ShadeArgs a) {
 }
 
 static inline int shade_offsets32(const ShadeArgs& a, long long n_max, bool bwd) {
-    auto fits = [&](long long rs, long long cs, int ch) {
-        return rs >= 0 && cs >= 0 && (n_max - 1) * rs + (ch - 1) * cs < 0x7fffffffLL / 4;
+    auto fits = [&](long long rs, long long cs, int ch) {      // SoA rows (unit row stride), every byte offset below 2^31
+        return rs == 1 && cs >= 0 && (n_max - 1) + (ch - 1) * cs < 0x7fffffffLL / 4;
     };
     return fits(a.nrm.rs, a.nrm.cs, 3) && fits(a.view.rs, a.view.cs, 3) && fits(a.feat.rs, a.feat.cs, 5) &&
            (!bwd || fits(a.dcolor.rs, a.dcolor.cs, 3)) && n_max < 0x3fffffffLL;

@@ -134,18 +134,29 @@ DM_HD F3 cube_fetch_rgbe(const void* __restrict__ tex, long long texel_base, int
 }
 // Split form of the 8-byte-texel lookups, so that a kernel can put other memory operations BETWEEN the issue of the gathers
 // and their first use: cube_tap_addr -> two 16 B row loads -> cube_tap_blend.
-struct CubeTap { long long idx; int P; float fx, fy; };
-DM_HD CubeTap cube_tap_addr(long long texel_base, int R, CubeCoord cc) {
+struct CubeTap { unsigned off0, off1; float fx, fy; };      // byte offsets of the two 16 B rows (an atlas is far below 4 GB)
+DM_HD CubeTap cube_tap_addr(int texel_base, int R, CubeCoord cc) {
     float x = cc.u * (float)R - 0.5f, y = cc.v * (float)R - 0.5f;
     float x0 = floorf(x), y0 = floorf(y);
     CubeTap t;
-    t.fx = x - x0; t.fy = y - y0; t.P = R + 2;
-    t.idx = texel_base + (long long)(cc.face * t.P + (int)y0 + 1) * t.P + (int)x0 + 1;
+    t.fx = x - x0; t.fy = y - y0;
+    const int P = R + 2;
+    const int idx = texel_base + (cc.face * P + (int)y0 + 1) * P + (int)x0 + 1;
+    t.off0 = (unsigned)idx * 8u;
+    t.off1 = (unsigned)(idx + P) * 8u;
     return t;
 }
-DM_HD HalfRowBits cube_tap_row(const void* __restrict__ tex, const CubeTap& t, int row) {
-    return *reinterpret_cast<const HalfRowBits*>((const char*)tex + (t.idx + (long long)row * t.P) * 8);
-}
+// default 16-byte row fetch: plain pointer + byte offset (host emulation, legacy paths); the kernels pass buffer loads
+struct PlainRows {
+    const void* base;
+    DM_HD HalfRowBits operator()(unsigned byte_off) const {
+        return *reinterpret_cast<const HalfRowBits*>((const char*)base + byte_off);
+    }
+};
+struct PlainFgRows {
+    const float4* base;
+    DM_HD float4 operator()(unsigned byte_off) const { return *reinterpret_cast<const float4*>((const char*)base + byte_off); }
+};
 DM_HD F3 cube_tap_blend(int fmt, HalfRowBits r0, HalfRowBits r1, float fx, float fy) {
     float w00 = (1.f - fx) * (1.f - fy), w10 = fx * (1.f - fy), w01 = (1.f - fx) * fy, w11 = fx * fy;
     if (fmt == kTexelRgb18e8) {
@@ -215,9 +226,9 @@ struct ShadeTaps {
 // `mip_off` / `mip_res`: the atlas' per-mip tables; the kernels pass LDS copies, because indexing the kernel-argument copy
 // with a per-lane mip level is a global load in front of the gathers that depend on it.
 // (functors, not pointers: a generic pointer to LDS trips a gfx950 code-generation bug in this ROCm release)
-template <int FMT, class MipOff, class MipRes>
+template <int FMT, class MipOff, class MipRes, class SpecRows, class DiffRows, class FgRows>
 DM_HD void shade_issue_t(const EnvAtlas& A, const MatCfg& M, int env, F3 n, F3 v, const float feat[5], ShadeCtx& c,
-                         ShadeTaps& t, MipOff mip_off, MipRes mip_res) {
+                         ShadeTaps& t, MipOff mip_off, MipRes mip_res, SpecRows spec_rows, DiffRows diff_rows, FgRows fg_rows) {
 #pragma unroll
     for (int k = 0; k < 5; ++k) c.s[k] = sigmoidf(feat[k]);
     c.albedo = f3(sat(c.s[0]), sat(c.s[1]), sat(c.s[2]));
@@ -234,12 +245,12 @@ DM_HD void shade_issue_t(const EnvAtlas& A, const MatCfg& M, int env, F3 n, F3 v
         int iy0 = (int)y0;
         int iy1 = min(iy0 + 1, L - 1);
         iy0 = max(iy0, 0);
-        t.fga = A.fg_pairs[iy0 * (L + 1) + (int)x0 + 1];
-        t.fgb = A.fg_pairs[iy1 * (L + 1) + (int)x0 + 1];
+        t.fga = fg_rows((unsigned)(iy0 * (L + 1) + (int)x0 + 1) * 16u);
+        t.fgb = fg_rows((unsigned)(iy1 * (L + 1) + (int)x0 + 1) * 16u);
     }
     {
-        CubeTap d = cube_tap_addr((long long)env * A.diff_env_stride, A.diff_res, cube_coord(n));
-        t.da = cube_tap_row(A.diff, d, 0); t.db = cube_tap_row(A.diff, d, 1);
+        CubeTap d = cube_tap_addr(env * (int)A.diff_env_stride, A.diff_res, cube_coord(n));
+        t.da = diff_rows(d.off0); t.db = diff_rows(d.off1);
         t.dfx = d.fx; t.dfy = d.fy;
     }
     {
@@ -248,15 +259,15 @@ DM_HD void shade_issue_t(const EnvAtlas& A, const MatCfg& M, int env, F3 n, F3 v
         int l0 = min((int)floorf(level), A.n_mips - 1);
         int l1 = min(l0 + 1, A.n_mips - 1);
         t.mipf = level - (float)l0;
-        const long long envt = (long long)env * A.spec_env_stride;
+        const int envt = env * (int)A.spec_env_stride;
         CubeCoord rc = cube_coord(refl);
-        CubeTap a0 = cube_tap_addr(envt + mip_off(l0), mip_res(l0), rc);
-        t.s0a = cube_tap_row(A.spec, a0, 0); t.s0b = cube_tap_row(A.spec, a0, 1);
+        CubeTap a0 = cube_tap_addr(envt + (int)mip_off(l0), mip_res(l0), rc);
+        t.s0a = spec_rows(a0.off0); t.s0b = spec_rows(a0.off1);
         t.sfx0 = a0.fx; t.sfy0 = a0.fy;
         // l1 == l0 (last mip): the same rows are simply fetched twice (an L1 hit); copying the first pair instead would put
         // a wait for it in the middle of the gather sequence
-        CubeTap a1 = cube_tap_addr(envt + mip_off(l1), mip_res(l1), rc);
-        t.s1a = cube_tap_row(A.spec, a1, 0); t.s1b = cube_tap_row(A.spec, a1, 1);
+        CubeTap a1 = cube_tap_addr(envt + (int)mip_off(l1), mip_res(l1), rc);
+        t.s1a = spec_rows(a1.off0); t.s1b = spec_rows(a1.off1);
         t.sfx1 = a1.fx; t.sfy1 = a1.fy;
     }
 }
@@ -292,8 +303,8 @@ DM_HD void shade_eval_t(const EnvAtlas& A, const MatCfg& M, int env, F3 n, F3 v,
     const int fmt = FMT >= 0 ? FMT : A.texel_format;
     if (fmt != kTexelF32 && A.fg_pairs) {                // production configuration: same arithmetic as the kernels' two stages
         ShadeTaps t;
-        shade_issue_t<FMT>(A, M, env, n, v, feat, c, t, [&](int l) { return (long long)A.mip_off[l]; },
-                           [&](int l) { return A.mip_res[l]; });
+        shade_issue_t<FMT>(A, M, env, n, v, feat, c, t, [&](int l) { return (int)A.mip_off[l]; },
+                           [&](int l) { return A.mip_res[l]; }, PlainRows{A.spec}, PlainRows{A.diff}, PlainFgRows{A.fg_pairs});
         shade_finish_t<FMT>(A, M, t, c);
         return;
     }
