@@ -891,7 +891,7 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
             for (int i = 0; i < 8; ++i) {
                 const int t = i >> 2, q4 = i & 3;
                 if (have_next) {
-                    if (i == 1) read_k(1);                // second half's fragments: needed from slice 4 on
+                    if (i == 3) read_k(1);                // second half's fragments: needed from slice 4 on
                     nxt[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][q4], qf[q4], q4 == 0 ? cinit : nxt[t], 0, 0, 0);
                 }
 #pragma unroll
@@ -906,7 +906,7 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
                     bf16x2 plo = __builtin_convertvector(lo, bf16x2), phi = __builtin_convertvector(hi2, bf16x2);
                     pf[ks][e0] = plo[0]; pf[ks][e0 + 1] = plo[1]; pf[ks][e0 + 2] = phi[0]; pf[ks][e0 + 3] = phi[1];
                 }
-                if (i == 6) read_v(vf0, 0);               // V^T fragments of tile j: first 32 output rows
+                if (i == 7) read_v(vf0, 0);               // V^T fragments of tile j: first 32 output rows
                 // keep the four row-sum chains where they are: left alone, the SLP vectoriser gathers all 32 adds into 16
                 // v_pk_add_f32 behind the last slice, where no MFMA covers them
                 asm volatile("" : "+v"(ps[0]), "+v"(ps[1]), "+v"(ps[2]), "+v"(ps[3]));
@@ -919,7 +919,7 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int dt = i >> 2, ks = i & 3;
-                if (i == 0) read_v(vf1, 1);
+                if (i == 2) read_v(vf1, 1);
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt == 0 ? vf0[ks] : vf1[ks], pf[ks], o[dt], 0, 0, 0);
                 if (have_next) {                          // registers 2i, 2i+1 of both halves per slice; four chains
                     const int r = 2 * i;
@@ -946,11 +946,21 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
             iter(sA, sB, std::false_type{});
             iter(sB, sA, std::false_type{});
         }
-        bool flip = false;
-        while (j < n_tiles) {
-            if (!flip) iter(sA, sB, std::true_type{});
-            else iter(sB, sA, std::true_type{});
-            flip = !flip;
+        // Tail (the last tiles, at most five; also whole short sequences): leave the pipeline and finish with the plain
+        // tile-at-a-time form.  sA holds the scores of tile j (S^T already formed against the current C operand); the tiles
+        // issued so far reach min(n_tiles, j + 3).  A pipelined tail would need both register sets live across its
+        // run-time branches and spilled ~70 dwords per iteration: slower than the whole main loop on 64-tile sequences.
+        for (bool have_scores = true; j < n_tiles; ++j, have_scores = false) {
+            const int newer = min(n_tiles, j + 3) - (j + 1);            // issued tiles younger than tile j: 0, 1 or 2
+            if (newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");
+            else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (j + 3 < n_tiles) issue(j + 3, (stage + 3) & 3, std::true_type{});
+            if (!have_scores) qk(stage, sA);
+            else if (j + 1 == n_tiles) { /* masked inside softmax_pv */ }
+            softmax_pv(j, stage, j == 0, sA, sA, false, std::true_type{});
+            stage = (stage + 1) & 3;
         }
     }
 
