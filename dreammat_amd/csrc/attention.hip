@@ -892,7 +892,14 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
                 const int t = i >> 2, q4 = i & 3;
                 if (have_next) {
                     if (i == 3) read_k(1);                // second half's fragments: needed from slice 4 on
-                    nxt[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][q4], qf[q4], q4 == 0 ? cinit : nxt[t], 0, 0, 0);
+                    if (q4 == 0) {
+                        // chain head: D = nxt[t], C = the (loop-invariant) C-operand vector.  Through the builtin hipcc ties D
+                        // to C and first COPIES the 16 registers (32 v_mov per tile); the instruction itself takes distinct
+                        // registers.  The next MFMA of the chain reads exactly this D as its C: no wait states needed.
+                        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(nxt[t]) : "v"(kf[t][0]), "v"(qf[0]), "v"(cinit));
+                    } else {
+                        nxt[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][q4], qf[q4], nxt[t], 0, 0, 0);
+                    }
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
