@@ -349,7 +349,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                // weights as the A operand, pixels as B: the accumulator fragment is D^T[n][m] -- lane = pixel, registers =
+                // channels, so the epilogue can store 16 contiguous bytes (8 channels of one pixel) per lane
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
     };
     auto kstep = [&](int stage, int st_next, auto issue_tag) {
         constexpr bool ISSUE = decltype(issue_tag)::value;
@@ -392,41 +394,75 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     }
 
     // ---- epilogue: y = acc + bias[n] (+ rowbias[image(m), n]) (+ res[m, n]), one rounding to bf16.
-    // D layout: lane holds column n = l31 of each 32x32 fragment, rows (r&3) + 8*(r>>2) + 4*hi.
-    float bv[NT];
-    int ncol[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-        ncol[j] = n0 + TN * wn + 32 * j + l31;
-        bv[j] = (a.bias && ncol[j] < a.Cout) ? (float)a.bias[ncol[j]] : 0.f;
-    }
+    // D^T layout: lane = pixel l31 of the fragment, register r = channel (r&3) + 8*(r>>2) + 4*hi.  Group g = r>>2 is four
+    // consecutive channels (8 bytes as bf16); lanes l and l+32 hold the two halves of one 8-channel run.  One
+    // v_permlane32_swap per dword on the group pair (g, g+1) turns that into 16 contiguous bytes per lane: lanes 0-31 get
+    // channels 8g..8g+7, lanes 32-63 channels 8g+8..8g+15 of their pixel -> TWO 16-byte stores per 32x32 fragment.  The
+    // first version stored every element on its own (2 bytes per lane, 128 store instructions per wave and tile): at
+    // Cin = 128 the store issue took longer than the K loop (tools/conv_fit.sh: 0.40 ms of 0.96 ms did not scale with K).
     const int img0 = Y0 / a.Hout;                      // image of the patch's first row (wave-uniform)
     const int rem0 = Y0 - img0 * a.Hout;
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT; ++i) {
+        const int d = TM * wm + 32 * i + l31;          // this lane's pixel of the tile
+        const int ty = d >> a.tw_log2;
+        const int Y = Y0 + ty;
+        const int xo = X0 + (d & TWm);
+        const bool pix_ok = Y < rows_total && xo < a.Wout;
+        const long long m = (long long)Y * a.Wout + xo;           // = (b*Hout + yo)*Wout + xo
+        const __bf16* rb = nullptr;
+        if (a.rowbias) {
+            int img = img0, t = rem0 + ty;
+            while (t >= a.Hout) { t -= a.Hout; ++img; }         // a patch spans at most TH / Hout + 1 images
+            rb = a.rowbias + (long long)min(img, a.B - 1) * a.Cout;
+        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int d = TM * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const int ty = d >> a.tw_log2;
-            const int Y = Y0 + ty;
-            const int xo = X0 + (d & TWm);
-            if (Y >= rows_total || xo >= a.Wout) continue;
-            const long long m = (long long)Y * a.Wout + xo;       // = (b*Hout + yo)*Wout + xo
-            const __bf16* rb = nullptr;
-            if (a.rowbias) {
-                int img = img0, t = rem0 + ty;
-                while (t >= a.Hout) { t -= a.Hout; ++img; }     // a patch spans at most TH / Hout + 1 images
-                rb = a.rowbias + (long long)img * a.Cout;
-            }
+        for (int j = 0; j < NT; ++j) {
+            const int nbase = n0 + TN * wn + 32 * j;   // first channel of this fragment (wave-uniform)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (ncol[j] >= a.Cout) continue;
-                float v = acc[i][j][r] + bv[j];
-                if (rb) v += (float)rb[ncol[j]];
-                if (a.res) v += (float)a.res[m * a.Cout + ncol[j]];
-                a.y[m * a.Cout + ncol[j]] = (__bf16)v;
+            for (int gp = 0; gp < 2; ++gp) {           // group pairs (0,1) and (2,3)
+                // fp32 adds in the accumulator layout (register 4g+e = channel nbase + 8g + 4hi + e), one rounding to bf16
+                unsigned w[2][2];                      // [group of the pair][dword] = 4 bf16 per group
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int g = 2 * gp + q;
+                    const int n = nbase + 8 * g + 4 * hi;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                    if (n < a.Cout) {
+                        if (a.bias) {
+                            const uint2 bb = *reinterpret_cast<const uint2*>(a.bias + n);
+                            v[0] += __builtin_bit_cast(float, bb.x << 16); v[1] += __builtin_bit_cast(float, bb.x & 0xffff0000u);
+                            v[2] += __builtin_bit_cast(float, bb.y << 16); v[3] += __builtin_bit_cast(float, bb.y & 0xffff0000u);
+                        }
+                        if (rb) {
+                            const uint2 bb = *reinterpret_cast<const uint2*>(rb + n);
+                            v[0] += __builtin_bit_cast(float, bb.x << 16); v[1] += __builtin_bit_cast(float, bb.x & 0xffff0000u);
+                            v[2] += __builtin_bit_cast(float, bb.y << 16); v[3] += __builtin_bit_cast(float, bb.y & 0xffff0000u);
+                        }
+                        if (a.res && pix_ok) {
+                            const uint2 rr = *reinterpret_cast<const uint2*>(a.res + m * a.Cout + n);
+                            v[0] += __builtin_bit_cast(float, rr.x << 16); v[1] += __builtin_bit_cast(float, rr.x & 0xffff0000u);
+                            v[2] += __builtin_bit_cast(float, rr.y << 16); v[3] += __builtin_bit_cast(float, rr.y & 0xffff0000u);
+                        }
+                    }
+                    f32x2 lo = {v[0], v[1]}, hi2 = {v[2], v[3]};
+                    bf16x2 plo = __builtin_convertvector(lo, bf16x2), phi = __builtin_convertvector(hi2, bf16x2);
+                    w[q][0] = __builtin_bit_cast(unsigned, plo);
+                    w[q][1] = __builtin_bit_cast(unsigned, phi);
+                }
+                // v_permlane32_swap(vdst = group g, src = group g+1): lanes 32-63 of vdst <-> lanes 0-31 of src.  Afterwards
+                //   result[0]: lanes 0-31 own group g (ch 8g..8g+3)        | lanes 32-63 the lower lanes' group g+1 (ch 8g+8..+11)
+                //   result[1]: lanes 0-31 the upper lanes' group g (+4..+7) | lanes 32-63 own group g+1 (ch 8g+12..+15)
+                const auto s0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+                const int c0 = nbase + 16 * gp + 8 * hi;   // this lane now owns channels c0 .. c0+7 of its pixel
+                if (pix_ok && c0 < a.Cout)
+                    *reinterpret_cast<uint4*>(a.y + m * a.Cout + c0) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
             }
         }
+    }
 }
 
 template <int BMT, int BN, int NW, int WMW, int NSTAGE>
@@ -494,7 +530,8 @@ int dm_conv3x3_nhwc_bf16_fused(const void* x, const void* w, const void* bias, c
                                int pad_y, int pad_x, hipStream_t stream) {
     if (!x || !w || !y || B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || stride <= 0) return DM_ERR_ARG;
     if (Cin % 32 != 0 || Cout % 64 != 0) return DM_ERR_UNSUPPORTED;
-    if (((uintptr_t)x | (uintptr_t)w) & 15) return DM_ERR_ARG;
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return DM_ERR_ARG;
+    if (((uintptr_t)bias | (uintptr_t)rowbias | (uintptr_t)residual) & 7) return DM_ERR_ARG;
     ConvArgs a;
     a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const __bf16*)bias; a.y = (__bf16*)y;
     a.rowbias = (const __bf16*)rowbias; a.res = (const __bf16*)residual;

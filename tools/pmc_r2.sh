@@ -27,6 +27,7 @@ for v in ${ATTN_VARIANTS:-v3p v3l v3}; do
   run_stats attn_$v attn 24 5 4096 4096 64 5 $v
   run_pmc sq_attn_$v "$SQ" attn 24 5 4096 4096 64 5 $v
   run_pmc sq2_attn_$v "$SQ2" attn 24 5 4096 4096 64 5 $v
+  run_pmc grbm_attn_$v "GRBM_GUI_ACTIVE GRBM_COUNT" attn 24 5 4096 4096 64 5 $v
 done
 v=${ATTN_MAIN:-v3}
 run_pmc fetch_attn_$v "FETCH_SIZE" attn 24 5 4096 4096 64 5 $v
