@@ -10,8 +10,9 @@ SDS gradient -> backward into hash grid + MLP -> all-reduce (RCCL) -> fused Adam
 sharded over the N ranks (strong scaling: total work per step is fixed), config = BASELINE configs[2]:
 50 880-triangle displaced sphere, 512^2, 5 synthetic env maps, SD-2.1-base shaped nets (the reference's
 model, dreammat.yaml:60; --sd sd15 selects the SD-1.5 shapes), bf16, seeded random weights and
-synthetic condition maps (no checkpoints / Blender on this box).  Inputs of every step are resident in
-HBM before the timed region.  Rank 0 prints ONE JSON line.
+synthetic condition maps (no checkpoints / Blender on this box).  The per-view camera tensors and condition maps of all
+128 x 5 (view, environment) pairs are resident in HBM; each timed step includes its own collate (draw + device gather).
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -59,7 +60,10 @@ def system_config(a, views_per_rank):
     return {
         "geometry": {"shape_init": a.mesh, "shape_init_params": 0.8},
         "material": {"use_raytracing": False, "environment_scale": 2.0, "env_max_res": a.env_res, "env_min_res": 16,
-                     "n_envs": 5},
+                     "n_envs": 5,
+                     # the reference's own split-sum LUT (tests/golden/assets, copied from load/lights); falls back to the
+                     # analytic stand-in when the file is absent -- `config.fg_lut` in the JSON line says which one ran
+                     "fg_lut_path": os.path.join(ROOT, "tests", "golden", "assets", "bsdf_256_256.bin")},
         "guidance": {"use_controlnet": True, "control_types": ["light"], "condition_scales": [1.0],
                      "condition_scales_anneal": [0.8], "control_anneal_start_step": 700, "width": a.res,
                      "height": a.res, "pretrained_model_name_or_path": a.sd, "synthetic": True, "cond_scale": 1.05,
@@ -228,22 +232,21 @@ def main():
     system.configure_optimizers()
     trainer = Trainer(system, dm, max_steps=10 ** 9, seed=0)
     trainer.seed_rank_streams()   # parameters are identical (seed 0 build + rank-0 broadcast); t / noise / jitter are per rank
-    total = a.warmup + a.steps
-    batches = [to_device(dm.train_dataset.collate(), dev) for _ in range(total)]     # resident in HBM
-    torch.cuda.synchronize()
-
+    # The data path is INSIDE the timed step: collate() draws this step's views / environments and gathers the camera
+    # tensors and the 22-channel condition maps from the HBM-resident tables (data.py `resident`; built during warm-up,
+    # like the reference decodes its pre-render tree once at start-up).  No step input is prepared ahead of the clock.
     def sync():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(a.warmup):
-        trainer.train_one_step(batches[i])
+    for i in range(max(a.warmup, 1)):
+        trainer.train_one_step()
     sync()
     hipops.enable_kernel_timing(True)
     t0 = time.perf_counter()
     for i in range(a.steps):
-        loss, logs = trainer.train_one_step(batches[a.warmup + i])
+        loss, logs = trainer.train_one_step()
     sync()
     elapsed = time.perf_counter() - t0
     hipops.enable_kernel_timing(False)
@@ -262,6 +265,10 @@ def main():
                                       f"{a.res}^2, {a.views} views/step, 5 synthetic env maps, {a.sd} UNet+22ch ControlNet "
                                       f"(random init), split-sum shading, hash-grid field 16x2 2^19",
                           "views_per_step": a.views, "views_per_rank": vpr, "resolution": a.res, "sd_arch": a.sd,
+                          "timed_region": "collate (draw + HBM gather of cameras and condition maps) + render + VAE/ControlNet/UNet + "
+                                          "SDS + backward + all-reduce + Adam; debug buffers off (written every 1000 steps only)",
+                          "fg_lut": "reference bsdf_256_256.bin" if system.material.real_fg_lut else "analytic stand-in (file absent)",
+                          "atlas_texel": system.material.atlas.texel,
                           "parallelism": f"dp{world} (views sharded, 1 all-reduce of {system.flat.numel * 4 / 1e6:.1f} MB fp32 grads)",
                           "final_loss": float(loss)}}
         # ---- rooflines, all from HIP events recorded around the launches of the timed region

@@ -1012,9 +1012,9 @@ int launch_attn_v3(const AttnArgs& a, hipStream_t stream) {
 
 static int g_attn_mode = -1;
 static int attn_mode_from_name(const char* e) {
-    if (!e || !strcmp(e, "v3")) return 3;
+    if (!e || !strcmp(e, "v3l")) return 4;
+    if (!strcmp(e, "v3")) return 3;
     if (!strcmp(e, "v3p")) return 5;
-    if (!strcmp(e, "v3l")) return 4;
     if (!strcmp(e, "v3s")) return 2;
     if (!strcmp(e, "dma")) return 1;
     if (!strcmp(e, "staged")) return 0;
@@ -1023,7 +1023,7 @@ static int attn_mode_from_name(const char* e) {
 static int attn_mode() {
     if (g_attn_mode < 0) {
         g_attn_mode = attn_mode_from_name(getenv("DREAMMAT_ATTN_KERNEL"));
-        if (g_attn_mode < 0) g_attn_mode = 3;
+        if (g_attn_mode < 0) g_attn_mode = 4;           // v3l: best or equal on every UNet shape (tools/r2_probe.py)
     }
     return g_attn_mode;
 }
@@ -1108,8 +1108,8 @@ int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* ou
     a.vt_bs = vt_bs; a.vt_hs = vt_hs; a.vt_ds = vt_ds; a.o_bs = o_bs; a.o_ss = o_ss; a.o_hs = o_hs;
     a.B = B; a.Hh = Hh; a.Sq = Sq; a.Skv = Skv; a.D = D;
     a.scale_log2 = scale * 1.4426950408889634f;
-    // Kernel choice: dm_attention_select() / DREAMMAT_ATTN_KERNEL = v3 (prologue Q scaling, 2 waves per SIMD) |
-    // v3l (v3 with late fragment reads, 3 waves per SIMD) | v3p (two-phase software pipeline for Skv >= 1024, v3l below) |
+    // Kernel choice: dm_attention_select() / DREAMMAT_ATTN_KERNEL = v3l (default: prologue Q scaling, late fragment reads,
+    // 3 waves per SIMD) | v3 (early fragment reads, 2 waves per SIMD) | v3p (two-phase software pipeline for Skv >= 1024, v3l below) |
     // v3s (v3 without the Q scaling) | dma (round-1 kernel) | staged
     // (register-staged): A/B measurements and regression tests.  D = 40/80/160 heads always use the staged kernel.
     const int mode = attn_mode();

@@ -404,7 +404,7 @@ def material_smoothness(feat, featj, n_dev):
 
 # ------------------------------------------------------------------------------------------ attention
 def attention_select(name=None):
-    """Kernel variant of every later attention() call: "v3p" | "v3" (default) | "v3l" | "v3s" | "dma" | "staged"; None restores the
+    """Kernel variant of every later attention() call: "v3l" (default) | "v3" | "v3p" | "v3s" | "dma" | "staged"; None restores the
     DREAMMAT_ATTN_KERNEL / default choice (dm_attention_select)."""
     check(_lib.lib().dm_attention_select(name.encode() if name is not None else None), "dm_attention_select")
 

@@ -54,6 +54,7 @@ class DreamMatMaterial(BaseModule):
         if latlongs is None:
             latlongs = self._load_envmaps()
         fg = load_fg_lut(self.cfg.fg_lut_path)
+        self.real_fg_lut = fg is not None
         if fg is None:
             print(f"[dreammat_amd] {self.cfg.fg_lut_path} not found: using the analytic stand-in FG LUT")
             fg = approx_fg_lut()

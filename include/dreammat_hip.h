@@ -220,7 +220,7 @@ int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* ou
                           int D, long long q_bs, long long q_ss, long long q_hs, long long k_bs, long long k_ss,
                           long long k_hs, long long vt_bs, long long vt_hs, long long vt_ds, long long o_bs,
                           long long o_ss, long long o_hs, float scale, dm_stream_t stream);
-/* Kernel variant for every later dm_attention_fwd_bf16 call of the process: "v3p", "v3" (default), "v3l", "v3s", "dma" (round 1),
+/* Kernel variant for every later dm_attention_fwd_bf16 call of the process: "v3l" (default), "v3", "v3p", "v3s", "dma" (round 1),
  * "staged"; NULL = back to the DREAMMAT_ATTN_KERNEL environment variable / default.  For A/B measurements and for the
  * parity tests, which run every variant.  DM_ERR_ARG for an unknown name. */
 int dm_attention_select(const char* name);
