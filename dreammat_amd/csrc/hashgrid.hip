@@ -8,6 +8,8 @@
 //         them are fully coalesced.
 // One thread per (point, level); blockIdx.y = level so a workgroup hammers one level's table
 // region (L2 locality).  Backward uses hardware fp32 atomics (-munsafe-fp-atomics).
+#include <algorithm>
+
 #include "dm_common.h"
 
 namespace {
@@ -253,6 +255,137 @@ __global__ __launch_bounds__(LH_THREADS) void k_hashgrid_bwd_lds(HashArgs a, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward, third formulation -- the hashed levels.  fp32 global atomics retire at ~20.7 G/s on MI355X whatever the
+// table size or the sharing pattern (tools/atomic_probe.cpp: shared table, one private table per XCD, lane pairs on one
+// 8-byte slot: all 20.5-20.8 G/s), and on a hashed level nothing can be merged locally: a level's 18 M corner updates
+// (8 x 2.3 M points) hit its 2^19 entries pseudo-randomly, ~35 updates per entry but never from neighbouring lanes.
+// So the updates are first ROUTED, then accumulated where atomics are cheap:
+//   pass 1  k_hg_bin    every point emits its 8 (entry, g0*w, g1*w) tuples per level into one of size/16384 bins (a bin =
+//                       16384 consecutive table entries); a workgroup ranks its tuples per bin with LDS counters and
+//                       reserves the bin space with ONE global atomic per (workgroup, bin) -- 128x fewer than per tuple;
+//   pass 2  k_hg_acc    one workgroup per (level, bin, split) sums its share of the bin's tuples into a 128 KB LDS table
+//                       (ds_add_f32) and writes the table to a partial slab;
+//   pass 3  k_hg_sum    dtable += sum over the splits' slabs (plain read-modify-write, no atomics).
+// A tuple that finds its bin full (capacity = 1.3 x the uniform share) falls back to the global atomic: time, not
+// correctness.  Bytes: 16 B per tuple written and read once = 0.59 GB per level.
+constexpr int HB_LOG2 = 14, HB_ENTRIES = 1 << HB_LOG2;     // table entries per bin: 2 x 16384 fp32 = 128 KB of LDS
+constexpr int HB_MAX_BINS = 64;                            // log2_hashmap_size <= 20
+constexpr int HB_SPLITS = 4;
+constexpr int HB_ACC_THREADS = 1024;
+
+struct BinArgs {
+    HashArgs h;
+    int levels[kMaxLevels];        // binned levels (indices into h.lv)
+    int n_binned;
+    uint4* tuples;                 // [n_binned][HB_MAX_BINS][cap]
+    unsigned* counts;              // [n_binned][HB_MAX_BINS]   (zeroed by the launcher)
+    float* partial;                // [n_binned][HB_SPLITS][max_size * 2]
+    long long cap;                 // tuples per bin
+    long long max_size;            // largest level size among the binned levels
+};
+
+__global__ __launch_bounds__(256) void k_hg_bin(BinArgs a) {
+    __shared__ unsigned lcnt[HB_MAX_BINS], lbase[HB_MAX_BINS];
+    const int tid = threadIdx.x;
+    const int li = blockIdx.y, l = a.levels[li];
+    if (tid < HB_MAX_BINS) lcnt[tid] = 0;
+    __syncthreads();
+    const long long M = a.h.m_dev ? (long long)*a.h.m_dev : a.h.m_max;
+    const long long m = (long long)blockIdx.x * blockDim.x + tid;
+    const bool valid = m < M;
+    const float scale = a.h.lv.scale[l];
+    const unsigned res = a.h.lv.res[l], size = a.h.lv.size[l], off = a.h.lv.offset[l];
+    unsigned idx[8], rank[8];
+    float v0[8], v1[8];
+    if (valid) {
+        float w[3];
+        unsigned cell[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            float xn = (a.h.x[m * a.h.x_rs + d * a.h.x_cs] + a.h.radius) * a.h.inv_2r;
+            float p = xn * scale + 0.5f;
+            float fl = floorf(p);
+            w[d] = p - fl;
+            cell[d] = (unsigned)(int)fl;
+        }
+        const float g0 = a.h.dout[m * a.h.dout_rs + (2 * l) * a.h.dout_cs];
+        const float g1 = a.h.dout[m * a.h.dout_rs + (2 * l + 1) * a.h.dout_cs];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            unsigned cx = cell[0] + (c & 1), cy = cell[1] + ((c >> 1) & 1), cz = cell[2] + ((c >> 2) & 1);
+            float wt = ((c & 1) ? w[0] : 1.f - w[0]) * (((c >> 1) & 1) ? w[1] : 1.f - w[1]) *
+                       (((c >> 2) & 1) ? w[2] : 1.f - w[2]);
+            idx[c] = grid_index(cx, cy, cz, res, size);
+            v0[c] = g0 * wt;
+            v1[c] = g1 * wt;
+            rank[c] = atomicAdd(&lcnt[idx[c] >> HB_LOG2], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid < HB_MAX_BINS) {
+        const unsigned n = lcnt[tid];
+        lbase[tid] = n ? atomicAdd(&a.counts[li * HB_MAX_BINS + tid], n) : 0u;
+    }
+    __syncthreads();
+    if (valid) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const unsigned bin = idx[c] >> HB_LOG2;
+            const long long pos = (long long)lbase[bin] + rank[c];
+            if (pos < a.cap) {
+                a.tuples[((long long)li * HB_MAX_BINS + bin) * a.cap + pos] =
+                    make_uint4(idx[c] & (HB_ENTRIES - 1), __float_as_uint(v0[c]), __float_as_uint(v1[c]), 0u);
+            } else {                                       // bin full: the slow, always-correct route
+                float* dst = a.h.dtable + 2 * (size_t)(off + idx[c]);
+                atomicAdd(dst, v0[c]);
+                atomicAdd(dst + 1, v1[c]);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(HB_ACC_THREADS) void k_hg_acc(BinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];      // [HB_ENTRIES][2]
+    const int tid = threadIdx.x;
+    const int li = blockIdx.y, l = a.levels[li];
+    const int bin = blockIdx.x / HB_SPLITS, split = blockIdx.x - bin * HB_SPLITS;
+    const unsigned size = a.h.lv.size[l];
+    if ((long long)bin * HB_ENTRIES >= (long long)size) return;      // this level has fewer bins
+    for (int i = tid; i < HB_ENTRIES / 2; i += HB_ACC_THREADS) reinterpret_cast<float4*>(tab)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const long long n = min((long long)a.counts[li * HB_MAX_BINS + bin], a.cap);
+    const long long lo = n * split / HB_SPLITS, hi = n * (split + 1) / HB_SPLITS;
+    const uint4* src = a.tuples + ((long long)li * HB_MAX_BINS + bin) * a.cap;
+    for (long long i = lo + tid; i < hi; i += HB_ACC_THREADS) {
+        const uint4 t = src[i];
+        atomicAdd(&tab[2 * t.x], __uint_as_float(t.y));
+        atomicAdd(&tab[2 * t.x + 1], __uint_as_float(t.z));
+    }
+    __syncthreads();
+    const int n_ent = (int)min((long long)HB_ENTRIES, (long long)size - (long long)bin * HB_ENTRIES);
+    float* dst = a.partial + ((long long)li * HB_SPLITS + split) * a.max_size * 2 + (long long)bin * HB_ENTRIES * 2;
+    for (int i = tid; i < n_ent / 2; i += HB_ACC_THREADS) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<float4*>(tab)[i];
+    if ((n_ent & 1) && tid == 0) { dst[2 * (n_ent - 1)] = tab[2 * (n_ent - 1)]; dst[2 * (n_ent - 1) + 1] = tab[2 * (n_ent - 1) + 1]; }
+}
+
+__global__ __launch_bounds__(256) void k_hg_sum(BinArgs a) {
+    const int li = blockIdx.y, l = a.levels[li];
+    const unsigned size = a.h.lv.size[l], off = a.h.lv.offset[l];
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= size) return;
+    float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int s = 0; s < HB_SPLITS; ++s) {
+        const float2 p = reinterpret_cast<const float2*>(a.partial + ((long long)li * HB_SPLITS + s) * a.max_size * 2)[e];
+        acc.x += p.x; acc.y += p.y;
+    }
+    float2* dst = reinterpret_cast<float2*>(a.h.dtable) + off + e;
+    float2 cur = *dst;
+    cur.x += acc.x; cur.y += acc.y;
+    *dst = cur;
+}
+
 bool fill_levels(GridLevels& lv, int n_levels, const float* scale, const uint32_t* res, const uint32_t* size,
                  const uint32_t* offset) {
     if (n_levels <= 0 || n_levels > kMaxLevels || !scale || !res || !size || !offset) return false;
@@ -310,6 +443,85 @@ int dm_hashgrid_bwd(const float* x, long long x_rs, long long x_cs, const int32_
     if (n_levels > n_dedup)
         hipLaunchKernelGGL(k_hashgrid_bwd2<false>, dim3(dm_div_up(2 * m_max, 256), n_levels - n_dedup), dim3(256), 0,
                            stream, a, n_dedup);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+// Workspace of dm_hashgrid_bwd_binned for at most m_max points (0 if no level of this grid takes the binned route).
+static bool hg_level_hashed(uint32_t res, uint32_t size) { return (unsigned long long)res * res * res > size; }
+static long long hg_bin_cap(long long m_max, uint32_t size) {
+    const long long bins = (size + HB_ENTRIES - 1) / HB_ENTRIES;
+    return (8 * m_max / bins) * 13 / 10 + 4096;
+}
+size_t dm_hashgrid_bwd_workspace_bytes(long long m_max, int n_levels, const uint32_t* lv_res, const uint32_t* lv_size) {
+    if (m_max <= 0 || n_levels <= 0 || n_levels > kMaxLevels || !lv_res || !lv_size) return 0;
+    long long n_binned = 0, cap = 0, max_size = 0;
+    for (int i = 0; i < n_levels; ++i)
+        if (hg_level_hashed(lv_res[i], lv_size[i]) && lv_size[i] <= (uint32_t)HB_MAX_BINS * HB_ENTRIES) {
+            ++n_binned;
+            cap = std::max(cap, hg_bin_cap(m_max, lv_size[i]));
+            max_size = std::max<long long>(max_size, lv_size[i]);
+        }
+    if (!n_binned) return 0;
+    return (size_t)(n_binned * HB_MAX_BINS * cap * 16 + n_binned * HB_MAX_BINS * 4 + 256 +
+                    n_binned * HB_SPLITS * max_size * 8 + 256);
+}
+
+// dm_hashgrid_bwd with the hashed levels routed through bins (see k_hg_bin); the dense levels run the kernels of
+// dm_hashgrid_bwd.  `workspace` = dm_hashgrid_bwd_workspace_bytes(m_max, ...) bytes of device memory, 256 B aligned.
+int dm_hashgrid_bwd_binned(const float* x, long long x_rs, long long x_cs, const int32_t* m_dev, long long m_max,
+                           const float* denc, long long denc_rs, long long denc_cs, int n_levels, const float* lv_scale,
+                           const uint32_t* lv_res, const uint32_t* lv_size, const uint32_t* lv_offset, float radius,
+                           float* dtable, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    BinArgs b = {};
+    HashArgs& a = b.h;
+    if (!x || !denc || !dtable || m_max <= 0 || !(radius > 0.f) || !fill_levels(a.lv, n_levels, lv_scale, lv_res, lv_size, lv_offset))
+        return DM_ERR_ARG;
+    const size_t need = dm_hashgrid_bwd_workspace_bytes(m_max, n_levels, lv_res, lv_size);
+    if (need && (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 255))) return DM_ERR_WORKSPACE;
+    a.x = x; a.x_rs = x_rs; a.x_cs = x_cs; a.dout = denc; a.dout_rs = denc_rs; a.dout_cs = denc_cs;
+    a.dtable = dtable; a.m_dev = m_dev; a.m_max = m_max; a.radius = radius; a.inv_2r = 1.0f / (2.0f * radius);
+    // dense levels: contiguous prefix (resolution grows with the level), same kernels as dm_hashgrid_bwd
+    int n_dense = 0;
+    while (n_dense < n_levels && !(hg_level_hashed(lv_res[n_dense], lv_size[n_dense]) &&
+                                   lv_size[n_dense] <= (uint32_t)HB_MAX_BINS * HB_ENTRIES)) ++n_dense;
+    long long cap = 0, max_size = 0;
+    for (int i = n_dense; i < n_levels; ++i) {
+        if (!(hg_level_hashed(lv_res[i], lv_size[i]) && lv_size[i] <= (uint32_t)HB_MAX_BINS * HB_ENTRIES)) return DM_ERR_UNSUPPORTED;
+        b.levels[b.n_binned++] = i;
+        cap = std::max(cap, hg_bin_cap(m_max, lv_size[i]));
+        max_size = std::max<long long>(max_size, lv_size[i]);
+    }
+    DM_ENTER();
+    if (n_dense > 0) {
+        int n_lds = 0;
+        while (n_lds < n_dense && lv_res[n_lds] <= 110) ++n_lds;
+        if (n_lds > 0)
+            hipLaunchKernelGGL(k_hashgrid_bwd_lds, dim3(dm_div_up(m_max, LH_THREADS * LH_PTS), n_lds), dim3(LH_THREADS), 0, stream, a, 0);
+        if (n_dense > n_lds)
+            hipLaunchKernelGGL(k_hashgrid_bwd2<true>, dim3(dm_div_up(2 * m_max, 256), n_dense - n_lds), dim3(256), 0, stream, a, n_lds);
+    }
+    if (b.n_binned > 0) {
+        char* ws = (char*)workspace;
+        b.tuples = (uint4*)ws;
+        ws += (size_t)b.n_binned * HB_MAX_BINS * cap * 16;
+        b.counts = (unsigned*)ws;
+        ws += ((size_t)b.n_binned * HB_MAX_BINS * 4 + 255) / 256 * 256;
+        b.partial = (float*)ws;
+        b.cap = cap; b.max_size = max_size;
+        hipError_t e = hipMemsetAsync(b.counts, 0, (size_t)b.n_binned * HB_MAX_BINS * 4, stream);
+        if (e != hipSuccess) return (int)e;
+        static bool attr_set = false;
+        if (!attr_set) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hg_acc), hipFuncAttributeMaxDynamicSharedMemorySize, HB_ENTRIES * 8);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        const int max_bins = (int)((max_size + HB_ENTRIES - 1) / HB_ENTRIES);
+        hipLaunchKernelGGL(k_hg_bin, dim3(dm_div_up(m_max, 256), b.n_binned), dim3(256), 0, stream, b);
+        hipLaunchKernelGGL(k_hg_acc, dim3(max_bins * HB_SPLITS, b.n_binned), dim3(HB_ACC_THREADS), HB_ENTRIES * 8, stream, b);
+        hipLaunchKernelGGL(k_hg_sum, dim3(dm_div_up(max_size, 256), b.n_binned), dim3(256), 0, stream, b);
+    }
     DM_LAUNCH_CHECK();
     return DM_OK;
 }

@@ -283,6 +283,20 @@ class GridSpec:
         self.levels = [dict(scale=a, res=b, size=c, offset=d) for a, b, c, d in zip(scale, res, size, offset)]
 
 
+# backward route: >= this many points -> the binned kernels (dm_hashgrid_bwd_binned), below -> one global atomic pair per corner.
+# The workspace (16 B per corner update x 1.3 + the per-split slabs: ~4.3 GB at 8 views x 512^2) is allocated once and kept.
+HASHGRID_BINNED_MIN_POINTS = 1 << 16
+_HG_WS = {}
+
+
+def _hashgrid_workspace(nbytes, device):
+    key = (device.type, device.index)
+    ws = _HG_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        _HG_WS[key] = ws = torch.empty(int(nbytes * 1.1) + 256, dtype=torch.uint8, device=device)
+    return ws
+
+
 class _HashGrid(torch.autograd.Function):
     """x [M,3] (any strides) -> enc, returned as an [M,2L] VIEW of a feature-major [2L,M] buffer.
     `grad_sink`: optional pre-allocated gradient buffer of `table` (the flat all-reduce buffer); the
@@ -315,9 +329,20 @@ class _HashGrid(torch.autograd.Function):
         if M > 0:
             rs, cs = _rs_cs(x)
             grs, gcs = _rs_cs(g)
-            check(_lib.lib().dm_hashgrid_bwd(x.data_ptr(), rs, cs, None, M, g.data_ptr(), grs, gcs, spec.n_levels,
-                                             spec.c_scale, spec.c_res, spec.c_size, spec.c_offset, float(ctx.radius),
-                                             dtable.data_ptr(), _stream()), "dm_hashgrid_bwd")
+            L = _lib.lib()
+            ws_bytes = int(L.dm_hashgrid_bwd_workspace_bytes(M, spec.n_levels, spec.c_res, spec.c_size)) \
+                if M >= HASHGRID_BINNED_MIN_POINTS else 0
+            with _Timed(f"hashgrid_bwd[{'binned' if ws_bytes else 'atomic'}]", float(M) * (12 + 4 * spec.n_output_dims)):
+                if ws_bytes:
+                    ws = _hashgrid_workspace(ws_bytes, x.device)
+                    check(L.dm_hashgrid_bwd_binned(x.data_ptr(), rs, cs, None, M, g.data_ptr(), grs, gcs, spec.n_levels,
+                                                   spec.c_scale, spec.c_res, spec.c_size, spec.c_offset, float(ctx.radius),
+                                                   dtable.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+                          "dm_hashgrid_bwd_binned")
+                else:
+                    check(L.dm_hashgrid_bwd(x.data_ptr(), rs, cs, None, M, g.data_ptr(), grs, gcs, spec.n_levels,
+                                            spec.c_scale, spec.c_res, spec.c_size, spec.c_offset, float(ctx.radius),
+                                            dtable.data_ptr(), _stream()), "dm_hashgrid_bwd")
         return None, (None if direct else dtable), None, None, None
 
 

@@ -107,6 +107,14 @@ int dm_hashgrid_fwd(const float* x, long long x_rs, long long x_cs, const int32_
                     const uint32_t* lv_size_host, const uint32_t* lv_offset_host, float radius, float* enc,
                     long long enc_rs, long long enc_cs, dm_stream_t stream);
 /* Backward of the above wrt the table; ADDS into dtable (caller zeroes it once per step). */
+/* The same gradient with the HASHED levels (resolution^3 > table size) routed through bins instead of one global atomic pair per
+ * corner (fp32 atomics retire at ~20 G/s on MI355X): tuples are binned by table region, summed in LDS, added once.  Workspace:
+ * dm_hashgrid_bwd_workspace_bytes() bytes of device memory, 256 B aligned, contents irrelevant.  ADDS into dtable. */
+size_t dm_hashgrid_bwd_workspace_bytes(long long m_max, int n_levels, const uint32_t* lv_res, const uint32_t* lv_size);
+int dm_hashgrid_bwd_binned(const float* x, long long x_rs, long long x_cs, const int32_t* m_dev, long long m_max,
+                           const float* denc, long long denc_rs, long long denc_cs, int n_levels, const float* lv_scale,
+                           const uint32_t* lv_res, const uint32_t* lv_size, const uint32_t* lv_offset, float radius,
+                           float* dtable, void* workspace, size_t workspace_bytes, dm_stream_t stream);
 int dm_hashgrid_bwd(const float* x, long long x_rs, long long x_cs, const int32_t* m_dev, long long m_max,
                     const float* denc, long long denc_rs, long long denc_cs, int n_levels,
                     const float* lv_scale_host, const uint32_t* lv_res_host, const uint32_t* lv_size_host,

@@ -150,6 +150,37 @@ def test_hashgrid_full_size_levels(dev):
     assert (enc.cpu() - ref).abs().max() < 1e-4 * 1e-1 * 10
 
 
+@pytest.mark.parametrize("n_levels,log2,M", [(16, 19, 200000), (12, 15, 70000), (10, 13, 66000)])
+def test_hashgrid_backward_binned_route_vs_oracle_and_atomic_route(dev, monkeypatch, n_levels, log2, M):
+    """dm_hashgrid_bwd_binned (hashed levels routed through table-region bins, LDS accumulation, one add per entry) against
+    the oracle's autograd and against the one-atomic-per-corner route, incl. the full dreammat.yaml grid (11 hashed levels,
+    32 bins each), a 2-bin and a 1-bin table, pixel-coherent points, and a bin-overflow run (capacity forced tiny)."""
+    torch.manual_seed(3)
+    spec = hipops.GridSpec(n_levels=n_levels, log2_hashmap_size=log2)
+    lv, tot = ofield.grid_levels(n_levels=n_levels, log2_hashmap_size=log2)
+    t = torch.linspace(0, 1, M)[:, None]
+    x = torch.cat([-0.7 + 1.4 * t, 0.5 * torch.sin(9 * t), 0.3 * torch.cos(5 * t) + 0.01 * torch.randn(M, 1)], dim=1)
+    x[: M // 3] = torch.rand(M // 3, 3) * 1.8 - 0.9
+    table = torch.rand(tot * 2) * 2 - 1
+    dy = torch.randn(M, 2 * n_levels)
+    to = table.reshape(-1, 2).clone().requires_grad_()
+    ofield.hash_encode(ofield.contract_to_unisphere(x), to, lv).backward(dy)
+    grads = {}
+    for route, min_pts in (("binned", 0), ("atomic", 1 << 40)):
+        monkeypatch.setattr(hipops, "HASHGRID_BINNED_MIN_POINTS", min_pts)
+        tg = table.to(dev).requires_grad_()
+        hipops.enable_kernel_timing(True)
+        hipops.hashgrid_encode(x.t().contiguous().to(dev).t(), tg, spec, 1.0).backward(dy.to(dev))
+        torch.cuda.synchronize()
+        assert any(k == f"hashgrid_bwd[{route}]" for k in hipops.kernel_times()), route
+        hipops.enable_kernel_timing(False)
+        grads[route] = tg.grad.cpu().reshape(-1, 2)
+    gmax = to.grad.abs().max()
+    for route, g in grads.items():
+        assert (g - to.grad).abs().max() < 1e-3 * gmax, route
+    assert (grads["binned"] - grads["atomic"]).abs().max() < 1e-4 * gmax
+
+
 @pytest.fixture(scope="module")
 def envs():
     lat = [util.synthetic_latlong(i) * 0.02 for i in range(3)]

@@ -188,6 +188,41 @@ def shade_section(a, res):
                         feat_smooth, dcol, gb.pix_idx[:N], env_of_view, H * W, texel != "fp32")
 
 
+def hashgrid_section(a, res):
+    """backward of the full 16-level grid on the bench scene's 2 x N sample points: atomic route vs binned route."""
+    B, H, W = 8, 512, 512
+    m = pmesh.displaced_sphere(160, 160)
+    batch = util.make_views(B, H, W, seed=0)
+    v = m.v_pos.to(dev); tri = m.t_pos_idx.to(dev).int().contiguous(); vn = m.v_nrm.to(dev)
+    pos = hipops.vertex_transform(v, batch["mvp_mtx"].to(dev))
+    rast = hipops.RasterContext(dev).rasterize(pos, tri, H, W)
+    gb = hipops.gbuffer_compact(rast, tri, v, vn, batch["rays_d"].to(dev), torch.rand(B, H, W, device=dev),
+                                torch.randn(B, H, W, device=dev), 0.05)
+    pts2 = torch.cat([gb.pos, gb.pos_jitter], dim=1).t()
+    M = pts2.shape[0]
+    spec = hipops.GridSpec()
+    dt = torch.zeros(spec.n_params, device=dev)
+    dy = torch.randn(2 * spec.n_levels, M, device=dev)
+    L = _lib.lib()
+    ws_bytes = int(L.dm_hashgrid_bwd_workspace_bytes(M, spec.n_levels, spec.c_res, spec.c_size))
+    ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=dev)
+
+    def atomic():
+        _lib.check(L.dm_hashgrid_bwd(pts2.data_ptr(), pts2.stride(0), pts2.stride(1), None, M, dy.data_ptr(), 1, M, spec.n_levels,
+                                     spec.c_scale, spec.c_res, spec.c_size, spec.c_offset, 1.0, dt.data_ptr(), hipops._stream()))
+
+    def binned():
+        _lib.check(L.dm_hashgrid_bwd_binned(pts2.data_ptr(), pts2.stride(0), pts2.stride(1), None, M, dy.data_ptr(), 1, M,
+                                            spec.n_levels, spec.c_scale, spec.c_res, spec.c_size, spec.c_offset, 1.0,
+                                            dt.data_ptr(), ws.data_ptr(), ws.numel(), hipops._stream()))
+    tm = ab({"atomic": atomic, "binned": binned}, a.rounds, max(2, a.iters // 3))
+    for k, t in tm.items():
+        r = {"op": "hashgrid_bwd", "route": k, "M": M, "ms_median": t["median_s"] * 1e3, "workspace_GB": ws_bytes / 1e9,
+             "corner_updates_M": M * 16 * 8 / 1e6}
+        res.append(r)
+        print(json.dumps(r), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
@@ -195,9 +230,12 @@ def main():
     ap.add_argument("--skip-attn", action="store_true")
     ap.add_argument("--skip-shade", action="store_true")
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--skip-hashgrid", action="store_true")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     res = []
+    if not a.skip_hashgrid:
+        hashgrid_section(a, res)
     if not a.skip_shade:
         shade_section(a, res)
     if not a.skip_attn:
