@@ -104,9 +104,10 @@ __global__ __launch_bounds__(128) void k_mc_shade(McArgs a) {
 // ---- one WAVE per pixel: the nd + ns sample directions are spread over the 64 lanes (6 rounds for 200 + 128), each
 // lane traces its own occlusion rays and accumulates its share of A / B / Ld / Ls; a butterfly reduction combines the
 // lanes, lane 0 finishes the pixel.  All rays of a wave start at the same surface point, so the top of the BVH is
-// shared; the hit bits of a round are exactly one __ballot.  Opt-in (DREAMMAT_MC_KERNEL=wave) until it has been
-// validated and timed on the GPU; the decomposition itself (strided samples, bit packing, finish on the combined sums)
-// is checked on the CPU by tests/hostemu (emu_mc_shade with lanes > 1).
+// shared; the hit bits of a round are exactly one __ballot.  Default since round 2 (MI355X, 100 k points of the 50 880-triangle
+// bench mesh, 200 + 128 directions: serial 130 ms / 0.25 G rays/s, wave 82 ms, wave + 4-wide BVH 68 ms / 0.48 G rays/s --
+// profiles/r02_mc_probe.json); DREAMMAT_MC_KERNEL=serial selects the one-thread-per-pixel kernel.  The decomposition
+// (strided samples, bit packing, finish on the combined sums) is checked on the CPU by tests/hostemu.
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void k_mc_shade_wave(McArgs a) {
 
 bool use_wave_kernel() {
     const char* e = getenv("DREAMMAT_MC_KERNEL");      // read per call: tests toggle it
-    return e && !strcmp(e, "wave");
+    return !(e && !strcmp(e, "serial"));
 }
 
 template <bool BWD>

@@ -632,8 +632,9 @@ class McScene:
         self.samples_s = fibonacci_direction_samples(n_specular).to(dev)
         self.n_diffuse, self.n_specular = int(n_diffuse), int(n_specular)
         self.hit_words = int(_lib.lib().dm_mc_hit_words(self.n_diffuse, self.n_specular))
-        # DREAMMAT_BVH=4: trace through the 4-wide nodes (opt-in until timed on the GPU; same hits by construction)
-        self.nodes4 = bvh.nodes4_host.to(dev) if os.environ.get("DREAMMAT_BVH") == "4" else None
+        # 4-wide nodes (child boxes in the parent: a quarter of the dependent fetches per ray, same hits by construction) are
+        # the default since they were timed (profiles/r02_mc_probe.json); DREAMMAT_BVH=2 selects the binary tree
+        self.nodes4 = bvh.nodes4_host.to(dev) if os.environ.get("DREAMMAT_BVH", "4") == "4" else None
         self.struct = _lib.McSceneStruct(bvh.nodes.data_ptr(), bvh.tris.data_ptr(), self.lights.data_ptr(),
                                          self.lights.shape[0], self.lights.shape[1], self.lights.shape[2],
                                          self.samples_d.data_ptr(), self.samples_s.data_ptr(), self.n_diffuse,

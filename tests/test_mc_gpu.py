@@ -93,7 +93,7 @@ def test_material_plugin_raytracing_branch_runs(dev):
 @pytest.mark.parametrize("bvh_width", ["2", "4"])
 @pytest.mark.parametrize("variant", ["schlick", "ggx_smith"])
 def test_mc_wave_kernel_matches_the_serial_kernel(variant, bvh_width, monkeypatch):
-    """the opt-in one-wave-per-pixel Monte-Carlo kernel (DREAMMAT_MC_KERNEL=wave; samples over the 64 lanes, ballot hit
+    """the one-wave-per-pixel Monte-Carlo kernel (the default; samples over the 64 lanes, ballot hit
     bits, butterfly reduction) against the validated one-thread-per-pixel kernel; its decomposition is CPU-checked in
     tests/test_golden_cpu.py."""
     if not torch.cuda.is_available():
@@ -104,7 +104,7 @@ def test_mc_wave_kernel_matches_the_serial_kernel(variant, bvh_width, monkeypatc
     g = {k: torch.from_numpy(v) if v.ndim else v
          for k, v in np.load(os.path.join(os.path.dirname(__file__), "golden", "mc_shading.npz")).items()}
     bvh = hipops.MeshBvh(g["v_pos"], g["tri"], dev)
-    monkeypatch.delenv("DREAMMAT_BVH", raising=False)
+    monkeypatch.setenv("DREAMMAT_BVH", "2")                # reference: the validated serial kernel on the binary tree
     scene_ref = hipops.McScene(bvh, [g["light"]], g[f"{variant}_dsamp"].shape[0], g[f"{variant}_ssamp"].shape[0], variant)
     monkeypatch.setenv("DREAMMAT_BVH", bvh_width)          # "4": trace through the 4-wide collapse of the same tree
     scene_new = hipops.McScene(bvh, [g["light"]], g[f"{variant}_dsamp"].shape[0], g[f"{variant}_ssamp"].shape[0], variant)
@@ -120,7 +120,7 @@ def test_mc_wave_kernel_matches_the_serial_kernel(variant, bvh_width, monkeypatc
                                torch.zeros(1, dtype=torch.int32, device=dev), scene, mat, 1 << 30, rd, rs, True)
         (outs[0] * g[f"{variant}_wgt"].to(dev)).sum().backward()
         return [o.detach().cpu() for o in outs], feats.grad.cpu()
-    monkeypatch.delenv("DREAMMAT_MC_KERNEL", raising=False)
+    monkeypatch.setenv("DREAMMAT_MC_KERNEL", "serial")
     ref_out, ref_grad = run(scene_ref)
     monkeypatch.setenv("DREAMMAT_MC_KERNEL", "wave")
     out, grad = run(scene_new)
