@@ -14,6 +14,7 @@
 // (conflict-free ds_read_b128), one barrier per K-step.  The same kernel computes the data gradient
 // (the VAE encoder is differentiated through): dx = conv(dy, w') with w' = taps flipped, Cin<->Cout
 // swapped (prepared once on the host side).  Requirements: Cin % 32 == 0, Cout % 64 == 0.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -26,6 +27,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgs {
     const __bf16* x;     // [B, Hin, Win, Cin]
@@ -184,10 +187,8 @@ __global__ __launch_bounds__(256) void k_conv3x3(ConvArgs a, long long n_mt, int
 //  * LDS rows are unpadded 128 B (the DMA writes wave-uniform base + lane*16); bank conflicts are
 //    avoided by XOR-swizzling the 16 B chunk index with (row>>1)&7 -- applied to the per-lane SOURCE
 //    address on the way in and to the ds_read address on the way out (same involution both sides).
-//  * out-of-image taps read from a 16-byte zero page instead of being predicated.
+//  * out-of-image taps are buffer offsets beyond num_records (the descriptor's range check returns zeros).
 //  * counted s_waitcnt vmcnt(L) + raw s_barrier: one barrier per K-step, loads span the barrier.
-__device__ __attribute__((aligned(16))) unsigned int g_zero_page[4] = {0, 0, 0, 0};
-
 template <int BMT, int BN, int NW, int WMW, int NSTAGE>
 __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n_mt, int n_nt) {
     // BMT x BN x 64 workgroup tile, NW waves laid out WMW (along M) x NW/WMW (along N), NSTAGE-deep LDS ring.
@@ -208,68 +209,98 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     static_assert(TM % 32 == 0 && TN % 32 == 0 && BMT % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile shape");
     static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // NSTAGE * STAGE
+#if defined(__HIP_DEVICE_COMPILE__)   // __amdgpu_buffer_rsrc_t does not exist in the host pass (the stub needs no body)
 
-    long long mt; int nt;
-    {
-        const long long total = n_mt * n_nt;
-        const long long lin = (long long)blockIdx.x;
-        const long long per_xcd = (total + 7) / 8;
-        const long long id = (lin & 7) * per_xcd + (lin >> 3);
-        if ((lin >> 3) >= per_xcd || id >= total) return;
-        mt = id / n_nt;
-        nt = (int)(id - mt * n_nt);
-    }
+    // PERSISTENT workgroups: gridDim.x (a multiple of 8) workgroups walk the tiles of their XCD's contiguous id range
+    // (block b runs on XCD b % 8, private L2 each) with stride gridDim.x / 8, and the LDS-DMA ring keeps running ACROSS
+    // tile boundaries: while tile t's last K-steps multiply and its epilogue stores, the first K-steps of tile t+1 are
+    // already landing.  One workgroup per tile paid a cold prologue (address set-up, first DMA round trip), a store tail
+    // and a relaunch per tile -- 0.25 ms of the 0.80 ms of the 8 x 128->128 @512^2 layer did not scale with K
+    // (tools/conv_fit.sh), with one workgroup per CU nothing else could cover it.
+    const long long total = n_mt * n_nt;
+    const long long per_xcd = (total + 7) / 8;
+    const int wpx = (int)(gridDim.x >> 3);             // workgroups per XCD
+    const long long xbeg = (long long)(blockIdx.x & 7) * per_xcd;
+    const long long xend = xbeg + per_xcd < total ? xbeg + per_xcd : total;
+    const long long first = xbeg + (blockIdx.x >> 3);
+    if (first >= xend) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int wm = wave / WNW, wn = wave % WNW;
     // M tile = patch of TW x TH output pixels: rows Y0.. of the tall image [B*Hout, Wout], columns X0..
     // (tile row r -> pixel (Y0 + r / TW, X0 + r % TW)).  A 1-D run of BMT pixels re-reads 3 full image rows per
     // tile; the patch re-reads a one-pixel halo: (TH+2)(TW+2)/(TH*TW) = 1.2-1.3x.
     const int TWm = (1 << a.tw_log2) - 1;
-    const int tile_y = (int)(mt / a.tiles_x);          // B*Hout < 2^31 (checked by the launcher): 32-bit row math
-    const int Y0 = tile_y * (BMT >> a.tw_log2);
-    const int X0 = (int)(mt - (long long)tile_y * a.tiles_x) << a.tw_log2;
     const int rows_total = a.B * a.Hout;
-    const int n0 = nt * BN;
+    auto tile_coords = [&](long long id, int& Y0, int& X0, int& n0) __attribute__((always_inline)) {
+        const long long mt = id / n_nt;
+        const int nt = (int)(id - mt * n_nt);
+        const int tile_y = (int)(mt / a.tiles_x);      // B*Hout < 2^31 (checked by the launcher): 32-bit row math
+        Y0 = tile_y * (BMT >> a.tw_log2);
+        X0 = (int)(mt - (long long)tile_y * a.tiles_x) << a.tw_log2;
+        n0 = nt * BN;
+    };
     const int lrow = lane >> 3, lslot = lane & 7;      // this lane's row / 16 B slot inside one DMA instruction
-    const unsigned long long zero = (unsigned long long)g_zero_page;
 
-    // A rows of this lane: wave*(BMT/NW) + 8*i + lrow.  Everything that depends on the row is computed ONCE:
-    // a pointer to tap (0,0) / channel 0 of the row's receptive field (pre-swizzled chunk; it may lie outside
-    // the image and is only dereferenced for taps whose bit is set in a_mask) and a 9-bit tap-validity mask.
-    // The K-loop then needs one 64-bit add and one select per DMA instruction (the first version recomputed
-    // ((b*Hin + y)*Win + x)*Cin per tap: ~110 VALU / 24 quarter-rate multiplies per K-step per wave, more
-    // issue time than the 16 MFMAs they feed).
-    const __bf16* a_ptr[A_INSTR];
+    // ---- issue side: buffer-addressed DMA (buffer_load_dwordx4 ... lds).  Both operands are described by a raw buffer
+    // resource (the launcher admits tensors below 4 GB), so a lane's source is a 32-bit byte offset and an out-of-image
+    // tap is the offset OOB >= num_records: the hardware returns zeros for it -- no zero page, no 64-bit pointer
+    // arithmetic, half the address registers of the pointer version (which spilled once the ring ran across tiles).
+    // A rows of this lane: wave*(BMT/NW) + 8*i + lrow.  Everything that depends on the row is computed ONCE per tile:
+    // the byte offset of tap (0,0) / channel 0 of the row's receptive field (pre-swizzled chunk; it may lie before the
+    // tensor -- it wraps mod 2^32 and is only used for taps whose bit is set in a_mask, where offset + tap offset is a
+    // true in-tensor offset again) and a 9-bit tap-validity mask.  The K-loop then needs one 32-bit add and one select
+    // per DMA instruction (the first version recomputed ((b*Hin + y)*Win + x)*Cin per tap: ~110 VALU / 24 quarter-rate
+    // multiplies per K-step per wave, more issue time than the 16 MFMAs they feed).
+    constexpr unsigned OOB = 0xfffffff0u;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.x, 0, (int)(unsigned)((long long)a.B * a.Hin * a.Win * a.Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.w, 0, (int)(unsigned)((long long)a.Cout * 9 * a.Cin * 2), 0x00020000);
+    // epilogue tensors: an absent bias / rowbias / residual is a zero-sized descriptor (every load returns 0)
+    const unsigned y_bytes = (unsigned)(a.M * a.Cout * 2);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, a.res ? (int)y_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.Cout * 2 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbrs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.rowbias, 0, a.rowbias ? a.B * a.Cout * 2 : 0, 0x00020000);
+    constexpr int NST = MT * NT * 2;                   // 16-byte stores per wave and tile (exact: dropped ones are issued too)
+    unsigned a_off[A_INSTR];
     unsigned a_mask[A_INSTR];
+    unsigned b_off[B_INSTR];
+    const float rcp_hout = 1.0f / (float)a.Hout;       // B*Hout < 2^22 (launcher): one correction step makes the quotient exact
+    auto setup_issue_tile = [&](long long id) __attribute__((always_inline)) {
+        int Y0, X0, n0;
+        tile_coords(id, Y0, X0, n0);
 #pragma unroll
-    for (int i = 0; i < A_INSTR; ++i) {
-        int row = wave * (BMT / NW) + 8 * i + lrow;
-        int Y = Y0 + (row >> a.tw_log2);
-        int xo = X0 + (row & TWm);
-        bool ok = Y < rows_total && xo < a.Wout;
-        int Yc = ok ? Y : 0;
-        int b = Yc / a.Hout;
-        int yo = Yc - b * a.Hout;
-        int y0 = yo * a.stride - a.pad_y;
-        int x0 = (ok ? xo : 0) * a.stride - a.pad_x;
-        a_ptr[i] = a.x + (((long long)b * a.Hin + y0) * a.Win + x0) * a.Cin + (lslot ^ ((row >> 1) & 7)) * 8;
-        unsigned mk = 0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            int yy = y0 + t / 3, xx = x0 + t % 3;
-            if (ok && (unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)a.Win) mk |= 1u << t;
+        for (int i = 0; i < A_INSTR; ++i) {
+            const int row = wave * (BMT / NW) + 8 * i + lrow;
+            const int Y = Y0 + (row >> a.tw_log2);
+            const int xo = X0 + (row & TWm);
+            const bool ok = Y < rows_total && xo < a.Wout;
+            const int Yc = ok ? Y : 0;
+            int b = (int)((float)Yc * rcp_hout);
+            int yo = Yc - b * a.Hout;
+            if (yo < 0) { yo += a.Hout; --b; }
+            if (yo >= a.Hout) { yo -= a.Hout; ++b; }
+            const int y0 = yo * a.stride - a.pad_y;
+            const int x0 = (ok ? xo : 0) * a.stride - a.pad_x;
+            a_off[i] = (unsigned)(((((long long)b * a.Hin + y0) * a.Win + x0) * a.Cin + (lslot ^ ((row >> 1) & 7)) * 8) * 2);
+            // taps (dy, dx) inside the image: 3 column bits replicated into the valid rows
+            unsigned xb = ((unsigned)x0 < (unsigned)a.Win ? 1u : 0u) | ((unsigned)(x0 + 1) < (unsigned)a.Win ? 2u : 0u) |
+                          ((unsigned)(x0 + 2) < (unsigned)a.Win ? 4u : 0u);
+            if (!ok) xb = 0;
+            a_mask[i] = ((unsigned)y0 < (unsigned)a.Hin ? xb : 0u) | ((unsigned)(y0 + 1) < (unsigned)a.Hin ? xb << 3 : 0u) |
+                        ((unsigned)(y0 + 2) < (unsigned)a.Hin ? xb << 6 : 0u);
         }
-        a_mask[i] = mk;
-    }
-    // weight rows past Cout (ragged last tile, e.g. 320 = 2.5 x 128) re-read row Cout-1: finite values that
-    // only reach accumulator columns the epilogue never stores
-    const __bf16* b_ptr[B_INSTR];
+        // weight rows past Cout (ragged last tile, e.g. 320 = 2.5 x 128) re-read row Cout-1: finite values that
+        // only reach accumulator rows the epilogue never stores
 #pragma unroll
-    for (int i = 0; i < B_INSTR; ++i) {
-        int row = wave * (BN / NW) + 8 * i + lrow;
-        int rc = min(n0 + row, a.Cout - 1);
-        b_ptr[i] = a.w + (long long)rc * 9LL * a.Cin + (lslot ^ ((row >> 1) & 7)) * 8;
-    }
+        for (int i = 0; i < B_INSTR; ++i) {
+            const int row = wave * (BN / NW) + 8 * i + lrow;
+            const int rc = min(n0 + row, a.Cout - 1);
+            b_off[i] = (unsigned)(((long long)rc * 9LL * a.Cin + (lslot ^ ((row >> 1) & 7)) * 8) * 2);
+        }
+    };
     const int kt_per_tap = a.Cin / BK;
     const int n_steps = 9 * kt_per_tap;
 
@@ -279,33 +310,46 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     // (83 KB-830 KB per CU, x32 CUs per 4 MB L2): rocprofv3 FETCH_SIZE showed 2.1x (Cin=128) to 6.3x (Cin=320)
     // the compulsory bytes and a 66-76 % L2 hit rate (profiles/r01_pmc_conv_v0.json).
     int i_tap = 0, i_kc = 0;
-    long long toff = 0, woff = 0;                      // element offsets of the step being issued
+    long long issue_tile = first;                      // tile the cursor is in
+    int issue_on = 1;                                  // 0 once the last tile's last step has been requested
+    int n_ahead = 0;                                   // K-steps requested but not yet consumed
+    unsigned toff = 0, woff = 0;                       // byte offsets of the step being issued
     unsigned bit = 1u;
-    auto cursor_set = [&]() {
+    auto cursor_set = [&]() __attribute__((always_inline)) {
         const int dy = (i_tap * 11) >> 5, dx = i_tap - 3 * dy;                      // tap / 3, tap % 3 for tap < 9
-        toff = (long long)(dy * a.Win + dx) * a.Cin + i_kc * BK;                     // from a_ptr
-        woff = (long long)i_tap * a.Cin + i_kc * BK;                                 // weights are [Cout][tap][Cin]
+        toff = (unsigned)(((dy * a.Win + dx) * a.Cin + i_kc * BK) * 2);              // from a_off
+        woff = (unsigned)((i_tap * a.Cin + i_kc * BK) * 2);                          // weights are [Cout][tap][Cin]
         bit = 1u << i_tap;
     };
-    auto cursor_next = [&]() { if (++i_tap == 9) { i_tap = 0; ++i_kc; } };
+    // advance to the next K-step; at the end of a tile move on to this workgroup's next tile (or stop)
+    auto cursor_next = [&]() __attribute__((always_inline)) {
+        ++n_ahead;
+        if (++i_tap == 9) {
+            i_tap = 0;
+            if (++i_kc == kt_per_tap) {
+                i_kc = 0;
+                issue_tile += wpx;
+                if (issue_tile < xend) setup_issue_tile(issue_tile);
+                else issue_on = 0;
+            }
+        }
+    };
     // DMA piece p of the step at the cursor (p < A_INSTR: 8 activation rows, else 8 weight rows) into `stage`
-    auto piece = [&](int p, int stage) {
+    auto piece = [&](int p, int stage) __attribute__((always_inline)) {
         char* ab = smem + stage * STAGE;
         if (p < A_INSTR) {
             // select, never a branch: the DMA must execute with ALL lanes active (an inactive lane would
-            // leave its LDS slot stale); out-of-image taps read the 16-byte zero page
-            const void* src = (a_mask[p] & bit) ? (const void*)(a_ptr[p] + toff) : (const void*)zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(ab + (wave * (BMT / NW) + 8 * p) * ROWB),
-                                             16, 0, 0);
+            // leave its LDS slot stale); out-of-image taps read zeros through the descriptor's range check
+            const unsigned vo = (a_mask[p] & bit) ? a_off[p] + toff : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(ab + (wave * (BMT / NW) + 8 * p) * ROWB),
+                                                     16, (int)vo, 0, 0, 0);
         } else {
             const int q = p - A_INSTR;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[q] + woff),
-                                             (__attribute__((address_space(3))) void*)(ab + A_BYTES + (wave * (BN / NW) + 8 * q) * ROWB),
-                                             16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(ab + A_BYTES + (wave * (BN / NW) + 8 * q) * ROWB),
+                                                     16, (int)b_off[q], (int)woff, 0, 0);
         }
     };
-    auto issue = [&](int stage) {
+    auto issue = [&](int stage) __attribute__((always_inline)) {
         cursor_set();
 #pragma unroll
         for (int p = 0; p < L; ++p) piece(p, stage);
@@ -313,18 +357,13 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     };
 
     f32x16 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // ring protocol: at the top of step s every wave waits for ITS OWN step-s DMAs (counted vmcnt leaves the
     // NSTAGE-2 younger steps in flight), then the barrier makes all waves' step-s data visible and proves
     // everybody has finished reading stage (s-1) % NSTAGE, which is the stage the next issue overwrites.
+    setup_issue_tile(first);
     issue(0);
-    if (NSTAGE == 3 && n_steps > 1) issue(1);
+    if (NSTAGE == 3 && issue_on) issue(1);
     // One K-step: 4 chunks of 16 K.  Chunk kk (a) reads the fragments of chunk kk+1 into the other register set,
     // (b) issues its quarter of the NEXT stage's DMA pieces, (c) runs its MT*NT MFMAs on fragments that were read
     // one chunk earlier -- so LDS latency and the DMA issue time (60-180 cycles per 1 KB piece) sit under MFMA
@@ -353,116 +392,155 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
                 // channels, so the epilogue can store 16 contiguous bytes (8 channels of one pixel) per lane
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
     };
-    auto kstep = [&](int stage, int st_next, auto issue_tag) {
-        constexpr bool ISSUE = decltype(issue_tag)::value;
+    // ONE body for steps that issue and steps that only drain (`issue_on` is wave-uniform and only guards the DMA pieces):
+    // two instantiations in one loop made the register allocator give each its own accumulator set.
+    auto kstep = [&](int stage, int st_next) __attribute__((always_inline)) {
         // 3-deep ring: the pieces have a whole extra step to land, spread them over all 4 chunks.  2-deep ring:
         // they are needed at the next barrier, so the last chunk issues nothing (>= a quarter step of lead time)
         constexpr int NCH = (NSTAGE == 2) ? 3 : 4;
-        auto pieces = [&](int kk) {
-            if (ISSUE && kk < NCH) {
+        const bool on = __builtin_amdgcn_readfirstlane(issue_on) != 0;
+        auto pieces = [&](int kk) __attribute__((always_inline)) {
+            if (on && kk < NCH) {
 #pragma unroll
                 for (int p = kk; p < L; p += NCH) piece(p, st_next);
             }
         };
         bf16x8 a0[MT], b0[NT], a1[MT], b1[NT];         // two fragment sets, used alternately (named, not indexed:
-        if (ISSUE) cursor_set();                       // a parity-indexed array is not promoted to registers)
+        if (on) cursor_set();                          // a parity-indexed array is not promoted to registers)
         read_frags(stage, 0, a0, b0);
         read_frags(stage, 1, a1, b1); pieces(0); mma(a0, b0); __builtin_amdgcn_sched_barrier(0);
         read_frags(stage, 2, a0, b0); pieces(1); mma(a1, b1); __builtin_amdgcn_sched_barrier(0);
         read_frags(stage, 3, a1, b1); pieces(2); mma(a0, b0); __builtin_amdgcn_sched_barrier(0);
-        pieces(3); mma(a1, b1);
-        if (ISSUE) cursor_next();
+        pieces(3); mma(a1, b1); __builtin_amdgcn_sched_barrier(0);
+        if (on) cursor_next();
     };
-    // main loop (every step issues the DMAs of step s + NSTAGE - 1) and drain (nothing left to issue) are SEPARATE
-    // loops: with both bodies under one loop the register allocator gave each its own accumulator set
-    int stage = 0, s = 0;
-    const int n_main = n_steps - (NSTAGE - 1);
-    for (; s < n_main; ++s) {
-        if (NSTAGE == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int st2 = stage + NSTAGE - 1; if (st2 >= NSTAGE) st2 -= NSTAGE;
-        kstep(stage, st2, std::true_type{});
-        stage = stage + 1; if (stage >= NSTAGE) stage = 0;
-    }
-    for (; s < n_steps; ++s) {
-        if (NSTAGE == 3 && s + 1 < n_steps) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        kstep(stage, 0, std::false_type{});
-        stage = stage + 1; if (stage >= NSTAGE) stage = 0;
-    }
-
-    // ---- epilogue: y = acc + bias[n] (+ rowbias[image(m), n]) (+ res[m, n]), one rounding to bf16.
-    // D^T layout: lane = pixel l31 of the fragment, register r = channel (r&3) + 8*(r>>2) + 4*hi.  Group g = r>>2 is four
-    // consecutive channels (8 bytes as bf16); lanes l and l+32 hold the two halves of one 8-channel run.  One
-    // v_permlane32_swap per dword on the group pair (g, g+1) turns that into 16 contiguous bytes per lane: lanes 0-31 get
-    // channels 8g..8g+7, lanes 32-63 channels 8g+8..8g+15 of their pixel -> TWO 16-byte stores per 32x32 fragment.  The
-    // first version stored every element on its own (2 bytes per lane, 128 store instructions per wave and tile): at
-    // Cin = 128 the store issue took longer than the K loop (tools/conv_fit.sh: 0.40 ms of 0.96 ms did not scale with K).
-    const int img0 = Y0 / a.Hout;                      // image of the patch's first row (wave-uniform)
-    const int rem0 = Y0 - img0 * a.Hout;
+    int stage = 0;
+    for (long long ct = first; ct < xend; ct += wpx) {
+        int Y0, X0, n0;
+        tile_coords(ct, Y0, X0, n0);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int d = TM * wm + 32 * i + l31;          // this lane's pixel of the tile
-        const int ty = d >> a.tw_log2;
-        const int Y = Y0 + ty;
-        const int xo = X0 + (d & TWm);
-        const bool pix_ok = Y < rows_total && xo < a.Wout;
-        const long long m = (long long)Y * a.Wout + xo;           // = (b*Hout + yo)*Wout + xo
-        const __bf16* rb = nullptr;
-        if (a.rowbias) {
-            int img = img0, t = rem0 + ty;
-            while (t >= a.Hout) { t -= a.Hout; ++img; }         // a patch spans at most TH / Hout + 1 images
-            rb = a.rowbias + (long long)min(img, a.B - 1) * a.Cout;
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int s = 0; s < n_steps; ++s) {
+            // Wait for the DMAs of the step being consumed; vmcnt counts in issue order, so what may stay in flight is
+            // whatever was issued AFTER them: (NSTAGE == 3) the next step's L DMAs, and -- during the first NSTAGE-1 steps
+            // of every tile but the first -- the NST epilogue stores of the previous tile, which were issued between this
+            // step's DMAs and the ones that followed.  Counting them lets the stores drain under the new tile's first
+            // K-steps instead of being waited for at its first barrier.
+            const bool two = NSTAGE == 3 && n_ahead >= 2;
+            if (s < NSTAGE - 1 && ct != first) {
+                if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L + NST) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+            } else {
+                if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            --n_ahead;
+            int st2 = stage + NSTAGE - 1; if (st2 >= NSTAGE) st2 -= NSTAGE;
+            kstep(stage, st2);
+            stage = stage + 1; if (stage >= NSTAGE) stage = 0;
         }
+
+        // ---- epilogue: y = acc + bias[n] (+ rowbias[image(m), n]) (+ res[m, n]), one rounding to bf16.
+        // D^T layout: lane = pixel l31 of the fragment, register r = channel (r&3) + 8*(r>>2) + 4*hi.  Group g = r>>2 is
+        // four consecutive channels (8 bytes as bf16); lanes l and l+32 hold the two halves of one 8-channel run.  One
+        // v_permlane32_swap per dword on the group pair (g, g+1) turns that into 16 contiguous bytes per lane: lanes 0-31
+        // get channels 8g..8g+7, lanes 32-63 channels 8g+8..8g+15 of their pixel -> TWO 16-byte stores per 32x32
+        // fragment.  (The first version stored every element on its own: 128 store instructions per wave and tile.)
+        // Every access is a buffer instruction whose out-of-range cases (no bias / rowbias / residual tensor, ragged
+        // pixel or channel) are the offset OOB or a zero-sized descriptor -- loads return 0, stores are dropped -- so the
+        // epilogue is straight-line code: the compiler batches the loads of a fragment ahead of their use (the branchy
+        // version waited vmcnt(0) after each of its 8-byte loads: 12 exposed round trips per fragment, 15 us per tile,
+        // the 0.25 ms of the 512^2 layers that did not scale with K in tools/conv_fit.sh), and each wave issues EXACTLY
+        // NST stores per tile, which is what lets the next tile's first K-steps count them in s_waitcnt (see above).
+        const int img0 = Y0 / a.Hout;                  // image of the patch's first row (wave-uniform)
+        const int rem0 = Y0 - img0 * a.Hout;
+        unsigned poff[MT], rboff[MT];                  // byte offset of this lane's pixel in y / res, of its image's rowbias row
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int d = TM * wm + 32 * i + l31;      // this lane's pixel of the tile
+            const int ty = d >> a.tw_log2;
+            const int Y = Y0 + ty;
+            const int xo = X0 + (d & TWm);
+            const bool pix_ok = Y < rows_total && xo < a.Wout;
+            poff[i] = pix_ok ? (unsigned)(((long long)Y * a.Wout + xo) * a.Cout * 2) : OOB;   // m = (b*Hout + yo)*Wout + xo
+            int img = img0, t = rem0 + ty;
+            while (t >= a.Hout) { t -= a.Hout; ++img; }                                       // a patch spans at most TH / Hout + 1 images
+            rboff[i] = (unsigned)(min(img, a.B - 1) * a.Cout * 2);
+        }
+        auto unpack_add = [](float (&v)[4], const u32x2 p) __attribute__((always_inline)) {
+            v[0] += __builtin_bit_cast(float, p[0] << 16); v[1] += __builtin_bit_cast(float, p[0] & 0xffff0000u);
+            v[2] += __builtin_bit_cast(float, p[1] << 16); v[3] += __builtin_bit_cast(float, p[1] & 0xffff0000u);
+        };
+        const bool has_res = a.res != nullptr, has_rb = a.rowbias != nullptr;
+        // Loads are issued ahead of the stores (the compiler keeps program order between a buffer load and a buffer store
+        // it cannot prove disjoint): the rowbias row and the residual of fragment f + 1 are requested before the stores of
+        // fragment f, so only the first fragment of a tile waits for a full round trip.
+        auto frag_load = [&](int i, int j, u32x2 (&r)[8]) __attribute__((always_inline)) {
+            const int nbase = n0 + TN * wn + 32 * j;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nbase + 8 * g + 4 * hi;
+                const bool n_ok = n < a.Cout;
+                if (has_rb) r[g] = __builtin_amdgcn_raw_buffer_load_b64(rbrs, (int)(n_ok ? rboff[i] + (unsigned)n * 2u : OOB), 0, 0);
+                if (has_res)
+                    r[4 + g] = __builtin_amdgcn_raw_buffer_load_b64(rrs, (int)(n_ok && poff[i] != OOB ? poff[i] + (unsigned)n * 2u : OOB), 0, 0);
+            }
+        };
+        u32x2 pre[2][8];                               // [parity of f = j*MT + i][rowbias g 0..3 | residual g 0..3]
+#pragma unroll
+        for (int g = 0; g < 8; ++g) pre[0][g] = pre[1][g] = u32x2{0u, 0u};
+        frag_load(0, 0, pre[0]);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int nbase = n0 + TN * wn + 32 * j;   // first channel of this fragment (wave-uniform)
+            // bias of this lane's 16 channels of the fragment (register 4g+e = channel nbase + 8g + 4hi + e), once per j
+            u32x2 bp[4];
 #pragma unroll
-            for (int gp = 0; gp < 2; ++gp) {           // group pairs (0,1) and (2,3)
-                // fp32 adds in the accumulator layout (register 4g+e = channel nbase + 8g + 4hi + e), one rounding to bf16
-                unsigned w[2][2];                      // [group of the pair][dword] = 4 bf16 per group
+            for (int g = 0; g < 4; ++g) {
+                const int n = nbase + 8 * g + 4 * hi;
+                bp[g] = __builtin_amdgcn_raw_buffer_load_b64(brs, (int)(n < a.Cout ? (unsigned)n * 2u : OOB), 0, 0);
+            }
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int g = 2 * gp + q;
-                    const int n = nbase + 8 * g + 4 * hi;
-                    float v[4];
+            for (int i = 0; i < MT; ++i) {
+                constexpr int kLast = MT * NT - 1;
+                const int f = j * MT + i;
+                if (f < kLast) frag_load((f + 1) % MT, (f + 1) / MT, pre[(f + 1) & 1]);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-                    if (n < a.Cout) {
-                        if (a.bias) {
-                            const uint2 bb = *reinterpret_cast<const uint2*>(a.bias + n);
-                            v[0] += __builtin_bit_cast(float, bb.x << 16); v[1] += __builtin_bit_cast(float, bb.x & 0xffff0000u);
-                            v[2] += __builtin_bit_cast(float, bb.y << 16); v[3] += __builtin_bit_cast(float, bb.y & 0xffff0000u);
-                        }
-                        if (rb) {
-                            const uint2 bb = *reinterpret_cast<const uint2*>(rb + n);
-                            v[0] += __builtin_bit_cast(float, bb.x << 16); v[1] += __builtin_bit_cast(float, bb.x & 0xffff0000u);
-                            v[2] += __builtin_bit_cast(float, bb.y << 16); v[3] += __builtin_bit_cast(float, bb.y & 0xffff0000u);
-                        }
-                        if (a.res && pix_ok) {
-                            const uint2 rr = *reinterpret_cast<const uint2*>(a.res + m * a.Cout + n);
-                            v[0] += __builtin_bit_cast(float, rr.x << 16); v[1] += __builtin_bit_cast(float, rr.x & 0xffff0000u);
-                            v[2] += __builtin_bit_cast(float, rr.y << 16); v[3] += __builtin_bit_cast(float, rr.y & 0xffff0000u);
-                        }
+                for (int gp = 0; gp < 2; ++gp) {       // group pairs (0,1) and (2,3)
+                    unsigned w[2][2];                  // [group of the pair][dword] = 4 bf16 per group
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int g = 2 * gp + q;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                        unpack_add(v, bp[g]);
+                        unpack_add(v, pre[f & 1][g]);
+                        unpack_add(v, pre[f & 1][4 + g]);
+                        f32x2 lo = {v[0], v[1]}, hi2 = {v[2], v[3]};
+                        bf16x2 plo = __builtin_convertvector(lo, bf16x2), phi = __builtin_convertvector(hi2, bf16x2);
+                        w[q][0] = __builtin_bit_cast(unsigned, plo);
+                        w[q][1] = __builtin_bit_cast(unsigned, phi);
                     }
-                    f32x2 lo = {v[0], v[1]}, hi2 = {v[2], v[3]};
-                    bf16x2 plo = __builtin_convertvector(lo, bf16x2), phi = __builtin_convertvector(hi2, bf16x2);
-                    w[q][0] = __builtin_bit_cast(unsigned, plo);
-                    w[q][1] = __builtin_bit_cast(unsigned, phi);
+                    // v_permlane32_swap(vdst = group g, src = group g+1): lanes 32-63 of vdst <-> lanes 0-31 of src.  Afterwards
+                    //   result[0]: lanes 0-31 own group g (ch 8g..8g+3)        | lanes 32-63 the lower lanes' group g+1 (ch 8g+8..+11)
+                    //   result[1]: lanes 0-31 the upper lanes' group g (+4..+7) | lanes 32-63 own group g+1 (ch 8g+12..+15)
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+                    const int c0 = nbase + 16 * gp + 8 * hi;   // this lane now owns channels c0 .. c0+7 of its pixel
+                    const u32x4 out = {s0[0], s1[0], s0[1], s1[1]};
+                    __builtin_amdgcn_raw_buffer_store_b128(out, yrs, (int)(poff[i] != OOB && c0 < a.Cout ? poff[i] + (unsigned)c0 * 2u : OOB),
+                                                           0, 0);
                 }
-                // v_permlane32_swap(vdst = group g, src = group g+1): lanes 32-63 of vdst <-> lanes 0-31 of src.  Afterwards
-                //   result[0]: lanes 0-31 own group g (ch 8g..8g+3)        | lanes 32-63 the lower lanes' group g+1 (ch 8g+8..+11)
-                //   result[1]: lanes 0-31 the upper lanes' group g (+4..+7) | lanes 32-63 own group g+1 (ch 8g+12..+15)
-                const auto s0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
-                const int c0 = nbase + 16 * gp + 8 * hi;   // this lane now owns channels c0 .. c0+7 of its pixel
-                if (pix_ok && c0 < a.Cout)
-                    *reinterpret_cast<uint4*>(a.y + m * a.Cout + c0) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
             }
         }
-    }
+    }   // tile loop
+#endif
 }
 
 template <int BMT, int BN, int NW, int WMW, int NSTAGE>
@@ -483,10 +561,24 @@ int launch_conv_dma(const ConvArgs& a_in, hipStream_t stream) {
     a.tw_log2 = tw_log2;
     a.tiles_x = (a.Wout + (1 << tw_log2) - 1) >> tw_log2;
     const int TH = BMT >> tw_log2;
-    if ((long long)a.B * a.Hout + 512 > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
+    if ((long long)a.B * a.Hout + 512 >= (1 << 22)) return DM_ERR_UNSUPPORTED;      // float-reciprocal row -> image split
+    if ((long long)a.B * a.Hin * a.Win * a.Cin * 2 > 0xffffff00LL || (long long)a.Cout * 9 * a.Cin * 2 > 0xffffff00LL)
+        return DM_ERR_UNSUPPORTED;                                                    // 32-bit buffer offsets
+    if (a.M * a.Cout * 2 > 0xffffff00LL) return DM_ERR_UNSUPPORTED;
     long long n_mt = (((long long)a.B * a.Hout + TH - 1) / TH) * a.tiles_x;
     int n_nt = (a.Cout + BN - 1) / BN;
-    long long blocks = ((n_mt * n_nt + 7) / 8) * 8;
+    // persistent grid: as many workgroups as the chip holds at once (LDS- and thread-limited), never more than tiles
+    static int n_cu = 0;
+    if (!n_cu) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return DM_ERR_UNSUPPORTED;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int wg_per_cu = std::max(1, std::min((160 * 1024) / LDS, 2048 / (NW * 64)));
+    const long long total = n_mt * n_nt, per_xcd = (total + 7) / 8;
+    long long wpx = std::min<long long>(per_xcd, (long long)n_cu * wg_per_cu / 8);
+    long long blocks = 8 * std::max<long long>(wpx, 1);
     if (blocks > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
     DM_ENTER();
     hipLaunchKernelGGL((k_conv3x3_dma<BMT, BN, NW, WMW, NSTAGE>), dim3((unsigned)blocks), dim3(NW * 64), LDS, stream, a,

@@ -23,6 +23,23 @@ run_stats() { # name args...
 SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU"
 SQ2="SQ_WAVES SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM"
 rocprofv3 -L > $OUT/counters_available.txt 2>&1
+SECTIONS=${PMC_SECTIONS:-attn shade}
+if [[ " $SECTIONS " == *" conv "* ]]; then
+  # the dominant conv shapes: 8 x 128->128 @512^2 (VAE, tile 640) and 24 x 320->320 @64^2 (UNet, tile 320)
+  for case in "vae128 640 8 512 512 128 128" "unet320 320 24 64 64 320 320" "unet640 256 24 32 32 640 640"; do
+    set -- $case; nm=$1; export DREAMMAT_CONV_TILE=$2; shift 2
+    run_stats conv_$nm conv "$@" 10
+    run_pmc sq_conv_$nm "$SQ" conv "$@" 5
+    run_pmc sq2_conv_$nm "$SQ2" conv "$@" 5
+    run_pmc grbm_conv_$nm "GRBM_GUI_ACTIVE GRBM_COUNT" conv "$@" 5
+    run_pmc fetch_conv_$nm "FETCH_SIZE" conv "$@" 5
+    run_pmc write_conv_$nm "WRITE_SIZE" conv "$@" 5
+    run_pmc tcc_conv_$nm "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" conv "$@" 5
+    run_pmc tcp_conv_$nm "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" conv "$@" 5
+    unset DREAMMAT_CONV_TILE
+  done
+fi
+if [[ " $SECTIONS " == *" attn "* ]]; then
 for v in ${ATTN_VARIANTS:-v3p v3l v3}; do
   run_stats attn_$v attn 24 5 4096 4096 64 5 $v
   run_pmc sq_attn_$v "$SQ" attn 24 5 4096 4096 64 5 $v
@@ -32,7 +49,8 @@ done
 v=${ATTN_MAIN:-v3}
 run_pmc fetch_attn_$v "FETCH_SIZE" attn 24 5 4096 4096 64 5 $v
 run_pmc write_attn_$v "WRITE_SIZE" attn 24 5 4096 4096 64 5 $v
-for c in ${SHADE_CASES:-fp32 rgb18e8}; do
+fi
+[[ " $SECTIONS " == *" shade "* ]] && for c in ${SHADE_CASES:-fp32 rgb18e8}; do
   f=${DM_SHADE_CASE_DIR:-/tmp}/shade_case_$c.bin
   [ -f $f ] || continue
   run_stats shade_$c shadef $f 10
