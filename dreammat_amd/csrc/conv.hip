@@ -15,6 +15,7 @@
 // (the VAE encoder is differentiated through): dx = conv(dy, w') with w' = taps flipped, Cin<->Cout
 // swapped (prepared once on the host side).  Requirements: Cin % 32 == 0, Cout % 64 == 0.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -43,6 +44,8 @@ struct ConvArgs {
     // LDS-DMA kernels: an M tile is a 2-D patch of TW x (BMT/TW) output pixels of the "tall image" [B*Hout, Wout]
     int tw_log2;         // log2(TW)
     int tiles_x;         // ceil(Wout / TW)
+    unsigned long long* timeline;   // DREAMMAT_CONV_TIMELINE=1 (development): s_memtime stamps per tile, else null
+    int timeline_steps;             // DREAMMAT_CONV_TIMELINE=2: stamp every K-step instead
 };
 
 constexpr int BM = 128;
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(256) void k_conv3x3(ConvArgs a, long long n_mt, int
 //  * out-of-image taps are buffer offsets beyond num_records (the descriptor's range check returns zeros).
 //  * counted s_waitcnt vmcnt(L) + raw s_barrier: one barrier per K-step, loads span the barrier.
 template <int BMT, int BN, int NW, int WMW, int NSTAGE>
-__global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n_mt, int n_nt) {
+__global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n_mt, int n_nt, int stagger_units) {
     // BMT x BN x 64 workgroup tile, NW waves laid out WMW (along M) x NW/WMW (along N), NSTAGE-deep LDS ring.
     //   <128, 64|128, 4, 2, 3>  wave tile 64 x 32|64, 2-5 workgroups per CU (small problems)
     //   <256, 128, 8, 4, 3>     wave tile 64 x 64, one workgroup per CU
@@ -217,12 +220,12 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     // already landing.  One workgroup per tile paid a cold prologue (address set-up, first DMA round trip), a store tail
     // and a relaunch per tile -- 0.25 ms of the 0.80 ms of the 8 x 128->128 @512^2 layer did not scale with K
     // (tools/conv_fit.sh), with one workgroup per CU nothing else could cover it.
-    const long long total = n_mt * n_nt;
-    const long long per_xcd = (total + 7) / 8;
+    const int total = (int)(n_mt * n_nt);              // < 2^31 (launcher)
+    const int per_xcd = (total + 7) / 8;
     const int wpx = (int)(gridDim.x >> 3);             // workgroups per XCD
-    const long long xbeg = (long long)(blockIdx.x & 7) * per_xcd;
-    const long long xend = xbeg + per_xcd < total ? xbeg + per_xcd : total;
-    const long long first = xbeg + (blockIdx.x >> 3);
+    const int xbeg = (int)(blockIdx.x & 7) * per_xcd;
+    const int xend = min(xbeg + per_xcd, total);
+    const int first = xbeg + (int)(blockIdx.x >> 3);
     if (first >= xend) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int wm = wave / WNW, wn = wave % WNW;
@@ -231,13 +234,18 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     // tile; the patch re-reads a one-pixel halo: (TH+2)(TW+2)/(TH*TW) = 1.2-1.3x.
     const int TWm = (1 << a.tw_log2) - 1;
     const int rows_total = a.B * a.Hout;
-    auto tile_coords = [&](long long id, int& Y0, int& X0, int& n0) __attribute__((always_inline)) {
-        const long long mt = id / n_nt;
-        const int nt = (int)(id - mt * n_nt);
-        const int tile_y = (int)(mt / a.tiles_x);      // B*Hout < 2^31 (checked by the launcher): 32-bit row math
-        Y0 = tile_y * (BMT >> a.tw_log2);
-        X0 = (int)(mt - (long long)tile_y * a.tiles_x) << a.tw_log2;
-        n0 = nt * BN;
+    // 32-bit tile arithmetic (the launcher admits < 2^31 tiles): this runs inside the K loop when the issue cursor
+    // crosses into the next tile, where every cycle is a cycle without MFMAs -- the first persistent version spent 13 k
+    // cycles per tile here on two 64-bit divisions, 64-bit address products and the spills around them
+    // (DREAMMAT_CONV_TIMELINE=2).
+    auto tile_coords = [&](int id, int& Y0, int& X0, int& n0) __attribute__((always_inline)) {
+        const unsigned uid = (unsigned)id;
+        const unsigned mt = uid / (unsigned)n_nt;
+        const unsigned nt = uid - mt * (unsigned)n_nt;
+        const unsigned tile_y = mt / (unsigned)a.tiles_x;
+        Y0 = (int)(tile_y * (unsigned)(BMT >> a.tw_log2));
+        X0 = (int)((mt - tile_y * (unsigned)a.tiles_x) << a.tw_log2);
+        n0 = (int)nt * BN;
     };
     const int lrow = lane >> 3, lslot = lane & 7;      // this lane's row / 16 B slot inside one DMA instruction
 
@@ -268,9 +276,15 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     unsigned a_mask[A_INSTR];
     unsigned b_off[B_INSTR];
     const float rcp_hout = 1.0f / (float)a.Hout;       // B*Hout < 2^22 (launcher): one correction step makes the quotient exact
-    auto setup_issue_tile = [&](long long id) __attribute__((always_inline)) {
+    auto setup_issue_tile = [&](int id) __attribute__((always_inline)) {
         int Y0, X0, n0;
         tile_coords(id, Y0, X0, n0);
+        // re-derive the lane constants from an opaque copy of the thread id: computed once before the tile loop they stay
+        // live across the K loop, where there is no register for them -- the compiler spilled them and every reload in
+        // here waited (in order) behind the DMAs just issued: 23 serialized scratch round trips, 11 k cycles per tile
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));
+        const int wave = t_ >> 6, lrow = (t_ & 63) >> 3, lslot = t_ & 7;
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
             const int row = wave * (BMT / NW) + 8 * i + lrow;
@@ -284,7 +298,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
             if (yo >= a.Hout) { yo -= a.Hout; ++b; }
             const int y0 = yo * a.stride - a.pad_y;
             const int x0 = (ok ? xo : 0) * a.stride - a.pad_x;
-            a_off[i] = (unsigned)(((((long long)b * a.Hin + y0) * a.Win + x0) * a.Cin + (lslot ^ ((row >> 1) & 7)) * 8) * 2);
+            // mod 2^32 on purpose (see above): every product wraps consistently
+            a_off[i] = ((((unsigned)b * (unsigned)a.Hin + (unsigned)y0) * (unsigned)a.Win + (unsigned)x0) * (unsigned)a.Cin +
+                        (unsigned)((lslot ^ ((row >> 1) & 7)) * 8)) * 2u;
             // taps (dy, dx) inside the image: 3 column bits replicated into the valid rows
             unsigned xb = ((unsigned)x0 < (unsigned)a.Win ? 1u : 0u) | ((unsigned)(x0 + 1) < (unsigned)a.Win ? 2u : 0u) |
                           ((unsigned)(x0 + 2) < (unsigned)a.Win ? 4u : 0u);
@@ -298,7 +314,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
         for (int i = 0; i < B_INSTR; ++i) {
             const int row = wave * (BN / NW) + 8 * i + lrow;
             const int rc = min(n0 + row, a.Cout - 1);
-            b_off[i] = (unsigned)(((long long)rc * 9LL * a.Cin + (lslot ^ ((row >> 1) & 7)) * 8) * 2);
+            b_off[i] = ((unsigned)rc * 9u * (unsigned)a.Cin + (unsigned)((lslot ^ ((row >> 1) & 7)) * 8)) * 2u;
         }
     };
     const int kt_per_tap = a.Cin / BK;
@@ -310,7 +326,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     // (83 KB-830 KB per CU, x32 CUs per 4 MB L2): rocprofv3 FETCH_SIZE showed 2.1x (Cin=128) to 6.3x (Cin=320)
     // the compulsory bytes and a 66-76 % L2 hit rate (profiles/r01_pmc_conv_v0.json).
     int i_tap = 0, i_kc = 0;
-    long long issue_tile = first;                      // tile the cursor is in
+    int issue_tile = first;                            // tile the cursor is in
     int issue_on = 1;                                  // 0 once the last tile's last step has been requested
     int n_ahead = 0;                                   // K-steps requested but not yet consumed
     unsigned toff = 0, woff = 0;                       // byte offsets of the step being issued
@@ -361,6 +377,14 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     // ring protocol: at the top of step s every wave waits for ITS OWN step-s DMAs (counted vmcnt leaves the
     // NSTAGE-2 younger steps in flight), then the barrier makes all waves' step-s data visible and proves
     // everybody has finished reading stage (s-1) % NSTAGE, which is the stage the next issue overwrites.
+    // STAGGER: every tile costs the same, so without this all workgroups reach their epilogues together and the chip
+    // writes one 32-45 MB burst per tile round at the HBM write rate (13.6 us per round at 8 x 128->128 @512^2, during
+    // which the in-order vmcnt holds the next tile's DMA waits behind the stores).  Workgroup k of an XCD starts
+    // (k % 8) / 8 of a tile late, so the stores of the 8 phases interleave with the other phases' K-loops.
+    if (stagger_units > 0) {
+        const int ph = (int)((blockIdx.x >> 3) & 7);
+        for (int t = 0; t < ph * stagger_units; ++t) __builtin_amdgcn_s_sleep(127);
+    }
     setup_issue_tile(first);
     issue(0);
     if (NSTAGE == 3 && issue_on) issue(1);
@@ -394,7 +418,15 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     };
     // ONE body for steps that issue and steps that only drain (`issue_on` is wave-uniform and only guards the DMA pieces):
     // two instantiations in one loop made the register allocator give each its own accumulator set.
-    auto kstep = [&](int stage, int st_next) __attribute__((always_inline)) {
+    // The MFMAs of a step's LAST chunk are issued after the NEXT step's barrier, behind that step's first fragment reads:
+    // with two waves per SIMD the matrix pipe otherwise drains at every barrier for (vmcnt wait + barrier skew + LDS read
+    // latency) -- MFMA busy was 46 % of the kernel's cycles with zero bank conflicts and 3 % LDS waits
+    // (profiles/r02_pmc_conv_*.json).  The fragments are in registers by then (lgkmcnt(0) before the barrier), so the
+    // stage they came from may be overwritten.
+    constexpr bool PEND = MT * NT < 10;                // (the 64 x 160 wave tile has no registers left to carry a set across)
+    bf16x8 a0[MT], b0[NT], a1[MT], b1[NT];             // two fragment sets, used alternately (named, not indexed:
+                                                       // a parity-indexed array is not promoted to registers)
+    auto kstep = [&](int stage, int st_next, bool pending) __attribute__((always_inline)) {
         // 3-deep ring: the pieces have a whole extra step to land, spread them over all 4 chunks.  2-deep ring:
         // they are needed at the next barrier, so the last chunk issues nothing (>= a quarter step of lead time)
         constexpr int NCH = (NSTAGE == 2) ? 3 : 4;
@@ -405,19 +437,26 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
                 for (int p = kk; p < L; p += NCH) piece(p, st_next);
             }
         };
-        bf16x8 a0[MT], b0[NT], a1[MT], b1[NT];         // two fragment sets, used alternately (named, not indexed:
-        if (on) cursor_set();                          // a parity-indexed array is not promoted to registers)
+        if (on) cursor_set();
         read_frags(stage, 0, a0, b0);
+        if (PEND && pending) mma(a1, b1);              // chunk 3 of the previous step of this tile
+        __builtin_amdgcn_sched_barrier(0);
         read_frags(stage, 1, a1, b1); pieces(0); mma(a0, b0); __builtin_amdgcn_sched_barrier(0);
         read_frags(stage, 2, a0, b0); pieces(1); mma(a1, b1); __builtin_amdgcn_sched_barrier(0);
         read_frags(stage, 3, a1, b1); pieces(2); mma(a0, b0); __builtin_amdgcn_sched_barrier(0);
-        pieces(3); mma(a1, b1); __builtin_amdgcn_sched_barrier(0);
+        pieces(3);
+        if (!PEND) mma(a1, b1);
         if (on) cursor_next();
     };
     int stage = 0;
-    for (long long ct = first; ct < xend; ct += wpx) {
+    int tl_i = 0;
+    auto stamp = [&]() __attribute__((always_inline)) {
+        if (a.timeline && tid == 0 && tl_i < 64) a.timeline[(long long)blockIdx.x * 64 + tl_i++] = __builtin_amdgcn_s_memtime();
+    };
+    for (int ct = first; ct < xend; ct += wpx) {
         int Y0, X0, n0;
         tile_coords(ct, Y0, X0, n0);
+        stamp();
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -432,18 +471,21 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
             // K-steps instead of being waited for at its first barrier.
             const bool two = NSTAGE == 3 && n_ahead >= 2;
             if (s < NSTAGE - 1 && ct != first) {
-                if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L + NST) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+                if (two) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(L + NST) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NST) : "memory");
             } else {
-                if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (two) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(L) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             }
             __builtin_amdgcn_s_barrier();
+            if (a.timeline_steps) stamp();
             --n_ahead;
             int st2 = stage + NSTAGE - 1; if (st2 >= NSTAGE) st2 -= NSTAGE;
-            kstep(stage, st2);
+            kstep(stage, st2, s > 0);
             stage = stage + 1; if (stage >= NSTAGE) stage = 0;
         }
+        if (PEND) mma(a1, b1);                         // the last step's last chunk
+        stamp();
 
         // ---- epilogue: y = acc + bias[n] (+ rowbias[image(m), n]) (+ res[m, n]), one rounding to bf16.
         // D^T layout: lane = pixel l31 of the fragment, register r = channel (r&3) + 8*(r>>2) + 4*hi.  Group g = r>>2 is
@@ -460,6 +502,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
         const int img0 = Y0 / a.Hout;                  // image of the patch's first row (wave-uniform)
         const int rem0 = Y0 - img0 * a.Hout;
         unsigned poff[MT], rboff[MT];                  // byte offset of this lane's pixel in y / res, of its image's rowbias row
+        int te_ = tid;                                 // (opaque copy: see setup_issue_tile)
+        asm volatile("" : "+v"(te_));
+        const int l31 = te_ & 31, hi = (te_ >> 5) & 1, wm = (te_ >> 6) / WNW, wn = (te_ >> 6) % WNW;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int d = TM * wm + 32 * i + l31;      // this lane's pixel of the tile
@@ -539,6 +584,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
                 }
             }
         }
+        stamp();
     }   // tile loop
 #endif
 }
@@ -579,11 +625,48 @@ int launch_conv_dma(const ConvArgs& a_in, hipStream_t stream) {
     const long long total = n_mt * n_nt, per_xcd = (total + 7) / 8;
     long long wpx = std::min<long long>(per_xcd, (long long)n_cu * wg_per_cu / 8);
     long long blocks = 8 * std::max<long long>(wpx, 1);
-    if (blocks > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
+    if (blocks > 0x7fffffffLL || total > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
+    // stagger unit = 1/8 of a tile's K loop in s_sleep(127) periods (8128 cycles): per K-step each SIMD runs
+    // (NW/4) waves x (BMT/WMW/32)(BN/(NW/WMW)/32) x 4 MFMAs of 32 cycles, at ~2/3 of the matrix pipe
+    int stagger = 0;
+    // OFF by default: measured on 8 x 128->128 @512^2 it removes the post-epilogue drain (tile 85 k -> 75 k cycles) but the
+    // late starters finish 7/8 of a tile later, a wash at 16 tiles per workgroup (0.79 vs 0.81 ms); it needs a dynamic
+    // tile queue to pay.  DREAMMAT_CONV_STAGGER=1 enables it for experiments.
+    static const bool use_stagger = getenv("DREAMMAT_CONV_STAGGER") && !strcmp(getenv("DREAMMAT_CONV_STAGGER"), "1");
+    if (use_stagger && per_xcd >= 3 * wpx) {
+        const long long step_cycles = (long long)(NW / 4) * (BMT / WMW / 32) * (BN / (NW / WMW) / 32) * 4 * 32 * 3 / 2;
+        stagger = (int)std::max<long long>(1, 9LL * (a.Cin / 64) * step_cycles / 8 / 8128);
+    }
     DM_ENTER();
+    static const bool timeline = getenv("DREAMMAT_CONV_TIMELINE") != nullptr;      // development aid, see tools/conv_fit.sh
+    static unsigned long long* tl_buf = nullptr;
+    a.timeline = nullptr;
+    if (timeline) {
+        if (!tl_buf && hipMalloc(&tl_buf, 4096 * 64 * 8) != hipSuccess) return DM_ERR_UNSUPPORTED;
+        if (blocks <= 4096) { (void)hipMemsetAsync(tl_buf, 0, 4096 * 64 * 8, stream); a.timeline = tl_buf; }
+        a.timeline_steps = atoi(getenv("DREAMMAT_CONV_TIMELINE")) == 2;
+    }
     hipLaunchKernelGGL((k_conv3x3_dma<BMT, BN, NW, WMW, NSTAGE>), dim3((unsigned)blocks), dim3(NW * 64), LDS, stream, a,
-                       n_mt, n_nt);
+                       n_mt, n_nt, stagger);
     hipError_t e = hipGetLastError();
+    if (a.timeline && e == hipSuccess) {
+        // per-tile phases of workgroups 0 and 8 (s_memtime ticks): K loop | epilogue | gap to the next tile's first stamp
+        static unsigned long long host[4096 * 64];
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(host, tl_buf, sizeof(host), hipMemcpyDeviceToHost);
+        for (int b : {0, 8}) {
+            fprintf(stderr, "[conv timeline] wg %d:", b);
+            const unsigned long long* t = host + (size_t)b * 64;
+            int n = 0;
+            while (n < 64 && t[n]) ++n;
+            if (a.timeline_steps) {
+                for (int i = 1; i < n; ++i) fprintf(stderr, " %llu", t[i] - t[i - 1]);
+            } else {
+                for (int i = 0; i + 2 < n; i += 3) fprintf(stderr, " K=%llu E=%llu", t[i + 1] - t[i], t[i + 2] - t[i + 1]);
+            }
+            fprintf(stderr, "  total=%llu\n", n ? t[n - 1] - t[0] : 0ULL);
+        }
+    }
     return e == hipSuccess ? DM_OK : (int)e;
 }
 
@@ -626,7 +709,7 @@ int dm_conv3x3_nhwc_bf16_fused(const void* x, const void* w, const void* bias, c
     if (((uintptr_t)bias | (uintptr_t)rowbias | (uintptr_t)residual) & 7) return DM_ERR_ARG;
     ConvArgs a;
     a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const __bf16*)bias; a.y = (__bf16*)y;
-    a.rowbias = (const __bf16*)rowbias; a.res = (const __bf16*)residual;
+    a.rowbias = (const __bf16*)rowbias; a.res = (const __bf16*)residual; a.timeline = nullptr; a.timeline_steps = 0;
     a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
     a.stride = stride; a.pad_y = pad_y; a.pad_x = pad_x;
     a.M = (long long)B * Hout * Wout;
