@@ -192,7 +192,12 @@ __global__ __launch_bounds__(256) void k_conv3x3(ConvArgs a, long long n_mt, int
 //    address on the way in and to the ds_read address on the way out (same involution both sides).
 //  * out-of-image taps are buffer offsets beyond num_records (the descriptor's range check returns zeros).
 //  * counted s_waitcnt vmcnt(L) + raw s_barrier: one barrier per K-step, loads span the barrier.
-template <int BMT, int BN, int NW, int WMW, int NSTAGE>
+// TAPS = 9: 3x3 convolution.  TAPS = 1: the same machine as a plain GEMM y[M, N] = x[M, K] w[N, K]^T (the launcher presents
+// x as a [1, M/16, 16, K] image, no padding) -- the Linear / 1x1 layers of the UNet, with the same fused epilogues.
+// EPI = 1 (TAPS = 1 only): GEGLU epilogue.  The weight rows arrive interleaved in blocks of 32 (32 value rows, then their
+// 32 gate rows), so fragment pair (2jj, 2jj+1) of a wave holds value and gate of the same 32 output channels and the
+// epilogue writes value * gelu(gate) into y[M, N/2]: the 2x wide intermediate never reaches HBM.
+template <int BMT, int BN, int NW, int WMW, int NSTAGE, int TAPS = 9, int EPI = 0>
 __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n_mt, int n_nt, int stagger_units) {
     // BMT x BN x 64 workgroup tile, NW waves laid out WMW (along M) x NW/WMW (along N), NSTAGE-deep LDS ring.
     //   <128, 64|128, 4, 2, 3>  wave tile 64 x 32|64, 2-5 workgroups per CU (small problems)
@@ -263,15 +268,16 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.x, 0, (int)(unsigned)((long long)a.B * a.Hin * a.Win * a.Cin * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.w, 0, (int)(unsigned)((long long)a.Cout * 9 * a.Cin * 2), 0x00020000);
+        (void*)a.w, 0, (int)(unsigned)((long long)a.Cout * TAPS * a.Cin * 2), 0x00020000);
     // epilogue tensors: an absent bias / rowbias / residual is a zero-sized descriptor (every load returns 0)
-    const unsigned y_bytes = (unsigned)(a.M * a.Cout * 2);
+    const int OC = EPI == 1 ? a.Cout / 2 : a.Cout;      // output channels = row length of y / res
+    const unsigned y_bytes = (unsigned)(a.M * OC * 2);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, a.res ? (int)y_bytes : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.Cout * 2 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rbrs =
         __builtin_amdgcn_make_buffer_rsrc((void*)a.rowbias, 0, a.rowbias ? a.B * a.Cout * 2 : 0, 0x00020000);
-    constexpr int NST = MT * NT * 2;                   // 16-byte stores per wave and tile (exact: dropped ones are issued too)
+    constexpr int NST = MT * NT * 2 / (EPI == 1 ? 2 : 1);   // 16-byte stores per wave and tile (exact: dropped ones are issued too)
     unsigned a_off[A_INSTR];
     unsigned a_mask[A_INSTR];
     unsigned b_off[B_INSTR];
@@ -314,11 +320,11 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
         for (int i = 0; i < B_INSTR; ++i) {
             const int row = wave * (BN / NW) + 8 * i + lrow;
             const int rc = min(n0 + row, a.Cout - 1);
-            b_off[i] = ((unsigned)rc * 9u * (unsigned)a.Cin + (unsigned)((lslot ^ ((row >> 1) & 7)) * 8)) * 2u;
+            b_off[i] = ((unsigned)rc * (unsigned)TAPS * (unsigned)a.Cin + (unsigned)((lslot ^ ((row >> 1) & 7)) * 8)) * 2u;
         }
     };
     const int kt_per_tap = a.Cin / BK;
-    const int n_steps = 9 * kt_per_tap;
+    const int n_steps = TAPS * kt_per_tap;
 
     // issue cursor (wave-uniform => SGPRs).  K order = channel block OUTER, tap INNER: the 9 taps of one 64-channel
     // block re-read the same 128-byte line of every halo pixel back to back, so the per-CU L2 working set is
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     // advance to the next K-step; at the end of a tile move on to this workgroup's next tile (or stop)
     auto cursor_next = [&]() __attribute__((always_inline)) {
         ++n_ahead;
-        if (++i_tap == 9) {
+        if (TAPS == 1 || ++i_tap == TAPS) {
             i_tap = 0;
             if (++i_kc == kt_per_tap) {
                 i_kc = 0;
@@ -512,7 +518,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
             const int Y = Y0 + ty;
             const int xo = X0 + (d & TWm);
             const bool pix_ok = Y < rows_total && xo < a.Wout;
-            poff[i] = pix_ok ? (unsigned)(((long long)Y * a.Wout + xo) * a.Cout * 2) : OOB;   // m = (b*Hout + yo)*Wout + xo
+            poff[i] = pix_ok ? ((unsigned)Y * (unsigned)a.Wout + (unsigned)xo) * (unsigned)OC * 2u : OOB;   // m = (b*Hout + yo)*Wout + xo
             int img = img0, t = rem0 + ty;
             while (t >= a.Hout) { t -= a.Hout; ++img; }                                       // a patch spans at most TH / Hout + 1 images
             rboff[i] = (unsigned)(min(img, a.B - 1) * a.Cout * 2);
@@ -536,6 +542,52 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
                     r[4 + g] = __builtin_amdgcn_raw_buffer_load_b64(rrs, (int)(n_ok && poff[i] != OOB ? poff[i] + (unsigned)n * 2u : OOB), 0, 0);
             }
         };
+        if constexpr (EPI == 1) {
+            // GEGLU: fragments (2jj, 2jj+1) = value / gate of output channels ob .. ob+31 (rows interleaved by the host)
+            static_assert(EPI == 0 || NT % 2 == 0, "GEGLU needs value/gate fragment pairs");
+#pragma unroll
+            for (int jj = 0; jj < NT / 2; ++jj) {
+                const int nb = n0 + TN * wn + 64 * jj;     // first (interleaved) weight row of the value fragment
+                const int ob = (n0 + TN * wn) / 2 + 32 * jj;
+                u32x2 bpv[4], bpg[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = nb + 8 * g + 4 * hi;
+                    bpv[g] = __builtin_amdgcn_raw_buffer_load_b64(brs, (int)(n < a.Cout ? (unsigned)n * 2u : OOB), 0, 0);
+                    bpg[g] = __builtin_amdgcn_raw_buffer_load_b64(brs, (int)(n + 32 < a.Cout ? (unsigned)(n + 32) * 2u : OOB), 0, 0);
+                }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        unsigned w[2][2];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int g = 2 * gp + q;
+                            float v[4], gt[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * jj][4 * g + e]; gt[e] = acc[i][2 * jj + 1][4 * g + e]; }
+                            unpack_add(v, bpv[g]);
+                            unpack_add(gt, bpg[g]);
+                            // the Linear output is a bf16 tensor in the unfused path: round value and gate before the gate function
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float vr = (float)(__bf16)v[e], gr = (float)(__bf16)gt[e];
+                                v[e] = vr * (0.5f * gr * (1.f + erff(gr * 0.70710678118654752f)));
+                            }
+                            f32x2 lo = {v[0], v[1]}, hi2 = {v[2], v[3]};
+                            bf16x2 plo = __builtin_convertvector(lo, bf16x2), phi = __builtin_convertvector(hi2, bf16x2);
+                            w[q][0] = __builtin_bit_cast(unsigned, plo);
+                            w[q][1] = __builtin_bit_cast(unsigned, phi);
+                        }
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+                        const int c0 = ob + 16 * gp + 8 * hi;
+                        const u32x4 out = {s0[0], s1[0], s0[1], s1[1]};
+                        __builtin_amdgcn_raw_buffer_store_b128(out, yrs, (int)(poff[i] != OOB && c0 < OC ? poff[i] + (unsigned)c0 * 2u : OOB), 0, 0);
+                    }
+            }
+        } else {
         u32x2 pre[2][8];                               // [parity of f = j*MT + i][rowbias g 0..3 | residual g 0..3]
 #pragma unroll
         for (int g = 0; g < 8; ++g) pre[0][g] = pre[1][g] = u32x2{0u, 0u};
@@ -579,23 +631,24 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
                     const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
                     const int c0 = nbase + 16 * gp + 8 * hi;   // this lane now owns channels c0 .. c0+7 of its pixel
                     const u32x4 out = {s0[0], s1[0], s0[1], s1[1]};
-                    __builtin_amdgcn_raw_buffer_store_b128(out, yrs, (int)(poff[i] != OOB && c0 < a.Cout ? poff[i] + (unsigned)c0 * 2u : OOB),
+                    __builtin_amdgcn_raw_buffer_store_b128(out, yrs, (int)(poff[i] != OOB && c0 < OC ? poff[i] + (unsigned)c0 * 2u : OOB),
                                                            0, 0);
                 }
             }
+        }
         }
         stamp();
     }   // tile loop
 #endif
 }
 
-template <int BMT, int BN, int NW, int WMW, int NSTAGE>
+template <int BMT, int BN, int NW, int WMW, int NSTAGE, int TAPS = 9, int EPI = 0>
 int launch_conv_dma(const ConvArgs& a_in, hipStream_t stream) {
     constexpr int LDS = NSTAGE * (BMT + BN) * 128;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_dma<BMT, BN, NW, WMW, NSTAGE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_dma<BMT, BN, NW, WMW, NSTAGE, TAPS, EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -608,7 +661,7 @@ int launch_conv_dma(const ConvArgs& a_in, hipStream_t stream) {
     a.tiles_x = (a.Wout + (1 << tw_log2) - 1) >> tw_log2;
     const int TH = BMT >> tw_log2;
     if ((long long)a.B * a.Hout + 512 >= (1 << 22)) return DM_ERR_UNSUPPORTED;      // float-reciprocal row -> image split
-    if ((long long)a.B * a.Hin * a.Win * a.Cin * 2 > 0xffffff00LL || (long long)a.Cout * 9 * a.Cin * 2 > 0xffffff00LL)
+    if ((long long)a.B * a.Hin * a.Win * a.Cin * 2 > 0xffffff00LL || (long long)a.Cout * TAPS * a.Cin * 2 > 0xffffff00LL)
         return DM_ERR_UNSUPPORTED;                                                    // 32-bit buffer offsets
     if (a.M * a.Cout * 2 > 0xffffff00LL) return DM_ERR_UNSUPPORTED;
     long long n_mt = (((long long)a.B * a.Hout + TH - 1) / TH) * a.tiles_x;
@@ -635,7 +688,7 @@ int launch_conv_dma(const ConvArgs& a_in, hipStream_t stream) {
     static const bool use_stagger = getenv("DREAMMAT_CONV_STAGGER") && !strcmp(getenv("DREAMMAT_CONV_STAGGER"), "1");
     if (use_stagger && per_xcd >= 3 * wpx) {
         const long long step_cycles = (long long)(NW / 4) * (BMT / WMW / 32) * (BN / (NW / WMW) / 32) * 4 * 32 * 3 / 2;
-        stagger = (int)std::max<long long>(1, 9LL * (a.Cin / 64) * step_cycles / 8 / 8128);
+        stagger = (int)std::max<long long>(1, (long long)TAPS * (a.Cin / 64) * step_cycles / 8 / 8128);
     }
     DM_ENTER();
     static const bool timeline = getenv("DREAMMAT_CONV_TIMELINE") != nullptr;      // development aid, see tools/conv_fit.sh
@@ -646,7 +699,7 @@ int launch_conv_dma(const ConvArgs& a_in, hipStream_t stream) {
         if (blocks <= 4096) { (void)hipMemsetAsync(tl_buf, 0, 4096 * 64 * 8, stream); a.timeline = tl_buf; }
         a.timeline_steps = atoi(getenv("DREAMMAT_CONV_TIMELINE")) == 2;
     }
-    hipLaunchKernelGGL((k_conv3x3_dma<BMT, BN, NW, WMW, NSTAGE>), dim3((unsigned)blocks), dim3(NW * 64), LDS, stream, a,
+    hipLaunchKernelGGL((k_conv3x3_dma<BMT, BN, NW, WMW, NSTAGE, TAPS, EPI>), dim3((unsigned)blocks), dim3(NW * 64), LDS, stream, a,
                        n_mt, n_nt, stagger);
     hipError_t e = hipGetLastError();
     if (a.timeline && e == hipSuccess) {
@@ -755,6 +808,47 @@ int dm_conv3x3_nhwc_bf16(const void* x, const void* w, const void* bias, void* y
                          int Hout, int Wout, int Cout, int stride, int pad_y, int pad_x, hipStream_t stream) {
     return dm_conv3x3_nhwc_bf16_fused(x, w, bias, nullptr, nullptr, y, B, Hin, Win, Cin, Hout, Wout, Cout, stride, pad_y,
                                       pad_x, stream);
+}
+
+// y[M, N] = x[M, K] w[N, K]^T + bias[N] (+ residual[M, N]); all bf16 row-major, fp32 accumulate, one rounding.
+// geglu != 0: w / bias rows are interleaved in blocks of 32 (32 value rows, their 32 gate rows, ...) and
+// y[M, N/2] = value * gelu(gate) with value and gate rounded to bf16 first (what the unfused Linear -> GEGLU pair computes).
+// Runs the 1-tap instantiation of the LDS-DMA convolution kernel above (M % 16 == 0, K % 64 == 0, N % 64 == 0; geglu: N % 128).
+int dm_gemm_bf16_fused(const void* x, const void* w, const void* bias, const void* residual, void* y, long long M, int K,
+                       int N, int geglu, hipStream_t stream) {
+    if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0) return DM_ERR_ARG;
+    if (M % 16 != 0 || K % 64 != 0 || N % 64 != 0 || (geglu && (N % 128 != 0 || residual))) return DM_ERR_UNSUPPORTED;
+    if (M / 16 >= (1 << 22)) return DM_ERR_UNSUPPORTED;
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return DM_ERR_ARG;
+    if (((uintptr_t)bias | (uintptr_t)residual) & 7) return DM_ERR_ARG;
+    ConvArgs a;
+    a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const __bf16*)bias; a.y = (__bf16*)y;
+    a.rowbias = nullptr; a.res = (const __bf16*)residual; a.timeline = nullptr; a.timeline_steps = 0;
+    a.B = 1; a.Hin = a.Hout = (int)(M / 16); a.Win = a.Wout = 16; a.Cin = K; a.Cout = N;
+    a.stride = 1; a.pad_y = 0; a.pad_x = 0;
+    a.M = M;
+    auto n_wg = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
+    const char* tile_env = getenv("DREAMMAT_GEMM_TILE");     // 128 | 256 | 512 forces a variant (tests / A-B measurements)
+    int tile = tile_env ? atoi(tile_env) : 0;
+    if (!tile) {
+        if (!(N >= 128 && M >= 2048)) tile = 128;
+        else if (N % 256 == 0 && n_wg(256, 256) >= 200) tile = 512;
+        else tile = 256;
+    }
+    if (geglu) {
+        switch (tile) {
+        case 512: return launch_conv_dma<256, 256, 8, 2, 2, 1, 1>(a, stream);
+        case 256: return launch_conv_dma<256, 128, 8, 4, 3, 1, 1>(a, stream);
+        default: return launch_conv_dma<128, 128, 4, 2, 3, 1, 1>(a, stream);
+        }
+    }
+    switch (tile) {
+    case 512: return launch_conv_dma<256, 256, 8, 2, 2, 1, 0>(a, stream);
+    case 256: return launch_conv_dma<256, 128, 8, 4, 3, 1, 0>(a, stream);
+    default:
+        return (N % 128 == 0) ? launch_conv_dma<128, 128, 4, 2, 3, 1, 0>(a, stream)
+                              : launch_conv_dma<128, 64, 4, 2, 3, 1, 0>(a, stream);
+    }
 }
 
 }  // extern "C"

@@ -19,11 +19,14 @@ def _stream():
 
 
 # ---- optional per-kernel HIP-event timing (bench.py's live roofline numbers) --------------------
-_TIMING = {"on": False, "events": {}}
+_TIMING = {"on": False, "events": {}, "only": None}
 
 
-def enable_kernel_timing(on=True):
+def enable_kernel_timing(on=True, only=None):
+    """HIP events around every launch below (`only`: key prefixes to restrict it to -- an event pair costs ~2 us of
+    stream time, so a measured region should time only the kernels it reports)."""
     _TIMING["on"] = on
+    _TIMING["only"] = tuple(only) if only else None
     if on:
         _TIMING["events"] = {}
 
@@ -35,14 +38,15 @@ class _Timed:
         self.key, self.work = key, work
 
     def __enter__(self):
-        if _TIMING["on"]:
+        self.live = _TIMING["on"] and (_TIMING["only"] is None or self.key.startswith(_TIMING["only"]))
+        if self.live:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
         return self
 
     def __exit__(self, *a):
-        if _TIMING["on"]:
+        if self.live:
             self.e1.record()
             _TIMING["events"].setdefault(self.key, []).append((self.e0, self.e1, self.work))
 
@@ -434,6 +438,12 @@ def attention_select(name=None):
     check(_lib.lib().dm_attention_select(name.encode() if name is not None else None), "dm_attention_select")
 
 
+def attention_variant():
+    """name of the variant attention() runs unless attention_select() overrode it (for reports)."""
+    import os
+    return os.environ.get("DREAMMAT_ATTN_KERNEL", "v3l")
+
+
 def attention(q, k, vt, heads, scale=None):
     """q [B,Sq,C], k [B,Skv,C] bf16 (C = heads*D, last dim contiguous), vt [B,C,Skv_pad] bf16
     (V transposed, rows zero-padded to a multiple of 8) -> out [B,Sq,C] bf16."""
@@ -475,6 +485,40 @@ def conv3x3_nhwc(x_nhwc, w_tap_major, bias, stride=1, pad=(1, 1), out_hw=None, r
             rowbias.data_ptr() if rowbias is not None else None, residual.data_ptr() if residual is not None else None,
             y.data_ptr(), B, H, W, Cin, Ho, Wo, Cout, stride, pad[0], pad[1], _stream()), "dm_conv3x3_nhwc_bf16_fused")
     return y
+
+
+def gemm_fused(x, w, bias=None, residual=None, geglu=False):
+    """y[..., N] = x[..., K] @ w[N, K]^T + bias (+ residual[..., N]) on the 1-tap LDS-DMA kernel (forward only).
+    geglu: `w` / `bias` rows interleaved by `geglu_interleave`; returns value * gelu(gate), [..., N/2]."""
+    _need_cuda(x, w, bias, residual)
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and w.dtype == torch.bfloat16 and w.is_contiguous()
+    N, K = w.shape
+    M = x.numel() // K
+    assert x.shape[-1] == K
+    No = N // 2 if geglu else N
+    y = torch.empty(*x.shape[:-1], No, device=x.device, dtype=torch.bfloat16)
+    if bias is not None:
+        assert bias.dtype == torch.bfloat16 and bias.is_contiguous() and bias.numel() == N
+    if residual is not None:
+        assert residual.dtype == torch.bfloat16 and residual.is_contiguous() and residual.shape == y.shape
+    with _Timed(f"gemm{'+geglu' if geglu else ''}{'+res' if residual is not None else ''}[M={M},K={K},N={N}]", 2.0 * M * K * N):
+        check(_lib.lib().dm_gemm_bf16_fused(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                            residual.data_ptr() if residual is not None else None, y.data_ptr(), M, K, N,
+                                            1 if geglu else 0, _stream()), "dm_gemm_bf16_fused")
+    return y
+
+
+def gemm_fused_ok(M, K, N, geglu=False):
+    return M % 16 == 0 and K % 64 == 0 and N % (128 if geglu else 64) == 0
+
+
+def geglu_interleave(t):
+    """rows [value(inner) | gate(inner)] -> blocks of 32 value rows followed by their 32 gate rows (dm_gemm_bf16_fused)."""
+    inner = t.shape[0] // 2
+    assert inner % 32 == 0
+    v = t[:inner].reshape(inner // 32, 32, *t.shape[1:])
+    g = t[inner:].reshape(inner // 32, 32, *t.shape[1:])
+    return torch.stack([v, g], dim=1).reshape(t.shape).contiguous()
 
 
 class _Conv3x3S1(torch.autograd.Function):

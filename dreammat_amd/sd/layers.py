@@ -57,7 +57,7 @@ class Conv2d(nn.Conv2d):
         ph, pw = self.padding
         if kh == 1 and kw == 1 and sh == 1 and sw == 1 and ph == 0 and pw == 0:
             xn = x.permute(0, 2, 3, 1)                                   # free for channels-last activations
-            y = F.linear(xn, self.weight.view(Cout, Cin), self.bias)     # [B,H,W,Cout]
+            y = linear_fused(xn, self.weight.view(Cout, Cin), self.bias)  # [B,H,W,Cout]
             return y.permute(0, 3, 1, 2)
         cols = F.unfold(x, (kh, kw), padding=(ph, pw), stride=(sh, sw))  # [B, Cin*kh*kw, L]
         # [B, L, K] @ [K, Cout]: the result is produced directly in NHWC, like every other layer of the nets
@@ -160,6 +160,18 @@ def _rows_kernel_ok(x, *params):
     return x.is_cuda and x.dtype == torch.bfloat16 and CONV_BACKEND == "mfma" and not needs_grad
 
 
+def linear_fused(x, weight, bias, residual=None):
+    """F.linear(x, weight, bias) (+ residual): frozen bf16 layers on the GPU run the hand-written MFMA GEMM with the adds in
+    its epilogue (csrc/conv.hip, 1-tap instantiation); everything else is the ATen call."""
+    N, K = weight.shape
+    if (_rows_kernel_ok(x, weight) and weight.dtype == torch.bfloat16 and hipops.gemm_fused_ok(x.numel() // K, K, N)
+            and (residual is None or residual.dtype == torch.bfloat16)):
+        r = residual.contiguous() if residual is not None else None
+        return hipops.gemm_fused(x.contiguous(), weight.detach().contiguous(), bias.detach() if bias is not None else None, r)
+    y = F.linear(x, weight, bias)
+    return y + residual if residual is not None else y
+
+
 def layer_norm(norm: nn.LayerNorm, x):
     C = x.shape[-1]
     if _rows_kernel_ok(x, norm.weight) and C % 8 == 0 and C <= 2048:
@@ -235,15 +247,16 @@ class Attention(nn.Module):
         self.to_v = nn.Linear(cross_dim, query_dim, bias=bias)
         self.to_out = nn.ModuleList([nn.Linear(query_dim, query_dim), nn.Identity()])
 
-    def forward(self, x, context=None):
+    def forward(self, x, context=None, residual=None):
+        """-> to_out(attention) (+ residual, added in the output projection's epilogue)."""
         if context is None:
             src, kv_len = x, x.shape[1]
         else:
             src, kv_len = context.t, context.len
-        q = self.to_q(x)
-        k = self.to_k(src)
+        q = linear_fused(x, self.to_q.weight, self.to_q.bias)
+        k = linear_fused(src, self.to_k.weight, self.to_k.bias)
         o = attention_core(q, k, self.to_v.weight, self.to_v.bias, src, self.heads, kv_len)
-        return self.to_out[0](o)
+        return linear_fused(o, self.to_out[0].weight, self.to_out[0].bias, residual)
 
 
 class GEGLU(nn.Module):
@@ -251,7 +264,22 @@ class GEGLU(nn.Module):
         super().__init__()
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
+    def _interleaved(self):
+        w = self.proj.weight
+        key = (w.data_ptr(), w._version, w.dtype)
+        if getattr(self, "_il_key", None) != key:
+            self._w_il = hipops.geglu_interleave(w.detach())
+            self._b_il = hipops.geglu_interleave(self.proj.bias.detach()) if self.proj.bias is not None else None
+            self._il_key = key
+        return self._w_il, self._b_il
+
     def forward(self, x):
+        w = self.proj.weight
+        N, K = w.shape
+        if (_rows_kernel_ok(x, w) and w.dtype == torch.bfloat16 and (N // 2) % 32 == 0
+                and hipops.gemm_fused_ok(x.numel() // K, K, N, geglu=True)):
+            w_il, b_il = self._interleaved()                       # GEMM + GEGLU in one kernel: the 2x wide tensor never exists
+            return hipops.gemm_fused(x.contiguous(), w_il, b_il, None, geglu=True)
         h = self.proj(x)
         if _rows_kernel_ok(h) and h.shape[-1] % 16 == 0:
             return hipops.geglu_rows(h.contiguous())
@@ -264,8 +292,8 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Identity(), nn.Linear(dim * 4, dim)])
 
-    def forward(self, x):
-        return self.net[2](self.net[0](x))
+    def forward(self, x, residual=None):
+        return linear_fused(self.net[0](x), self.net[2].weight, self.net[2].bias, residual)
 
 
 class BasicTransformerBlock(nn.Module):
@@ -279,9 +307,9 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, x, context):
-        x = self.attn1(layer_norm(self.norm1, x)) + x
-        x = self.attn2(layer_norm(self.norm2, x), context) + x
-        return self.ff(layer_norm(self.norm3, x)) + x
+        x = self.attn1(layer_norm(self.norm1, x), None, x)         # the three residual adds ride in GEMM epilogues
+        x = self.attn2(layer_norm(self.norm2, x), context, x)
+        return self.ff(layer_norm(self.norm3, x), x)
 
 
 class Transformer2DModel(nn.Module):
@@ -298,15 +326,16 @@ class Transformer2DModel(nn.Module):
         res = x
         h = group_norm_act(self.norm, x, False)
         if self.use_linear:
-            h = self.proj_in(h.permute(0, 2, 3, 1).reshape(B, H * W, C))
+            h = linear_fused(h.permute(0, 2, 3, 1).reshape(B, H * W, C), self.proj_in.weight, self.proj_in.bias)
         else:
             h = self.proj_in(h).permute(0, 2, 3, 1).reshape(B, H * W, C)
         for blk in self.transformer_blocks:
             h = blk(h, context)
         if self.use_linear:
-            h = self.proj_out(h).reshape(B, H, W, C).permute(0, 3, 1, 2)
-        else:
-            h = self.proj_out(h.reshape(B, H, W, C).permute(0, 3, 1, 2))
+            r = res.permute(0, 2, 3, 1).reshape(B, H * W, C)      # a view for channels-last activations
+            h = linear_fused(h, self.proj_out.weight, self.proj_out.bias, r)
+            return h.reshape(B, H, W, C).permute(0, 3, 1, 2)
+        h = self.proj_out(h.reshape(B, H, W, C).permute(0, 3, 1, 2))
         return h + res
 
 

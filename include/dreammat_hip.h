@@ -249,6 +249,16 @@ int dm_conv3x3_nhwc_bf16_fused(const void* x, const void* w, const void* bias, c
                                void* y, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int stride,
                                int pad_y, int pad_x, dm_stream_t stream);
 
+/* Linear / 1x1-convolution layers of the same nets (diffusers Attention.to_q/to_k/to_out, FeedForward, Transformer2DModel
+ * proj_in/proj_out, ResnetBlock2D.conv_shortcut: the F.linear / 1x1 F.conv2d calls under
+ * models/guidance/dreammat_guidance.py:205-292) on the 1-tap instantiation of the same kernel:
+ * y[M,N] = x[M,K] w[N,K]^T + bias[N] (+ residual[M,N]), bf16 row-major, fp32 accumulate, rounded once.
+ * geglu != 0 fuses diffusers' GEGLU (`hidden, gate = proj(x).chunk(2); hidden * gelu(gate)`): w and bias rows interleaved in
+ * blocks of 32 (32 value rows, then their 32 gate rows), y is [M, N/2]; value and gate are rounded to bf16 before the gate
+ * function, as the unfused pair does.  M % 16 == 0, K % 64 == 0, N % 64 == 0 (geglu: N % 128 == 0, no residual). */
+int dm_gemm_bf16_fused(const void* x, const void* w, const void* bias, const void* residual, void* y, long long M, int K,
+                       int N, int geglu, dm_stream_t stream);
+
 /* ---- normalisation ----------------------------------------------------------------------- */
 /* GroupNorm(32) [+ SiLU] of the ResnetBlock2D / Transformer2DModel / conv_norm_out layers of the same nets,
  * NHWC bf16: x,y [B,HW,C], gamma/beta [C] bf16.  ws: dm_groupnorm_workspace_floats(B,C) fp32, kept by the caller

@@ -385,10 +385,10 @@ def test_unet_controlnet_gpu_fp32_and_bf16_hip_attention(dev):
             kt = hipops.kernel_times()
             n_attn = sum(v["launches"] for k, v in kt.items() if k.startswith("attention"))
             n_ln = sum(v["launches"] for k, v in kt.items() if k.startswith("layernorm"))
-            n_gg = sum(v["launches"] for k, v in kt.items() if k.startswith("geglu"))
+            n_gg = sum(v["launches"] for k, v in kt.items() if k.startswith(("geglu", "gemm+geglu")))
             hipops.enable_kernel_timing(False)
         assert n_attn == 46, n_attn                    # 2x(16 UNet + 7 ControlNet) attention launches, all on MFMA
-        assert n_ln == 69 and n_gg == 23, (n_ln, n_gg)  # 3 LayerNorms + 1 GEGLU per transformer block, HIP kernels
+        assert n_ln == 69 and n_gg == 23, (n_ln, n_gg)  # 3 LayerNorms + 1 GEGLU (own kernel or GEMM epilogue) per block
         rel = ((yb - oy).abs().max() / oy.abs().max()).item()
         assert rel < 6e-2, (arch_name, rel)
 
@@ -762,6 +762,83 @@ def test_conv3x3_fused_epilogue(dev, monkeypatch, tile, B, Cin, Cout, H, W):
     assert err < 2e-2 * ref.abs().max().item() + 1e-2, err
     y1 = hipops.conv3x3_nhwc(x.to(dev), wt.to(dev), bias.to(dev), 1, (1, 1), None, rowbias.to(dev), None).float().cpu()
     assert (y1 - (ref - res.float())).abs().max().item() < 2e-2 * ref.abs().max().item() + 1e-2
+
+
+@pytest.mark.parametrize("tile,M,K,N,res", [
+    (None, 4096, 320, 320, True),            # to_out / proj_out @ 64x64 (ragged N tile at 128/256 wide tiles)
+    (None, 1024, 1280, 1280, False),
+    ("128", 272, 64, 192, True),             # ragged M tile, 128x64 variant
+    ("128", 2048, 128, 256, False),
+    ("256", 4096, 640, 640, True),
+    ("512", 8192, 320, 512, True),
+    (None, 32, 1280, 320, False),            # time_emb_proj-sized
+])
+def test_gemm_fused_vs_fp32_reference(dev, monkeypatch, tile, M, K, N, res):
+    """Linear / 1x1-conv layers on the 1-tap LDS-DMA kernel: y = x w^T + bias (+ residual), every tile variant."""
+    if tile:
+        monkeypatch.setenv("DREAMMAT_GEMM_TILE", tile)
+    torch.manual_seed(5)
+    x = torch.randn(M, K).bfloat16()
+    w = (torch.randn(N, K) * 0.05).bfloat16()
+    b = torch.randn(N).bfloat16()
+    r = torch.randn(M, N).bfloat16() if res else None
+    y = hipops.gemm_fused(x.to(dev), w.to(dev), b.to(dev), r.to(dev) if res else None).float().cpu()
+    ref = x.float() @ w.float().t() + b.float() + (r.float() if res else 0.0)
+    err = (y - ref).abs().max().item()
+    assert err < 1e-2 * ref.abs().max().item() + 1e-2, err
+    y0 = hipops.gemm_fused(x.to(dev), w.to(dev), None, None).float().cpu()
+    assert (y0 - x.float() @ w.float().t()).abs().max().item() < 1e-2 * ref.abs().max().item() + 1e-2
+
+
+@pytest.mark.parametrize("tile,M,K,inner", [(None, 4096, 320, 1280), ("128", 1040, 64, 192), ("256", 2048, 640, 2560),
+                                             ("512", 4096, 320, 1280)])
+def test_gemm_geglu_epilogue_vs_unfused_pair(dev, monkeypatch, tile, M, K, inner):
+    """diffusers GEGLU (`hidden, gate = proj(x).chunk(2); hidden * gelu(gate)`) fused into the projection GEMM: must equal
+    the unfused pair, which rounds the projection to bf16 before the gate function."""
+    if tile:
+        monkeypatch.setenv("DREAMMAT_GEMM_TILE", tile)
+    torch.manual_seed(6)
+    x = torch.randn(M, K).bfloat16()
+    w = (torch.randn(2 * inner, K) * 0.08).bfloat16()
+    b = torch.randn(2 * inner).bfloat16()
+    y = hipops.gemm_fused(x.to(dev), hipops.geglu_interleave(w).to(dev), hipops.geglu_interleave(b).to(dev), None,
+                          geglu=True).float().cpu()
+    h = (x.float() @ w.float().t() + b.float()).bfloat16().float()
+    ref = h[:, :inner] * torch.nn.functional.gelu(h[:, inner:])
+    assert tuple(y.shape) == (M, inner)
+    # a 1-ulp difference of the bf16-rounded projection (fp32 summation order) moves the product by ~1 %
+    err = (y - ref).abs()
+    assert err.max().item() < 2e-2 * ref.abs().max().item() + 2e-2, err.max().item()
+    assert err.mean().item() < 2e-3 * ref.abs().mean().item() + 1e-4, err.mean().item()
+
+
+def test_transformer_block_fused_gemms_vs_aten(dev):
+    """BasicTransformerBlock / Transformer2DModel with the Linear layers, their residual adds and GEGLU on the fused GEMM
+    kernel vs the same module evaluated with ATen ops in fp32."""
+    from dreammat_amd.sd import layers
+    torch.manual_seed(7)
+    C, heads, B, H, W = 320, 5, 2, 16, 16
+    blk = layers.Transformer2DModel(C, heads, 1024, True).to(dev)
+    for p_ in blk.parameters():
+        p_.requires_grad_(False)
+    x = torch.randn(B, C, H, W)
+    ctx = torch.randn(B, 77, 1024)
+    ref_mod = blk.float()
+    with torch.no_grad():
+        monkey = layers.CONV_BACKEND
+        layers.CONV_BACKEND = "gemm"                    # ATen path
+        ref = ref_mod(x.to(dev), layers.PaddedContext(ctx.to(dev))).float().cpu()
+        layers.CONV_BACKEND = monkey
+        blk16 = blk.to(torch.bfloat16)
+        hipops.enable_kernel_timing(True)
+        y = blk16(x.to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last),
+                  layers.PaddedContext(ctx.to(dev, torch.bfloat16))).float().cpu()
+        torch.cuda.synchronize()
+        keys = list(hipops.kernel_times())
+        hipops.enable_kernel_timing(False)
+    assert sum(k.startswith("gemm") for k in keys) >= 5 and any(k.startswith("gemm+geglu") for k in keys), keys
+    err = (y - ref).abs().max().item()
+    assert err < 3e-2 * ref.abs().max().item() + 3e-2, err
 
 
 def test_narrow_head_conv_zero_padded_to_mfma_tile(dev):

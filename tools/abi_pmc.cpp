@@ -64,6 +64,27 @@ static int run_conv(int B, int H, int W, int Cin, int Cout, int iters) {
     return 0;
 }
 
+static int run_gemm(long long M, int K, int N, int geglu, int iters) {
+    const size_t nx = (size_t)M * K, nw = (size_t)N * K, ny = (size_t)M * (geglu ? N / 2 : N);
+    std::vector<unsigned short> hx(nx), hw(nw), hb(N);
+    for (auto& v : hx) v = bf16_small();
+    for (auto& v : hw) v = bf16_small();
+    for (auto& v : hb) v = bf16_small();
+    void *dx, *dw, *db, *dy, *dr;
+    if (upload(&dx, hx) || upload(&dw, hw) || upload(&db, hb)) return 2;
+    CK(hipMalloc(&dy, ny * 2));
+    CK(hipMalloc(&dr, ny * 2));
+    CK(hipMemset(dr, 0, ny * 2));
+    float ms;
+    int rc = timed(iters, &ms, [&] { return dm_gemm_bf16_fused(dx, dw, db, geglu ? nullptr : dr, dy, M, K, N, geglu, nullptr); });
+    if (rc) return rc;
+    const double flops = 2.0 * M * K * (double)N;
+    printf("{\"op\":\"gemm\",\"M\":%lld,\"K\":%d,\"N\":%d,\"geglu\":%d,\"ms\":%.4f,\"TFLOPs\":%.1f,\"alg_MB\":%.1f,\"GBps\":%.0f}\n", M, K, N,
+           geglu, ms, flops / (ms * 1e-3) / 1e12, (nx + nw + ny * (geglu ? 1 : 2)) * 2 / 1e6,
+           (nx + nw + ny * (geglu ? 1 : 2)) * 2 / 1e9 / (ms * 1e-3));
+    return 0;
+}
+
 static int run_attn(int B, int Hh, int Sq, int Skv, int D, int iters) {
     const int C = Hh * D, Sp = (Skv + 7) / 8 * 8;
     std::vector<unsigned short> hq((size_t)B * Sq * C), hk((size_t)B * Skv * C), hv((size_t)B * C * Sp);
@@ -184,6 +205,7 @@ static int run_shade_file(const char* path, int iters) {
 }
 
 int main(int argc, char** argv) {
+    if (argc >= 7 && !strcmp(argv[1], "gemm")) return run_gemm(atoll(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]));
     if (argc >= 8 && !strcmp(argv[1], "conv")) return run_conv(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]));
     if (argc >= 9 && !strcmp(argv[1], "attn") && dm_attention_select(argv[8])) { printf("unknown attention variant %s\n", argv[8]); return 1; }
     if (argc >= 4 && !strcmp(argv[1], "shadef")) return run_shade_file(argv[2], atoi(argv[3]));
