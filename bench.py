@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-timeout", type=int, default=150)
     ap.add_argument("--env-res", type=int, default=128)
+    ap.add_argument("--graph", choices=["on", "off", "auto"], default="auto",
+                    help="hipGraph replay of the ControlNet+UNet noise prediction (guidance hip_graph)")
     ap.add_argument("--dump-kernels", default=None, help="write the per-kernel HIP-event table of the timed region (JSON) here")
     return ap.parse_args()
 
@@ -68,6 +70,7 @@ def system_config(a, views_per_rank):
         "guidance": {"use_controlnet": True, "control_types": ["light"], "condition_scales": [1.0],
                      "condition_scales_anneal": [0.8], "control_anneal_start_step": 700, "width": a.res,
                      "height": a.res, "pretrained_model_name_or_path": a.sd, "synthetic": True, "cond_scale": 1.05,
+                     "hip_graph": {"on": True, "off": False, "auto": "auto"}[a.graph],
                      "uncond_scale": [0, -1.0, -0.5, 2000], "null_scale": [0, 0.0, -0.5, 2000], "noise_scale": 0.0,
                      "min_step_percent": [500, 0.2, 0.02, 501], "max_step_percent": [500, 0.8, 0.5, 501]},
         "prompt_processor": {"prompt": "a DSLR photo of a ceramic vase", "negative_prompt": "ugly, low resolution",
@@ -290,6 +293,7 @@ def main():
                                           "SDS + backward + all-reduce + Adam; debug buffers off (written every 1000 steps only)",
                           "fg_lut": "reference bsdf_256_256.bin" if system.material.real_fg_lut else "analytic stand-in (file absent)",
                           "atlas_texel": system.material.atlas.texel,
+                          "noise_pred_hip_graph": bool(getattr(system.guidance, "_graphs", None)),
                           "parallelism": f"dp{world} (views sharded, 1 all-reduce of {system.flat.numel * 4 / 1e6:.1f} MB fp32 grads)",
                           "final_loss": float(loss)}}
         # ---- rooflines from HIP events around the launches: `roofline` (conv) live in the timed region, the others on the

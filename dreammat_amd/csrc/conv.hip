@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_conv3x3(ConvArgs a, long long n_mt, int
 // 32 gate rows), so fragment pair (2jj, 2jj+1) of a wave holds value and gate of the same 32 output channels and the
 // epilogue writes value * gelu(gate) into y[M, N/2]: the 2x wide intermediate never reaches HBM.
 template <int BMT, int BN, int NW, int WMW, int NSTAGE, int TAPS = 9, int EPI = 0>
-__global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n_mt, int n_nt, int stagger_units) {
+__global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n_mt, int n_nt, int stagger_units, int ksplit, float* __restrict__ ws) {
     // BMT x BN x 64 workgroup tile, NW waves laid out WMW (along M) x NW/WMW (along N), NSTAGE-deep LDS ring.
     //   <128, 64|128, 4, 2, 3>  wave tile 64 x 32|64, 2-5 workgroups per CU (small problems)
     //   <256, 128, 8, 4, 3>     wave tile 64 x 64, one workgroup per CU
@@ -225,7 +225,10 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     // already landing.  One workgroup per tile paid a cold prologue (address set-up, first DMA round trip), a store tail
     // and a relaunch per tile -- 0.25 ms of the 0.80 ms of the 8 x 128->128 @512^2 layer did not scale with K
     // (tools/conv_fit.sh), with one workgroup per CU nothing else could cover it.
-    const int total = (int)(n_mt * n_nt);              // < 2^31 (launcher)
+    // SPLIT-K (ksplit > 1, small-M problems: 1280->1280 @8x8 has 20 output tiles for 256 CUs): a work item is (output tile,
+    // K range); its fp32 partial sums go to ws[ks][M][Cout] and k_splitk_reduce adds them up with the bias / residual terms
+    constexpr bool SPLIT_OK = EPI == 0 && BMT <= 256 && BN <= 128;
+    const int total = (int)(n_mt * n_nt) * ksplit;     // < 2^31 (launcher)
     const int per_xcd = (total + 7) / 8;
     const int wpx = (int)(gridDim.x >> 3);             // workgroups per XCD
     const int xbeg = (int)(blockIdx.x & 7) * per_xcd;
@@ -243,8 +246,10 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     // crosses into the next tile, where every cycle is a cycle without MFMAs -- the first persistent version spent 13 k
     // cycles per tile here on two 64-bit divisions, 64-bit address products and the spills around them
     // (DREAMMAT_CONV_TIMELINE=2).
-    auto tile_coords = [&](int id, int& Y0, int& X0, int& n0) __attribute__((always_inline)) {
-        const unsigned uid = (unsigned)id;
+    auto tile_coords = [&](int id, int& Y0, int& X0, int& n0, int& ks) __attribute__((always_inline)) {
+        unsigned uid = (unsigned)id;
+        ks = 0;
+        if (SPLIT_OK && ksplit > 1) { ks = (int)(uid % (unsigned)ksplit); uid /= (unsigned)ksplit; }
         const unsigned mt = uid / (unsigned)n_nt;
         const unsigned nt = uid - mt * (unsigned)n_nt;
         const unsigned tile_y = mt / (unsigned)a.tiles_x;
@@ -252,6 +257,22 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
         X0 = (int)((mt - tile_y * (unsigned)a.tiles_x) << a.tw_log2);
         n0 = (int)nt * BN;
     };
+    const int kt_per_tap = a.Cin / BK;
+    const int n_steps = TAPS * kt_per_tap;
+    auto k_lo = [&](int ks) __attribute__((always_inline)) {     // first K-step of split ks (ks = ksplit: one past the end)
+        return (SPLIT_OK && ksplit > 1) ? (int)((long long)ks * n_steps / ksplit) : (ks ? n_steps : 0);
+    };
+
+    // issue cursor (wave-uniform => SGPRs).  K order = channel block OUTER, tap INNER: the 9 taps of one 64-channel
+    // block re-read the same 128-byte line of every halo pixel back to back, so the per-CU L2 working set is
+    // (TH+2)(TW+2) lines (41 KB for 16x16) whatever Cin is.  Tap-outer order swept all Cin between re-reads
+    // (83 KB-830 KB per CU, x32 CUs per 4 MB L2): rocprofv3 FETCH_SIZE showed 2.1x (Cin=128) to 6.3x (Cin=320)
+    // the compulsory bytes and a 66-76 % L2 hit rate (profiles/r01_pmc_conv_v0.json).
+    int i_tap = 0, i_kc = 0;
+    int i_step = 0, i_end = 0;                         // K-step at the cursor / end of the cursor's K range
+    int issue_tile = first;                            // work item the cursor is in
+    int issue_on = 1;                                  // 0 once the last item's last step has been requested
+    int n_ahead = 0;                                   // K-steps requested but not yet consumed
     const int lrow = lane >> 3, lslot = lane & 7;      // this lane's row / 16 B slot inside one DMA instruction
 
     // ---- issue side: buffer-addressed DMA (buffer_load_dwordx4 ... lds).  Both operands are described by a raw buffer
@@ -283,8 +304,11 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     unsigned b_off[B_INSTR];
     const float rcp_hout = 1.0f / (float)a.Hout;       // B*Hout < 2^22 (launcher): one correction step makes the quotient exact
     auto setup_issue_tile = [&](int id) __attribute__((always_inline)) {
-        int Y0, X0, n0;
-        tile_coords(id, Y0, X0, n0);
+        int Y0, X0, n0, ks;
+        tile_coords(id, Y0, X0, n0, ks);
+        i_step = k_lo(ks); i_end = k_lo(ks + 1);
+        i_kc = TAPS == 1 ? i_step : i_step / TAPS;
+        i_tap = TAPS == 1 ? 0 : i_step - i_kc * TAPS;
         // re-derive the lane constants from an opaque copy of the thread id: computed once before the tile loop they stay
         // live across the K loop, where there is no register for them -- the compiler spilled them and every reload in
         // here waited (in order) behind the DMAs just issued: 23 serialized scratch round trips, 11 k cycles per tile
@@ -323,18 +347,6 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
             b_off[i] = ((unsigned)rc * (unsigned)TAPS * (unsigned)a.Cin + (unsigned)((lslot ^ ((row >> 1) & 7)) * 8)) * 2u;
         }
     };
-    const int kt_per_tap = a.Cin / BK;
-    const int n_steps = TAPS * kt_per_tap;
-
-    // issue cursor (wave-uniform => SGPRs).  K order = channel block OUTER, tap INNER: the 9 taps of one 64-channel
-    // block re-read the same 128-byte line of every halo pixel back to back, so the per-CU L2 working set is
-    // (TH+2)(TW+2) lines (41 KB for 16x16) whatever Cin is.  Tap-outer order swept all Cin between re-reads
-    // (83 KB-830 KB per CU, x32 CUs per 4 MB L2): rocprofv3 FETCH_SIZE showed 2.1x (Cin=128) to 6.3x (Cin=320)
-    // the compulsory bytes and a 66-76 % L2 hit rate (profiles/r01_pmc_conv_v0.json).
-    int i_tap = 0, i_kc = 0;
-    int issue_tile = first;                            // tile the cursor is in
-    int issue_on = 1;                                  // 0 once the last tile's last step has been requested
-    int n_ahead = 0;                                   // K-steps requested but not yet consumed
     unsigned toff = 0, woff = 0;                       // byte offsets of the step being issued
     unsigned bit = 1u;
     auto cursor_set = [&]() __attribute__((always_inline)) {
@@ -346,14 +358,11 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     // advance to the next K-step; at the end of a tile move on to this workgroup's next tile (or stop)
     auto cursor_next = [&]() __attribute__((always_inline)) {
         ++n_ahead;
-        if (TAPS == 1 || ++i_tap == TAPS) {
-            i_tap = 0;
-            if (++i_kc == kt_per_tap) {
-                i_kc = 0;
-                issue_tile += wpx;
-                if (issue_tile < xend) setup_issue_tile(issue_tile);
-                else issue_on = 0;
-            }
+        if (TAPS == 1 || ++i_tap == TAPS) { i_tap = 0; ++i_kc; }
+        if (++i_step == i_end) {
+            issue_tile += wpx;
+            if (issue_tile < xend) setup_issue_tile(issue_tile);
+            else issue_on = 0;
         }
     };
     // DMA piece p of the step at the cursor (p < A_INSTR: 8 activation rows, else 8 weight rows) into `stage`
@@ -460,8 +469,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
         if (a.timeline && tid == 0 && tl_i < 64) a.timeline[(long long)blockIdx.x * 64 + tl_i++] = __builtin_amdgcn_s_memtime();
     };
     for (int ct = first; ct < xend; ct += wpx) {
-        int Y0, X0, n0;
-        tile_coords(ct, Y0, X0, n0);
+        int Y0, X0, n0, ks;
+        tile_coords(ct, Y0, X0, n0, ks);
+        const int s_lo = k_lo(ks), s_hi = k_lo(ks + 1);
         stamp();
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -469,14 +479,14 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int s = 0; s < n_steps; ++s) {
+        for (int s = s_lo; s < s_hi; ++s) {
             // Wait for the DMAs of the step being consumed; vmcnt counts in issue order, so what may stay in flight is
             // whatever was issued AFTER them: (NSTAGE == 3) the next step's L DMAs, and -- during the first NSTAGE-1 steps
             // of every tile but the first -- the NST epilogue stores of the previous tile, which were issued between this
             // step's DMAs and the ones that followed.  Counting them lets the stores drain under the new tile's first
             // K-steps instead of being waited for at its first barrier.
             const bool two = NSTAGE == 3 && n_ahead >= 2;
-            if (s < NSTAGE - 1 && ct != first) {
+            if (s - s_lo < NSTAGE - 1 && ct != first && !(SPLIT_OK && ksplit > 1)) {
                 if (two) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(L + NST) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NST) : "memory");
             } else {
@@ -487,7 +497,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
             if (a.timeline_steps) stamp();
             --n_ahead;
             int st2 = stage + NSTAGE - 1; if (st2 >= NSTAGE) st2 -= NSTAGE;
-            kstep(stage, st2, s > 0);
+            kstep(stage, st2, s > s_lo);
             stage = stage + 1; if (stage >= NSTAGE) stage = 0;
         }
         if (PEND) mma(a1, b1);                         // the last step's last chunk
@@ -542,7 +552,24 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
                     r[4 + g] = __builtin_amdgcn_raw_buffer_load_b64(rrs, (int)(n_ok && poff[i] != OOB ? poff[i] + (unsigned)n * 2u : OOB), 0, 0);
             }
         };
-        if constexpr (EPI == 1) {
+        if (SPLIT_OK && ksplit > 1) {
+            // fp32 partial sums of this K range: ws[ks][m][n], 16 bytes (4 consecutive channels) per lane and group
+            const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(ws + (long long)ks * a.M * a.Cout), 0, (int)(unsigned)(a.M * a.Cout * 4), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = n0 + TN * wn + 32 * j + 8 * g + 4 * hi;
+                        // (element copies first: __builtin_bit_cast applied directly to an ext-vector element reads element 0)
+                        const float f0 = acc[i][j][4 * g], f1 = acc[i][j][4 * g + 1], f2 = acc[i][j][4 * g + 2], f3 = acc[i][j][4 * g + 3];
+                        const u32x4 out = {__builtin_bit_cast(unsigned, f0), __builtin_bit_cast(unsigned, f1),
+                                           __builtin_bit_cast(unsigned, f2), __builtin_bit_cast(unsigned, f3)};
+                        __builtin_amdgcn_raw_buffer_store_b128(out, prs, (int)(poff[i] != OOB && n < a.Cout ? poff[i] * 2u + (unsigned)n * 4u : OOB), 0, 0);
+                    }
+        } else if constexpr (EPI == 1) {
             // GEGLU: fragments (2jj, 2jj+1) = value / gate of output channels ob .. ob+31 (rows interleaved by the host)
             static_assert(EPI == 0 || NT % 2 == 0, "GEGLU needs value/gate fragment pairs");
 #pragma unroll
@@ -642,6 +669,57 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
 #endif
 }
 
+// split-K reduction: y[m][n] = sum_ks ws[ks][m][n] + bias[n] + rowbias[image(m)][n] + res[m][n], 8 channels per thread
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ ws, int ksplit, long long M, int Cout, long long hw,
+                                                        const __bf16* __restrict__ bias, const __bf16* __restrict__ rowbias,
+                                                        const __bf16* __restrict__ res, __bf16* __restrict__ y) {
+    const long long idx = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (idx >= M * Cout) return;
+    const long long m = idx / Cout;
+    const int n = (int)(idx - m * Cout);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    for (int ks = 0; ks < ksplit; ++ks) {
+        const float4* p = reinterpret_cast<const float4*>(ws + (long long)ks * M * Cout + idx);
+        const float4 lo = p[0], hi = p[1];
+        v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
+    }
+    auto add8 = [&](const __bf16* src) {
+        const uint4 u = *reinterpret_cast<const uint4*>(src);
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[2 * e] += __builtin_bit_cast(float, w[e] << 16);
+            v[2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xffff0000u);
+        }
+    };
+    if (bias) add8(bias + n);
+    if (rowbias) add8(rowbias + (m / hw) * Cout + n);
+    if (res) add8(res + idx);
+    unsigned o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f32x2 pr = {v[2 * e], v[2 * e + 1]};
+        o[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2));
+    }
+    *reinterpret_cast<uint4*>(y + idx) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// grow-only fp32 scratch for the split-K partials.  Owned by the library, used in stream order: launches that need it on
+// DIFFERENT streams at the same time would share it (the nets of this repo run on one stream); first use allocates, so a
+// stream capture must be preceded by an eager run of the same shapes (torch's capture warm-up does that).
+static float* splitk_workspace(size_t floats) {
+    static float* buf = nullptr;
+    static size_t cap = 0;
+    if (floats > cap) {
+        if (buf) { (void)hipDeviceSynchronize(); (void)hipFree(buf); buf = nullptr; cap = 0; }
+        if (hipMalloc(&buf, floats * sizeof(float)) != hipSuccess) return nullptr;
+        cap = floats;
+    }
+    return buf;
+}
+
 template <int BMT, int BN, int NW, int WMW, int NSTAGE, int TAPS = 9, int EPI = 0>
 int launch_conv_dma(const ConvArgs& a_in, hipStream_t stream) {
     constexpr int LDS = NSTAGE * (BMT + BN) * 128;
@@ -675,7 +753,21 @@ int launch_conv_dma(const ConvArgs& a_in, hipStream_t stream) {
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     const int wg_per_cu = std::max(1, std::min((160 * 1024) / LDS, 2048 / (NW * 64)));
-    const long long total = n_mt * n_nt, per_xcd = (total + 7) / 8;
+    // split-K when the output tiles alone would leave most of the chip idle: enough K ranges to fill it, each at least 6
+    // K-steps long (DREAMMAT_CONV_SPLITK = 0 disables, = S forces S)
+    constexpr bool SPLIT_OK = EPI == 0 && BMT <= 256 && BN <= 128;
+    int ksplit = 1;
+    if (SPLIT_OK) {
+        const long long slots = (long long)n_cu * wg_per_cu, tiles = n_mt * n_nt;
+        const int n_steps = TAPS * (a.Cin / 64);
+        const char* env = getenv("DREAMMAT_CONV_SPLITK");
+        if (env && atoi(env) > 0) ksplit = std::min(atoi(env), n_steps);
+        else if (!env && tiles * 2 <= slots) ksplit = (int)std::max<long long>(1, std::min<long long>({slots / tiles, (long long)n_steps / 6, 16LL}));
+        if (ksplit > 1 && ((long long)ksplit * a.M * a.Cout * 4 > 0xffffff00LL || a.Cout % 8)) ksplit = 1;
+    }
+    float* ws = nullptr;
+    if (ksplit > 1 && !(ws = splitk_workspace((size_t)ksplit * a.M * a.Cout))) return DM_ERR_UNSUPPORTED;
+    const long long total = n_mt * n_nt * ksplit, per_xcd = (total + 7) / 8;
     long long wpx = std::min<long long>(per_xcd, (long long)n_cu * wg_per_cu / 8);
     long long blocks = 8 * std::max<long long>(wpx, 1);
     if (blocks > 0x7fffffffLL || total > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
@@ -700,8 +792,14 @@ int launch_conv_dma(const ConvArgs& a_in, hipStream_t stream) {
         a.timeline_steps = atoi(getenv("DREAMMAT_CONV_TIMELINE")) == 2;
     }
     hipLaunchKernelGGL((k_conv3x3_dma<BMT, BN, NW, WMW, NSTAGE, TAPS, EPI>), dim3((unsigned)blocks), dim3(NW * 64), LDS, stream, a,
-                       n_mt, n_nt, stagger);
+                       n_mt, n_nt, stagger, ksplit, ws);
     hipError_t e = hipGetLastError();
+    if (ksplit > 1 && e == hipSuccess) {
+        const long long n8 = a.M * a.Cout / 8;
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, stream, ws, ksplit, a.M, a.Cout,
+                           (long long)a.Hout * a.Wout, a.bias, a.rowbias, a.res, a.y);
+        e = hipGetLastError();
+    }
     if (a.timeline && e == hipSuccess) {
         // per-tile phases of workgroups 0 and 8 (s_memtime ticks): K loop | epilogue | gap to the next tile's first stamp
         static unsigned long long host[4096 * 64];

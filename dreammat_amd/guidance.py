@@ -64,6 +64,11 @@ class StableDiffusionLightGuidance(BaseObject):
         # seeded random UNet / VAE / ControlNet when no checkpoint is on disk: allowed only when asked for (bench, tests;
         # the 'tiny*' architectures have no checkpoints at all) -- a 30k-step run on random nets must not start silently
         synthetic: bool = False
+        # replay the ControlNet + UNet noise prediction (~1300 kernel launches per step, forward only, frozen weights, static
+        # shapes) as ONE captured hipGraph: the host then issues one launch per step for it instead of one per kernel, which
+        # is what keeps a rank busy once its share of the views is small (8 GPUs: 1 view = batch 3 per rank)
+        # "auto": only when the per-rank batch is small enough for the host to be the bottleneck (see _graph_ok)
+        hip_graph: Any = "auto"
 
     cfg: Config
 
@@ -178,17 +183,70 @@ class StableDiffusionLightGuidance(BaseObject):
                                                            self.cfg.view_dependent_prompting,
                                                            return_null_text_embeddings=True)
         with torch.no_grad():
-            ctx = PaddedContext(text_embeddings.to(self.weights_dtype))
-            latent_model_input = torch.cat([latents_noisy] * 3, dim=0)
-            t3 = torch.cat([t] * 3)
-            if self.use_controlnet and not all(s == 0 for s in condition_scales):
-                # the reference relies on a [3]+[1] broadcast here (B=1 only); the ControlNet tiles the
-                # conditioning EMBEDDING over the three branches (branch-major, like torch.cat([x]*3))
-                down, mid = self.multi_control_forward(latent_model_input, t3, ctx, image_cond, condition_scales)
-                noise_pred = self.forward_unet(latent_model_input, t3, ctx, down, mid)
+            if self._graph_ok(latents_noisy):
+                noise_pred = self._noise_pred_graphed(latents_noisy, t, text_embeddings, image_cond, condition_scales)
             else:
-                noise_pred = self.forward_unet(latent_model_input, t3, ctx)
+                noise_pred = self._noise_pred(latents_noisy, t, text_embeddings, image_cond, condition_scales)
         return noise_pred.chunk(3)
+
+    def _noise_pred(self, latents_noisy, t, text_embeddings, image_cond, condition_scales):
+        ctx = PaddedContext(text_embeddings.to(self.weights_dtype))
+        latent_model_input = torch.cat([latents_noisy] * 3, dim=0)
+        t3 = torch.cat([t] * 3)
+        if self.use_controlnet and not all(s == 0 for s in condition_scales):
+            # the reference relies on a [3]+[1] broadcast here (B=1 only); the ControlNet tiles the
+            # conditioning EMBEDDING over the three branches (branch-major, like torch.cat([x]*3))
+            down, mid = self.multi_control_forward(latent_model_input, t3, ctx, image_cond, condition_scales)
+            return self.forward_unet(latent_model_input, t3, ctx, down, mid)
+        return self.forward_unet(latent_model_input, t3, ctx)
+
+    # ---------------------------------------------------------------- hipGraph replay of the noise prediction
+    GRAPH_AUTO_MAX_VIEWS = 2
+    def _graph_ok(self, latents):
+        want = self.cfg.hip_graph
+        if want == "auto":
+            want = latents.shape[0] <= self.GRAPH_AUTO_MAX_VIEWS
+        nets_frozen = not any(p.requires_grad for p in self.unet.parameters())
+        return bool(want) and latents.is_cuda and nets_frozen and not torch.cuda.is_current_stream_capturing()
+
+    def _noise_pred_graphed(self, latents_noisy, t, text_embeddings, image_cond, condition_scales):
+        """Same arithmetic as `_noise_pred`, captured once per (shapes, conditioning scales) and replayed: inputs are copied
+        into the capture's static buffers (the 22-channel condition maps are converted to the nets' dtype by that copy),
+        the output is cloned out of the graph's pool."""
+        scales = tuple(float(s) for s in condition_scales)
+        key = (tuple(latents_noisy.shape), latents_noisy.dtype, tuple(text_embeddings.shape), scales,
+               tuple((tuple(c.shape), tuple(c.stride())) for c in image_cond))
+        g = self._graphs.get(key) if hasattr(self, "_graphs") else None
+        if g is None:
+            if not hasattr(self, "_graphs"):
+                self._graphs = {}
+            st = {"lat": torch.empty_like(latents_noisy), "t": torch.empty_like(t),
+                  "emb": torch.empty_like(text_embeddings, dtype=self.weights_dtype),
+                  "cond": [torch.empty_strided(c.shape, c.stride(), dtype=self.weights_dtype, device=c.device) for c in image_cond]}
+
+            def load():
+                st["lat"].copy_(latents_noisy); st["t"].copy_(t); st["emb"].copy_(text_embeddings)
+                for d, c in zip(st["cond"], image_cond):
+                    d.copy_(c)
+            load()
+            # eager warm-up on a side stream (first-use initialisation inside the library, allocator warm-up), then capture
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._noise_pred(st["lat"], st["t"], st["emb"], st["cond"], scales)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                st["out"] = self._noise_pred(st["lat"], st["t"], st["emb"], st["cond"], scales)
+            g = self._graphs[key] = (graph, st)
+            if len(self._graphs) > 4:       # annealed conditioning scales re-capture; keep the pool bounded
+                self._graphs.pop(next(iter(self._graphs)))
+        graph, st = g
+        st["lat"].copy_(latents_noisy); st["t"].copy_(t); st["emb"].copy_(text_embeddings)
+        for d, c in zip(st["cond"], image_cond):
+            d.copy_(c)
+        graph.replay()
+        return st["out"].clone()
 
     def compute_grad_sds(self, prompt_utils, condition_scales, latents, image_cond, elevation, azimuth,
                          camera_distances, rng=None):

@@ -393,6 +393,37 @@ def test_unet_controlnet_gpu_fp32_and_bf16_hip_attention(dev):
         assert rel < 6e-2, (arch_name, rel)
 
 
+def test_noise_prediction_hip_graph_replay_equals_eager(dev, tmp_path, monkeypatch):
+    """The ControlNet + UNet noise prediction replayed from one captured hipGraph (guidance `hip_graph`) must give the
+    eager result bit for bit, on fresh inputs of later steps too (inputs are copied into the capture's static buffers)."""
+    monkeypatch.chdir(tmp_path)
+    from dreammat_amd.guidance import StableDiffusionLightGuidance
+    from dreammat_amd.prompt import StableDiffusionPromptProcessor
+    cfg = {"pretrained_model_name_or_path": "tiny", "use_controlnet": True, "control_types": ["light"],
+           "condition_scales": [0.9], "width": 128, "height": 128, "cond_scale": 1.05, "uncond_scale": -0.75,
+           "null_scale": -0.25}
+    torch.manual_seed(0)
+    ge = StableDiffusionLightGuidance(dict(cfg, hip_graph=False))      # both: the same seeded synthetic weights, on the GPU
+    gg = StableDiffusionLightGuidance(dict(cfg, hip_graph=True))
+    assert next(ge.unet.parameters()).is_cuda and next(ge.unet.parameters()).dtype == torch.bfloat16
+    pp = StableDiffusionPromptProcessor({"prompt": "a wooden chair", "negative_prompt": "ugly",
+                                         "pretrained_model_name_or_path": "tiny"})
+    B = 2
+    elev, azim, dist = torch.tensor([10.0, 70.0], device=dev), torch.tensor([5.0, 170.0], device=dev), torch.tensor([3.5, 3.2], device=dev)
+    for step in range(3):                                   # step 0 captures, steps 1-2 replay with new inputs
+        g = torch.Generator().manual_seed(10 + step)
+        rgb = torch.rand(B, 128, 128, 3, generator=g).to(dev)
+        cond = torch.rand(B, 128, 128, 22, generator=g).to(dev)
+        rng = {"t": torch.tensor([400 - 100 * step, 77 + step], device=dev), "noise": torch.randn(B, 4, 16, 16, generator=g).to(dev),
+               "posterior_noise": torch.randn(B, 4, 16, 16, generator=g).to(dev)}
+        oe = ge(rgb, pp(), elev, azim, dist, condition_map=cond, rng=rng)
+        og = gg(rgb, pp(), elev, azim, dist, condition_map=cond, rng=rng)
+        for k in ("e_text", "e_uncond", "e_null", "grad"):
+            assert torch.equal(ge._last[k], gg._last[k]), (step, k, (ge._last[k] - gg._last[k]).abs().max().item())
+        assert float(oe["loss_sds"]) == float(og["loss_sds"])
+    assert len(gg._graphs) == 1 and not hasattr(ge, "_graphs")
+
+
 def test_full_sds_step_vs_oracle(dev, tmp_path, monkeypatch):
     """BASELINE config 1 shape (2-triangle quad, 1 view, constant env, fp32 nets): one complete optimizer
     step through the plugin API vs the oracle's step: loss, parameter gradients, Adam-updated parameters."""
@@ -839,6 +870,32 @@ def test_transformer_block_fused_gemms_vs_aten(dev):
     assert sum(k.startswith("gemm") for k in keys) >= 5 and any(k.startswith("gemm+geglu") for k in keys), keys
     err = (y - ref).abs().max().item()
     assert err < 3e-2 * ref.abs().max().item() + 3e-2, err
+
+
+@pytest.mark.parametrize("split,B,Cin,Cout,H,W", [(None, 3, 1280, 1280, 8, 8), ("7", 3, 640, 1280, 8, 8), ("3", 2, 128, 192, 16, 24),
+                                                  ("16", 3, 1280, 1280, 16, 16), ("0", 3, 1280, 1280, 8, 8)])
+def test_conv3x3_split_k_small_m(dev, monkeypatch, split, B, Cin, Cout, H, W):
+    """Small-M layers (1 view per rank: batch 3 at 8x8 / 16x16) split the K loop over workgroups; fp32 partials + reduce
+    kernel must reproduce bias + rowbias + residual exactly like the single-pass epilogue."""
+    if split is not None:
+        monkeypatch.setenv("DREAMMAT_CONV_SPLITK", split)
+    torch.manual_seed(11)
+    x = torch.randn(B, H, W, Cin).bfloat16()
+    w = (torch.randn(Cout, Cin, 3, 3) * 0.03).bfloat16()
+    bias, rowbias, res = torch.randn(Cout).bfloat16(), torch.randn(B, Cout).bfloat16(), torch.randn(B, H, W, Cout).bfloat16()
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    y = hipops.conv3x3_nhwc(x.to(dev), wt.to(dev), bias.to(dev), 1, (1, 1), None, rowbias.to(dev), res.to(dev)).float().cpu()
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias.float(), padding=1).permute(0, 2, 3, 1)
+    ref = ref + rowbias.float()[:, None, None, :] + res.float()
+    err = (y - ref).abs().max().item()
+    assert err < 1e-2 * ref.abs().max().item() + 1e-2, err
+    # the linear layers of the same resolution (1-tap instantiation)
+    xm = torch.randn(B * H * W // 16 * 16, Cin).bfloat16()
+    wm = (torch.randn(Cout, Cin) * 0.05).bfloat16()
+    rm = torch.randn(xm.shape[0], Cout).bfloat16()
+    ym = hipops.gemm_fused(xm.to(dev), wm.to(dev), bias.to(dev), rm.to(dev)).float().cpu()
+    refm = xm.float() @ wm.float().t() + bias.float() + rm.float()
+    assert (ym - refm).abs().max().item() < 1e-2 * refm.abs().max().item() + 1e-2
 
 
 def test_narrow_head_conv_zero_padded_to_mfma_tile(dev):
