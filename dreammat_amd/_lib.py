@@ -102,6 +102,8 @@ _SIGS = {
     "dm_groupnorm_workspace_floats": (c_size_t, [c_int, c_int]),
     "dm_groupnorm_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                       c_int, c_void_p]),
+    "dm_groupnorm_nhwc_infer": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                                        c_int, c_void_p]),
     "dm_groupnorm_nhwc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                       c_float, c_int, c_void_p]),
     "dm_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _LL, c_int, c_float, c_void_p]),

@@ -569,14 +569,18 @@ def conv3x3_s2_autograd(x_nhwc, w_fwd, w_dgrad, bias, lead_pad):
 
 
 # ------------------------------------------------------------------------------------------ group norm
-def _gn_fwd(x_nhwc, gamma, beta, eps, act):
+def _gn_fwd(x_nhwc, gamma, beta, eps, act, keep_for_backward=True):
+    """keep_for_backward=False: the 2-launch inference entry (coefficients formed inside the apply kernel, nothing saved)."""
     B, H, W, C = x_nhwc.shape
     y = torch.empty_like(x_nhwc)
     ws = torch.empty(int(_lib.lib().dm_groupnorm_workspace_floats(B, C)), device=x_nhwc.device, dtype=torch.float32)
+    infer = (not keep_for_backward and C % 8 == 0 and gamma.is_contiguous() and beta.is_contiguous()
+             and gamma.data_ptr() % 16 == 0 and beta.data_ptr() % 16 == 0)
+    fn, name = ((_lib.lib().dm_groupnorm_nhwc_infer, "dm_groupnorm_nhwc_infer") if infer
+                else (_lib.lib().dm_groupnorm_nhwc_fwd, "dm_groupnorm_nhwc_fwd"))
     with _Timed(f"groupnorm_fwd[C={C},HW={H * W}]", 6.0 * B * H * W * C):
-        check(_lib.lib().dm_groupnorm_nhwc_fwd(x_nhwc.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
-                                               ws.data_ptr(), B, H * W, C, float(eps), int(act), _stream()),
-              "dm_groupnorm_nhwc_fwd")
+        check(fn(x_nhwc.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), ws.data_ptr(), B, H * W, C, float(eps),
+                 int(act), _stream()), name)
     return y, ws
 
 
@@ -606,7 +610,7 @@ def groupnorm_nhwc(x_nhwc, gamma, beta, eps, act):
     assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous() and gamma.dtype == torch.bfloat16
     if torch.is_grad_enabled() and x_nhwc.requires_grad:
         return _GroupNormAct.apply(x_nhwc, gamma, beta, eps, act)
-    return _gn_fwd(x_nhwc, gamma, beta, eps, act)[0]
+    return _gn_fwd(x_nhwc, gamma, beta, eps, act, keep_for_backward=False)[0]
 
 
 # ------------------------------------------------------------------------------------------ ray queries (row f-1)

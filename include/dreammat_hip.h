@@ -260,6 +260,10 @@ int dm_gemm_bf16_fused(const void* x, const void* w, const void* bias, const voi
                        int N, int geglu, dm_stream_t stream);
 
 /* ---- normalisation ----------------------------------------------------------------------- */
+/* Forward only (frozen nets under no_grad): the coefficient kernel folded into the apply kernel -- 2 launches instead of
+ * 3, same arithmetic; ws = scratch of dm_groupnorm_workspace_floats(B,C), nothing is kept in it. */
+int dm_groupnorm_nhwc_infer(const void* x, const void* gamma, const void* beta, void* y, float* ws, int B, int HW, int C,
+                            float eps, int act, dm_stream_t stream);
 /* GroupNorm(32) [+ SiLU] of the ResnetBlock2D / Transformer2DModel / conv_norm_out layers of the same nets,
  * NHWC bf16: x,y [B,HW,C], gamma/beta [C] bf16.  ws: dm_groupnorm_workspace_floats(B,C) fp32, kept by the caller
  * between fwd and bwd.  act: 0 = none, 1 = SiLU.  bwd returns dx only (weights are frozen on this path). */

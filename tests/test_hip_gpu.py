@@ -592,6 +592,9 @@ def test_groupnorm_silu_nhwc_vs_fp32_reference(dev, B, C, H, W, act):
     y = hipops.groupnorm_nhwc(xg, gamma.to(dev), beta.to(dev), 1e-5, act)
     got = y.permute(0, 3, 1, 2).float().cpu()
     assert (got - ref).abs().max() < 3e-2 * max(1.0, ref.abs().max().item())
+    with torch.no_grad():       # inference entry (coefficients formed inside the apply kernel): same arithmetic as the 3-kernel path
+        yi = hipops.groupnorm_nhwc(xg.detach(), gamma.to(dev), beta.to(dev), 1e-5, act)
+    assert (yi.float() - y.detach().float()).abs().max().item() <= 2 ** -6 * max(1.0, y.detach().float().abs().max().item())   # <= 1 bf16 ulp
     dy = torch.randn_like(ref).bfloat16()
     y.backward(dy.to(dev).permute(0, 2, 3, 1).contiguous())
     ref.backward(dy.float())
