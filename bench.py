@@ -85,17 +85,17 @@ def system_config(a, views_per_rank):
 def pmc_traffic(kernel_key, batch):
     """HBM traffic per launch of the kernel named by `kernel_key` ("... conv3x3[Cin->Cout@HxW,s1]" at batch `batch`, or
     "... attention_fwd_bf16[Sq=..,Skv=..,h=..,D=..]" at batch 3*`batch`) from the newest committed counter profile
-    (profiles/r*_pmc_conv_*.json), if exactly that shape was profiled."""
+    (profiles/r*_pmc_final.json, written by tools/pmc_r2.sh + tools/pmc_collect.py), if exactly that shape was profiled."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_conv_*.json")))
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_final.json")))
     if not files:
         return None
     m = re.search(r"conv3x3\[(\d+)->(\d+)@(\d+)x(\d+),s1\]", kernel_key)
     m2 = re.search(r"attention_fwd_bf16\[Sq=(\d+),Skv=(\d+),h=(\d+),D=(\d+)\]", kernel_key)
     if m:
         cin, cout, h, w = (int(g) for g in m.groups())
-        tag = f"{batch}_{h}_{w}_{cin}_{cout}"
+        tag = f"conv_{batch}_{h}_{w}_{cin}_{cout}"
         alg = 2.0 * (batch * h * w * (cin + cout) + 9 * cin * cout)
     elif m2:
         sq, skv, heads, d = (int(g) for g in m2.groups())
@@ -103,18 +103,29 @@ def pmc_traffic(kernel_key, batch):
         alg = 2.0 * 3 * batch * heads * d * (2 * sq + 2 * skv)
     else:
         return None
+
+    def first(name, counter):       # the profiled process runs one kernel: take the row that has the counter
+        for row in ctr.get(name, {}).values():
+            if counter in row:
+                return row[counter]
+        raise KeyError(name)
     try:
         ctr = json.load(open(files[-1]))["counters"]
-        fetch = next(iter(ctr["fetch_" + tag].values()))["FETCH_SIZE"]
-        write = next(iter(ctr["write_" + tag].values()))["WRITE_SIZE"]
-    except (KeyError, StopIteration, ValueError, OSError):
+        fetch, write = first("fetch_" + tag, "FETCH_SIZE"), first("write_" + tag, "WRITE_SIZE")
+    except (KeyError, ValueError, OSError):
         return None
     out = {"traffic": (2.0 * fetch + write) * 1024.0, "traffic_unit": "bytes/launch", "algorithmic_bytes": alg,
            "traffic_source": "profiles/" + os.path.basename(files[-1])}
-    hit = ctr.get("tcc_" + tag)
-    if hit:
-        c = next(iter(hit.values()))
-        out["l2_hit_rate"] = c["TCC_HIT_sum"] / max(1.0, c["TCC_REQ_sum"])
+    try:
+        out["l2_hit_rate"] = first("tcc_" + tag, "TCC_HIT_sum") / max(1.0, first("tcc_" + tag, "TCC_REQ_sum"))
+    except KeyError:
+        pass
+    try:    # clock the kernel actually ran at: GRBM_GUI_ACTIVE (summed over 8 XCDs) / kernel duration
+        st = json.load(open(files[-1]))["kernel_stats"].get(tag)
+        if st:
+            out["shader_clock_ghz_under_load"] = first("grbm_" + tag, "GRBM_GUI_ACTIVE") / 8.0 / (st[0]["avg_us"] * 1e3)
+    except (KeyError, ValueError, OSError):
+        pass
     return out
 
 
@@ -331,7 +342,7 @@ def main():
             if tr:
                 res[nm].update(tr)
         res["roofline_note"] = ("traffic: HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB from `rocprofv3 --pmc` on the "
-                                "same kernel and shape (conv, attention) through the C ABI driver tools/abi_pmc.cpp (tools/pmc_abi.sh; FETCH_SIZE "
+                                "same kernel and shape (conv, attention) through the C ABI driver tools/abi_pmc.cpp (tools/pmc_r2.sh; FETCH_SIZE "
                                 "doubled per MI355X_MICROARCH.md); not collected live because rocprofv3 --pmc segfaults "
                                 "under python+torch in this image (profiles/r01_pmc_attempt_segfault.log)")
         for nm, key in (("roofline_shade_fwd", "shade_fwd"), ("roofline_shade_bwd", "shade_bwd")):

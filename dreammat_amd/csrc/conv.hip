@@ -926,14 +926,16 @@ int dm_gemm_bf16_fused(const void* x, const void* w, const void* bias, const voi
     a.stride = 1; a.pad_y = 0; a.pad_x = 0;
     a.M = M;
     auto n_wg = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
-    const char* tile_env = getenv("DREAMMAT_GEMM_TILE");     // 128 | 256 | 512 forces a variant (tests / A-B measurements)
+    const char* tile_env = getenv("DREAMMAT_GEMM_TILE");     // 128 | 256 | 320 | 512 forces a variant (tests / A-B measurements)
     int tile = tile_env ? atoi(tile_env) : 0;
     if (!tile) {
         if (!(N >= 128 && M >= 2048)) tile = 128;
         else if (N % 256 == 0 && n_wg(256, 256) >= 200) tile = 512;
+        else if (!geglu && N == 320 && K <= 640 && n_wg(256, 320) >= 160) tile = 320;   // no ragged N tile, x read once (64 -> 59 us)
         else tile = 256;
     }
     if (geglu) {
+        if (tile == 320) tile = 256;
         switch (tile) {
         case 512: return launch_conv_dma<256, 256, 8, 2, 2, 1, 1>(a, stream);
         case 256: return launch_conv_dma<256, 128, 8, 4, 3, 1, 1>(a, stream);
@@ -942,6 +944,7 @@ int dm_gemm_bf16_fused(const void* x, const void* w, const void* bias, const voi
     }
     switch (tile) {
     case 512: return launch_conv_dma<256, 256, 8, 2, 2, 1, 0>(a, stream);
+    case 320: return launch_conv_dma<256, 320, 8, 4, 2, 1, 0>(a, stream);
     case 256: return launch_conv_dma<256, 128, 8, 4, 3, 1, 0>(a, stream);
     default:
         return (N % 128 == 0) ? launch_conv_dma<128, 128, 4, 2, 3, 1, 0>(a, stream)

@@ -805,6 +805,8 @@ def test_conv3x3_fused_epilogue(dev, monkeypatch, tile, B, Cin, Cout, H, W):
     ("128", 2048, 128, 256, False),
     ("256", 4096, 640, 640, True),
     ("512", 8192, 320, 512, True),
+    ("320", 4096, 320, 640, True),
+    ("320", 2064, 128, 320, False),
     (None, 32, 1280, 320, False),            # time_emb_proj-sized
 ])
 def test_gemm_fused_vs_fp32_reference(dev, monkeypatch, tile, M, K, N, res):

@@ -1,0 +1,24 @@
+"""Merge the per-pass counter summaries of tools/pmc_r2.sh (gpurun_out/pmc_r2/*.json) into ONE committed file:
+usage: pmc_collect.py gpurun_out/pmc_r2 profiles/r02_pmc_final.json
+-> {"counters": {pass_name: {kernel: {counter: mean per dispatch}}}, "kernel_stats": {name: [rows of *_kernel_stats.csv]}}"""
+import csv
+import glob
+import json
+import os
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+out = {"counters": {}, "kernel_stats": {}, "note": "rocprofv3 --pmc passes (own runs, --kernel-trace only) on tools/_abi_pmc; "
+       "FETCH_SIZE / WRITE_SIZE in KiB; GRBM_GUI_ACTIVE is summed over the 8 XCDs"}
+for f in sorted(glob.glob(os.path.join(src, "*.json"))):
+    try:
+        d = json.load(open(f))
+    except ValueError:
+        continue
+    out["counters"][os.path.basename(f)[:-5]] = {k: {c: v["mean"] for c, v in ctr.items()} for k, ctr in d.items()}
+for f in sorted(glob.glob(os.path.join(src, "stats_*.csv"))):
+    rows = list(csv.DictReader(open(f)))
+    out["kernel_stats"][os.path.basename(f)[6:-4]] = [
+        {"name": r["Name"][:120], "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3} for r in rows[:4]]
+json.dump(out, open(dst, "w"), indent=1)
+print(dst, len(out["counters"]), "passes")

@@ -26,8 +26,9 @@ rocprofv3 -L > $OUT/counters_available.txt 2>&1
 SECTIONS=${PMC_SECTIONS:-attn shade}
 if [[ " $SECTIONS " == *" conv "* ]]; then
   # the dominant conv shapes: 8 x 128->128 @512^2 (VAE, tile 640) and 24 x 320->320 @64^2 (UNet, tile 320)
-  for case in "vae128 640 8 512 512 128 128" "unet320 320 24 64 64 320 320" "unet640 256 24 32 32 640 640"; do
-    set -- $case; nm=$1; export DREAMMAT_CONV_TILE=$2; shift 2
+  for case in "640 8 512 512 128 128" "320 24 64 64 320 320" "512 24 64 64 512 512" "256 24 32 32 640 640"; do
+    set -- $case; export DREAMMAT_CONV_TILE=$1; shift 1
+    nm=$(echo "$@" | tr ' ' '_')              # conv_<B>_<H>_<W>_<Cin>_<Cout>: the tag bench.py's pmc_traffic() looks up
     run_stats conv_$nm conv "$@" 10
     run_pmc sq_conv_$nm "$SQ" conv "$@" 5
     run_pmc sq2_conv_$nm "$SQ2" conv "$@" 5
@@ -47,8 +48,8 @@ for v in ${ATTN_VARIANTS:-v3p v3l v3}; do
   run_pmc grbm_attn_$v "GRBM_GUI_ACTIVE GRBM_COUNT" attn 24 5 4096 4096 64 5 $v
 done
 v=${ATTN_MAIN:-v3}
-run_pmc fetch_attn_$v "FETCH_SIZE" attn 24 5 4096 4096 64 5 $v
-run_pmc write_attn_$v "WRITE_SIZE" attn 24 5 4096 4096 64 5 $v
+run_pmc fetch_attn_24_5_4096_4096_64 "FETCH_SIZE" attn 24 5 4096 4096 64 5 $v
+run_pmc write_attn_24_5_4096_4096_64 "WRITE_SIZE" attn 24 5 4096 4096 64 5 $v
 fi
 [[ " $SECTIONS " == *" shade "* ]] && for c in ${SHADE_CASES:-fp32 rgb18e8}; do
   f=${DM_SHADE_CASE_DIR:-/tmp}/shade_case_$c.bin
