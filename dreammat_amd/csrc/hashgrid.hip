@@ -265,12 +265,15 @@ __global__ __launch_bounds__(LH_THREADS) void k_hashgrid_bwd_lds(HashArgs a, int
 //                       16384 consecutive table entries); a workgroup ranks its tuples per bin with LDS counters and
 //                       reserves the bin space with ONE global atomic per (workgroup, bin) -- 128x fewer than per tuple;
 //   pass 2  k_hg_acc    one workgroup per (level, bin, split) sums its share of the bin's tuples into a 128 KB LDS table
-//                       (ds_add_f32) and writes the table to a partial slab;
+//                       and writes the table to a partial slab.  The table is 64-bit FIXED POINT (value * 2^44 / max|dL/denc|
+//                       of the level, found by pass 1): ds_add_u64 retires 8.6x the tuples per second of two ds_add_f32
+//                       (855 vs 99 G tuples/s, tools/lds_atomic_probe.cpp -- LDS float atomics are a slow path on this
+//                       chip), resolves 6e-14 of the level's largest gradient, and makes the sums order-independent;
 //   pass 3  k_hg_sum    dtable += sum over the splits' slabs (plain read-modify-write, no atomics).
 // A tuple that finds its bin full (capacity = 1.3 x the uniform share) falls back to the global atomic: time, not
-// correctness.  Bytes: 16 B per tuple written and read once = 0.59 GB per level.
-constexpr int HB_LOG2 = 14, HB_ENTRIES = 1 << HB_LOG2;     // table entries per bin: 2 x 16384 fp32 = 128 KB of LDS
-constexpr int HB_MAX_BINS = 64;                            // log2_hashmap_size <= 20
+// correctness.  Bytes: 8 B per tuple written and read once = 0.13 GB per level and pass at 1 M points.
+constexpr int HB_LOG2 = 13, HB_ENTRIES = 1 << HB_LOG2;     // table entries per bin: 2 x 8192 x 8 B fixed point = 128 KB of LDS
+constexpr int HB_MAX_BINS = 128;                           // log2_hashmap_size <= 20
 constexpr int HB_SPLITS = 4;
 constexpr int HB_ACC_THREADS = 1024;
 
@@ -278,19 +281,41 @@ struct BinArgs {
     HashArgs h;
     int levels[kMaxLevels];        // binned levels (indices into h.lv)
     int n_binned;
-    uint4* tuples;                 // [n_binned][bins][cap]
+    uint2* tuples;                 // [n_binned][bins][cap], 8 bytes each: entry-in-bin (14 bits) | v0 (25) | v1 (25)
     int bins;                      // bins of the largest binned level (row pitch of `tuples`)
     unsigned* counts;              // [n_binned][HB_MAX_BINS]   (zeroed by the launcher)
-    float* partial;                // [n_binned][HB_SPLITS][max_size * 2]
+    unsigned* gmax_bits;           // [n_binned] max |dL/denc| of the level as float bits (zeroed by the launcher)
+    long long* partial;            // [n_binned][HB_SPLITS][max_size * 2] fixed point
     long long cap;                 // tuples per bin
     long long max_size;            // largest level size among the binned levels
 };
 
+// 8-byte tuple: bits [0,14) entry within the bin, [14,39) v0, [39,64) v1, the values as fp32 with the low 7 mantissa bits
+// rounded away (sign, 8 exponent bits, 16 mantissa bits: relative error <= 2^-17 per contribution, far inside the 1e-3
+// gradient tolerance) -- half the bytes of the (index, fp32, fp32, pad) tuple of the first version, on both passes.
+__device__ __forceinline__ uint2 hb_pack(unsigned e, float v0, float v1) {
+    const unsigned long long a = (__float_as_uint(v0) + 0x40u) >> 7, b = (__float_as_uint(v1) + 0x40u) >> 7;   // round to nearest
+    const unsigned long long w = (unsigned long long)e | (a << HB_LOG2) | (b << (HB_LOG2 + 25));
+    return make_uint2((unsigned)w, (unsigned)(w >> 32));
+}
+// round-to-nearest double -> int64 for |d| < 2^51 with two plain fp64 / integer ops (no 64-bit convert instruction needed)
+__device__ __forceinline__ long long hb_fixed(double d) {
+    const double magic = 6755399441055744.0;               // 1.5 * 2^52
+    return __double_as_longlong(d + magic) - __double_as_longlong(magic);
+}
+__device__ __forceinline__ void hb_unpack(unsigned lo, unsigned hi, unsigned& e, float& v0, float& v1) {
+    const unsigned long long w = (unsigned long long)lo | ((unsigned long long)hi << 32);
+    e = (unsigned)w & (HB_ENTRIES - 1);
+    v0 = __uint_as_float((unsigned)((w >> HB_LOG2) & 0x1ffffffu) << 7);
+    v1 = __uint_as_float((unsigned)(w >> (HB_LOG2 + 25)) << 7);
+}
+
 __global__ __launch_bounds__(256) void k_hg_bin(BinArgs a) {
-    __shared__ unsigned lcnt[HB_MAX_BINS], lbase[HB_MAX_BINS];
+    __shared__ unsigned lcnt[HB_MAX_BINS], lbase[HB_MAX_BINS], lmax;
     const int tid = threadIdx.x;
     const int li = blockIdx.y, l = a.levels[li];
     if (tid < HB_MAX_BINS) lcnt[tid] = 0;
+    if (tid == HB_MAX_BINS) lmax = 0;
     __syncthreads();
     const long long M = a.h.m_dev ? (long long)*a.h.m_dev : a.h.m_max;
     const long long m = (long long)blockIdx.x * blockDim.x + tid;
@@ -299,6 +324,7 @@ __global__ __launch_bounds__(256) void k_hg_bin(BinArgs a) {
     const unsigned res = a.h.lv.res[l], size = a.h.lv.size[l], off = a.h.lv.offset[l];
     unsigned idx[8], rank[8];
     float v0[8], v1[8];
+    float gm = 0.f;
     if (valid) {
         float w[3];
         unsigned cell[3];
@@ -312,6 +338,7 @@ __global__ __launch_bounds__(256) void k_hg_bin(BinArgs a) {
         }
         const float g0 = a.h.dout[m * a.h.dout_rs + (2 * l) * a.h.dout_cs];
         const float g1 = a.h.dout[m * a.h.dout_rs + (2 * l + 1) * a.h.dout_cs];
+        gm = fmaxf(fabsf(g0), fabsf(g1));
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             unsigned cx = cell[0] + (c & 1), cy = cell[1] + ((c >> 1) & 1), cz = cell[2] + ((c >> 2) & 1);
@@ -323,11 +350,21 @@ __global__ __launch_bounds__(256) void k_hg_bin(BinArgs a) {
             rank[c] = atomicAdd(&lcnt[idx[c] >> HB_LOG2], 1u);
         }
     }
+    // the level's largest |gradient| (scale of pass 2's fixed point): wave max, one global atomicMax per wave; NaN / Inf
+    // gradients are not representable in fixed point and are left out of the max (their tuples then saturate to 0 / garbage,
+    // like any sum that contains them)
+    if (!(gm <= 3.0e38f)) gm = 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) gm = fmaxf(gm, __shfl_xor(gm, o));
+    if ((tid & 63) == 0) atomicMax(&lmax, __float_as_uint(gm));          // (non-negative floats order like their bits)
     __syncthreads();
     if (tid < HB_MAX_BINS) {
         const unsigned n = lcnt[tid];
         lbase[tid] = n ? atomicAdd(&a.counts[li * HB_MAX_BINS + tid], n) : 0u;
     }
+    // one same-address global atomic per WORKGROUP at most, and only while this workgroup's max still beats the published
+    // one (a plain read first): 15 k waves per level hammering one address cost 4 ms
+    if (tid == HB_MAX_BINS && lmax > __atomic_load_n(&a.gmax_bits[li], __ATOMIC_RELAXED)) atomicMax(&a.gmax_bits[li], lmax);
     __syncthreads();
     if (valid) {
 #pragma unroll
@@ -335,8 +372,7 @@ __global__ __launch_bounds__(256) void k_hg_bin(BinArgs a) {
             const unsigned bin = idx[c] >> HB_LOG2;
             const long long pos = (long long)lbase[bin] + rank[c];
             if (pos < a.cap) {
-                a.tuples[((long long)li * a.bins + bin) * a.cap + pos] =
-                    make_uint4(idx[c] & (HB_ENTRIES - 1), __float_as_uint(v0[c]), __float_as_uint(v1[c]), 0u);
+                a.tuples[((long long)li * a.bins + bin) * a.cap + pos] = hb_pack(idx[c] & (HB_ENTRIES - 1), v0[c], v1[c]);
             } else {                                       // bin full: the slow, always-correct route
                 float* dst = a.h.dtable + 2 * (size_t)(off + idx[c]);
                 atomicAdd(dst, v0[c]);
@@ -347,38 +383,46 @@ __global__ __launch_bounds__(256) void k_hg_bin(BinArgs a) {
 }
 
 __global__ __launch_bounds__(HB_ACC_THREADS) void k_hg_acc(BinArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float tab[];      // [HB_ENTRIES][2]
+    extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];      // [HB_ENTRIES][2] fixed point
     const int tid = threadIdx.x;
     const int li = blockIdx.y, l = a.levels[li];
     const int bin = blockIdx.x / HB_SPLITS, split = blockIdx.x - bin * HB_SPLITS;
     const unsigned size = a.h.lv.size[l];
     if ((long long)bin * HB_ENTRIES >= (long long)size) return;      // this level has fewer bins
-    for (int i = tid; i < HB_ENTRIES / 2; i += HB_ACC_THREADS) reinterpret_cast<float4*>(tab)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < HB_ENTRIES; i += HB_ACC_THREADS) reinterpret_cast<uint4*>(tab)[i] = make_uint4(0u, 0u, 0u, 0u);
+    const float gmax = __uint_as_float(a.gmax_bits[li]);
+    const double S = gmax > 0.f ? 17592186044416.0 / (double)gmax : 0.0;       // 2^44 / max: |q| <= 2^44, 2^19 terms of headroom
     __syncthreads();
     const long long n = min((long long)a.counts[li * HB_MAX_BINS + bin], a.cap);
     const long long lo = n * split / HB_SPLITS, hi = n * (split + 1) / HB_SPLITS;
-    const uint4* src = a.tuples + ((long long)li * a.bins + bin) * a.cap;
-    // eight independent 16-byte loads in flight per thread (one per iteration left the loop latency-bound: 2.6 ms for
-    // 3.2 GB); entries past the end become index 0 / value 0, which adds nothing
-    constexpr int U = 8;
+    const uint2* src = a.tuples + ((long long)li * a.bins + bin) * a.cap;
+    // eight independent 16-byte loads in flight per thread.  They are BUFFER loads whose descriptor ends at this split's
+    // last tuple: lanes past the end read zeros (index 0, value 0: adds nothing) without a branch -- a conditional
+    // `i < hi ? src[i] : 0` compiles to a branch and an s_waitcnt vmcnt(0) per load (the waitcnt pass assumes the load-free
+    // path), i.e. eight SERIALIZED HBM round trips per trip: 2.6 ms for 1.4 GB.
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, (int)(unsigned)(hi * 8), 0x00020000);
+    constexpr int U = 16;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     for (long long i0 = lo; i0 < hi; i0 += (long long)U * HB_ACC_THREADS) {
-        uint4 t[U];
+        u32x2 t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            t[u] = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(unsigned)((i0 + (long long)u * HB_ACC_THREADS + tid) * 8), 0, 0);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long long i = i0 + (long long)u * HB_ACC_THREADS + tid;
-            t[u] = i < hi ? src[i] : make_uint4(0u, 0u, 0u, 0u);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            atomicAdd(&tab[2 * t[u].x], __uint_as_float(t[u].y));
-            atomicAdd(&tab[2 * t[u].x + 1], __uint_as_float(t[u].z));
+            unsigned e;
+            float v0, v1;
+            hb_unpack(t[u][0], t[u][1], e, v0, v1);         // an all-zero (out-of-range) tuple adds 0 to entry 0
+            atomicAdd(&tab[2 * e], (unsigned long long)hb_fixed((double)v0 * S));
+            atomicAdd(&tab[2 * e + 1], (unsigned long long)hb_fixed((double)v1 * S));
         }
     }
+#endif
     __syncthreads();
     const int n_ent = (int)min((long long)HB_ENTRIES, (long long)size - (long long)bin * HB_ENTRIES);
-    float* dst = a.partial + ((long long)li * HB_SPLITS + split) * a.max_size * 2 + (long long)bin * HB_ENTRIES * 2;
-    for (int i = tid; i < n_ent / 2; i += HB_ACC_THREADS) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<float4*>(tab)[i];
-    if ((n_ent & 1) && tid == 0) { dst[2 * (n_ent - 1)] = tab[2 * (n_ent - 1)]; dst[2 * (n_ent - 1) + 1] = tab[2 * (n_ent - 1) + 1]; }
+    long long* dst = a.partial + ((long long)li * HB_SPLITS + split) * a.max_size * 2 + (long long)bin * HB_ENTRIES * 2;
+    for (int i = tid; i < n_ent; i += HB_ACC_THREADS) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<uint4*>(tab)[i];
 }
 
 __global__ __launch_bounds__(256) void k_hg_sum(BinArgs a) {
@@ -386,12 +430,14 @@ __global__ __launch_bounds__(256) void k_hg_sum(BinArgs a) {
     const unsigned size = a.h.lv.size[l], off = a.h.lv.offset[l];
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= size) return;
-    float2 acc = make_float2(0.f, 0.f);
+    long long q0 = 0, q1 = 0;
 #pragma unroll
     for (int s = 0; s < HB_SPLITS; ++s) {
-        const float2 p = reinterpret_cast<const float2*>(a.partial + ((long long)li * HB_SPLITS + s) * a.max_size * 2)[e];
-        acc.x += p.x; acc.y += p.y;
+        const longlong2 p = reinterpret_cast<const longlong2*>(a.partial + ((long long)li * HB_SPLITS + s) * a.max_size * 2)[e];
+        q0 += p.x; q1 += p.y;
     }
+    const double inv = (double)__uint_as_float(a.gmax_bits[li]) / 17592186044416.0;
+    const float2 acc = make_float2((float)((double)q0 * inv), (float)((double)q1 * inv));
     float2* dst = reinterpret_cast<float2*>(a.h.dtable) + off + e;
     float2 cur = *dst;
     cur.x += acc.x; cur.y += acc.y;
@@ -476,7 +522,7 @@ size_t dm_hashgrid_bwd_workspace_bytes(long long m_max, int n_levels, const uint
         }
     if (!n_binned) return 0;
     const long long bins = (max_size + HB_ENTRIES - 1) / HB_ENTRIES;
-    return (size_t)(n_binned * bins * cap * 16 + n_binned * HB_MAX_BINS * 4 + 256 + n_binned * HB_SPLITS * max_size * 8 + 256);
+    return (size_t)(n_binned * bins * cap * 8 + n_binned * (HB_MAX_BINS + 1) * 4 + 256 + n_binned * HB_SPLITS * max_size * 16 + 256);
 }
 
 // dm_hashgrid_bwd with the hashed levels routed through bins (see k_hg_bin); the dense levels run the kernels of
@@ -516,23 +562,25 @@ int dm_hashgrid_bwd_binned(const float* x, long long x_rs, long long x_cs, const
     if (b.n_binned > 0) {
         char* ws = (char*)workspace;
         b.bins = (int)((max_size + HB_ENTRIES - 1) / HB_ENTRIES);
-        b.tuples = (uint4*)ws;
-        ws += (size_t)b.n_binned * b.bins * cap * 16;
+        b.tuples = (uint2*)ws;
+        ws += (size_t)b.n_binned * b.bins * cap * 8;
         b.counts = (unsigned*)ws;
-        ws += ((size_t)b.n_binned * HB_MAX_BINS * 4 + 255) / 256 * 256;
-        b.partial = (float*)ws;
+        b.gmax_bits = b.counts + (size_t)b.n_binned * HB_MAX_BINS;
+        ws += ((size_t)b.n_binned * (HB_MAX_BINS + 1) * 4 + 255) / 256 * 256;
+        b.partial = (long long*)ws;
         b.cap = cap; b.max_size = max_size;
-        hipError_t e = hipMemsetAsync(b.counts, 0, (size_t)b.n_binned * HB_MAX_BINS * 4, stream);
+        if (cap * 8 > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;       // k_hg_acc addresses a bin with 32-bit byte offsets
+        hipError_t e = hipMemsetAsync(b.counts, 0, (size_t)b.n_binned * (HB_MAX_BINS + 1) * 4, stream);
         if (e != hipSuccess) return (int)e;
         static bool attr_set = false;
         if (!attr_set) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hg_acc), hipFuncAttributeMaxDynamicSharedMemorySize, HB_ENTRIES * 8);
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_hg_acc), hipFuncAttributeMaxDynamicSharedMemorySize, HB_ENTRIES * 16);
             if (e != hipSuccess) return (int)e;
             attr_set = true;
         }
         const int max_bins = (int)((max_size + HB_ENTRIES - 1) / HB_ENTRIES);
         hipLaunchKernelGGL(k_hg_bin, dim3(dm_div_up(m_max, 256), b.n_binned), dim3(256), 0, stream, b);
-        hipLaunchKernelGGL(k_hg_acc, dim3(max_bins * HB_SPLITS, b.n_binned), dim3(HB_ACC_THREADS), HB_ENTRIES * 8, stream, b);
+        hipLaunchKernelGGL(k_hg_acc, dim3(max_bins * HB_SPLITS, b.n_binned), dim3(HB_ACC_THREADS), HB_ENTRIES * 16, stream, b);
         hipLaunchKernelGGL(k_hg_sum, dim3(dm_div_up(max_size, 256), b.n_binned), dim3(256), 0, stream, b);
     }
     DM_LAUNCH_CHECK();
