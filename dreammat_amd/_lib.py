@@ -98,6 +98,7 @@ _SIGS = {
                               + [_LL] * 12 + [c_float, c_void_p]),
     "dm_conv3x3_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "dm_conv3x3_nhwc_bf16_fused": (c_int, [c_void_p] * 6 + [c_int] * 10 + [c_void_p]),
+    "dm_conv3x3_small_nhwc_bf16": (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p]),
     "dm_gemm_bf16_fused": (c_int, [c_void_p] * 5 + [_LL, c_int, c_int, c_int, c_void_p]),
     "dm_groupnorm_workspace_floats": (c_size_t, [c_int, c_int]),
     "dm_groupnorm_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,

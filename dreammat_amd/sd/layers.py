@@ -38,11 +38,12 @@ class Conv2d(nn.Conv2d):
         if getattr(self, "_prep_key", None) != key:
             Cout, Cin = w.shape[0], w.shape[1]
             wd, bd = w.detach(), (self.bias.detach() if self.bias is not None else None)
-            if Cout < 64:
-                # narrow heads (UNet conv_out 320->4, VAE conv_out 512->8): zero-pad Cout to one 64-wide MFMA tile
-                # instead of an im2col + GEMM lowering; callers slice the first Cout channels back out
-                wd = torch.cat([wd, wd.new_zeros(64 - Cout, Cin, 3, 3)], dim=0)
-                bd = torch.cat([bd, bd.new_zeros(64 - Cout)]) if bd is not None else None
+            if Cout % 64:
+                # narrow heads (UNet conv_out 320->4, VAE conv_out 512->8) and the 96-wide stem layers: zero-pad Cout to
+                # whole 64-wide MFMA tiles instead of an im2col + GEMM lowering; callers slice the first Cout channels back out
+                padc = -Cout % 64
+                wd = torch.cat([wd, wd.new_zeros(padc, Cin, 3, 3)], dim=0)
+                bd = torch.cat([bd, bd.new_zeros(padc)]) if bd is not None else None
             Cp = wd.shape[0]
             self._w_fwd = wd.permute(0, 2, 3, 1).reshape(Cp, 9 * Cin).contiguous()
             self._w_dgrad = wd.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9 * Cp).contiguous()
@@ -104,6 +105,26 @@ class Conv2d(nn.Conv2d):
             y = hipops.conv3x3_nhwc(xn, w_fwd, self._bias_p, 1, (1, 1), None, None, rn)
         return y.permute(0, 3, 1, 2)
 
+    def small_ok(self, x):
+        """few-channel stem layers on the direct kernel (forward only, frozen nets)."""
+        Cout, Cin, kh, kw = self.weight.shape
+        return (CONV_BACKEND == "mfma" and x.is_cuda and x.dtype == torch.bfloat16 and kh == 3 and kw == 3
+                and Cin in hipops.SMALL_CONV_CIN and Cout % 16 == 0 and self.stride[0] == self.stride[1]
+                and self.padding[0] == self.padding[1] and self._frozen() and not (torch.is_grad_enabled() and x.requires_grad))
+
+    def forward_small(self, x, act):
+        """act(conv(x) + bias) with act = 0 none / 1 SiLU fused before the rounding (ControlNetConditioningEmbedding)."""
+        w_fwd, _ = self._prepared()
+        Cout = self.weight.shape[0]
+        xn = x.permute(0, 2, 3, 1).contiguous()
+        y = hipops.conv3x3_small_nhwc(xn, w_fwd[:Cout], self._bias_p[:Cout] if self._bias_p is not None else None,
+                                      self.stride[0], tuple(self.padding), act)
+        return y.permute(0, 3, 1, 2)
+
+    def forward_silu(self, x):
+        """F.silu(self(x)); one kernel on the few-channel stem layers."""
+        return self.forward_small(x, 1) if self.small_ok(x) else F.silu(self(x))
+
     def forward_strided_asym(self, x):
         """stride-2 conv over F.pad(x, (0,1,0,1)) (AutoencoderKL downsampler) without materialising the pad."""
         w_fwd, w_dgrad = self._prepared()
@@ -120,7 +141,11 @@ class Conv2d(nn.Conv2d):
             return super().forward(x)
         Cout, Cin, kh, kw = self.weight.shape
         needs_grad = torch.is_grad_enabled() and x.requires_grad
-        narrow = Cout < 64 and Cin % 64 == 0                              # zero-padded to 64 outputs (_prepared)
+        if self.small_ok(x):
+            return self.forward_small(x, 0)
+        # zero-padded to whole 64-wide tiles (_prepared): always for the LDS-DMA kernel's shapes, and for the register-staged
+        # kernel (Cin % 64 != 0) when nothing needs a gradient
+        narrow = Cout % 64 != 0 and (Cin % 64 == 0 or (Cin % 32 == 0 and not needs_grad))
         ok = (CONV_BACKEND == "mfma" and x.dtype == torch.bfloat16 and kh == 3 and kw == 3 and Cin % 32 == 0
               and (Cout % 64 == 0 or narrow) and self.stride[0] == self.stride[1] and self._frozen()
               and (not needs_grad or (self.stride[0] == 1 and self.padding == (1, 1) and Cin % 64 == 0)))

@@ -186,9 +186,9 @@ class ControlNetConditioningEmbedding(nn.Module):
         self.conv_out = Conv2d(chans[-1], out_ch, 3, padding=1)
 
     def forward(self, c):
-        x = F.silu(self.conv_in(c))
+        x = self.conv_in.forward_silu(c)
         for b in self.blocks:
-            x = F.silu(b(x))
+            x = b.forward_silu(x)
         return self.conv_out(x)
 
 

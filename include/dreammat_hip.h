@@ -249,6 +249,13 @@ int dm_conv3x3_nhwc_bf16_fused(const void* x, const void* w, const void* bias, c
                                void* y, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int stride,
                                int pad_y, int pad_x, dm_stream_t stream);
 
+/* The few-channel stem convolutions of the same nets (ControlNetConditioningEmbedding 22->16, 16->16, 16->32 s2, 32->32,
+ * 32->96 s2; conv_in 4->320): direct form, one thread per output pixel x 16 output channels, no im2col.  Same tensor
+ * layouts as dm_conv3x3_nhwc_bf16; Cin in {4, 8, 16, 22, 32}, Cout % 16 == 0; act = 1 applies the SiLU that follows these
+ * layers in ControlNetConditioningEmbedding.forward before the rounding to bf16. */
+int dm_conv3x3_small_nhwc_bf16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin,
+                               int Hout, int Wout, int Cout, int stride, int pad_y, int pad_x, int act, dm_stream_t stream);
+
 /* Linear / 1x1-convolution layers of the same nets (diffusers Attention.to_q/to_k/to_out, FeedForward, Transformer2DModel
  * proj_in/proj_out, ResnetBlock2D.conv_shortcut: the F.linear / 1x1 F.conv2d calls under
  * models/guidance/dreammat_guidance.py:205-292) on the 1-tap instantiation of the same kernel:

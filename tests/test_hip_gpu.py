@@ -903,6 +903,46 @@ def test_conv3x3_split_k_small_m(dev, monkeypatch, split, B, Cin, Cout, H, W):
     assert (ym - refm).abs().max().item() < 1e-2 * refm.abs().max().item() + 1e-2
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,stride,act", [(2, 22, 16, 40, 24, 1, 1), (1, 16, 16, 33, 17, 1, 1), (2, 16, 32, 32, 32, 2, 1),
+                                                         (1, 32, 96, 24, 24, 2, 1), (3, 4, 320, 16, 16, 1, 0), (1, 32, 32, 9, 13, 1, 0),
+                                                         (1, 8, 48, 12, 12, 1, 1)])
+def test_conv3x3_small_channel_direct_kernel(dev, B, Cin, Cout, H, W, stride, act):
+    """the few-channel stem convs (ControlNet conditioning embedding, conv_in) on the direct kernel, with the fused SiLU."""
+    torch.manual_seed(4)
+    x = torch.randn(B, H, W, Cin).bfloat16()
+    w = (torch.randn(Cout, Cin, 3, 3) * 0.2).bfloat16()
+    bias = torch.randn(Cout).bfloat16()
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    y = hipops.conv3x3_small_nhwc(x.to(dev), wt.to(dev), bias.to(dev), stride, (1, 1), act).float().cpu()
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias.float(), stride=stride, padding=1)
+    if act:
+        ref = torch.nn.functional.silu(ref)
+    ref = ref.permute(0, 2, 3, 1)
+    assert y.shape == ref.shape
+    assert (y - ref).abs().max().item() < 1e-2 * ref.abs().max().item() + 1e-2
+
+
+def test_controlnet_cond_embedding_stem_kernels_vs_aten(dev):
+    """ControlNetConditioningEmbedding (22 -> 16 -> 32 -> 96 -> 256 -> 320, SiLU between) on the direct stem kernel + the
+    Cout-padded MFMA kernel vs the ATen fp32 evaluation; no im2col launch may remain."""
+    from dreammat_amd.sd import models
+    torch.manual_seed(8)
+    emb = models.ControlNetConditioningEmbedding(320, 22, (16, 32, 96, 256)).to(dev)
+    for p_ in emb.parameters():
+        p_.requires_grad_(False)
+    c = torch.rand(2, 22, 64, 64)
+    with torch.no_grad():
+        ref = emb.float()(c.to(dev)).float().cpu()
+        e16 = emb.to(torch.bfloat16)
+        hipops.enable_kernel_timing(True)
+        y = e16(c.to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)).float().cpu()
+        torch.cuda.synchronize()
+        keys = list(hipops.kernel_times())
+        hipops.enable_kernel_timing(False)
+    assert sum(k.startswith("conv3x3_small") for k in keys) == 5 and sum(k.startswith("conv3x3[") for k in keys) == 3, keys
+    assert (y - ref).abs().max().item() < 3e-2 * ref.abs().max().item() + 3e-2
+
+
 def test_narrow_head_conv_zero_padded_to_mfma_tile(dev):
     """UNet conv_out (320->4) / VAE conv_out (512->8): Cout zero-padded to 64 for the MFMA kernel, forward + dgrad."""
     from dreammat_amd.sd import layers
