@@ -305,6 +305,7 @@ def main():
                           "fg_lut": "reference bsdf_256_256.bin" if system.material.real_fg_lut else "analytic stand-in (file absent)",
                           "atlas_texel": system.material.atlas.texel,
                           "noise_pred_hip_graph": bool(getattr(system.guidance, "_graphs", None)),
+                          "process_group": (dist.get_backend() if use_dist else None),
                           "parallelism": f"dp{world} (views sharded, 1 all-reduce of {system.flat.numel * 4 / 1e6:.1f} MB fp32 grads)",
                           "final_loss": float(loss)}}
         # ---- rooflines from HIP events around the launches: `roofline` (conv) live in the timed region, the others on the
