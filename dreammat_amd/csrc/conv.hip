@@ -615,25 +615,37 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
                     }
             }
         } else {
-        u32x2 pre[2][8];                               // [parity of f = j*MT + i][rowbias g 0..3 | residual g 0..3]
+        u32x2 pre[2][8];                               // [parity of the fragment counter][rowbias g 0..3 | residual g 0..3]
 #pragma unroll
         for (int g = 0; g < 8; ++g) pre[0][g] = pre[1][g] = u32x2{0u, 0u};
-        frag_load(0, 0, pre[0]);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int nbase = n0 + TN * wn + 32 * j;   // first channel of this fragment (wave-uniform)
-            // bias of this lane's 16 channels of the fragment (register 4g+e = channel nbase + 8g + 4hi + e), once per j
-            u32x2 bp[4];
+        // Fragment order.  PIXEL-MAJOR when a wave has at most two channel fragments: the stores that together fill one
+        // 128-byte line of a pixel row (64 channels = 2 fragments x 2 group pairs) are then issued back to back instead of MT
+        // fragments apart, so the write path sees whole lines (WRITE_SIZE was 1.33x the tensor on 8 x 128->128 @512^2:
+        // lines written back partially and again).  Channel-major (bias registers per j) for the 5-fragment wave tile.
+        constexpr bool PIX_MAJOR = NT <= 2;
+        constexpr int NBP = PIX_MAJOR ? NT : 1;
+        u32x2 bp[NBP][4];                              // bias of this lane's 16 channels of fragment j (register 4g+e = channel nbase + 8g + 4hi + e)
+        auto load_bias = [&](int j, u32x2 (&bq)[4]) __attribute__((always_inline)) {
+            const int nbase = n0 + TN * wn + 32 * j;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = nbase + 8 * g + 4 * hi;
-                bp[g] = __builtin_amdgcn_raw_buffer_load_b64(brs, (int)(n < a.Cout ? (unsigned)n * 2u : OOB), 0, 0);
+                bq[g] = __builtin_amdgcn_raw_buffer_load_b64(brs, (int)(n < a.Cout ? (unsigned)n * 2u : OOB), 0, 0);
             }
+        };
+        if (PIX_MAJOR) {
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                constexpr int kLast = MT * NT - 1;
-                const int f = j * MT + i;
-                if (f < kLast) frag_load((f + 1) % MT, (f + 1) / MT, pre[(f + 1) & 1]);
+            for (int j = 0; j < NT; ++j) load_bias(j, bp[j % NBP]);
+        }
+        frag_load(0, 0, pre[0]);
+#pragma unroll
+        for (int f = 0; f < MT * NT; ++f) {
+            constexpr int kLast = MT * NT - 1;
+            const int i = PIX_MAJOR ? f / NT : f % MT, j = PIX_MAJOR ? f % NT : f / MT;
+            const int nbase = n0 + TN * wn + 32 * j;   // first channel of this fragment (wave-uniform)
+            if (!PIX_MAJOR && i == 0) load_bias(j, bp[0]);
+            if (f < kLast) frag_load(PIX_MAJOR ? (f + 1) / NT : (f + 1) % MT, PIX_MAJOR ? (f + 1) % NT : (f + 1) / MT, pre[(f + 1) & 1]);
+            {
 #pragma unroll
                 for (int gp = 0; gp < 2; ++gp) {       // group pairs (0,1) and (2,3)
                     unsigned w[2][2];                  // [group of the pair][dword] = 4 bf16 per group
@@ -643,7 +655,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
                         float v[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-                        unpack_add(v, bp[g]);
+                        unpack_add(v, bp[PIX_MAJOR ? j : 0][g]);
                         unpack_add(v, pre[f & 1][g]);
                         unpack_add(v, pre[f & 1][4 + g]);
                         f32x2 lo = {v[0], v[1]}, hi2 = {v[2], v[3]};
