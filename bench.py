@@ -129,6 +129,25 @@ def pmc_traffic(kernel_key, batch):
     return out
 
 
+def shade_traffic(key, texel):
+    """HBM bytes per launch of k_shade_fwd / k_shade_bwd from the committed counter pass on the bench scene's REAL G-buffer
+    (tools/r2_probe.py dumps it, tools/_abi_pmc `shadef` replays it under rocprofv3 --pmc; 1.15 M covered pixels)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_final.json")))
+    if not files:
+        return None
+    try:
+        ctr = json.load(open(files[-1]))["counters"]
+        case = texel if ("fetch_shade_" + texel) in ctr else "fp32"
+        kern = "k_" + key
+        fetch = next(v["FETCH_SIZE"] for k, v in ctr["fetch_shade_" + case].items() if kern in k)
+        write = next(v["WRITE_SIZE"] for k, v in ctr["write_shade_" + case].items() if kern in k)
+    except (KeyError, StopIteration, ValueError, OSError):
+        return None
+    return {"traffic": (2.0 * fetch + write) * 1024.0, "traffic_unit": "bytes/launch at 1.15 M covered pixels (counter pass, atlas " + case + ")",
+            "traffic_source": "profiles/" + os.path.basename(files[-1])}
+
+
 def effective_cores():
     """CPU cores this process may actually use (affinity mask and cgroup quota), capped at 64: os.cpu_count()
     reports the host's cores even inside a small container and oversubscribing torch's thread pool by 10x
@@ -203,7 +222,8 @@ def cpu_baseline(a, system, max_threads=None):
     scale = (a.res / H) ** 2
     step_s = scale * (a.views * (t_render + t_vae) + 3 * a.views * t_nets)
     return {"value": 1.0 / step_s, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle fp32 on host at {H}^2 (x{scale:.0f} to {a.res}^2): 1 view render fwd+bwd {t_render:.2f}s, "
+            "extrapolated": True,      # a bounded sample (1 view, 1 branch item, half resolution) scaled to the full step
+            "sample": f"EXTRAPOLATED from oracle fp32 on host at {H}^2 (x{scale:.0f} to {a.res}^2): 1 view render fwd+bwd {t_render:.2f}s, "
                       f"1 VAE-enc fwd+bwd {t_vae:.2f}s, 1 branch-item ControlNet+UNet fwd {t_nets:.2f}s; "
                       f"step = {scale:.0f} x ({a.views} x (render+vae) + {3 * a.views} x nets)",
             "host_cpus": os.cpu_count()}
@@ -353,6 +373,7 @@ def main():
                 res[nm] = {"kernel": "k_" + key, "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
                            "frac": gbs / 8000.0, "traffic": None, "avg_us": r["avg_ms"] * 1e3,
                            "covered_pixels": r["work_per_launch"] / (56.0 if key == "shade_fwd" else 76.0)}
+                res[nm].update(shade_traffic(key, system.material.atlas.texel) or {})
         if world == 1 and not a.no_cpu_baseline:
             import signal
 
