@@ -19,14 +19,13 @@ import torch.nn.functional as F
 from .. import hipops
 
 
-# Convolution backends on the GPU (bf16):
-#   "mfma"   (default) 3x3 convs run in the hand-written implicit-GEMM MFMA kernel (csrc/conv.hip) on NHWC
-#            activations; 1x1 convs are plain GEMMs on the NHWC view; the few shapes the kernel does not
-#            cover (Cin % 32 != 0: conv_in / conditioning stem; strided convs that need a gradient) use "gemm".
-#   "gemm"   im2col (torch's unfold) + one batched hipBLASLt GEMM: no JIT, 9x activation traffic.
-#   "miopen" torch's default.  MIOpen ships no gfx950 kernel database in this ROCm image, so every new
-#            conv shape JIT-compiles on first use: ~25 minutes of cold start on a fresh box.
-CONV_BACKEND = os.environ.get("DREAMMAT_CONV", "mfma")
+# The product runs ONE lowering on the GPU: "mfma" -- 3x3 convs in the hand-written implicit-GEMM MFMA kernels (csrc/conv.hip,
+# csrc/conv_small.hip) on NHWC activations, Linear / 1x1 layers on the 1-tap instantiation of the same kernel.  There is no
+# environment switch.  Tests and tools/*_probe.py may assign `layers.CONV_BACKEND = "gemm"` (im2col + hipBLASLt, ATen
+# elementwise: the A/B baseline and the fp32 evaluation the bf16 kernels are compared with) for the duration of a measurement;
+# "miopen" = torch's default conv, unusable in this image (no gfx950 kernel database: every shape JIT-compiles, ~25 min).
+# Tensors that are not on the GPU (the CPU test tier: fp32 plumbing of the same modules) take the ATen path.
+CONV_BACKEND = "mfma"
 
 
 class Conv2d(nn.Conv2d):
