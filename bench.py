@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--env-res", type=int, default=128)
     ap.add_argument("--graph", choices=["on", "off", "auto"], default="auto",
                     help="hipGraph replay of the ControlNet+UNet noise prediction (guidance hip_graph)")
+    ap.add_argument("--resident", choices=["auto", "on", "off"], default="auto",
+                    help="condition maps / cameras of all (view, env) pairs resident in HBM (data.py); off = per-step H2D")
     ap.add_argument("--dump-kernels", default=None, help="write the per-kernel HIP-event table of the timed region (JSON) here")
     return ap.parse_args()
 
@@ -260,7 +262,8 @@ def main():
     dm = RandomCameraDataModule(cfg={"height": a.res, "width": a.res, "batch_size": vpr, "use_fix_views": True,
                                      "camera_distance_range": [3.0, 4.0], "fovy_range": [25, 45], "camera_perturb": 0.0,
                                      "center_perturb": 0.0, "up_perturb": 0.0, "elevation_range": [-20, 45],
-                                     "azimuth_range": [-180, 180], "condition_source": "synthetic", "seed": 0},
+                                     "azimuth_range": [-180, 180], "condition_source": "synthetic", "seed": 0,
+                                     "resident": {"auto": None, "on": True, "off": False}[a.resident]},
                                 rank=rank, device=dev)
     dm.setup("fit")
     system.on_fit_start()
@@ -313,7 +316,7 @@ def main():
 
     if rank == 0:
         ms = elapsed / a.steps * 1e3
-        res = {"metric": "SDS steps/sec (512^2, 8 views)", "value": a.steps / elapsed, "unit": "steps/s",
+        res = {"metric": f"SDS steps/sec ({a.res}^2, {a.views} views)", "value": a.steps / elapsed, "unit": "steps/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": f"BASELINE configs[2]: {system.geometry.mesh.t_pos_idx.shape[0]}-tri displaced sphere, "
@@ -326,6 +329,7 @@ def main():
                           "atlas_texel": system.material.atlas.texel,
                           "noise_pred_hip_graph": bool(getattr(system.guidance, "_graphs", None)),
                           "process_group": (dist.get_backend() if use_dist else None),
+                          "peak_hbm_gb": torch.cuda.max_memory_allocated() / 1e9,
                           "parallelism": f"dp{world} (views sharded, 1 all-reduce of {system.flat.numel * 4 / 1e6:.1f} MB fp32 grads)",
                           "final_loss": float(loss)}}
         # ---- rooflines from HIP events around the launches: `roofline` (conv) live in the timed region, the others on the

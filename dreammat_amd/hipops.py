@@ -464,6 +464,9 @@ def attention(q, k, vt, heads, scale=None):
 
 
 # ------------------------------------------------------------------------------------------ convolution
+CONV_MAX_TENSOR_BYTES = 0xffffff00      # per-launch limit of the buffer-addressed kernels (tests lower it)
+
+
 def conv3x3_nhwc(x_nhwc, w_tap_major, bias, stride=1, pad=(1, 1), out_hw=None, rowbias=None, residual=None):
     """x [B,H,W,Cin] bf16 contiguous, w [Cout, 9*Cin] bf16 (tap-major) -> y [B,Ho,Wo,Cout] bf16.
     rowbias [B,Cout] / residual [B,Ho,Wo,Cout] (bf16) are added in the kernel epilogue (Cin % 64 == 0)."""
@@ -479,6 +482,17 @@ def conv3x3_nhwc(x_nhwc, w_tap_major, bias, stride=1, pad=(1, 1), out_hw=None, r
         assert rowbias.dtype == torch.bfloat16 and rowbias.is_contiguous() and tuple(rowbias.shape) == (B, Cout)
     if residual is not None:
         assert residual.dtype == torch.bfloat16 and residual.is_contiguous() and residual.shape == y.shape
+    # the LDS-DMA kernel addresses a tensor with 32-bit byte offsets: batches whose activations pass 4 GB (16 views at
+    # 1024^2 through the VAE) run as consecutive image chunks of the same contiguous buffers
+    per_img = 2 * max(H * W * Cin, Ho * Wo * Cout)
+    if B > 1 and B * per_img > CONV_MAX_TENSOR_BYTES:
+        step = max(1, CONV_MAX_TENSOR_BYTES // per_img)
+        for b0 in range(0, B, step):
+            b1 = min(B, b0 + step)
+            y[b0:b1] = conv3x3_nhwc(x_nhwc[b0:b1], w_tap_major, bias, stride, pad, out_hw,
+                                    rowbias[b0:b1] if rowbias is not None else None,
+                                    residual[b0:b1] if residual is not None else None)
+        return y
     with _Timed(f"conv3x3[{Cin}->{Cout}@{Ho}x{Wo},s{stride}]", 2.0 * B * Ho * Wo * Cout * 9 * Cin):
         check(_lib.lib().dm_conv3x3_nhwc_bf16_fused(
             x_nhwc.data_ptr(), w_tap_major.data_ptr(), bias.data_ptr() if bias is not None else None,
@@ -516,6 +530,14 @@ def gemm_fused(x, w, bias=None, residual=None, geglu=False):
     assert x.shape[-1] == K
     No = N // 2 if geglu else N
     y = torch.empty(*x.shape[:-1], No, device=x.device, dtype=torch.bfloat16)
+    if 2 * M * max(K, No) > CONV_MAX_TENSOR_BYTES:           # same 32-bit addressing limit: row chunks of the same buffers
+        rows = max(16, (CONV_MAX_TENSOR_BYTES // (2 * max(K, No))) // 16 * 16)
+        x2, y2 = x.reshape(M, K), y.view(M, No)
+        r2 = residual.reshape(M, No) if residual is not None else None
+        for m0 in range(0, M, rows):
+            m1 = min(M, m0 + rows)
+            y2[m0:m1] = gemm_fused(x2[m0:m1], w, bias, r2[m0:m1] if r2 is not None else None, geglu)
+        return y
     if bias is not None:
         assert bias.dtype == torch.bfloat16 and bias.is_contiguous() and bias.numel() == N
     if residual is not None:

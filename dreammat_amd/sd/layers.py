@@ -233,6 +233,11 @@ class PaddedContext:
         self.t = F.pad(ctx, (0, 0, 0, pad)) if pad else ctx
 
 
+def _zero_tail(vt, kv_len):
+    vt[:, :, kv_len:] = 0
+    return vt
+
+
 def attention_core(q, k, v_weight, v_bias, kv_src, heads, kv_len):
     """softmax(QK^T/sqrt(d)) V with V = kv_src @ v_weight^T (+bias).  q [B,Sq,C], k [B,Skv,C].
     CUDA+bf16 -> MFMA kernel (V produced directly transposed by the projection GEMM);
@@ -244,6 +249,15 @@ def attention_core(q, k, v_weight, v_bias, kv_src, heads, kv_len):
     if q.is_cuda and q.dtype == torch.bfloat16 and not needs_grad:     # the MFMA kernel is forward-only
         if kv_src.shape[1] % 8:                                       # V^T rows must be 16 B multiples
             kv_src = F.pad(kv_src, (0, 0, 0, (-kv_src.shape[1]) % 8))
+        Bk, Sk = kv_src.shape[0], kv_src.shape[1]
+        if C >= 640 and Bk >= 16 and Sk * C >= (1 << 20) and hipops.gemm_fused_ok(Bk * Sk, kv_src.shape[2], C):
+            # hipBLASLt / rocBLAS in this image fault (HIPBLAS_STATUS_INTERNAL_ERROR, then an illegal address) on the strided-
+            # batched W[C,C] @ X[B,S,C]^T for 24 x 4096 x 640, 24 x 1024 x 1280, 24 x 4096 x 1280 ... (tools/blas_probe.py:
+            # the 1024^2 configurations; every shape of the 512^2 step is fine): there V comes from the fused GEMM kernel
+            # and is transposed by a copy
+            v = linear_fused(kv_src, v_weight, v_bias)
+            return hipops.attention(q, k[:, :kv_len], v.transpose(1, 2).contiguous(), heads) if kv_len == Sk else \
+                hipops.attention(q, k[:, :kv_len], _zero_tail(v.transpose(1, 2).contiguous(), kv_len), heads)
         vt = torch.matmul(v_weight, kv_src.transpose(1, 2))           # [B, C, Skv_pad]: V^T for free
         if v_bias is not None:
             vt = vt + v_bias[None, :, None]

@@ -962,6 +962,25 @@ def test_rccl_world1_step_through_bench(dev):
     assert "ProcessGroupNCCL" in r.stderr or "NCCL" in r.stderr.upper() or res["config"].get("process_group") == "nccl"
 
 
+def test_conv_and_gemm_chunk_batches_past_the_32bit_addressing_limit(dev, monkeypatch):
+    """activations past 4 GB per tensor (cfg5: 16 views at 1024^2 through the VAE) run as image / row chunks of the same
+    buffers; exercised here by lowering the limit instead of allocating 4 GB."""
+    torch.manual_seed(12)
+    B, H, W, Cin, Cout = 5, 16, 16, 64, 128
+    x = torch.randn(B, H, W, Cin).bfloat16().to(dev)
+    w = (torch.randn(Cout, 9 * Cin) * 0.05).bfloat16().to(dev)
+    b = torch.randn(Cout).bfloat16().to(dev)
+    rb, res = torch.randn(B, Cout).bfloat16().to(dev), torch.randn(B, H, W, Cout).bfloat16().to(dev)
+    ref = hipops.conv3x3_nhwc(x, w, b, 1, (1, 1), None, rb, res)
+    xm, wm = torch.randn(1024, 128).bfloat16().to(dev), (torch.randn(256, 128) * 0.05).bfloat16().to(dev)
+    rm = torch.randn(1024, 256).bfloat16().to(dev)
+    refm = hipops.gemm_fused(xm, wm, None, rm)
+    monkeypatch.setattr(hipops, "CONV_MAX_TENSOR_BYTES", 2 * 2 * H * W * Cout + 100)       # two images per launch
+    assert torch.equal(hipops.conv3x3_nhwc(x, w, b, 1, (1, 1), None, rb, res), ref)
+    monkeypatch.setattr(hipops, "CONV_MAX_TENSOR_BYTES", 2 * 300 * 256)                    # 288-row chunks
+    assert torch.equal(hipops.gemm_fused(xm, wm, None, rm), refm)
+
+
 def test_narrow_head_conv_zero_padded_to_mfma_tile(dev):
     """UNet conv_out (320->4) / VAE conv_out (512->8): Cout zero-padded to 64 for the MFMA kernel, forward + dgrad."""
     from dreammat_amd.sd import layers
