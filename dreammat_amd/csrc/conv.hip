@@ -719,15 +719,23 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
 }
 
 // grow-only fp32 scratch for the split-K partials.  Owned by the library, used in stream order: launches that need it on
-// DIFFERENT streams at the same time would share it (the nets of this repo run on one stream); first use allocates, so a
-// stream capture must be preceded by an eager run of the same shapes (torch's capture warm-up does that).
+// DIFFERENT streams at the same time would share it (the nets of this repo run on one stream).  First use allocates, so a
+// stream capture must be preceded by an eager run of the same shapes (torch's capture warm-up does that).  A buffer that has
+// been handed out is NEVER freed: a captured hipGraph (guidance `hip_graph`) keeps replaying kernels that hold its address,
+// so growing means allocating a larger one (at least 2x) next to it -- the dead ones add up to less than the live one.
 static float* splitk_workspace(size_t floats) {
     static float* buf = nullptr;
     static size_t cap = 0;
     if (floats > cap) {
-        if (buf) { (void)hipDeviceSynchronize(); (void)hipFree(buf); buf = nullptr; cap = 0; }
-        if (hipMalloc(&buf, floats * sizeof(float)) != hipSuccess) return nullptr;
-        cap = floats;
+        size_t got = std::max(floats, 2 * cap);
+        float* nb = nullptr;
+        if (hipMalloc(&nb, got * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            got = floats;
+            if (hipMalloc(&nb, got * sizeof(float)) != hipSuccess) return nullptr;
+        }
+        buf = nb;
+        cap = got;
     }
     return buf;
 }
