@@ -162,6 +162,57 @@ def test_bench_reads_counter_profiles():
     assert bench.pmc_traffic("k_unknown foo", 8) is None
 
 
+def test_bench_reads_shade_counters_of_the_real_gbuffer():
+    import bench
+    tr = bench.shade_traffic("shade_fwd", "rgb18e8")
+    assert tr and tr["traffic_source"].startswith("profiles/") and 30e6 < tr["traffic"] < 400e6      # ~64 MB algorithmic at 1.15 M px
+    assert bench.shade_traffic("shade_bwd", "rgb18e8")["traffic"] > tr["traffic"] * 0.8
+    assert bench.shade_traffic("no_such_kernel", "rgb18e8") is None
+
+
+def test_geglu_interleave_layout_is_the_fused_kernels_contract():
+    """dm_gemm_bf16_fused(geglu=1) reads weight rows in blocks of 64: 32 value rows of output channels 32t..32t+31, then their
+    32 gate rows; a torch emulation of that contract on the interleaved weight must equal the unfused Linear -> GEGLU."""
+    from dreammat_amd import hipops
+    torch.manual_seed(0)
+    inner, K, M = 96, 40, 7
+    w, b, x = torch.randn(2 * inner, K), torch.randn(2 * inner), torch.randn(M, K)
+    wi, bi = hipops.geglu_interleave(w), hipops.geglu_interleave(b)
+    assert wi.shape == w.shape and torch.equal(wi[:32], w[:32]) and torch.equal(wi[32:64], w[inner:inner + 32])
+    h = x @ wi.t() + bi                                        # what the GEMM accumulates, columns in interleaved order
+    hv = h.view(M, inner // 32, 2, 32)
+    fused = (hv[:, :, 0] * torch.nn.functional.gelu(hv[:, :, 1])).reshape(M, inner)
+    ref = x @ w.t() + b
+    ref = ref[:, :inner] * torch.nn.functional.gelu(ref[:, inner:])
+    assert torch.allclose(fused, ref, atol=1e-5)
+    assert hipops.gemm_fused_ok(4096, 320, 2560, geglu=True) and not hipops.gemm_fused_ok(4096, 320, 2560 + 64, geglu=True)
+    assert not hipops.gemm_fused_ok(4100, 320, 320) and not hipops.gemm_fused_ok(4096, 300, 320)
+
+
+def test_step_window_tool_cuts_whole_steps_out_of_a_kernel_trace(tmp_path):
+    """tools/step_window.py: per-step table between the starts of a once-per-step kernel (k_hg_acc)."""
+    import csv
+    import subprocess
+    import sys
+    rows = []
+    t = 1000
+    for step in range(5):
+        for name, dur in (("setup_only" if step == 0 else "k_a", 10000), ("(anonymous namespace)::k_hg_acc(BinArgs)", 50000), ("k_b", 30000), ("k_b", 30000)):
+            rows.append({"Kernel_Name": name, "Start_Timestamp": t, "End_Timestamp": t + dur})
+            t += dur + 5
+    f = tmp_path / "trace.csv"
+    with open(f, "w", newline="") as fh:
+        wr = csv.DictWriter(fh, fieldnames=list(rows[0]))
+        wr.writeheader()
+        wr.writerows(rows)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "step_window.py"), str(f), "1", "4"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    tab = {r[0]: r for r in csv.reader(out.stdout.splitlines())}
+    assert float(tab["k_b"][1]) == 2.0 and float(tab["k_a"][1]) == 1.0 and "setup_only" not in tab
+    assert abs(float(tab["k_b"][2]) - 0.060) < 1e-9                                  # ms per step
+
+
 def test_fibonacci_direction_tables_match_the_reference():
     """hipops.fibonacci_direction_samples == the (azimuth, elevation) tables DreamMatMaterial.configure builds from the
     reference's sample_sphere (tests/golden/mc_shading.npz stores the reference's own tables)."""
