@@ -916,8 +916,11 @@ int dm_conv3x3_nhwc_bf16_fused(const void* x, const void* w, const void* bias, c
         case 512: return launch_conv_dma<256, 256, 8, 2, 2>(a, stream);      // wave tile 128 x 64
         case 256: return launch_conv_dma<256, 128, 8, 4, 3>(a, stream);      // wave tile 64 x 64
         default:
-            return (Cout % 128 == 0) ? launch_conv_dma<128, 128, 4, 2, 3>(a, stream)
-                                     : launch_conv_dma<128, 64, 4, 2, 3>(a, stream);
+            if (Cout % 128 != 0) return launch_conv_dma<128, 64, 4, 2, 3>(a, stream);
+            // long K and enough tiles: the 2-stage ring (64 KB, two workgroups per CU) wins (24 x 1280->1280 @8x8 82 -> 70 us,
+            // 3 x 640->640 @32x32 48 -> 43 us); short K or a handful of tiles: the 3-stage ring (3 x 1280 @8x8 26 vs 30 us)
+            return (Cin >= 320 && n_wg(128, 128) >= 48) ? launch_conv_dma<128, 128, 4, 2, 2>(a, stream)
+                                                         : launch_conv_dma<128, 128, 4, 2, 3>(a, stream);
         }
     }
     if (rowbias || residual) return DM_ERR_UNSUPPORTED;
@@ -962,7 +965,7 @@ int dm_gemm_bf16_fused(const void* x, const void* w, const void* bias, const voi
         switch (tile) {
         case 512: return launch_conv_dma<256, 256, 8, 2, 2, 1, 1>(a, stream);
         case 256: return launch_conv_dma<256, 128, 8, 4, 3, 1, 1>(a, stream);
-        default: return launch_conv_dma<128, 128, 4, 2, 3, 1, 1>(a, stream);
+        default: return launch_conv_dma<128, 128, 4, 2, 2, 1, 1>(a, stream);
         }
     }
     switch (tile) {
@@ -970,7 +973,9 @@ int dm_gemm_bf16_fused(const void* x, const void* w, const void* bias, const voi
     case 320: return launch_conv_dma<256, 320, 8, 4, 2, 1, 0>(a, stream);
     case 256: return launch_conv_dma<256, 128, 8, 4, 3, 1, 0>(a, stream);
     default:
-        return (N % 128 == 0) ? launch_conv_dma<128, 128, 4, 2, 3, 1, 0>(a, stream)
+        // 2-stage ring (64 KB): TWO workgroups per CU, one's epilogue under the other's K loop -- 25 % faster than the 3-stage
+        // single-workgroup form on every small-M Linear shape (tools/gemm_fit.sh)
+        return (N % 128 == 0) ? launch_conv_dma<128, 128, 4, 2, 2, 1, 0>(a, stream)
                               : launch_conv_dma<128, 64, 4, 2, 3, 1, 0>(a, stream);
     }
 }
