@@ -236,7 +236,9 @@ class StableDiffusionLightGuidance(BaseObject):
                 self._noise_pred(st["lat"], st["t"], st["emb"], st["cond"], scales)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread-local capture mode: the RCCL watchdog thread of a multi-rank job polls its events with HIP calls of its own,
+            # which a global-mode capture would reject
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 st["out"] = self._noise_pred(st["lat"], st["t"], st["emb"], st["cond"], scales)
             g = self._graphs[key] = (graph, st)
             if len(self._graphs) > 4:       # annealed conditioning scales re-capture; keep the pool bounded
