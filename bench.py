@@ -392,9 +392,15 @@ def main():
                                        "sample": "not completed", "error": repr(e)}
             finally:
                 signal.alarm(0)
-        print(json.dumps(res), flush=True)
+    # the JSON line must be the LAST thing on stdout: RCCL printf()s "Librccl path : ..." into the C stdio buffer, which a pipe
+    # only flushes at exit (after python's own print) -- tear the process group down and flush C stdio first
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
