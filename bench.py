@@ -394,13 +394,16 @@ def main():
                 signal.alarm(0)
     # the JSON line must be the LAST thing on stdout: RCCL printf()s "Librccl path : ..." into the C stdio buffer, which a pipe
     # only flushes at exit (after python's own print) -- tear the process group down and flush C stdio first
+    import ctypes
+    sys.stdout.flush()
+    ctypes.CDLL(None).fflush(None)            # every rank: whatever sits in C stdio goes out now ...
+    if use_dist:
+        dist.barrier()                        # ... before rank 0 prints the line
+    if rank == 0:
+        print(json.dumps(res), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    import ctypes
-    ctypes.CDLL(None).fflush(None)
-    if rank == 0:
-        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
