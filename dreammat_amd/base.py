@@ -71,6 +71,9 @@ class BaseModule(nn.Module, Updateable):
         weights: Optional[str] = None
 
     cfg: Config
+    # state_dict key prefixes of reference modules that exist in its checkpoints but are never used on the path
+    IGNORED_REFERENCE_KEYS = ("metallic_predictor.", "roughness_predictor.", "albedo_predictor.", "inner_light.",
+                              "light_pts", "FG_LUT", "sdf_network.", "normal_network.")
 
     def __init__(self, cfg=None, *args, **kwargs):
         super().__init__()
@@ -82,12 +85,18 @@ class BaseModule(nn.Module, Updateable):
             path, module_name = self.cfg.weights.split(":")
             ckpt = torch.load(path, map_location="cpu")
             sd = {k[len(module_name) + 1:]: v for k, v in ckpt["state_dict"].items() if k.startswith(module_name + ".")}
-            # reference checkpoints carry keys this repo does not instantiate (the never-used predictor heads of
-            # dreammat_mesh.py:136-139, inner-light MLPs): skipped and reported, like Trainer.load_checkpoint
+            # The reference is strict here (utils/base.py:109).  Its checkpoints carry keys this repo does not instantiate
+            # (never-used predictor heads of dreammat_mesh.py:137-139, the inner-light MLP / probe buffers of
+            # dreammat_material.py:400-414): only THOSE may be skipped; any missing key, or an unexpected key outside the
+            # allow-list (wrong module prefix, truncated or mismatched checkpoint), raises instead of silently leaving
+            # parameters at their random initialisation.
             res = self.load_state_dict(sd, strict=False)
-            if res.missing_keys or res.unexpected_keys:
-                print(f"[dreammat_amd] weights '{self.cfg.weights}': missing {list(res.missing_keys)}, "
-                      f"ignored {list(res.unexpected_keys)}")
+            unexpected = [k for k in res.unexpected_keys if not k.startswith(self.IGNORED_REFERENCE_KEYS)]
+            if res.missing_keys or unexpected:
+                raise RuntimeError(f"weights '{self.cfg.weights}' do not match {type(self).__name__}: "
+                                   f"missing {list(res.missing_keys)}, unexpected {unexpected}")
+            if res.unexpected_keys:
+                print(f"[dreammat_amd] weights '{self.cfg.weights}': ignored reference-only keys {list(res.unexpected_keys)}")
             self.do_update_step(ckpt.get("epoch", 0), ckpt.get("global_step", 0), on_load_weights=True)
         self._dummy: torch.Tensor
         self.register_buffer("_dummy", torch.zeros(0).float(), persistent=False)

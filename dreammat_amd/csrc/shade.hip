@@ -72,9 +72,9 @@ __device__ __forceinline__ void shade_pixel_loop(const ShadeArgs& a, Body&& body
     const long long N = *a.n_dev;
     const long long stride = (long long)gridDim.x * blockDim.x;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
     if (FMT == kTexelF32 || !a.atlas.fg_pairs || a.n_views > kMaxViewsLds || !a.offsets32) {   // legacy: monolithic, one-pixel prefetch,
                                                                                                 // any row strides
+        if (i >= N) return;
         ShadeIn cur, nxt;
         shade_load<BWD>(a, i, cur);
         for (; i < N; i += stride) {
@@ -98,6 +98,9 @@ __device__ __forceinline__ void shade_pixel_loop(const ShadeArgs& a, Body&& body
     }
     if ((int)threadIdx.x < a.n_views) s_env[threadIdx.x] = a.env_of_view[threadIdx.x];
     __syncthreads();
+    // only now may a thread without a pixel leave: in the boundary workgroup of a small launch (N % 256 below the table
+    // sizes) the threads that fill the upper table entries are exactly the ones past the end
+    if (i >= N) return;
     const float inv_hw = 1.0f / (float)a.HW;
     auto env_of = [&](int pix) {
         int view = (int)((float)pix * inv_hw);           // pix < 2^24 is exact in fp32; one step of correction covers the rounding

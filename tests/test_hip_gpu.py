@@ -225,6 +225,36 @@ def test_shade_forward_backward(dev, envs):
         assert (a.cpu() - b).abs().max() < 1e-3 * b.abs().max(), nm
 
 
+@pytest.mark.parametrize("N", [1, 2, 3, 257, 258, 259, 515, 770])
+def test_shade_small_launch_boundary_workgroup(dev, envs, N):
+    """with N < grid capacity and N % 256 in [1, max(n_mips, n_views)) the boundary workgroup's
+    threads past the end used to leave before they had filled their entries of the LDS mip / view->environment tables;
+    the tail pixels (last view, any mip) then read uninitialised LDS.  Several views, all mips, forward + backward."""
+    lat, fg, oenvs = envs
+    atlas = penv.EnvAtlas(lat, scale=2.0, min_res=8, max_res=32, fg_lut=fg, device=dev)
+    torch.manual_seed(N)
+    HW = max(1, (N + 2) // 3)                              # the N pixels span three views; the tail is in the last one
+    n = torch.nn.functional.normalize(torch.randn(N, 3), dim=-1)
+    v = torch.nn.functional.normalize(n + 0.8 * torch.randn(N, 3), dim=-1)
+    feat = (torch.randn(N, 5) * 2.0).requires_grad_()       # wide roughness range: every specular mip is visited
+    pix = torch.arange(N, dtype=torch.int32)
+    env_of_view = torch.tensor([1, 2, 0], dtype=torch.int32)
+    env = env_of_view[(pix // HW).long()].long()
+    out, _ = oshade.material_forward(feat, feat.detach(), v, n, oenvs, env, fg)
+    dcol = torch.randn(N, 3)
+    (out["color"] * dcol).sum().backward()
+    from dreammat_amd._lib import MatCfgStruct
+    mat = MatCfgStruct(0.0, 0.9, 0.1, 0.95)
+    n_dev = torch.tensor([N], dtype=torch.int32, device=dev)
+    soa = lambda t: t.detach().t().contiguous().to(dev).t()     # [C,N] storage: the layout of the kernels' fast pixel loop
+    for _ in range(3):                                      # LDS garbage differs from launch to launch
+        fgpu = soa(feat).requires_grad_()
+        col = hipops.shade(fgpu, soa(n), soa(v), pix.to(dev), n_dev, env_of_view.to(dev), atlas, mat, HW, False)[0]
+        assert (col.detach().cpu() - out["color"].detach()).abs().max() < 1e-5
+        (col * dcol.to(dev)).sum().backward()
+        assert (fgpu.grad.cpu() - feat.grad).abs().max() < 1e-3 * max(float(feat.grad.abs().max()), 1e-6)
+
+
 def test_adam_matches_torch(dev):
     torch.manual_seed(0)
     n = 4096 * 3 + 8

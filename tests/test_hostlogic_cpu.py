@@ -384,3 +384,16 @@ def test_partial_weight_load_skips_reference_only_keys(tmp_path):
     torch.save({"state_dict": sd, "epoch": 0, "global_step": 7}, tmp_path / "ref.ckpt")
     g1 = dreammat_amd.find("dreammat-mesh")(dict(cfg, weights=f"{tmp_path / 'ref.ckpt'}:geometry"))
     assert torch.equal(g1.encoding.encoding.params, g0.encoding.encoding.params)
+    # anything else is an error, as in the reference (utils/base.py:109 is strict) -- a wrong
+    # module prefix (nothing matches => every key missing), a truncated checkpoint, or an unknown extra key
+    with pytest.raises(RuntimeError, match="missing"):
+        dreammat_amd.find("dreammat-mesh")(dict(cfg, weights=f"{tmp_path / 'ref.ckpt'}:geometri"))
+    bad = dict(sd)
+    bad["geometry.some_new_head.weight"] = torch.zeros(2)
+    torch.save({"state_dict": bad}, tmp_path / "bad.ckpt")
+    with pytest.raises(RuntimeError, match="unexpected"):
+        dreammat_amd.find("dreammat-mesh")(dict(cfg, weights=f"{tmp_path / 'bad.ckpt'}:geometry"))
+    trunc = {k: v for k, v in sd.items() if "feature_network" not in k}
+    torch.save({"state_dict": trunc}, tmp_path / "trunc.ckpt")
+    with pytest.raises(RuntimeError, match="missing"):
+        dreammat_amd.find("dreammat-mesh")(dict(cfg, weights=f"{tmp_path / 'trunc.ckpt'}:geometry"))
