@@ -22,25 +22,11 @@
 
 #include <type_traits>
 
-#include "dm_common.h"
+#include "attn_common.h"
+
+using namespace dm_attn;
 
 namespace {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-struct AttnArgs {
-    const __bf16* q; const __bf16* k; const __bf16* vt; __bf16* out;
-    long long q_bs, q_ss, q_hs;       // element strides: batch, sequence, head (d contiguous)
-    long long k_bs, k_ss, k_hs;
-    long long vt_bs, vt_hs, vt_ds;    // V^T: batch, head, d-row (kv contiguous)
-    long long o_bs, o_ss, o_hs;
-    int B, Hh, Sq, Skv, D;
-    float scale_log2;                 // softmax scale * log2(e)
-};
 
 constexpr int kQRowsPerWave = 32;
 constexpr int kWaves = 4;
@@ -1013,6 +999,8 @@ int launch_attn_v3(const AttnArgs& a, hipStream_t stream) {
 static int g_attn_mode = -1;
 static int attn_mode_from_name(const char* e) {
     if (!e || !strcmp(e, "v3l")) return 4;
+    if (!strcmp(e, "w64")) return 6;
+    if (!strcmp(e, "w64m")) return 7;
     if (!strcmp(e, "v3")) return 3;
     if (!strcmp(e, "v3p")) return 5;
     if (!strcmp(e, "v3s")) return 2;
@@ -1112,7 +1100,13 @@ int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* ou
     // 3 waves per SIMD) | v3 (early fragment reads, 2 waves per SIMD) | v3p (two-phase software pipeline for Skv >= 1024, v3l below) |
     // v3s (v3 without the Q scaling) | dma (round-1 kernel) | staged
     // (register-staged): A/B measurements and regression tests.  D = 40/80/160 heads always use the staged kernel.
-    const int mode = attn_mode();
+    int mode = attn_mode();
+    if (mode >= 6) {
+        // one wave per SIMD, 256 query rows per workgroup (attn_w64.hip): whole 64-row kv tiles of 64-wide heads; short
+        // query sequences (one wave of four would work) and everything else stay with the v3l kernel
+        if (attn_w64_ok(a) && a.Sq >= 128) return launch_attn_w64(a, mode - 6, stream);
+        mode = 4;
+    }
     if (mode >= 2 && attn_v3_ok(a) && (D <= 64 || (D > 96 && D <= 128))) {
         if (D <= 64) {
             // the pipelined form pays off on long sequences; its (register-starved) tail handles the last four tiles

@@ -1,0 +1,29 @@
+// Shared argument block / vector types of the attention kernels (attention.hip, attn_w64.hip).
+#pragma once
+#include "dm_common.h"
+
+namespace dm_attn {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct AttnArgs {
+    const __bf16* q; const __bf16* k; const __bf16* vt; __bf16* out;
+    long long q_bs, q_ss, q_hs;       // element strides: batch, sequence, head (d contiguous)
+    long long k_bs, k_ss, k_hs;
+    long long vt_bs, vt_hs, vt_ds;    // V^T: batch, head, d-row (kv contiguous)
+    long long o_bs, o_ss, o_hs;
+    int B, Hh, Sq, Skv, D;
+    float scale_log2;                 // softmax scale * log2(e)
+};
+
+// attn_w64.hip: the one-wave-per-SIMD kernel (D = 64, Skv % 64 == 0).  `variant` bit 0: row sums on the matrix pipe.
+bool attn_w64_ok(const AttnArgs& a);
+int launch_attn_w64(const AttnArgs& a, int variant, hipStream_t stream);
+
+}  // namespace dm_attn

@@ -18,6 +18,7 @@ SOURCES = {
     # MFMA results stay in VGPRs: the softmax consumes every S element with VALU ops, and the AGPR form cost
     # 127 v_accvgpr_read/write per KV tile
     "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    "attn_w64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "conv.hip": [],
     "conv_small.hip": [],
     "groupnorm.hip": [],
@@ -27,7 +28,7 @@ SOURCES = {
     "mc_shade.hip": [],
     "host.cpp": [],
 }
-HEADERS = ["dm_common.h", "raster_core.h", "shade_core.h", "bvh_core.h", "mc_shade_core.h"]
+HEADERS = ["dm_common.h", "attn_common.h", "raster_core.h", "shade_core.h", "bvh_core.h", "mc_shade_core.h"]
 
 
 def _newer(src, dst):

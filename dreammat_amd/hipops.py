@@ -433,7 +433,7 @@ def material_smoothness(feat, featj, n_dev):
 
 # ------------------------------------------------------------------------------------------ attention
 def attention_select(name=None):
-    """Kernel variant of every later attention() call: "v3l" (default) | "v3" | "v3p" | "v3s" | "dma" | "staged"; None restores the
+    """Kernel variant of every later attention() call: "w64" | "w64m" (one wave per SIMD, D = 64 with whole kv tiles; else v3l) | "v3l" | "v3" | "v3p" | "v3s" | "dma" | "staged"; None restores the
     DREAMMAT_ATTN_KERNEL / default choice (dm_attention_select)."""
     check(_lib.lib().dm_attention_select(name.encode() if name is not None else None), "dm_attention_select")
 

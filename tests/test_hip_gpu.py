@@ -275,10 +275,12 @@ def test_adam_matches_torch(dev):
 ATTN_CASES = [  # (B, heads, Sq, Skv, D)
     (2, 5, 256, 256, 64), (1, 5, 4096, 4096, 64), (3, 10, 1024, 1024, 64), (2, 20, 64, 64, 64),
     (2, 5, 1024, 77, 64), (2, 20, 256, 77, 64), (2, 8, 256, 256, 40), (1, 8, 192, 77, 80), (1, 8, 128, 128, 160),
-    (1, 2, 100, 130, 128)]
+    (1, 2, 100, 130, 128),
+    # the one-wave-per-SIMD kernel (w64): ragged query blocks, fewer than 256 queries, odd / even tile counts, one tile
+    (1, 2, 320, 256, 64), (1, 3, 128, 192, 64), (2, 2, 256, 64, 64), (1, 1, 700, 128, 64)]
 
 
-ATTN_VARIANTS = ["v3p", "v3", "v3l", "v3s", "dma", "staged"]
+ATTN_VARIANTS = ["w64", "w64m", "v3p", "v3", "v3l", "v3s", "dma", "staged"]
 
 
 @pytest.fixture
@@ -325,6 +327,56 @@ def test_attention_online_softmax_rescale_branch(dev, attn_variant):
     ref = (torch.softmax(qf @ kf.transpose(-1, -2) * D ** -0.5, -1) @ vf).transpose(1, 2).reshape(B, S, h * D)
     assert torch.isfinite(out).all()
     assert (out - ref).abs().max() < 3e-2
+
+
+@pytest.mark.parametrize("attn_variant", ["w64", "w64m", "v3l"], indirect=True)
+def test_attention_lazy_shift_overflow_takes_the_exact_path(dev, attn_variant):
+    """The w64 kernel keeps the row shift of the FIRST kv tile and re-bases lazily; a score that outgrows it by more than
+    2^100 inside one tile cannot be represented and must send the workgroup through its exact (textbook online softmax) path.
+    Rows next to it (same wave, other waves of the workgroup, other workgroups) must be unaffected."""
+    torch.manual_seed(2)
+    B, h, S, D = 1, 2, 512, 64
+    q = torch.randn(B, S, h * D); k = torch.randn(B, S, h * D); v = torch.randn(B, S, h * D)
+    q[:, 37, :D] = 6.0                       # head 0, row 37: logit 64*36/8 = 288 nats = 415 in the log2 domain against key 200
+    k[:, 200, :D] = 6.0
+    q[:, 300, D:] = -5.0                     # head 1, row 300 (second workgroup): 200 nats against key 511 (the last tile)
+    k[:, 511, D:] = -5.0
+    qb, kb, vb = (t.to(dev).bfloat16() for t in (q, k, v))
+    out = hipops.attention(qb, kb, vb.transpose(1, 2).contiguous(), h).float().cpu()
+    qf, kf, vf = (t.float().cpu().view(B, S, h, D).transpose(1, 2) for t in (qb, kb, vb))
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * D ** -0.5, -1) @ vf).transpose(1, 2).reshape(B, S, h * D)
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max() < 3e-2
+    assert (out[0, 37, :D] - vf[0, 0, 200]).abs().max() < 2e-2        # that row is its spiked key's value
+
+
+@pytest.mark.parametrize("attn_variant", ["w64", "v3l"], indirect=True)
+def test_attention_cfg5_sequence_16384_vs_chunked_fp32(dev, attn_variant):
+    """BASELINE configs[4] (1024^2 renders -> 128^2 latents): S = 16384, 5 heads of 64 -- 256 kv tiles per row, the longest
+    accumulation the kernels see.  Reference: fp32 softmax(QK^T)V on the bf16-rounded inputs, query chunks of 2048
+    (1 GB of scores per chunk), plus a float64 CPU spot check of a few rows."""
+    torch.manual_seed(4)
+    B, h, S, D = 1, 5, 16384, 64
+    q = torch.randn(B, S, h * D, device=dev).bfloat16()
+    k = torch.randn(B, S, h * D, device=dev).bfloat16()
+    v = torch.randn(B, S, h * D, device=dev).bfloat16()
+    out = hipops.attention(q, k, v.transpose(1, 2).contiguous(), h).float()
+    qf, kf, vf = (t.float().view(B, S, h, D).transpose(1, 2) for t in (q, k, v))
+    ref = torch.empty(B, h, S, D, device=dev)
+    for c0 in range(0, S, 2048):
+        sc = qf[:, :, c0:c0 + 2048] @ kf.transpose(-1, -2) * D ** -0.5
+        ref[:, :, c0:c0 + 2048] = torch.softmax(sc, -1) @ vf
+    ref = ref.transpose(1, 2).reshape(B, S, h * D)
+    err = (out - ref).abs()
+    assert err.max().item() < 1e-2 and err.mean().item() < 1e-3, (err.max().item(), err.mean().item())
+    rows = [0, 4095, 9001, 16383]
+    q64, k64, v64 = qf.double().cpu(), kf.double().cpu(), vf.double().cpu()
+    r64 = (torch.softmax(q64[:, :, rows] @ k64.transpose(-1, -2) * D ** -0.5, -1) @ v64).transpose(1, 2).reshape(B, len(rows), h * D)
+    assert (out[:, rows].double().cpu() - r64).abs().max().item() < 1e-2
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, f"attn_s16384_{attn_variant}.json"), "w") as f:
+        json.dump({"variant": attn_variant, "B": B, "heads": h, "S": S, "D": D, "max_abs_err_vs_fp32": err.max().item(),
+                   "mean_abs_err_vs_fp32": err.mean().item()}, f)
 
 
 def test_renderer_end_to_end_vs_oracle(dev, envs):

@@ -47,7 +47,7 @@ def ab(fns, rounds, iters):
 
 
 def attention_section(a, res):
-    variants = ["v3p", "v3", "v3l", "v3s", "dma", "staged"]
+    variants = a.variants.split(",")
     shapes = [(24, 5, 4096, 4096, 64), (24, 10, 1024, 1024, 64), (24, 20, 256, 256, 64), (24, 20, 64, 64, 64),
               (24, 5, 4096, 77, 64), (24, 10, 1024, 77, 64), (3, 5, 4096, 4096, 64), (48, 5, 16384, 16384, 64)]
     if a.quick:
@@ -231,6 +231,8 @@ def main():
     ap.add_argument("--skip-shade", action="store_true")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--skip-hashgrid", action="store_true")
+    ap.add_argument("--variants", default="v3p,v3,v3l,v3s,dma,staged", help="attention kernels to compare (dm_attention_select names)")
+    ap.add_argument("--out", default="r2_probe.json")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     res = []
@@ -240,7 +242,7 @@ def main():
         shade_section(a, res)
     if not a.skip_attn:
         attention_section(a, res)
-    with open(os.path.join(OUT, "r2_probe.json"), "w") as fh:
+    with open(os.path.join(OUT, a.out), "w") as fh:
         json.dump(res, fh, indent=1)
 
 
