@@ -94,6 +94,7 @@ _SIGS = {
                         + [c_void_p, c_void_p, c_void_p, _LL, c_int, c_void_p, c_void_p, c_void_p, c_void_p, _LL, _LL,
                            c_void_p, _LL, _LL, c_void_p]),
     "dm_attention_select": (c_int, [ctypes.c_char_p]),
+    "dm_attention_selected": (ctypes.c_char_p, []),
     "dm_attention_fwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]
                               + [_LL] * 12 + [c_float, c_void_p]),
     "dm_conv3x3_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),

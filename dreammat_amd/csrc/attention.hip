@@ -228,273 +228,6 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Variant 2 (DP = 64 or 128): K and V^T tiles travel HBM/L2 -> LDS by DMA (global_load_lds, 16 B per lane)
-// through a 3-stage ring with counted s_waitcnt vmcnt(L) + one raw s_barrier per KV tile, so two tiles of
-// loads are in flight behind the MFMAs and no VGPRs / ds_write instructions are spent on staging.
-// LDS rows are unpadded (DMA writes base + lane*16); the 16 B chunk index is XOR-swizzled with
-// (row>>1)&7 (128 B rows) or row&15 (256 B rows) -- on the per-lane SOURCE address on the way in and on
-// the ds_read address on the way out.  V^T keeps the natural kv order; the k-slot permutation of the
-// P.V product is folded into two 8-byte ds_reads per k-step instead.  Out-of-range rows / chunks read
-// a 16-byte zero page (the DMA must run with all lanes active).
-__device__ __attribute__((aligned(16))) unsigned int g_attn_zero_page[4] = {0, 0, 0, 0};
-
-template <int DP>
-__global__ __launch_bounds__(256) void k_attn_fwd_dma(AttnArgs a) {
-    static_assert(DP == 64 || DP == 128, "DMA variant: power-of-two row sizes only");
-    constexpr int KSTEPS = DP / 16, DT = DP / 32;
-    constexpr int KROW = DP * 2;                       // K row bytes
-    constexpr int VROW = kKvTile * 2;                  // V^T row bytes (128)
-    constexpr int KBYTES = kKvTile * KROW, VBYTES = DP * VROW, STAGE = KBYTES + VBYTES;
-    constexpr int KCH = KROW / 16;                     // chunks per K row: 8 or 16
-    constexpr int KRPI = 64 / KCH;                     // K rows per DMA instruction: 8 or 4
-    constexpr int K_INSTR = kKvTile / KRPI / 4;        // per wave: 2 or 4
-    constexpr int V_INSTR = DP / 8 / 4;                // per wave: 2 or 4
-    constexpr int L = K_INSTR + V_INSTR;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
-    // 1-D grid, XCD-aware: block id i runs on XCD i % 8 (private 4 MB L2 each).  All query blocks of one
-    // (batch, head) go to ONE XCD, so its K / V^T (1 MB at S = 4096) are pulled from HBM once instead of by every
-    // XCD (rocprofv3: FETCH 4.1x the algorithmic bytes, 75 % L2 hit rate with the (q block, bh) 2-D grid).
-    int bh, qb;
-    {
-        const int nq = (a.Sq + kWaves * kQRowsPerWave - 1) / (kWaves * kQRowsPerWave);
-        const int BH = a.B * a.Hh, id = blockIdx.x;
-        if ((BH & 7) == 0) {
-            const int j = id >> 3;
-            bh = (j / nq) * 8 + (id & 7);
-            qb = j - (j / nq) * nq;
-        } else {
-            bh = id / nq;
-            qb = id - bh * nq;
-        }
-    }
-    const int b = bh / a.Hh, h = bh - b * a.Hh;
-    const int q_row = qb * (kWaves * kQRowsPerWave) + wave * kQRowsPerWave + l31;
-    const bool q_ok = q_row < a.Sq;
-    const int skv_pad8 = (a.Skv + 7) & ~7;
-    auto kswz = [](int r) { return KCH == 8 ? ((r >> 1) & 7) : (r & 15); };
-
-    bf16x8 qf[KSTEPS];
-    {
-        const __bf16* qp = a.q + (long long)b * a.q_bs + (long long)q_row * a.q_ss + (long long)h * a.q_hs;
-#pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
-            int d = 16 * kk + 8 * hi;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (q_ok && d < a.D) v = ld16(qp + d);
-            qf[kk] = __builtin_bit_cast(bf16x8, v);
-        }
-    }
-    const __bf16* kp = a.k + (long long)b * a.k_bs + (long long)h * a.k_hs;
-    const __bf16* vp = a.vt + (long long)b * a.vt_bs + (long long)h * a.vt_hs;
-    const unsigned long long zero = (unsigned long long)g_attn_zero_page;
-
-    // per-lane constants of its DMA slots
-    int k_row[K_INSTR], k_col[K_INSTR];
-#pragma unroll
-    for (int i = 0; i < K_INSTR; ++i) {
-        int r = (wave * K_INSTR + i) * KRPI + lane / KCH;
-        k_row[i] = r;
-        k_col[i] = ((lane % KCH) ^ kswz(r)) * 8;       // source element offset that lands in this lane's slot
-    }
-    int v_row[V_INSTR], v_col[V_INSTR];
-#pragma unroll
-    for (int i = 0; i < V_INSTR; ++i) {
-        int d = (wave * V_INSTR + i) * 8 + (lane >> 3);
-        v_row[i] = d;
-        v_col[i] = ((lane & 7) ^ ((d >> 1) & 7)) * 8;
-    }
-    auto issue = [&](int kv0, int stage) {
-        char* kb = smem + stage * STAGE;
-        char* vb = kb + KBYTES;
-#pragma unroll
-        for (int i = 0; i < K_INSTR; ++i) {
-            int kv = kv0 + k_row[i];
-            bool ok = kv < a.Skv && k_col[i] < a.D;
-            int kvc = min(kv, a.Skv - 1);
-            int colc = min(k_col[i], a.D - 8);
-            unsigned long long real = (unsigned long long)(kp + (long long)kvc * a.k_ss + colc);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ok ? real : zero),
-                                             (__attribute__((address_space(3))) void*)(kb + (wave * K_INSTR + i) * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < V_INSTR; ++i) {
-            int kvc0 = kv0 + v_col[i];
-            bool ok = v_row[i] < a.D && kvc0 < skv_pad8;
-            int dc = min(v_row[i], a.D - 1);
-            int kc = min(kvc0, skv_pad8 - 8);
-            unsigned long long real = (unsigned long long)(vp + (long long)dc * a.vt_ds + kc);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ok ? real : zero),
-                                             (__attribute__((address_space(3))) void*)(vb + (wave * V_INSTR + i) * 1024), 16, 0, 0);
-        }
-    };
-
-    f32x16 o[DT];
-#pragma unroll
-    for (int i = 0; i < DT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    const int n_tiles = (a.Skv + kKvTile - 1) / kKvTile;
-    issue(0, 0);
-    if (n_tiles > 1) issue(kKvTile, 1);
-    // One KV tile.  MASKED is only instantiated for the drain iterations (the last tile may be ragged): with the
-    // bounds test in the main loop the compiler if-converted it into 32 compares + 32 selects per tile.
-    static_assert(DT % 2 == 0, "PV loop is unrolled by two row blocks");
-    auto read_v = [&](const char* vb, int dt, bf16x8 (&vf)[4]) {
-        const int row = 32 * dt + l31;
-        const char* rb = vb + row * VROW + 8 * hi;
-        const int sw = (row >> 1) & 7;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            // k-slots (hi, j') <-> kv 16ks + (j'&3) + 8(j'>>2) + 4hi: two 8-byte pieces of chunks 2ks and 2ks+1
-            // read as bf16 vectors, like the K fragments: an `unsigned`-typed LDS read after the LDS-DMA issue makes
-            // hipcc insert s_waitcnt vmcnt(0) (it may alias the DMA's destination under TBAA), which drained the
-            // whole 3-deep ring every tile
-            bf16x4 lo = *reinterpret_cast<const bf16x4*>(rb + (((2 * ks) ^ sw) << 4));
-            bf16x4 hi2 = *reinterpret_cast<const bf16x4*>(rb + (((2 * ks + 1) ^ sw) << 4));
-            vf[ks] = __builtin_shufflevector(lo, hi2, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
-    };
-    bf16x8 pf[4];
-    auto pv = [&](int dt, const bf16x8 (&vf)[4]) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[ks], pf[ks], o[dt], 0, 0, 0);
-    };
-    auto tile = [&](int kv0, int stage, auto masked_tag) {
-        constexpr bool MASKED = decltype(masked_tag)::value;
-        const char* kb = smem + stage * STAGE;
-        const char* vb = kb + KBYTES;
-        bf16x8 v0[4], v1[4];
-
-        // S^T = K Q^T: all K fragments first (one LDS latency per tile, not one per MFMA), then the MFMAs
-        bf16x8 kf[2][KSTEPS];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int row = 32 * t + l31;
-#pragma unroll
-            for (int kk = 0; kk < KSTEPS; ++kk)
-                kf[t][kk] = *reinterpret_cast<const bf16x8*>(kb + row * KROW + (((2 * kk + hi) ^ kswz(row)) << 4));
-        }
-        f32x16 s[2];
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
-#pragma unroll
-            for (int kk = 0; kk < KSTEPS; ++kk)
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][kk], qf[kk], s[t], 0, 0, 0);
-        }
-        __builtin_amdgcn_s_setprio(0);
-        read_v(vb, 0, v0);                             // first V^T block: its LDS latency hides under the softmax
-        if (MASKED) {
-            if (kv0 + kKvTile > a.Skv) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int kv = kv0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        if (kv >= a.Skv) s[t][r] = -INFINITY;
-                    }
-            }
-        }
-        float mx = s[0][0];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32)) * a.scale_log2;
-        float m_new = m_run, alpha = 1.0f;
-        const bool rescale = !__all(mx <= m_run + 8.0f);
-        if (rescale) {
-            m_new = fmaxf(m_run, mx);
-            alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        }
-        float psum = 0.f;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(s[t][r] * a.scale_log2 - m_new);
-                s[t][r] = p;
-                psum += p;
-            }
-        if (rescale) {
-            l_run *= alpha;
-#pragma unroll
-            for (int i = 0; i < DT; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-        }
-        l_run += psum;
-        m_run = m_new;
-
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int t = ks >> 1, u = ks & 1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                f32x2 two = {s[t][8 * u + 2 * e], s[t][8 * u + 2 * e + 1]};
-                bf16x2 pk = __builtin_convertvector(two, bf16x2);
-                pf[ks][2 * e] = pk[0];
-                pf[ks][2 * e + 1] = pk[1];
-            }
-        }
-        // O^T += V^T P^T, 32 output rows (dt) at a time; the fragments of block dt+1 are read while block dt multiplies
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int dt = 0; dt < DT; dt += 2) {
-            read_v(vb, dt + 1, v1);
-            pv(dt, v0);
-            if (dt + 2 < DT) read_v(vb, dt + 2, v0);
-            pv(dt + 1, v1);
-        }
-        __builtin_amdgcn_s_setprio(0);
-    };
-
-    // main loop: full tiles, each issuing the DMAs of tile j+2; drain: the last (up to) two tiles, nothing to issue.
-    // Separate loops so that each body gets one accumulator register set (see conv.hip).
-    int stage = 0, j = 0;
-    for (; j + 2 < n_tiles; ++j) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-        __builtin_amdgcn_s_barrier();
-        int st2 = stage + 2; if (st2 >= 3) st2 -= 3;
-        issue((j + 2) * kKvTile, st2);
-        tile(j * kKvTile, stage, std::false_type{});
-        stage = stage + 1; if (stage >= 3) stage = 0;
-    }
-    for (; j < n_tiles; ++j) {
-        if (j + 1 < n_tiles) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        tile(j * kKvTile, stage, std::true_type{});
-        stage = stage + 1; if (stage >= 3) stage = 0;
-    }
-
-    float l_tot = l_run + __shfl_xor(l_run, 32);
-    float inv = 1.0f / l_tot;
-    if (q_ok) {
-        __bf16* op = a.out + (long long)b * a.o_bs + (long long)q_row * a.o_ss + (long long)h * a.o_hs;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                int d = 32 * dt + 8 * g + 4 * hi;
-                if (d < a.D) {
-                    f32x2 x0 = {o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv};
-                    f32x2 x1 = {o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
-                    bf16x2 y0 = __builtin_convertvector(x0, bf16x2), y1 = __builtin_convertvector(x1, bf16x2);
-                    bf16x4 y = {y0[0], y0[1], y1[0], y1[1]};
-                    *reinterpret_cast<bf16x4*>(op + d) = y;
-                }
-            }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Variant 3 (DP = 64 or 128): same decomposition (4 waves x 32 query rows, 64-kv tiles, 3-stage LDS-DMA ring) with
 // the per-tile instruction stream cut from ~290 to ~150 non-MFMA instructions -- the kernel is bound by VALU issue
 // beside the MFMAs (rocprofv3 round 1: 218 M VALU instructions against 503 M MFMA-busy cycles, SQ_WAIT_INST_ANY 46 %):
@@ -503,7 +236,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd_dma(AttnArgs a) {
 //    no address arithmetic, clamps, selects or zero page in the loop (was ~50 VALU + 12 SALU per tile);
 //  * K rows land in LDS with bits 2 and 3 of the row index swapped, which makes the accumulator order of S^T the NATURAL
 //    k order of the P.V product: V^T fragments are single ds_read_b128 (was two ds_read_b64 each);
-//  * PRESCALE: Q is multiplied by scale*log2(e) once in the prologue (one extra bf16 rounding of Q) and the running
+//  * Q is multiplied by scale*log2(e) once in the prologue (one extra bf16 rounding of Q) and the running
 //    maximum enters through the MFMA's C operand (S' = K.Q'^T - m), so the softmax numerator is a bare v_exp_f32 per
 //    element: no multiply, no subtract;
 //  * the running maximum is only revised when some row outgrows it by more than 2^8 (as before); the revision path
@@ -511,9 +244,9 @@ __global__ __launch_bounds__(256) void k_attn_fwd_dma(AttnArgs a) {
 __device__ __forceinline__ int attn_swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
 // VLATE: the V^T fragments are read inside the P.V loop (16 VGPRs at a time) instead of ahead of the softmax (32 VGPRs
-// across it); with PRESCALE that is the difference between 2 and 3 resident waves per SIMD.
-template <int DP, bool PRESCALE, bool VLATE, bool PIPE>
-__global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(AttnArgs a) {
+// across it): the difference between 2 and 3 resident waves per SIMD.
+template <int DP, bool VLATE>
+__global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // __amdgpu_buffer_rsrc_t does not exist in the host pass (the stub needs no body)
     static_assert(DP == 64 || DP == 128, "power-of-two row sizes only");
     constexpr int KSTEPS = DP / 16, DT = DP / 32;
@@ -521,7 +254,7 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
     constexpr int KBYTES = kKvTile * KROW, VBYTES = DP * VROW, STAGE = KBYTES + VBYTES;
     constexpr int KCH = KROW / 16, KRPI = 64 / KCH, K_INSTR = kKvTile / KRPI / 4, V_INSTR = DP / 8 / 4;
     constexpr int L = K_INSTR + V_INSTR;
-    constexpr int NST = PIPE ? 4 : 3;                   // LDS ring depth (the pipelined form needs K one iteration earlier)
+    constexpr int NST = 3;                               // LDS ring depth
     constexpr int OOB = 0x40000000;                     // beyond any num_records the launcher admits
     constexpr float THR = 8.0f;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -564,7 +297,7 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
             uint4 v = make_uint4(0, 0, 0, 0);
             if (q_ok && d < a.D) v = ld16(qp + d);
             qf[kk] = __builtin_bit_cast(bf16x8, v);
-            if (PRESCALE) {
+            {
 #pragma unroll
                 for (int e = 0; e < 8; e += 2) {
                     f32x2 two = {(float)qf[kk][e] * a.scale_log2, (float)qf[kk][e + 1] * a.scale_log2};
@@ -620,10 +353,10 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
     for (int i = 0; i < DT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    f32x16 cinit;                                        // C operand of the first S^T MFMA: -m (PRESCALE) or 0
+    f32x16 cinit;                                        // C operand of the first S^T MFMA: -m
 #pragma unroll
     for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
-    float m_run = 0.f, l_run = 0.f;                      // PRESCALE: cinit == -m_run at all times
+    float m_run = 0.f, l_run = 0.f;                      // cinit == -m_run at all times
     bf16x8 pf[4];
 
     // S^T = K.Q^T (+ C operand) of the tile in `stage`
@@ -638,7 +371,7 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
         };
         read_k(0);
         if (!VLATE) read_k(1);
-        if (!PIPE) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (VLATE && t == 0) read_k(1);
@@ -647,11 +380,10 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
             for (int kk = 1; kk < KSTEPS; ++kk)
                 s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][kk], qf[kk], s[t], 0, 0, 0);
         }
-        if (!PIPE) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
     };
-    // softmax of tile j (scores in `s`) and O^T += V^T.P^T.  PIPE: `sn` holds the scores of tile j+1, computed against the
-    // C operand as it was BEFORE this tile's possible re-base -- the re-base path shifts them as well.
-    auto softmax_pv = [&](int j, int stage, bool first, f32x16 (&s)[2], f32x16 (&sn)[2], bool have_next, auto masked_tag) {
+    // softmax of tile j (scores in `s`) and O^T += V^T.P^T
+    auto softmax_pv = [&](int j, int stage, bool first, f32x16 (&s)[2], auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         const char* vb = smem + stage * STAGE + KBYTES;
         bf16x8 vf[DT][4];
@@ -678,7 +410,7 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
                     }
             }
         }
-        // ---- row maximum of this tile (relative to the running maximum when PRESCALE): four independent chains
+        // ---- row maximum of this tile (relative to the running maximum): four independent chains
         float mq[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) mq[c] = fmaxf(s[0][c], s[1][c]);
@@ -687,7 +419,7 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
         float mx = fmaxf(fmaxf(mq[0], mq[1]), fmaxf(mq[2], mq[3]));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         float ps[4] = {0.f, 0.f, 0.f, 0.f};            // four independent partial row sums (a single chain of 32 dependent adds stalls)
-        if (PRESCALE) {
+        {
             if (first || !__all(mx <= THR)) {            // wave-uniform; the previous tile's P.V is complete
                 const float delta = first ? mx : fmaxf(mx, 0.f);
                 const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
@@ -699,36 +431,12 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
                     for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { s[0][r] -= delta; s[1][r] -= delta; cinit[r] = -m_run; }
-                if (PIPE && have_next) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { sn[0][r] -= delta; sn[1][r] -= delta; }
-                }
             }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float p = __builtin_amdgcn_exp2f(s[t][r]);
-                    s[t][r] = p;
-                    ps[r & 3] += p;
-                }
-        } else {
-            mx *= a.scale_log2;
-            if (first || !__all(mx <= m_run + THR)) {
-                const float m_new = first ? mx : fmaxf(m_run, mx);
-                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(m_run - m_new);
-                m_run = m_new;
-                l_run *= alpha;
-#pragma unroll
-                for (int i = 0; i < DT; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-            }
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[t][r], a.scale_log2, -m_run));
                     s[t][r] = p;
                     ps[r & 3] += p;
                 }
@@ -760,12 +468,9 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
     // prologue: tiles 0 and 1 (the last tile of the sequence is always issued through the guarded form)
     if (n_tiles == 1) issue(0, 0, std::true_type{}); else issue(0, 0, std::false_type{});
     if (n_tiles == 2) issue(1, 1, std::true_type{}); else if (n_tiles > 2) issue(1, 1, std::false_type{});
-    if (PIPE) {
-        if (n_tiles == 3) issue(2, 2, std::true_type{}); else if (n_tiles > 3) issue(2, 2, std::false_type{});
-    }
     int stage = 0, j = 0;
-    f32x16 sA[2], sB[2];
-    if (!PIPE) {
+    f32x16 sA[2];
+    {
         // main loop: tile j computes while tiles j+1, j+2 are in flight; every tile touched here is a full one
         for (; j + 3 < n_tiles; ++j) {
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
@@ -773,7 +478,7 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
             int st2 = stage + 2; if (st2 >= 3) st2 -= 3;
             issue(j + 2, st2, std::false_type{});
             qk(stage, sA);
-            softmax_pv(j, stage, j == 0, sA, sA, false, std::false_type{});
+            softmax_pv(j, stage, j == 0, sA, std::false_type{});
             stage = stage + 1; if (stage >= 3) stage = 0;
         }
         // tail: at most three tiles; issues the (possibly ragged) last tile guarded, masks the last tile
@@ -786,174 +491,8 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
                 issue(j + 2, st2, std::true_type{});
             }
             qk(stage, sA);
-            softmax_pv(j, stage, j == 0, sA, sA, false, std::true_type{});
+            softmax_pv(j, stage, j == 0, sA, std::true_type{});
             stage = stage + 1; if (stage >= 3) stage = 0;
-        }
-    } else {
-        // Two-phase software pipeline (PRESCALE only): every MFMA of the loop is issued with independent VALU work behind it.
-        //   phase A:  S^T(j+1) = K(j+1).Q'^T   [8 MFMAs]  beside  exp / row-sum / bf16 convert of tile j   (-> P(j))
-        //   phase B:  O^T += V^T(j).P(j)^T      [8 MFMAs]  beside  the row maximum of tile j+1
-        // so the re-base decision of tile j+1 (needs its maximum) is ready at the top of the next iteration, before that
-        // tile's exponentials and before S^T(j+2) is started against the then-current C operand.  Two named score register
-        // sets alternate (no copies).  `sched_barrier(0)` pins one MFMA + its slice of VALU work per region: an in-order wave
-        // can only overlap the two pipes if they alternate in program order.
-        // K(j+1) must have landed one iteration early: loads are issued K first, V^T second, so waiting for all but the
-        // newest V_INSTR of them leaves only V^T(j+1) in flight.
-        static_assert(!PIPE || (PRESCALE && DP == 64), "pipelined form: D = 64 with the prologue Q scaling");
-        auto mask_tile = [&](int jt, f32x16 (&s)[2]) {
-            if ((jt + 1) * kKvTile > a.Skv) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int kv = jt * kKvTile + 32 * t + 16 * (r >> 3) + 8 * hi + 4 * ((r >> 2) & 1) + (r & 3);
-                        if (kv >= a.Skv) s[t][r] = -INFINITY;
-                    }
-            }
-        };
-        auto row_max = [&](const f32x16 (&s)[2]) {
-            float mq[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) mq[c] = fmaxf(s[0][c], s[1][c]);
-#pragma unroll
-            for (int r = 4; r < 16; ++r) mq[r & 3] = fmaxf(fmaxf(mq[r & 3], s[0][r]), s[1][r]);
-            const float mx = fmaxf(fmaxf(mq[0], mq[1]), fmaxf(mq[2], mq[3]));
-            return fmaxf(mx, __shfl_xor(mx, 32));
-        };
-        if (n_tiles > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");      // tiles 1, 2 may still be in flight
-        else if (n_tiles > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        qk(0, sA);
-        if (n_tiles == 1) mask_tile(0, sA);
-        float mx_cur = row_max(sA);
-        auto iter = [&](f32x16 (&cur)[2], f32x16 (&nxt)[2], auto tail_tag) {
-            constexpr bool TAIL = decltype(tail_tag)::value;
-            const bool have_next = !TAIL || j + 1 < n_tiles;
-            // needed now: all of tile j and K(j+1).  Issue order is K, V^T per tile, so in the steady state everything except
-            // V^T(j+1) and tile j+2 (issued one iteration ago) must have landed; the tail waits more than necessary
-            if (!TAIL) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V_INSTR + L) : "memory");
-            else if (have_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(V_INSTR) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            const int st1 = (stage + 1) & 3, st3 = (stage + 3) & 3;
-            if (!TAIL) issue(j + 3, st3, std::false_type{});
-            else if (j + 3 < n_tiles) issue(j + 3, st3, std::true_type{});
-            // ---- K fragments of tile j+1 (their LDS latency hides under the re-base test and the first exponentials)
-            const char* kb = smem + st1 * STAGE;
-            const char* vb = smem + stage * STAGE + KBYTES;
-            bf16x8 kf[2][KSTEPS];
-            auto read_k = [&](int t) {
-                const int row = 32 * t + l31;
-#pragma unroll
-                for (int kk = 0; kk < KSTEPS; ++kk)
-                    kf[t][kk] = *reinterpret_cast<const bf16x8*>(kb + row * KROW + (((2 * kk + hi) ^ kswz(row)) << 4));
-            };
-            auto read_v = [&](bf16x8 (&vf)[4], int dt) {
-                const int row = 32 * dt + l31, sw = (row >> 1) & 7;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    vf[ks] = *reinterpret_cast<const bf16x8*>(vb + row * VROW + (((2 * ks + hi) ^ sw) << 4));
-            };
-            if (have_next) read_k(0);
-            // ---- re-base of tile j (rare, wave-uniform): nothing of tile j+1 exists yet, so only tile j's scores move
-            const bool first = j == 0;
-            if (first || !__all(mx_cur <= THR)) {
-                const float delta = first ? mx_cur : fmaxf(mx_cur, 0.f);
-                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
-                m_run += delta;
-                l_run *= alpha;
-#pragma unroll
-                for (int i = 0; i < DT; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { cur[0][r] -= delta; cur[1][r] -= delta; cinit[r] = -m_run; }
-            }
-            // ---- phase A
-            float ps[4] = {0.f, 0.f, 0.f, 0.f};
-            bf16x8 vf0[4], vf1[4];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int t = i >> 2, q4 = i & 3;
-                if (have_next) {
-                    if (i == 3) read_k(1);                // second half's fragments: needed from slice 4 on
-                    if (q4 == 0) {
-                        // chain head: D = nxt[t], C = the (loop-invariant) C-operand vector.  Through the builtin hipcc ties D
-                        // to C and first COPIES the 16 registers (32 v_mov per tile); the instruction itself takes distinct
-                        // registers.  The next MFMA of the chain reads exactly this D as its C: no wait states needed.
-                        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(nxt[t]) : "v"(kf[t][0]), "v"(qf[0]), "v"(cinit));
-                    } else {
-                        nxt[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][q4], qf[q4], nxt[t], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float pexp = __builtin_amdgcn_exp2f(cur[t][4 * q4 + c]);
-                    cur[t][4 * q4 + c] = pexp;
-                    ps[c] += pexp;
-                }
-                {   // registers 4*q4 .. +3 of tile half t are k-slots e = 4*(q4&1) .. +3 of k-step ks = 2t + (q4>>1)
-                    const int ks = 2 * t + (q4 >> 1), e0 = 4 * (q4 & 1);
-                    f32x2 lo = {cur[t][4 * q4], cur[t][4 * q4 + 1]}, hi2 = {cur[t][4 * q4 + 2], cur[t][4 * q4 + 3]};
-                    bf16x2 plo = __builtin_convertvector(lo, bf16x2), phi = __builtin_convertvector(hi2, bf16x2);
-                    pf[ks][e0] = plo[0]; pf[ks][e0 + 1] = plo[1]; pf[ks][e0 + 2] = phi[0]; pf[ks][e0 + 3] = phi[1];
-                }
-                if (i == 7) read_v(vf0, 0);               // V^T fragments of tile j: first 32 output rows
-                // keep the four row-sum chains where they are: left alone, the SLP vectoriser gathers all 32 adds into 16
-                // v_pk_add_f32 behind the last slice, where no MFMA covers them
-                asm volatile("" : "+v"(ps[0]), "+v"(ps[1]), "+v"(ps[2]), "+v"(ps[3]));
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
-            // ---- phase B
-            if (TAIL && have_next) mask_tile(j + 1, nxt);
-            float mq[4];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int dt = i >> 2, ks = i & 3;
-                if (i == 2) read_v(vf1, 1);
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dt == 0 ? vf0[ks] : vf1[ks], pf[ks], o[dt], 0, 0, 0);
-                if (have_next) {                          // registers 2i, 2i+1 of both halves per slice; four chains
-                    const int r = 2 * i;
-                    if (i < 2) {
-                        mq[r & 3] = fmaxf(nxt[0][r], nxt[1][r]);
-                        mq[(r + 1) & 3] = fmaxf(nxt[0][r + 1], nxt[1][r + 1]);
-                    } else {
-                        mq[r & 3] = fmaxf(fmaxf(mq[r & 3], nxt[0][r]), nxt[1][r]);
-                        mq[(r + 1) & 3] = fmaxf(fmaxf(mq[(r + 1) & 3], nxt[0][r + 1]), nxt[1][r + 1]);
-                    }
-                    // opaque to the re-association pass, which otherwise rebuilds the max tree behind the last MFMA
-                    asm volatile("" : "+v"(mq[r & 3]), "+v"(mq[(r + 1) & 3]));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (have_next) {
-                const float mx = fmaxf(fmaxf(mq[0], mq[1]), fmaxf(mq[2], mq[3]));
-                mx_cur = fmaxf(mx, __shfl_xor(mx, 32));
-            }
-            stage = st1;
-            ++j;
-        };
-        while (j + 5 < n_tiles) {                        // two full tiles per trip (iter advances j): named register sets
-            iter(sA, sB, std::false_type{});
-            iter(sB, sA, std::false_type{});
-        }
-        // Tail (the last tiles, at most five; also whole short sequences): leave the pipeline and finish with the plain
-        // tile-at-a-time form.  sA holds the scores of tile j (S^T already formed against the current C operand); the tiles
-        // issued so far reach min(n_tiles, j + 3).  A pipelined tail would need both register sets live across its
-        // run-time branches and spilled ~70 dwords per iteration: slower than the whole main loop on 64-tile sequences.
-        for (bool have_scores = true; j < n_tiles; ++j, have_scores = false) {
-            const int newer = min(n_tiles, j + 3) - (j + 1);            // issued tiles younger than tile j: 0, 1 or 2
-            if (newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");
-            else if (newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (j + 3 < n_tiles) issue(j + 3, (stage + 3) & 3, std::true_type{});
-            if (!have_scores) qk(stage, sA);
-            else if (j + 1 == n_tiles) { /* masked inside softmax_pv */ }
-            softmax_pv(j, stage, j == 0, sA, sA, false, std::true_type{});
-            stage = (stage + 1) & 3;
         }
     }
 
@@ -978,12 +517,12 @@ __global__ __launch_bounds__(256, (VLATE && !PIPE) ? 3 : 2) void k_attn_fwd_v3(A
 #endif
 }
 
-template <int DP, bool PRESCALE, bool VLATE, bool PIPE>
+template <int DP, bool VLATE>
 int launch_attn_v3(const AttnArgs& a, hipStream_t stream) {
-    constexpr int LDS = (PIPE ? 4 : 3) * (kKvTile * DP * 2 + DP * kKvTile * 2);
+    constexpr int LDS = 3 * (kKvTile * DP * 2 + DP * kKvTile * 2);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_fwd_v3<DP, PRESCALE, VLATE, PIPE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_fwd_v3<DP, VLATE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -991,54 +530,39 @@ int launch_attn_v3(const AttnArgs& a, hipStream_t stream) {
     const long long n_blocks = (long long)dm_div_up(a.Sq, kWaves * kQRowsPerWave) * a.B * a.Hh;
     if (n_blocks > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
     DM_ENTER();
-    hipLaunchKernelGGL((k_attn_fwd_v3<DP, PRESCALE, VLATE, PIPE>), dim3((unsigned)n_blocks), dim3(256), LDS, stream, a);
+    hipLaunchKernelGGL((k_attn_fwd_v3<DP, VLATE>), dim3((unsigned)n_blocks), dim3(256), LDS, stream, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? DM_OK : (int)e;
 }
 
+// Kernel families: "auto" (default: the dispatch below), or one family forced for A/B runs and the parity tests --
+//   "w64"    one wave per SIMD, 256 query rows per workgroup (attn_w64.hip): 64-wide heads, whole 64-row kv tiles
+//   "v3l"    4 waves x 32 query rows, LDS-DMA ring (k_attn_fwd_v3): D <= 64 or 96 < D <= 128, any sequence lengths
+//   "staged" register-staged generic kernel (k_attn_fwd): any D <= 160 (the SD-1.5 heads of 40 / 80 / 160)
+// A forced family falls through to the next one when a shape is outside its domain.
+enum { kAttnAuto = 0, kAttnW64 = 1, kAttnV3l = 2, kAttnStaged = 3 };
 static int g_attn_mode = -1;
 static int attn_mode_from_name(const char* e) {
-    if (!e || !strcmp(e, "v3l")) return 4;
-    if (!strcmp(e, "w64")) return 6;
-    if (!strcmp(e, "w64m")) return 7;
-    if (!strcmp(e, "v3")) return 3;
-    if (!strcmp(e, "v3p")) return 5;
-    if (!strcmp(e, "v3s")) return 2;
-    if (!strcmp(e, "dma")) return 1;
-    if (!strcmp(e, "staged")) return 0;
+    if (!e || !strcmp(e, "auto")) return kAttnAuto;
+    if (!strcmp(e, "w64")) return kAttnW64;
+    if (!strcmp(e, "v3l")) return kAttnV3l;
+    if (!strcmp(e, "staged")) return kAttnStaged;
     return -1;
 }
 static int attn_mode() {
     if (g_attn_mode < 0) {
         g_attn_mode = attn_mode_from_name(getenv("DREAMMAT_ATTN_KERNEL"));
-        if (g_attn_mode < 0) g_attn_mode = 4;           // v3l: best or equal on every UNet shape (tools/r2_probe.py)
+        if (g_attn_mode < 0) g_attn_mode = kAttnAuto;
     }
     return g_attn_mode;
 }
+static const char* const kAttnNames[] = {"auto", "w64", "v3l", "staged"};
 
 // the buffer-descriptor DMA addresses one (batch, head) operand with 32-bit byte offsets
 static bool attn_v3_ok(const AttnArgs& a) {
     const long long skv_pad8 = (a.Skv + 7) & ~7;
     const long long kb = (((long long)a.Skv + kKvTile) * a.k_ss + a.D) * 2, vb = (((long long)a.D - 1) * a.vt_ds + skv_pad8 + kKvTile) * 2;
     return kb < 0x40000000LL && vb < 0x40000000LL && a.k_ss >= a.D && a.vt_ds >= skv_pad8;
-}
-
-template <int DP>
-int launch_attn_dma(const AttnArgs& a, hipStream_t stream) {
-    constexpr int LDS = 3 * (kKvTile * DP * 2 + DP * kKvTile * 2);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_fwd_dma<DP>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
-    const long long n_blocks = (long long)dm_div_up(a.Sq, kWaves * kQRowsPerWave) * a.B * a.Hh;
-    if (n_blocks > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
-    DM_ENTER();
-    hipLaunchKernelGGL(k_attn_fwd_dma<DP>, dim3((unsigned)n_blocks), dim3(256), LDS, stream, a);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? DM_OK : (int)e;
 }
 
 template <int DP>
@@ -1063,9 +587,9 @@ int launch_attn(const AttnArgs& a, hipStream_t stream) {
 
 extern "C" {
 
-// Selects the attention kernel variant by name ("v3", "v3l", "v3s", "dma", "staged"; NULL = environment / default) for
+// Selects the attention kernel family by name ("auto", "w64", "v3l", "staged"; NULL = DREAMMAT_ATTN_KERNEL / "auto") for
 // every later dm_attention_fwd_bf16 call of the process.  Returns DM_OK or DM_ERR_ARG for an unknown name.  Meant for
-// A/B measurements and for the parity tests, which run every variant.
+// A/B measurements and for the parity tests, which run every family.
 int dm_attention_select(const char* name) {
     if (!name) { g_attn_mode = -1; return DM_OK; }
     const int m = attn_mode_from_name(name);
@@ -1073,6 +597,9 @@ int dm_attention_select(const char* name) {
     g_attn_mode = m;
     return DM_OK;
 }
+
+// Name of the family the next dm_attention_fwd_bf16 call dispatches from (what dm_attention_select / the environment chose).
+const char* dm_attention_selected(void) { return kAttnNames[attn_mode()]; }
 
 // q   [B, Sq, Hh, D]  via strides (q_bs, q_ss, q_hs), d contiguous
 // k   [B, Skv, Hh, D] via strides
@@ -1096,31 +623,18 @@ int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* ou
     a.vt_bs = vt_bs; a.vt_hs = vt_hs; a.vt_ds = vt_ds; a.o_bs = o_bs; a.o_ss = o_ss; a.o_hs = o_hs;
     a.B = B; a.Hh = Hh; a.Sq = Sq; a.Skv = Skv; a.D = D;
     a.scale_log2 = scale * 1.4426950408889634f;
-    // Kernel choice: dm_attention_select() / DREAMMAT_ATTN_KERNEL = v3l (default: prologue Q scaling, late fragment reads,
-    // 3 waves per SIMD) | v3 (early fragment reads, 2 waves per SIMD) | v3p (two-phase software pipeline for Skv >= 1024, v3l below) |
-    // v3s (v3 without the Q scaling) | dma (round-1 kernel) | staged
-    // (register-staged): A/B measurements and regression tests.  D = 40/80/160 heads always use the staged kernel.
-    int mode = attn_mode();
-    if (mode >= 6) {
-        // one wave per SIMD, 256 query rows per workgroup (attn_w64.hip): whole 64-row kv tiles of 64-wide heads; short
-        // query sequences (one wave of four would work) and everything else stay with the v3l kernel
-        if (attn_w64_ok(a) && a.Sq >= 128) return launch_attn_w64(a, mode - 6, stream);
-        mode = 4;
-    }
-    if (mode >= 2 && attn_v3_ok(a) && (D <= 64 || (D > 96 && D <= 128))) {
-        if (D <= 64) {
-            // the pipelined form pays off on long sequences; its (register-starved) tail handles the last four tiles
-            if (mode == 5 && a.Skv >= 16 * kKvTile) return launch_attn_v3<64, true, true, true>(a, stream);
-            if (mode == 5) return launch_attn_v3<64, true, true, false>(a, stream);
-            if (mode == 4) return launch_attn_v3<64, true, true, false>(a, stream);
-            return mode == 3 ? launch_attn_v3<64, true, false, false>(a, stream) : launch_attn_v3<64, false, false, false>(a, stream);
-        }
-        return mode == 2 ? launch_attn_v3<128, false, false, false>(a, stream) : launch_attn_v3<128, true, false, false>(a, stream);
-    }
-    const bool use_dma = mode >= 1;
-    if (D <= 64) return use_dma ? launch_attn_dma<64>(a, stream) : launch_attn<64>(a, stream);
+    a.timeline = nullptr;
+    const int mode = attn_mode();
+    // auto: the one-wave-per-SIMD kernel wherever a workgroup's 256 query rows are (nearly) filled and the sequence is long
+    // enough to amortise its prologue (S >= 1024: 756 vs 738 TF/s at S = 1024, 1021 vs 980 at 4096, 981 vs 780 at batch 3;
+    // v3l wins at S = 256: 375 vs 343, profiles/r03_probe_attn.json); cross-attention (77 keys) and short sequences: v3l
+    if (mode <= kAttnW64 && attn_w64_ok(a) && (mode == kAttnW64 ? a.Sq >= 128 : (a.Sq >= 1024 && a.Skv >= 1024)))
+        return launch_attn_w64(a, stream);
+    if (mode <= kAttnV3l && attn_v3_ok(a) && (D <= 64 || (D > 96 && D <= 128)))
+        return D <= 64 ? launch_attn_v3<64, true>(a, stream) : launch_attn_v3<128, false>(a, stream);
+    if (D <= 64) return launch_attn<64>(a, stream);
     if (D <= 96) return launch_attn<96>(a, stream);
-    if (D <= 128) return use_dma ? launch_attn_dma<128>(a, stream) : launch_attn<128>(a, stream);
+    if (D <= 128) return launch_attn<128>(a, stream);
     return launch_attn<160>(a, stream);
 }
 

@@ -20,10 +20,11 @@ struct AttnArgs {
     long long o_bs, o_ss, o_hs;
     int B, Hh, Sq, Skv, D;
     float scale_log2;                 // softmax scale * log2(e)
+    unsigned long long* timeline;     // DREAMMAT_ATTN_TIMELINE (development): s_memtime stamps of the w64 kernel, else null
 };
 
-// attn_w64.hip: the one-wave-per-SIMD kernel (D = 64, Skv % 64 == 0).  `variant` bit 0: row sums on the matrix pipe.
+// attn_w64.hip: the one-wave-per-SIMD kernel (D = 64, Skv % 64 == 0)
 bool attn_w64_ok(const AttnArgs& a);
-int launch_attn_w64(const AttnArgs& a, int variant, hipStream_t stream);
+int launch_attn_w64(const AttnArgs& a, hipStream_t stream);
 
 }  // namespace dm_attn

@@ -9,7 +9,14 @@
 //   * every K / V^T fragment read from LDS multiplies against both query blocks (LDS reads per MFMA halved);
 //   * one instruction stream per SIMD, software-pipelined by hand: while the MFMAs of S^T(j+1) = K(j+1).Q^T and of
 //     O^T += V^T(j).P(j)^T run, the same wave issues the exponentials / sums / bf16 packs of tile j, two scores per MFMA slot
-//     ("chunk"), pinned with sched_barrier so that the in-order wave alternates the two pipes;
+//     ("chunk"), pinned with sched_barrier so that the in-order wave alternates the two pipes.  tools/issue_probe.cpp prices
+//     that chunk alone at 37.6 cycles (v_exp_f32 9.4, v_add_f32 5.5, v_cvt_pk 6.4 per instruction from one wave; 5 plain VALU
+//     hide behind a 32-cycle MFMA, two exponentials and three do not), i.e. 1203 cycles per tile against 1024 of MFMA; the
+//     kernel measures 1808 (s_memtime, DREAMMAT_ATTN_TIMELINE): the other ~600 are the 16 fragment reads, 4 LDS-DMA issues,
+//     address / ring arithmetic and the per-tile barrier;
+//   * ONE score register set: the first kv half of tile j+1 is formed in the second half of tile j, into the registers whose
+//     scores have just been packed, the second half of tile j in its own first half -- 64 instead of 128 VGPRs, which is what
+//     lets everything VALU-addressable fit the 256 architectural VGPRs without spills;
 //   * the fragments are re-loaded just in time: a K fragment register is refilled with tile j+2's data right after its last
 //     use for tile j+1 (V^T likewise), so no LDS latency is ever exposed and no second fragment set is needed;
 //   * NO row maximum in the loop.  softmax is shift-invariant, so any per-row shift m works as long as nothing overflows:
@@ -19,11 +26,15 @@
 //     O, l, the C operand and the already formed S'(j+1).  A row whose scores outgrow the first tile's maximum by more than
 //     ~2^100 between two checks is caught by a finiteness test and the WHOLE workgroup redoes its block with the textbook
 //     online softmax (exact path below; tests force it);
-//   * row sums either as f32 adds (2 chains per block) or, MSUM, on the matrix pipe: v_mfma_f32_4x4x4_16b_bf16 with an
-//     all-ones A operand adds the four packed probabilities of each lane into a per-lane accumulator in one issue slot;
+//   * row sums as f32 adds, two chains per query block.  Measured and dropped: the sums on the matrix pipe (two
+//     v_mfma_f32_16x16x32_bf16 per packed slice against a 0/1 A operand: 34 instructions fewer per tile, 2 % SLOWER; a
+//     v_mfma_f32_4x4x4_16b_bf16 form 15 % slower) -- the small MFMAs serialise with the 32x32 ones they sit between;
 //   * O leaves through LDS as whole 128-byte rows (16 B per lane) instead of 8-byte pieces at a row stride.
 // Layouts (K rows with index bits 2/3 swapped, XOR-swizzled 16 B chunks, accumulator order == B-operand order of the
 // second product) are those of attention.hip's k_attn_fwd_v3; tests/mfma_sim.py models them on the CPU.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "attn_common.h"
@@ -39,7 +50,7 @@ constexpr int kRowsPerWg = 256;
 
 __device__ __forceinline__ int swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
-template <int PD, bool MSUM>
+template <int PD>
 __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // (__amdgpu_buffer_rsrc_t does not exist in the host pass)
     constexpr int NST = PD + 3;        // ring: tiles j (V^T) .. j+2+PD, and the DMA target is the stage tile j-1 left an iteration ago
@@ -47,6 +58,10 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto stamp = [&](int i) {        // development aid: four s_memtime stamps per wave (entry, loop start, loop end, exit)
+        if (a.timeline && lane == 0 && blockIdx.x < 1024) a.timeline[((long long)blockIdx.x * 4 + wave) * 4 + i] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
     // 1-D grid, XCD-aware: all query blocks of one (batch, head) run on one XCD (its K / V^T are fetched from HBM once)
     int bh, qblk;
     {
@@ -101,19 +116,20 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
         v_voff[i] = (int)(((long long)d * a.vt_ds + col) * 2);
     }
     const int k_tile_bytes = (int)(a.k_ss * 2 * kTile);
-    auto issue = [&](int tile, int stage) {
+    // piece 0, 1: this wave's two 1 KiB slices of the K tile; 2, 3: of the V^T tile
+    auto issue_piece = [&](int tile, int stage, int i) {
         const int tc = min(tile, n_tiles - 1);            // tiles past the end re-fetch the last one (keeps the vmcnt counts
-        const int ks = tc * k_tile_bytes, vs = tc * (kTile * 2);   // uniform; their stage is never read)
-        char* kb = smem + stage * kStage;
-        char* vb = kb + kKBytes;
+        char* sb = smem + stage * kStage;                 // uniform; their stage is never read)
+        if (i < 2)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)(sb + (wave * 2 + i) * 1024),
+                                                     16, k_voff[i], tc * k_tile_bytes, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (__attribute__((address_space(3))) void*)(sb + kKBytes + (wave * 2 + i - 2) * 1024),
+                                                     16, v_voff[i - 2], tc * (kTile * 2), 0, 0);
+    };
+    auto issue = [&](int tile, int stage) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)(kb + (wave * 2 + i) * 1024),
-                                                     16, k_voff[i], ks, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, (__attribute__((address_space(3))) void*)(vb + (wave * 2 + i) * 1024),
-                                                     16, v_voff[i], vs, 0, 0);
+        for (int i = 0; i < 4; ++i) issue_piece(tile, stage, i);
     };
     // fragment addresses inside a stage: K (t, kk) at t*4096 + off4[kk], V^T (dt, ks) at 8192 + dt*4096 + off4[ks]
     int off4[4];
@@ -129,33 +145,33 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
         for (int d = 0; d < 2; ++d)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[i][d][r] = 0.f;
-    f32x16 sA[2][2], sB[2][2];       // scores [query block][kv half], two sets alternating between tiles
+    f32x16 s[2][2];                  // scores [query block][kv half] -- ONE set: half t = 0 of tile j+1 is formed while half
+                                     // t = 1 of tile j is consumed, and the other way round (see tile_body)
     f32x16 cin[2];                   // C operand of the first QK^T MFMA of a chain: -m of the lane's row, in all 16 registers
     bf16x8 kf[8], vf[2][4], pf[2];   // K fragments (t*4+kk), V^T fragments [dt][ks], packed P of the slice in flight (two buffers)
     float lA[2] = {0.f, 0.f}, lB[2] = {0.f, 0.f};
-    f32x4 lacc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    const s16x4 ones4 = {0x3f80, 0x3f80, 0x3f80, 0x3f80};
     bool bad = false;
 
-    // ---- prologue: tiles 0 .. PD+1 in flight, S'(0) with the exact row maximum of tile 0
+    // ---- prologue: tiles 0 .. PD+1 in flight; S'(0), first kv half, with the exact row maximum over those 32 keys as the shift
 #pragma unroll
     for (int t = 0; t < PD + 2; ++t) issue(t, t);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * kL) : "memory");       // tiles 0 and 1 have landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();
 #pragma unroll
-    for (int p = 0; p < 8; ++p) kf[p] = frag(smem, (p >> 2) * 4096 + off4[p & 3]);
+    for (int kk = 0; kk < 4; ++kk) kf[kk] = frag(smem, off4[kk]);
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
+    for (int qb = 0; qb < 2; ++qb) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int r = 0; r < 16; ++r) s[qb][0][r] = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sA[qb][t][r] = 0.f;
+        for (int kk = 0; kk < 4; ++kk)
+            s[qb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[qb][kk], s[qb][0], 0, 0, 0);
+    }
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                sA[qb][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t * 4 + kk], qf[qb][kk], sA[qb][t], 0, 0, 0);
-        }
-#pragma unroll
-    for (int p = 0; p < 8; ++p) kf[p] = frag(smem + kStage, (p >> 2) * 4096 + off4[p & 3]);       // K(1)
+    for (int kk = 0; kk < 4; ++kk) {
+        kf[kk] = frag(smem + kStage, off4[kk]);                  // K(1), first half
+        kf[4 + kk] = frag(smem, 4096 + off4[kk]);                // K(0), second half
+    }
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -164,42 +180,50 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
     for (int qb = 0; qb < 2; ++qb) {
         float mq[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) mq[c] = fmaxf(sA[qb][0][c], sA[qb][1][c]);
+        for (int c = 0; c < 4; ++c) mq[c] = s[qb][0][c];
 #pragma unroll
-        for (int r = 4; r < 16; ++r) mq[r & 3] = fmaxf(fmaxf(mq[r & 3], sA[qb][0][r]), sA[qb][1][r]);
+        for (int r = 4; r < 16; ++r) mq[r & 3] = fmaxf(mq[r & 3], s[qb][0][r]);
         float mx = fmaxf(fmaxf(mq[0], mq[1]), fmaxf(mq[2], mq[3]));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { cin[qb][r] = -mx; sA[qb][0][r] -= mx; sA[qb][1][r] -= mx; }
+        for (int r = 0; r < 16; ++r) { cin[qb][r] = -mx; s[qb][0][r] -= mx; }
     }
 
-    // O^T += V^T.P^T with the accumulator pinned to the AGPR half of the register file: VALU instructions address only the 256
-    // architectural VGPRs, which the two score sets (128), the C-operand vectors (32) and the fragments in flight fill; O is
-    // touched by nothing but these MFMAs (and the rare re-base) until the epilogue.  Operands are at least one chunk old.
+    // O^T += V^T.P^T with the accumulator and the V^T fragment pinned to the AGPR half of the register file (VALU instructions
+    // address only the 256 architectural VGPRs; O is touched by nothing but these MFMAs and the rare re-base until the
+    // epilogue).  Operands are at least one chunk old.
     auto pv_mfma = [](f32x16& acc, const bf16x8& va, const bf16x8& pb) {
         asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(va), "v"(pb));
     };
-    // One tile: exponentials / sums / packs of the scores in `cur` (tile j), P.V of tile j, and -- unless LAST -- S'(j+1)
-    // into `nxt` and the just-in-time reloads of the K fragments (tile j+2, from kb2) and V^T fragments (tile j+1, from vb1).
-    // 33 "chunks": chunk c carries one MFMA, the two exponentials of scores 2c, 2c+1 of the tile (slice p = c / 4 is query
-    // block p & 1, 16-wide k-step p >> 1) and the sums + pack of chunk c-1 (skewed by one: nothing waits on a v_exp result).
-    auto tile_body = [&](f32x16 (&cur)[2][2], f32x16 (&nxt)[2][2], const char* kb2, const char* vb1, auto last_tag) {
+    // One tile j, 33 "chunks" of one MFMA + two exponentials (scores 2c, 2c+1 of the tile; slice p = c / 4 is query block
+    // p & 1, 16-wide k-step p >> 1, kv half t = p >> 2) + the sums and the bf16 pack of chunk c-1 (skewed by one: nothing
+    // waits on a v_exp result).  The MFMAs of period p = c / 4:
+    //   chunks 4p, 4p+1   QK^T with one K fragment, both query blocks:  p < 4: half t = 1 of THIS tile (fragment 4+p), consumed
+    //                     from period 4 on;  p >= 4: half t = 0 of tile j+1 (fragment p-4) into the registers whose slices
+    //                     0..3 have just been packed.  The fragment register is then refilled for the tile after (K(j+1) second
+    //                     half from ks1, K(j+2) first half from kb2): just in time, no second fragment set, no exposed LDS latency.
+    //   chunks 4p+2, 4p+3 P.V of slice p-1, both head_dim blocks; after query block 1 the V^T fragments of that k-step are
+    //                     refilled from tile j+1 (vb1).
+    // LAST: nothing of tile j+1 exists.
+    auto tile_body = [&](const char* ks1, const char* kb2, const char* vb1, int dma_tile, int dma_stage, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
 #pragma unroll
         for (int c = 0; c <= 32; ++c) {
             const int p = c >> 2, c4 = c & 3;
+            // the four LDS-DMA pieces of tile j+2+PD, one every eight chunks (all four at the top of the tile measured the same)
+            if (!LAST && (c & 7) == 3) issue_piece(dma_tile, dma_stage, c >> 3);
             if (c < 32) {
                 if (c4 < 2) {
-                    if (!LAST) {                                   // QK^T with fragment p = (kv half p >> 2, k-step p & 3), query block c4
-                        const int tq = p >> 2, kq = p & 3, qb = c4;
+                    if (p < 4 || !LAST) {
+                        const int tq = p < 4 ? 1 : 0, kq = p & 3, qb = c4, f = p < 4 ? 4 + p : p - 4;
                         if (kq == 0) {
-                            // chain head: D = nxt, C = the loop-invariant C-operand vector.  Through the builtin hipcc ties D
+                            // chain head: D = s, C = the loop-invariant C-operand vector.  Through the builtin hipcc ties D
                             // to C and first copies 16 registers; the instruction itself takes distinct ones.
-                            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(nxt[qb][tq]) : "v"(kf[p]), "v"(qf[qb][0]), "v"(cin[qb]));
+                            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(s[qb][tq]) : "v"(kf[f]), "v"(qf[qb][0]), "v"(cin[qb]));
                         } else {
-                            nxt[qb][tq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[p], qf[qb][kq], nxt[qb][tq], 0, 0, 0);
+                            s[qb][tq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[f], qf[qb][kq], s[qb][tq], 0, 0, 0);
                         }
-                        if (c4 == 1) kf[p] = frag(kb2, tq * 4096 + off4[kq]);
+                        if (!LAST && c4 == 1) kf[f] = p < 4 ? frag(ks1, 4096 + off4[kq]) : frag(kb2, off4[kq]);
                     }
                 } else if (p > 0) {                                // P.V of slice p-1, head_dim block c4 - 2
                     const int pp = p - 1, ks = pp >> 1, qb = pp & 1, dt = c4 - 2;
@@ -211,28 +235,23 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
                 }
                 {
                     const int qb = p & 1, ks = p >> 1, t = ks >> 1, r = 8 * (ks & 1) + 2 * c4;
-                    cur[qb][t][r] = __builtin_amdgcn_exp2f(cur[qb][t][r]);
-                    cur[qb][t][r + 1] = __builtin_amdgcn_exp2f(cur[qb][t][r + 1]);
+                    s[qb][t][r] = __builtin_amdgcn_exp2f(s[qb][t][r]);
+                    s[qb][t][r + 1] = __builtin_amdgcn_exp2f(s[qb][t][r + 1]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);                     // exponentials first: their consumers are a whole chunk away
             if (c > 0) {
                 const int cc = c - 1, pq = cc >> 2, e = cc & 3;
                 const int qb = pq & 1, ks = pq >> 1, t = ks >> 1, r = 8 * (ks & 1) + 2 * e;
-                const float v0 = cur[qb][t][r], v1 = cur[qb][t][r + 1];
+                const float v0 = s[qb][t][r], v1 = s[qb][t][r + 1];
                 f32x2 two = {v0, v1};
                 bf16x2 pk = __builtin_convertvector(two, bf16x2);
                 pf[pq & 1][2 * e] = pk[0];
                 pf[pq & 1][2 * e + 1] = pk[1];
-                if (!MSUM) {
-                    lA[qb] += v0;
-                    lB[qb] += v1;
-                    // keep the chains where they are: left alone, the SLP vectoriser gathers the adds into v_pk_add_f32
-                    asm volatile("" : "+v"(lA[qb]), "+v"(lB[qb]));
-                } else if (e & 1) {
-                    bf16x4 four = {pf[pq & 1][2 * e - 2], pf[pq & 1][2 * e - 1], pf[pq & 1][2 * e], pf[pq & 1][2 * e + 1]};
-                    lacc[qb] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones4, __builtin_bit_cast(s16x4, four), lacc[qb], 0, 0, 0);
-                }
+                lA[qb] += v0;
+                lB[qb] += v1;
+                // keep the chains where they are: left alone, the SLP vectoriser gathers the adds into v_pk_add_f32
+                asm volatile("" : "+v"(lA[qb]), "+v"(lB[qb]));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -246,9 +265,10 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
             vf[1][3] = frag(vb1, 4096 + off4[3]);
         }
     };
-    auto row_sum = [&](int qb) { return MSUM ? lacc[qb][0] : lA[qb] + lB[qb]; };
-    // rare, wave-uniform: shift the rows whose sums have grown past 2^20 down to [0.5, 1)
-    auto maybe_rebase = [&](f32x16 (&nxt)[2][2]) {
+    auto row_sum = [&](int qb) { return lA[qb] + lB[qb]; };
+    // rare, wave-uniform: shift the rows whose sums have grown past 2^20 down to [0.5, 1).  The scores already formed against
+    // the old C operand are the first kv half of the next tile.
+    auto maybe_rebase = [&]() {
         const float l0 = row_sum(0), l1 = row_sum(1);
         if (__builtin_expect(__any(!(l0 <= 0x1p30f) || !(l1 <= 0x1p30f)), 0)) {     // (also true for NaN)
 #pragma unroll
@@ -262,53 +282,29 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
 #pragma unroll
                 for (int d = 0; d < 2; ++d)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        o[qb][d][r] = __builtin_ldexpf(o[qb][d][r], -e);
-                        nxt[qb][d][r] -= fe;
-                    }
+                    for (int r = 0; r < 16; ++r) o[qb][d][r] = __builtin_ldexpf(o[qb][d][r], -e);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) cin[qb][r] -= fe;
+                for (int r = 0; r < 16; ++r) { s[qb][0][r] -= fe; cin[qb][r] -= fe; }
                 lA[qb] = __builtin_ldexpf(lA[qb], -e);
                 lB[qb] = __builtin_ldexpf(lB[qb], -e);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) lacc[qb][r] = __builtin_ldexpf(lacc[qb][r], -e);
             }
         }
     };
 
     // ---- main loop
+    stamp(1);
     int j = 0, s1 = 1, s2 = 2, sd = (2 + PD) % NST;        // stages of tiles j+1, j+2, j+2+PD
-    auto top = [&]() {
+    for (; j < n_tiles - 1; ++j) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * kL) : "memory");     // tile j+2 has landed
         __builtin_amdgcn_s_barrier();
-        issue(j + 2 + PD, sd);
-    };
-    auto advance = [&]() {
-        ++j;
+        tile_body(smem + s1 * kStage, smem + s2 * kStage, smem + s1 * kStage + kKBytes, j + 2 + PD, sd, std::false_type{});
+        maybe_rebase();
         s1 = s1 + 1 == NST ? 0 : s1 + 1;
         s2 = s2 + 1 == NST ? 0 : s2 + 1;
         sd = sd + 1 == NST ? 0 : sd + 1;
-    };
-    // two tiles per trip (named score sets, no copies); an odd remainder and the last tile (nothing to prefetch) after the loop
-    for (int trips = (n_tiles - 1) >> 1; trips > 0; --trips) {
-        top();
-        tile_body(sA, sB, smem + s2 * kStage, smem + s1 * kStage + kKBytes, std::false_type{});
-        maybe_rebase(sB);
-        advance();
-        top();
-        tile_body(sB, sA, smem + s2 * kStage, smem + s1 * kStage + kKBytes, std::false_type{});
-        maybe_rebase(sA);
-        advance();
     }
-    if (((n_tiles - 1) & 1) != 0) {
-        top();
-        tile_body(sA, sB, smem + s2 * kStage, smem + s1 * kStage + kKBytes, std::false_type{});
-        maybe_rebase(sB);
-        advance();
-        tile_body(sB, sB, smem, smem, std::true_type{});
-    } else {
-        tile_body(sA, sA, smem, smem, std::true_type{});
-    }
+    tile_body(smem, smem, smem, 0, 0, std::true_type{});
+    stamp(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the re-fetched tiles past the end must not outlive the workgroup's LDS
 
     float l_tot[2];
@@ -341,18 +337,18 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
                 for (int ks = 0; ks < 4; ++ks) vf[dt][ks] = frag(smem + kKBytes, dt * 4096 + off4[ks]);
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
-                f32x16 s[2];
+                f32x16 sx[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
+                    for (int r = 0; r < 16; ++r) sx[t][r] = 0.f;
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
-                        s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t * 4 + kk], qf[qb][kk], s[t], 0, 0, 0);
+                        sx[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t * 4 + kk], qf[qb][kk], sx[t], 0, 0, 0);
                 }
-                float mx = s[0][0];
+                float mx = sx[0][0];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(sx[0][r], sx[1][r]));
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
                 const float m_new = fmaxf(m_run[qb], mx);
                 const float alpha = __builtin_amdgcn_exp2f(m_run[qb] - m_new);
@@ -368,7 +364,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int t = ks >> 1, r = 8 * (ks & 1) + 2 * e;
-                        const float p0 = __builtin_amdgcn_exp2f(s[t][r] - m_new), p1 = __builtin_amdgcn_exp2f(s[t][r + 1] - m_new);
+                        const float p0 = __builtin_amdgcn_exp2f(sx[t][r] - m_new), p1 = __builtin_amdgcn_exp2f(sx[t][r + 1] - m_new);
                         l_run[qb] += p0 + p1;
                         f32x2 two = {p0, p1};
                         bf16x2 pk = __builtin_convertvector(two, bf16x2);
@@ -415,15 +411,17 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
             if (row0 + row < a.Sq) *reinterpret_cast<uint4*>(op + (long long)(row0 + row) * a.o_ss + chunk * 8) = v;
         }
     }
+    stamp(3);
 #endif
 }
 
-template <int PD, bool MSUM>
-int launch(const AttnArgs& a, hipStream_t stream) {
+template <int PD>
+int launch(const AttnArgs& a_in, hipStream_t stream) {
+    AttnArgs a = a_in;
     constexpr int LDS = (PD + 3) * kStage;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_fwd_w64<PD, MSUM>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_fwd_w64<PD>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -431,8 +429,33 @@ int launch(const AttnArgs& a, hipStream_t stream) {
     const long long n_blocks = (long long)dm_div_up(a.Sq, kRowsPerWg) * a.B * a.Hh;
     if (n_blocks > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
     DM_ENTER();
-    hipLaunchKernelGGL((k_attn_fwd_w64<PD, MSUM>), dim3((unsigned)n_blocks), dim3(256), LDS, stream, a);
+    static const bool timeline = getenv("DREAMMAT_ATTN_TIMELINE") != nullptr;
+    static unsigned long long* tl_buf = nullptr;
+    constexpr int TLN = 1024 * 16;
+    if (timeline) {
+        if (!tl_buf && hipMalloc(&tl_buf, TLN * 8) != hipSuccess) return DM_ERR_UNSUPPORTED;
+        (void)hipMemsetAsync(tl_buf, 0, TLN * 8, stream);
+        a.timeline = tl_buf;
+    }
+    hipLaunchKernelGGL((k_attn_fwd_w64<PD>), dim3((unsigned)n_blocks), dim3(256), LDS, stream, a);
     hipError_t e = hipGetLastError();
+    if (timeline && e == hipSuccess) {
+        static unsigned long long host[TLN];
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(host, tl_buf, sizeof(host), hipMemcpyDeviceToHost);
+        const int n_tiles = a.Skv / kTile;
+        for (int b : {0, 8, 300, 1000}) {
+            if (b >= n_blocks) continue;
+            for (int w = 0; w < 4; ++w) {
+                const unsigned long long* t = host + ((size_t)b * 4 + w) * 4;
+                fprintf(stderr, "[attn timeline] wg %d wave %d: prologue %llu  loop %llu (%.0f / tile, %d tiles)  epilogue %llu\n", b, w,
+                        t[1] - t[0], t[2] - t[1], (double)(t[2] - t[1]) / n_tiles, n_tiles, t[3] - t[2]);
+            }
+        }
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (long long i = 0; i < std::min<long long>(n_blocks, 1024) * 4; ++i) { t0 = std::min(t0, host[i * 4]); t1 = std::max(t1, host[i * 4 + 3]); }
+        fprintf(stderr, "[attn timeline] first entry -> last exit of the first %lld workgroups: %llu ticks\n", std::min<long long>(n_blocks, 1024), t1 - t0);
+    }
     return e == hipSuccess ? DM_OK : (int)e;
 }
 
@@ -446,8 +469,6 @@ bool attn_w64_ok(const AttnArgs& a) {
            (a.o_bs & 7) == 0 && (((uintptr_t)a.out) & 15) == 0;
 }
 
-int launch_attn_w64(const AttnArgs& a, int variant, hipStream_t stream) {
-    return (variant & 1) ? launch<2, true>(a, stream) : launch<2, false>(a, stream);
-}
+int launch_attn_w64(const AttnArgs& a, hipStream_t stream) { return launch<2>(a, stream); }
 
 }  // namespace dm_attn

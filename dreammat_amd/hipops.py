@@ -433,15 +433,14 @@ def material_smoothness(feat, featj, n_dev):
 
 # ------------------------------------------------------------------------------------------ attention
 def attention_select(name=None):
-    """Kernel variant of every later attention() call: "w64" | "w64m" (one wave per SIMD, D = 64 with whole kv tiles; else v3l) | "v3l" | "v3" | "v3p" | "v3s" | "dma" | "staged"; None restores the
-    DREAMMAT_ATTN_KERNEL / default choice (dm_attention_select)."""
+    """Kernel family of every later attention() call: "auto" (default) | "w64" (one wave per SIMD; 64-wide heads, whole kv
+    tiles) | "v3l" | "staged"; None restores the DREAMMAT_ATTN_KERNEL / default choice (dm_attention_select)."""
     check(_lib.lib().dm_attention_select(name.encode() if name is not None else None), "dm_attention_select")
 
 
 def attention_variant():
-    """name of the variant attention() runs unless attention_select() overrode it (for reports)."""
-    import os
-    return os.environ.get("DREAMMAT_ATTN_KERNEL", "v3l")
+    """name of the family the library dispatches from (dm_attention_selected: what dm_attention_select / the environment chose)."""
+    return _lib.lib().dm_attention_selected().decode()
 
 
 def attention(q, k, vt, heads, scale=None):

@@ -228,10 +228,14 @@ int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* ou
                           int D, long long q_bs, long long q_ss, long long q_hs, long long k_bs, long long k_ss,
                           long long k_hs, long long vt_bs, long long vt_hs, long long vt_ds, long long o_bs,
                           long long o_ss, long long o_hs, float scale, dm_stream_t stream);
-/* Kernel variant for every later dm_attention_fwd_bf16 call of the process: "v3l" (default), "v3", "v3p", "v3s", "dma" (round 1),
- * "staged"; NULL = back to the DREAMMAT_ATTN_KERNEL environment variable / default.  For A/B measurements and for the
- * parity tests, which run every variant.  DM_ERR_ARG for an unknown name. */
+/* Kernel family for every later dm_attention_fwd_bf16 call of the process: "auto" (default: one wave per SIMD with 256
+ * query rows per workgroup for 64-wide heads at S >= 1024, the 4 x 32-row LDS-DMA kernel otherwise, the register-staged
+ * generic kernel for head sizes 40 / 80 / 160), or "w64" / "v3l" / "staged" to force one (shapes outside its domain fall
+ * through to the next); NULL = back to the DREAMMAT_ATTN_KERNEL environment variable / "auto".  For A/B measurements and
+ * the parity tests, which run every family.  DM_ERR_ARG for an unknown name. */
 int dm_attention_select(const char* name);
+/* name of the family in force ("auto", "w64", "v3l", "staged"): what reports should quote */
+const char* dm_attention_selected(void);
 
 /* ---- convolution ------------------------------------------------------------------------- */
 /* 3x3 convolutions of UNet2DConditionModel / ControlNetModel / AutoencoderKL (the F.conv2d calls diffusers

@@ -231,7 +231,7 @@ def main():
     ap.add_argument("--skip-shade", action="store_true")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--skip-hashgrid", action="store_true")
-    ap.add_argument("--variants", default="v3p,v3,v3l,v3s,dma,staged", help="attention kernels to compare (dm_attention_select names)")
+    ap.add_argument("--variants", default="auto,w64,v3l,staged", help="attention kernels to compare (dm_attention_select names)")
     ap.add_argument("--out", default="r2_probe.json")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
