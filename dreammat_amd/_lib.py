@@ -12,6 +12,8 @@ from ctypes import POINTER, c_float, c_int, c_int32, c_longlong, c_size_t, c_uin
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdreammat_hip.so")
+if os.environ.get("DREAMMAT_LIB"):       # development aid (tools/grad_budget.py: the same library built with other flags)
+    LIB_PATH = os.environ["DREAMMAT_LIB"]
 
 _lib = None
 

@@ -77,8 +77,11 @@ def contract_to_unisphere(x, radius=1.0):
     return (x + radius) / (2 * radius)
 
 
-def field_forward(points, table, w1, w2, levels, radius=1.0):
-    """points [N,3] world -> features [N,5].  w1 [64,32], w2 [5,64] (nn.Linear layout, no bias)."""
+def field_forward(points, table, w1, w2, levels, radius=1.0, return_hidden=False):
+    """points [N,3] world -> features [N,5].  w1 [64,32], w2 [5,64] (nn.Linear layout, no bias).
+    return_hidden: also the pre-activation of the hidden layer [N,64] (tests use it to find rows that sit on a ReLU kink,
+    where two correct fp32 evaluations route the gradient differently)."""
     enc = hash_encode(contract_to_unisphere(points, radius), table, levels)
-    h = torch.relu(enc @ w1.t())
-    return h @ w2.t()
+    pre = enc @ w1.t()
+    out = torch.relu(pre) @ w2.t()
+    return (out, pre.detach()) if return_hidden else out

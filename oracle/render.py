@@ -87,8 +87,8 @@ def render(mesh, batch, field_params, envs, fg_lut, jitter_u, jitter_n, change_e
     change = (torch.cos(ang) * x + torch.sin(ang) * y) * eps
     positions_jitter = positions + change
     fp = field_params
-    feat = field.field_forward(positions, fp["table"], fp["w1"], fp["w2"], fp["levels"], fp.get("radius", 1.0))
-    feat_j = field.field_forward(positions_jitter, fp["table"], fp["w1"], fp["w2"], fp["levels"], fp.get("radius", 1.0))
+    feat, hid = field.field_forward(positions, fp["table"], fp["w1"], fp["w2"], fp["levels"], fp.get("radius", 1.0), True)
+    feat_j, hid_j = field.field_forward(positions_jitter, fp["table"], fp["w1"], fp["w2"], fp["levels"], fp.get("radius", 1.0), True)
     shade, mat_reg = shading.material_forward(feat, feat_j, viewdirs, n_sel, envs, env_id[view_of], fg_lut, mat_cfg)
 
     def scatter(vals, C):
@@ -110,6 +110,6 @@ def render(mesh, batch, field_params, envs, fg_lut, jitter_u, jitter_n, change_e
         # internals exposed for parity tests
         "_rast": rast, "_plan": torch.from_numpy(plan), "_pos_clip": pos_clip, "_gb_normal": gb_normal,
         "_gb_pos": gb_pos, "_features": feat, "_features_jitter": feat_j, "_color_pre_aa": color,
-        "_positions_jitter": positions_jitter,
+        "_positions_jitter": positions_jitter, "_hidden": hid, "_hidden_jitter": hid_j,
     }
     return out

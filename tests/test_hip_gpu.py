@@ -472,7 +472,13 @@ def test_unet_controlnet_gpu_fp32_and_bf16_hip_attention(dev):
         assert n_attn == 46, n_attn                    # 2x(16 UNet + 7 ControlNet) attention launches, all on MFMA
         assert n_ln == 69 and n_gg == 23, (n_ln, n_gg)  # 3 LayerNorms + 1 GEGLU (own kernel or GEMM epilogue) per block
         rel = ((yb - oy).abs().max() / oy.abs().max()).item()
-        assert rel < 6e-2, (arch_name, rel)
+        rel_mean = ((yb - oy).abs().mean() / oy.abs().mean()).item()
+        os.makedirs(OUT, exist_ok=True)
+        with open(os.path.join(OUT, f"tiny_eps_parity_{arch_name}.json"), "w") as fh:
+            json.dump({"arch": arch_name, "bf16_rel_max": rel, "bf16_rel_mean": rel_mean}, fh)
+        # bf16 storage of every activation through ~60 layers: max-rel ~1e-2; the gate is tight enough for a regression
+        # (a wrong scale, a dropped residual, a kernel falling back to garbage) to fail it
+        assert rel < 2e-2 and rel_mean < 2e-2, (arch_name, rel, rel_mean)      # measured 1.0e-2 / 1.2e-2
 
 
 def test_noise_prediction_hip_graph_replay_equals_eager(dev, tmp_path, monkeypatch):
@@ -1124,6 +1130,56 @@ def test_exporter_bakes_the_fitted_field_on_the_gpu(tmp_path):
                                                          "texture_roughness.png"]
 
 
+def test_exporter_bake_on_apple_obj_vs_oracle(dev):
+    """f-3 (mesh_exporter.py:53-137) on the reference's own apple.obj (4 164 triangles, its own vt atlas) against the ORACLE:
+    the UV-space coverage ids / barycentrics of the bake bit-equal to oracle/raster_ref.c, and every covered texel's albedo /
+    metallic / roughness equal to oracle/field.py's hash grid + MLP evaluated at the oracle-interpolated position, through
+    the reference's export activation (dreammat_material.py:765-797: squared-roughness range, sqrt).  Texels next to a chart
+    border get the dilation's mean of covered neighbours (ours; the reference inpaints with cv2): checked for being a convex
+    combination of covered texels, not against a reference value."""
+    import dreammat_amd
+    dreammat_amd._import_plugins()
+    torch.manual_seed(3)
+    geo = dreammat_amd.find("dreammat-mesh")({"shape_init": "mesh:" + os.path.join(ASSETS, "apple.obj"), "shape_init_params": 0.7,
+                                              "shape_init_mesh_up": "+y", "shape_init_mesh_front": "+z"}).to(dev)
+    with torch.no_grad():
+        geo.encoding.encoding.params.uniform_(-1, 1)
+        geo.feature_network.layers[0].weight.copy_(torch.randn(64, 32) * 0.3)
+        geo.feature_network.layers[2].weight.copy_(torch.randn(5, 64) * 0.3)
+    lat = [torch.full((16, 32, 3), 0.25) for _ in range(5)]
+    mat = dreammat_amd.find("dreammat-material")({"use_raytracing": False, "env_max_res": 32, "env_min_res": 8}, latlongs=lat).to(dev)
+    S = 256
+    ex = dreammat_amd.find("mesh-exporter")({"texture_size": S, "texture_format": "png", "xatlas_pack_options": {"padding": 2}},
+                                            geometry=geo, material=mat, background=None)
+    mesh = geo.isosurface()
+    assert mesh.v_tex is not None and mesh.t_tex_idx.shape[0] == 4164
+    maps, holes = ex.bake_textures(mesh)
+    # ---- oracle: rasterize the uv triangles, interpolate positions, evaluate the field, activate
+    uv = mesh.v_tex.float().cpu() * 2.0 - 1.0
+    uv4 = torch.cat([uv, torch.zeros_like(uv[:, :1]), torch.ones_like(uv[:, :1])], -1)[None].numpy()
+    t_tex = mesh.t_tex_idx.cpu().numpy().astype(np.int32)
+    t_pos = mesh.t_pos_idx.cpu().numpy().astype(np.int32)
+    ro = oraster.rasterize(uv4, t_tex, S, S)
+    covered = torch.from_numpy(ro[0, :, :, 3] > 0)
+    assert torch.equal(~holes.cpu(), covered)
+    assert 0.2 < float(covered.float().mean()) < 0.95
+    pos = torch.from_numpy(oraster.interpolate(mesh.v_pos.float().cpu().numpy(), ro, t_pos))[0].reshape(-1, 3)
+    lv, _ = ofield.grid_levels()
+    feats = ofield.field_forward(pos, geo.encoding.encoding.params.detach().cpu().reshape(-1, 2),
+                                 geo.feature_network.layers[0].weight.detach().cpu(),
+                                 geo.feature_network.layers[2].weight.detach().cpu(), lv, radius=1.0)
+    m = torch.sigmoid(feats)
+    ref = {"albedo": m[:, :3], "metallic": m[:, 3:4] * 0.9, "roughness": torch.sqrt(m[:, 4:5] * (0.9 - 0.01) + 0.01 + 1e-7)}
+    sel = covered.reshape(-1)
+    for k in ("albedo", "metallic", "roughness"):
+        got = maps[k].reshape(S * S, -1).cpu()
+        assert (got[sel] - ref[k][sel]).abs().max() < 1e-4, k
+        # dilated ring: inside the range of the covered texels (a mean of covered neighbours), further out: zero
+        ring = got[~sel]
+        assert float(ring.min()) >= -1e-6 and float(ring.max()) <= float(got[sel].max()) + 1e-6
+    assert float((maps["albedo"].reshape(S * S, -1).cpu()[~sel].abs().sum(-1) > 0).float().mean()) > 0.01   # the ring exists
+
+
 def test_condition_map_producer_vs_oracle_composition():
     """SURVEY row f-2 (`condition_source: render`): depth / Blender-convention view normal / 6 probe-material light maps
     from the HIP kernels, against the same recipe composed from the oracle's CPU pieces (C rasterizer + interpolate,
@@ -1228,11 +1284,35 @@ def _golden_cfg2_env():
     return env
 
 
-def test_cfg2_real_assets_render_vs_oracle(dev):
-    """run_examples.sh:2 (`shape_init=mesh:load/shapes/objs/apple.obj shape_init_params=0.7`) with dreammat.yaml's geometry
-    (+y up, +z front, 16-level 2^19 hash grid), environment_scale 2.0 and the real FG LUT (dreammat_material.py:383,399-404):
-    4 views @512^2 through the plugin API against the oracle -- coverage bit-equal, shaded pixels within 1e-3, gradients
-    within 1e-3; the product's GPU-built environment atlas against the oracle's prefilter of the same HDR."""
+def _mask_kink_ambiguous(dy, ref, eps=1e-4, eps_relu=3e-4):
+    """Zeroes the upstream gradient wherever it could reach a pixel that sits ON A KINK of the reference's own function, where
+    two correct fp32 evaluations (different summation orders) land on different sides and disagree by that pixel's WHOLE
+    gradient -- a discontinuity, not a rounding error:
+      * the clamp(0, 1) of the shaded colour (dreammat_material.py:700; torch.clamp passes the gradient only inside [0, 1]);
+        solidly clamped pixels carry no gradient on either side, so masking them loses nothing;
+      * a hidden unit of the field MLP within `eps_relu` of its ReLU kink (networks.py:150-187).  The band is as wide as the two
+        sides' hidden pre-activations differ: interpolated positions differ by ulps, the finest grid levels scale that by 4096,
+        and these tests fill the table with white noise (adjacent entries O(1) apart), so encodings differ by ~1e-4.  tools/grad_budget.py located the single table entry that made up the 9.8e-4 of round 2 this
+        way: identical across atlas formats, fast-math on/off and both hash-grid backward routes, and the ORACLE's field
+        backward fed with the PRODUCT's per-pixel feature gradients reproduces the oracle's table gradient to 3e-5.
+    The antialias blend hands a pixel's gradient to its 4-neighbours' colours, hence the dilation.  (The jittered rows feed only
+    the smoothness regulariser, whose per-row gradient is ~1e-8 of the table's.)  Returns (masked dy, fraction of the COVERED
+    pixels' channels masked)."""
+    B, H, W, _ = dy.shape
+    covered = (ref["_rast"][..., 3] > 0)
+    col = ref["_color_pre_aa"].detach()
+    amb = ((col > 1.0 - eps) | (col < eps)) & covered[..., None]                      # [B,H,W,3]: the clamp acts per channel
+    relu = torch.zeros(B * H * W, dtype=torch.bool)
+    relu[covered.reshape(-1)] = (ref["_hidden"].abs() < eps_relu).any(-1)
+    amb = amb | relu.reshape(B, H, W, 1)
+    d = amb.clone()
+    d[:, 1:] |= amb[:, :-1]; d[:, :-1] |= amb[:, 1:]; d[:, :, 1:] |= amb[:, :, :-1]; d[:, :, :-1] |= amb[:, :, 1:]
+    return dy * (~d).to(dy.dtype), float((d & covered[..., None]).float().sum() / (3 * covered.float().sum()))
+
+
+def _cfg2_compare(dev, texel=None, oracle_cache=None, strict=True, mask_clamp=True):
+    """scene + comparison of test_cfg2_real_assets_render_vs_oracle; `texel` overrides the atlas storage format (the gradient
+    error budget study of tools/grad_budget.py runs it with "fp32"), `oracle_cache` (dict) keeps the CPU oracle's result."""
     import hashlib
     import dreammat_amd
     from dreammat_amd.geometry import DreamMatMesh
@@ -1251,13 +1331,19 @@ def test_cfg2_real_assets_render_vs_oracle(dev):
         geom.encoding.encoding.params.copy_(torch.rand_like(geom.encoding.encoding.params) * 2 - 1)
         geom.feature_network.layers[0].weight.copy_(torch.randn(64, 32) * 0.3)
         geom.feature_network.layers[2].weight.copy_(torch.randn(5, 64) * 0.3)
-    mat = DreamMatMaterial({"use_raytracing": False, "environment_scale": 2.0, "n_envs": 1,
-                            "environment_texture": os.path.join(ASSETS, "mud_road_puresky_1k.hdr"),
-                            "fg_lut_path": os.path.join(ASSETS, "bsdf_256_256.bin")}).to(dev)
+    if texel is not None:
+        os.environ["DREAMMAT_ATLAS"] = texel
+    try:
+        mat = DreamMatMaterial({"use_raytracing": False, "environment_scale": 2.0, "n_envs": 1,
+                                "environment_texture": os.path.join(ASSETS, "mud_road_puresky_1k.hdr"),
+                                "fg_lut_path": os.path.join(ASSETS, "bsdf_256_256.bin")}).to(dev)
+    finally:
+        if texel is not None:
+            del os.environ["DREAMMAT_ATLAS"]
     fg = penv.load_fg_lut(os.path.join(ASSETS, "bsdf_256_256.bin"))
     assert torch.equal(mat.FG_LUT[0].cpu(), fg) and abs(float(fg[0, 0, 0]) - 0.00973) < 1e-5
     golden_env = _golden_cfg2_env()
-    assert mat.atlas.mip_res == [128, 64, 32, 16] and mat.atlas.texel == "rgb18e8"
+    assert mat.atlas.mip_res == [128, 64, 32, 16] and mat.atlas.texel == (texel or "rgb18e8")
     for k in range(4):
         a, b = mat.atlas.specular[0][k].cpu(), golden_env.specular[k]
         assert (a - b).abs().max() <= 1e-4 * b.abs().max(), k
@@ -1278,7 +1364,17 @@ def test_cfg2_real_assets_render_vs_oracle(dev):
     table = geom.encoding.encoding.params.detach().cpu().reshape(-1, 2).clone().requires_grad_()
     w1 = geom.feature_network.layers[0].weight.detach().cpu().clone().requires_grad_()
     w2 = geom.feature_network.layers[2].weight.detach().cpu().clone().requires_grad_()
-    ref = orender.render(md, batch, dict(table=table, w1=w1, w2=w2, levels=lv, radius=1.0), [golden_env], fg, ju, jn)
+    dy = torch.randn(B, H, W, 3, generator=g)
+    if oracle_cache is not None and "ref" in oracle_cache:
+        ref, table, w1, w2, dy, masked = oracle_cache["ref"]
+    else:
+        ref = orender.render(md, batch, dict(table=table, w1=w1, w2=w2, levels=lv, radius=1.0), [golden_env], fg, ju, jn)
+        dy, masked = _mask_kink_ambiguous(dy, ref) if mask_clamp else (dy, 0.0)
+        if oracle_cache is not None:
+            ref["_features"].retain_grad(); ref["_features_jitter"].retain_grad()
+        ((ref["comp_rgb"] * dy).sum() + 2.0 * ref["loss_mat_reg"]).backward()
+        if oracle_cache is not None:
+            oracle_cache["ref"] = (ref, table, w1, w2, dy, masked)
     assert np.array_equal(out["_internals"]["rast"].cpu().numpy().view(np.uint32), ref["_rast"].numpy().view(np.uint32))
     cover = float((ref["opacity"] > 0).float().mean())
     assert 0.1 < cover < 0.6
@@ -1290,7 +1386,142 @@ def test_cfg2_real_assets_render_vs_oracle(dev):
     mse = ((out["comp_rgb"].detach().cpu() - ref["comp_rgb"].detach()) ** 2).mean().item()
     psnr = 10 * np.log10(1.0 / max(mse, 1e-20))
     assert psnr > 80, psnr
+    if oracle_cache is not None:          # per-pixel feature gradients, for locating a disagreement (tools/grad_budget.py)
+        out["_internals"]["features"].retain_grad(); out["_internals"]["features_jitter"].retain_grad()
+    ((out["comp_rgb"] * dy.to(dev)).sum() + 2.0 * out["loss_mat_reg"]).backward()
+    if oracle_cache is not None and ref["_features"].grad is not None:
+        for nm_f, hf, of in (("features", out["_internals"]["features"], ref["_features"]),
+                             ("features_jitter", out["_internals"]["features_jitter"], ref["_features_jitter"])):
+            d = (hf.grad.cpu() - of.grad).abs().max(dim=1).values
+            top = torch.topk(d, 3).indices
+            sel = (ref["_rast"][..., 3] > 0).reshape(-1).nonzero()[:, 0]
+            oracle_cache["pixel_detail_" + nm_f] = [
+                {"row": int(i), "pixel": int(sel[i]), "hip_dfeat": hf.grad[i].cpu().tolist(), "oracle_dfeat": of.grad[i].tolist(),
+                 "oracle_feat": of[i].tolist(), "hip_feat": hf[i].detach().cpu().tolist(),
+                 "oracle_color_pre_aa": ref["_color_pre_aa"].reshape(-1, 3)[sel[i]].tolist(),
+                 "roughness": float(ref["roughness"].reshape(-1)[sel[i]]), "dy": dy.reshape(-1, 3)[sel[i]].tolist()} for i in top]
+    if oracle_cache is not None and oracle_cache.get("split_field_backward"):
+        # the ORACLE's field backward fed with the PRODUCT's per-pixel feature gradients: separates an upstream disagreement
+        # (shade / antialias) from one inside the hash-grid + MLP backward
+        sel_b = (ref["_rast"][..., 3] > 0).reshape(-1)
+        t2 = table.detach().clone().requires_grad_()
+        f2 = ofield.field_forward(ref["_gb_pos"].reshape(-1, 3)[sel_b], t2, w1.detach(), w2.detach(), lv, 1.0)
+        fj2 = ofield.field_forward(ref["_positions_jitter"].detach(), t2, w1.detach(), w2.detach(), lv, 1.0)
+        ((f2 * out["_internals"]["features"].grad.cpu()).sum() + (fj2 * out["_internals"]["features_jitter"].grad.cpu()).sum()).backward()
+        th = geom.encoding.encoding.params.grad.cpu().reshape(-1, 2)
+        oracle_cache["split"] = {"oracle_bwd_of_hip_dfeat_vs_hip_table": float((t2.grad - th).abs().max() / table.grad.abs().max()),
+                                 "oracle_bwd_of_hip_dfeat_vs_oracle_table": float((t2.grad - table.grad).abs().max() / table.grad.abs().max())}
+    rels = {}
+    for a, b, nm in ((geom.encoding.encoding.params.grad.cpu().reshape(-1, 2), table.grad, "table"),
+                     (geom.feature_network.layers[0].weight.grad.cpu(), w1.grad, "w1"),
+                     (geom.feature_network.layers[2].weight.grad.cpu(), w2.grad, "w2")):
+        rels[nm] = ((a - b).abs().max() / b.abs().max()).item()
+        assert rels[nm] < 1e-3 or not strict, (nm, rels[nm])
+        if nm == "table" and oracle_cache is not None:       # where the largest table-gradient error sits (tools/grad_budget.py)
+            i = int((a - b).abs().max(dim=1).values.argmax())
+            offs = [l["offset"] for l in lv] if isinstance(lv[0], dict) else None
+            oracle_cache["table_detail"] = {"entry": i, "hip": a[i].tolist(), "oracle": b[i].tolist(),
+                                            "oracle_abs_max": float(b.abs().max()), "level_offsets": offs,
+                                            "rel_err_of_that_entry": float(((a[i] - b[i]).abs().max() / b[i].abs().max().clamp(min=1e-30)))}
+    return {"psnr_db": psnr, "coverage_ids_equal": True, "covered_fraction": cover, "max_abs_err": errs,
+            "grad_rel_err": rels, "assets": sums, "atlas_texel": mat.atlas.texel,
+            "kink_ambiguous_fraction_of_covered_channels_masked_in_dy": masked}
+
+
+
+
+def test_cfg2_real_assets_render_vs_oracle(dev):
+    """run_examples.sh:2 (`shape_init=mesh:load/shapes/objs/apple.obj shape_init_params=0.7`) with dreammat.yaml's geometry
+    (+y up, +z front, 16-level 2^19 hash grid), environment_scale 2.0 and the real FG LUT (dreammat_material.py:383,399-404):
+    4 views @512^2 through the plugin API against the oracle -- coverage bit-equal, shaded pixels within 1e-3, gradients
+    within 1e-3; the product's GPU-built environment atlas against the oracle's prefilter of the same HDR."""
+    res = _cfg2_compare(dev)
+    with open(os.path.join(OUT, "cfg2_render_parity.json"), "w") as fh:
+        json.dump(res, fh)
+
+
+def test_cfg3_bench_scene_render_vs_oracle(dev):
+    """The BENCH configuration end to end (BASELINE configs[2]): the 50 880-triangle displaced sphere
+    (`sphere:160:160`), 8 views @512^2, the five seeded synthetic probes of bench.py at cube resolutions 16..128, the real FG
+    LUT, the full 16-level 2^19 hash grid, bin-overflow check on -- through the plugin API against the oracle: coverage ids /
+    (u, v, z/w) bit-equal, all 11 renderer outputs within 1e-3, hash-table / MLP gradients within 1e-3.
+    The oracle's O(res^4) prefilter is pinned for probe 0 (tests/golden/cfg3_env0.npz, make_cfg3_env.py); for the other four the
+    oracle reads the product's own unpacked fp32 cubes, so its lookups (face choice, seams, mips, trilinear blend) are what
+    is compared there."""
+    import bench
+    from dreammat_amd.geometry import DreamMatMesh
+    from dreammat_amd.material import DreamMatMaterial
+    from dreammat_amd.renderer import RaytraceRender
+    from dreammat_amd.background import SolidColorBackground
+    torch.manual_seed(0)
+    geom = DreamMatMesh({"shape_init": "sphere:160:160", "shape_init_params": 0.8}).to(dev)
+    assert geom.t_buffer.shape[0] == 50880 and geom.encoding.spec.n_params == 12599920
+    with torch.no_grad():
+        geom.encoding.encoding.params.copy_(torch.rand_like(geom.encoding.encoding.params) * 2 - 1)
+        geom.feature_network.layers[0].weight.copy_(torch.randn(64, 32) * 0.3)
+        w2_init = torch.randn(5, 64) * 0.3
+        # dark albedo (features <= 0 after the ReLU layer): under the bench's probes (radiance ~1.6 x scale 2, 100x sun lobes) a
+        # mid-grey material saturates 98 % of the covered channels at the clamp(0, 1), where no gradient flows at all
+        w2_init[:3] = -w2_init[:3].abs() * 2.0
+        geom.feature_network.layers[2].weight.copy_(w2_init)
+    lat = [bench.synthetic_latlong(i) for i in range(5)]
+    fg_path = os.path.join(ASSETS, "bsdf_256_256.bin")
+    mat = DreamMatMaterial({"use_raytracing": False, "environment_scale": 2.0, "env_max_res": 128, "env_min_res": 16,
+                            "n_envs": 5, "fg_lut_path": fg_path}, latlongs=lat).to(dev)
+    fg = penv.load_fg_lut(fg_path)
+    assert mat.atlas.mip_res == [128, 64, 32, 16] and mat.atlas.texel == "rgb18e8" and mat.real_fg_lut
+    gz = np.load(os.path.join(os.path.dirname(ASSETS), "cfg3_env0.npz"))
+    for k in range(4):
+        a, b = mat.atlas.specular[0][k].cpu(), torch.from_numpy(gz[f"spec{k}"])
+        # mips 1..3 agree to 1e-6.  Mip 0 is the GGX prefilter at roughness 0.08 (alpha^2 = 4e-5) of a probe with a 100x sun lobe:
+        # D(h) = a2 / (pi ((n.h)^2 (a2 - 1) + 1)^2) cancels catastrophically in fp32 next to n.h = 1, so two correct fp32
+        # evaluations (CPU oracle, GPU product) differ by up to ~1e-3 of a texel on the lobe's flank (measured 8.6e-4 at one
+        # texel, mean 5.5e-5); the real HDR of cfg2 (no such lobe) holds 1e-4 of the maximum
+        tol = 5e-4 if k == 0 else 1e-5
+        assert (a - b).abs().max() <= tol * b.abs().max(), (k, float((a - b).abs().max()), float(b.abs().max()))
+        assert ((a - b).abs() / b.abs().clamp(min=1e-3)).mean() < 2e-4, k
+    assert (mat.atlas.diffuse[0].cpu() - torch.from_numpy(gz["diffuse"])).abs().max() < 1e-5 * max(1.0, float(gz["diffuse"].max()))
+    oenvs = []
+    for e in range(5):
+        env = oenv.EnvLight.__new__(oenv.EnvLight)
+        if e == 0:
+            env.specular = [torch.from_numpy(gz[f"spec{k}"]) for k in range(4)]
+            env.diffuse = torch.from_numpy(gz["diffuse"])
+        else:
+            env.specular = [m.cpu().clone() for m in mat.atlas.specular[e]]
+            env.diffuse = mat.atlas.diffuse[e].cpu().clone()
+        env.base = env.specular[0]
+        oenvs.append(env)
+    rend = RaytraceRender({}, geometry=geom, material=mat, background=SolidColorBackground({}))
+    B, H, W = 8, 512, 512
+    batch = util.make_views(B, H, W, seed=0)
+    batch["env_id"] = torch.tensor([0, 3, 1, 4, 2, 0, 2, 1], dtype=torch.long)
+    g = torch.Generator().manual_seed(11)
+    ju, jn = torch.rand(B, H, W, generator=g), torch.randn(B, H, W, generator=g)
+    gbatch = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    out = rend(**gbatch, light_positions=None, jitter_u=ju.to(dev), jitter_n=jn.to(dev), check_overflow=True)
+    md = dict(v_pos=geom.v_buffer.cpu().numpy(), v_nrm=geom.vnrm_buffer.cpu().numpy(),
+              t_pos_idx=geom.t_buffer.cpu().numpy().astype(np.int32))
+    md["opp"] = oraster.build_topology(md["t_pos_idx"])
+    lv, tot = ofield.grid_levels()
+    table = geom.encoding.encoding.params.detach().cpu().reshape(-1, 2).clone().requires_grad_()
+    w1 = geom.feature_network.layers[0].weight.detach().cpu().clone().requires_grad_()
+    w2 = geom.feature_network.layers[2].weight.detach().cpu().clone().requires_grad_()
+    ref = orender.render(md, batch, dict(table=table, w1=w1, w2=w2, levels=lv, radius=1.0), oenvs, fg, ju, jn)
+    assert np.array_equal(out["_internals"]["rast"].cpu().numpy().view(np.uint32), ref["_rast"].numpy().view(np.uint32))
+    cover = float((ref["opacity"] > 0).float().mean())
+    assert 0.3 < cover < 0.7, cover
+    errs = {}
+    for k in ["comp_rgb", "opacity", "comp_depth", "comp_normal", "albedo", "metalness", "roughness", "specular_light",
+              "diffuse_light", "specular_color", "diffuse_color"]:
+        errs[k] = (out[k].detach().cpu() - ref[k].detach()).abs().max().item()
+        assert errs[k] < 1e-3, (k, errs[k])
+    mse = ((out["comp_rgb"].detach().cpu() - ref["comp_rgb"].detach()) ** 2).mean().item()
+    psnr = 10 * np.log10(1.0 / max(mse, 1e-20))
+    assert psnr > 80, psnr
     dy = torch.randn(B, H, W, 3, generator=g)
+    dy, masked = _mask_kink_ambiguous(dy, ref)      # (the 100x sun lobes saturate many pixels)
+    assert masked < 0.5, masked                     # the gradient comparison must keep a substantial part of the image
     ((out["comp_rgb"] * dy.to(dev)).sum() + 2.0 * out["loss_mat_reg"]).backward()
     ((ref["comp_rgb"] * dy).sum() + 2.0 * ref["loss_mat_reg"]).backward()
     rels = {}
@@ -1299,9 +1530,11 @@ def test_cfg2_real_assets_render_vs_oracle(dev):
                      (geom.feature_network.layers[2].weight.grad.cpu(), w2.grad, "w2")):
         rels[nm] = ((a - b).abs().max() / b.abs().max()).item()
         assert rels[nm] < 1e-3, (nm, rels[nm])
-    with open(os.path.join(OUT, "cfg2_render_parity.json"), "w") as fh:
-        json.dump({"psnr_db": psnr, "coverage_ids_equal": True, "covered_fraction": cover, "max_abs_err": errs,
-                   "grad_rel_err": rels, "assets": sums}, fh)
+    errs["kink_ambiguous_fraction_of_covered_channels_masked_in_dy"] = masked
+    with open(os.path.join(OUT, "cfg3_render_parity.json"), "w") as fh:
+        json.dump({"config": "BASELINE configs[2]: sphere:160:160, 8 views @512^2, 5 probes @128, 16 x 2^19 grid",
+                   "psnr_db": psnr, "coverage_ids_equal": True, "covered_fraction": cover, "max_abs_err": errs,
+                   "grad_rel_err": rels}, fh)
 
 
 def test_full_size_sd21_unet_controlnet_eps_vs_oracle(dev):
@@ -1343,6 +1576,8 @@ def test_full_size_sd21_unet_controlnet_eps_vs_oracle(dev):
     assert sum(v["launches"] for k, v in kt.items() if k.startswith("attention")) == 46
     assert any(k.startswith("conv3x3") for k in kt)
     rel16 = ((yb - oy).abs().max() / oy.abs().max()).item()
+    rel16_mean = ((yb - oy).abs().mean() / oy.abs().mean()).item()
     with open(os.path.join(OUT, "full_size_eps_parity.json"), "w") as fh:
-        json.dump({"fp32_rel_max": rel32, "bf16_rel_max": rel16, "eps_abs_max": float(oy.abs().max())}, fh)
-    assert rel16 < 8e-2, rel16
+        json.dump({"fp32_rel_max": rel32, "bf16_rel_max": rel16, "bf16_rel_mean": rel16_mean,
+                   "eps_abs_max": float(oy.abs().max())}, fh)
+    assert rel16 < 2e-2 and rel16_mean < 2e-2, (rel16, rel16_mean)     # measured 1.0-1.2e-2 / 0.9e-2 (rounds 2, 3)
