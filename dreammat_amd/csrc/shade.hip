@@ -6,6 +6,8 @@
 // address unit visits: 16 gather instructions per pixel with RGBA-fp32 texels and plain LUT taps, 8 with 8-byte
 // texels (one 16 B load per bilinear row) and the FG x-pair table -- see shade_core.h.
 // Reference: threestudio/models/materials/dreammat_material.py:679-711, 746-762.
+#include <cstdlib>
+
 #include "shade_core.h"
 
 using namespace dm;
@@ -67,8 +69,11 @@ __device__ __forceinline__ void shade_load(const ShadeArgs& a, long long i, Shad
 // input stream of the next pixel, every iteration: the streaming latency was never hidden (rocprofv3 on the real
 // G-buffer: 28 us with an atlas of ONE texel per face, i.e. without any gather divergence at all, against 31 us with the real
 // atlas).  Now the only loads older than the gathers were issued a whole iteration earlier.
+// `out`: the kernel's per-pixel result rows (forward: colour, 3 channels; backward: d loss / d features, 5 channels); `body`
+// receives a store functor (channel, value) for them -- 64-bit pointer arithmetic on the general path, buffer stores with one
+// 32-bit lane offset per pixel on the fast path (three v_mad_u64_u32 per store cost more issue slots than the shading of a texel)
 template <int FMT, bool BWD, class Body>
-__device__ __forceinline__ void shade_pixel_loop(const ShadeArgs& a, Body&& body) {
+__device__ __forceinline__ void shade_pixel_loop(const ShadeArgs& a, const StridedOut& out, Body&& body) {
     const long long N = *a.n_dev;
     const long long stride = (long long)gridDim.x * blockDim.x;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -83,7 +88,8 @@ __device__ __forceinline__ void shade_pixel_loop(const ShadeArgs& a, Body&& body
             int env = a.env_of_view[cur.pix / a.HW];
             ShadeCtx c;
             shade_eval_t<FMT>(a.atlas, a.mat, env, cur.n, cur.v, cur.f, c);
-            body(i, cur.dc, c);
+            const long long ii = i;
+            body(i, cur.dc, c, [&](int k, float v) { out.p[ii * out.rs + k * out.cs] = v; });
             if (more) cur = nxt;
         }
         return;
@@ -102,10 +108,16 @@ __device__ __forceinline__ void shade_pixel_loop(const ShadeArgs& a, Body&& body
     // sizes) the threads that fill the upper table entries are exactly the ones past the end
     if (i >= N) return;
     const float inv_hw = 1.0f / (float)a.HW;
+    const int hw_shift = (a.HW & (a.HW - 1)) == 0 ? __builtin_ctz(a.HW) : -1;     // 512^2, 1024^2, ...: a shift
     auto env_of = [&](int pix) {
-        int view = (int)((float)pix * inv_hw);           // pix < 2^24 is exact in fp32; one step of correction covers the rounding
-        view -= (view * a.HW > pix) ? 1 : 0;
-        view += ((view + 1) * a.HW <= pix) ? 1 : 0;
+        int view;
+        if (hw_shift >= 0) {
+            view = pix >> hw_shift;
+        } else {
+            view = (int)((float)pix * inv_hw);           // pix < 2^24 is exact in fp32; one step of correction covers the rounding
+            view -= (view * a.HW > pix) ? 1 : 0;
+            view += ((view + 1) * a.HW <= pix) ? 1 : 0;
+        }
         return s_env[view];                              // (n_views <= kMaxViewsLds on this path)
     };
     // Everything is addressed as (uniform buffer descriptor) + (32-bit lane offset) [+ scalar offset]: no 64-bit lane
@@ -119,6 +131,8 @@ __device__ __forceinline__ void shade_pixel_loop(const ShadeArgs& a, Body&& body
     const __amdgpu_buffer_rsrc_t r_feat = __builtin_amdgcn_make_buffer_rsrc((void*)a.feat.p, 0, kAll, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_pix = __builtin_amdgcn_make_buffer_rsrc((void*)a.pix_idx, 0, kAll, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_dcol = __builtin_amdgcn_make_buffer_rsrc((void*)(BWD ? a.dcolor.p : a.nrm.p), 0, kAll, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc((void*)out.p, 0, kAll, 0x00020000);
+    const int out_rs = (int)out.rs, out_cs4 = (int)out.cs * 4;
     const int nc = (int)a.nrm.cs * 4, vc = (int)a.view.cs * 4, fc = (int)a.feat.cs * 4, dcs = BWD ? (int)a.dcolor.cs * 4 : 0;
     auto ldf = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
         return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
@@ -158,7 +172,10 @@ __device__ __forceinline__ void shade_pixel_loop(const ShadeArgs& a, Body&& body
         load_soa(min(idx + 2 * s32, last), cur);
         __builtin_amdgcn_sched_barrier(0);
         shade_finish_t<FMT>(a.atlas, a.mat, t, c);
-        if (idx < n32) body(idx, dc, c);
+        if (idx < n32) {
+            const int vo = DM_MUL24((int)idx, out_rs) * 4;
+            body(idx, dc, c, [&](int k, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_out, vo, k * out_cs4, 0); });
+        }
     };
     for (; j < n32; j += 2 * s32) {
         step(A, j);
@@ -169,10 +186,10 @@ __device__ __forceinline__ void shade_pixel_loop(const ShadeArgs& a, Body&& body
 
 template <int FMT, bool DBG>
 __global__ __launch_bounds__(256, 3) void k_shade_fwd(ShadeArgs a) {
-    shade_pixel_loop<FMT, false>(a, [&](long long i, F3, const ShadeCtx& c) {
-        a.color.p[i * a.color.rs] = sat(c.pre.x);
-        a.color.p[i * a.color.rs + a.color.cs] = sat(c.pre.y);
-        a.color.p[i * a.color.rs + 2 * a.color.cs] = sat(c.pre.z);
+    shade_pixel_loop<FMT, false>(a, a.color, [&](long long i, F3, const ShadeCtx& c, auto&& st) {
+        st(0, sat(c.pre.x));
+        st(1, sat(c.pre.y));
+        st(2, sat(c.pre.z));
         if (DBG) {
             F3 sl = lin2srgb(c.spec), dl = lin2srgb(c.diff), sc = lin2srgb(c.spec_albedo), dc = lin2srgb(c.albedo);
             a.albedo[3 * i] = c.albedo.x; a.albedo[3 * i + 1] = c.albedo.y; a.albedo[3 * i + 2] = c.albedo.z;
@@ -188,11 +205,11 @@ __global__ __launch_bounds__(256, 3) void k_shade_fwd(ShadeArgs a) {
 
 template <int FMT>
 __global__ __launch_bounds__(256, 3) void k_shade_bwd(ShadeArgs a) {
-    shade_pixel_loop<FMT, true>(a, [&](long long i, F3 dc, const ShadeCtx& c) {
+    shade_pixel_loop<FMT, true>(a, a.dfeat, [&](long long i, F3 dc, const ShadeCtx& c, auto&& st) {
         float df[5];
         shade_backward(a.mat, c, dc, df);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) a.dfeat.p[i * a.dfeat.rs + k * a.dfeat.cs] = df[k];
+        for (int k = 0; k < 5; ++k) st(k, df[k]);
     });
 }
 
@@ -200,12 +217,17 @@ static inline int shade_offsets32(const ShadeArgs& a, long long n_max, bool bwd)
     auto fits = [&](long long rs, long long cs, int ch) {      // SoA rows (unit row stride), every byte offset below 2^31
         return rs == 1 && cs >= 0 && (n_max - 1) + (ch - 1) * cs < 0x7fffffffLL / 4;
     };
+    auto out_fits = [&](long long rs, long long cs, int ch) {   // outputs: any small row stride (24-bit multiply), 31-bit byte offsets
+        return rs >= 1 && rs < (1 << 20) && cs >= 0 && n_max < (1 << 23) && (n_max - 1) * rs + (ch - 1) * cs < 0x7fffffffLL / 4;
+    };
     return fits(a.nrm.rs, a.nrm.cs, 3) && fits(a.view.rs, a.view.cs, 3) && fits(a.feat.rs, a.feat.cs, 5) &&
-           (!bwd || fits(a.dcolor.rs, a.dcolor.cs, 3)) && n_max < 0x3fffffffLL;
+           (bwd ? fits(a.dcolor.rs, a.dcolor.cs, 3) && out_fits(a.dfeat.rs, a.dfeat.cs, 5) : out_fits(a.color.rs, a.color.cs, 3)) &&
+           n_max < 0x3fffffffLL;
 }
 
 // persistent launch: enough workgroups to fill every CU at the kernels' occupancy, never more than needed
 static inline int shade_blocks(long long n_max, int wg_per_cu) {
+    if (const char* e = getenv("DREAMMAT_SHADE_WGPCU")) wg_per_cu = atoi(e);     // development knob
     long long need = (n_max + 255) / 256;
     return (int)std::min<long long>(need, 256 * wg_per_cu);
 }

@@ -34,6 +34,14 @@ struct MatCfg {
     float min_metallic, max_metallic, min_roughness, max_roughness;
 };
 
+// 24-bit integer multiply: full rate on the VALU (v_mul_i32_i24 / v_mad_i32_i24), where a 32-bit v_mul_lo_u32 takes four
+// issue slots.  Every product in this file is an index into an atlas far below 2^24 texels per factor.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DM_MUL24(a, b) __mul24((a), (b))
+#else
+#define DM_MUL24(a, b) ((a) * (b))
+#endif
+
 struct F3 { float x, y, z; };
 DM_HD F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
 DM_HD F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -45,13 +53,17 @@ DM_HD float sat(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
 
 // nvdiffrast indexCubeMap: direction -> face, (u,v) in [0,1]
 DM_HD int cube_index(F3 d, float& u, float& v) {
-    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
-    int face; float c, a, b;
-    if (az > fmaxf(ax, ay)) { c = d.z; face = 4; a = (c > 0.f) ? d.x : -d.x; b = -d.y; }
-    else if (ay > ax)       { c = d.y; face = 2; a = d.x; b = (c > 0.f) ? d.z : -d.z; }
-    else                    { c = d.x; face = 0; a = (c > 0.f) ? -d.z : d.z; b = -d.y; }
-    if (c < 0.f) face += 1;
-    float m = 0.5f / fabsf(c);
+    // branch-free form of: |z| > max(|x|,|y|) -> z faces (4,5); else |y| > |x| -> y faces (2,3); else x faces (0,1)
+    const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    const bool zmaj = az > fmaxf(ax, ay);
+    const bool ymaj = !zmaj && ay > ax;
+    const float c = zmaj ? d.z : (ymaj ? d.y : d.x);
+    const bool pos = c > 0.f;
+    const float xs = pos ? d.x : -d.x, zs = pos ? d.z : -d.z;          // x faces: a = -sign(c) z; y faces: b = sign(c) z
+    const float a = zmaj ? xs : (ymaj ? d.x : -zs);
+    const float b = ymaj ? zs : -d.y;
+    const int face = (zmaj ? 4 : (ymaj ? 2 : 0)) + (c < 0.f ? 1 : 0);
+    const float m = 0.5f / fabsf(c);
     u = sat(a * m + 0.5f);
     v = sat(b * m + 0.5f);
     return face;
@@ -141,7 +153,7 @@ DM_HD CubeTap cube_tap_addr(int texel_base, int R, CubeCoord cc) {
     CubeTap t;
     t.fx = x - x0; t.fy = y - y0;
     const int P = R + 2;
-    const int idx = texel_base + (cc.face * P + (int)y0 + 1) * P + (int)x0 + 1;
+    const int idx = texel_base + DM_MUL24(DM_MUL24(cc.face, P) + (int)y0 + 1, P) + (int)x0 + 1;
     t.off0 = (unsigned)idx * 8u;
     t.off1 = (unsigned)(idx + P) * 8u;
     return t;
@@ -157,14 +169,26 @@ struct PlainFgRows {
     const float4* base;
     DM_HD float4 operator()(unsigned byte_off) const { return *reinterpret_cast<const float4*>((const char*)base + byte_off); }
 };
+// shared-exponent texels: the exponent scales the bilinear WEIGHT (one multiply per texel), the three 18-bit mantissas are
+// converted and accumulated as they are -- 10 instructions per texel instead of 13 + 3 (the kernels are VALU-bound: ~450
+// instructions per pixel, 12 texels per pixel)
+DM_HD void rgb18e8_accum(unsigned lo, unsigned hi, float w, F3& acc) {
+    const unsigned r = lo & 0x3ffffu, g = ((lo >> 18) | (hi << 14)) & 0x3ffffu, b = (hi >> 4) & 0x3ffffu;
+    const unsigned ebits = (hi >> 22) << 23;
+    float sc;
+    __builtin_memcpy(&sc, &ebits, 4);
+    const float ws = w * sc;
+    acc.x += (float)r * ws; acc.y += (float)g * ws; acc.z += (float)b * ws;
+}
 DM_HD F3 cube_tap_blend(int fmt, HalfRowBits r0, HalfRowBits r1, float fx, float fy) {
     float w00 = (1.f - fx) * (1.f - fy), w10 = fx * (1.f - fy), w01 = (1.f - fx) * fy, w11 = fx * fy;
     if (fmt == kTexelRgb18e8) {
-        F3 t00 = rgb18e8_decode(r0.x, r0.y), t10 = rgb18e8_decode(r0.z, r0.w);
-        F3 t01 = rgb18e8_decode(r1.x, r1.y), t11 = rgb18e8_decode(r1.z, r1.w);
-        return f3(t00.x * w00 + t10.x * w10 + t01.x * w01 + t11.x * w11,
-                  t00.y * w00 + t10.y * w10 + t01.y * w01 + t11.y * w11,
-                  t00.z * w00 + t10.z * w10 + t01.z * w01 + t11.z * w11);
+        F3 acc = f3(0.f, 0.f, 0.f);
+        rgb18e8_accum(r0.x, r0.y, w00, acc);
+        rgb18e8_accum(r0.z, r0.w, w10, acc);
+        rgb18e8_accum(r1.x, r1.y, w01, acc);
+        rgb18e8_accum(r1.z, r1.w, w11, acc);
+        return acc;
     }
     return f3(half_lo(r0.x) * w00 + half_lo(r0.z) * w10 + half_lo(r1.x) * w01 + half_lo(r1.z) * w11,
               half_hi(r0.x) * w00 + half_hi(r0.z) * w10 + half_hi(r1.x) * w01 + half_hi(r1.z) * w11,
@@ -245,11 +269,11 @@ DM_HD void shade_issue_t(const EnvAtlas& A, const MatCfg& M, int env, F3 n, F3 v
         int iy0 = (int)y0;
         int iy1 = min(iy0 + 1, L - 1);
         iy0 = max(iy0, 0);
-        t.fga = fg_rows((unsigned)(iy0 * (L + 1) + (int)x0 + 1) * 16u);
-        t.fgb = fg_rows((unsigned)(iy1 * (L + 1) + (int)x0 + 1) * 16u);
+        t.fga = fg_rows((unsigned)(DM_MUL24(iy0, L + 1) + (int)x0 + 1) * 16u);
+        t.fgb = fg_rows((unsigned)(DM_MUL24(iy1, L + 1) + (int)x0 + 1) * 16u);
     }
     {
-        CubeTap d = cube_tap_addr(env * (int)A.diff_env_stride, A.diff_res, cube_coord(n));
+        CubeTap d = cube_tap_addr(DM_MUL24(env, (int)A.diff_env_stride), A.diff_res, cube_coord(n));
         t.da = diff_rows(d.off0); t.db = diff_rows(d.off1);
         t.dfx = d.fx; t.dfy = d.fy;
     }
@@ -259,7 +283,7 @@ DM_HD void shade_issue_t(const EnvAtlas& A, const MatCfg& M, int env, F3 n, F3 v
         int l0 = min((int)floorf(level), A.n_mips - 1);
         int l1 = min(l0 + 1, A.n_mips - 1);
         t.mipf = level - (float)l0;
-        const int envt = env * (int)A.spec_env_stride;
+        const int envt = DM_MUL24(env, (int)A.spec_env_stride);
         CubeCoord rc = cube_coord(refl);
         CubeTap a0 = cube_tap_addr(envt + (int)mip_off(l0), mip_res(l0), rc);
         t.s0a = spec_rows(a0.off0); t.s0b = spec_rows(a0.off1);
