@@ -7,12 +7,19 @@ frozen (:638), per step (:858-915)
     down, mid = controlnet(x_t, t, text, cond);  eps = unet(x_t, t, text, down, mid);  loss = mse(eps, noise)
 
 and the classifier-free-guidance dropout of the dataset (controlnet_train/diffusers_dataset.py:148-159: 5 % each for
-dropping the whole condition / the depth / the normal / the light maps, 30 % for an empty prompt).  What is NOT here: the accelerate launcher, the CLIP text
-encoder (text embeddings are an input) and the Blender dataset producer.  The frozen UNet / VAE run on the same HIP
+dropping the whole condition / the depth / the normal / the light maps, 30 % for an empty prompt), the dataset itself
+(`ControlNetRenderDataset`: the reference's Blender output tree color/ depth/ normal/ light/ per object, read with PIL,
+diffusers_dataset.py:10-159) and a one-process-per-GPU launcher (`python -m dreammat_amd.controlnet_train`, the reference
+uses HF accelerate, diffusers_train_controlnet.py:858-915: same loop, gradients all-reduced over RCCL).  What is NOT here: the CLIP
+text encoder (text embeddings come from prompt.py's encoder or its synthetic stand-in) and Blender (the tree is an input).  The frozen UNet / VAE run on the same HIP
 kernels as the SDS path wherever those are differentiable (implicit-GEMM conv data gradients, GroupNorm backward); the
 attention of the UNet falls back to the matmul-softmax path under autograd (the MFMA attention kernel is forward-only)
 and the trainable ControlNet convolutions use the im2col lowering, so this is a correctness-first implementation.
 """
+import json
+import os
+
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -102,3 +109,194 @@ class ControlNetTrainer:
     def state_dict(self):
         """diffusers key layout (loadable by dreammat_amd.sd.loading and by diffusers' ControlNetModel)."""
         return self.controlnet.state_dict()
+
+
+# ------------------------------------------------------------------------------------------------ dataset
+def _imread(path):
+    from PIL import Image
+    if not os.path.exists(path):
+        return None
+    return Image.open(path)
+
+
+def _resize_area(img, size):
+    """cv2.INTER_AREA for a downscale = box filter"""
+    from PIL import Image
+    return img if img.size == (size, size) else img.resize((size, size), Image.BOX)
+
+
+def load_rgb(path, size):
+    """diffusers_dataset.py:27-42: RGB(A) PNG -> [size,size,3] in [0,1]; transparent pixels -> 0; a missing file -> zeros."""
+    img = _imread(path)
+    if img is None:
+        return np.zeros((size, size, 3), np.float32)
+    a = np.asarray(img.convert("RGBA") if img.mode in ("RGBA", "LA", "P") else img.convert("RGB")).copy()
+    if a.shape[2] == 4:
+        a[a[..., 3] == 0] = 0
+        a = a[..., :3]
+    from PIL import Image
+    a = np.asarray(_resize_area(Image.fromarray(a), size))
+    return a.astype(np.float32) / 255.0
+
+
+def load_target(path, size):
+    """:44-60: -> ([size,size,3] in [-1,1], had_alpha); transparent pixels -> white; a missing file -> ones."""
+    img = _imread(path)
+    if img is None:
+        return np.ones((size, size, 3), np.float32), False
+    alpha = img.mode in ("RGBA", "LA")
+    a = np.asarray(img.convert("RGBA") if alpha else img.convert("RGB")).copy()
+    if alpha:
+        a[a[..., 3] == 0] = 255
+        a = a[..., :3]
+    from PIL import Image
+    a = np.asarray(_resize_area(Image.fromarray(a), size))
+    return a.astype(np.float32) / 127.5 - 1.0, alpha
+
+
+def load_depth(path, size):
+    """:62-82: 16-bit PNG in millimetres -> [size,size,1]: 0 on the background, else the inverse depth min-max normalised to
+    [0.3, 1] over the object; also the object mask."""
+    from PIL import Image
+    img = Image.open(path)
+    if img.size != (size, size):
+        img = img.resize((size, size), Image.NEAREST)
+    depth = np.asarray(img).astype(np.float64) / 1000.0
+    mask = depth > 0
+    if mask.sum() <= 0:
+        return depth[..., None].astype(np.float32), mask
+    inv = 1.0 / (depth + 1e-6)
+    dmax, dmin = inv[mask].max(), inv[mask].min()
+    depth[mask] = (1 - 0.3) * (inv[mask] - dmin) / (dmax - dmin + 1e-6) + 0.3
+    return depth[..., None].astype(np.float32), mask
+
+
+class ControlNetRenderDataset(torch.utils.data.Dataset):
+    """diffusers_dataset.py:84-159 (DiffusersDataset): <datadir>/<object>/{color,depth,normal,light}/..., 5 environments x 16
+    views per object, prompts from a JSON {object: prompt}.  Item = pixel_values [H,W,3] in [-1,1], the prompt string, and
+    conditioning_pixel_values [H,W,22] = depth | normal | light m0r0 m0r.5 m0r1 m1r0 m1r.5 m1r1.  `use_cfg`: the reference's
+    condition / prompt dropout, drawn from `rng` (random.Random) so that tests can pin it."""
+    env_num, view_num = 5, 16
+
+    def __init__(self, datadir, promptfile, size=512, use_cfg=False, rng=None):
+        import random
+        self.size, self.use_cfg, self.rng = size, use_cfg, rng or random.Random()
+        with open(promptfile) as fh:
+            content = json.load(fh)
+        self.obj_info = [{"path": os.path.join(datadir, k), "prompt": v} for k, v in content.items()
+                         if os.path.isdir(os.path.join(datadir, k))]
+
+    def __len__(self):
+        return len(self.obj_info) * self.env_num * self.view_num
+
+    def __getitem__(self, idx):
+        per = self.env_num * self.view_num
+        info = self.obj_info[idx // per]
+        env, view = (idx % per) // self.view_num + 1, (idx % per) % self.view_num
+        p, S = info["path"], self.size
+        target, alpha = load_target(f"{p}/color/{view:03d}_color_env{env}.png", S)
+        depth, mask = load_depth(f"{p}/depth/{view:03d}.png", S)
+        normal = load_rgb(f"{p}/normal/{view:03d}.png", S)
+        if not alpha:
+            target[~mask] = 1.0
+        lights = [load_rgb(f"{p}/light/{view:03d}_m{m}r{r}_env{env}.png", S)
+                  for m in ("0.0", "1.0") for r in ("0.0", "0.5", "1.0")]
+        source = np.concatenate([depth, normal] + lights, axis=-1)
+        prompt = info["prompt"]
+        if self.use_cfg:
+            r = self.rng.random()
+            if r < 0.05:
+                source = np.zeros_like(source)
+            elif 0.05 < r < 0.1:
+                source[..., 0] = 0
+            elif 0.1 < r < 0.15:
+                source[..., 1:4] = 0
+            elif 0.15 < r < 0.2:
+                source[..., 4:] = 0
+            elif 0.2 < r < 0.5:
+                prompt = ""
+        return dict(pixel_values=torch.from_numpy(target), input_ids=prompt, conditioning_pixel_values=torch.from_numpy(source))
+
+
+def collate(items):
+    """training script :700-720: NHWC arrays -> NCHW float tensors, prompts stay a list"""
+    return {"pixel_values": torch.stack([i["pixel_values"] for i in items]).permute(0, 3, 1, 2).contiguous().float(),
+            "conditioning_pixel_values": torch.stack([i["conditioning_pixel_values"] for i in items]).permute(0, 3, 1, 2).contiguous().float(),
+            "prompts": [i["input_ids"] for i in items]}
+
+
+def main(argv=None):
+    """One process per GPU (python -m torch.distributed.run ... -m dreammat_amd.controlnet_train): the loop of
+    diffusers_train_controlnet.py:858-915 with the ControlNet gradients all-reduced before clipping."""
+    import argparse
+    import torch.distributed as dist
+    from .prompt import StableDiffusionPromptProcessor
+    from .sd import AutoencoderKLEncoder, UNet2DConditionModel
+    from .sd.models import arch_for
+    from .sd.loading import load_component
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pretrained_model_name_or_path", default="stabilityai/stable-diffusion-2-1-base")
+    ap.add_argument("--train_data_dir", required=True)
+    ap.add_argument("--prompt_file", required=True)
+    ap.add_argument("--output_dir", default="controlnet_out")
+    ap.add_argument("--resolution", type=int, default=512)
+    ap.add_argument("--train_batch_size", type=int, default=4)
+    ap.add_argument("--learning_rate", type=float, default=1e-5)
+    ap.add_argument("--max_train_steps", type=int, default=1000)
+    ap.add_argument("--checkpointing_steps", type=int, default=500)
+    ap.add_argument("--use_cfg", action="store_true")
+    ap.add_argument("--synthetic", action="store_true", help="random-init nets / pseudo text embeddings (no checkpoints on this box)")
+    a = ap.parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))) if torch.cuda.is_available() else torch.device("cpu")
+    if world > 1:
+        dist.init_process_group("nccl" if dev.type == "cuda" else "gloo")
+    arch = arch_for(a.pretrained_model_name_or_path)
+    torch.manual_seed(0)
+    vae, unet = AutoencoderKLEncoder(arch), UNet2DConditionModel(arch)
+    if not a.synthetic:
+        load_component(vae, a.pretrained_model_name_or_path, "vae")
+        load_component(unet, a.pretrained_model_name_or_path, "unet")
+    dt = torch.bfloat16 if dev.type == "cuda" else torch.float32
+    vae.to(dev, dt); unet.to(dev, dt)
+    tr = ControlNetTrainer(vae, unet, lr=a.learning_rate)
+    tr.controlnet.to(dev)
+    ds = ControlNetRenderDataset(a.train_data_dir, a.prompt_file, a.resolution, a.use_cfg)
+    sampler = torch.utils.data.distributed.DistributedSampler(ds, world, rank, shuffle=True, seed=0) if world > 1 else None
+    dl = torch.utils.data.DataLoader(ds, batch_size=a.train_batch_size, shuffle=sampler is None, sampler=sampler,
+                                     collate_fn=collate, drop_last=True)
+    embed = {}
+
+    def text(prompts):
+        for p in set(prompts):
+            if p not in embed:
+                pp = StableDiffusionPromptProcessor({"prompt": p or " ", "pretrained_model_name_or_path": a.pretrained_model_name_or_path,
+                                                     "synthetic": a.synthetic, "use_perp_neg": False})
+                embed[p] = pp.text_embeddings[:1].to(dev)
+        return torch.cat([embed[p] for p in prompts])
+    while tr.global_step < a.max_train_steps:
+        for batch in dl:
+            loss = controlnet_training_loss(tr.vae, tr.unet, tr.controlnet, tr.scheduler, batch["pixel_values"].to(dev, dt),
+                                            batch["conditioning_pixel_values"].to(dev), text(batch["prompts"]))
+            loss.backward()
+            if world > 1:
+                for p in tr.controlnet.parameters():
+                    if p.grad is not None:
+                        dist.all_reduce(p.grad)
+                        p.grad /= world
+            torch.nn.utils.clip_grad_norm_(tr.controlnet.parameters(), tr.max_grad_norm)
+            tr.opt.step(); tr.opt.zero_grad(set_to_none=True)
+            tr.global_step += 1
+            if rank == 0 and tr.global_step % 10 == 0:
+                print(json.dumps({"step": tr.global_step, "loss": float(loss)}), flush=True)
+            if rank == 0 and tr.global_step % a.checkpointing_steps == 0:
+                os.makedirs(a.output_dir, exist_ok=True)
+                torch.save(tr.state_dict(), os.path.join(a.output_dir, f"controlnet_step{tr.global_step}.pt"))
+            if tr.global_step >= a.max_train_steps:
+                break
+    return tr
+
+
+if __name__ == "__main__":
+    main()

@@ -42,6 +42,31 @@ def dilate_charts(image, hole_mask, n_iter):
     return img[0].permute(1, 2, 0)
 
 
+def per_triangle_atlas(n_faces, texture_size, padding, device):
+    """-> (v_tex [3 n_faces, 2] in [0,1], t_tex_idx [n_faces, 3] int64): face f occupies one half of cell f // 2 of a
+    ceil(sqrt(n_faces / 2))^2 grid; the two triangles of a cell are separated by a diagonal gutter."""
+    import math
+    cells = max(1, math.ceil(math.sqrt((n_faces + 1) // 2)))
+    cell = 1.0 / cells
+    g = min(0.25 * cell, max(float(padding), 0.5) / float(texture_size))      # gutter in uv units
+    f = torch.arange(n_faces, device=device)
+    c = f // 2
+    ox = (c % cells).float() * cell
+    oy = (c // cells).float() * cell
+    lo, hi = g, cell - g
+    upper = (f % 2 == 1)
+    # lower triangle: (lo,lo) (hi-g,lo) (lo,hi-g); upper triangle: (hi,hi) (lo+g,hi) (hi,lo+g)
+    ax = torch.where(upper, torch.full_like(ox, hi), torch.full_like(ox, lo))
+    ay = ax.clone()
+    bx = torch.where(upper, torch.full_like(ox, lo + g), torch.full_like(ox, hi - g))
+    by = ay.clone()
+    cx = ax.clone()
+    cy = torch.where(upper, torch.full_like(ox, lo + g), torch.full_like(ox, hi - g))
+    uv = torch.stack([torch.stack([ox + ax, oy + ay], -1), torch.stack([ox + bx, oy + by], -1),
+                      torch.stack([ox + cx, oy + cy], -1)], 1).reshape(-1, 2)
+    return uv.float(), torch.arange(3 * n_faces, device=device, dtype=torch.int64).reshape(n_faces, 3)
+
+
 @dreammat_amd.register("mesh-exporter")
 class MeshExporter(BaseModule):
     @dataclass
@@ -86,9 +111,14 @@ class MeshExporter(BaseModule):
                 "map_Pr": None, "map_format": self.cfg.texture_format}
 
     def _require_uv(self, mesh):
+        """mesh_exporter.py:53-60 unwraps a mesh without UVs through `mesh.unwrap_uv` (xatlas).  xatlas is not available here;
+        the stand-in is the simplest valid atlas: one right triangle per face in a square grid of cells (two triangles per
+        cell, `padding` texels of gutter), every face its own chart -- no stretch optimisation, no chart merging, but a
+        bijective atlas the baker and any OBJ viewer accept."""
         if mesh.v_tex is None:
-            raise NotImplementedError("the mesh has no UVs and xatlas is not available here: export a mesh that carries "
-                                      "vt records (all of load/shapes/objs do) or set exporter.save_uv=false")
+            mesh.v_tex, mesh.t_tex_idx = per_triangle_atlas(mesh.t_pos_idx.shape[0], int(self.cfg.texture_size),
+                                                            int(self.cfg.xatlas_pack_options.get("padding", 2)),
+                                                            mesh.v_pos.device)
 
     @torch.no_grad()
     def bake_textures(self, mesh):

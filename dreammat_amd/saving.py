@@ -25,6 +25,22 @@ def save_rgba(path, rgb, alpha):
     return path
 
 
+def save_gif(img_dir, n_frames=120, fps=30, name="eval.gif"):
+    """saving.py:401-408: frames `<img_dir>/<i>.png`, i = 0..n_frames-1 (the reference hard-codes 120 = its test view count),
+    written as `<img_dir>/eval.gif` at `fps` (imageio there, PIL here; frames that are missing end the sequence early)."""
+    frames = []
+    for i in range(int(n_frames)):
+        f = os.path.join(img_dir, f"{i}.png")
+        if not os.path.exists(f):
+            break
+        frames.append(Image.open(f).convert("RGB"))
+    if not frames:
+        raise FileNotFoundError(f"no frames 0.png.. under {img_dir}")
+    out = os.path.join(img_dir, name)
+    frames[0].save(out, save_all=True, append_images=frames[1:], duration=max(1, int(round(1000.0 / fps))), loop=0)
+    return out
+
+
 def _np(x):
     return x.detach().float().cpu().numpy() if torch.is_tensor(x) else x
 

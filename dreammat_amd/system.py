@@ -315,16 +315,22 @@ class Trainer:
 
     @torch.no_grad()
     def test(self):
-        """systems/dreammat.py:247-300: per-view albedo / roughness / metallic / render RGBA PNGs."""
-        from .saving import save_rgba
+        """systems/dreammat.py:247-300: per view the five-panel grid `view/<i>.png` (render | normal | albedo | metalness |
+        roughness) and the albedo / roughness / metallic / render RGBA PNGs; then `view/eval.gif` (on_test_epoch_end, 30 fps)."""
+        from .saving import save_gif, save_image_grid, save_rgba
         s = self.system
         self.dm.setup("test")
         base = os.path.join(self.trial_dir, "save", f"it{s.true_global_step}-test")
-        for i in range(len(self.dm.test_dataset)):
+        n = len(self.dm.test_dataset)
+        for i in range(n):
             out = s(to_device(self.dm.test_dataset[i], s.device_))
             a = out["opacity"][0]
+            save_image_grid(os.path.join(base, "view", f"{i}.png"),
+                            [out["comp_rgb"][0], out["comp_normal"][0], out["albedo"][0], out["metalness"][0].expand(-1, -1, 3),
+                             out["roughness"][0].expand(-1, -1, 3)])
             for name, key in (("albedo", "albedo"), ("roughness", "roughness"), ("metallic", "metalness"), ("render", "comp_rgb")):
                 img = out[key][0]
                 if img.shape[-1] == 1:
                     img = img.expand(-1, -1, 3)
                 save_rgba(os.path.join(base, name, f"{i}.png"), img, a)
+        return save_gif(os.path.join(base, "view"), n_frames=n, fps=30)

@@ -296,14 +296,11 @@ def test_mesh_exporter_bakes_textures_and_writes_obj_mtl(monkeypatch, tmp_path):
     assert kd.shape == (S, S, 3) and np.abs(kd.astype(np.float32) / 255 - maps["albedo"].numpy()).max() < 1 / 255 + 1e-6
     re = pmesh.load_obj(str(tmp_path / "exp" / "model.obj"))
     assert torch.allclose(re.v_pos, m.v_pos) and torch.equal(re.t_pos_idx, m.t_pos_idx)
-    # vertex-colour variant and the no-UV error
+    # vertex-colour variant (a mesh without UVs gets the per-triangle atlas: test_per_triangle_atlas_fallback_and_gif_writer)
     ex2 = MeshExporter({"fmt": "obj", "save_uv": False}, geometry=Geo(), material=Mat(), background=None)
     p2 = saving.save_obj(str(tmp_path / "exp2" / "m"), **ex2()[0].params)
     first_v = [l for l in open(p2[0]).read().splitlines() if l.startswith("v ")][0].split()
     assert len(first_v) == 7                                # x y z r g b
-    m.v_tex = None
-    with pytest.raises(NotImplementedError):
-        ex()
     assert "mesh-exporter" in dreammat_amd.__modules__ or dreammat_amd.find("mesh-exporter") is MeshExporter
 
 
@@ -397,3 +394,65 @@ def test_partial_weight_load_skips_reference_only_keys(tmp_path):
     torch.save({"state_dict": trunc}, tmp_path / "trunc.ckpt")
     with pytest.raises(RuntimeError, match="missing"):
         dreammat_amd.find("dreammat-mesh")(dict(cfg, weights=f"{tmp_path / 'trunc.ckpt'}:geometry"))
+
+
+def test_per_triangle_atlas_fallback_and_gif_writer(monkeypatch, tmp_path):
+    """f-3 remainder: a mesh without UVs gets the per-triangle atlas (mesh_exporter.py:53-60 would call xatlas):
+    every face its own chart, charts disjoint and inside [0,1]^2, each chart covered by at least one texel at the default
+    resolution; and saving.save_gif (saving.py:401-408) assembles `<i>.png` frames into eval.gif."""
+    import numpy as np
+    from PIL import Image
+
+    from dreammat_amd import mesh as pmesh, saving
+    from dreammat_amd.exporter import MeshExporter, per_triangle_atlas
+    from oracle import raster as oraster
+
+    nf, S = 37, 256
+    uv, tt = per_triangle_atlas(nf, S, 2, torch.device("cpu"))
+    assert uv.shape == (3 * nf, 2) and tt.shape == (nf, 3) and float(uv.min()) > 0 and float(uv.max()) < 1
+    clip = torch.cat([uv * 2 - 1, torch.zeros(3 * nf, 1), torch.ones(3 * nf, 1)], -1)[None].numpy()
+    ro = oraster.rasterize(clip, tt.numpy().astype(np.int32), S, S)
+    ids = ro[0, :, :, 3].astype(np.int64)
+    assert set(np.unique(ids)) == set(range(nf + 1))             # 0 = gutter; every face owns texels
+    # charts are disjoint with a gutter: no two DIFFERENT faces in 4-neighbouring texels
+    for a, b in ((ids[:, 1:], ids[:, :-1]), (ids[1:], ids[:-1])):
+        touch = (a != b) & (a > 0) & (b > 0)
+        assert not touch.any()
+
+    class CpuRaster:
+        def __init__(self, device):
+            pass
+
+        def rasterize(self, pos, tri, H, W, check_overflow=False):
+            return torch.from_numpy(oraster.rasterize(pos, tri, H, W))
+    monkeypatch.setattr(hipops, "RasterContext", CpuRaster)
+    monkeypatch.setattr(hipops, "interpolate", lambda attr, rast, tri: torch.from_numpy(oraster.interpolate(attr, rast, tri)))
+    m = pmesh.quad_mesh()
+    m.v_tex, m.t_tex_idx = None, None
+
+    class Geo:
+        def isosurface(self):
+            return m
+
+        def export(self, points, **kw):
+            return {"features": torch.cat([points * 4.0, points[:, :2] * 2.0], dim=-1)}
+
+    class Mat:
+        def export(self, features, **kw):
+            s = torch.sigmoid(features)
+            return {"albedo": s[..., :3], "metallic": s[..., 3:4], "roughness": s[..., 4:5]}
+    ex = MeshExporter({"texture_size": 64, "texture_format": "png"}, geometry=Geo(), material=Mat(), background=None)
+    outs = ex()                                                  # used to raise NotImplementedError without UVs
+    assert m.v_tex is not None and outs[0].params["map_Kd"].shape == (64, 64, 3)
+    paths = saving.save_obj(str(tmp_path / "m.obj"), **outs[0].params)
+    assert any(p.endswith("texture_kd.png") for p in paths)
+    # gif
+    d = tmp_path / "view"
+    d.mkdir()
+    for i in range(5):
+        Image.fromarray(np.full((8, 12, 3), 40 * i, np.uint8)).save(d / f"{i}.png")
+    g = saving.save_gif(str(d), n_frames=120, fps=30)
+    im = Image.open(g)
+    assert im.n_frames == 5 and im.size == (12, 8)
+    with pytest.raises(FileNotFoundError):
+        saving.save_gif(str(tmp_path / "nothing"))

@@ -156,3 +156,77 @@ def test_controlnet_training_step_and_cfg_dropout():
     assert int((z.any(1) & ~(all0 | depth0 | normal0 | light0)).sum()) == 0
     dt = (t2.view(-1) == 0)
     assert abs(float(dt.float().mean()) - 0.30) < 0.01 and int((dt & z.any(1)).sum()) == 0   # never both
+
+
+def test_controlnet_render_dataset_reads_the_reference_tree(tmp_path):
+    """f-4 remainder: the dataset of controlnet_train/diffusers_dataset.py:84-159 on a synthetic tree in the
+    reference's layout -- index -> (object, environment, view) mapping, 22 channels in the reference's order, depth decoding
+    (16-bit mm -> inverse min-max to [0.3, 1], background 0), transparent pixels (condition -> 0, target -> white),
+    target without alpha whitened by the depth mask, and the pinned CFG dropout."""
+    import json
+    import random
+
+    import numpy as np
+    from PIL import Image
+
+    from dreammat_amd import controlnet_train as ct
+    S = 8
+    root = tmp_path / "data"
+    for sub in ("color", "depth", "normal", "light"):
+        (root / "obj_a" / sub).mkdir(parents=True)
+    (root / "not_listed").mkdir()
+    rs = np.random.RandomState(0)
+    depth_mm = np.zeros((S, S), np.uint16)
+    depth_mm[2:6, 2:6] = rs.randint(1500, 2500, (4, 4))
+    view, env = 3, 2
+    Image.fromarray(depth_mm).save(root / "obj_a" / "depth" / f"{view:03d}.png")
+    nrm = rs.randint(0, 255, (S, S, 4)).astype(np.uint8); nrm[..., 3] = 255; nrm[0, 0, 3] = 0
+    Image.fromarray(nrm, "RGBA").save(root / "obj_a" / "normal" / f"{view:03d}.png")
+    col = rs.randint(0, 255, (S, S, 3)).astype(np.uint8)
+    Image.fromarray(col, "RGB").save(root / "obj_a" / "color" / f"{view:03d}_color_env{env}.png")
+    lights = {}
+    for m in ("0.0", "1.0"):
+        for r in ("0.0", "0.5", "1.0"):
+            a = rs.randint(0, 255, (S, S, 3)).astype(np.uint8)
+            lights[(m, r)] = a
+            Image.fromarray(a, "RGB").save(root / "obj_a" / "light" / f"{view:03d}_m{m}r{r}_env{env}.png")
+    (tmp_path / "prompts.json").write_text(json.dumps({"obj_a": "a red teapot", "missing_dir": "x"}))
+    ds = ct.ControlNetRenderDataset(str(root), str(tmp_path / "prompts.json"), size=S)
+    assert len(ds) == 5 * 16                                        # one listed object with a directory
+    item = ds[(env - 1) * 16 + view]
+    assert item["input_ids"] == "a red teapot"
+    src, tgt = item["conditioning_pixel_values"].numpy(), item["pixel_values"].numpy()
+    assert src.shape == (S, S, 22) and tgt.shape == (S, S, 3)
+    mask = depth_mm > 0
+    d = depth_mm.astype(np.float64) / 1000
+    inv = 1 / (d + 1e-6)
+    ref_d = np.where(mask, 0.7 * (inv - inv[mask].min()) / (inv[mask].max() - inv[mask].min() + 1e-6) + 0.3, 0)
+    assert np.abs(src[..., 0] - ref_d).max() < 1e-6 and src[..., 0][mask].min() >= 0.3 - 1e-6
+    ref_n = nrm[..., :3].astype(np.float32) / 255; ref_n[0, 0] = 0            # transparent -> 0
+    assert np.abs(src[..., 1:4] - ref_n).max() < 1e-6
+    k = 4
+    for m in ("0.0", "1.0"):
+        for r in ("0.0", "0.5", "1.0"):
+            assert np.abs(src[..., k:k + 3] - lights[(m, r)].astype(np.float32) / 255).max() < 1e-6, (m, r)
+            k += 3
+    ref_t = col.astype(np.float32) / 127.5 - 1; ref_t[~mask] = 1.0          # no alpha: whitened outside the depth mask
+    assert np.abs(tgt - ref_t).max() < 1e-6
+    b = ct.collate([item, item])
+    assert b["pixel_values"].shape == (2, 3, S, S) and b["conditioning_pixel_values"].shape == (2, 22, S, S)
+    # pinned CFG dropout: the same draw as the reference's `random.random()` thresholds
+    for seed, check in ((1, None), (5, None), (8, None)):
+        r = random.Random(seed).random()
+        it = ct.ControlNetRenderDataset(str(root), str(tmp_path / "prompts.json"), S, True, random.Random(seed))[(env - 1) * 16 + view]
+        s2 = it["conditioning_pixel_values"].numpy()
+        if r < 0.05:
+            assert not s2.any()
+        elif 0.05 < r < 0.1:
+            assert not s2[..., 0].any() and np.array_equal(s2[..., 1:], src[..., 1:])
+        elif 0.1 < r < 0.15:
+            assert not s2[..., 1:4].any()
+        elif 0.15 < r < 0.2:
+            assert not s2[..., 4:].any()
+        elif 0.2 < r < 0.5:
+            assert it["input_ids"] == "" and np.array_equal(s2, src)
+        else:
+            assert it["input_ids"] == "a red teapot" and np.array_equal(s2, src)
