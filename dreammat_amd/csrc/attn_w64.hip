@@ -136,6 +136,18 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) off4[i] = l31 * 128 + ((((2 * i + hi) ^ ((l31 >> 1) & 7))) << 4);
     auto frag = [&](const char* base, int off) { return *reinterpret_cast<const bf16x8*>(base + off); };
+    // The loop is unrolled over the ring so that every stage is a compile-time constant: a fragment read is then ONE
+    // ds_read_b128 with an immediate offset on a loop-invariant address register (8 v_add_u32 + ~20 SALU per tile before).
+    // A DS offset has 16 bits; stage 4 lies past it and gets its own address registers.
+    const char* fb[4];
+    const char* fb4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { fb[i] = smem + off4[i]; fb4[i] = smem + off4[i] + 65536; }
+    auto sfrag = [&](auto stage_tag, int i, int off) {       // fragment i of `stage`, `off` bytes into the stage
+        constexpr int ST = decltype(stage_tag)::value;
+        if (ST * kStage + 12288 + 4096 <= 65536) return *reinterpret_cast<const bf16x8*>(fb[i] + ST * kStage + off);
+        return *reinterpret_cast<const bf16x8*>(fb4[i] + (ST * kStage - 65536) + off);
+    };
 
     // ---- state
     f32x16 o[2][2];                  // [query block][32-row block of head_dim]
@@ -205,8 +217,9 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
     //   chunks 4p+2, 4p+3 P.V of slice p-1, both head_dim blocks; after query block 1 the V^T fragments of that k-step are
     //                     refilled from tile j+1 (vb1).
     // LAST: nothing of tile j+1 exists.
-    auto tile_body = [&](const char* ks1, const char* kb2, const char* vb1, int dma_tile, int dma_stage, auto last_tag) {
+    auto tile_body = [&](auto s1_tag, auto s2_tag, auto sd_tag, int dma_tile, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
+        constexpr int dma_stage = decltype(sd_tag)::value;
 #pragma unroll
         for (int c = 0; c <= 32; ++c) {
             const int p = c >> 2, c4 = c & 3;
@@ -223,14 +236,14 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
                         } else {
                             s[qb][tq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[f], qf[qb][kq], s[qb][tq], 0, 0, 0);
                         }
-                        if (!LAST && c4 == 1) kf[f] = p < 4 ? frag(ks1, 4096 + off4[kq]) : frag(kb2, off4[kq]);
+                        if (!LAST && c4 == 1) kf[f] = p < 4 ? sfrag(s1_tag, kq, 4096) : sfrag(s2_tag, kq, 0);
                     }
                 } else if (p > 0) {                                // P.V of slice p-1, head_dim block c4 - 2
                     const int pp = p - 1, ks = pp >> 1, qb = pp & 1, dt = c4 - 2;
                     pv_mfma(o[qb][dt], vf[dt][ks], pf[pp & 1]);
                     if (!LAST && dt == 1 && qb == 1) {
-                        vf[0][ks] = frag(vb1, off4[ks]);
-                        vf[1][ks] = frag(vb1, 4096 + off4[ks]);
+                        vf[0][ks] = sfrag(s1_tag, ks, kKBytes);
+                        vf[1][ks] = sfrag(s1_tag, ks, kKBytes + 4096);
                     }
                 }
                 {
@@ -261,8 +274,8 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
         asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o[1][0]) : "a"(vf[0][3]), "v"(pf[1]));
         pv_mfma(o[1][1], vf[1][3], pf[1]);
         if (!LAST) {
-            vf[0][3] = frag(vb1, off4[3]);
-            vf[1][3] = frag(vb1, 4096 + off4[3]);
+            vf[0][3] = sfrag(s1_tag, 3, kKBytes);
+            vf[1][3] = sfrag(s1_tag, 3, kKBytes + 4096);
         }
     };
     auto row_sum = [&](int qb) { return lA[qb] + lB[qb]; };
@@ -293,17 +306,29 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
 
     // ---- main loop
     stamp(1);
-    int j = 0, s1 = 1, s2 = 2, sd = (2 + PD) % NST;        // stages of tiles j+1, j+2, j+2+PD
-    for (; j < n_tiles - 1; ++j) {
+    int j = 0;
+    auto one = [&](auto r_tag) {                             // tile j with j % NST == R: stages of tiles j+1, j+2, j+2+PD
+        constexpr int R = decltype(r_tag)::value;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * kL) : "memory");     // tile j+2 has landed
         __builtin_amdgcn_s_barrier();
-        tile_body(smem + s1 * kStage, smem + s2 * kStage, smem + s1 * kStage + kKBytes, j + 2 + PD, sd, std::false_type{});
+        tile_body(std::integral_constant<int, (R + 1) % NST>{}, std::integral_constant<int, (R + 2) % NST>{},
+                  std::integral_constant<int, (R + 2 + PD) % NST>{}, j + 2 + PD, std::false_type{});
         maybe_rebase();
-        s1 = s1 + 1 == NST ? 0 : s1 + 1;
-        s2 = s2 + 1 == NST ? 0 : s2 + 1;
-        sd = sd + 1 == NST ? 0 : sd + 1;
+        ++j;
+    };
+    static_assert(NST == 5, "the ring is unrolled by hand below");
+    while (j + NST <= n_tiles - 1) {
+        one(std::integral_constant<int, 0>{}); one(std::integral_constant<int, 1>{}); one(std::integral_constant<int, 2>{});
+        one(std::integral_constant<int, 3>{}); one(std::integral_constant<int, 4>{});
     }
-    tile_body(smem, smem, smem, 0, 0, std::true_type{});
+    {   // the remaining 0..4 tiles before the last one (j % NST == 0 here)
+        const int rem = n_tiles - 1 - j;
+        if (rem > 0) one(std::integral_constant<int, 0>{});
+        if (rem > 1) one(std::integral_constant<int, 1>{});
+        if (rem > 2) one(std::integral_constant<int, 2>{});
+        if (rem > 3) one(std::integral_constant<int, 3>{});
+    }
+    tile_body(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0, std::true_type{});
     stamp(2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the re-fetched tiles past the end must not outlive the workgroup's LDS
 
