@@ -84,6 +84,30 @@ def system_config(a, views_per_rank):
     }
 
 
+def baseline_config_name(a, n_tris):
+    """which BASELINE.json `configs` entry the run's shape is (the string used to be hard-coded to configs[2])"""
+    if a.res == 512 and a.views == 8 and 40000 <= n_tris <= 60000:
+        return "BASELINE configs[2]" if int(os.environ.get("WORLD_SIZE", 1)) == 1 else "BASELINE configs[3] (configs[2] sharded by view)"
+    if a.res == 512 and a.views == 4 and n_tris < 12000:
+        return "BASELINE configs[1]"
+    if a.res == 1024 and a.views == 16 and n_tris >= 190000:
+        return "BASELINE configs[4] shape (bf16 nets and bf16 MFMA attention: the fp8 attention of that entry is not built)"
+    return "custom shape (no BASELINE.json entry)"
+
+
+def _profile_commit(path):
+    """provenance of a committed counter profile: the commit / date tools/pmc_collect.py stamped into it (the GPU box has no
+    .git) and a content hash -- a stale counter file is visible in the JSON line"""
+    import hashlib
+    try:
+        raw = open(path, "rb").read()
+        d = json.loads(raw)
+        return {"collected_at_commit": d.get("collected_at_commit"), "collected_on": d.get("collected_on"),
+                "sha256_12": hashlib.sha256(raw).hexdigest()[:12]}
+    except Exception:
+        return None
+
+
 def pmc_traffic(kernel_key, batch):
     """HBM traffic per launch of the kernel named by `kernel_key` ("... conv3x3[Cin->Cout@HxW,s1]" at batch `batch`, or
     "... attention_fwd_bf16[Sq=..,Skv=..,h=..,D=..]" at batch 3*`batch`) from the newest committed counter profile
@@ -117,7 +141,7 @@ def pmc_traffic(kernel_key, batch):
     except (KeyError, ValueError, OSError):
         return None
     out = {"traffic": (2.0 * fetch + write) * 1024.0, "traffic_unit": "bytes/launch", "algorithmic_bytes": alg,
-           "traffic_source": "profiles/" + os.path.basename(files[-1])}
+           "traffic_source": "profiles/" + os.path.basename(files[-1]), "traffic_source_commit": _profile_commit(files[-1])}
     try:
         out["l2_hit_rate"] = first("tcc_" + tag, "TCC_HIT_sum") / max(1.0, first("tcc_" + tag, "TCC_REQ_sum"))
     except KeyError:
@@ -147,7 +171,7 @@ def shade_traffic(key, texel):
     except (KeyError, StopIteration, ValueError, OSError):
         return None
     return {"traffic": (2.0 * fetch + write) * 1024.0, "traffic_unit": "bytes/launch at 1.15 M covered pixels (counter pass, atlas " + case + ")",
-            "traffic_source": "profiles/" + os.path.basename(files[-1])}
+            "traffic_source": "profiles/" + os.path.basename(files[-1]), "traffic_source_commit": _profile_commit(files[-1])}
 
 
 def effective_cores():
@@ -171,17 +195,17 @@ def effective_cores():
 
 
 def cpu_baseline(a, system, max_threads=None):
-    """The oracle (fp32 torch + C rasterizer) timed on this box's host cores on a BOUNDED sample of the same
-    workload (~10-40 s of CPU work): everything at HALF resolution (256^2 image, 32^2 latents) for ONE view --
-    render fwd+bwd on the full 50k-triangle mesh and the full 16-level hash grid, VAE-encoder fwd+bwd, one
-    branch-item of ControlNet+UNet -- scaled x4 to 512^2 (convs/linears/field are linear in pixels; the S^2
-    self-attention part is under-counted, which favours the CPU) and to the full step (x views, x 3*views)."""
+    """The oracle (fp32 torch + C rasterizer) timed on this box's host cores on a BOUNDED sample of the same workload
+    (~20-40 s of CPU work), every stage at the REAL resolution (staged timing at cfg2/3): ONE view's render
+    fwd+bwd at res^2 on the full 50k-triangle mesh and the full 16-level hash grid, ONE image's VAE-encoder fwd+bwd at
+    res^2, ONE branch-item of ControlNet+UNet at (res/8)^2 latents -- multiplied by the step's counts (x views, x 3*views
+    branch items).  No extrapolation in resolution (round 2 ran at half resolution and scaled by 4)."""
     import numpy as np
     from oracle import envlight as oenv, field as ofield, raster as oraster, render as orender, sd_nets as osd
     from oracle import camera as ocam
     cores = effective_cores()
     torch.set_num_threads(max_threads or cores)
-    H = W = a.res // 2
+    H = W = a.res
     mesh = system.geometry.mesh
     md = dict(v_pos=mesh.v_pos.cpu().numpy(), v_nrm=mesh.v_nrm.cpu().numpy(),
               t_pos_idx=mesh.t_pos_idx.cpu().numpy().astype(np.int32))
@@ -221,13 +245,12 @@ def cpu_baseline(a, system, max_threads=None):
         d, m = osd.controlnet_forward(sd_c, lat, tt, ctx, cond, 1.0, arch.heads, arch.use_linear_projection)
         osd.unet_forward(sd_u, lat, tt, ctx, arch.heads, arch.use_linear_projection, d, m)
         t_nets = time.time() - t0
-    scale = (a.res / H) ** 2
-    step_s = scale * (a.views * (t_render + t_vae) + 3 * a.views * t_nets)
+    step_s = a.views * (t_render + t_vae) + 3 * a.views * t_nets
     return {"value": 1.0 / step_s, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "extrapolated": True,      # a bounded sample (1 view, 1 branch item, half resolution) scaled to the full step
-            "sample": f"EXTRAPOLATED from oracle fp32 on host at {H}^2 (x{scale:.0f} to {a.res}^2): 1 view render fwd+bwd {t_render:.2f}s, "
+            "extrapolated": True,      # a bounded sample (1 view, 1 image, 1 branch item, all at full resolution) x the step's counts
+            "sample": f"oracle fp32 on host at the real {H}^2: 1 view render fwd+bwd {t_render:.2f}s, "
                       f"1 VAE-enc fwd+bwd {t_vae:.2f}s, 1 branch-item ControlNet+UNet fwd {t_nets:.2f}s; "
-                      f"step = {scale:.0f} x ({a.views} x (render+vae) + {3 * a.views} x nets)",
+                      f"step = {a.views} x (render+vae) + {3 * a.views} x nets (counts only: nothing is scaled in resolution)",
             "host_cpus": os.cpu_count()}
 
 
@@ -319,7 +342,8 @@ def main():
         res = {"metric": f"SDS steps/sec ({a.res}^2, {a.views} views)", "value": a.steps / elapsed, "unit": "steps/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": f"BASELINE configs[2]: {system.geometry.mesh.t_pos_idx.shape[0]}-tri displaced sphere, "
+               "config": {"workload": f"{baseline_config_name(a, system.geometry.mesh.t_pos_idx.shape[0])}: "
+                                      f"{system.geometry.mesh.t_pos_idx.shape[0]}-tri displaced sphere, "
                                       f"{a.res}^2, {a.views} views/step, 5 synthetic env maps, {a.sd} UNet+22ch ControlNet "
                                       f"(random init), split-sum shading, hash-grid field 16x2 2^19",
                           "views_per_step": a.views, "views_per_rank": vpr, "resolution": a.res, "sd_arch": a.sd,

@@ -95,6 +95,33 @@ __global__ __launch_bounds__(256) void k_geglu(const __bf16* __restrict__ h, __b
     }
 }
 
+
+// Skip connection of a UNet up block with the ControlNet residual folded in (diffusers UNet2DConditionModel.forward:
+// `down_block_res_samples = [s + r ...]` then `torch.cat([hidden, res_sample], dim=1)` in every up-block resnet):
+// y[row, 0:Cx] = x[row], y[row, Cx:Cx+Cs] = s[row] (+ r[row] * r_scale) -- one pass instead of an add pass and a cat pass.
+__global__ __launch_bounds__(256) void k_cat_add(const __bf16* __restrict__ x, const __bf16* __restrict__ s, const __bf16* __restrict__ r,
+                                                 __bf16* __restrict__ y, long long rows, int Cx, int Cs, float r_scale) {
+    const int cx8 = Cx / 8, c8 = (Cx + Cs) / 8;
+    const long long total = rows * c8;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long row = i / c8;
+        const int c = (int)(i - row * c8);
+        bf16x8 v;
+        if (c < cx8) {
+            v = *reinterpret_cast<const bf16x8*>(x + row * Cx + c * 8);
+        } else {
+            const long long o = row * Cs + (long long)(c - cx8) * 8;
+            v = *reinterpret_cast<const bf16x8*>(s + o);
+            if (r) {
+                const bf16x8 w = *reinterpret_cast<const bf16x8*>(r + o);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = (__bf16)((float)v[k] + (float)w[k] * r_scale);
+            }
+        }
+        *reinterpret_cast<bf16x8*>(y + row * (long long)(Cx + Cs) + c * 8) = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -132,6 +159,23 @@ int dm_geglu_bf16(const void* h, void* y, long long rows, int inner, hipStream_t
     const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 256 * 32);
     DM_ENTER();
     hipLaunchKernelGGL(k_geglu, dim3(grid), dim3(256), 0, stream, (const __bf16*)h, (__bf16*)y, rows, inner);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+// x [rows, Cx], s [rows, Cs], r [rows, Cs] or NULL, y [rows, Cx + Cs], all bf16 row-contiguous, Cx % 8 == Cs % 8 == 0.
+// The sum is rounded to bf16 once (the unfused pair rounded s + r to bf16 as well: same values when r_scale == 1).
+int dm_cat_add_bf16(const void* x, const void* s, const void* r, void* y, long long rows, int Cx, int Cs, float r_scale,
+                    hipStream_t stream) {
+    if (!x || !s || !y || rows < 0 || Cx <= 0 || Cs <= 0) return DM_ERR_ARG;
+    if (Cx % 8 != 0 || Cs % 8 != 0) return DM_ERR_UNSUPPORTED;
+    if (((uintptr_t)x | (uintptr_t)s | (uintptr_t)r | (uintptr_t)y) & 15) return DM_ERR_ARG;
+    if (rows == 0) return DM_OK;
+    const long long total = rows * ((Cx + Cs) / 8);
+    const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 256 * 32);
+    DM_ENTER();
+    hipLaunchKernelGGL(k_cat_add, dim3(grid), dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)s, (const __bf16*)r, (__bf16*)y,
+                       rows, Cx, Cs, r_scale);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }

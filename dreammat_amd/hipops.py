@@ -813,6 +813,22 @@ def geglu_rows(h):
     return y
 
 
+def cat_add_nhwc(x, s, r=None, r_scale=1.0):
+    """x [B,Cx,H,W], s / r [B,Cs,H,W] bf16 in channels-last memory -> cat([x, s + r_scale * r], dim=1), channels-last
+    (forward only): the up-block skip connection with the ControlNet residual folded in, one pass."""
+    _need_cuda(x, s)
+    B, Cx, H, W = x.shape
+    Cs = s.shape[1]
+    xn, sn = x.permute(0, 2, 3, 1), s.permute(0, 2, 3, 1)
+    rn = r.permute(0, 2, 3, 1) if r is not None else None
+    assert xn.is_contiguous() and sn.is_contiguous() and (rn is None or rn.is_contiguous()) and x.dtype == torch.bfloat16
+    y = torch.empty(B, H, W, Cx + Cs, device=x.device, dtype=x.dtype)
+    with _Timed(f"cat_add[Cx={Cx},Cs={Cs}]", 2.0 * B * H * W * (2 * Cx + (3 if r is not None else 2) * Cs)):
+        check(_lib.lib().dm_cat_add_bf16(xn.data_ptr(), sn.data_ptr(), rn.data_ptr() if rn is not None else None, y.data_ptr(),
+                                         B * H * W, Cx, Cs, float(r_scale), _stream()), "dm_cat_add_bf16")
+    return y.permute(0, 3, 1, 2)
+
+
 # ------------------------------------------------------------------------------------------ optimiser
 def adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, grad_scale=1.0, zero_grad=True):
     _need_cuda(param, grad, exp_avg, exp_avg_sq)

@@ -90,6 +90,19 @@ class MidBlock(nn.Module):
         return self.resnets[1](x, temb)
 
 
+def _cat_skip(x, skip):
+    """torch.cat([x, skip], dim=1) with skip = s or the pair (s, ControlNet residual r) -> s + r"""
+    s, r = skip if isinstance(skip, tuple) else (skip, None)
+    fused = (x.is_cuda and x.dtype == torch.bfloat16 and not (torch.is_grad_enabled() and (x.requires_grad or s.requires_grad
+             or (r is not None and r.requires_grad))) and x.shape[1] % 8 == 0 and s.shape[1] % 8 == 0
+             and x.permute(0, 2, 3, 1).is_contiguous() and s.permute(0, 2, 3, 1).is_contiguous()
+             and (r is None or (r.dtype == x.dtype and r.permute(0, 2, 3, 1).is_contiguous())))
+    if fused:
+        from .. import hipops
+        return hipops.cat_add_nhwc(x, s, r)
+    return torch.cat([x, s if r is None else s + r], dim=1)
+
+
 class UpBlock(nn.Module):
     def __init__(self, in_ch, prev_ch, out_ch, temb, n_layers, heads, cross_dim, linear, add_up):
         super().__init__()
@@ -104,7 +117,7 @@ class UpBlock(nn.Module):
 
     def forward(self, x, skips, temb, ctx):
         for i, r in enumerate(self.resnets):
-            x = r(torch.cat([x, skips.pop()], dim=1), temb)
+            x = r(_cat_skip(x, skips.pop()), temb)
             if self.attentions is not None:
                 x = self.attentions[i](x, ctx)
         if self.upsamplers is not None:
@@ -165,7 +178,9 @@ class UNet2DConditionModel(_Encoder):
             x, outs = blk(x, temb, ctx)
             skips += outs
         if down_block_additional_residuals is not None:
-            skips = [s + r for s, r in zip(skips, down_block_additional_residuals)]
+            # (skip, ControlNet residual) pairs: the sum is formed where the up block concatenates it (one fused pass on the
+            # GPU instead of an add pass here and a cat pass there)
+            skips = [(s, r) for s, r in zip(skips, down_block_additional_residuals)]
         x = self.mid_block(x, temb, ctx)
         if mid_block_additional_residual is not None:
             x = x + mid_block_additional_residual
@@ -223,8 +238,9 @@ class ControlNetModel(_Encoder):
             x, o = blk(x, temb, ctx)
             outs += o
         x = self.mid_block(x, temb, ctx)
-        down = [conv(o) * conditioning_scale for conv, o in zip(self.controlnet_down_blocks, outs)]
-        mid = self.controlnet_mid_block(x) * conditioning_scale
+        unit = isinstance(conditioning_scale, (int, float)) and float(conditioning_scale) == 1.0    # (x * 1.0 still launches a kernel: 14 per forward)
+        down = [conv(o) if unit else conv(o) * conditioning_scale for conv, o in zip(self.controlnet_down_blocks, outs)]
+        mid = self.controlnet_mid_block(x) if unit else self.controlnet_mid_block(x) * conditioning_scale
         return down, mid
 
     @classmethod

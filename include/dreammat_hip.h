@@ -291,6 +291,11 @@ int dm_groupnorm_nhwc_bwd(const void* x, const void* gamma, const void* beta, co
 int dm_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, long long rows, int C, float eps,
                       dm_stream_t stream);
 int dm_geglu_bf16(const void* h, void* y, long long rows, int inner, dm_stream_t stream);
+/* Skip connection of a UNet up block with the ControlNet residual folded in (diffusers' `down_block_res_samples = [s + r]`
+ * followed by `torch.cat([hidden, res_sample], dim=1)`, reached from dreammat_guidance.py:261-282): y[row] = x[row] | (s[row] +
+ * r_scale * r[row]); x [rows,Cx], s/r [rows,Cs] (r may be NULL), y [rows,Cx+Cs], bf16, Cx % 8 == Cs % 8 == 0. */
+int dm_cat_add_bf16(const void* x, const void* s, const void* r, void* y, long long rows, int Cx, int Cs, float r_scale,
+                    dm_stream_t stream);
 
 /* ---- optimiser ---------------------------------------------------------------------------- */
 /* torch.optim.Adam step (configs/dreammat.yaml:110-115 via systems/utils.py:34-53) over one flat

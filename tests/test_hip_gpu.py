@@ -255,6 +255,20 @@ def test_shade_small_launch_boundary_workgroup(dev, envs, N):
         assert (fgpu.grad.cpu() - feat.grad).abs().max() < 1e-3 * max(float(feat.grad.abs().max()), 1e-6)
 
 
+@pytest.mark.parametrize("B,Cx,Cs,H,W,with_r", [(3, 640, 320, 16, 16, True), (2, 1280, 1280, 8, 8, True), (1, 320, 320, 33, 17, False),
+                                                 (2, 8, 24, 5, 7, True)])
+def test_cat_add_skip_connection_vs_torch(dev, B, Cx, Cs, H, W, with_r):
+    """dm_cat_add_bf16: torch.cat([x, s + r], dim=1) of the UNet up blocks (ControlNet residual folded in) in one pass,
+    channels-last; bit-equal to the unfused pair (both round s + r to bf16 once)."""
+    torch.manual_seed(0)
+    mk = lambda c: torch.randn(B, c, H, W, device=dev).bfloat16().contiguous(memory_format=torch.channels_last)
+    x, sk, r = mk(Cx), mk(Cs), (mk(Cs) if with_r else None)
+    y = hipops.cat_add_nhwc(x, sk, r)
+    ref = torch.cat([x, sk + r if with_r else sk], dim=1)
+    assert y.shape == ref.shape and torch.equal(y, ref)
+    assert y.permute(0, 2, 3, 1).is_contiguous()
+
+
 def test_adam_matches_torch(dev):
     torch.manual_seed(0)
     n = 4096 * 3 + 8

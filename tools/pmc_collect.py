@@ -20,5 +20,15 @@ for f in sorted(glob.glob(os.path.join(src, "stats_*.csv"))):
     rows = list(csv.DictReader(open(f)))
     out["kernel_stats"][os.path.basename(f)[6:-4]] = [
         {"name": r["Name"][:120], "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3} for r in rows[:4]]
+# provenance: the tree the counters were taken on (pmc_collect runs where .git is) -- bench.py copies it into the JSON line so
+# that a stale counter file is visible
+import subprocess
+import time
+try:
+    out["collected_at_commit"] = subprocess.run(["git", "log", "-1", "--format=%h %cs"], capture_output=True, text=True,
+                                                 cwd=os.path.dirname(os.path.abspath(__file__))).stdout.strip()
+except Exception:
+    out["collected_at_commit"] = None
+out["collected_on"] = time.strftime("%Y-%m-%d")
 json.dump(out, open(dst, "w"), indent=1)
 print(dst, len(out["counters"]), "passes")
