@@ -14,6 +14,8 @@ Nets run in bf16 on the MI355X (reference: fp16, `half_precision_weights`), atte
 from dataclasses import dataclass, field
 from typing import Any, List, Optional
 
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -182,15 +184,28 @@ class StableDiffusionLightGuidance(BaseObject):
         text_embeddings = prompt_utils.get_text_embeddings(elevation, azimuth, camera_distances,
                                                            self.cfg.view_dependent_prompting,
                                                            return_null_text_embeddings=True)
+        # the same selection as (bank of distinct embeddings, row ids): the frozen cross-attention K / V projections of the bank
+        # are computed once and gathered per step (sd/layers.py PaddedContext)
+        bank_ids = None
+        if hasattr(prompt_utils, "get_text_embedding_bank") and text_embeddings.is_cuda and not os.environ.get("DREAMMAT_NO_KV_BANK"):
+            bank, ids = prompt_utils.get_text_embedding_bank(elevation, azimuth, camera_distances, self.cfg.view_dependent_prompting)
+            bank_ids = (self._bank_cast(bank), ids)
         with torch.no_grad():
             if self._graph_ok(latents_noisy):
-                noise_pred = self._noise_pred_graphed(latents_noisy, t, text_embeddings, image_cond, condition_scales)
+                noise_pred = self._noise_pred_graphed(latents_noisy, t, text_embeddings, image_cond, condition_scales, bank_ids)
             else:
-                noise_pred = self._noise_pred(latents_noisy, t, text_embeddings, image_cond, condition_scales)
+                noise_pred = self._noise_pred(latents_noisy, t, text_embeddings, image_cond, condition_scales, bank_ids)
         return noise_pred.chunk(3)
 
-    def _noise_pred(self, latents_noisy, t, text_embeddings, image_cond, condition_scales):
-        ctx = PaddedContext(text_embeddings.to(self.weights_dtype))
+    def _bank_cast(self, bank):
+        """the bank in the nets' dtype, converted once per bank tensor"""
+        key = (bank.data_ptr(), bank._version, self.weights_dtype)
+        if getattr(self, "_bank_key", None) != key:
+            self._bank_t, self._bank_key = bank.to(self.weights_dtype), key
+        return self._bank_t
+
+    def _noise_pred(self, latents_noisy, t, text_embeddings, image_cond, condition_scales, bank_ids=None):
+        ctx = PaddedContext(text_embeddings.to(self.weights_dtype), *(bank_ids or (None, None)))
         latent_model_input = torch.cat([latents_noisy] * 3, dim=0)
         t3 = torch.cat([t] * 3)
         if self.use_controlnet and not all(s == 0 for s in condition_scales):
@@ -209,13 +224,14 @@ class StableDiffusionLightGuidance(BaseObject):
         nets_frozen = not any(p.requires_grad for p in self.unet.parameters())
         return bool(want) and latents.is_cuda and nets_frozen and not torch.cuda.is_current_stream_capturing()
 
-    def _noise_pred_graphed(self, latents_noisy, t, text_embeddings, image_cond, condition_scales):
+    def _noise_pred_graphed(self, latents_noisy, t, text_embeddings, image_cond, condition_scales, bank_ids=None):
         """Same arithmetic as `_noise_pred`, captured once per (shapes, conditioning scales) and replayed: inputs are copied
         into the capture's static buffers (the 22-channel condition maps are converted to the nets' dtype by that copy),
         the output is cloned out of the graph's pool."""
         scales = tuple(float(s) for s in condition_scales)
         key = (tuple(latents_noisy.shape), latents_noisy.dtype, tuple(text_embeddings.shape), scales,
-               tuple((tuple(c.shape), tuple(c.stride())) for c in image_cond))
+               tuple((tuple(c.shape), tuple(c.stride())) for c in image_cond),
+               None if bank_ids is None else (bank_ids[0].data_ptr(), bank_ids[0]._version))
         g = self._graphs.get(key) if hasattr(self, "_graphs") else None
         if g is None:
             if not hasattr(self, "_graphs"):
@@ -223,23 +239,28 @@ class StableDiffusionLightGuidance(BaseObject):
             st = {"lat": torch.empty_like(latents_noisy), "t": torch.empty_like(t),
                   "emb": torch.empty_like(text_embeddings, dtype=self.weights_dtype),
                   "cond": [torch.empty_strided(c.shape, c.stride(), dtype=self.weights_dtype, device=c.device) for c in image_cond]}
+            if bank_ids is not None:        # the bank tensor itself is static (one object for the run); the row ids are an input
+                st["bank"], st["ids"] = bank_ids[0], torch.empty_like(bank_ids[1])
 
             def load():
                 st["lat"].copy_(latents_noisy); st["t"].copy_(t); st["emb"].copy_(text_embeddings)
                 for d, c in zip(st["cond"], image_cond):
                     d.copy_(c)
+                if bank_ids is not None:
+                    st["ids"].copy_(bank_ids[1])
             load()
+            sb = (st["bank"], st["ids"]) if bank_ids is not None else None
             # eager warm-up on a side stream (first-use initialisation inside the library, allocator warm-up), then capture
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                self._noise_pred(st["lat"], st["t"], st["emb"], st["cond"], scales)
+                self._noise_pred(st["lat"], st["t"], st["emb"], st["cond"], scales, sb)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             # thread-local capture mode: the RCCL watchdog thread of a multi-rank job polls its events with HIP calls of its own,
             # which a global-mode capture would reject
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                st["out"] = self._noise_pred(st["lat"], st["t"], st["emb"], st["cond"], scales)
+                st["out"] = self._noise_pred(st["lat"], st["t"], st["emb"], st["cond"], scales, sb)
             g = self._graphs[key] = (graph, st)
             if len(self._graphs) > 4:       # annealed conditioning scales re-capture; keep the pool bounded
                 self._graphs.pop(next(iter(self._graphs)))
@@ -247,6 +268,10 @@ class StableDiffusionLightGuidance(BaseObject):
         st["lat"].copy_(latents_noisy); st["t"].copy_(t); st["emb"].copy_(text_embeddings)
         for d, c in zip(st["cond"], image_cond):
             d.copy_(c)
+        if "ids" in st:
+            if bank_ids is None or bank_ids[0].data_ptr() != st["bank"].data_ptr():
+                raise RuntimeError("the captured noise prediction gathers from a prompt-embedding bank that has been replaced")
+            st["ids"].copy_(bank_ids[1])
         graph.replay()
         return st["out"].clone()
 

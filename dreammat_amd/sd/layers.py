@@ -224,17 +224,48 @@ class TimestepEmbedding(nn.Module):
 
 
 class PaddedContext:
-    """encoder_hidden_states zero-padded to a multiple of 8 tokens (16 B rows for V^T) + true length."""
+    """encoder_hidden_states zero-padded to a multiple of 8 tokens (16 B rows for V^T) + true length.
 
-    def __init__(self, ctx):
+    `bank` / `ids` (optional): the rows of the batch are `bank[ids]` with `bank` a SMALL set of distinct embeddings that
+    does not change between steps (DreamMat: 4 view-dependent prompts x {text, negative} + the empty prompt = 9, drawn 3 x
+    views times per step).  The nets are frozen, so the K / V^T projections of the bank are computed ONCE per cross-attention
+    layer and a step only gathers them (Attention.forward): 46 projection GEMMs per step become 46 row gathers."""
+
+    def __init__(self, ctx, bank=None, ids=None):
         B, S, C = ctx.shape
         self.len = S
         pad = (-S) % 8
         self.t = F.pad(ctx, (0, 0, 0, pad)) if pad else ctx
+        self.bank, self.ids = None, None
+        if bank is not None and ids is not None:
+            self.bank = F.pad(bank, (0, 0, 0, pad)) if pad else bank
+            self.ids = ids
+            self.bank_key = (bank.data_ptr(), bank._version, tuple(bank.shape), bank.dtype)
 
 
 def _zero_tail(vt, kv_len):
     vt[:, :, kv_len:] = 0
+    return vt
+
+
+def project_vt(v_weight, v_bias, kv_src, kv_len):
+    """V^T = (kv_src @ v_weight^T + bias)^T as [B, C, Skv_pad] bf16 with the padded tail zeroed (the layout the MFMA kernels take)."""
+    C = v_weight.shape[0]
+    if kv_src.shape[1] % 8:                                       # V^T rows must be 16 B multiples
+        kv_src = F.pad(kv_src, (0, 0, 0, (-kv_src.shape[1]) % 8))
+    Bk, Sk = kv_src.shape[0], kv_src.shape[1]
+    if C >= 640 and Bk >= 16 and Sk * C >= (1 << 20) and hipops.gemm_fused_ok(Bk * Sk, kv_src.shape[2], C):
+        # hipBLASLt / rocBLAS in this image fault (HIPBLAS_STATUS_INTERNAL_ERROR, then an illegal address) on the strided-
+        # batched W[C,C] @ X[B,S,C]^T for 24 x 4096 x 640, 24 x 1024 x 1280, 24 x 4096 x 1280 ... (tools/blas_probe.py:
+        # the 1024^2 configurations; every shape of the 512^2 step is fine): there V comes from the fused GEMM kernel
+        # and is transposed by a copy
+        vt = linear_fused(kv_src, v_weight, v_bias).transpose(1, 2).contiguous()
+        return vt if kv_len == Sk else _zero_tail(vt, kv_len)
+    vt = torch.matmul(v_weight, kv_src.transpose(1, 2))           # [B, C, Skv_pad]: V^T for free
+    if v_bias is not None:
+        vt = vt + v_bias[None, :, None]
+        if kv_len < vt.shape[2]:
+            vt[:, :, kv_len:] = 0
     return vt
 
 
@@ -247,23 +278,7 @@ def attention_core(q, k, v_weight, v_bias, kv_src, heads, kv_len):
     needs_grad = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or kv_src.requires_grad
                                               or v_weight.requires_grad)
     if q.is_cuda and q.dtype == torch.bfloat16 and not needs_grad:     # the MFMA kernel is forward-only
-        if kv_src.shape[1] % 8:                                       # V^T rows must be 16 B multiples
-            kv_src = F.pad(kv_src, (0, 0, 0, (-kv_src.shape[1]) % 8))
-        Bk, Sk = kv_src.shape[0], kv_src.shape[1]
-        if C >= 640 and Bk >= 16 and Sk * C >= (1 << 20) and hipops.gemm_fused_ok(Bk * Sk, kv_src.shape[2], C):
-            # hipBLASLt / rocBLAS in this image fault (HIPBLAS_STATUS_INTERNAL_ERROR, then an illegal address) on the strided-
-            # batched W[C,C] @ X[B,S,C]^T for 24 x 4096 x 640, 24 x 1024 x 1280, 24 x 4096 x 1280 ... (tools/blas_probe.py:
-            # the 1024^2 configurations; every shape of the 512^2 step is fine): there V comes from the fused GEMM kernel
-            # and is transposed by a copy
-            v = linear_fused(kv_src, v_weight, v_bias)
-            return hipops.attention(q, k[:, :kv_len], v.transpose(1, 2).contiguous(), heads) if kv_len == Sk else \
-                hipops.attention(q, k[:, :kv_len], _zero_tail(v.transpose(1, 2).contiguous(), kv_len), heads)
-        vt = torch.matmul(v_weight, kv_src.transpose(1, 2))           # [B, C, Skv_pad]: V^T for free
-        if v_bias is not None:
-            vt = vt + v_bias[None, :, None]
-            if kv_len < vt.shape[2]:
-                vt[:, :, kv_len:] = 0
-        return hipops.attention(q, k[:, :kv_len], vt, heads)
+        return hipops.attention(q, k[:, :kv_len], project_vt(v_weight, v_bias, kv_src, kv_len), heads)
     v = F.linear(kv_src, v_weight, v_bias)
     qh = q.view(B, Sq, heads, D).transpose(1, 2)
     kh = k[:, :kv_len].reshape(B, kv_len, heads, D).transpose(1, 2)
@@ -292,8 +307,22 @@ class Attention(nn.Module):
         else:
             src, kv_len = context.t, context.len
         q = linear_fused(x, self.to_q.weight, self.to_q.bias)
-        k = linear_fused(src, self.to_k.weight, self.to_k.bias)
-        o = attention_core(q, k, self.to_v.weight, self.to_v.bias, src, self.heads, kv_len)
+        frozen = not (torch.is_grad_enabled() and (self.to_k.weight.requires_grad or self.to_v.weight.requires_grad))
+        if (context is not None and context.bank is not None and frozen and x.is_cuda and x.dtype == torch.bfloat16
+                and not (torch.is_grad_enabled() and x.requires_grad)):
+            # frozen projections of a fixed bank of prompt embeddings: computed once, gathered per step
+            key = (context.bank_key, self.to_k.weight.data_ptr(), self.to_k.weight._version, self.to_v.weight.data_ptr(),
+                   self.to_v.weight._version)
+            if getattr(self, "_kv_bank_key", None) != key:
+                with torch.no_grad():
+                    self._kv_bank = (linear_fused(context.bank, self.to_k.weight, self.to_k.bias),
+                                     project_vt(self.to_v.weight, self.to_v.bias, context.bank, kv_len))
+                self._kv_bank_key = key
+            kb, vtb = self._kv_bank
+            o = hipops.attention(q, kb.index_select(0, context.ids)[:, :kv_len], vtb.index_select(0, context.ids), self.heads)
+        else:
+            k = linear_fused(src, self.to_k.weight, self.to_k.bias)
+            o = attention_core(q, k, self.to_v.weight, self.to_v.bias, src, self.heads, kv_len)
         return linear_fused(o, self.to_out[0].weight, self.to_out[0].bias, residual)
 
 
