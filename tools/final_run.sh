@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-end validation + measurement pass on the GPU box (round 2).  Writes small files to gpurun_out/ only; copy what is to be
+# Round-end validation + measurement pass on the GPU box (rounds 2, 3).  Writes small files to gpurun_out/ only; copy what is to be
 # judged into profiles/ afterwards (tools/pmc_collect.py for the counters).
 #   1 full GPU test suite   2 default bench line (with the CPU baseline)   3 rocprofv3 --kernel-trace --stats of the same
 #   bench command + per-step kernel tables at 8 views and at 1 view per rank   4 A/B probe (also dumps the bench scene's real
@@ -25,9 +25,12 @@ for v in 8 1; do
   f=$(find /tmp/prof_final_$v -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 tools/step_window.py "$f" 3 6 > gpurun_out/final_step_kernels_${v}views.csv
   head -1 gpurun_out/final_step_kernels_${v}views.csv | cut -c40-160
 done
-PYTHONPATH=$R timeout 400 python tools/r2_probe.py --rounds 3 --iters 10 > gpurun_out/final_r2_probe.log 2>&1 < /dev/null
+PYTHONPATH=$R timeout 400 python tools/r2_probe.py --rounds 3 --iters 10 --variants auto,w64,v3l,staged --out final_probe.json > gpurun_out/final_r2_probe.log 2>&1 < /dev/null
 grep '"op": "shade"' gpurun_out/final_r2_probe.log | cut -c1-260 | tail -4
-PMC_SECTIONS="conv attn shade" ATTN_VARIANTS="v3l" ATTN_MAIN=v3l timeout 900 bash tools/pmc_r2.sh > gpurun_out/final_pmc.log 2>&1
+PMC_SECTIONS="conv attn shade" ATTN_VARIANTS="w64 v3l" ATTN_MAIN=w64 timeout 900 bash tools/pmc_r2.sh > gpurun_out/final_pmc.log 2>&1
+DREAMMAT_ATTN_TIMELINE=1 tools/_abi_pmc attn 24 5 4096 4096 64 2 w64 2>&1 | grep "wg 300" > gpurun_out/final_attn_timeline.txt
+DREAMMAT_ATTN_TIMELINE=1 tools/_abi_pmc attn 4 5 16384 16384 64 2 w64 2>&1 | grep "wg 300" >> gpurun_out/final_attn_timeline.txt
+tools/_issue_probe > gpurun_out/final_issue_probe.jsonl 2>&1
 bash tools/conv_b3.sh > gpurun_out/final_conv_batch3.txt 2>&1
 timeout 200 bash tools/gemm_fit.sh > gpurun_out/final_gemm_shapes.txt 2>&1
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
