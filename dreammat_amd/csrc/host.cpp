@@ -84,7 +84,7 @@ struct BvhBuilder {
 
 extern "C" {
 
-int dm_abi_version(void) { return 2; }
+int dm_abi_version(void) { return 3; }     // 3: + dm_attention_selected, dm_cat_add_bf16; dm_attention_select names changed
 
 // opp[t][i] = vertex opposite to edge i of triangle t in the other triangle sharing that edge,
 // -1 if none.  Edge 0 = (v1,v2), edge 1 = (v2,v0), edge 2 = (v0,v1).  Host pointers.
