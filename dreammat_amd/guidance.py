@@ -94,18 +94,26 @@ class StableDiffusionLightGuidance(BaseObject):
                              "unet": load_component(self.unet, root, "unet")}
         self.controlnets = []
         if self.use_controlnet:
+            # dreammat_guidance.py:99-119: 'light' = the 22-channel geometry- and light-aware ControlNet (cfg.controlnet_path);
+            # 'depth' / 'normal' = the public sd15 ControlNets (3-channel condition; they only fit an sd15 base model)
+            sources = {"light": (self.cfg.controlnet_path, None),
+                       "depth": ("lllyasviel/control_v11f1p_sd15_depth", 3),
+                       "normal": ("lllyasviel/control_v11p_sd15_normalbae", 3)}
             for ct in self.cfg.control_types:
-                if ct != "light":
-                    # 'depth' / 'normal' name sd15 ControlNets in the reference (:103-106): 3-channel cond
-                    raise NotImplementedError(f"control type '{ct}': only the 22-channel 'light' ControlNet is built")
+                if ct not in sources:
+                    raise ValueError(f"unsupported controlnet type '{ct}' (the reference exits here, :107-109)")
+                path, cch = sources[ct]
+                if path is not None and ct != "light":
+                    cand = os.path.join(self.cfg.cache_dir or "", path)
+                    path = cand if os.path.isdir(cand) else (path if os.path.isdir(path) else None)
                 with torch.device(self.device):
-                    cn = ControlNetModel.from_unet(self.unet)
-                loaded = load_component(cn, self.cfg.controlnet_path, "controlnet")
+                    cn = ControlNetModel.from_unet(self.unet, cch)
+                loaded = load_component(cn, path, "controlnet")
                 if not loaded:
                     # zero-convs would make a random-init ControlNet a no-op: give the synthetic one signal
                     for conv in list(cn.controlnet_down_blocks) + [cn.controlnet_mid_block, cn.controlnet_cond_embedding.conv_out]:
                         torch.nn.init.normal_(conv.weight, std=0.02)
-                self.real_weights["controlnet"] = loaded
+                self.real_weights["controlnet" if ct == "light" else "controlnet_" + ct] = loaded
                 self.controlnets.append(cn)
         torch.random.set_rng_state(gen_state)
         missing = [k for k, ok in self.real_weights.items() if not ok]
@@ -197,6 +205,34 @@ class StableDiffusionLightGuidance(BaseObject):
                 noise_pred = self._noise_pred(latents_noisy, t, text_embeddings, image_cond, condition_scales, bank_ids)
         return noise_pred.chunk(3)
 
+    def compute_with_perpneg(self, condition_scales, prompt_utils, latents_noisy, t, elevation, azimuth, camera_distances,
+                             image_cond):
+        """dreammat_guidance.py:319-386: five branch items per view (text, negative prompt, two Perp-Neg view prompts, empty
+        prompt) through ControlNet + UNet; the two view-prompt predictions enter through their components perpendicular to
+        (text - uncond), weighted by the prompt processor's negative weights."""
+        from .prompt import perpendicular_component
+        text_embeddings, neg_w = prompt_utils.get_text_embeddings_perp_neg(elevation, azimuth, camera_distances,
+                                                                           self.cfg.view_dependent_prompting,
+                                                                           return_null_text_embeddings=True)
+        B = latents_noisy.shape[0]
+        n_neg = neg_w.shape[-1]
+        # The reference stacks the negatives view-major (v0n0, v0n1, v1n0, ...) against latents repeated branch-major
+        # (cat([x] * 5)) and reads them back with [i::n_neg]: consistent at its B = 1 only.  Here the negatives are put
+        # branch-major (all views' first negative, then all views' second) so that item k of every branch is view k (D4).
+        neg = text_embeddings[2 * B:2 * B + n_neg * B]
+        neg = neg.view(B, n_neg, *neg.shape[1:]).transpose(0, 1).reshape(n_neg * B, *neg.shape[1:])
+        text_embeddings = torch.cat([text_embeddings[:2 * B], neg, text_embeddings[2 * B + n_neg * B:]], dim=0)
+        with torch.no_grad():
+            noise_pred = self._noise_pred(latents_noisy, t, text_embeddings, image_cond, condition_scales, None,
+                                          n_branch=3 + n_neg)
+        e_text, e_uncond, e_null = noise_pred[:B], noise_pred[B:2 * B], noise_pred[(2 + n_neg) * B:]
+        e_pos = e_text - e_uncond
+        accum = 0
+        for i in range(n_neg):
+            e_i = noise_pred[(2 + i) * B:(3 + i) * B]
+            accum = accum + neg_w[:, i].view(-1, 1, 1, 1).to(e_pos.dtype) * perpendicular_component(e_i - e_uncond, e_pos)
+        return e_text, e_uncond, e_null, accum
+
     def _bank_cast(self, bank):
         """the bank in the nets' dtype, converted once per bank tensor"""
         key = (bank.data_ptr(), bank._version, self.weights_dtype)
@@ -204,10 +240,10 @@ class StableDiffusionLightGuidance(BaseObject):
             self._bank_t, self._bank_key = bank.to(self.weights_dtype), key
         return self._bank_t
 
-    def _noise_pred(self, latents_noisy, t, text_embeddings, image_cond, condition_scales, bank_ids=None):
+    def _noise_pred(self, latents_noisy, t, text_embeddings, image_cond, condition_scales, bank_ids=None, n_branch=3):
         ctx = PaddedContext(text_embeddings.to(self.weights_dtype), *(bank_ids or (None, None)))
-        latent_model_input = torch.cat([latents_noisy] * 3, dim=0)
-        t3 = torch.cat([t] * 3)
+        latent_model_input = torch.cat([latents_noisy] * n_branch, dim=0)
+        t3 = torch.cat([t] * n_branch)
         if self.use_controlnet and not all(s == 0 for s in condition_scales):
             # the reference relies on a [3]+[1] broadcast here (B=1 only); the ControlNet tiles the
             # conditioning EMBEDDING over the three branches (branch-major, like torch.cat([x]*3))
@@ -286,13 +322,18 @@ class StableDiffusionLightGuidance(BaseObject):
         if noise is None:
             noise = torch.randn_like(latents)
         latents_noisy = self.scheduler.add_noise(latents, noise, t)
+        e_perpneg = None
         if getattr(prompt_utils, "use_perp_neg", False):
-            raise NotImplementedError("perp-neg prompting (dreammat_guidance.py:319-386) is not on the default path")
-        e_text, e_uncond, e_null = self.compute_without_perpneg(condition_scales, prompt_utils, latents_noisy, t,
-                                                                elevation, azimuth, camera_distances, image_cond)
+            e_text, e_uncond, e_null, e_perpneg = self.compute_with_perpneg(condition_scales, prompt_utils, latents_noisy, t,
+                                                                            elevation, azimuth, camera_distances, image_cond)
+        else:
+            e_text, e_uncond, e_null = self.compute_without_perpneg(condition_scales, prompt_utils, latents_noisy, t,
+                                                                    elevation, azimuth, camera_distances, image_cond)
         w = (1 - self.alphas[t]).view(-1, 1, 1, 1)
         grad = w * (self.cond_scale * e_text + self.uncond_scale * e_uncond + self.null_scale * e_null
                     + self.noise_scale * noise)
+        if e_perpneg is not None:
+            grad = grad + w * self.perpneg_scale * e_perpneg
         ev = {"uncond_m_noise_norm": (e_uncond - noise).norm(), "text_m_noise_norm": (e_text - noise).norm(),
               "text_m_uncond_norm": (e_text - e_uncond).norm(), "text_m_null_norm": (e_text - e_null).norm(),
               "null_m_uncond_norm": (e_null - e_uncond).norm(), "noise_norm": noise.norm(),

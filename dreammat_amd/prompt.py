@@ -47,6 +47,10 @@ class PromptProcessorOutput:
     direction2idx: dict
     use_perp_neg: bool = False
     banks: dict = None          # persistent (bank tensors live in the prompt processor: one object for the whole run)
+    perp_neg_f_sb: tuple = (1, 0.5, -0.606)
+    perp_neg_f_fsb: tuple = (1, 0.5, +0.967)
+    perp_neg_f_fs: tuple = (4, 0.5, -2.426)
+    perp_neg_f_sf: tuple = (4, 0.5, -2.426)
 
     def get_text_embeddings(self, elevation, azimuth, camera_distances, view_dependent_prompting=True,
                             return_null_text_embeddings=False):
@@ -87,6 +91,49 @@ class PromptProcessorOutput:
         return banks["plain"], torch.cat([z, z + 1, z + 2])
 
 
+    def get_text_embeddings_perp_neg(self, elevation, azimuth, camera_distances, view_dependent_prompting=True,
+                                     return_null_text_embeddings=False):
+        """prompt_processors/base.py:87-184 (Perp-Neg, arXiv 2304.04968): per view a positive embedding interpolated between
+        the front / side / back prompts by |azimuth|, two "negative" view prompts with weights
+        -f(r) = -(a exp(-b r) + c), the view's negative-prompt embedding, optionally the empty prompt.
+        -> (text_embeddings [B (pos) + B (uncond) + 2B (neg) (+ B null), 77, D], neg_guidance_weights [B, 2])."""
+        assert view_dependent_prompting, "Perp-Neg only works with view-dependent prompting"
+        batch_size = elevation.shape[0]
+        direction_idx = torch.zeros_like(elevation, dtype=torch.long)
+        for d in self.directions:
+            direction_idx[d.condition(elevation, azimuth, camera_distances)] = self.direction2idx[d.name]
+        side, front, back, overhead = (self.text_embeddings_vd[i] for i in range(4))
+        decay = lambda abc, r: abc[0] * torch.exp(-abc[1] * r) + abc[2]
+        pos, neg, wts, unc = [], [], [], []
+        for idx, azi in zip(direction_idx, azimuth):
+            azi = shift_azimuth_deg(azi)
+            unc.append(self.uncond_text_embeddings_vd[idx])
+            if idx.item() == 3:                                   # overhead: no interpolation, dummy negatives with weight 0
+                pos.append(overhead)
+                neg += [self.uncond_text_embeddings_vd[idx], self.uncond_text_embeddings_vd[idx]]
+                wts += [0.0, 0.0]
+            elif torch.abs(azi) < 90:                             # front <-> side: r = 1 at the front
+                r = 1 - torch.abs(azi) / 90
+                pos.append(r * front + (1 - r) * side)
+                neg += [front, side]
+                wts += [-decay(self.perp_neg_f_fs, r), -decay(self.perp_neg_f_sf, 1 - r)]
+            else:                                                 # side <-> back: r = 1 at the side
+                r = 2.0 - torch.abs(azi) / 90
+                pos.append(r * side + (1 - r) * back)
+                neg += [side, front]
+                wts += [-decay(self.perp_neg_f_sb, r), -decay(self.perp_neg_f_fsb, r)]
+        parts = [torch.stack(pos, dim=0), torch.stack(unc, dim=0), torch.stack(neg, dim=0)]
+        if return_null_text_embeddings:
+            parts.append(self.null_text_embeddings.expand(batch_size, -1, -1))
+        return torch.cat(parts, dim=0), torch.as_tensor(wts, device=elevation.device).reshape(batch_size, 2)
+
+
+def perpendicular_component(x, y):
+    """utils/ops.py:431-441: the component of x [B,C,H,W] perpendicular to y, per batch item"""
+    eps = torch.ones_like(x[:, 0, 0, 0]) * 1e-6
+    return x - (torch.mul(x, y).sum(dim=[1, 2, 3]) / torch.maximum(torch.mul(y, y).sum(dim=[1, 2, 3]), eps)).view(-1, 1, 1, 1) * y
+
+
 @dreammat_amd.register("stable-diffusion-prompt-processor")
 class StableDiffusionPromptProcessor(BaseObject):
     @dataclass
@@ -106,6 +153,11 @@ class StableDiffusionPromptProcessor(BaseObject):
         use_cache: bool = True
         spawn: bool = True
         use_perp_neg: bool = False
+        # a exp(-b r) + c (prompt_processors/base.py:214-224)
+        perp_neg_f_sb: tuple = (1, 0.5, -0.606)
+        perp_neg_f_fsb: tuple = (1, 0.5, +0.967)
+        perp_neg_f_fs: tuple = (4, 0.5, -2.426)
+        perp_neg_f_sf: tuple = (4, 0.5, -2.426)
         cache_dir: str = ".threestudio_cache/text_embeddings"
         # addition: md5-seeded pseudo embeddings when the CLIP text encoder is not on disk.  Off by default: a run with
         # a real model name and no encoder is an error, not a silent stand-in ('tiny*' architectures are synthetic by
@@ -115,8 +167,6 @@ class StableDiffusionPromptProcessor(BaseObject):
     cfg: Config
 
     def configure(self) -> None:
-        if self.cfg.use_perp_neg:
-            raise NotImplementedError("perp-neg prompting is not on DreamMat's default path")
         if not torch.cuda.is_available():
             self.device = torch.device("cpu")
         c = self.cfg
@@ -209,4 +259,6 @@ class StableDiffusionPromptProcessor(BaseObject):
     def __call__(self) -> PromptProcessorOutput:
         return PromptProcessorOutput(self.text_embeddings, self.uncond_text_embeddings, self.null_text_embeddings,
                                      self.text_embeddings_vd, self.uncond_text_embeddings_vd, self.directions,
-                                     self.direction2idx, False, self.__dict__.setdefault("_banks", {}))
+                                     self.direction2idx, bool(self.cfg.use_perp_neg), self.__dict__.setdefault("_banks", {}),
+                                     tuple(self.cfg.perp_neg_f_sb), tuple(self.cfg.perp_neg_f_fsb),
+                                     tuple(self.cfg.perp_neg_f_fs), tuple(self.cfg.perp_neg_f_sf))

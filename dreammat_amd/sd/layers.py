@@ -4,10 +4,14 @@ encoder) with diffusers-compatible parameter names, so `from_pretrained` checkpo
 22-channel `zzzyuqing/light-geo-controlnet` (README.md:26) load with `load_state_dict(strict=True)`.
 
 diffusers is an un-vendored dependency of the reference (requirements.txt:7); it is used through
-threestudio/models/guidance/dreammat_guidance.py:110-154, 205-292.  Convs / linears / norms stay on
-PyTorch-ROCm (MIOpen, hipBLASLt); the QK^T.softmax.V of every transformer block runs in the MFMA
-kernel of csrc/attention.hip (bf16 on the GPU).  fp32 / CPU execution (BASELINE config 1: fp32
-plumbing run) uses the plain matmul-softmax path below; a CUDA bf16 call NEVER falls back.
+threestudio/models/guidance/dreammat_guidance.py:110-154, 205-292.  On the GPU in bf16 every layer here runs in the
+hand-written gfx950 kernels of csrc/ (DESIGN.md sections 1 and 3): 3x3 convs and their data gradients in the persistent
+implicit-GEMM kernel (conv.hip / conv_small.hip), Linear / 1x1 layers with bias / residual / GEGLU epilogues in its 1-tap
+instantiation, GroupNorm(+SiLU) fwd / bwd (groupnorm.hip), LayerNorm / GEGLU / the skip concat (transformer.hip), the
+QK^T.softmax.V of every transformer block in attn_w64.hip / attention.hip.  What stays on ATen / hipBLASLt is listed in
+DESIGN.md section 1 (V^T projections, the VAE mid-block attention, anything differentiated that has no hand-written backward).
+fp32 / CPU execution (BASELINE config 1: fp32 plumbing run, the fp32 legs of the parity tests) uses the plain torch paths
+below; a CUDA bf16 call NEVER falls back to them silently.
 """
 import math
 import os

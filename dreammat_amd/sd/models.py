@@ -210,11 +210,14 @@ class ControlNetConditioningEmbedding(nn.Module):
 class ControlNetModel(_Encoder):
     """ControlNetModel.from_unet(unet, conditioning_channels=22) (controlnet_train/diffusers_train_controlnet.py:638)."""
 
-    def __init__(self, arch: SDArch):
+    def __init__(self, arch: SDArch, cond_channels: Optional[int] = None):
+        """cond_channels: 22 (arch default: the light-geo ControlNet) or 3 (the sd15 depth / normal ControlNets the
+        reference names for control_types 'depth' / 'normal', dreammat_guidance.py:103-106)"""
         super().__init__()
         self._build_encoder(arch)
         bo = arch.block_out
-        self.controlnet_cond_embedding = ControlNetConditioningEmbedding(bo[0], arch.cond_channels, arch.cond_embed_channels)
+        self.cond_channels = cond_channels or arch.cond_channels
+        self.controlnet_cond_embedding = ControlNetConditioningEmbedding(bo[0], self.cond_channels, arch.cond_embed_channels)
         chans = [bo[0]]
         for i, oc in enumerate(bo):
             chans += [oc] * arch.layers_per_block
@@ -244,8 +247,8 @@ class ControlNetModel(_Encoder):
         return down, mid
 
     @classmethod
-    def from_unet(cls, unet: UNet2DConditionModel):
-        cn = cls(unet.arch)
+    def from_unet(cls, unet: UNet2DConditionModel, cond_channels: Optional[int] = None):
+        cn = cls(unet.arch, cond_channels)
         sd = {k: v for k, v in unet.state_dict().items()
               if k.startswith(("conv_in.", "time_embedding.", "down_blocks.", "mid_block."))}
         cn.load_state_dict(sd, strict=False)

@@ -230,3 +230,99 @@ def test_controlnet_render_dataset_reads_the_reference_tree(tmp_path):
             assert it["input_ids"] == "" and np.array_equal(s2, src)
         else:
             assert it["input_ids"] == "a red teapot" and np.array_equal(s2, src)
+
+
+def test_guidance_perp_neg_branch_matches_oracle_composition(tmp_path, monkeypatch):
+    """Non-default `use_perp_neg` (dreammat_guidance.py:319-386, 440-486) at the reference's B = 1: five branch items through
+    ControlNet + UNet, the two view-prompt predictions enter perpendicular to (text - uncond) with the prompt processor's
+    negative weights, scaled by perpneg_scale.  Oracle: the functional nets + the reference's formulas (golden-pinned pieces:
+    tests/golden/perpneg.npz)."""
+    monkeypatch.chdir(tmp_path)
+    from dreammat_amd.guidance import StableDiffusionLightGuidance
+    from dreammat_amd.prompt import StableDiffusionPromptProcessor, perpendicular_component
+    gd = StableDiffusionLightGuidance({"pretrained_model_name_or_path": "tiny", "use_controlnet": True,
+                                       "control_types": ["light"], "condition_scales": [1.0], "width": 128,
+                                       "height": 128, "cond_scale": 1.05, "uncond_scale": -0.75, "null_scale": -0.25,
+                                       "perpneg_scale": 0.6, "half_precision_weights": True})
+    gd.update_step(0, 0)
+    assert abs(gd.perpneg_scale - 0.6) < 1e-9
+    pp = StableDiffusionPromptProcessor({"prompt": "a wooden chair", "negative_prompt": "ugly", "use_perp_neg": True,
+                                         "pretrained_model_name_or_path": "tiny"})
+    pu = pp()
+    assert pu.use_perp_neg
+    g = torch.Generator().manual_seed(5)
+    rgb = torch.rand(1, 128, 128, 3, generator=g)
+    cond = torch.rand(1, 128, 128, 22, generator=g)
+    elev, azim, dist = torch.tensor([10.0]), torch.tensor([60.0]), torch.tensor([3.5])
+    rng = {"t": torch.tensor([400]), "noise": torch.randn(1, 4, 16, 16, generator=g),
+           "posterior_noise": torch.randn(1, 4, 16, 16, generator=g)}
+    out = gd(rgb, pu, elev, azim, dist, env_id=torch.tensor([0]), condition_map=cond, rng=rng)
+    emb, w = pu.get_text_embeddings_perp_neg(elev, azim, dist, True, True)          # [5, 77, D], [1, 2]
+    assert emb.shape[0] == 5 and float(w.abs().sum()) > 0
+    nets = {"vae": gd.vae.state_dict(), "unet": gd.unet.state_dict(), "controlnet": gd.controlnets[0].state_dict()}
+    a = gd.arch
+    with torch.no_grad():
+        mean, logvar = osd.vae_encode_moments(nets["vae"], rgb.permute(0, 3, 1, 2) * 2 - 1)
+        lat = (mean + torch.exp(0.5 * logvar) * rng["posterior_noise"]) * 0.18215
+        ac = osd.alphas_cumprod()[rng["t"]].view(-1, 1, 1, 1)
+        noisy = ac.sqrt() * lat + (1 - ac).sqrt() * rng["noise"]
+        lat5, t5 = torch.cat([noisy] * 5), torch.cat([rng["t"]] * 5)
+        cond5 = torch.cat([cond.permute(0, 3, 1, 2)] * 5)
+        d, m = osd.controlnet_forward(nets["controlnet"], lat5, t5, emb, cond5, 1.0, a.heads, a.use_linear_projection)
+        eps = osd.unet_forward(nets["unet"], lat5, t5, emb, a.heads, a.use_linear_projection, d, m)
+    e_text, e_unc, e_n0, e_n1, e_null = eps[0:1], eps[1:2], eps[2:3], eps[3:4], eps[4:5]
+    e_pos = e_text - e_unc
+    perp = w[:, 0].view(-1, 1, 1, 1) * perpendicular_component(e_n0 - e_unc, e_pos) + \
+        w[:, 1].view(-1, 1, 1, 1) * perpendicular_component(e_n1 - e_unc, e_pos)
+    wt = (1 - osd.alphas_cumprod()[rng["t"]]).view(-1, 1, 1, 1)
+    grad = wt * (1.05 * e_text - 0.75 * e_unc - 0.25 * e_null) + wt * 0.6 * perp
+    assert (gd._last["grad"] - grad).abs().max() <= 1e-3 * grad.abs().max()
+    loss = 0.5 * ((lat - (lat - grad)) ** 2).sum() / 1
+    assert abs(float(out["loss_sds"]) - float(loss)) <= 1e-3 * abs(float(loss))
+
+
+def test_guidance_multi_controlnet_light_depth_normal(tmp_path, monkeypatch):
+    """Non-default control_types (dreammat_guidance.py:99-119, 205-241, 518-534): one ControlNet per type -- the 22-channel
+    light-geo net plus 3-channel depth / normal nets -- whose residuals are summed with their own conditioning scales before
+    the UNet.  Against the functional oracle with the same (random) weights; the renderer's depth map is repeated to three
+    channels, an unknown type is an error."""
+    monkeypatch.chdir(tmp_path)
+    from dreammat_amd.guidance import StableDiffusionLightGuidance
+    from dreammat_amd.prompt import StableDiffusionPromptProcessor
+    cfg = {"pretrained_model_name_or_path": "tiny", "use_controlnet": True, "control_types": ["light", "depth", "normal"],
+           "condition_scales": [1.0, 0.5, 0.7], "width": 128, "height": 128, "cond_scale": 1.05, "uncond_scale": -0.75,
+           "null_scale": -0.25, "half_precision_weights": True}
+    gd = StableDiffusionLightGuidance(dict(cfg))
+    assert [cn.cond_channels for cn in gd.controlnets] == [22, 3, 3]
+    with pytest.raises(ValueError):
+        StableDiffusionLightGuidance(dict(cfg, control_types=["canny"], condition_scales=[1.0]))
+    gd.update_step(0, 0)
+    pp = StableDiffusionPromptProcessor({"prompt": "a wooden chair", "negative_prompt": "ugly", "pretrained_model_name_or_path": "tiny"})
+    B = 1
+    g = torch.Generator().manual_seed(9)
+    rgb = torch.rand(B, 128, 128, 3, generator=g)
+    light = torch.rand(B, 128, 128, 22, generator=g)
+    depth = torch.rand(B, 128, 128, 1, generator=g)
+    normal = torch.rand(B, 128, 128, 3, generator=g)
+    elev, azim, dist = torch.tensor([10.0]), torch.tensor([5.0]), torch.tensor([3.5])
+    rng = {"t": torch.tensor([300]), "noise": torch.randn(B, 4, 16, 16, generator=g),
+           "posterior_noise": torch.randn(B, 4, 16, 16, generator=g)}
+    gd(rgb, pp(), elev, azim, dist, env_id=torch.tensor([0]), condition_map=light, cond_depth=depth, cond_normal=normal, rng=rng)
+    emb = pp().get_text_embeddings(elev, azim, dist, True, True)
+    a = gd.arch
+    with torch.no_grad():
+        mean, logvar = osd.vae_encode_moments(gd.vae.state_dict(), rgb.permute(0, 3, 1, 2) * 2 - 1)
+        lat = (mean + torch.exp(0.5 * logvar) * rng["posterior_noise"]) * 0.18215
+        ac = osd.alphas_cumprod()[rng["t"]].view(-1, 1, 1, 1)
+        noisy = ac.sqrt() * lat + (1 - ac).sqrt() * rng["noise"]
+        lat3, t3 = torch.cat([noisy] * 3), torch.cat([rng["t"]] * 3)
+        down = mid = None
+        conds = [light.permute(0, 3, 1, 2), depth.permute(0, 3, 1, 2).repeat(1, 3, 1, 1), normal.permute(0, 3, 1, 2)]
+        for cn, c, sc in zip(gd.controlnets, conds, (1.0, 0.5, 0.7)):
+            d, m = osd.controlnet_forward(cn.state_dict(), lat3, t3, emb, torch.cat([c] * 3), sc, a.heads, a.use_linear_projection)
+            down, mid = (d, m) if down is None else ([x + y for x, y in zip(down, d)], mid + m)
+        eps = osd.unet_forward(gd.unet.state_dict(), lat3, t3, emb, a.heads, a.use_linear_projection, down, mid)
+    e3 = torch.cat([gd._last["e_text"], gd._last["e_uncond"], gd._last["e_null"]])
+    assert (e3 - eps).abs().max() <= 1e-3 * eps.abs().max()
+    # the three nets must actually differ in what they contribute
+    assert float((gd.controlnets[1].controlnet_cond_embedding.conv_in.weight).abs().sum()) > 0
