@@ -45,7 +45,7 @@ struct ConvArgs {
     int tw_log2;         // log2(TW)
     int tiles_x;         // ceil(Wout / TW)
     unsigned long long* timeline;   // DREAMMAT_CONV_TIMELINE=1 (development): s_memtime stamps per tile, else null
-    int timeline_steps;             // DREAMMAT_CONV_TIMELINE=2: stamp every K-step instead
+    int timeline_steps;             // DREAMMAT_CONV_TIMELINE=2: stamp every K-step instead; 4: per-wave sums of body / waits / barrier
 };
 
 constexpr int BM = 128;
@@ -465,8 +465,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     };
     int stage = 0;
     int tl_i = 0;
+    unsigned long long tl_sum[5] = {0, 0, 0, 0, 0}, tl_prev = __builtin_amdgcn_s_memtime();
     auto stamp = [&]() __attribute__((always_inline)) {
-        if (a.timeline && tid == 0 && tl_i < 64) a.timeline[(long long)blockIdx.x * 64 + tl_i++] = __builtin_amdgcn_s_memtime();
+        if (a.timeline && a.timeline_steps != 4 && tid == 0 && tl_i < 64) a.timeline[(long long)blockIdx.x * 64 + tl_i++] = __builtin_amdgcn_s_memtime();
     };
     for (int ct = first; ct < xend; ct += wpx) {
         int Y0, X0, n0, ks;
@@ -486,15 +487,24 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
             // step's DMAs and the ones that followed.  Counting them lets the stores drain under the new tile's first
             // K-steps instead of being waited for at its first barrier.
             const bool two = NSTAGE == 3 && n_ahead >= 2;
+            // DREAMMAT_CONV_TIMELINE=4: s_memtime differences summed in SGPRs (no stores inside the loop, every wave):
+            // MFMA body | fragment-read wait | DMA wait | barrier.  Each column carries one ~130-tick s_memtime round trip.
+            const bool tl4 = a.timeline_steps == 4;
+            unsigned long long t_a = 0, t_b = 0, t_c = 0;
+            if (tl4) { t_a = __builtin_amdgcn_s_memtime(); tl_sum[0] += t_a - tl_prev; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (tl4) { t_b = __builtin_amdgcn_s_memtime(); tl_sum[1] += t_b - t_a; }
             if (s - s_lo < NSTAGE - 1 && ct != first && !(SPLIT_OK && ksplit > 1)) {
-                if (two) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(L + NST) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NST) : "memory");
+                if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L + NST) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
             } else {
-                if (two) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(L) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            if (tl4) { t_c = __builtin_amdgcn_s_memtime(); tl_sum[2] += t_c - t_b; }
             __builtin_amdgcn_s_barrier();
-            if (a.timeline_steps) stamp();
+            if (tl4) { tl_prev = __builtin_amdgcn_s_memtime(); tl_sum[3] += tl_prev - t_c; ++tl_sum[4]; }
+            if (a.timeline_steps == 2) stamp();
             --n_ahead;
             int st2 = stage + NSTAGE - 1; if (st2 >= NSTAGE) st2 -= NSTAGE;
             kstep(stage, st2, s > s_lo);
@@ -677,7 +687,10 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
         }
         }
         stamp();
+        if (a.timeline_steps == 4) tl_prev = __builtin_amdgcn_s_memtime();     // (the epilogue is not part of the next body)
     }   // tile loop
+    if (a.timeline && a.timeline_steps == 4 && lane == 0)      // every wave's sums: slots 8 + 5 * wave ..
+        for (int i = 0; i < 5; ++i) a.timeline[(long long)blockIdx.x * 64 + 8 + 5 * wave + i] = tl_sum[i];
 #endif
 }
 
@@ -809,7 +822,7 @@ int launch_conv_dma(const ConvArgs& a_in, hipStream_t stream) {
     if (timeline) {
         if (!tl_buf && hipMalloc(&tl_buf, 4096 * 64 * 8) != hipSuccess) return DM_ERR_UNSUPPORTED;
         if (blocks <= 4096) { (void)hipMemsetAsync(tl_buf, 0, 4096 * 64 * 8, stream); a.timeline = tl_buf; }
-        a.timeline_steps = atoi(getenv("DREAMMAT_CONV_TIMELINE")) == 2;
+        a.timeline_steps = atoi(getenv("DREAMMAT_CONV_TIMELINE")) >= 2 ? atoi(getenv("DREAMMAT_CONV_TIMELINE")) : 0;
     }
     hipLaunchKernelGGL((k_conv3x3_dma<BMT, BN, NW, WMW, NSTAGE, TAPS, EPI>), dim3((unsigned)blocks), dim3(NW * 64), LDS, stream, a,
                        n_mt, n_nt, stagger, ksplit, ws);
@@ -830,7 +843,16 @@ int launch_conv_dma(const ConvArgs& a_in, hipStream_t stream) {
             const unsigned long long* t = host + (size_t)b * 64;
             int n = 0;
             while (n < 64 && t[n]) ++n;
-            if (a.timeline_steps) {
+            if (a.timeline_steps == 4) {
+                fprintf(stderr, " per K-step, s_memtime ticks\n");
+                for (int w = 0; w < NW; ++w) {
+                    const unsigned long long* u = t + 8 + 5 * w;
+                    const double ns = (double)std::max<unsigned long long>(1, u[4]);
+                    fprintf(stderr, "    wave %d over %llu steps: body %.0f | LDS wait %.0f | DMA wait %.0f | barrier %.0f\n", w, u[4],
+                            u[0] / ns, u[1] / ns, u[2] / ns, u[3] / ns);
+                }
+                continue;
+            } else if (a.timeline_steps) {
                 for (int i = 1; i < n; ++i) fprintf(stderr, " %llu", t[i] - t[i - 1]);
             } else {
                 for (int i = 0; i + 2 < n; i += 3) fprintf(stderr, " K=%llu E=%llu", t[i + 1] - t[i], t[i + 2] - t[i + 1]);
