@@ -43,6 +43,9 @@ def parse():
                     help="hipGraph replay of the ControlNet+UNet noise prediction (guidance hip_graph)")
     ap.add_argument("--resident", choices=["auto", "on", "off"], default="auto",
                     help="condition maps / cameras of all (view, env) pairs resident in HBM (data.py); off = per-step H2D")
+    ap.add_argument("--raytracing", action="store_true",
+                    help="the reference's DEFAULT material branch (use_raytracing: true, 200 + 128 Monte-Carlo directions per pixel with "
+                         "occlusion rays) instead of the split-sum branch BASELINE.json's metric is quoted on: not a BASELINE config")
     ap.add_argument("--dump-kernels", default=None, help="write the per-kernel HIP-event table of the timed region (JSON) here")
     return ap.parse_args()
 
@@ -64,7 +67,8 @@ def synthetic_latlong(seed, h=256, w=512):
 def system_config(a, views_per_rank):
     return {
         "geometry": {"shape_init": a.mesh, "shape_init_params": 0.8},
-        "material": {"use_raytracing": False, "environment_scale": 2.0, "env_max_res": a.env_res, "env_min_res": 16,
+        "material": {"use_raytracing": bool(a.raytracing), "diffuse_sample_num": 200, "specular_sample_num": 128,
+                     "environment_scale": 2.0, "env_max_res": a.env_res, "env_min_res": 16,
                      "n_envs": 5,
                      # the reference's own split-sum LUT (tests/golden/assets, copied from load/lights); falls back to the
                      # analytic stand-in when the file is absent -- `config.fg_lut` in the JSON line says which one ran
@@ -86,6 +90,8 @@ def system_config(a, views_per_rank):
 
 def baseline_config_name(a, n_tris):
     """which BASELINE.json `configs` entry the run's shape is (the string used to be hard-coded to configs[2])"""
+    if a.raytracing:
+        return "custom shape (no BASELINE.json entry: the reference's default Monte-Carlo ray-traced material branch, SURVEY row f-1)"
     if a.res == 512 and a.views == 8 and 40000 <= n_tris <= 60000:
         return "BASELINE configs[2]" if int(os.environ.get("WORLD_SIZE", 1)) == 1 else "BASELINE configs[3] (configs[2] sharded by view)"
     if a.res == 512 and a.views == 4 and n_tris < 12000:
@@ -345,7 +351,8 @@ def main():
                "config": {"workload": f"{baseline_config_name(a, system.geometry.mesh.t_pos_idx.shape[0])}: "
                                       f"{system.geometry.mesh.t_pos_idx.shape[0]}-tri displaced sphere, "
                                       f"{a.res}^2, {a.views} views/step, 5 synthetic env maps, {a.sd} UNet+22ch ControlNet "
-                                      f"(random init), split-sum shading, hash-grid field 16x2 2^19",
+                                      f"(random init), " + ("Monte-Carlo shading (200 + 128 directions, occlusion rays)" if a.raytracing else "split-sum shading") +
+                                      ", hash-grid field 16x2 2^19",
                           "views_per_step": a.views, "views_per_rank": vpr, "resolution": a.res, "sd_arch": a.sd,
                           "timed_region": "collate (draw + HBM gather of cameras and condition maps) + render + VAE/ControlNet/UNet + "
                                           "SDS + backward + all-reduce + Adam; debug buffers off (written every 1000 steps only)",

@@ -42,7 +42,16 @@ class McSceneStruct(ctypes.Structure):
     """dm_mc_scene (include/dreammat_hip.h): host struct with device pointers for the Monte-Carlo shading kernels."""
     _fields_ = [("bvh_nodes", c_void_p), ("bvh_tris", c_void_p), ("lights", c_void_p), ("n_env", c_int),
                 ("light_h", c_int), ("light_w", c_int), ("samples_diffuse", c_void_p), ("samples_specular", c_void_p),
-                ("n_diffuse", c_int), ("n_specular", c_int), ("geometry_ggx_smith", c_int), ("bvh_nodes4", c_void_p)]
+                ("n_diffuse", c_int), ("n_specular", c_int), ("geometry_ggx_smith", c_int), ("bvh_nodes4", c_void_p),
+                ("grid", c_void_p)]
+
+
+class GridStruct(ctypes.Structure):
+    """dm_grid (include/dreammat_hip.h): occupancy grid of the mesh, host struct with device pointers."""
+    _fields_ = [("gmin", c_float * 3), ("cell", c_float), ("inv_cell", c_float), ("dim", c_int32 * 3),
+                ("n_words", c_int32), ("n_occ", c_int32), ("n_entries", c_longlong),
+                ("bits", c_void_p), ("sbase", c_void_p), ("off16", c_void_p), ("dist4", c_void_p), ("occ_start", c_void_p),
+                ("cell_tris", c_void_p)]
 
 
 _LL = c_longlong
@@ -88,6 +97,9 @@ _SIGS = {
     "dm_bvh_build": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "dm_bvh_collapse4": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "dm_bvh_any_hit_rays": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _LL, c_float, c_void_p, c_void_p]),
+    "dm_grid_build": (c_int, [c_void_p, c_int32, c_int32, POINTER(GridStruct), POINTER(c_void_p), POINTER(c_longlong)]),
+    "dm_host_free": (None, [c_void_p]),
+    "dm_grid_any_hit_rays": (c_int, [POINTER(GridStruct), c_void_p, c_void_p, _LL, c_float, c_void_p, c_void_p]),
     "dm_mc_hit_words": (c_int, [c_int, c_int]),
     "dm_mc_shade_fwd": (c_int, [POINTER(McSceneStruct), POINTER(MatCfgStruct)] + [c_void_p, _LL, _LL] * 4
                         + [c_void_p, c_void_p, c_void_p, _LL, c_int, c_void_p, c_void_p, c_void_p, c_void_p, _LL, _LL]

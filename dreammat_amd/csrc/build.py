@@ -28,7 +28,7 @@ SOURCES = {
     "mc_shade.hip": [],
     "host.cpp": [],
 }
-HEADERS = ["dm_common.h", "attn_common.h", "raster_core.h", "shade_core.h", "bvh_core.h", "mc_shade_core.h"]
+HEADERS = ["dm_common.h", "attn_common.h", "raster_core.h", "shade_core.h", "bvh_core.h", "grid_core.h", "mc_shade_core.h"]
 
 
 def _newer(src, dst):

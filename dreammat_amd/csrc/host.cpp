@@ -3,13 +3,16 @@
 // the DreamMat mesh is fixed, so it is built once per mesh) and library introspection.
 #include <algorithm>
 #include <cfloat>
+#include <cmath>
 #include <cstdlib>
 #include <cstdint>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "bvh_core.h"
 #include "dm_common.h"
+#include "grid_core.h"
 
 namespace {
 
@@ -84,7 +87,7 @@ struct BvhBuilder {
 
 extern "C" {
 
-int dm_abi_version(void) { return 3; }     // 3: + dm_attention_selected, dm_cat_add_bf16; dm_attention_select names changed
+int dm_abi_version(void) { return 4; }     // 4: + dm_grid_build / dm_grid_any_hit_rays / dm_host_free, dm_mc_scene.grid
 
 // opp[t][i] = vertex opposite to edge i of triangle t in the other triangle sharing that edge,
 // -1 if none.  Edge 0 = (v1,v2), edge 1 = (v2,v0), edge 2 = (v0,v1).  Host pointers.
@@ -213,5 +216,182 @@ int dm_bvh_collapse4(const void* nodes2_v, int32_t n_nodes2, void* nodes4_out, i
     *n_nodes4_out = (int32_t)out.size();
     return DM_OK;
 }
+
+}  // extern "C"
+
+// ---- uniform occupancy grid of the same triangles (csrc/grid_core.h) ---------------------------------------------------
+namespace {
+
+// Akenine-Moeller triangle / box overlap (separating axes: 3 box normals, the triangle normal, 9 edge cross products),
+// box centred at c with half size h (already inflated by the caller); v* are absolute positions.
+bool tri_box_overlap(const float c[3], float h, const float v0a[3], const float v1a[3], const float v2a[3]) {
+    double v0[3], v1[3], v2[3];
+    for (int d = 0; d < 3; ++d) { v0[d] = (double)v0a[d] - c[d]; v1[d] = (double)v1a[d] - c[d]; v2[d] = (double)v2a[d] - c[d]; }
+    const double e[3][3] = {{v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]},
+                            {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]},
+                            {v0[0] - v2[0], v0[1] - v2[1], v0[2] - v2[2]}};
+    for (int d = 0; d < 3; ++d) {                                   // box normals
+        const double lo = std::min(v0[d], std::min(v1[d], v2[d])), hi = std::max(v0[d], std::max(v1[d], v2[d]));
+        if (lo > h || hi < -h) return false;
+    }
+    for (int i = 0; i < 3; ++i)                                     // edge i x axis a
+        for (int a = 0; a < 3; ++a) {
+            double ax[3] = {0, 0, 0};
+            const int b = (a + 1) % 3, cc = (a + 2) % 3;            // axis = unit_a x e[i]
+            ax[b] = -e[i][cc]; ax[cc] = e[i][b];
+            const double p0 = ax[0] * v0[0] + ax[1] * v0[1] + ax[2] * v0[2];
+            const double p1 = ax[0] * v1[0] + ax[1] * v1[1] + ax[2] * v1[2];
+            const double p2 = ax[0] * v2[0] + ax[1] * v2[1] + ax[2] * v2[2];
+            const double r = h * (std::fabs(ax[0]) + std::fabs(ax[1]) + std::fabs(ax[2]));
+            if (std::min(p0, std::min(p1, p2)) > r || std::max(p0, std::max(p1, p2)) < -r) return false;
+        }
+    const double n[3] = {e[0][1] * e[1][2] - e[0][2] * e[1][1], e[0][2] * e[1][0] - e[0][0] * e[1][2],
+                         e[0][0] * e[1][1] - e[0][1] * e[1][0]};   // triangle plane
+    const double dist = n[0] * v0[0] + n[1] * v0[1] + n[2] * v0[2];
+    const double r = h * (std::fabs(n[0]) + std::fabs(n[1]) + std::fabs(n[2]));
+    return std::fabs(dist) <= r;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Conservative voxelisation of dm_bvh_build's triangle array (tris12 = its `tris_out`, [n_tri][12]) into a uniform grid of at
+// most `res` cells along the longest axis of the mesh box (res <= 0: chosen from the triangle count, <= 96 so that the
+// occupancy tables fit LDS).  HOST function.  *blob_out (malloc'd, release with dm_host_free) holds the five sections of
+// csrc/grid_core.h, each padded to 16 bytes:
+//   bits[n_words] u32 | sbase[ceil(n_words / 64)] u32 | off16[n_words] u16 | dist4[one nibble per 2x2x2 block] |
+//   occ_start[n_occ + 1] u32 | cell_tris[n_entries][12] f32
+// and `grid` receives the scalars (its pointers are left NULL: the caller copies the blob to the device and fills them).
+int dm_grid_build(const float* tris12, int32_t n_tri, int32_t res, void* grid_v, uint32_t** blob_out, int64_t* blob_words) {
+    if (!tris12 || !grid_v || !blob_out || !blob_words || n_tri <= 0) return DM_ERR_ARG;
+    DmGrid& g = *(DmGrid*)grid_v;
+    if (res <= 0) {
+        // a closed surface of n triangles occupies ~6 res^2 cells: ~2 triangles per occupied cell (the bench mesh, 50 880
+        // triangles: res 64 traced fastest of 48 / 56 / 64 / 76 / 84, profiles/r03_mc_probe.json)
+        res = std::min(76, (int)std::lround(std::sqrt((double)n_tri / 12.5)));
+        if (const char* e = getenv("DREAMMAT_GRID_RES")) res = atoi(e);          // tuning knob (tools/mc_probe.py)
+    }
+    res = std::max(4, std::min(96, res));                           // (<= 76: tables + per-wave scratch of the shading kernel fit LDS)
+    float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+    auto vert = [&](int32_t t, int k, float* p) {
+        const float* s = tris12 + 12 * (size_t)t;
+        for (int d = 0; d < 3; ++d) p[d] = k == 0 ? s[d] : s[d] + s[4 * k + d];
+    };
+    for (int32_t t = 0; t < n_tri; ++t)
+        for (int k = 0; k < 3; ++k) {
+            float p[3];
+            vert(t, k, p);
+            for (int d = 0; d < 3; ++d) {
+                if (!std::isfinite(p[d])) return DM_ERR_ARG;
+                lo[d] = std::min(lo[d], p[d]); hi[d] = std::max(hi[d], p[d]);
+            }
+        }
+    float ext = std::max(hi[0] - lo[0], std::max(hi[1] - lo[1], hi[2] - lo[2]));
+    if (!(ext > 0.f)) ext = 1.f;
+    const float cell = ext * 1.02f / (float)res;                    // 1 % margin on either side of the longest axis
+    for (int d = 0; d < 3; ++d) {
+        const float mid = 0.5f * (lo[d] + hi[d]);
+        int n = (int)std::ceil((hi[d] - lo[d]) / cell + 0.04f);
+        n = std::max(1, std::min(res, n));
+        g.dim[d] = n;
+        g.gmin[d] = mid - 0.5f * (float)n * cell;
+    }
+    g.cell = cell; g.inv_cell = 1.0f / cell;
+    const long long n_cells = (long long)g.dim[0] * g.dim[1] * g.dim[2];
+    g.n_words = (int)((n_cells + 31) / 32);
+    const float infl = 1e-3f * cell;
+    std::vector<std::pair<uint32_t, uint32_t>> ent;                  // (cell, triangle)
+    ent.reserve((size_t)n_tri * 8);
+    for (int32_t t = 0; t < n_tri; ++t) {
+        float v[3][3];
+        for (int k = 0; k < 3; ++k) vert(t, k, v[k]);
+        int c0[3], c1[3];
+        for (int d = 0; d < 3; ++d) {
+            const float a = std::min(v[0][d], std::min(v[1][d], v[2][d])) - infl, b = std::max(v[0][d], std::max(v[1][d], v[2][d])) + infl;
+            c0[d] = std::max(0, std::min(g.dim[d] - 1, (int)std::floor((a - g.gmin[d]) * g.inv_cell)));
+            c1[d] = std::max(0, std::min(g.dim[d] - 1, (int)std::floor((b - g.gmin[d]) * g.inv_cell)));
+        }
+        for (int z = c0[2]; z <= c1[2]; ++z)
+            for (int y = c0[1]; y <= c1[1]; ++y)
+                for (int x = c0[0]; x <= c1[0]; ++x) {
+                    const float c[3] = {g.gmin[0] + ((float)x + 0.5f) * cell, g.gmin[1] + ((float)y + 0.5f) * cell,
+                                        g.gmin[2] + ((float)z + 0.5f) * cell};
+                    if (tri_box_overlap(c, 0.5f * cell + infl, v[0], v[1], v[2]))
+                        ent.emplace_back((uint32_t)(((long long)z * g.dim[1] + y) * g.dim[0] + x), (uint32_t)t);
+                }
+    }
+    std::sort(ent.begin(), ent.end());
+    std::vector<uint32_t> bits(g.n_words, 0u), occ_start;
+    for (size_t i = 0; i < ent.size(); ++i)
+        if (i == 0 || ent[i].first != ent[i - 1].first) {
+            bits[ent[i].first >> 5] |= 1u << (ent[i].first & 31);
+            occ_start.push_back((uint32_t)i);
+        }
+    g.n_occ = (int)occ_start.size();
+    occ_start.push_back((uint32_t)ent.size());
+    g.n_entries = (long long)ent.size();
+    // block distance field: Chebyshev distance (in 2x2x2 blocks) to the nearest block that holds an occupied cell, <= 15
+    const int bd[3] = {(g.dim[0] + 1) / 2, (g.dim[1] + 1) / 2, (g.dim[2] + 1) / 2};
+    const long long n_blocks = (long long)bd[0] * bd[1] * bd[2];
+    std::vector<uint8_t> dist((size_t)n_blocks, 255);
+    for (long long c = 0; c < n_cells; ++c)
+        if ((bits[c >> 5] >> (c & 31)) & 1u) {
+            const int x = (int)(c % g.dim[0]), y = (int)((c / g.dim[0]) % g.dim[1]), z = (int)(c / ((long long)g.dim[0] * g.dim[1]));
+            dist[((size_t)(z >> 1) * bd[1] + (y >> 1)) * bd[0] + (x >> 1)] = 0;
+        }
+    for (int r = 1; r <= 15; ++r) {
+        std::vector<size_t> grow;
+        for (int z = 0; z < bd[2]; ++z)
+            for (int y = 0; y < bd[1]; ++y)
+                for (int x = 0; x < bd[0]; ++x) {
+                    const size_t b = ((size_t)z * bd[1] + y) * bd[0] + x;
+                    if (dist[b] != 255) continue;
+                    bool near = false;
+                    for (int dz = -1; dz <= 1 && !near; ++dz)
+                        for (int dy = -1; dy <= 1 && !near; ++dy)
+                            for (int dx = -1; dx <= 1 && !near; ++dx) {
+                                const int X = x + dx, Y = y + dy, Z = z + dz;
+                                if (X < 0 || Y < 0 || Z < 0 || X >= bd[0] || Y >= bd[1] || Z >= bd[2]) continue;
+                                near = dist[((size_t)Z * bd[1] + Y) * bd[0] + X] == r - 1;
+                            }
+                    if (near) grow.push_back(b);
+                }
+        for (size_t b : grow) dist[b] = (uint8_t)r;
+    }
+    // sections, each padded to 16 bytes: bits | sbase | off16 | dist4 | occ_start | cell_tris
+    auto pad4 = [](int64_t w) { return (w + 3) / 4 * 4; };
+    const int64_t nsb = (g.n_words + 63) / 64;
+    const int64_t w_bits = pad4(g.n_words), w_sb = pad4(nsb), w_off = pad4((g.n_words + 1) / 2), w_dist = pad4((n_blocks + 7) / 8),
+                  w_occ = pad4((int64_t)occ_start.size());
+    const int64_t words = w_bits + w_sb + w_off + w_dist + w_occ + 12 * (int64_t)ent.size();
+    uint32_t* blob = (uint32_t*)calloc((size_t)words, 4);
+    if (!blob) return DM_ERR_WORKSPACE;
+    uint32_t* p = blob;
+    std::memcpy(p, bits.data(), (size_t)g.n_words * 4);
+    uint32_t* sb = blob + w_bits;
+    uint16_t* off = (uint16_t*)(blob + w_bits + w_sb);
+    uint32_t run = 0, in_block = 0;
+    for (int w = 0; w < g.n_words; ++w) {
+        if ((w & 63) == 0) { sb[w >> 6] = run; in_block = 0; }
+        off[w] = (uint16_t)in_block;                                // < 64 * 32
+        const uint32_t pc = (uint32_t)__builtin_popcount(bits[w]);
+        run += pc; in_block += pc;
+    }
+    uint8_t* d4 = (uint8_t*)(blob + w_bits + w_sb + w_off);
+    for (long long b = 0; b < n_blocks; ++b) d4[b >> 1] |= (uint8_t)(std::min<int>(dist[(size_t)b], 15) << ((b & 1) * 4));
+    std::memcpy(blob + w_bits + w_sb + w_off + w_dist, occ_start.data(), occ_start.size() * 4);
+    float* ct = (float*)(blob + w_bits + w_sb + w_off + w_dist + w_occ);
+    for (size_t i = 0; i < ent.size(); ++i) {
+        std::memcpy(ct + 12 * i, tris12 + 12 * (size_t)ent[i].second, 48);
+        const int32_t id = (int32_t)ent[i].second;
+        std::memcpy(ct + 12 * i + 3, &id, 4);                       // (slot 3 is unused by the intersection test)
+    }
+    g.bits = g.sbase = g.occ_start = nullptr; g.off16 = nullptr; g.dist4 = nullptr; g.cell_tris = nullptr;
+    *blob_out = blob; *blob_words = words;
+    return DM_OK;
+}
+
+void dm_host_free(void* p) { free(p); }
 
 }  // extern "C"

@@ -26,6 +26,7 @@ struct dm_mc_scene {
     int n_diffuse, n_specular;
     int geometry_ggx_smith;
     const void* bvh_nodes4;
+    const void* grid;                 // const dm_grid* (host struct, device pointers) or null
 };
 }
 
@@ -39,6 +40,7 @@ struct StrOut { float* p; long long rs, cs; };
 struct McArgs {
     McCfg cfg;
     const DmBvhNode* nodes; const float* tris; const DmBvhNode4* nodes4;
+    DmGrid grid; int use_grid; int grid_in_lds; int grid_table_words;
     const float* lights; int n_env, light_h, light_w;
     const float* samples_d; const float* samples_s;
     Str pos, nrm, view, feat, dcolor;
@@ -65,6 +67,7 @@ __global__ __launch_bounds__(128) void k_mc_shade(McArgs a) {
     const int env = a.env_of_view[a.pix_idx[i] / a.HW];
     McScene sc;
     sc.nodes = a.nodes; sc.tris = a.tris; sc.nodes4 = a.nodes4;
+    sc.grid = a.use_grid ? &a.grid : nullptr; sc.grid_tb = {a.grid.bits, a.grid.sbase, a.grid.off16, a.grid.dist4};
     sc.light = a.lights + (size_t)env * a.light_h * a.light_w * 3; sc.light_h = a.light_h; sc.light_w = a.light_w;
     sc.samples_d = a.samples_d; sc.samples_s = a.samples_s;
     const float rd = a.rand_d ? a.rand_d[i] : -1.f, rs = a.rand_s ? a.rand_s[i] : -1.f;
@@ -116,9 +119,120 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ void wave_sum_inplace(float& v) { v = wave_sum(v); }
 __device__ __forceinline__ void wave_sum_inplace(Dual& v) { v.v = wave_sum(v.v); v.d = wave_sum(v.d); }
 
-template <bool BWD>
-__global__ __launch_bounds__(256) void k_mc_shade_wave(McArgs a) {
+// ---- wave-cooperative occupancy-grid traversal (the one-wave-per-pixel forward kernel).  Same cells, same triangle tests and
+// the same boolean per ray as dm_grid_any_hit (csrc/grid_core.h), reorganised for 64 lanes: measured with in-kernel counters
+// on the bench scene, the per-ray form ran the cell loop with 21 of 64 lanes active and the triangle loop with 9 -- 163
+// triangle-loop trips per 64 rays for 28 tests per ray -- because every lane reaches its occupied cells at its own step and
+// the lists have their own lengths.  Here a round has three wave-uniform parts:
+//   (1) every live ray walks empty cells (LDS reads + VALU) until it stands on an occupied cell or is gone;
+//   (2) the lanes' triangle lists are laid end to end (prefix sum of the lengths) and the (ray, triangle) pairs are dealt out
+//       64 at a time -- pair k belongs to the lane with the largest prefix <= k (6-step search in LDS), whose ray it reads from
+//       LDS: full lanes whatever the individual list lengths;
+//   (3) rays that were hit stop, the others step past their cell.
+// development counters (tools/build_variant.sh st mc_shade.hip -DDM_MC_STATS; tools/mc_probe.py --stats): wave-level trips
+#ifdef DM_MC_STATS
+__device__ unsigned long long dm_mc_stats[8];
+#define DM_STAT(i, n) do { if (lane == 0) atomicAdd(&dm_mc_stats[i], (unsigned long long)(n)); } while (0)
+#else
+#define DM_STAT(i, n) do { } while (0)
+#endif
+
+struct WaveScratch {
+    unsigned start[64];           // exclusive prefix of this round's list lengths
+    unsigned e0[64];              // first record of each lane's list
+    float ray[64][6];             // origin, direction
+    unsigned hit[64];
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ bool grid_trace_wave(const DmGrid& g, const DmGridTables& tb, bool active, float ox, float oy, float oz,
+                                                float dx, float dy, float dz, float t_max, WaveScratch* ws, int lane) {
+    DmDda s;
+    bool alive = active && dm_dda_init(g, s, ox, oy, oz, dx, dy, dz, t_max);
+    bool hit = false;
+    ws->ray[lane][0] = ox; ws->ray[lane][1] = oy; ws->ray[lane][2] = oz;
+    ws->ray[lane][3] = dx; ws->ray[lane][4] = dy; ws->ray[lane][5] = dz;
+    ws->hit[lane] = 0u;
+    DM_STAT(0, 1);                                       // wave-rays
+    while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
+        DM_STAT(1, 1);                                   // rounds
+        int c = 0;
+        uint32_t w = 0;
+        bool found = false;
+        while (__builtin_amdgcn_ballot_w64(alive && !found) != 0ull) {
+            DM_STAT(2, 1);                               // cell-walk trips
+            DM_STAT(3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(alive && !found)));
+            if (alive && !found) {
+                c = dm_dda_cell(g, s);
+                w = tb.bits[c >> 5];
+                if ((w >> (c & 31)) & 1u) found = true;
+                else alive = dm_dda_advance(g, tb, s, ox, oy, oz, dx, dy, dz);
+            }
+        }
+        unsigned e0 = 0, cnt = 0;
+        if (found) {
+            const uint32_t r = dm_grid_rank(tb, c, w);
+            e0 = g.occ_start[r];
+            cnt = g.occ_start[r + 1] - e0;
+        }
+        unsigned incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        const unsigned total = __shfl(incl, 63, 64);
+        if (total == 0u) break;                          // nobody found a cell: every ray is gone
+        ws->start[lane] = incl - cnt;
+        ws->e0[lane] = e0;
+        wave_lds_sync();
+        DM_STAT(5, total);                               // (ray, triangle) pairs
+        for (unsigned base = 0; base < total; base += 64) {
+            DM_STAT(4, 1);                               // pair batches
+            const unsigned k = base + lane;
+            if (k < total) {
+                int lo = 0;
+#pragma unroll
+                for (int st = 32; st > 0; st >>= 1)
+                    if (ws->start[lo + st] <= k) lo += st;
+                const unsigned e = ws->e0[lo] + (k - ws->start[lo]);
+                const float* r6 = ws->ray[lo];
+                if (dm_bvh_ray_triangle(g.cell_tris + 12 * (size_t)e, r6[0], r6[1], r6[2], r6[3], r6[4], r6[5], t_max)) ws->hit[lo] = 1u;
+            }
+        }
+        wave_lds_sync();
+        if (found) {
+            if (ws->hit[lane]) { hit = true; alive = false; }
+            else alive = dm_dda_step(g, s);
+        }
+        wave_lds_sync();                                 // (the next round rewrites start / e0)
+    }
+    return hit;
+}
+
+template <bool BWD, int BLOCK, bool COOP = false>
+__global__ __launch_bounds__(BLOCK) void k_mc_shade_wave(McArgs a) {
     using S = typename std::conditional<BWD, Dual, float>::type;
+    // occupancy tables of the mesh grid (bits | sbase | off16, contiguous and 16-byte padded in the blob): one LDS copy per
+    // workgroup, shared by its 16 waves -- see csrc/grid_core.h
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_grid[];
+    DmGridTables gtb = {a.grid.bits, a.grid.sbase, a.grid.off16, a.grid.dist4};
+    if (!BWD && a.use_grid && a.grid_in_lds) {
+        const int nw = a.grid_table_words;
+        for (int w = threadIdx.x; w < nw; w += blockDim.x) lds_grid[w] = a.grid.bits[w];
+        __syncthreads();
+        gtb.bits = lds_grid;
+        gtb.sbase = lds_grid + (a.grid.sbase - a.grid.bits);
+        gtb.off16 = reinterpret_cast<const uint16_t*>(lds_grid + (reinterpret_cast<const uint32_t*>(a.grid.off16) - a.grid.bits));
+        gtb.dist4 = reinterpret_cast<const uint8_t*>(lds_grid + (reinterpret_cast<const uint32_t*>(a.grid.dist4) - a.grid.bits));
+    }
+    WaveScratch* ws = nullptr;
+    if (COOP) ws = reinterpret_cast<WaveScratch*>(lds_grid + (a.grid_in_lds ? (a.grid_table_words + 3) / 4 * 4 : 0)) + (threadIdx.x >> 6);
     const long long N = *a.n_dev;
     const int lane = threadIdx.x & 63;
     const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -132,6 +246,7 @@ __global__ __launch_bounds__(256) void k_mc_shade_wave(McArgs a) {
         const int env = a.env_of_view[a.pix_idx[i] / a.HW];
         McScene sc;
         sc.nodes = a.nodes; sc.tris = a.tris; sc.nodes4 = a.nodes4;
+        sc.grid = a.use_grid ? &a.grid : nullptr; sc.grid_tb = gtb;
         sc.light = a.lights + (size_t)env * a.light_h * a.light_w * 3; sc.light_h = a.light_h; sc.light_w = a.light_w;
         sc.samples_d = a.samples_d; sc.samples_s = a.samples_s;
         McFrame fr;
@@ -146,7 +261,17 @@ __global__ __launch_bounds__(256) void k_mc_shade_wave(McArgs a) {
             const bool active = s < sn;
             bool hit = false;
             if (BWD && active) hit = (gb[s >> 5] >> (s & 31)) & 1u;
-            if (active) sample_eval<S, !BWD>(a.cfg, sc, fr, al, s, hit, acc);
+            if (!BWD && COOP) {
+                // the occlusion rays of the round, traced by the whole wave together (grid_trace_wave)
+                V3<float> d = {0.f, 0.f, 1.f};
+                if (active) d = sample_dir<float>(a.cfg, sc, fr, px.alpha, s);
+                const float eps = 1e-5f;                   // get_lights (:490-507), as in occluded()
+                hit = grid_trace_wave(a.grid, gtb, active, fr.p[0] + d.x * eps, fr.p[1] + d.y * eps, fr.p[2] + d.z * eps, d.x, d.y, d.z,
+                                      10.0f, ws, lane);
+                if (active) sample_eval<S, false>(a.cfg, sc, fr, al, s, hit, acc);
+            } else if (active) {
+                sample_eval<S, !BWD>(a.cfg, sc, fr, al, s, hit, acc);
+            }
             if (!BWD) {
                 const unsigned long long m = __ballot(active && hit);
                 if (lane == 0) {
@@ -195,8 +320,26 @@ bool use_wave_kernel() {
 template <bool BWD>
 void launch_mc(const McArgs& a, long long n_max, hipStream_t stream) {
     if (use_wave_kernel()) {
-        const unsigned grid = (unsigned)std::min<long long>((n_max + 3) / 4, 256 * 8);
-        hipLaunchKernelGGL(k_mc_shade_wave<BWD>, dim3(grid), dim3(256), 0, stream, a);
+        if constexpr (!BWD) {
+            if (a.use_grid) {
+                // one workgroup of 16 waves per CU around ONE LDS copy of the occupancy tables + a scratch block per wave
+                // (8 waves with twice the registers, no spills: 27.5 vs 18.1 ms on the bench scene -- occupancy wins)
+                const size_t lds = (a.grid_in_lds ? (size_t)((a.grid_table_words + 3) / 4 * 4) * 4 : 0) + 16 * sizeof(WaveScratch);
+                static bool attr_set = false;
+                if (!attr_set) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mc_shade_wave<false, 1024, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    attr_set = true;
+                }
+                const unsigned grid = (unsigned)std::min<long long>((n_max + 15) / 16, 256);
+                hipLaunchKernelGGL((k_mc_shade_wave<false, 1024, true>), dim3(grid), dim3(1024), lds, stream, a);
+                return;
+            }
+        }
+        {
+            const unsigned grid = (unsigned)std::min<long long>((n_max + 3) / 4, 256 * 8);
+            hipLaunchKernelGGL((k_mc_shade_wave<BWD, 256>), dim3(grid), dim3(256), 0, stream, a);
+        }
     } else {
         hipLaunchKernelGGL(k_mc_shade<BWD>, dim3(dm_div_up(n_max, 128)), dim3(128), 0, stream, a);
     }
@@ -211,12 +354,35 @@ bool fill(McArgs& a, const dm_mc_scene* s, const dm_mat_cfg* mat) {
     a.nodes = (const DmBvhNode*)s->bvh_nodes; a.tris = s->bvh_tris; a.nodes4 = (const DmBvhNode4*)s->bvh_nodes4;
     a.lights = s->lights; a.n_env = s->n_env; a.light_h = s->light_h; a.light_w = s->light_w;
     a.samples_d = s->samples_diffuse; a.samples_s = s->samples_specular;
+    a.use_grid = 0; a.grid_in_lds = 0;
+    if (s->grid) {
+        a.grid = *(const DmGrid*)s->grid;
+        if (!a.grid.bits || !a.grid.sbase || !a.grid.off16 || !a.grid.dist4 || !a.grid.occ_start || !a.grid.cell_tris || a.grid.n_words <= 0)
+            return false;
+        a.use_grid = 1;
+        // the four tables are the first sections of dm_grid_build's blob (contiguous, in this order): copy them to LDS when they fit
+        const long long n_blocks = (long long)((a.grid.dim[0] + 1) / 2) * ((a.grid.dim[1] + 1) / 2) * ((a.grid.dim[2] + 1) / 2);
+        const long long tw = (reinterpret_cast<const uint32_t*>(a.grid.dist4) - a.grid.bits) + (n_blocks + 7) / 8;
+        const bool contiguous = a.grid.sbase > a.grid.bits && reinterpret_cast<const uint32_t*>(a.grid.off16) > a.grid.sbase &&
+                                reinterpret_cast<const uint32_t*>(a.grid.dist4) > reinterpret_cast<const uint32_t*>(a.grid.off16) && tw < (1 << 20);
+        a.grid_table_words = contiguous ? (int)tw : 0;
+        a.grid_in_lds = contiguous && ((size_t)tw + 3) / 4 * 16 + 16 * sizeof(WaveScratch) <= 160 * 1024;
+    }
     return true;
 }
 
 }  // namespace
 
 extern "C" {
+
+#ifdef DM_MC_STATS
+int dm_mc_debug_stats(unsigned long long* out8) {       // development: read and clear the counters
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(dm_mc_stats), sizeof(z)) != hipSuccess) return DM_ERR_UNSUPPORTED;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(dm_mc_stats), z, sizeof(z));
+    return DM_OK;
+}
+#endif
 
 int dm_mc_hit_words(int n_diffuse, int n_specular) { return (n_diffuse + n_specular + 31) / 32; }
 

@@ -18,6 +18,7 @@
 #pragma once
 #include "bvh_core.h"
 #include "dm_common.h"
+#include "grid_core.h"
 
 namespace dm {
 namespace mc {
@@ -80,6 +81,7 @@ struct McCfg {
 struct McScene {
     const DmBvhNode* nodes; const float* tris;                       // dm_bvh_build outputs
     const DmBvhNode4* nodes4;                                        // optional 4-wide form (dm_bvh_collapse4), else null
+    const DmGrid* grid; DmGridTables grid_tb;                        // optional occupancy grid (dm_grid_build) + where its tables are (LDS / global)
     const float* light; int light_h, light_w;                        // lat-long radiance [h][w][3] of this pixel's env
     const float* samples_d; const float* samples_s;                  // [n][2] (azimuth, elevation) tables in [0,1]^2
 };
@@ -115,6 +117,7 @@ DM_HD void env_lookup(const McScene& sc, float dx, float dy, float dz, float* rg
 // get_lights (:490-507): the ray starts 1e-5 along the direction; miss <=> no hit closer than 10
 DM_HD bool occluded(const McScene& sc, const float* p, float dx, float dy, float dz) {
     const float eps = 1e-5f;
+    if (sc.grid) return dm_grid_any_hit(*sc.grid, sc.grid_tb, p[0] + dx * eps, p[1] + dy * eps, p[2] + dz * eps, dx, dy, dz, 10.0f);
     if (sc.nodes4) return dm_bvh4_any_hit(sc.nodes4, sc.tris, p[0] + dx * eps, p[1] + dy * eps, p[2] + dz * eps, dx, dy, dz, 10.0f);
     return dm_bvh_any_hit(sc.nodes, sc.tris, p[0] + dx * eps, p[1] + dy * eps, p[2] + dz * eps, dx, dy, dz, 10.0f);
 }
@@ -194,30 +197,21 @@ template <class S> DM_HD void acc_clear(S a, McAcc<S>& acc) {
     for (int c = 0; c < 3; ++c) { acc.A[c] = cst(a, 0.f); acc.B[c] = cst(a, 0.f); acc.Ld[c] = 0.f; acc.Ls[c] = 0.f; }
 }
 
-// sample s of the pixel: s < nd = cosine-weighted direction s around the normal (:554-573, pdf NoL/pi * nd/sn), else GGX
-// direction s - nd around the mirror direction (:575-596, pdf D NoH / (4 VoH + 1e-5) * ns/sn).
-// TRACE: shoot the occlusion ray and return the result in `hit`; else take `hit` as given (recorded by the forward).
-template <class S, bool TRACE>
-DM_HD void sample_eval(const McCfg& cfg, const McScene& sc, const McFrame& fr, S a, int s, bool& hit, McAcc<S>& acc) {
-    const int nd = cfg.n_diffuse, ns = cfg.n_specular, sn = nd + ns;
+// direction of sample s of the pixel: s < nd = cosine-weighted direction s around the normal (:554-573), else GGX direction
+// s - nd around the mirror direction (:575-596; it depends on alpha, hence S)
+template <class S>
+DM_HD V3<S> sample_dir(const McCfg& cfg, const McScene& sc, const McFrame& fr, S a, int s) {
+    const int nd = cfg.n_diffuse;
+    V3<S> d;
     if (s < nd) {
         float az = sc.samples_d[2 * s] * kPi * 2.f;
         const float el = sc.samples_d[2 * s + 1];
         if (fr.rand_d >= 0.f) az = fmodf(az + fr.rand_d * kPi * 2.f, 2.f * kPi);
         const float el_sqrt = sqrtf(el + 1e-7f), cz = sqrtf(1.f - el + 1e-7f);
         const float cx = el_sqrt * cosf(az), cy = el_sqrt * sinf(az);
-        float d[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) d[c] = cx * fr.xd[c] + cy * fr.yd[c] + cz * fr.n[c];
-        if (TRACE) hit = occluded(sc, fr.p, d[0], d[1], d[2]);
-        float L[3] = {0.f, 0.f, 0.f};
-        if (!hit) env_lookup(sc, d[0], d[1], d[2], L);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) acc.Ld[c] += L[c];
-        const float NoL_d = sat_(d[0] * fr.n[0] + d[1] * fr.n[1] + d[2] * fr.n[2]);
-        V3<S> ds;
-        ds.x = cst(a, d[0]); ds.y = cst(a, d[1]); ds.z = cst(a, d[2]);
-        add_sample<S>(cfg, fr.n, fr.v, fr.NoV, a, ds, half_vector(ds, fr.v), cst(a, NoL_d / kPi * ((float)nd / (float)sn)), L, acc);
+        d.x = cst(a, cx * fr.xd[0] + cy * fr.yd[0] + cz * fr.n[0]);
+        d.y = cst(a, cx * fr.xd[1] + cy * fr.yd[1] + cz * fr.n[1]);
+        d.z = cst(a, cx * fr.xd[2] + cy * fr.yd[2] + cz * fr.n[2]);
     } else {
         const int j = s - nd;
         float phi = kPi * 2.f * sc.samples_s[2 * j];
@@ -226,13 +220,29 @@ DM_HD void sample_eval(const McCfg& cfg, const McScene& sc, const McFrame& fr, S
         S cos_t = sqrt_((1.0f - el + 1e-6f) / (1.0f + (a * a - 1.0f) * el + 1e-6f) + 1e-6f);
         S sin_t = sqrt_(1.0f - cos_t * cos_t + 1e-6f);
         const float cph = cosf(phi), sph = sinf(phi);
-        V3<S> d;
         d.x = (cph * sin_t) * fr.xs[0] + (sph * sin_t) * fr.ys[0] + cos_t * fr.r[0];
         d.y = (cph * sin_t) * fr.xs[1] + (sph * sin_t) * fr.ys[1] + cos_t * fr.r[1];
         d.z = (cph * sin_t) * fr.xs[2] + (sph * sin_t) * fr.ys[2] + cos_t * fr.r[2];
-        if (TRACE) hit = occluded(sc, fr.p, val(d.x), val(d.y), val(d.z));
-        float L[3] = {0.f, 0.f, 0.f};
-        if (!hit) env_lookup(sc, val(d.x), val(d.y), val(d.z), L);
+    }
+    return d;
+}
+
+// sample s of the pixel: pdf NoL/pi * nd/sn (cosine-weighted) or D NoH / (4 VoH + 1e-5) * ns/sn (GGX).
+// TRACE: shoot the occlusion ray and return the result in `hit`; else take `hit` as given (recorded by the forward, or found
+// by the wave-cooperative traversal of the one-wave-per-pixel kernel).
+template <class S, bool TRACE>
+DM_HD void sample_eval(const McCfg& cfg, const McScene& sc, const McFrame& fr, S a, int s, bool& hit, McAcc<S>& acc) {
+    const int nd = cfg.n_diffuse, ns = cfg.n_specular, sn = nd + ns;
+    const V3<S> d = sample_dir<S>(cfg, sc, fr, a, s);
+    if (TRACE) hit = occluded(sc, fr.p, val(d.x), val(d.y), val(d.z));
+    float L[3] = {0.f, 0.f, 0.f};
+    if (!hit) env_lookup(sc, val(d.x), val(d.y), val(d.z), L);
+    if (s < nd) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc.Ld[c] += L[c];
+        const float NoL_d = sat_(val(d.x) * fr.n[0] + val(d.y) * fr.n[1] + val(d.z) * fr.n[2]);
+        add_sample<S>(cfg, fr.n, fr.v, fr.NoV, a, d, half_vector(d, fr.v), cst(a, NoL_d / kPi * ((float)nd / (float)sn)), L, acc);
+    } else {
 #pragma unroll
         for (int c = 0; c < 3; ++c) acc.Ls[c] += L[c];
         const V3<S> h = half_vector(d, fr.v);

@@ -658,7 +658,7 @@ class MeshBvh:
     """BVH of a fixed mesh (dm_bvh_build, host) with device copies of the node / triangle arrays; the counterpart of
     `RayTracer(vertices, triangles)` (raytracing_renderer.py:20-31)."""
 
-    def __init__(self, v_pos, tri, device=None):
+    def __init__(self, v_pos, tri, device=None, grid_res=0):
         v = v_pos.detach().float().cpu().contiguous()
         t = tri.detach().to(torch.int32).cpu().contiguous()
         n_tri = t.shape[0]
@@ -677,9 +677,56 @@ class MeshBvh:
               "dm_bvh_collapse4")
         self.n_nodes4 = int(n4.value)
         self.nodes4_host = nodes4[:self.n_nodes4].contiguous()
-        self.nodes = self.tris = None
+        # occupancy grid of the same triangles (csrc/grid_core.h): what the shading kernels walk by default
+        self.grid_host = _lib.GridStruct()
+        blob, words = ctypes.c_void_p(), ctypes.c_longlong(0)
+        check(_lib.lib().dm_grid_build(tris.data_ptr(), n_tri, int(grid_res), ctypes.byref(self.grid_host), ctypes.byref(blob),
+                                       ctypes.byref(words)), "dm_grid_build")
+        try:
+            buf = (ctypes.c_uint32 * words.value).from_address(blob.value)
+            self.grid_blob_host = torch.from_numpy(np.frombuffer(buf, dtype=np.int32).copy())
+        finally:
+            _lib.lib().dm_host_free(blob)
+        self.nodes = self.tris = self.grid = self.grid_blob = None
         if device is not None:
             self.nodes, self.tris = self.nodes_host.to(device), self.tris_host.to(device)
+            self.grid_blob = self.grid_blob_host.to(device)
+            self.grid = self.grid_struct(self.grid_blob)
+
+    def _grid_offsets(self):
+        """word offsets of the five 16-byte-padded sections of the blob (dm_grid_build)."""
+        h = self.grid_host
+        pad4 = lambda w: (w + 3) // 4 * 4
+        o_sb = pad4(h.n_words)
+        o_off = o_sb + pad4((h.n_words + 63) // 64)
+        o_dist = o_off + pad4((h.n_words + 1) // 2)
+        n_blocks = ((h.dim[0] + 1) // 2) * ((h.dim[1] + 1) // 2) * ((h.dim[2] + 1) // 2)
+        o_occ = o_dist + pad4((n_blocks + 7) // 8)
+        o_tri = o_occ + pad4(h.n_occ + 1)
+        return 0, o_sb, o_off, o_dist, o_occ, o_tri
+
+    def grid_struct(self, blob):
+        """dm_grid whose pointers address the sections of `blob` (bits | sbase | off16 | dist4 | occ_start | cell_tris)."""
+        g = _lib.GridStruct()
+        ctypes.memmove(ctypes.byref(g), ctypes.byref(self.grid_host), ctypes.sizeof(g))
+        base = blob.data_ptr()
+        g.bits, g.sbase, g.off16, g.dist4, g.occ_start, g.cell_tris = [base + 4 * o for o in self._grid_offsets()]
+        return g
+
+    def grid_sections(self):
+        """(bits, rank of every word's first cell, occ_start, triangle id of every record) as host int64 tensors (tests)."""
+        h, b = self.grid_host, self.grid_blob_host
+        o = self._grid_offsets()
+        u = lambda t: t.to(torch.int64) & 0xffffffff
+        bits, sbase = u(b[o[0]:o[0] + h.n_words]), u(b[o[1]:o[1] + (h.n_words + 63) // 64])
+        off16 = b[o[2]:o[3]].view(torch.int16)[:h.n_words].to(torch.int64) & 0xffff
+        rank = sbase.repeat_interleave(64)[:h.n_words] + off16
+        d8 = b[o[3]:o[4]].view(torch.uint8).to(torch.int64)
+        n_blocks = ((h.dim[0] + 1) // 2) * ((h.dim[1] + 1) // 2) * ((h.dim[2] + 1) // 2)
+        dist = torch.stack([d8 & 15, d8 >> 4], -1).reshape(-1)[:n_blocks]
+        occ = u(b[o[4]:o[4] + h.n_occ + 1])
+        ids = b[o[5]:].reshape(-1, 12)[:, 3].to(torch.int64)
+        return bits, rank, occ, ids, dist
 
     def any_hit(self, origins, dirs, t_max=10.0):
         """hit mask [n] (bool) of rays origins + t*dirs, 0 < t < t_max (miss <=> the reference's depth >= 10)."""
@@ -690,6 +737,17 @@ class MeshBvh:
         hit = torch.empty(o.shape[0], dtype=torch.uint8, device=o.device)
         check(_lib.lib().dm_bvh_any_hit_rays(self.nodes.data_ptr(), self.tris.data_ptr(), o.data_ptr(), d.data_ptr(),
                                              o.shape[0], float(t_max), hit.data_ptr(), _stream()), "dm_bvh_any_hit_rays")
+        return hit.bool().reshape(origins.shape[:-1])
+
+    def any_hit_grid(self, origins, dirs, t_max=10.0):
+        """the same query through the occupancy grid (dm_grid_any_hit_rays)."""
+        _need_cuda(origins, dirs)
+        if self.grid is None:
+            raise _lib.DmError("MeshBvh was built without a device")
+        o, d = _f32c(origins.reshape(-1, 3)), _f32c(dirs.reshape(-1, 3))
+        hit = torch.empty(o.shape[0], dtype=torch.uint8, device=o.device)
+        check(_lib.lib().dm_grid_any_hit_rays(ctypes.byref(self.grid), o.data_ptr(), d.data_ptr(), o.shape[0], float(t_max),
+                                              hit.data_ptr(), _stream()), "dm_grid_any_hit_rays")
         return hit.bool().reshape(origins.shape[:-1])
 
 
@@ -723,11 +781,17 @@ class McScene:
         # 4-wide nodes (child boxes in the parent: a quarter of the dependent fetches per ray, same hits by construction) are
         # the default since they were timed (profiles/r02_mc_probe.json); DREAMMAT_BVH=2 selects the binary tree
         self.nodes4 = bvh.nodes4_host.to(dev) if os.environ.get("DREAMMAT_BVH", "4") == "4" else None
+        # occlusion queries: the occupancy grid (default since round 3) or, DREAMMAT_MC_TRACER=bvh, the tree
+        self.grid = None
+        if os.environ.get("DREAMMAT_MC_TRACER", "grid") == "grid":
+            self.grid_blob = bvh.grid_blob_host.to(dev)
+            self.grid = bvh.grid_struct(self.grid_blob)
         self.struct = _lib.McSceneStruct(bvh.nodes.data_ptr(), bvh.tris.data_ptr(), self.lights.data_ptr(),
                                          self.lights.shape[0], self.lights.shape[1], self.lights.shape[2],
                                          self.samples_d.data_ptr(), self.samples_s.data_ptr(), self.n_diffuse,
                                          self.n_specular, 1 if geometry_type == "ggx_smith" else 0,
-                                         self.nodes4.data_ptr() if self.nodes4 is not None else None)
+                                         self.nodes4.data_ptr() if self.nodes4 is not None else None,
+                                         ctypes.addressof(self.grid) if self.grid is not None else None)
 
 
 class _McShade(torch.autograd.Function):

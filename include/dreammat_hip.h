@@ -179,6 +179,27 @@ int dm_bvh_build(const float* v_pos_host, int32_t n_vert, const int32_t* tri_hos
 /* Optional 4-wide form of the same tree (the four child boxes stored in the parent, 128 B nodes: a quarter to a third of
  * the dependent fetches per ray).  HOST function; nodes4_out holds n_nodes2 entries, *n_nodes4_out = entries used. */
 int dm_bvh_collapse4(const void* nodes2_host, int32_t n_nodes2, void* nodes4_out, int32_t* n_nodes4_out);
+/* Uniform occupancy grid over the same triangles (csrc/grid_core.h): the occlusion query as a 3-D DDA whose empty-space
+ * steps touch no memory (the kernels keep the bits in LDS).  HOST function.  tris12 = dm_bvh_build's tris_out; res = cells
+ * along the longest axis of the mesh box (<= 0: chosen from n_tri, at most 96).  *blob_out is malloc'd (dm_host_free) and
+ * holds six sections, each padded to 16 bytes: bits[n_words] u32 | sbase[ceil(n_words / 64)] u32 | off16[n_words] u16 |
+ * dist4[a nibble per 2x2x2 block of cells: distance in blocks to the nearest occupied one] | occ_start[n_occ + 1] u32 | cell_tris[n_entries][12] f32 (the triangles of every occupied cell inline; slot 3 = the triangle's
+ * number in leaf order as int bits).  `grid` receives the scalars, its pointers are left NULL for the caller to fill with
+ * the device addresses of the sections. */
+typedef struct dm_grid {
+    float gmin[3]; float cell, inv_cell;
+    int32_t dim[3];
+    int32_t n_words, n_occ;
+    long long n_entries;
+    const uint32_t* bits; const uint32_t* sbase; const uint16_t* off16; const uint8_t* dist4; const uint32_t* occ_start;
+    const float* cell_tris;
+} dm_grid;
+int dm_grid_build(const float* tris12, int32_t n_tri, int32_t res, dm_grid* grid, uint32_t** blob_out, int64_t* blob_words);
+void dm_host_free(void* p);
+/* dm_bvh_any_hit_rays through the grid (same answers: a boolean over the same triangle test); grid = host struct with
+ * device pointers. */
+int dm_grid_any_hit_rays(const dm_grid* grid_host, const float* origins, const float* dirs, long long n, float t_max,
+                         unsigned char* hit, dm_stream_t stream);
 /* `RayTracer.trace` as DreamMatMaterial.get_lights consumes it (dreammat_material.py:490-507,
  * raytracing_renderer.py:318-324): hit[i] = 1 iff ray origins[i] + t*dirs[i] meets the mesh for some 0 < t < t_max
  * (double-sided).  Device pointers; origins, dirs [n,3] fp32. */
@@ -200,6 +221,8 @@ typedef struct dm_mc_scene {
     int n_diffuse, n_specular;
     int geometry_ggx_smith;                             /* cfg.geometry_type: 0 = 'schlick', 1 = 'ggx_smith' */
     const void* bvh_nodes4;                             /* optional: device copy of dm_bvh_collapse4's output, else NULL */
+    const dm_grid* grid;                                /* optional: occupancy grid with device pointers (then the occlusion
+                                                         * queries walk the grid instead of the tree), else NULL */
 } dm_mc_scene;
 int dm_mc_hit_words(int n_diffuse, int n_specular);
 int dm_mc_shade_fwd(const dm_mc_scene* scene_host, const dm_mat_cfg* mat_host, const float* pos, long long pos_rs,

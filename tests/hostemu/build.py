@@ -11,7 +11,7 @@ LIB = os.path.join(OUT, "libdm_hostemu.so")
 def build(force=False):
     src = os.path.join(HERE, "hostemu.hip")
     deps = [src] + [os.path.join(HERE, "..", "..", "dreammat_amd", "csrc", h)
-                    for h in ("raster_core.h", "shade_core.h", "bvh_core.h", "mc_shade_core.h", "dm_common.h")]
+                    for h in ("raster_core.h", "shade_core.h", "bvh_core.h", "grid_core.h", "mc_shade_core.h", "dm_common.h")]
     os.makedirs(OUT, exist_ok=True)
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(d) for d in deps):
         return LIB

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "../../dreammat_amd/csrc/bvh_core.h"
+#include "../../dreammat_amd/csrc/grid_core.h"
 #include "../../dreammat_amd/csrc/mc_shade_core.h"
 #include "../../dreammat_amd/csrc/raster_core.h"
 #include "../../dreammat_amd/csrc/shade_core.h"
@@ -171,7 +172,7 @@ int emu_mc_shade(const float* cfg4, int nd, int ns, int ggx_smith, const void* n
                  const float* dcolor, float* dfeat, int lanes) {
     using namespace dm::mc;
     McCfg cfg = {cfg4[0], cfg4[1], cfg4[2], cfg4[3], nd, ns, ggx_smith};
-    McScene sc = {(const DmBvhNode*)nodes, tris, (const DmBvhNode4*)nodes4, light, lh, lw, samples_d, samples_s};
+    McScene sc = {(const DmBvhNode*)nodes, tris, (const DmBvhNode4*)nodes4, nullptr, {nullptr, nullptr, nullptr, nullptr}, light, lh, lw, samples_d, samples_s};
     const int words = kMaxSamples / 32;
     if (nd + ns > kMaxSamples || (lanes != 1 && lanes != 64)) return -1;
     const int used_words = (nd + ns + 31) / 32;
@@ -240,6 +241,42 @@ int emu_bvh4_any_hit(const void* nodes4, const float* tris, const float* org, co
     for (long long i = 0; i < n; ++i)
         hit[i] = dm_bvh4_any_hit((const DmBvhNode4*)nodes4, tris, org[3 * i], org[3 * i + 1], org[3 * i + 2], dir[3 * i],
                                  dir[3 * i + 1], dir[3 * i + 2], t_max) ? 1 : 0;
+    return 0;
+}
+
+// the occupancy-grid traversal (grid_core.h): grid = a dm_grid whose pointers address host memory.  stats (optional, [n][3]):
+// walk moves (steps + leaps) / occupied cells / triangles tested per ray, from a replay with dm_grid_any_hit's control flow
+int emu_grid_any_hit(const void* grid_v, const float* org, const float* dir, long long n, float t_max, unsigned char* hit, int* stats) {
+    const DmGrid g = *(const DmGrid*)grid_v;
+    const DmGridTables tb = {g.bits, g.sbase, g.off16, g.dist4};
+    for (long long i = 0; i < n; ++i)
+        hit[i] = dm_grid_any_hit(g, tb, org[3 * i], org[3 * i + 1], org[3 * i + 2], dir[3 * i], dir[3 * i + 1], dir[3 * i + 2], t_max) ? 1 : 0;
+    if (!stats) return 0;
+    for (long long i = 0; i < n; ++i) {
+        int moves = 0, occ = 0, tests = 0;
+        const float ox = org[3 * i], oy = org[3 * i + 1], oz = org[3 * i + 2], dx = dir[3 * i], dy = dir[3 * i + 1], dz = dir[3 * i + 2];
+        DmDda s;
+        bool alive = dm_dda_init(g, s, ox, oy, oz, dx, dy, dz, t_max);
+        while (alive) {
+            ++moves;
+            const int c = dm_dda_cell(g, s);
+            const uint32_t w = tb.bits[c >> 5];
+            if ((w >> (c & 31)) & 1u) {
+                ++occ;
+                const uint32_t r = dm_grid_rank(tb, c, w);
+                bool h = false;
+                for (uint32_t e = g.occ_start[r]; e < g.occ_start[r + 1] && !h; ++e) {
+                    ++tests;
+                    h = dm_bvh_ray_triangle(g.cell_tris + 12 * (size_t)e, ox, oy, oz, dx, dy, dz, t_max);
+                }
+                if (h) break;
+                alive = dm_dda_step(g, s);
+            } else {
+                alive = dm_dda_advance(g, tb, s, ox, oy, oz, dx, dy, dz);
+            }
+        }
+        stats[3 * i] = moves; stats[3 * i + 1] = occ; stats[3 * i + 2] = tests;
+    }
     return 0;
 }
 

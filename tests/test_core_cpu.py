@@ -203,7 +203,7 @@ def test_c_abi_exports_every_declared_symbol():
     """The library loads on a GPU-less box and exports exactly what include/dreammat_hip.h declares."""
     import os, re
     L = _lib.lib()
-    assert L.dm_abi_version() == 3
+    assert L.dm_abi_version() == 4
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "dreammat_hip.h")).read()
     declared = set(re.findall(r"\b(dm_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
@@ -306,6 +306,71 @@ def test_bvh_build_and_traversal_core_vs_brute_force(hostemu):
                                  ctypes.c_float(10.0), ctypes.c_void_p(hit4.data_ptr()))
         assert torch.equal(hit4, hit) and 1 <= bvh.n_nodes4 <= bvh.n_nodes
         assert 0.2 < ref.float().mean() < 0.95
+        # the occupancy grid (dm_grid_build + csrc/grid_core.h): a conservative voxelisation walked by a DDA -- the same
+        # boolean over the same triangle test, so the answers must be IDENTICAL to the tree's
+        for res in (0, 7, 33):
+            b2 = hipops.MeshBvh(m.v_pos, m.t_pos_idx, grid_res=res)
+            g = b2.grid_struct(b2.grid_blob_host)
+            bits, rank, occ, ids, dist = b2.grid_sections()
+            dim = [int(x) for x in g.dim]
+            n_cells = dim[0] * dim[1] * dim[2]
+            assert g.n_words == (n_cells + 31) // 32 and max(dim) <= 96 and g.n_occ == len(occ) - 1 and int(occ[-1]) == g.n_entries == len(ids)
+            assert sorted(set(ids.tolist())) == list(range(n_tri))                    # every triangle is listed somewhere
+            pop = torch.tensor([bin(int(w)).count("1") for w in bits.tolist()])
+            assert int(pop.sum()) == g.n_occ and torch.equal(rank, torch.cumsum(pop, 0) - pop)
+            # block distance field: 0 exactly on the blocks that hold an occupied cell, neighbours differ by at most 1
+            bd = [(x + 1) // 2 for x in dim]
+            cells = torch.zeros(n_cells, dtype=torch.bool)
+            for wi, wv in enumerate(bits.tolist()):
+                for bb in range(32):
+                    if (wv >> bb) & 1:
+                        cells[wi * 32 + bb] = True
+            cz = torch.zeros(2 * bd[2], 2 * bd[1], 2 * bd[0], dtype=torch.bool)
+            cz[:dim[2], :dim[1], :dim[0]] = cells.reshape(dim[2], dim[1], dim[0])
+            blk = cz.reshape(bd[2], 2, bd[1], 2, bd[0], 2).any(5).any(3).any(1)
+            D = dist.reshape(bd[2], bd[1], bd[0])
+            assert torch.equal(D == 0, blk) and int(D.max()) <= 15
+            for ax in range(3):
+                assert int((D.narrow(ax, 1, bd[2 - ax] - 1) - D.narrow(ax, 0, bd[2 - ax] - 1)).abs().max()) <= 1
+            # every vertex lies in a cell that lists its triangle
+            cell = ((tv.reshape(-1, 3) - torch.tensor(list(g.gmin))) * g.inv_cell).floor().long()
+            assert (cell >= 0).all() and (cell < torch.tensor(dim)).all()
+            hitg = torch.zeros(o.shape[0], dtype=torch.uint8)
+            stats = torch.zeros(o.shape[0], 3, dtype=torch.int32)
+            hostemu.emu_grid_any_hit(ctypes.byref(g), ctypes.c_void_p(o.data_ptr()),
+                                     ctypes.c_void_p(d.data_ptr()), ctypes.c_longlong(o.shape[0]), ctypes.c_float(10.0),
+                                     ctypes.c_void_p(hitg.data_ptr()), ctypes.c_void_p(stats.data_ptr()))
+            assert torch.equal(hitg, hit), (res, int((hitg != hit).sum()))
+            assert int(stats[:, 0].max()) <= 3 * 96 and (res != 0 or float(stats[:1500, 2].float().mean()) < 40)
+
+
+def test_grid_voxelisation_of_large_and_degenerate_triangles(hostemu):
+    """dm_grid_build on the shapes a mesh-sized heuristic gets wrong: the 2-triangle quad of BASELINE configs[0] (triangles
+    far larger than a cell, flat in one axis) and a sliver; rays through it against the brute-force test."""
+    import ctypes
+
+    from dreammat_amd import hipops
+    from oracle import mc_shading as omc
+    v = torch.tensor([[-1.0, -1.0, 0.0], [1.0, -1.0, 0.0], [1.0, 1.0, 0.0], [-1.0, 1.0, 0.0], [0.0, 0.0, 0.5], [1e-4, 0.0, 0.5], [0.0, 2.0, 0.7]])
+    f = torch.tensor([[0, 1, 2], [0, 2, 3], [4, 5, 6]], dtype=torch.int32)
+    torch.manual_seed(1)
+    o = torch.cat([torch.randn(3000, 3) * 1.5, torch.tensor([[0.3, 0.2, 1.0], [0.0, 0.0, -1.0]])]).contiguous()
+    tgt = torch.cat([torch.rand(3000, 2) * 2.6 - 1.3, torch.rand(3000, 1) * 0.6], -1)          # towards the quad and the sliver
+    d = torch.cat([torch.nn.functional.normalize(tgt - o[:3000], dim=-1), torch.tensor([[0.0, 0.0, -1.0], [0.0, 0.0, 1.0]])]).contiguous()
+    ref = omc.trace_any_hit(v, f, o, d)
+    for res in (0, 16, 96):
+        b = hipops.MeshBvh(v, f, grid_res=res)
+        g = b.grid_struct(b.grid_blob_host)
+        hit = torch.zeros(o.shape[0], dtype=torch.uint8)
+        hostemu.emu_grid_any_hit(ctypes.byref(g), ctypes.c_void_p(o.data_ptr()),
+                                 ctypes.c_void_p(d.data_ptr()), ctypes.c_longlong(o.shape[0]), ctypes.c_float(10.0),
+                                 ctypes.c_void_p(hit.data_ptr()), None)
+        hb = torch.zeros(o.shape[0], dtype=torch.uint8)
+        hostemu.emu_bvh_any_hit(ctypes.c_void_p(b.nodes_host.data_ptr()), ctypes.c_void_p(b.tris_host.data_ptr()),
+                                ctypes.c_void_p(o.data_ptr()), ctypes.c_void_p(d.data_ptr()), ctypes.c_longlong(o.shape[0]),
+                                ctypes.c_float(10.0), ctypes.c_void_p(hb.data_ptr()))
+        assert torch.equal(hit, hb), (res, int((hit != hb).sum()))
+        assert int((hit.bool() != ref).sum()) <= 2 and 0.1 < ref.float().mean() < 0.9
 
 
 def test_rgb18e8_texels_and_fg_pair_table(hostemu, env_pair):

@@ -39,6 +39,15 @@ def test_bvh_any_hit_kernel_vs_brute_force(dev):
     hit = bvh.any_hit(o.to(dev), d.to(dev)).cpu()
     ref = omc.trace_any_hit(m.v_pos.float(), m.t_pos_idx, o, d)
     assert int((hit != ref).sum()) <= 4
+    # the occupancy grid (dm_grid_build + dm_grid_any_hit_rays): the same boolean over the same triangle test => identical
+    for res in (0, 9, 40):
+        b2 = hipops.MeshBvh(m.v_pos, m.t_pos_idx, dev, grid_res=res)
+        assert torch.equal(b2.any_hit_grid(o.to(dev), d.to(dev)).cpu(), hit), res
+    # rays that start outside the box, miss it, or run along an axis
+    o2 = torch.tensor([[3.0, 0.0, 0.0], [3.0, 3.0, 3.0], [0.0, 0.0, -4.0], [0.0, 5.0, 0.0], [0.0, 0.0, 0.0]])
+    d2 = torch.tensor([[-1.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
+    assert torch.equal(bvh.any_hit_grid(o2.to(dev), d2.to(dev)).cpu(), bvh.any_hit(o2.to(dev), d2.to(dev)).cpu())
+    assert bvh.any_hit(o2.to(dev), d2.to(dev)).cpu().tolist() == [True, False, True, False, True]
 
 
 @pytest.mark.parametrize("variant", ["schlick", "ggx_smith"])
@@ -90,12 +99,13 @@ def test_material_plugin_raytracing_branch_runs(dev):
     assert torch.isfinite(f.grad).all() and f.grad.abs().sum() > 0
 
 
-@pytest.mark.parametrize("bvh_width", ["2", "4"])
+@pytest.mark.parametrize("tracer", ["bvh2", "bvh4", "grid"])
 @pytest.mark.parametrize("variant", ["schlick", "ggx_smith"])
-def test_mc_wave_kernel_matches_the_serial_kernel(variant, bvh_width, monkeypatch):
+def test_mc_wave_kernel_matches_the_serial_kernel(variant, tracer, monkeypatch):
     """the one-wave-per-pixel Monte-Carlo kernel (the default; samples over the 64 lanes, ballot hit
-    bits, butterfly reduction) against the validated one-thread-per-pixel kernel; its decomposition is CPU-checked in
-    tests/test_golden_cpu.py."""
+    bits, butterfly reduction) against the validated one-thread-per-pixel kernel on the binary tree, with each way of
+    answering the occlusion queries: binary / 4-wide BVH walked per lane, and (the default) the occupancy grid walked by the
+    whole wave together (grid_trace_wave).  The decomposition is CPU-checked in tests/test_golden_cpu.py."""
     if not torch.cuda.is_available():
         pytest.skip("needs the MI355X")
     import numpy as np
@@ -105,10 +115,13 @@ def test_mc_wave_kernel_matches_the_serial_kernel(variant, bvh_width, monkeypatc
          for k, v in np.load(os.path.join(os.path.dirname(__file__), "golden", "mc_shading.npz")).items()}
     bvh = hipops.MeshBvh(g["v_pos"], g["tri"], dev)
     monkeypatch.setenv("DREAMMAT_BVH", "2")                # reference: the validated serial kernel on the binary tree
+    monkeypatch.setenv("DREAMMAT_MC_TRACER", "bvh")
     scene_ref = hipops.McScene(bvh, [g["light"]], g[f"{variant}_dsamp"].shape[0], g[f"{variant}_ssamp"].shape[0], variant)
-    monkeypatch.setenv("DREAMMAT_BVH", bvh_width)          # "4": trace through the 4-wide collapse of the same tree
+    assert scene_ref.grid is None and scene_ref.nodes4 is None
+    monkeypatch.setenv("DREAMMAT_BVH", "2" if tracer == "bvh2" else "4")
+    monkeypatch.setenv("DREAMMAT_MC_TRACER", "grid" if tracer == "grid" else "bvh")
     scene_new = hipops.McScene(bvh, [g["light"]], g[f"{variant}_dsamp"].shape[0], g[f"{variant}_ssamp"].shape[0], variant)
-    assert (scene_new.nodes4 is not None) == (bvh_width == "4")
+    assert (scene_new.grid is not None) == (tracer == "grid") and (scene_new.nodes4 is not None) == (tracer != "bvh2")
     mat = _lib.MatCfgStruct(0.0, 0.9, 0.01, 0.9)
     N = g["pts"].shape[0]
     rd, rs = g[f"{variant}_rand_d"].to(dev).contiguous(), g[f"{variant}_rand_s"].to(dev).contiguous()

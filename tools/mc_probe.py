@@ -24,10 +24,18 @@ nd = torch.full((1,), N, dtype=torch.int32, device=dev)
 rd, rs = torch.rand(N, device=dev), torch.rand(N, device=dev)
 lights = [torch.rand(512, 1024, 3) for _ in range(5)]
 results = []
-for kernel in ("serial", "wave"):
-    for width in ("2", "4"):
-        os.environ["DREAMMAT_BVH"] = width
+# (kernel, tracer, BVH width / grid resolution): the round-2 best (wave x 4-wide tree) next to the occupancy grid
+cases = [("wave", "bvh", "4")] + [("wave", "grid", r) for r in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "64", "96"])]
+if "--all" in sys.argv:
+    cases = [("serial", "bvh", "2"), ("serial", "bvh", "4"), ("wave", "bvh", "2")] + cases
+ref_color = None
+for kernel, tracer, width in cases:
+    if True:
+        os.environ["DREAMMAT_BVH"] = width if tracer == "bvh" else "4"
         os.environ["DREAMMAT_MC_KERNEL"] = kernel
+        os.environ["DREAMMAT_MC_TRACER"] = tracer
+        if tracer == "grid":
+            bvh = hipops.MeshBvh(m.v_pos, m.t_pos_idx, dev, grid_res=int(width))
         scene = hipops.McScene(bvh, lights, 200, 128, "schlick")
 
         def run():
@@ -36,8 +44,19 @@ for kernel in ("serial", "wave"):
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         e[0].record(); c = run(); e[1].record(); c.sum().backward(); e[2].record(); torch.cuda.synchronize()
         tf, tb = e[0].elapsed_time(e[1]), e[1].elapsed_time(e[2])
-        res = {"kernel": kernel, "bvh_width": int(width), "N": N, "samples": 328, "tris": int(m.t_pos_idx.shape[0]),
+        if ref_color is None:
+            ref_color = c.detach().clone()
+        n_diff = int(((c - ref_color).abs().max(-1).values > 1e-6).sum())
+        res = {"kernel": kernel, "tracer": tracer, "bvh_width_or_grid_res": int(width), "max_abs_diff_vs_first": float((c - ref_color).abs().max()), "pixels_that_differ": n_diff, "N": N, "samples": 328, "tris": int(m.t_pos_idx.shape[0]),
                "fwd_ms": tf, "bwd_ms": tb, "fwd_Grays_per_s": N * 328 / tf / 1e6, "color_mean": float(c.mean())}
+        if hasattr(_lib.lib(), "dm_mc_debug_stats") and "--stats" in sys.argv:
+            import ctypes
+            st = (ctypes.c_ulonglong * 8)()
+            _lib.lib().dm_mc_debug_stats(st)            # clear what the warm-up and the timed run left
+            run(); torch.cuda.synchronize()
+            _lib.lib().dm_mc_debug_stats(st)
+            q = list(st)
+            res["stats"] = {"wave_rays": q[0], "rounds": q[1], "cell_walk_trips": q[2], "cell_walk_lanes": q[3], "pair_batches": q[4], "pairs": q[5]}
         print(json.dumps(res), flush=True)
         results.append(res)
 os.makedirs("gpurun_out", exist_ok=True)
