@@ -17,6 +17,11 @@ if [ $rc -ne 0 ]; then echo "GPU TESTS FAILED (rc=$rc): skipping the measurement
 timeout 500 python bench.py > gpurun_out/final_bench.log 2>&1 < /dev/null
 grep '^{"metric' gpurun_out/final_bench.log > gpurun_out/final_bench_line.json
 cut -c1-200 gpurun_out/final_bench_line.json
+# the reference's default material branch (Monte-Carlo shading with occlusion rays) on the same scene, and the kernel alone
+timeout 400 python bench.py --raytracing --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null < /dev/null | grep '^{"metric' > gpurun_out/final_bench_line_raytracing.json
+cut -c1-120 gpurun_out/final_bench_line_raytracing.json
+timeout 200 python tools/mc_probe.py 100000 0 2>/dev/null | grep '^{' > gpurun_out/final_mc_probe.jsonl
+[ "${FINAL_QUICK:-0}" = 1 ] && { python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1; exit 0; }
 export TMPDIR=/tmp
 for v in 8 1; do
   rm -rf /tmp/prof_final_$v
