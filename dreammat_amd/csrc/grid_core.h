@@ -113,14 +113,11 @@ DM_HD bool dm_dda_step(const DmGrid& g, DmDda& s) {
     return (unsigned)s.ix < (unsigned)g.dim[0] && (unsigned)s.iy < (unsigned)g.dim[1] && (unsigned)s.iz < (unsigned)g.dim[2];
 }
 
-// the move from an EMPTY cell: a plain step next to the surface, a leap to the exit of the empty cube of blocks around the
-// cell where the distance field allows one (see the layout notes).  false = the ray is gone.
-DM_HD bool dm_dda_advance(const DmGrid& g, const DmGridTables& tb, DmDda& s, float ox, float oy, float oz, float dx, float dy, float dz) {
-    const int bx = s.ix >> 1, by = s.iy >> 1, bz = s.iz >> 1;
-    const int bd0 = (g.dim[0] + 1) >> 1, bd1 = (g.dim[1] + 1) >> 1;
-    const int bi = (bz * bd1 + by) * bd0 + bx;
-    const int D = (tb.dist4[bi >> 1] >> ((bi & 1) * 4)) & 15;
+// the move from an EMPTY cell whose block distance is D: a plain step next to the surface (D < 2), a leap to the exit of the
+// empty cube of blocks around the cell where the distance field allows one (see the layout notes).  false = the ray is gone.
+DM_HD bool dm_dda_advance_d(const DmGrid& g, DmDda& s, int D, float ox, float oy, float oz, float dx, float dy, float dz) {
     if (D < 2) return dm_dda_step(g, s);
+    const int bx = s.ix >> 1, by = s.iy >> 1, bz = s.iz >> 1;
     // faces of the cube of blocks [b - (D - 1), b + (D - 1)] on the sides the ray travels towards
     const float two = 2.0f * g.cell;
     const float px = g.gmin[0] + (float)(dx > 0.f ? bx + D : bx - D + 1) * two;
@@ -134,6 +131,12 @@ DM_HD bool dm_dda_advance(const DmGrid& g, const DmGridTables& tb, DmDda& s, flo
     if (!(t <= s.t1)) return false;                    // out of the box / past t_max before the cube ends
     dm_dda_seek(g, s, ox, oy, oz, dx, dy, dz, t);
     return true;
+}
+
+DM_HD bool dm_dda_advance(const DmGrid& g, const DmGridTables& tb, DmDda& s, float ox, float oy, float oz, float dx, float dy, float dz) {
+    const int bd0 = (g.dim[0] + 1) >> 1, bd1 = (g.dim[1] + 1) >> 1;
+    const int bi = ((s.iz >> 1) * bd1 + (s.iy >> 1)) * bd0 + (s.ix >> 1);
+    return dm_dda_advance_d(g, s, (tb.dist4[bi >> 1] >> ((bi & 1) * 4)) & 15, ox, oy, oz, dx, dy, dz);
 }
 
 DM_HD int dm_dda_cell(const DmGrid& g, const DmDda& s) { return (s.iz * g.dim[1] + s.iy) * g.dim[0] + s.ix; }

@@ -126,8 +126,10 @@ __device__ __forceinline__ void wave_sum_inplace(Dual& v) { v.v = wave_sum(v.v);
 // the lists have their own lengths.  Here a round has three wave-uniform parts:
 //   (1) every live ray walks empty cells (LDS reads + VALU) until it stands on an occupied cell or is gone;
 //   (2) the lanes' triangle lists are laid end to end (prefix sum of the lengths) and the (ray, triangle) pairs are dealt out
-//       64 at a time -- pair k belongs to the lane with the largest prefix <= k (6-step search in LDS), whose ray it reads from
-//       LDS: full lanes whatever the individual list lengths;
+//       64 at a time -- every lane with a list writes its number over its stretch of an owner table in LDS, pair k reads its
+//       owner there and the owner's ray next to it: full lanes whatever the individual list lengths.  (The first version found
+//       the owner by a 6-step search over the prefixes: six DEPENDENT LDS round trips per batch, SQ_WAIT_ANY 45 % of the
+//       wave-cycles -- profiles/r03_pmc_mc.json);
 //   (3) rays that were hit stop, the others step past their cell.
 // development counters (tools/build_variant.sh st mc_shade.hip -DDM_MC_STATS; tools/mc_probe.py --stats): wave-level trips
 #ifdef DM_MC_STATS
@@ -137,11 +139,14 @@ __device__ unsigned long long dm_mc_stats[8];
 #define DM_STAT(i, n) do { } while (0)
 #endif
 
+constexpr unsigned kOwnerWindow = 512;   // pairs per pass of part (2) (a round of the bench scene has ~200)
+
 struct WaveScratch {
     unsigned start[64];           // exclusive prefix of this round's list lengths
     unsigned e0[64];              // first record of each lane's list
     float ray[64][6];             // origin, direction
     unsigned hit[64];
+    unsigned char owner[kOwnerWindow];   // pair k of the current window -> lane that owns it
 };
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -150,7 +155,14 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-__device__ __forceinline__ bool grid_trace_wave(const DmGrid& g, const DmGridTables& tb, bool active, float ox, float oy, float oz,
+// the four tables as LDS pointers (32-bit addresses, ds_read): through generic pointers the walk loop read them with flat
+// loads and 64-bit address arithmetic, 119 VALU per cell
+#define DM_LDS __attribute__((address_space(3)))
+struct LdsTables {
+    const DM_LDS uint32_t* bits; const DM_LDS uint32_t* sbase; const DM_LDS uint16_t* off16; const DM_LDS uint8_t* dist4;
+};
+
+__device__ __forceinline__ bool grid_trace_wave(const DmGrid& g, const LdsTables& tb, bool active, float ox, float oy, float oz,
                                                 float dx, float dy, float dz, float t_max, WaveScratch* ws, int lane) {
     DmDda s;
     bool alive = active && dm_dda_init(g, s, ox, oy, oz, dx, dy, dz, t_max);
@@ -159,6 +171,7 @@ __device__ __forceinline__ bool grid_trace_wave(const DmGrid& g, const DmGridTab
     ws->ray[lane][3] = dx; ws->ray[lane][4] = dy; ws->ray[lane][5] = dz;
     ws->hit[lane] = 0u;
     DM_STAT(0, 1);                                       // wave-rays
+    const int bd0 = (g.dim[0] + 1) >> 1, bd1 = (g.dim[1] + 1) >> 1;
     while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
         DM_STAT(1, 1);                                   // rounds
         int c = 0;
@@ -168,15 +181,19 @@ __device__ __forceinline__ bool grid_trace_wave(const DmGrid& g, const DmGridTab
             DM_STAT(2, 1);                               // cell-walk trips
             DM_STAT(3, __builtin_popcountll(__builtin_amdgcn_ballot_w64(alive && !found)));
             if (alive && !found) {
+                // both table reads up front (one wait): the block distance decides how to move on from an empty cell
                 c = dm_dda_cell(g, s);
+                const int bi = ((s.iz >> 1) * bd1 + (s.iy >> 1)) * bd0 + (s.ix >> 1);
                 w = tb.bits[c >> 5];
+                const int D = (tb.dist4[bi >> 1] >> ((bi & 1) * 4)) & 15;
                 if ((w >> (c & 31)) & 1u) found = true;
-                else alive = dm_dda_advance(g, tb, s, ox, oy, oz, dx, dy, dz);
+                else alive = dm_dda_advance_d(g, s, D, ox, oy, oz, dx, dy, dz);
             }
         }
         unsigned e0 = 0, cnt = 0;
         if (found) {
-            const uint32_t r = dm_grid_rank(tb, c, w);
+            const int wi = c >> 5;
+            const uint32_t r = tb.sbase[wi >> 6] + (uint32_t)tb.off16[wi] + (uint32_t)__builtin_popcount(w & ((1u << (c & 31)) - 1u));
             e0 = g.occ_start[r];
             cnt = g.occ_start[r + 1] - e0;
         }
@@ -192,18 +209,22 @@ __device__ __forceinline__ bool grid_trace_wave(const DmGrid& g, const DmGridTab
         ws->e0[lane] = e0;
         wave_lds_sync();
         DM_STAT(5, total);                               // (ray, triangle) pairs
-        for (unsigned base = 0; base < total; base += 64) {
-            DM_STAT(4, 1);                               // pair batches
-            const unsigned k = base + lane;
-            if (k < total) {
-                int lo = 0;
-#pragma unroll
-                for (int st = 32; st > 0; st >>= 1)
-                    if (ws->start[lo + st] <= k) lo += st;
-                const unsigned e = ws->e0[lo] + (k - ws->start[lo]);
-                const float* r6 = ws->ray[lo];
-                if (dm_bvh_ray_triangle(g.cell_tris + 12 * (size_t)e, r6[0], r6[1], r6[2], r6[3], r6[4], r6[5], t_max)) ws->hit[lo] = 1u;
+        const unsigned my0 = incl - cnt, my1 = incl;
+        for (unsigned cbase = 0; cbase < total; cbase += kOwnerWindow) {
+            const unsigned cend = min(total, cbase + kOwnerWindow);
+            for (unsigned k = max(my0, cbase); k < min(my1, cend); ++k) ws->owner[k - cbase] = (unsigned char)lane;
+            wave_lds_sync();
+            for (unsigned base = cbase; base < cend; base += 64) {
+                DM_STAT(4, 1);                           // pair batches
+                const unsigned k = base + lane;
+                if (k < cend) {
+                    const int lo = ws->owner[k - cbase];
+                    const unsigned e = ws->e0[lo] + (k - ws->start[lo]);
+                    const float* r6 = ws->ray[lo];
+                    if (dm_bvh_ray_triangle(g.cell_tris + 12 * (size_t)e, r6[0], r6[1], r6[2], r6[3], r6[4], r6[5], t_max)) ws->hit[lo] = 1u;
+                }
             }
+            if (cend < total) wave_lds_sync();           // (the next window rewrites the owner table)
         }
         wave_lds_sync();
         if (found) {
@@ -232,7 +253,15 @@ __global__ __launch_bounds__(BLOCK) void k_mc_shade_wave(McArgs a) {
         gtb.dist4 = reinterpret_cast<const uint8_t*>(lds_grid + (reinterpret_cast<const uint32_t*>(a.grid.dist4) - a.grid.bits));
     }
     WaveScratch* ws = nullptr;
-    if (COOP) ws = reinterpret_cast<WaveScratch*>(lds_grid + (a.grid_in_lds ? (a.grid_table_words + 3) / 4 * 4 : 0)) + (threadIdx.x >> 6);
+    LdsTables ltb = {};
+    if (COOP) {                                          // (launched only with the tables in LDS)
+        ws = reinterpret_cast<WaveScratch*>(lds_grid + (a.grid_table_words + 3) / 4 * 4) + (threadIdx.x >> 6);
+        const DM_LDS uint32_t* lb = (const DM_LDS uint32_t*)lds_grid;
+        ltb.bits = lb;
+        ltb.sbase = lb + (a.grid.sbase - a.grid.bits);
+        ltb.off16 = (const DM_LDS uint16_t*)(lb + (reinterpret_cast<const uint32_t*>(a.grid.off16) - a.grid.bits));
+        ltb.dist4 = (const DM_LDS uint8_t*)(lb + (reinterpret_cast<const uint32_t*>(a.grid.dist4) - a.grid.bits));
+    }
     const long long N = *a.n_dev;
     const int lane = threadIdx.x & 63;
     const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -266,7 +295,7 @@ __global__ __launch_bounds__(BLOCK) void k_mc_shade_wave(McArgs a) {
                 V3<float> d = {0.f, 0.f, 1.f};
                 if (active) d = sample_dir<float>(a.cfg, sc, fr, px.alpha, s);
                 const float eps = 1e-5f;                   // get_lights (:490-507), as in occluded()
-                hit = grid_trace_wave(a.grid, gtb, active, fr.p[0] + d.x * eps, fr.p[1] + d.y * eps, fr.p[2] + d.z * eps, d.x, d.y, d.z,
+                hit = grid_trace_wave(a.grid, ltb, active, fr.p[0] + d.x * eps, fr.p[1] + d.y * eps, fr.p[2] + d.z * eps, d.x, d.y, d.z,
                                       10.0f, ws, lane);
                 if (active) sample_eval<S, false>(a.cfg, sc, fr, al, s, hit, acc);
             } else if (active) {
@@ -321,10 +350,10 @@ template <bool BWD>
 void launch_mc(const McArgs& a, long long n_max, hipStream_t stream) {
     if (use_wave_kernel()) {
         if constexpr (!BWD) {
-            if (a.use_grid) {
+            if (a.use_grid && a.grid_in_lds) {
                 // one workgroup of 16 waves per CU around ONE LDS copy of the occupancy tables + a scratch block per wave
                 // (8 waves with twice the registers, no spills: 27.5 vs 18.1 ms on the bench scene -- occupancy wins)
-                const size_t lds = (a.grid_in_lds ? (size_t)((a.grid_table_words + 3) / 4 * 4) * 4 : 0) + 16 * sizeof(WaveScratch);
+                const size_t lds = (size_t)((a.grid_table_words + 3) / 4 * 4) * 4 + 16 * sizeof(WaveScratch);
                 static bool attr_set = false;
                 if (!attr_set) {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mc_shade_wave<false, 1024, true>),

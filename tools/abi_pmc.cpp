@@ -5,6 +5,7 @@
 //   tools/_abi_pmc shade N n_env iters               split-sum shade forward + backward over N covered pixels
 //   tools/_abi_pmc shadef FILE iters                 the same on a dumped G-buffer + packed atlas (tools/r2_probe.py writes
 //                                                    /tmp/shade_case_*.bin: the step's REAL coherent G-buffer)
+//   tools/_abi_pmc mc N n_lon n_lat grid|bvh iters   Monte-Carlo shading forward over N surface points of a displaced sphere
 //   (attn takes an optional 8th argument: the kernel variant name for dm_attention_select)
 // Prints one JSON line with the HIP-event time per launch.  See tools/pmc_abi.sh for the rocprofv3 passes.
 #include <hip/hip_runtime.h>
@@ -154,6 +155,105 @@ static int run_shade(long long N, int n_env, int iters) {
     return 0;
 }
 
+// Monte-Carlo shading forward (row f-1) on the bench mesh's shape: displaced UV sphere (n_lon x n_lat), N surface points at
+// triangle centroids, 200 + 128 directions, 5 random lat-long environments; tracer = "grid" | "bvh".
+static int run_mc(long long N, int n_lon, int n_lat, const char* tracer, int iters) {
+    const float radius = 0.8f, amp = 0.15f, pi = 3.14159265358979f;
+    const int nr = n_lat - 1;
+    std::vector<float> v((size_t)(nr * n_lon + 2) * 3);
+    for (int i = 0; i < nr; ++i)
+        for (int j = 0; j < n_lon; ++j) {
+            const float t = pi * (i + 1) / n_lat, p = 2 * pi * j / n_lon, r = radius * (1 + amp * sinf(5 * t) * sinf(7 * p));
+            float* o = &v[(size_t)(i * n_lon + j) * 3];
+            o[0] = r * sinf(t) * cosf(p); o[1] = r * sinf(t) * sinf(p); o[2] = r * cosf(t);
+        }
+    const int i_n = nr * n_lon, i_s = i_n + 1;
+    v[3 * i_n + 2] = radius; v[3 * i_s + 2] = -radius;
+    std::vector<int> f;
+    for (int j = 0; j < n_lon; ++j) { f.push_back(i_n); f.push_back(j); f.push_back((j + 1) % n_lon); }
+    for (int i = 0; i + 1 < nr; ++i)
+        for (int j = 0; j < n_lon; ++j) {
+            const int jn = (j + 1) % n_lon, a = i * n_lon + j, b = i * n_lon + jn, c = (i + 1) * n_lon + j, d = (i + 1) * n_lon + jn;
+            f.push_back(a); f.push_back(c); f.push_back(b); f.push_back(b); f.push_back(c); f.push_back(d);
+        }
+    for (int j = 0; j < n_lon; ++j) { f.push_back((nr - 1) * n_lon + j); f.push_back(i_s); f.push_back((nr - 1) * n_lon + (j + 1) % n_lon); }
+    const int n_tri = (int)f.size() / 3, n_vert = (int)v.size() / 3;
+    std::vector<int> nodes((size_t)2 * n_tri * 8), order(n_tri), nodes4((size_t)2 * n_tri * 32);
+    std::vector<float> tris((size_t)n_tri * 12);
+    int n_nodes = 0, n_nodes4 = 0;
+    DM(dm_bvh_build(v.data(), n_vert, f.data(), n_tri, nodes.data(), tris.data(), order.data(), &n_nodes));
+    DM(dm_bvh_collapse4(nodes.data(), n_nodes, nodes4.data(), &n_nodes4));
+    nodes.resize((size_t)n_nodes * 8); nodes4.resize((size_t)n_nodes4 * 32);
+    dm_grid g;
+    uint32_t* blob = nullptr;
+    int64_t words = 0;
+    DM(dm_grid_build(tris.data(), n_tri, 0, &g, &blob, &words));
+    void *dnodes, *dnodes4, *dtris, *dblob;
+    if (upload(&dnodes, nodes) || upload(&dnodes4, nodes4) || upload(&dtris, tris)) return 2;
+    CK(hipMalloc(&dblob, (size_t)words * 4));
+    CK(hipMemcpy(dblob, blob, (size_t)words * 4, hipMemcpyHostToDevice));
+    dm_host_free(blob);
+    auto pad4 = [](long long w) { return (w + 3) / 4 * 4; };
+    const long long n_blocks = (long long)((g.dim[0] + 1) / 2) * ((g.dim[1] + 1) / 2) * ((g.dim[2] + 1) / 2);
+    const long long o_sb = pad4(g.n_words), o_off = o_sb + pad4((g.n_words + 63) / 64), o_dist = o_off + pad4((g.n_words + 1) / 2),
+                    o_occ = o_dist + pad4((n_blocks + 7) / 8), o_tri = o_occ + pad4(g.n_occ + 1);
+    const uint32_t* b32 = (const uint32_t*)dblob;
+    g.bits = b32; g.sbase = b32 + o_sb; g.off16 = (const uint16_t*)(b32 + o_off); g.dist4 = (const uint8_t*)(b32 + o_dist);
+    g.occ_start = b32 + o_occ; g.cell_tris = (const float*)(b32 + o_tri);
+    // points: centroids of random triangles pushed 1e-4 along the outward normal, view directions around it
+    std::vector<float> hp(3 * N), hn(3 * N), hv(3 * N), hf(5 * N), hrd(N), hrs(N);
+    std::vector<int> hpix(N), henv(8);
+    for (long long i = 0; i < N; ++i) {
+        const int t = (int)(rnd() % (unsigned)n_tri);
+        const float* a = &v[3 * (size_t)f[3 * t]]; const float* b = &v[3 * (size_t)f[3 * t + 1]]; const float* c = &v[3 * (size_t)f[3 * t + 2]];
+        float cen[3], e1[3], e2[3], n[3];
+        for (int k = 0; k < 3; ++k) { cen[k] = (a[k] + b[k] + c[k]) / 3.f; e1[k] = b[k] - a[k]; e2[k] = c[k] - a[k]; }
+        n[0] = e1[1] * e2[2] - e1[2] * e2[1]; n[1] = e1[2] * e2[0] - e1[0] * e2[2]; n[2] = e1[0] * e2[1] - e1[1] * e2[0];
+        float ln = 1.f / sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        if ((n[0] * cen[0] + n[1] * cen[1] + n[2] * cen[2]) < 0) ln = -ln;
+        float vv[3], lv = 0;
+        for (int k = 0; k < 3; ++k) { n[k] *= ln; vv[k] = n[k] + 0.6f * (frand() * 2 - 1); lv += vv[k] * vv[k]; }
+        lv = 1.f / sqrtf(lv);
+        for (int k = 0; k < 3; ++k) { hp[3 * i + k] = cen[k] + 1e-4f * n[k]; hn[3 * i + k] = n[k]; hv[3 * i + k] = vv[k] * lv; }
+        for (int k = 0; k < 5; ++k) hf[5 * i + k] = frand() * 4.f - 2.f;
+        hrd[i] = frand(); hrs[i] = frand();
+        hpix[i] = (int)(i % 8) * 512 * 512;
+    }
+    for (int k = 0; k < 8; ++k) henv[k] = k % 5;
+    const int lh = getenv("MC_LIGHT_H") ? atoi(getenv("MC_LIGHT_H")) : 512, lw = 2 * lh, nd = 200, ns = 128;   // (MC_LIGHT_H: cache-footprint experiments)
+    std::vector<float> hl((size_t)5 * lh * lw * 3), sd(2 * nd), ss(2 * ns);
+    for (auto& x : hl) x = frand();
+    auto fib = [&](std::vector<float>& o, int n) {
+        for (int k = 0; k < n; ++k) {
+            const double m = n + k, z = 2.0 * m / (2 * n) - 1.0, az = fmod(2 * 3.14159265358979 * m * ((sqrt(5.0) - 1) / 2), 2 * 3.14159265358979);
+            o[2 * k] = (float)(az * 0.5 / 3.14159265358979); o[2 * k + 1] = (float)(1 - 2 * asin(z) / 3.14159265358979);
+        }
+    };
+    fib(sd, nd); fib(ss, ns);
+    std::vector<int> hcount(1, (int)N);
+    void *dp, *dn, *dv, *df, *drd, *drs, *dpix, *denv, *dcount, *dl, *dsd, *dss, *dbits, *dcol;
+    if (upload(&dp, hp) || upload(&dn, hn) || upload(&dv, hv) || upload(&df, hf) || upload(&drd, hrd) || upload(&drs, hrs) || upload(&dpix, hpix) ||
+        upload(&denv, henv) || upload(&dcount, hcount) || upload(&dl, hl) || upload(&dsd, sd) || upload(&dss, ss)) return 2;
+    const int hw = dm_mc_hit_words(nd, ns);
+    CK(hipMalloc(&dbits, (size_t)N * hw * 4)); CK(hipMalloc(&dcol, (size_t)3 * N * 4));
+    dm_mc_scene sc;
+    memset(&sc, 0, sizeof(sc));
+    sc.bvh_nodes = dnodes; sc.bvh_tris = (const float*)dtris; sc.lights = (const float*)dl; sc.n_env = 5; sc.light_h = lh; sc.light_w = lw;
+    sc.samples_diffuse = (const float*)dsd; sc.samples_specular = (const float*)dss; sc.n_diffuse = nd; sc.n_specular = ns;
+    sc.geometry_ggx_smith = 0; sc.bvh_nodes4 = dnodes4; sc.grid = strcmp(tracer, "bvh") ? &g : nullptr;
+    dm_mat_cfg mc = {0.0f, 0.9f, 0.01f, 0.9f};
+    float ms;
+    int rc = timed(iters, &ms, [&] {
+        return dm_mc_shade_fwd(&sc, &mc, (float*)dp, 3, 1, (float*)dn, 3, 1, (float*)dv, 3, 1, (float*)df, 5, 1, (int*)dpix, (int*)denv, (int*)dcount, N,
+                               512 * 512, (float*)drd, (float*)drs, (uint32_t*)dbits, (float*)dcol, 1, N, nullptr, nullptr, nullptr, nullptr, nullptr,
+                               nullptr, nullptr, nullptr);
+    });
+    if (rc) return rc;
+    printf("{\"op\":\"mc\",\"tracer\":\"%s\",\"N\":%lld,\"tris\":%d,\"grid_dim\":[%d,%d,%d],\"rays\":%lld,\"fwd_ms\":%.4f,\"Grays_per_s\":%.3f}\n", tracer, N, n_tri,
+           g.dim[0], g.dim[1], g.dim[2], N * (nd + ns), ms, N * (nd + ns) / (ms * 1e-3) / 1e9);
+    return 0;
+}
+
 // File layout (little endian, written by tools/r2_probe.py): int64 header[16] = {magic 0x444d5348, N, views, HW, n_mips, diff_res,
 // lut_res, texel_format, spec_env_stride, diff_env_stride, spec_bytes, diff_bytes, has_pairs, 0, 0, 0}; int64 mip_off[8];
 // int32 mip_res[8]; then nrm[3][N] view[3][N] feat[5][N] dcol[3][N] (f32), pix[N] env_of_view[views] (i32), spec, diff,
@@ -210,7 +310,8 @@ int main(int argc, char** argv) {
     if (argc >= 9 && !strcmp(argv[1], "attn") && dm_attention_select(argv[8])) { printf("unknown attention variant %s\n", argv[8]); return 1; }
     if (argc >= 4 && !strcmp(argv[1], "shadef")) return run_shade_file(argv[2], atoi(argv[3]));
     if (argc >= 8 && !strcmp(argv[1], "attn")) return run_attn(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]));
+    if (argc >= 7 && !strcmp(argv[1], "mc")) return run_mc(atoll(argv[2]), atoi(argv[3]), atoi(argv[4]), argv[5], atoi(argv[6]));
     if (argc >= 5 && !strcmp(argv[1], "shade")) return run_shade(atoll(argv[2]), atoi(argv[3]), atoi(argv[4]));
-    printf("usage: %s conv B H W Cin Cout iters | attn B heads Sq Skv D iters | shade N n_env iters\n", argv[0]);
+    printf("usage: %s conv B H W Cin Cout iters | attn B heads Sq Skv D iters | shade N n_env iters | mc N n_lon n_lat grid|bvh iters\n", argv[0]);
     return 1;
 }
