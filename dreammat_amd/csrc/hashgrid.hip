@@ -95,6 +95,58 @@ __global__ __launch_bounds__(256) void k_hashgrid(HashArgs a) {
     }
 }
 
+// ---- uv-space field (dreammat_mesh.py:128-135, n_input_dims = 2): tcnn's grid over 2-D points.  grid_index<2>: dense
+// (x + y * res) while the running stride stays <= size, else (x * 1) ^ (y * 2654435761).  Not on the measured path (no
+// shipped config uses it): one thread per (point, level), one atomic pair per corner in the backward.
+__device__ __forceinline__ unsigned grid_index2(unsigned x, unsigned y, unsigned res, unsigned size) {
+    unsigned stride = 1, index = 0;
+    bool overflow = false;
+    if (stride <= size) { index += x * stride; unsigned long long s = (unsigned long long)stride * res; if (s > 0xffffffffull) overflow = true; stride = (unsigned)s; }
+    if (!overflow && stride <= size) { index += y * stride; unsigned long long s = (unsigned long long)stride * res; if (s > 0xffffffffull) overflow = true; stride = (unsigned)s; }
+    if (overflow || size < stride) index = (x * 1u) ^ (y * 2654435761u);
+    return index % size;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void k_hashgrid2d(HashArgs a) {
+    long long m = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long M = a.m_dev ? (long long)*a.m_dev : a.m_max;
+    if (m >= M) return;
+    const int l = blockIdx.y;
+    const float scale = a.lv.scale[l];
+    const unsigned res = a.lv.res[l], size = a.lv.size[l], off = a.lv.offset[l];
+    float w[2];
+    unsigned cell[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        float xn = (a.x[m * a.x_rs + d * a.x_cs] + a.radius) * a.inv_2r;
+        float p = xn * scale + 0.5f;
+        float fl = floorf(p);
+        w[d] = p - fl;
+        cell[d] = (unsigned)(int)fl;
+    }
+    float g0 = 0.f, g1 = 0.f;
+    if (BWD) { g0 = a.dout[m * a.dout_rs + (2 * l) * a.dout_cs]; g1 = a.dout[m * a.dout_rs + (2 * l + 1) * a.dout_cs]; }
+    float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const unsigned cx = cell[0] + (c & 1), cy = cell[1] + ((c >> 1) & 1);
+        const float wt = ((c & 1) ? w[0] : 1.f - w[0]) * (((c >> 1) & 1) ? w[1] : 1.f - w[1]);
+        const size_t e = off + grid_index2(cx, cy, res, size);
+        if (!BWD) {
+            const float2 t = a.table[e];
+            acc.x += t.x * wt; acc.y += t.y * wt;
+        } else {
+            atomicAdd(a.dtable + 2 * e, g0 * wt);
+            atomicAdd(a.dtable + 2 * e + 1, g1 * wt);
+        }
+    }
+    if (!BWD) {
+        a.out[m * a.out_rs + (2 * l) * a.out_cs] = acc.x;
+        a.out[m * a.out_rs + (2 * l + 1) * a.out_cs] = acc.y;
+    }
+}
+
 // Backward, second formulation.  Device-scope fp32 atomics retire at only ~20 G/s on MI355X (measured,
 // profiles/r01_hashgrid_bwd_per_level_v0.json: every level costs ~1.7-6.7 ms regardless of table size),
 // so the kernel is organised around ISSUING FEWER OF THEM:
@@ -476,6 +528,35 @@ int dm_hashgrid_fwd(const float* x, long long x_rs, long long x_cs, const int32_
 }
 
 // dtable must be zero-initialised (or hold the running gradient) by the caller: this ADDS into it.
+// The 2-D grid of the uv-space field (n_input_dims = 2): x [M,2] by strides, level sizes from res^2 (see csrc comment).
+int dm_hashgrid2d_fwd(const float* x, long long x_rs, long long x_cs, const int32_t* m_dev, long long m_max, const float* table,
+                      int n_levels, const float* lv_scale, const uint32_t* lv_res, const uint32_t* lv_size, const uint32_t* lv_offset,
+                      float radius, float* enc, long long enc_rs, long long enc_cs, hipStream_t stream) {
+    HashArgs a = {};
+    if (!x || !table || !enc || m_max <= 0 || !(radius > 0.f) || !fill_levels(a.lv, n_levels, lv_scale, lv_res, lv_size, lv_offset))
+        return DM_ERR_ARG;
+    a.x = x; a.x_rs = x_rs; a.x_cs = x_cs; a.table = (const float2*)table; a.out = enc; a.out_rs = enc_rs;
+    a.out_cs = enc_cs; a.m_dev = m_dev; a.m_max = m_max; a.radius = radius; a.inv_2r = 1.0f / (2.0f * radius);
+    DM_ENTER();
+    hipLaunchKernelGGL(k_hashgrid2d<false>, dim3(dm_div_up(m_max, 256), n_levels), dim3(256), 0, stream, a);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+int dm_hashgrid2d_bwd(const float* x, long long x_rs, long long x_cs, const int32_t* m_dev, long long m_max, const float* denc,
+                      long long denc_rs, long long denc_cs, int n_levels, const float* lv_scale, const uint32_t* lv_res,
+                      const uint32_t* lv_size, const uint32_t* lv_offset, float radius, float* dtable, hipStream_t stream) {
+    HashArgs a = {};
+    if (!x || !denc || !dtable || m_max <= 0 || !(radius > 0.f) || !fill_levels(a.lv, n_levels, lv_scale, lv_res, lv_size, lv_offset))
+        return DM_ERR_ARG;
+    a.x = x; a.x_rs = x_rs; a.x_cs = x_cs; a.dout = denc; a.dout_rs = denc_rs; a.dout_cs = denc_cs;
+    a.dtable = dtable; a.m_dev = m_dev; a.m_max = m_max; a.radius = radius; a.inv_2r = 1.0f / (2.0f * radius);
+    DM_ENTER();
+    hipLaunchKernelGGL(k_hashgrid2d<true>, dim3(dm_div_up(m_max, 256), n_levels), dim3(256), 0, stream, a);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
 int dm_hashgrid_bwd(const float* x, long long x_rs, long long x_cs, const int32_t* m_dev, long long m_max,
                     const float* denc, long long denc_rs, long long denc_cs, int n_levels, const float* lv_scale,
                     const uint32_t* lv_res, const uint32_t* lv_size, const uint32_t* lv_offset, float radius,

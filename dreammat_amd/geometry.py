@@ -30,17 +30,17 @@ class HashGridEncoding(nn.Module):
 
     def __init__(self, in_channels, config, radius=1.0):
         super().__init__()
-        assert in_channels == 3 and config.get("otype", "HashGrid") == "HashGrid", \
-            "only the 3-D HashGrid encoding of dreammat.yaml:43-49 is implemented"
+        assert in_channels in (2, 3) and config.get("otype", "HashGrid") == "HashGrid", \
+            "only the HashGrid encoding of dreammat.yaml:43-49 is implemented (3-D points, or 2-D texture coordinates)"
         self.spec = hipops.GridSpec(config["n_levels"], config["n_features_per_level"], config["log2_hashmap_size"],
-                                    config["base_resolution"], config["per_level_scale"])
+                                    config["base_resolution"], config["per_level_scale"], n_dims=in_channels)
         self.n_input_dims = in_channels
         self.n_output_dims = self.spec.n_output_dims
         self.radius = radius
         self.encoding = self._Inner(self.spec.n_params)
 
     def forward(self, x_world):
-        """x_world [M,3] in world space; contract_to_unisphere is fused into the kernel."""
+        """x_world [M,3] in world space (or [M,2] texture coordinates); contract_to_unisphere is fused into the kernel."""
         p = self.encoding.params
         # when the trainer has re-homed the parameters into its flat buffer (system.FlatParams), the
         # backward kernel accumulates straight into that gradient slice
@@ -126,9 +126,11 @@ class DreamMatMesh(BaseModule):
     cfg: Config
 
     def configure(self) -> None:
-        if self.cfg.n_input_dims != 3:
-            raise NotImplementedError("n_input_dims=2 (uv-space field) is not part of the first scope")
-        self.encoding = HashGridEncoding(3, self.cfg.pos_encoding_config, radius=self.cfg.radius)
+        if self.cfg.n_input_dims not in (2, 3):
+            raise ValueError(f"n_input_dims={self.cfg.n_input_dims}: 3 (surface points) or 2 (texture coordinates)")
+        # n_input_dims = 2 (dreammat_mesh.py:128-135, 246-250): the field lives in texture space -- the renderer queries it at
+        # the interpolated uv of a pixel, contracted with bbox2d = +-radius like the 3-D points (geometry/base.py:209-219)
+        self.encoding = HashGridEncoding(self.cfg.n_input_dims, self.cfg.pos_encoding_config, radius=self.cfg.radius)
         self.feature_network = VanillaMLP(self.encoding.n_output_dims, self.cfg.n_feature_dims,
                                           self.cfg.mlp_network_config)
         self.mesh = self._load_mesh()
@@ -171,7 +173,7 @@ class DreamMatMesh(BaseModule):
 
     def forward(self, points, output_normal: bool = False):
         assert not output_normal, f"Normal output is not supported for {self.__class__.__name__}"
-        enc = self.encoding(points.reshape(-1, 3))
+        enc = self.encoding(points.reshape(-1, self.cfg.n_input_dims))
         features = self.feature_network(enc).view(*points.shape[:-1], self.cfg.n_feature_dims)
         return {"features": features}
 

@@ -255,6 +255,18 @@ class _ScatterRows(torch.autograd.Function):
         return d.t(), None, None, None
 
 
+def gather_rows(dense, pix_idx, n_dev, n):
+    """dense [P,C] contiguous fp32 -> its rows at the covered pixels, [n,C] (no gradient: attributes of the fixed mesh)."""
+    _need_cuda(dense, pix_idx, n_dev)
+    dense = _f32c(dense)
+    C = dense.shape[-1]
+    out = torch.empty(n, C, device=dense.device, dtype=torch.float32)
+    if n > 0:
+        check(_lib.lib().dm_gather_rows(pix_idx.data_ptr(), n_dev.data_ptr(), n, dense.data_ptr(), C, out.data_ptr(), C, 1, _stream()),
+              "dm_gather_rows")
+    return out
+
+
 def scatter_rows(rows, pix_idx, n_dev, dense_init):
     """rows [N,C] (any strides), dense_init [P,C] contiguous -> [P,C]."""
     return _ScatterRows.apply(rows, pix_idx, n_dev, dense_init)
@@ -265,16 +277,17 @@ class GridSpec:
     """Per-level constants of the multiresolution hash grid (tcnn HashGrid semantics)."""
 
     def __init__(self, n_levels=16, n_features=2, log2_hashmap_size=19, base_resolution=16,
-                 per_level_scale=1.447269237440378):
+                 per_level_scale=1.447269237440378, n_dims=3):
         import math
         assert n_features == 2, "the HIP kernel is specialised for 2 features per level (dreammat.yaml:47)"
-        self.n_levels, self.n_features = n_levels, n_features
+        assert n_dims in (2, 3)
+        self.n_levels, self.n_features, self.n_dims = n_levels, n_features, n_dims
         scale, res, size, offset = [], [], [], []
         off = 0
         for l in range(n_levels):
             s = np.float32(math.pow(2.0, l * math.log2(per_level_scale)) * base_resolution - 1.0)
             r = int(math.ceil(float(s))) + 1
-            n = min((r ** 3 + 7) // 8 * 8, 1 << log2_hashmap_size)
+            n = min((r ** n_dims + 7) // 8 * 8, 1 << log2_hashmap_size)
             scale.append(float(s)); res.append(r); size.append(n); offset.append(off)
             off += n
         self.total_entries = off
@@ -313,11 +326,13 @@ class _HashGrid(torch.autograd.Function):
         M = x.shape[0]
         F = spec.n_output_dims
         enc = torch.empty(F, M, device=x.device, dtype=torch.float32)
+        assert x.shape[1] == spec.n_dims
         if M > 0:
             rs, cs = _rs_cs(x)
-            check(_lib.lib().dm_hashgrid_fwd(x.data_ptr(), rs, cs, None, M, table.data_ptr(), spec.n_levels,
-                                             spec.c_scale, spec.c_res, spec.c_size, spec.c_offset, float(radius),
-                                             enc.data_ptr(), 1, M, _stream()), "dm_hashgrid_fwd")
+            fwd, name = ((_lib.lib().dm_hashgrid_fwd, "dm_hashgrid_fwd") if spec.n_dims == 3
+                         else (_lib.lib().dm_hashgrid2d_fwd, "dm_hashgrid2d_fwd"))
+            check(fwd(x.data_ptr(), rs, cs, None, M, table.data_ptr(), spec.n_levels, spec.c_scale, spec.c_res, spec.c_size,
+                      spec.c_offset, float(radius), enc.data_ptr(), 1, M, _stream()), name)
         ctx.save_for_backward(x, table)
         ctx.spec, ctx.radius, ctx.grad_sink = spec, radius, grad_sink
         return enc.t()
@@ -334,6 +349,11 @@ class _HashGrid(torch.autograd.Function):
             rs, cs = _rs_cs(x)
             grs, gcs = _rs_cs(g)
             L = _lib.lib()
+            if spec.n_dims == 2:                       # uv-space field: the plain atomic route
+                check(L.dm_hashgrid2d_bwd(x.data_ptr(), rs, cs, None, M, g.data_ptr(), grs, gcs, spec.n_levels, spec.c_scale,
+                                          spec.c_res, spec.c_size, spec.c_offset, float(ctx.radius), dtable.data_ptr(), _stream()),
+                      "dm_hashgrid2d_bwd")
+                return None, (None if direct else dtable), None, None, None
             ws_bytes = int(L.dm_hashgrid_bwd_workspace_bytes(M, spec.n_levels, spec.c_res, spec.c_size)) \
                 if M >= HASHGRID_BINNED_MIN_POINTS else 0
             with _Timed(f"hashgrid_bwd[{'binned' if ws_bytes else 'atomic'}]", float(M) * (12 + 4 * spec.n_output_dims)):

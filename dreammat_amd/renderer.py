@@ -55,7 +55,7 @@ class RaytraceRender(BaseModule):
         return m
 
     def forward(self, env_id, rays_o, rays_d, w2c, mvp_mtx, camera_positions=None, light_positions=None,
-                height: int = 512, width: int = 512, jitter_u=None, jitter_n=None, **kwargs):
+                height: int = 512, width: int = 512, jitter_u=None, jitter_n=None, jitter_uv=None, **kwargs):
         mesh = self._mesh()
         dev = mesh.v_pos.device
         B, H, W = mvp_mtx.shape[0], height, width
@@ -80,8 +80,18 @@ class RaytraceRender(BaseModule):
             env_of_view = env_of_view.expand(B)
         env_of_view = env_of_view.contiguous()
 
-        # both field queries in ONE launch: rows [0,N) = surface points, [N,2N) = jittered points
-        pts2 = torch.cat([gb.pos, gb.pos_jitter], dim=1)            # [3, 2N] SoA
+        if getattr(self.geometry.cfg, "n_input_dims", 3) == 2:
+            # uv-space field (raytracing_renderer.py:177-181): the field is queried at the pixel's interpolated texture
+            # coordinate and at that coordinate + N(0, 0.005) per component (`jitter_uv` [N,2] ~ N(0,1): injectable draw)
+            if mesh.v_tex is None:
+                raise ValueError("n_input_dims=2 needs a mesh with texture coordinates")
+            texc = hipops.gather_rows(hipops.interpolate(mesh.v_tex.contiguous(), rast, tri).view(B * H * W, 2), gb.pix_idx, gb.n_dev, N)
+            if jitter_uv is None:
+                jitter_uv = torch.randn(N, 2, device=dev)
+            pts2 = torch.cat([texc, texc + 0.005 * jitter_uv[:N]], dim=0).t()      # [2, 2N]
+        else:
+            # both field queries in ONE launch: rows [0,N) = surface points, [N,2N) = jittered points
+            pts2 = torch.cat([gb.pos, gb.pos_jitter], dim=1)        # [3, 2N] SoA
         feats2 = self.geometry(pts2.t(), output_normal=False)["features"]   # [2N, 5]
         feat, feat_j = feats2[:N], feats2[N:]
         shade, mat_reg = self.material(gb.pos.t(), feat, feat_j, gb.view.t(), gb.nrm.t(), env_of_view,

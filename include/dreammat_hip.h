@@ -119,6 +119,15 @@ int dm_hashgrid_bwd(const float* x, long long x_rs, long long x_cs, const int32_
                     const float* denc, long long denc_rs, long long denc_cs, int n_levels,
                     const float* lv_scale_host, const uint32_t* lv_res_host, const uint32_t* lv_size_host,
                     const uint32_t* lv_offset_host, float radius, float* dtable, dm_stream_t stream);
+/* The 2-D grid of the uv-space field (DreamMatMesh n_input_dims = 2, dreammat_mesh.py:128-135, 246-250): x [M,2] texture
+ * coordinates by strides, contracted with the same +-radius box; level sizes min(next_multiple(res^2, 8), 2^log2_hashmap_size);
+ * bwd scatter-adds into dtable (zeroed by the caller) with one atomic pair per corner. */
+int dm_hashgrid2d_fwd(const float* x, long long x_rs, long long x_cs, const int32_t* m_dev, long long m_max, const float* table,
+                      int n_levels, const float* lv_scale, const uint32_t* lv_res, const uint32_t* lv_size,
+                      const uint32_t* lv_offset, float radius, float* enc, long long enc_rs, long long enc_cs, dm_stream_t stream);
+int dm_hashgrid2d_bwd(const float* x, long long x_rs, long long x_cs, const int32_t* m_dev, long long m_max, const float* denc,
+                      long long denc_rs, long long denc_cs, int n_levels, const float* lv_scale, const uint32_t* lv_res,
+                      const uint32_t* lv_size, const uint32_t* lv_offset, float radius, float* dtable, dm_stream_t stream);
 
 /* ---- material / shading ------------------------------------------------------------------- */
 /* Pre-filtered environment atlas (envlight.EnvLight equivalents for all env maps, built once at

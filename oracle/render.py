@@ -87,8 +87,15 @@ def render(mesh, batch, field_params, envs, fg_lut, jitter_u, jitter_n, change_e
     change = (torch.cos(ang) * x + torch.sin(ang) * y) * eps
     positions_jitter = positions + change
     fp = field_params
-    feat, hid = field.field_forward(positions, fp["table"], fp["w1"], fp["w2"], fp["levels"], fp.get("radius", 1.0), True)
-    feat_j, hid_j = field.field_forward(positions_jitter, fp["table"], fp["w1"], fp["w2"], fp["levels"], fp.get("radius", 1.0), True)
+    if "v_tex" in mesh and fp.get("n_input_dims", 3) == 2:
+        # uv-space field (raytracing_renderer.py:177-181): the interpolated texture coordinate and that + N(0, 0.005);
+        # `jitter_uv` [B,H,W,2] ~ N(0,1) is the injected draw (the reference draws per covered pixel)
+        texc = torch.from_numpy(raster.interpolate(mesh["v_tex"], rast_np, tri)).reshape(-1, 2)[sel]
+        positions_q, positions_jitter_q = texc, texc + 0.005 * batch["jitter_uv"]
+    else:
+        positions_q, positions_jitter_q = positions, positions_jitter
+    feat, hid = field.field_forward(positions_q, fp["table"], fp["w1"], fp["w2"], fp["levels"], fp.get("radius", 1.0), True)
+    feat_j, hid_j = field.field_forward(positions_jitter_q, fp["table"], fp["w1"], fp["w2"], fp["levels"], fp.get("radius", 1.0), True)
     shade, mat_reg = shading.material_forward(feat, feat_j, viewdirs, n_sel, envs, env_id[view_of], fg_lut, mat_cfg)
 
     def scatter(vals, C):

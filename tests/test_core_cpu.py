@@ -409,3 +409,25 @@ def test_rgb18e8_texels_and_fg_pair_table(hostemu, env_pair):
     gmax = np.abs(res["fp32"][1]).max()
     assert np.abs(res["rgb18e8"][0] - res["fp32"][0]).max() < 2e-6 and np.abs(res["rgb18e8"][1] - res["fp32"][1]).max() < 1e-5 * gmax
     assert np.abs(res["fp16"][0] - res["fp32"][0]).max() < 1e-3
+
+
+def test_oracle_hash_grid_over_two_dimensions():
+    """oracle/field.py restated for the uv-space field (n_input_dims = 2): level sizes from res^2, a dense level read at its
+    lattice points returns the table rows themselves (index = x + y * res), the four bilinear weights are a partition of unity,
+    and the encoding is continuous across cell borders."""
+    from oracle import field as ofield
+    lv, tot = ofield.grid_levels(n_levels=6, log2_hashmap_size=12, n_dims=2)
+    assert [l["res"] for l in lv][:3] == [16, 24, 34] and lv[0]["size"] == 256 and lv[1]["size"] == 24 * 24 and lv[2]["size"] == (34 * 34 + 7) // 8 * 8
+    assert all(l["size"] <= 4096 for l in lv) and lv[-1]["size"] == 4096 and tot == sum(l["size"] for l in lv)
+    torch.manual_seed(0)
+    table = torch.randn(tot, 2)
+    l0 = lv[0]
+    ij = torch.stack(torch.meshgrid(torch.arange(1, 15), torch.arange(1, 15), indexing="ij"), -1).reshape(-1, 2)
+    x = (ij.float() - 0.5) / l0["scale"]                               # pos = x * scale + 0.5 = integer lattice point
+    enc = ofield.hash_encode(x, table, lv[:1])
+    assert torch.allclose(enc, table[l0["offset"] + ij[:, 0] + ij[:, 1] * l0["res"]], atol=1e-5)
+    ones = torch.ones(tot, 2)
+    u = torch.rand(500, 2)
+    assert torch.allclose(ofield.hash_encode(u, ones, lv), torch.ones(500, 2 * len(lv)), atol=1e-5)
+    a = torch.tensor([[0.3, 0.41]])
+    assert (ofield.hash_encode(a + 1e-6, table, lv) - ofield.hash_encode(a - 1e-6, table, lv)).abs().max() < 1e-3

@@ -138,6 +138,92 @@ def test_hashgrid_forward_backward(dev):
         assert err < 1e-3 * to.grad.abs().max(), (layout, float(err))
 
 
+def test_hashgrid_2d_uv_space_field(dev):
+    """the uv-space field's grid (n_input_dims = 2, dm_hashgrid2d_fwd / _bwd): tcnn's rules over 2-D points, dense and hashed
+    levels (log2_hashmap_size 10 hashes from level 2 on; dreammat.yaml's 16 x 2^19 pyramid is dense up to res 724, level 10)."""
+    for n_levels, log2 in ((8, 10), (16, 19)):
+        torch.manual_seed(4)
+        spec = hipops.GridSpec(n_levels=n_levels, log2_hashmap_size=log2, n_dims=2)
+        lv, tot = ofield.grid_levels(n_levels=n_levels, log2_hashmap_size=log2, n_dims=2)
+        assert tot == spec.total_entries and [l["size"] for l in lv] == [l["size"] for l in spec.levels]
+        first_hashed = next(i for i, l in enumerate(lv) if l["size"] < l["res"] ** 2)
+        assert lv[0]["size"] == 16 * 16 and first_hashed == (2 if log2 == 10 else 11)
+        table = torch.rand(tot * 2) * 2 - 1
+        x = torch.rand(4000, 2) * 1.9 - 0.95
+        tg = table.to(dev).requires_grad_()
+        for layout in ("aos", "soa"):
+            xg = x.to(dev) if layout == "aos" else x.t().contiguous().to(dev).t()
+            enc = hipops.hashgrid_encode(xg, tg, spec, 1.0)
+            to = table.reshape(-1, 2).clone().requires_grad_()
+            ref = ofield.hash_encode(ofield.contract_to_unisphere(x), to, lv)
+            # (fp32 positions at scale 4095 carry 2.4e-4 of a cell: the fine levels of the 16-level pyramid see that in the weights)
+            assert (enc.detach().cpu() - ref.detach()).abs().max() < (1e-4 if n_levels == 8 else 2e-3), (n_levels, layout)
+            dy = torch.randn(4000, 2 * n_levels)
+            tg.grad = None
+            enc.backward(dy.to(dev))
+            ref.backward(dy)
+            err = (tg.grad.cpu().reshape(-1, 2) - to.grad).abs().max()
+            assert err < 1e-3 * to.grad.abs().max(), (n_levels, layout, float(err))
+
+
+def test_renderer_uv_space_field_vs_oracle(dev, envs):
+    """geometry.n_input_dims = 2 (dreammat_mesh.py:128-135, raytracing_renderer.py:177-181): the field is queried at the
+    pixel's interpolated texture coordinate and at that + N(0, 0.005); all outputs and the gradients against oracle/render.py
+    with the same injected draws."""
+    from dreammat_amd.geometry import DreamMatMesh
+    from dreammat_amd.material import DreamMatMaterial
+    from dreammat_amd.renderer import RaytraceRender
+    from dreammat_amd.background import SolidColorBackground
+    lat, fg, oenvs = envs
+    torch.manual_seed(0)
+    enc_cfg = {"otype": "HashGrid", "n_levels": 8, "n_features_per_level": 2, "log2_hashmap_size": 12,
+               "base_resolution": 16, "per_level_scale": 1.447269237440378}
+    geom = DreamMatMesh({"shape_init": "sphere:48:40", "shape_init_params": 0.7, "pos_encoding_config": enc_cfg, "n_input_dims": 2}).to(dev)
+    with torch.no_grad():
+        geom.encoding.encoding.params.copy_((torch.rand_like(geom.encoding.encoding.params) * 2 - 1))
+        geom.feature_network.layers[0].weight.copy_(torch.randn(64, 16) * 0.5)
+        geom.feature_network.layers[2].weight.copy_(torch.randn(5, 64) * 0.3)
+    mat = DreamMatMaterial({"use_raytracing": False, "environment_scale": 2.0, "env_max_res": 32, "env_min_res": 8,
+                            "n_envs": 3}, latlongs=lat).to(dev)
+    rend = RaytraceRender({}, geometry=geom, material=mat, background=SolidColorBackground({}))
+    B, H, W = 2, 96, 96
+    batch = util.make_views(B, H, W, seed=5)
+    batch["env_id"] = torch.tensor([2, 0])
+    g = torch.Generator().manual_seed(11)
+    ju, jn = torch.rand(B, H, W, generator=g), torch.randn(B, H, W, generator=g)
+    gbatch = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
+    # the per-covered-pixel uv draws: first a run with zeros to learn the coverage count, then the real one
+    out0 = rend(**gbatch, light_positions=None, jitter_u=ju.to(dev), jitter_n=jn.to(dev), jitter_uv=torch.zeros(B * H * W, 2, device=dev))
+    N = out0["_internals"]["gbuffer"].n
+    juv = torch.randn(N, 2, generator=g)
+    out = rend(**gbatch, light_positions=None, jitter_u=ju.to(dev), jitter_n=jn.to(dev), jitter_uv=juv.to(dev), check_overflow=True)
+    m = geom.mesh
+    md = dict(v_pos=m.v_pos.cpu().numpy(), v_nrm=m.v_nrm.cpu().numpy(), t_pos_idx=m.t_pos_idx.cpu().numpy().astype(np.int32),
+              v_tex=m.v_tex.cpu().numpy())
+    md["opp"] = oraster.build_topology(md["t_pos_idx"])
+    lv, tot = ofield.grid_levels(n_levels=8, log2_hashmap_size=12, n_dims=2)
+    table = geom.encoding.encoding.params.detach().cpu().reshape(-1, 2).clone().requires_grad_()
+    w1 = geom.feature_network.layers[0].weight.detach().cpu().clone().requires_grad_()
+    w2 = geom.feature_network.layers[2].weight.detach().cpu().clone().requires_grad_()
+    ob = dict(batch); ob["jitter_uv"] = juv
+    ref = orender.render(md, ob, dict(table=table, w1=w1, w2=w2, levels=lv, radius=1.0, n_input_dims=2), oenvs, fg, ju, jn)
+    assert np.array_equal(out["_internals"]["rast"].cpu().numpy().view(np.uint32), ref["_rast"].numpy().view(np.uint32))
+    assert (out["_internals"]["features"].detach().cpu() - ref["_features"].detach()).abs().max() < 1e-4
+    assert (out["_internals"]["features_jitter"].detach().cpu() - ref["_features_jitter"].detach()).abs().max() < 1e-4
+    assert (out0["_internals"]["features"] - out0["_internals"]["features_jitter"]).abs().max() == 0       # zero draw: same query
+    for k in ["comp_rgb", "albedo", "metalness", "roughness", "specular_color", "diffuse_color"]:
+        assert (out[k].detach().cpu() - ref[k].detach()).abs().max().item() < 1e-4, k
+    assert abs(float(out["loss_mat_reg"]) - float(ref["loss_mat_reg"])) < 1e-5 * max(1, abs(float(ref["loss_mat_reg"])))
+    dy = torch.randn(B, H, W, 3, generator=g)
+    ((out["comp_rgb"] * dy.to(dev)).sum() + 2.0 * out["loss_mat_reg"]).backward()
+    ((ref["comp_rgb"] * dy).sum() + 2.0 * ref["loss_mat_reg"]).backward()
+    for a, b, nm in ((geom.encoding.encoding.params.grad.cpu().reshape(-1, 2), table.grad, "table"),
+                     (geom.feature_network.layers[0].weight.grad.cpu(), w1.grad, "w1"),
+                     (geom.feature_network.layers[2].weight.grad.cpu(), w2.grad, "w2")):
+        rel = ((a - b).abs().max() / b.abs().max()).item()
+        assert rel < 2e-3, (nm, rel)
+
+
 def test_hashgrid_full_size_levels(dev):
     """all 16 levels of dreammat.yaml incl. the hashed ones (uint32 wrap-around index arithmetic)."""
     torch.manual_seed(1)
