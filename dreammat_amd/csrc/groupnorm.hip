@@ -41,27 +41,33 @@ __device__ __forceinline__ void load8(const float* p, float* o) {
 }
 
 // per-(b, channel) coefficients from the group statistics.  PASS 0: rows 0-4, PASS 1: rows 5-6.
+constexpr int GN_COEF_SLICES = 16;       // k_gn_coef: 1024 threads = 64 statistics x 16 interleaved slices of the partial rows
+
 template <int PASS>
-__global__ __launch_bounds__(256) void k_gn_coef(GnArgs a) {
-    // the 64 group statistics of this batch item: 256 threads = 64 statistics x 4 interleaved slices of the
-    // per-workgroup partials, combined in a fixed order (a per-channel serial walk over up to 257 partials cost
-    // 26 us per call)
-    __shared__ float red[4][64];
+__global__ __launch_bounds__(64 * GN_COEF_SLICES) void k_gn_coef(GnArgs a) {
+    // the 64 group statistics of this batch item: 64 statistics x 16 interleaved slices of the per-workgroup partials,
+    // combined in a fixed order (a per-channel serial walk over up to 257 partials cost 26 us per call; 4 slices over the
+    // 1537 rows of a one-image 512^2 tensor still 21 us, 44 times per step at one view per rank)
+    __shared__ float red[GN_COEF_SLICES][64];
     const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
     {
         const int st = threadIdx.x & 63, sl = threadIdx.x >> 6;
         const float* pp = (PASS == 0 ? a.part : a.bpart) + (long long)b * a.nblk * 64 + st;
         float t = 0.f;
 #pragma unroll 4
-        for (int k = sl; k < a.nblk; k += 4) t += pp[(long long)k * 64];
+        for (int k = sl; k < a.nblk; k += GN_COEF_SLICES) t += pp[(long long)k * 64];
         red[sl][st] = t;
     }
     __syncthreads();
     if (c >= a.C) return;
     const int cpg = a.C / 32, g = c / cpg;
     const float n = (float)a.HW * cpg;
-    const float t0 = (red[0][2 * g] + red[1][2 * g]) + (red[2][2 * g] + red[3][2 * g]);
-    const float t1 = (red[0][2 * g + 1] + red[1][2 * g + 1]) + (red[2][2 * g + 1] + red[3][2 * g + 1]);
+    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < GN_COEF_SLICES; q += 4) {
+        t0 += (red[q][2 * g] + red[q + 1][2 * g]) + (red[q + 2][2 * g] + red[q + 3][2 * g]);
+        t1 += (red[q][2 * g + 1] + red[q + 1][2 * g + 1]) + (red[q + 2][2 * g + 1] + red[q + 3][2 * g + 1]);
+    }
     float* co = a.coef + (long long)b * 7 * a.C;
     if (PASS == 0) {
         float m = t0 / n;
@@ -157,7 +163,8 @@ __global__ __launch_bounds__(256) void k_gn_stats(GnArgs a) {
 
 // MODE 0: y = act(x*A + S).  MODE 1: dx = rstd*dxhat - c1 - c2*xhat.
 // FUSED (forward only): no coefficient kernel in front -- every workgroup adds up the per-workgroup partials of its batch
-// item itself (same fixed order as k_gn_coef: 64 statistics x 4 interleaved slices) and forms A, S from gamma / beta on
+// item itself (64 statistics x 4 interleaved slices, a fixed order; k_gn_coef uses 16 slices, so the two differ in the last
+// bits of the sums) and forms A, S from gamma / beta on
 // the fly.  One launch less per GroupNorm; at 1 view per rank the coefficient kernel was a 9 us launch in front of a 7 us
 // apply, 110 times per step.
 template <int MODE, bool FUSED = false>
@@ -283,7 +290,7 @@ int dm_groupnorm_nhwc_fwd(const void* x, const void* gamma, const void* beta, vo
     a.nblk = (int)g.x;
     DM_ENTER();
     hipLaunchKernelGGL(k_gn_stats<0>, g, dim3(256), stats_lds_bytes(C), stream, a);
-    hipLaunchKernelGGL(k_gn_coef<0>, dim3(dm_div_up(C, 256), B), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(k_gn_coef<0>, dim3(dm_div_up(C, 64 * GN_COEF_SLICES), B), dim3(64 * GN_COEF_SLICES), 0, stream, a);
     hipLaunchKernelGGL(k_gn_apply<0>, g, dim3(256), 0, stream, a);
     DM_LAUNCH_CHECK();
     return DM_OK;
@@ -323,7 +330,7 @@ int dm_groupnorm_nhwc_bwd(const void* x, const void* gamma, const void* beta, co
     a.nblk = (int)g.x;
     DM_ENTER();
     hipLaunchKernelGGL(k_gn_stats<1>, g, dim3(256), stats_lds_bytes(C), stream, a);
-    hipLaunchKernelGGL(k_gn_coef<1>, dim3(dm_div_up(C, 256), B), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(k_gn_coef<1>, dim3(dm_div_up(C, 64 * GN_COEF_SLICES), B), dim3(64 * GN_COEF_SLICES), 0, stream, a);
     hipLaunchKernelGGL(k_gn_apply<1>, g, dim3(256), 0, stream, a);
     DM_LAUNCH_CHECK();
     return DM_OK;
