@@ -99,7 +99,7 @@ def test_material_plugin_raytracing_branch_runs(dev):
     assert torch.isfinite(f.grad).all() and f.grad.abs().sum() > 0
 
 
-@pytest.mark.parametrize("tracer", ["bvh2", "bvh4", "grid"])
+@pytest.mark.parametrize("tracer", ["bvh2", "bvh4", "grid", "grid96"])
 @pytest.mark.parametrize("variant", ["schlick", "ggx_smith"])
 def test_mc_wave_kernel_matches_the_serial_kernel(variant, tracer, monkeypatch):
     """the one-wave-per-pixel Monte-Carlo kernel (the default; samples over the 64 lanes, ballot hit
@@ -113,15 +113,19 @@ def test_mc_wave_kernel_matches_the_serial_kernel(variant, tracer, monkeypatch):
     dev = torch.device("cuda:0")
     g = {k: torch.from_numpy(v) if v.ndim else v
          for k, v in np.load(os.path.join(os.path.dirname(__file__), "golden", "mc_shading.npz")).items()}
-    bvh = hipops.MeshBvh(g["v_pos"], g["tri"], dev)
+    # "grid96": a 96-cell grid -- its tables and the per-wave scratch do not fit LDS together, the kernel walks the grid per lane
+    # with the tables in global memory
+    bvh = hipops.MeshBvh(g["v_pos"], g["tri"], dev, grid_res=96 if tracer == "grid96" else 0)
     monkeypatch.setenv("DREAMMAT_BVH", "2")                # reference: the validated serial kernel on the binary tree
     monkeypatch.setenv("DREAMMAT_MC_TRACER", "bvh")
     scene_ref = hipops.McScene(bvh, [g["light"]], g[f"{variant}_dsamp"].shape[0], g[f"{variant}_ssamp"].shape[0], variant)
     assert scene_ref.grid is None and scene_ref.nodes4 is None
     monkeypatch.setenv("DREAMMAT_BVH", "2" if tracer == "bvh2" else "4")
-    monkeypatch.setenv("DREAMMAT_MC_TRACER", "grid" if tracer == "grid" else "bvh")
+    monkeypatch.setenv("DREAMMAT_MC_TRACER", "grid" if tracer.startswith("grid") else "bvh")
     scene_new = hipops.McScene(bvh, [g["light"]], g[f"{variant}_dsamp"].shape[0], g[f"{variant}_ssamp"].shape[0], variant)
-    assert (scene_new.grid is not None) == (tracer == "grid") and (scene_new.nodes4 is not None) == (tracer != "bvh2")
+    assert (scene_new.grid is not None) == tracer.startswith("grid") and (scene_new.nodes4 is not None) == (tracer != "bvh2")
+    if tracer == "grid96":
+        assert max(scene_new.grid.dim) > 88
     mat = _lib.MatCfgStruct(0.0, 0.9, 0.01, 0.9)
     N = g["pts"].shape[0]
     rd, rs = g[f"{variant}_rand_d"].to(dev).contiguous(), g[f"{variant}_rand_s"].to(dev).contiguous()
