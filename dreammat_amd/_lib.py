@@ -16,6 +16,7 @@ if os.environ.get("DREAMMAT_LIB"):       # development aid (tools/grad_budget.py
     LIB_PATH = os.environ["DREAMMAT_LIB"]
 
 _lib = None
+ABI_VERSION = 4      # dm_abi_version() of the library this binding was written for (csrc/host.cpp, include/dreammat_hip.h)
 
 DM_ERRORS = {-1: "DM_ERR_ARG", -2: "DM_ERR_WORKSPACE", -3: "DM_ERR_UNSUPPORTED"}
 
@@ -148,6 +149,9 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        if L.dm_abi_version() != ABI_VERSION:
+            raise DmError(f"{LIB_PATH} has ABI version {L.dm_abi_version()}, this binding expects {ABI_VERSION}: rebuild it "
+                          "(`python -m dreammat_amd.csrc.build`)")
         _lib = L
     return _lib
 
