@@ -87,6 +87,9 @@ _SIGS = {
                                   c_void_p]),
     "dm_hashgrid2d_bwd": (c_int, [c_void_p, _LL, _LL, c_void_p, _LL, c_void_p, _LL, _LL, c_int, POINTER(c_float),
                                   POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32), c_float, c_void_p, c_void_p]),
+    "dm_field_mlp_fwd": (c_int, [c_void_p, _LL, _LL, c_void_p, c_void_p, c_int, c_int, c_void_p, _LL, c_void_p]),
+    "dm_field_mlp_bwd": (c_int, [c_void_p, _LL, _LL, c_void_p, c_void_p, c_int, c_int, c_void_p, _LL, _LL, c_void_p, _LL, c_void_p,
+                                 c_void_p, c_void_p]),
     "dm_hashgrid_bwd_workspace_bytes": (c_size_t, [_LL, c_int, POINTER(c_uint32), POINTER(c_uint32)]),
     "dm_hashgrid_bwd_binned": (c_int, [c_void_p, _LL, _LL, c_void_p, _LL, c_void_p, _LL, _LL, c_int, POINTER(c_float),
                                        POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32), c_float, c_void_p, c_void_p,

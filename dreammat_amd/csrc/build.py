@@ -15,6 +15,7 @@ SOURCES = {
     # shading tolerates approximate div/exp/rcp (1e-3 rel budget, results stay within 1e-5 of the oracle)
     "shade.hip": ["-munsafe-fp-atomics", "-ffast-math"],
     "hashgrid.hip": ["-munsafe-fp-atomics"],
+    "field_mlp.hip": ["-munsafe-fp-atomics"],
     # MFMA results stay in VGPRs: the softmax consumes every S element with VALU ops, and the AGPR form cost
     # 127 v_accvgpr_read/write per KV tile
     "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],

@@ -99,6 +99,9 @@ class VanillaMLP(nn.Module):
             # feature-major input (the hash-grid kernel's coalesced layout): keep the whole MLP
             # feature-major (W @ X^T) and hand back an [M, out] view -- same numbers, no transposes
             h = x.t()
+            if len(self.layers) == 3 and hipops.field_mlp_ok(h, self.layers[0].weight, self.layers[2].weight):
+                # the shipped shape (2L -> 64 -> ReLU -> n_out): both layers in one kernel, the hidden layer in registers
+                return hipops.field_mlp(h, self.layers[0].weight, self.layers[2].weight).t()
             for layer in self.layers:
                 h = _FeatureMajorLinear.apply(layer.weight, h) if isinstance(layer, nn.Linear) else torch.relu(h)
             return h.t()

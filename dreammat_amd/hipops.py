@@ -376,6 +376,56 @@ def hashgrid_encode(x, table, spec, radius=1.0, grad_sink=None):
     return _HashGrid.apply(x, table, spec, radius, grad_sink)
 
 
+# ------------------------------------------------------------------------------------------ feature network
+FIELD_MLP_FUSED = os.environ.get("DREAMMAT_FIELD_MLP", "fused") != "torch"
+
+
+def field_mlp_ok(x_fm, w1, w2):
+    """x_fm: feature-major activations [n_in, M] (a transposed view of the hash-grid output)"""
+    return (FIELD_MLP_FUSED and x_fm.is_cuda and x_fm.dtype == torch.float32 and x_fm.dim() == 2 and x_fm.stride(1) == 1
+            and x_fm.shape[0] in (16, 32) and tuple(w1.shape) == (64, x_fm.shape[0]) and w2.shape[1] == 64 and w2.shape[0] <= 8
+            and w1.dtype == torch.float32 and w2.dtype == torch.float32)
+
+
+class _FieldMlp(torch.autograd.Function):
+    """VanillaMLP of the feature field (Linear(n_in, 64, bias=False) -> ReLU -> Linear(64, n_out, bias=False)) in two fused
+    kernels (csrc/field_mlp.hip): feature-major in and out, the hidden layer recomputed in the backward."""
+
+    @staticmethod
+    def forward(ctx, x_fm, w1, w2):
+        n_in, M = x_fm.shape
+        n_out = w2.shape[0]
+        w1c, w2c = w1.contiguous(), w2.contiguous()
+        y = torch.empty(n_out, M, device=x_fm.device, dtype=torch.float32)
+        if M > 0:
+            with _Timed("field_mlp_fwd", 2.0 * M * (n_in * 64 + 64 * n_out)):
+                check(_lib.lib().dm_field_mlp_fwd(x_fm.data_ptr(), x_fm.stride(0), M, w1c.data_ptr(), w2c.data_ptr(), n_in, n_out,
+                                                  y.data_ptr(), M, _stream()), "dm_field_mlp_fwd")
+        ctx.save_for_backward(x_fm, w1c, w2c)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x_fm, w1, w2 = ctx.saved_tensors
+        n_in, M = x_fm.shape
+        n_out = w2.shape[0]
+        dx = torch.empty(n_in, M, device=g.device, dtype=torch.float32)
+        dw1, dw2 = torch.zeros_like(w1), torch.zeros_like(w2)
+        if M > 0:
+            with _Timed("field_mlp_bwd", 2.0 * M * (3 * n_in * 64 + 3 * 64 * n_out)):
+                # g [n_out, M] by strides: element (k, m) at g.stride(1) * m + g.stride(0) * k
+                check(_lib.lib().dm_field_mlp_bwd(x_fm.data_ptr(), x_fm.stride(0), M, w1.data_ptr(), w2.data_ptr(), n_in, n_out,
+                                                  g.data_ptr(), g.stride(1), g.stride(0), dx.data_ptr(), M, dw1.data_ptr(),
+                                                  dw2.data_ptr(), _stream()), "dm_field_mlp_bwd")
+        return dx, dw1, dw2
+
+
+def field_mlp(x_fm, w1, w2):
+    """[n_in, M] -> [n_out, M] (both feature-major, fp32)."""
+    _need_cuda(x_fm, w1, w2)
+    return _FieldMlp.apply(x_fm, w1, w2)
+
+
 # ------------------------------------------------------------------------------------------ shading
 class _Shade(torch.autograd.Function):
     @staticmethod

@@ -128,6 +128,15 @@ int dm_hashgrid2d_fwd(const float* x, long long x_rs, long long x_cs, const int3
 int dm_hashgrid2d_bwd(const float* x, long long x_rs, long long x_cs, const int32_t* m_dev, long long m_max, const float* denc,
                       long long denc_rs, long long denc_cs, int n_levels, const float* lv_scale, const uint32_t* lv_res,
                       const uint32_t* lv_size, const uint32_t* lv_offset, float radius, float* dtable, dm_stream_t stream);
+/* The feature network behind the encoding (dreammat_mesh.py:246-254 -> networks.py:150-187, VanillaMLP: bias-free
+ * Linear(n_in, 64) -> ReLU -> Linear(64, n_out), fp32), fused: x [n_in][M] and y / dx likewise by feature stride (points
+ * contiguous: the layout dm_hashgrid_fwd writes), w1 [64][n_in], w2 [n_out][64]; n_in = 16 | 32, n_out <= 8.  bwd writes dx
+ * and ADDS into dw1 / dw2 (float atomics, one set per wave); dy[m * dy_rs + k * dy_cs]. */
+int dm_field_mlp_fwd(const float* x, long long x_fs, long long M, const float* w1, const float* w2, int n_in, int n_out, float* y,
+                     long long y_fs, dm_stream_t stream);
+int dm_field_mlp_bwd(const float* x, long long x_fs, long long M, const float* w1, const float* w2, int n_in, int n_out,
+                     const float* dy, long long dy_rs, long long dy_cs, float* dx, long long dx_fs, float* dw1, float* dw2,
+                     dm_stream_t stream);
 
 /* ---- material / shading ------------------------------------------------------------------- */
 /* Pre-filtered environment atlas (envlight.EnvLight equivalents for all env maps, built once at

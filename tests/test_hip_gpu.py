@@ -224,6 +224,26 @@ def test_renderer_uv_space_field_vs_oracle(dev, envs):
         assert rel < 2e-3, (nm, rel)
 
 
+@pytest.mark.parametrize("n_in,n_out,M", [(32, 5, 100000), (16, 5, 4097), (32, 8, 63), (16, 3, 1)])
+def test_field_mlp_fused_vs_torch(dev, n_in, n_out, M):
+    """dm_field_mlp_fwd / _bwd (Linear -> ReLU -> Linear of the feature field in registers, weight gradients on the fp32 matrix
+    pipe) against torch fp32 on the CPU: outputs, input gradient, both weight gradients; ragged last batch, a single point."""
+    torch.manual_seed(6)
+    x = torch.randn(n_in, M)
+    w1, w2 = torch.randn(64, n_in) * 0.4, torch.randn(n_out, 64) * 0.3
+    dy = torch.randn(M, n_out)
+    xr, w1r, w2r = x.clone().requires_grad_(), w1.clone().requires_grad_(), w2.clone().requires_grad_()
+    ref = torch.relu(xr.t() @ w1r.t()) @ w2r.t()                        # [M, n_out]
+    ref.backward(dy)
+    xg, w1g, w2g = x.to(dev).requires_grad_(), w1.to(dev).requires_grad_(), w2.to(dev).requires_grad_()
+    assert hipops.field_mlp_ok(xg, w1g, w2g)
+    y = hipops.field_mlp(xg, w1g, w2g).t()                              # [M, n_out] view of the feature-major result
+    assert (y.detach().cpu() - ref.detach()).abs().max() <= 1e-5 * max(1.0, ref.abs().max().item())
+    y.backward(dy.to(dev))
+    for got, want, nm in ((xg.grad.cpu(), xr.grad, "dx"), (w1g.grad.cpu(), w1r.grad, "dw1"), (w2g.grad.cpu(), w2r.grad, "dw2")):
+        assert (got - want).abs().max() <= 2e-5 * max(1.0, want.abs().max().item()), (nm, float((got - want).abs().max()))
+
+
 def test_hashgrid_full_size_levels(dev):
     """all 16 levels of dreammat.yaml incl. the hashed ones (uint32 wrap-around index arithmetic)."""
     torch.manual_seed(1)
