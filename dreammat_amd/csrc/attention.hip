@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
     // ---- epilogue: normalise, store O[q][d]
     float l_tot = l_run + __shfl_xor(l_run, 32);
     float inv = 1.0f / l_tot;
+    if (a.lse && q_ok && hi == 0) a.lse[((long long)b * a.Hh + h) * a.Sq + q_row] = m_run + __builtin_amdgcn_logf(l_tot);
     if (q_ok) {
         __bf16* op = a.out + (long long)b * a.o_bs + (long long)q_row * a.o_ss + (long long)h * a.o_hs;
 #pragma unroll
@@ -607,10 +608,10 @@ const char* dm_attention_selected(void) { return kAttnNames[attn_mode()]; }
 //     multiple of 8 kv (vt_ds % 8 == 0)
 // out [B, Sq, Hh, D]  via strides.  All pointers 16 B aligned, all strides multiples of 8 elements
 // (out: multiples of 4).  D % 8 == 0, D <= 160.  scale = softmax scale (1/sqrt(D) for diffusers).
-int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* out, int B, int Hh, int Sq, int Skv,
-                          int D, long long q_bs, long long q_ss, long long q_hs, long long k_bs, long long k_ss,
-                          long long k_hs, long long vt_bs, long long vt_hs, long long vt_ds, long long o_bs,
-                          long long o_ss, long long o_hs, float scale, hipStream_t stream) {
+static int attention_fwd(const void* q, const void* k, const void* vt, void* out, float* lse, int B, int Hh, int Sq, int Skv,
+                         int D, long long q_bs, long long q_ss, long long q_hs, long long k_bs, long long k_ss,
+                         long long k_hs, long long vt_bs, long long vt_hs, long long vt_ds, long long o_bs,
+                         long long o_ss, long long o_hs, float scale, hipStream_t stream) {
     if (!q || !k || !vt || !out || B <= 0 || Hh <= 0 || Sq <= 0 || Skv <= 0 || D <= 0) return DM_ERR_ARG;
     if (D % 8 != 0 || D > 160) return DM_ERR_UNSUPPORTED;
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15 || ((uintptr_t)out & 7)) return DM_ERR_ARG;
@@ -624,7 +625,8 @@ int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* ou
     a.B = B; a.Hh = Hh; a.Sq = Sq; a.Skv = Skv; a.D = D;
     a.scale_log2 = scale * 1.4426950408889634f;
     a.timeline = nullptr;
-    const int mode = attn_mode();
+    a.lse = lse;
+    const int mode = lse ? kAttnStaged : attn_mode();     // the row statistics are an output of the generic kernel only
     // auto: the one-wave-per-SIMD kernel wherever a workgroup's 256 query rows are (nearly) filled and the sequence is long
     // enough to amortise its prologue (S >= 1024: 756 vs 738 TF/s at S = 1024, 1021 vs 980 at 4096, 981 vs 780 at batch 3;
     // v3l wins at S = 256: 375 vs 343, profiles/r03_probe_attn.json); cross-attention (77 keys) and short sequences: v3l
@@ -636,6 +638,26 @@ int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* ou
     if (D <= 96) return launch_attn<96>(a, stream);
     if (D <= 128) return launch_attn<128>(a, stream);
     return launch_attn<160>(a, stream);
+}
+
+int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* out, int B, int Hh, int Sq, int Skv,
+                          int D, long long q_bs, long long q_ss, long long q_hs, long long k_bs, long long k_ss,
+                          long long k_hs, long long vt_bs, long long vt_hs, long long vt_ds, long long o_bs,
+                          long long o_ss, long long o_hs, float scale, hipStream_t stream) {
+    return attention_fwd(q, k, vt, out, nullptr, B, Hh, Sq, Skv, D, q_bs, q_ss, q_hs, k_bs, k_ss, k_hs, vt_bs, vt_hs, vt_ds,
+                         o_bs, o_ss, o_hs, scale, stream);
+}
+
+// The forward of a DIFFERENTIATED attention (dm_attention_bwd_bf16, attn_bwd.hip): same arguments plus
+// lse [B, Hh, Sq] fp32 = rowmax + log2(rowsum) of the scaled scores in the log2 domain, from which the backward recomputes
+// the probabilities.  Always the register-staged generic kernel (the only one that keeps the unscaled running maximum).
+int dm_attention_fwd_lse_bf16(const void* q, const void* k, const void* vt, void* out, float* lse, int B, int Hh, int Sq,
+                              int Skv, int D, long long q_bs, long long q_ss, long long q_hs, long long k_bs,
+                              long long k_ss, long long k_hs, long long vt_bs, long long vt_hs, long long vt_ds,
+                              long long o_bs, long long o_ss, long long o_hs, float scale, hipStream_t stream) {
+    if (!lse) return DM_ERR_ARG;
+    return attention_fwd(q, k, vt, out, lse, B, Hh, Sq, Skv, D, q_bs, q_ss, q_hs, k_bs, k_ss, k_hs, vt_bs, vt_hs, vt_ds,
+                         o_bs, o_ss, o_hs, scale, stream);
 }
 
 }  // extern "C"

@@ -532,6 +532,82 @@ def attention(q, k, vt, heads, scale=None):
     return out
 
 
+ATTN_BWD_MAX_D = 128     # dm_attention_bwd_bf16 (csrc/attn_bwd.hip): head sizes up to 128
+
+
+def attention_train_ok(q, k, v, heads):
+    """the differentiated MFMA attention serves this call (bf16 on the device, head size a multiple of 8 up to 128,
+    16 B aligned rows); otherwise the caller composes the product from matmuls under autograd."""
+    D = q.shape[-1] // heads
+    return (q.is_cuda and q.dtype == k.dtype == v.dtype == torch.bfloat16 and D % 8 == 0 and D <= ATTN_BWD_MAX_D
+            and k.shape == v.shape and q.shape[0] * heads <= 65535)
+
+
+def _attention_fwd_lse(q, k, v, heads, scale):
+    """-> (q, k, v as handed to the kernel, out [B,Sq,C] bf16, lse [B,heads,Sq] fp32 = rowmax + log2(rowsum), log2 domain)."""
+    B, Sq, C = q.shape
+    Skv, D = k.shape[1], C // heads
+    q = q if q.stride(2) == 1 and q.stride(1) % 8 == 0 and q.stride(0) % 8 == 0 else q.contiguous()
+    if not (k.stride(2) == 1 and k.stride() == v.stride() and k.stride(1) % 8 == 0 and k.stride(0) % 8 == 0):
+        k, v = k.contiguous(), v.contiguous()
+    vt = torch.zeros(B, C, (Skv + 7) // 8 * 8, device=q.device, dtype=torch.bfloat16)
+    vt[:, :, :Skv] = v.transpose(1, 2)
+    out = torch.empty(B, Sq, C, device=q.device, dtype=torch.bfloat16)
+    lse = torch.empty(B, heads, Sq, device=q.device, dtype=torch.float32)
+    with _Timed(f"attention_fwd_lse_bf16[Sq={Sq},Skv={Skv},h={heads},D={D}]", 4.0 * B * Sq * Skv * C):
+        check(_lib.lib().dm_attention_fwd_lse_bf16(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), lse.data_ptr(),
+                                                   B, heads, Sq, Skv, D, q.stride(0), q.stride(1), D, k.stride(0),
+                                                   k.stride(1), D, vt.stride(0), D * vt.stride(1), vt.stride(1),
+                                                   out.stride(0), out.stride(1), D, scale, _stream()),
+              "dm_attention_fwd_lse_bf16")
+    return q, k, v, out, lse
+
+
+def attention_fwd_lse(q, k, v, heads, scale):
+    """forward half of attention_train on its own (tests): -> (out, lse)."""
+    _need_cuda(q, k, v)
+    return _attention_fwd_lse(q, k, v, heads, float(scale))[3:]
+
+
+class _AttentionTrain(torch.autograd.Function):
+    """softmax(q k^T / sqrt(D)) v under autograd: forward = the generic MFMA kernel, which also writes one statistic per
+    query row; backward = dm_attention_bwd_bf16 (probabilities recomputed tile by tile, nothing S x S stored)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale):
+        q, k, v, out, lse = _attention_fwd_lse(q, k, v, heads, scale)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.heads, ctx.scale = heads, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        heads = ctx.heads
+        B, Sq, C = q.shape
+        Skv, D = k.shape[1], C // heads
+        # q, out, dout and dq share one set of strides in the kernel (k, v, dk, dv another)
+        qc = q if q.is_contiguous() else q.contiguous()
+        kc, vc = (k, v) if k.is_contiguous() and v.is_contiguous() else (k.contiguous(), v.contiguous())
+        dout = dout.to(torch.bfloat16).contiguous()
+        dq, dk, dv = torch.empty_like(qc), torch.empty_like(kc), torch.empty_like(vc)
+        delta = torch.empty_like(lse)
+        with _Timed(f"attention_bwd_bf16[Sq={Sq},Skv={Skv},h={heads},D={D}]", 14.0 * B * Sq * Skv * C):
+            check(_lib.lib().dm_attention_bwd_bf16(qc.data_ptr(), kc.data_ptr(), vc.data_ptr(), out.data_ptr(), dout.data_ptr(),
+                                                   lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                                   dv.data_ptr(), B, heads, Sq, Skv, D, Sq * C, C, D, Skv * C, C, D,
+                                                   ctx.scale, _stream()), "dm_attention_bwd_bf16")
+        return dq, dk, dv, None, None
+
+
+def attention_train(q, k, v, heads, scale=None):
+    """differentiable attention: q [B,Sq,C], k, v [B,Skv,C] bf16 (C = heads*D) -> [B,Sq,C] bf16."""
+    _need_cuda(q, k, v)
+    assert attention_train_ok(q, k, v, heads), "attention_train: bf16 device tensors with head size % 8 == 0, <= 128"
+    sc = float(scale) if scale is not None else float(q.shape[-1] // heads) ** -0.5
+    return _AttentionTrain.apply(q, k, v, heads, sc)
+
+
 # ------------------------------------------------------------------------------------------ convolution
 CONV_MAX_TENSOR_BYTES = 0xffffff00      # per-launch limit of the buffer-addressed kernels (tests lower it)
 

@@ -275,15 +275,17 @@ def project_vt(v_weight, v_bias, kv_src, kv_len):
 
 def attention_core(q, k, v_weight, v_bias, kv_src, heads, kv_len):
     """softmax(QK^T/sqrt(d)) V with V = kv_src @ v_weight^T (+bias).  q [B,Sq,C], k [B,Skv,C].
-    CUDA+bf16 -> MFMA kernel (V produced directly transposed by the projection GEMM);
-    otherwise plain fp32-style math (autograd-capable)."""
+    CUDA+bf16 -> MFMA kernels (inference: V produced directly transposed by the projection GEMM; under autograd:
+    hipops.attention_train, whose backward recomputes the probabilities); otherwise plain fp32-style math."""
     B, Sq, C = q.shape
     D = C // heads
     needs_grad = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or kv_src.requires_grad
                                               or v_weight.requires_grad)
-    if q.is_cuda and q.dtype == torch.bfloat16 and not needs_grad:     # the MFMA kernel is forward-only
+    if q.is_cuda and q.dtype == torch.bfloat16 and not needs_grad:     # inference: V arrives transposed from its projection
         return hipops.attention(q, k[:, :kv_len], project_vt(v_weight, v_bias, kv_src, kv_len), heads)
     v = F.linear(kv_src, v_weight, v_bias)
+    if q.is_cuda and hipops.attention_train_ok(q, k, v, heads):        # differentiated (ControlNet training): MFMA fwd + bwd
+        return hipops.attention_train(q, k[:, :kv_len], v[:, :kv_len], heads)
     qh = q.view(B, Sq, heads, D).transpose(1, 2)
     kh = k[:, :kv_len].reshape(B, kv_len, heads, D).transpose(1, 2)
     vh = v[:, :kv_len].reshape(B, kv_len, heads, D).transpose(1, 2)

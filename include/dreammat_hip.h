@@ -269,6 +269,20 @@ int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* ou
                           int D, long long q_bs, long long q_ss, long long q_hs, long long k_bs, long long k_ss,
                           long long k_hs, long long vt_bs, long long vt_hs, long long vt_ds, long long o_bs,
                           long long o_ss, long long o_hs, float scale, dm_stream_t stream);
+/* Differentiated attention (the trainable transformer blocks of the ControlNet training loop,
+ * controlnet_train/diffusers_train_controlnet.py:858-915 -- there torch autograd runs diffusers' attention processors).
+ * Forward: dm_attention_fwd_bf16 plus lse [B,Hh,Sq] fp32 = rowmax + log2(rowsum) of the scaled scores (log2 domain).
+ * Backward: q, out, dout, dq share (q_bs,q_ss,q_hs); k, v, dk, dv share (k_bs,k_ss,k_hs); v is [B,Skv,Hh,D] (not
+ * transposed); delta [B,Hh,Sq] fp32 is scratch.  Nothing S x S is stored, no atomics (bit-reproducible).
+ * D % 8 == 0, D <= 128 (DM_ERR_UNSUPPORTED above); pointers 16 B aligned, strides multiples of 8 elements. */
+int dm_attention_fwd_lse_bf16(const void* q, const void* k, const void* vt, void* out, float* lse, int B, int Hh, int Sq,
+                              int Skv, int D, long long q_bs, long long q_ss, long long q_hs, long long k_bs,
+                              long long k_ss, long long k_hs, long long vt_bs, long long vt_hs, long long vt_ds,
+                              long long o_bs, long long o_ss, long long o_hs, float scale, dm_stream_t stream);
+int dm_attention_bwd_bf16(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
+                          float* delta, void* dq, void* dk, void* dv, int B, int Hh, int Sq, int Skv, int D,
+                          long long q_bs, long long q_ss, long long q_hs, long long k_bs, long long k_ss, long long k_hs,
+                          float scale, dm_stream_t stream);
 /* Kernel family for every later dm_attention_fwd_bf16 call of the process: "auto" (default: one wave per SIMD with 256
  * query rows per workgroup for 64-wide heads at S >= 1024, the 4 x 32-row LDS-DMA kernel otherwise, the register-staged
  * generic kernel for head sizes 40 / 80 / 160), or "w64" / "v3l" / "staged" to force one (shapes outside its domain fall

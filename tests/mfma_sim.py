@@ -188,3 +188,142 @@ if __name__ == "__main__":
         got = attention_wave_sim(Q, K, V, sc)
         got3, nb = attention_wave_sim_v3(Q, K, V, sc)
         print(D, Skv, np.abs(got - ref).max(), np.abs(got3 - ref).max(), nb)
+
+
+# ---------------------------------------------------------------------------------------------- attention backward
+def _mfma_fast(a_frag, b_frag, c_frag):
+    """mfma_32x32x16 with the lane loops vectorised (same layouts)."""
+    lanes = np.arange(64); hi = lanes >> 5; l31 = lanes & 31
+    A = np.zeros((32, 16)); Bm = np.zeros((16, 32))
+    for j in range(8):
+        A[l31, 8 * hi + j] = a_frag[:, j]
+        Bm[8 * hi + j, l31] = b_frag[:, j]
+    Dm = A @ Bm
+    out = c_frag.copy()
+    for r in range(16):
+        out[:, r] += Dm[(r & 3) + 8 * (r >> 2) + 4 * hi, l31]
+    return out
+
+
+def _stage_rows(X, r0, DP):
+    """load_rows + write_rowmajor of csrc/attn_bwd.hip: a [64, DP] LDS image, zeros past the end of X / past D."""
+    img = np.zeros((64, DP))
+    n = max(0, min(64, X.shape[0] - r0))
+    img[:n, :X.shape[1]] = X[r0:r0 + n]
+    return img
+
+
+def _stage_transposed(X, r0, DP):
+    """load_rows + write_transposed: [DP, 64] image, element (d, tpos(row)) = X[r0 + row][d], chunk by chunk like the kernel."""
+    img = np.zeros((DP, 64))
+    CPR = DP // 8
+    for c in range(64 * CPR):
+        row, col8 = c // CPR, c % CPR
+        chunk = np.zeros(8)
+        if r0 + row < X.shape[0] and col8 * 8 < X.shape[1]:
+            chunk = X[r0 + row, col8 * 8: col8 * 8 + 8]
+        for e in range(8):
+            img[8 * col8 + e, _swap23(row)] = chunk[e]
+    return img
+
+
+def _own_frags(X, rows, ok, DP):
+    """load_own: B-operand fragments [KSTEPS, 64, 8] of the row each lane owns."""
+    lanes = np.arange(64); hi = lanes >> 5
+    f = np.zeros((DP // 16, 64, 8))
+    for kk in range(DP // 16):
+        for l in range(64):
+            d = 16 * kk + 8 * hi[l]
+            if ok[l] and d < X.shape[1]:
+                f[kk, l] = X[rows[l], d: d + 8]
+    return f
+
+
+def _a_frag(img, row0, col0):
+    """A operand read: lane l takes img[row0 + (l & 31)][col0 + 8 (l >> 5) .. + 7]."""
+    lanes = np.arange(64); hi = lanes >> 5; l31 = lanes & 31
+    return np.stack([img[row0 + l31[l], col0 + 8 * hi[l]: col0 + 8 * hi[l] + 8] for l in range(64)])
+
+
+def _store_own(acc, scale, D, DP):
+    """store_own: [32, D] from the lanes' accumulator columns."""
+    lanes = np.arange(64); hi = lanes >> 5; l31 = lanes & 31
+    out = np.zeros((32, DP))
+    for dt in range(DP // 32):
+        for g in range(4):
+            for l in range(64):
+                d = 32 * dt + 8 * g + 4 * hi[l]
+                out[l31[l], d: d + 4] = acc[dt][l, 4 * g: 4 * g + 4] * scale
+    return out[:, :D]
+
+
+def attention_bwd_dq_wave_sim(Q, K, V, O, dO, lse2, scale, DP):
+    """One wave of k_attn_bwd_dq<DP> (csrc/attn_bwd.hip): its 32 query rows Q, O, dO [<=32, D] against all of K, V
+    [Skv, D]; lse2 = rowmax + log2(rowsum) of the scaled scores in the log2 domain.  Returns dQ [n, D] and delta [n]."""
+    n, D = Q.shape
+    Skv = K.shape[0]
+    lanes = np.arange(64); hi = lanes >> 5; l31 = lanes & 31
+    ok = l31 < n
+    rows = np.minimum(l31, n - 1)
+    qf, dof, of = (_own_frags(X, rows, ok, DP) for X in (Q, dO, O))
+    part = (dof * of).sum((0, 2))
+    delta_q = part + part[lanes ^ 32]
+    lse_q = np.where(ok, lse2[rows], 0.0)
+    sl2 = scale * 1.4426950408889634
+    DT, KSTEPS = DP // 32, DP // 16
+    dqT = np.zeros((DT, 64, 16))
+    for j in range((Skv + 63) // 64):
+        kb, vb, ktb = _stage_rows(K, 64 * j, DP), _stage_rows(V, 64 * j, DP), _stage_transposed(K, 64 * j, DP)
+        dsf = [None] * 4
+        for t in range(2):
+            s = np.zeros((64, 16)); dp = np.zeros((64, 16))
+            for kk in range(KSTEPS):
+                s = _mfma_fast(_a_frag(kb, 32 * t, 16 * kk), qf[kk], s)
+            for kk in range(KSTEPS):
+                dp = _mfma_fast(_a_frag(vb, 32 * t, 16 * kk), dof[kk], dp)
+            p = np.exp2(s * sl2 - lse_q[:, None])
+            ds = p * (dp - delta_q[:, None])
+            dsf[2 * t], dsf[2 * t + 1] = ds[:, :8], ds[:, 8:]
+        for dt in range(DT):
+            for ks in range(4):
+                dqT[dt] = _mfma_fast(_a_frag(ktb, 32 * dt, 16 * ks), dsf[ks], dqT[dt])
+    return _store_own(dqT, scale, D, DP)[:n], delta_q[:n]
+
+
+def attention_bwd_dkv_wave_sim(Q, K, V, dO, lse2, delta, scale, DP):
+    """One wave of k_attn_bwd_dkv<DP>: its 32 key rows K, V [<=32, D] against all query rows Q, dO [Sq, D]."""
+    n, D = K.shape
+    Sq = Q.shape[0]
+    lanes = np.arange(64); hi = lanes >> 5; l31 = lanes & 31
+    ok = l31 < n
+    rows = np.minimum(l31, n - 1)
+    kf, vf = _own_frags(K, rows, ok, DP), _own_frags(V, rows, ok, DP)
+    sl2 = scale * 1.4426950408889634
+    DT, KSTEPS = DP // 32, DP // 16
+    dvT = np.zeros((DT, 64, 16)); dkT = np.zeros((DT, 64, 16))
+    for j in range((Sq + 63) // 64):
+        q0 = 64 * j
+        qb, dob = _stage_rows(Q, q0, DP), _stage_rows(dO, q0, DP)
+        qtb, dotb = _stage_transposed(Q, q0, DP), _stage_transposed(dO, q0, DP)
+        lds_l = np.array([lse2[q0 + r] if q0 + r < Sq else np.inf for r in range(64)])
+        lds_d = np.array([delta[q0 + r] if q0 + r < Sq else 0.0 for r in range(64)])
+        pf, dsf = [None] * 4, [None] * 4
+        for t in range(2):
+            s = np.zeros((64, 16)); dp = np.zeros((64, 16))
+            for kk in range(KSTEPS):
+                s = _mfma_fast(_a_frag(qb, 32 * t, 16 * kk), kf[kk], s)
+            for kk in range(KSTEPS):
+                dp = _mfma_fast(_a_frag(dob, 32 * t, 16 * kk), vf[kk], dp)
+            for g in range(4):
+                for e in range(4):
+                    row = 32 * t + 8 * g + 4 * hi + e
+                    p = np.exp2(s[:, 4 * g + e] * sl2 - lds_l[row])
+                    s[:, 4 * g + e] = p
+                    dp[:, 4 * g + e] = p * (dp[:, 4 * g + e] - lds_d[row])
+            pf[2 * t], pf[2 * t + 1] = s[:, :8], s[:, 8:]
+            dsf[2 * t], dsf[2 * t + 1] = dp[:, :8], dp[:, 8:]
+        for dt in range(DT):
+            for ks in range(4):
+                dvT[dt] = _mfma_fast(_a_frag(dotb, 32 * dt, 16 * ks), pf[ks], dvT[dt])
+                dkT[dt] = _mfma_fast(_a_frag(qtb, 32 * dt, 16 * ks), dsf[ks], dkT[dt])
+    return _store_own(dkT, scale, D, DP)[:n], _store_own(dvT, 1.0, D, DP)[:n]

@@ -203,7 +203,7 @@ def test_c_abi_exports_every_declared_symbol():
     """The library loads on a GPU-less box and exports exactly what include/dreammat_hip.h declares."""
     import os, re
     L = _lib.lib()
-    assert L.dm_abi_version() == _lib.ABI_VERSION == 4
+    assert L.dm_abi_version() == _lib.ABI_VERSION == 5
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "dreammat_hip.h")).read()
     declared = set(re.findall(r"\b(dm_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
@@ -250,6 +250,31 @@ def test_attention_v3_index_math_and_rebase_logic_on_mfma_model():
             assert nb >= (2 if spike and Skv >= 200 else 1)
         O0, _ = attention_wave_sim_v3(Q, K, V, D ** -0.5, thr=0.0)      # THR = 0 and THR = 8 agree to rounding
         assert np.abs(O0 - O).max() < 1e-10
+
+
+def test_attention_backward_index_math_on_mfma_model():
+    """k_attn_bwd_dq / k_attn_bwd_dkv (csrc/attn_bwd.hip): the staging (row-major + transposed copy with the accumulator row
+    order), the fragment reads, the accumulator -> B-operand packing and the row statistics, followed literally on the
+    numpy MFMA model, against the closed-form gradient of softmax(QK^T.scale)V; ragged sequences, D < DP."""
+    from tests.mfma_sim import attention_bwd_dkv_wave_sim, attention_bwd_dq_wave_sim
+    rng = np.random.default_rng(2)
+    for D, DP, Sq, Skv in ((64, 64, 100, 77), (32, 32, 64, 130), (40, 64, 70, 64)):
+        Q = rng.standard_normal((Sq, D)); K = rng.standard_normal((Skv, D)); V = rng.standard_normal((Skv, D))
+        dO = rng.standard_normal((Sq, D))
+        sc = D ** -0.5
+        S = Q @ K.T * sc
+        m = S.max(1, keepdims=True); P = np.exp(S - m); l = P.sum(1, keepdims=True); P /= l
+        O = P @ V
+        lse2 = (m[:, 0] + np.log(l[:, 0])) * 1.4426950408889634
+        delta = (dO * O).sum(1)
+        dS = P * (dO @ V.T - delta[:, None])
+        dQ, dK, dV = dS @ K * sc, dS.T @ Q * sc, P.T @ dO
+        for q0 in range(0, Sq, 32):
+            dq, dl = attention_bwd_dq_wave_sim(Q[q0:q0 + 32], K, V, O[q0:q0 + 32], dO[q0:q0 + 32], lse2[q0:q0 + 32], sc, DP)
+            assert np.abs(dq - dQ[q0:q0 + 32]).max() < 1e-12 and np.abs(dl - delta[q0:q0 + 32]).max() < 1e-12
+        for k0 in range(0, Skv, 32):
+            dk, dv = attention_bwd_dkv_wave_sim(Q, K[k0:k0 + 32], V[k0:k0 + 32], dO, lse2, delta, sc, DP)
+            assert np.abs(dk - dK[k0:k0 + 32]).max() < 1e-12 and np.abs(dv - dV[k0:k0 + 32]).max() < 1e-12
 
 
 def test_bvh_build_and_traversal_core_vs_brute_force(hostemu):

@@ -431,6 +431,78 @@ def test_attention_vs_fp32_reference(dev, B, h, Sq, Skv, D, attn_variant):
     assert (out - ref).abs().mean().item() < 2e-3
 
 
+ATTN_BWD_CASES = [  # (B, heads, Sq, Skv, D): self / cross attention of the SD-2.1 and tiny nets, ragged tails, padded head sizes
+    (2, 2, 256, 256, 64), (1, 5, 1024, 1024, 64), (2, 5, 1024, 77, 64), (1, 1, 100, 77, 32), (1, 2, 300, 130, 64),
+    (2, 2, 64, 64, 32), (1, 2, 200, 136, 40), (1, 1, 130, 200, 80), (1, 2, 129, 65, 128)]
+
+
+def _attention_grads_fp32(qb, kb, vb, dob, h):
+    """out, dq, dk, dv of softmax(QK^T/sqrt(D))V in fp32 on the bf16-rounded inputs."""
+    B, Sq, C = qb.shape
+    D = C // h
+    q, k, v = (t.float().cpu().requires_grad_(True) for t in (qb, kb, vb))
+    qh, kh, vh = (t.view(B, -1, h, D).transpose(1, 2) for t in (q, k, v))
+    s = qh @ kh.transpose(-1, -2) * D ** -0.5
+    out = (torch.softmax(s, dim=-1) @ vh).transpose(1, 2).reshape(B, Sq, C)
+    out.backward(dob.float().cpu())
+    lse2 = torch.logsumexp(s.detach(), dim=-1) * 1.4426950408889634        # [B, h, Sq]
+    return out.detach(), q.grad, k.grad, v.grad, lse2
+
+
+@pytest.mark.parametrize("B,h,Sq,Skv,D", ATTN_BWD_CASES)
+def test_attention_backward_vs_fp32_autograd(dev, B, h, Sq, Skv, D):
+    """dm_attention_fwd_lse_bf16 + dm_attention_bwd_bf16 (the differentiated attention of the ControlNet training loop)
+    against fp32 autograd on the same bf16-rounded inputs: bf16 tolerance (P and dS are rounded to bf16 for the second
+    products, like the forward's P), and bit-reproducible (no atomics)."""
+    torch.manual_seed(1)
+    C = h * D
+    qb, kb, vb = (torch.randn(B, S, C).to(dev).bfloat16().requires_grad_(True) for S in (Sq, Skv, Skv))
+    dob = torch.randn(B, Sq, C).to(dev).bfloat16()
+    assert hipops.attention_train_ok(qb, kb, vb, h)
+    out = hipops.attention_train(qb, kb, vb, h)
+    out.backward(dob)
+    ref_out, rq, rk, rv, lse2 = _attention_grads_fp32(qb.detach(), kb.detach(), vb.detach(), dob, h)
+    o2, lse = hipops.attention_fwd_lse(qb.detach(), kb.detach(), vb.detach(), h, D ** -0.5)
+    assert torch.equal(o2, out.detach())
+    assert (lse.cpu() - lse2).abs().max().item() < 2e-3
+    assert (out.detach().float().cpu() - ref_out).abs().max().item() < 2e-2
+    report = {}
+    for name, got, ref in (("dq", qb.grad, rq), ("dk", kb.grad, rk), ("dv", vb.grad, rv)):
+        got = got.float().cpu()
+        report[name] = (bool(torch.isfinite(got).all()), ((got - ref).norm() / ref.norm()).item(),
+                        ((got - ref).abs().max() / ref.abs().max()).item())
+    print("attn_bwd", (B, h, Sq, Skv, D), report)
+    assert all(fin and rel < 1e-2 and worst < 3e-2 for fin, rel, worst in report.values()), report
+    g1 = [t.grad.clone() for t in (qb, kb, vb)]
+    for t in (qb, kb, vb):
+        t.grad = None
+    hipops.attention_train(qb, kb, vb, h).backward(dob)
+    assert all(torch.equal(a, t.grad) for a, t in zip(g1, (qb, kb, vb)))
+
+
+def test_attention_core_differentiated_path_uses_the_mfma_backward(dev):
+    """sd/layers.attention_core under autograd on the device in bf16 (the trainable ControlNet copy): forward + backward
+    run dm_attention_fwd_lse_bf16 / dm_attention_bwd_bf16 -- no S x S softmax in the autograd graph -- and the gradients
+    of the inputs and of the V projection agree with the composed fp32 product."""
+    from dreammat_amd.sd import layers
+    torch.manual_seed(2)
+    B, S, h, D = 2, 192, 2, 64
+    C = h * D
+    x = (torch.randn(B, S, C) * 0.5).to(dev).bfloat16()
+    q, k = (torch.randn(B, S, C).to(dev).bfloat16().requires_grad_(True) for _ in range(2))
+    wv = (torch.randn(C, C) * C ** -0.5).to(dev).bfloat16().requires_grad_(True)
+    dout = torch.randn(B, S, C).to(dev).bfloat16()
+    out = layers.attention_core(q, k, wv, None, x, h, S)
+    assert type(out.grad_fn).__name__ == "_AttentionTrainBackward"
+    out.backward(dout)
+    q32, k32, w32 = (t.detach().float().cpu().requires_grad_(True) for t in (q, k, wv))
+    ref = layers.attention_core(q32, k32, w32, None, x.float().cpu(), h, S)
+    ref.backward(dout.float().cpu())
+    for name, got, want in (("dq", q.grad, q32.grad), ("dk", k.grad, k32.grad), ("dWv", wv.grad, w32.grad)):
+        rel = ((got.float().cpu() - want).norm() / want.norm()).item()
+        assert rel < 2e-2, (name, rel)
+
+
 @pytest.mark.parametrize("attn_variant", ATTN_VARIANTS, indirect=True)
 def test_attention_online_softmax_rescale_branch(dev, attn_variant):
     """spiked keys late in the sequence force large running-max jumps (guide rule 26); a row whose first tile is dominated
