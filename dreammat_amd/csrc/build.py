@@ -23,6 +23,7 @@ SOURCES = {
     "attn_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "conv.hip": [],
     "conv_small.hip": [],
+    "conv_wgrad.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "groupnorm.hip": [],
     "transformer.hip": [],
     "adam.hip": [],

@@ -754,6 +754,77 @@ def conv3x3_s2_autograd(x_nhwc, w_fwd, w_dgrad, bias, lead_pad):
     return _Conv3x3S2.apply(x_nhwc, w_fwd, w_dgrad, bias, lead_pad)
 
 
+def conv3x3_train_ok(x_nhwc, weight, stride, padding):
+    """the trainable-conv route (MFMA forward, data gradient and weight gradient) serves this layer and input"""
+    if not (x_nhwc.is_cuda and x_nhwc.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.shape[2:] == (3, 3)
+            and tuple(padding) == (1, 1) and tuple(stride) in ((1, 1), (2, 2))):
+        return False
+    B, H, W, Cin = x_nhwc.shape
+    Cout, s = weight.shape[0], stride[0]
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    if Cin % 64 or Cout % 64 or H % s or W % s or Wo > 64 or Wo & (Wo - 1) or (Ho * Wo) % 64 or Ho % (64 // Wo):
+        return False
+    rows_in, cols_in = s * (64 // Wo - 1) + 3, s * (Wo - 1) + 3
+    return (64 + rows_in * cols_in) * 192 <= 160 * 1024
+
+
+def conv3x3_wgrad(x_nhwc, dy_nhwc, stride):
+    """dW [Cout, Cin, 3, 3] fp32 of a 3x3 / pad 1 conv from its NHWC bf16 input and output gradient (dm_conv3x3_wgrad_nhwc_bf16)."""
+    _need_cuda(x_nhwc, dy_nhwc)
+    B, H, W, Cin = x_nhwc.shape
+    _, Ho, Wo, Cout = dy_nhwc.shape
+    splits = int(_lib.lib().dm_conv3x3_wgrad_splits(B, Ho, Wo, Cin, Cout))
+    assert splits > 0 and x_nhwc.is_contiguous() and dy_nhwc.is_contiguous()
+    part = torch.empty(splits, Cout, 3, 3, Cin, device=x_nhwc.device, dtype=torch.float32)
+    with _Timed(f"conv3x3_wgrad[{Cin}->{Cout},{Ho}x{Wo},s{stride}]", 18.0 * B * Ho * Wo * Cin * Cout):
+        check(_lib.lib().dm_conv3x3_wgrad_nhwc_bf16(x_nhwc.data_ptr(), dy_nhwc.data_ptr(), part.data_ptr(), B, H, W, Cin, Cout,
+                                                    int(stride), _stream()), "dm_conv3x3_wgrad_nhwc_bf16")
+    return (part.sum(0) if splits > 1 else part[0]).permute(0, 3, 1, 2)
+
+
+class _Conv3x3Train(torch.autograd.Function):
+    """3x3 / pad 1 conv (stride 1 or 2) with TRAINABLE weights, all three products on the MFMA kernels: forward and data
+    gradient = the implicit-GEMM kernel (the data gradient on the flipped, channel-swapped weights; stride 2: on the
+    zero-inserted output gradient), weight gradient = dm_conv3x3_wgrad_nhwc_bf16.  No im2col buffer anywhere."""
+
+    @staticmethod
+    def forward(ctx, x_nhwc, weight, bias, stride):
+        wd = weight.detach()
+        Cout, Cin = wd.shape[:2]
+        B, H, W, _ = x_nhwc.shape
+        ctx.save_for_backward(x_nhwc, wd)
+        ctx.stride, ctx.has_bias = stride, bias is not None
+        w_fwd = wd.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+        return conv3x3_nhwc(x_nhwc, w_fwd, bias.detach() if bias is not None else None, stride, (1, 1),
+                            ((H - 1) // stride + 1, (W - 1) // stride + 1))
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wd = ctx.saved_tensors
+        g = g.contiguous()
+        B, H, W, Cin = x.shape
+        Cout = wd.shape[0]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            w_dgrad = wd.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous()
+            if ctx.stride == 1:
+                dx = conv3x3_nhwc(g, w_dgrad, None, 1, (1, 1))
+            else:
+                g_up = torch.zeros(B, H, W, Cout, device=g.device, dtype=g.dtype)
+                g_up[:, 0::2, 0::2] = g
+                dx = conv3x3_nhwc(g_up, w_dgrad, None, 1, (1, 1), (H, W))
+        if ctx.needs_input_grad[1]:
+            dw = conv3x3_wgrad(x, g, ctx.stride).to(wd.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = g.float().sum((0, 1, 2)).to(wd.dtype)
+        return dx, dw, db, None
+
+
+def conv3x3_train(x_nhwc, weight, bias, stride):
+    """y [B,Ho,Wo,Cout] = conv3x3(x) + bias, differentiable wrt x, weight and bias (see conv3x3_train_ok)."""
+    return _Conv3x3Train.apply(x_nhwc, weight, bias, int(stride))
+
+
 # ------------------------------------------------------------------------------------------ group norm
 def _gn_fwd(x_nhwc, gamma, beta, eps, act, keep_for_backward=True):
     """keep_for_backward=False: the 2-launch inference entry (coefficients formed inside the apply kernel, nothing saved)."""

@@ -153,6 +153,11 @@ class Conv2d(nn.Conv2d):
               and (Cout % 64 == 0 or narrow) and self.stride[0] == self.stride[1] and self._frozen()
               and (not needs_grad or (self.stride[0] == 1 and self.padding == (1, 1) and Cin % 64 == 0)))
         if not ok:
+            if CONV_BACKEND == "mfma" and not self._frozen():
+                xn = x.permute(0, 2, 3, 1).contiguous()
+                if hipops.conv3x3_train_ok(xn, self.weight, self.stride, self.padding):
+                    # trainable layer (ControlNet training): forward, data gradient and weight gradient on the MFMA kernels
+                    return hipops.conv3x3_train(xn, self.weight, self.bias, self.stride[0]).permute(0, 3, 1, 2)
             return self._forward_gemm(x)
         w_fwd, w_dgrad = self._prepared()
         bias = self._bias_p

@@ -308,6 +308,16 @@ int dm_conv3x3_nhwc_bf16_fused(const void* x, const void* w, const void* bias, c
                                void* y, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int stride,
                                int pad_y, int pad_x, dm_stream_t stream);
 
+/* Weight gradient of a 3x3 / pad 1 convolution with stride 1 or 2 -- the trainable convolutions of the ControlNet training
+ * loop (controlnet_train/diffusers_train_controlnet.py:858-915: torch autograd through F.conv2d there).
+ * x [B,H,W,Cin], dy [B,Ho,Wo,Cout] bf16 NHWC with Ho = (H - 1) / stride + 1; part [splits][Cout][3][3][Cin] fp32 where
+ * splits = dm_conv3x3_wgrad_splits(B, Ho, Wo, Cin, Cout): dW = the sum over the leading dimension (every split writes all of
+ * its slice: no zero fill, no atomics).  The data gradient is dm_conv3x3_nhwc_bf16 on the flipped, channel-swapped weights.
+ * Cin % 64 == 0, Cout % 64 == 0, Wo a power of two <= 64, Ho * Wo % 64 == 0 (DM_ERR_UNSUPPORTED otherwise; splits = 0). */
+int dm_conv3x3_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout);
+int dm_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* part, int B, int H, int W, int Cin, int Cout, int stride,
+                               dm_stream_t stream);
+
 /* The few-channel stem convolutions of the same nets (ControlNetConditioningEmbedding 22->16, 16->16, 16->32 s2, 32->32,
  * 32->96 s2; conv_in 4->320): direct form, one thread per output pixel x 16 output channels, no im2col.  Same tensor
  * layouts as dm_conv3x3_nhwc_bf16; Cin in {4, 8, 16, 22, 32}, Cout % 16 == 0; act = 1 applies the SiLU that follows these

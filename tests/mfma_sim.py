@@ -327,3 +327,60 @@ def attention_bwd_dkv_wave_sim(Q, K, V, dO, lse2, delta, scale, DP):
                 dvT[dt] = _mfma_fast(_a_frag(dotb, 32 * dt, 16 * ks), pf[ks], dvT[dt])
                 dkT[dt] = _mfma_fast(_a_frag(qtb, 32 * dt, 16 * ks), dsf[ks], dkT[dt])
     return _store_own(dkT, scale, D, DP)[:n], _store_own(dvT, 1.0, D, DP)[:n]
+
+
+# ---------------------------------------------------------------------------------------------- conv weight gradient
+def ds_read_tr16_b64(lds, addr):
+    """ds_read_b64_tr_b16 as measured on gfx950 (tools/tr_probe.cpp): lane 16 g + i receives, for j = 0..3, element (i & 3)
+    of the 4 consecutive 16-bit elements addressed by lane 16 g + 4 j + (i >> 2).  lds: flat array, addr [64] element indices."""
+    out = np.zeros((64, 4))
+    for l in range(64):
+        g, i = l >> 4, l & 15
+        for j in range(4):
+            out[l, j] = lds[addr[16 * g + 4 * j + (i >> 2)] + (i & 3)]
+    return out
+
+
+def conv_wgrad_workgroup_sim(x, dy, stride, co0=0, ci0=0):
+    """One workgroup of k_conv3x3_wgrad (csrc/conv_wgrad.hip) over all chunks: x [B,H,W,Cin], dy [B,Ho,Wo,Cout] ->
+    dW[co0:co0+64, 3, 3, ci0:ci0+64].  Follows the kernel's staging, per-lane transposing-read addresses and fragment order."""
+    B, H, W, Cin = x.shape
+    _, Ho, Wo, Cout = dy.shape
+    PITCH = 96                                   # elements (192 bytes)
+    rpc = 64 // Wo
+    rows_in, cols_in = stride * (rpc - 1) + 3, stride * (Wo - 1) + 3
+    lanes = np.arange(64); hi = lanes >> 5; l31 = lanes & 31; i16 = lanes & 15; g1 = (lanes >> 4) & 1
+    out = np.zeros((64, 9, 64))
+    for wave in range(4):
+        wm, wn = wave >> 1, wave & 1
+        off_a = np.zeros((4, 2, 64), dtype=np.int64); off_b = np.zeros((4, 2, 64), dtype=np.int64)
+        for ks in range(4):
+            for r in range(2):
+                p = 16 * ks + 8 * hi + 4 * r + (i16 >> 2)
+                off_a[ks, r] = p * PITCH + wm * 32 + 16 * g1 + 4 * (i16 & 3)
+                yl, xl = p // Wo, p % Wo
+                off_b[ks, r] = ((yl * stride) * cols_in + xl * stride) * PITCH + wn * 32 + 16 * g1 + 4 * (i16 & 3)
+        acc = np.zeros((9, 64, 16))
+        for c in range(B * Ho // rpc):
+            b, y0 = c // (Ho // rpc), (c % (Ho // rpc)) * rpc
+            dy_img = np.zeros(64 * PITCH); x_img = np.zeros(rows_in * cols_in * PITCH)
+            flat = dy[b].reshape(Ho * Wo, Cout)
+            for px in range(64):
+                dy_img[px * PITCH: px * PITCH + 64] = flat[y0 * Wo + px, co0:co0 + 64]
+            for pix in range(rows_in * cols_in):
+                ry, rx = pix // cols_in, pix % cols_in
+                yin, xin = stride * y0 - 1 + ry, rx - 1
+                if 0 <= yin < H and 0 <= xin < W:
+                    x_img[pix * PITCH: pix * PITCH + 64] = x[b, yin, xin, ci0:ci0 + 64]
+            af = [np.concatenate([ds_read_tr16_b64(dy_img, off_a[ks, 0]), ds_read_tr16_b64(dy_img, off_a[ks, 1])], 1)
+                  for ks in range(4)]
+            for t in range(9):
+                tap = ((t // 3) * cols_in + (t % 3)) * PITCH
+                for ks in range(4):
+                    bf = np.concatenate([ds_read_tr16_b64(x_img, tap + off_b[ks, 0]), ds_read_tr16_b64(x_img, tap + off_b[ks, 1])], 1)
+                    acc[t] = _mfma_fast(af[ks], bf, acc[t])
+        for t in range(9):
+            for r in range(16):
+                co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi
+                out[co, t, wn * 32 + l31] = acc[t][:, r]
+    return out.reshape(64, 3, 3, 64)

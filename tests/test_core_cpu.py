@@ -203,7 +203,7 @@ def test_c_abi_exports_every_declared_symbol():
     """The library loads on a GPU-less box and exports exactly what include/dreammat_hip.h declares."""
     import os, re
     L = _lib.lib()
-    assert L.dm_abi_version() == _lib.ABI_VERSION == 5
+    assert L.dm_abi_version() == _lib.ABI_VERSION == 6
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "dreammat_hip.h")).read()
     declared = set(re.findall(r"\b(dm_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
@@ -275,6 +275,23 @@ def test_attention_backward_index_math_on_mfma_model():
         for k0 in range(0, Skv, 32):
             dk, dv = attention_bwd_dkv_wave_sim(Q, K[k0:k0 + 32], V[k0:k0 + 32], dO, lse2, delta, sc, DP)
             assert np.abs(dk - dK[k0:k0 + 32]).max() < 1e-12 and np.abs(dv - dV[k0:k0 + 32]).max() < 1e-12
+
+
+def test_conv_weight_gradient_index_math_on_mfma_model():
+    """k_conv3x3_wgrad (csrc/conv_wgrad.hip): row-major staging, the per-lane addresses of the transposing LDS read
+    (ds_read_b64_tr_b16, modelled as measured by tools/tr_probe.cpp), halo / stride / tap arithmetic and the accumulator
+    store, followed literally on the numpy model against torch's conv2d weight gradient (stride 1 and 2, several rows per chunk)."""
+    import torch
+    from tests.mfma_sim import conv_wgrad_workgroup_sim
+    rng = np.random.default_rng(3)
+    for B, H, W, s in ((1, 8, 8, 1), (2, 16, 16, 2), (1, 16, 4, 1)):
+        x = rng.standard_normal((B, H, W, 64))
+        Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+        dy = rng.standard_normal((B, Ho, Wo, 64))
+        w = torch.zeros(64, 64, 3, 3, dtype=torch.float64, requires_grad=True)
+        y = torch.nn.functional.conv2d(torch.tensor(x).permute(0, 3, 1, 2), w, stride=s, padding=1)
+        y.backward(torch.tensor(dy).permute(0, 3, 1, 2))
+        assert np.abs(conv_wgrad_workgroup_sim(x, dy, s) - w.grad.permute(0, 2, 3, 1).numpy()).max() < 1e-11
 
 
 def test_bvh_build_and_traversal_core_vs_brute_force(hostemu):

@@ -431,6 +431,60 @@ def test_attention_vs_fp32_reference(dev, B, h, Sq, Skv, D, attn_variant):
     assert (out - ref).abs().mean().item() < 2e-3
 
 
+WGRAD_CASES = [  # (B, H, W, Cin, Cout, stride): the ControlNet's trainable 3x3 layers at 512^2 (64^2 latents) and small shapes
+    (2, 64, 64, 320, 320, 1), (2, 64, 64, 320, 320, 2), (2, 32, 32, 320, 640, 1), (1, 16, 16, 1280, 1280, 1),
+    (3, 8, 8, 128, 64, 1), (4, 16, 16, 64, 128, 2), (1, 16, 4, 64, 64, 1)]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,s", WGRAD_CASES)
+def test_conv_trainable_weights_all_three_products_vs_fp32(dev, B, H, W, Cin, Cout, s):
+    """hipops.conv3x3_train (the trainable convolutions of the ControlNet training loop): forward, data gradient and the
+    weight gradient of dm_conv3x3_wgrad_nhwc_bf16 (transposing LDS reads, per-split fp32 partials) against fp32 conv2d
+    autograd on the same bf16-rounded tensors; the weight gradient is bit-reproducible."""
+    torch.manual_seed(4)
+    x = torch.randn(B, H, W, Cin).to(dev).bfloat16().requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 3, 3) * (9 * Cin) ** -0.5).to(dev).bfloat16().requires_grad_(True)
+    bias = torch.randn(Cout).to(dev).bfloat16().requires_grad_(True)
+    assert hipops.conv3x3_train_ok(x, w, (s, s), (1, 1))
+    y = hipops.conv3x3_train(x, w, bias, s)
+    g = torch.randn_like(y)
+    y.backward(g)
+    x32, w32, b32 = (t.detach().float().cpu().requires_grad_(True) for t in (x, w, bias))
+    ref = torch.nn.functional.conv2d(x32.permute(0, 3, 1, 2), w32, b32, stride=s, padding=1)
+    ref.backward(g.float().cpu().permute(0, 3, 1, 2))
+    assert (y.detach().float().cpu() - ref.detach().permute(0, 2, 3, 1)).abs().max().item() < 3e-2
+    report = {}
+    for name, got, want in (("dx", x.grad, x32.grad), ("dw", w.grad, w32.grad), ("db", bias.grad, b32.grad)):
+        got = got.float().cpu()
+        report[name] = (((got - want).norm() / want.norm()).item(), ((got - want).abs().max() / want.abs().max()).item())
+    print("conv_train", (B, H, W, Cin, Cout, s), report)
+    assert all(rel < 6e-3 and worst < 2e-2 for rel, worst in report.values()), report     # outputs rounded to bf16 once
+    dw1 = hipops.conv3x3_wgrad(x.detach(), g, s)
+    assert torch.equal(dw1, hipops.conv3x3_wgrad(x.detach(), g, s))
+    assert ((dw1.cpu() - w32.grad).norm() / w32.grad.norm()).item() < 1e-4                # fp32 partials before the rounding
+
+
+def test_conv2d_module_with_trainable_weights_takes_the_mfma_route(dev):
+    """sd/layers.Conv2d with requires_grad weights on the device in bf16: no im2col lowering -- the autograd node is the
+    three-kernel function -- and shapes outside the weight-gradient kernel's domain still lower through im2col."""
+    from dreammat_amd.sd import layers
+    torch.manual_seed(5)
+    conv = layers.Conv2d(64, 128, 3, stride=2, padding=1).to(dev).bfloat16()
+    x = torch.randn(2, 64, 16, 16, device=dev).bfloat16().requires_grad_(True)
+    y = conv(x)
+    assert type(y.grad_fn).__name__ == "PermuteBackward0" and type(y.grad_fn.next_functions[0][0]).__name__ == "_Conv3x3TrainBackward"
+    y.float().square().mean().backward()
+    c32 = torch.nn.Conv2d(64, 128, 3, stride=2, padding=1)
+    c32.load_state_dict({k: v.float().cpu() for k, v in conv.state_dict().items()})
+    x32 = x.detach().float().cpu().requires_grad_(True)
+    c32(x32).square().mean().backward()
+    for got, want in ((x.grad, x32.grad), (conv.weight.grad, c32.weight.grad), (conv.bias.grad, c32.bias.grad)):
+        assert ((got.float().cpu() - want).norm() / want.norm()).item() < 2e-2
+    odd = layers.Conv2d(32, 64, 3, padding=1).to(dev).bfloat16()                         # Cin = 32: im2col lowering
+    yo = odd(torch.randn(1, 32, 8, 8, device=dev).bfloat16())
+    assert "_Conv3x3Train" not in type(yo.grad_fn).__name__ and yo.grad_fn is not None
+
+
 ATTN_BWD_CASES = [  # (B, heads, Sq, Skv, D): self / cross attention of the SD-2.1 and tiny nets, ragged tails, padded head sizes
     (2, 2, 256, 256, 64), (1, 5, 1024, 1024, 64), (2, 5, 1024, 77, 64), (1, 1, 100, 77, 32), (1, 2, 300, 130, 64),
     (2, 2, 64, 64, 32), (1, 2, 200, 136, 40), (1, 1, 130, 200, 80), (1, 2, 129, 65, 128)]
