@@ -13,9 +13,12 @@
 //                     S = Q.K^T, dP = dO.V^T             (A = Q / dO rows from LDS, B = K / V rows in registers)
 //                     dV^T += dO^T.P, dK^T += Q^T.dS     (A = dO^T / Q^T from LDS, B = P / dS from the accumulators)
 // As in the forward kernels the softmax index that is NOT contracted next stays on the lane (n of the 32x32x16 MFMA), so
-// the accumulator registers of the first product ARE the B operand of the second one; the transposed A operands are
-// produced while a tile is staged (global -> VGPR -> LDS, row-major copy + 2-byte scatter into the transposed copy with
-// bits 2 and 3 of the row index swapped inside each group of 16: the accumulator row order).
+// the accumulator registers of the first product ARE the B operand of the second one.  The transposed A operands (K^T, Q^T,
+// dO^T: 8 consecutive ROWS of one column per lane) come out of the SAME row-major LDS tiles through gfx950's transposing
+// read (ds_read_b64_tr_b16; semantics measured by tools/tr_probe.cpp: in a group of 16 lanes, lane i passes the address of
+// 4 consecutive columns of row k0 + (i >> 2) and receives column i of rows k0 .. k0 + 3): two reads per fragment, rows taken
+// in the accumulator's order (k0 = 16 ks + 8 r + 4 hi), no transposed copy and no 2-byte scatter (the first version staged
+// one: 474 TF/s executed at S = 4096; profiles/r03_attn_bwd_probe.jsonl).
 // Rows past the end of a sequence are staged as zeros: a zero K row contributes nothing to dQ (K^T column is zero), a zero
 // Q / dO row nothing to dK / dV (its L is +inf => P = 0); the lanes that own such rows are never stored.
 #include "attn_common.h"
@@ -41,15 +44,21 @@ template <int DP>
 struct Lay {
     static constexpr int KSTEPS = DP / 16, DT = DP / 32, CPR = DP / 8;
     static constexpr int RROW = DP * 2 + 16;        // bytes per row of a row-major tile (padded: conflict-free b128 reads)
-    static constexpr int TROW = kTile * 2 + 16;     // bytes per row of a transposed tile
-    static constexpr int RBYTES = kTile * RROW, TBYTES = DP * TROW;
+    static constexpr int RBYTES = kTile * RROW;
     static constexpr int NCH = kTile * CPR / 256;   // 16 B chunks per thread per operand
 };
 
 __device__ __forceinline__ uint4 ld16g(const __bf16* p) { return *reinterpret_cast<const uint4*>(p); }
-// position of row r inside a transposed tile: bits 2 and 3 swapped (accumulator row order of the 32x32 MFMA)
-__device__ __forceinline__ int tpos(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
-
+// A-operand fragment of X^T from the row-major tile of X: lane (m = column, hi) receives rows k0 .. k0 + 3 (first read) and
+// k0 + 8 .. k0 + 11 (second read) with k0 = 4 hi: the accumulator row order of one 16-wide k-step.  `p` = the lane's SOURCE
+// address (row 4 hi + (i >> 2), columns 16 g1 + 4 (i & 3) of the k-step / column tile), RROW = bytes per row.
+template <int RROW>
+__device__ __forceinline__ bf16x8 tr_frag(const char* p) {
+    typedef bf16x4 __attribute__((address_space(3))) * lds4;
+    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)const_cast<char*>(p));
+    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)const_cast<char*>(p + 8 * RROW));
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
 template <int DP>
 __device__ __forceinline__ void write_rowmajor(char* dst, const uint4 (&reg)[Lay<DP>::NCH], int tid) {
     using L = Lay<DP>;
@@ -57,21 +66,6 @@ __device__ __forceinline__ void write_rowmajor(char* dst, const uint4 (&reg)[Lay
     for (int i = 0; i < L::NCH; ++i) {
         const int c = tid + 256 * i, row = c / L::CPR, col8 = c - row * L::CPR;
         *reinterpret_cast<uint4*>(dst + row * L::RROW + col8 * 16) = reg[i];
-    }
-}
-template <int DP>
-__device__ __forceinline__ void write_transposed(char* dst, const uint4 (&reg)[Lay<DP>::NCH], int tid) {
-    using L = Lay<DP>;
-#pragma unroll
-    for (int i = 0; i < L::NCH; ++i) {
-        const int c = tid + 256 * i, row = c / L::CPR, col8 = c - row * L::CPR;
-        char* p = dst + (8 * col8) * L::TROW + tpos(row) * 2;
-        const uint32_t w[4] = {reg[i].x, reg[i].y, reg[i].z, reg[i].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            *reinterpret_cast<uint16_t*>(p + (2 * e) * L::TROW) = (uint16_t)(w[e] & 0xffffu);
-            *reinterpret_cast<uint16_t*>(p + (2 * e + 1) * L::TROW) = (uint16_t)(w[e] >> 16);
-        }
     }
 }
 // 64 rows x DP of a [rows, D] operand starting at row r0 (zeros past n_rows / past D)
@@ -130,9 +124,10 @@ __device__ __forceinline__ void store_own(__bf16* rowp, const f32x16 (&acc)[Lay<
 template <int DP>
 __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnBwdArgs a) {
     using L = Lay<DP>;
-    constexpr int BUF = 2 * L::RBYTES + L::TBYTES;      // K rows | V rows | K^T
+    constexpr int BUF = 2 * L::RBYTES;                  // K rows | V rows
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int tr_off = (4 * hi + ((lane & 15) >> 2)) * L::RROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
     const int bh = blockIdx.y, b = bh / a.Hh, h = bh - b * a.Hh;
     const int q_row = blockIdx.x * kOwn + wave * 32 + l31;
     const bool q_ok = q_row < a.Sq;
@@ -173,13 +168,11 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnBwdArgs a) {
     load_rows<DP>(vreg, vp, a.k_ss, 0, a.Skv, a.D, tid);
     write_rowmajor<DP>(smem, kreg, tid);
     write_rowmajor<DP>(smem + L::RBYTES, vreg, tid);
-    write_transposed<DP>(smem + 2 * L::RBYTES, kreg, tid);
     __syncthreads();
 
     for (int j = 0; j < n_tiles; ++j) {
         const char* kb = smem + (j & 1) * BUF;
         const char* vb = kb + L::RBYTES;
-        const char* ktb = kb + 2 * L::RBYTES;
         if (j + 1 < n_tiles) {
             load_rows<DP>(kreg, kp, a.k_ss, (j + 1) * kTile, a.Skv, a.D, tid);
             load_rows<DP>(vreg, vp, a.k_ss, (j + 1) * kTile, a.Skv, a.D, tid);
@@ -211,14 +204,13 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnBwdArgs a) {
         for (int dt = 0; dt < L::DT; ++dt)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                bf16x8 ktf = *reinterpret_cast<const bf16x8*>(ktb + (32 * dt + l31) * L::TROW + 32 * ks + 16 * hi);
+                const bf16x8 ktf = tr_frag<L::RROW>(kb + tr_off + ks * 16 * L::RROW + dt * 64);
                 dqT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf[ks], dqT[dt], 0, 0, 0);
             }
         if (j + 1 < n_tiles) {
             char* nb = smem + ((j + 1) & 1) * BUF;
             write_rowmajor<DP>(nb, kreg, tid);
             write_rowmajor<DP>(nb + L::RBYTES, vreg, tid);
-            write_transposed<DP>(nb + 2 * L::RBYTES, kreg, tid);
         }
         __syncthreads();
     }
@@ -229,9 +221,10 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnBwdArgs a) {
 template <int DP>
 __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnBwdArgs a) {
     using L = Lay<DP>;
-    constexpr int BUF = 2 * L::RBYTES + 2 * L::TBYTES + 2 * kTile * 4;   // Q rows | dO rows | Q^T | dO^T | L | delta
+    constexpr int BUF = 2 * L::RBYTES + 2 * kTile * 4;   // Q rows | dO rows | L | delta
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int tr_off = (4 * hi + ((lane & 15) >> 2)) * L::RROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
     const int bh = blockIdx.y, b = bh / a.Hh, h = bh - b * a.Hh;
     const int kv_row = blockIdx.x * kOwn + wave * 32 + l31;
     const bool kv_ok = kv_row < a.Skv;
@@ -255,7 +248,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnBwdArgs a) {
         }
     };
     auto write_stat = [&](char* buf) {
-        if (tid < 2 * kTile) reinterpret_cast<float*>(buf + 2 * L::RBYTES + 2 * L::TBYTES)[tid] = stat;
+        if (tid < 2 * kTile) reinterpret_cast<float*>(buf + 2 * L::RBYTES)[tid] = stat;
     };
     f32x16 dvT[L::DT], dkT[L::DT];
 #pragma unroll
@@ -269,17 +262,13 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnBwdArgs a) {
     load_stat(0);
     write_rowmajor<DP>(smem, qreg, tid);
     write_rowmajor<DP>(smem + L::RBYTES, doreg, tid);
-    write_transposed<DP>(smem + 2 * L::RBYTES, qreg, tid);
-    write_transposed<DP>(smem + 2 * L::RBYTES + L::TBYTES, doreg, tid);
     write_stat(smem);
     __syncthreads();
 
     for (int j = 0; j < n_tiles; ++j) {
         const char* qb = smem + (j & 1) * BUF;
         const char* dob = qb + L::RBYTES;
-        const char* qtb = qb + 2 * L::RBYTES;
-        const char* dotb = qtb + L::TBYTES;
-        const float* lds_l = reinterpret_cast<const float*>(dotb + L::TBYTES);
+        const float* lds_l = reinterpret_cast<const float*>(dob + L::RBYTES);
         const float* lds_d = lds_l + kTile;
         if (j + 1 < n_tiles) {
             load_rows<DP>(qreg, qp, a.q_ss, (j + 1) * kTile, a.Sq, a.D, tid);
@@ -320,17 +309,15 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnBwdArgs a) {
         for (int dt = 0; dt < L::DT; ++dt)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                bf16x8 dta = *reinterpret_cast<const bf16x8*>(dotb + (32 * dt + l31) * L::TROW + 32 * ks + 16 * hi);
+                const bf16x8 dta = tr_frag<L::RROW>(dob + tr_off + ks * 16 * L::RROW + dt * 64);
                 dvT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dta, pf[ks], dvT[dt], 0, 0, 0);
-                bf16x8 qta = *reinterpret_cast<const bf16x8*>(qtb + (32 * dt + l31) * L::TROW + 32 * ks + 16 * hi);
+                const bf16x8 qta = tr_frag<L::RROW>(qb + tr_off + ks * 16 * L::RROW + dt * 64);
                 dkT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta, dsf[ks], dkT[dt], 0, 0, 0);
             }
         if (j + 1 < n_tiles) {
             char* nb = smem + ((j + 1) & 1) * BUF;
             write_rowmajor<DP>(nb, qreg, tid);
             write_rowmajor<DP>(nb + L::RBYTES, doreg, tid);
-            write_transposed<DP>(nb + 2 * L::RBYTES, qreg, tid);
-            write_transposed<DP>(nb + 2 * L::RBYTES + L::TBYTES, doreg, tid);
             write_stat(nb);
         }
         __syncthreads();
@@ -344,8 +331,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnBwdArgs a) {
 template <int DP>
 int launch_bwd(const AttnBwdArgs& a, hipStream_t stream) {
     using L = Lay<DP>;
-    constexpr int LDS_DQ = 2 * (2 * L::RBYTES + L::TBYTES);
-    constexpr int LDS_DKV = 2 * (2 * L::RBYTES + 2 * L::TBYTES + 2 * kTile * 4);
+    constexpr int LDS_DQ = 2 * (2 * L::RBYTES);
+    constexpr int LDS_DKV = 2 * (2 * L::RBYTES + 2 * kTile * 4);
     static_assert(LDS_DKV <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {

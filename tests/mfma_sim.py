@@ -213,18 +213,17 @@ def _stage_rows(X, r0, DP):
     return img
 
 
-def _stage_transposed(X, r0, DP):
-    """load_rows + write_transposed: [DP, 64] image, element (d, tpos(row)) = X[r0 + row][d], chunk by chunk like the kernel."""
-    img = np.zeros((DP, 64))
-    CPR = DP // 8
-    for c in range(64 * CPR):
-        row, col8 = c // CPR, c % CPR
-        chunk = np.zeros(8)
-        if r0 + row < X.shape[0] and col8 * 8 < X.shape[1]:
-            chunk = X[r0 + row, col8 * 8: col8 * 8 + 8]
-        for e in range(8):
-            img[8 * col8 + e, _swap23(row)] = chunk[e]
-    return img
+def _tr_a_frag(img, ks, dt):
+    """tr_frag of csrc/attn_bwd.hip: A-operand fragment of img^T (img = row-major [64, DP] tile) for k-step ks / column tile
+    dt, through the transposing LDS read with the kernel's per-lane source addresses (pitch = DP + 8 elements)."""
+    DP = img.shape[1]
+    P = DP + 8
+    flat = np.zeros(64 * P)
+    for r in range(64):
+        flat[r * P: r * P + DP] = img[r]
+    lanes = np.arange(64); hi = lanes >> 5; i16 = lanes & 15; g1 = (lanes >> 4) & 1
+    addr = (16 * ks + 4 * hi + (i16 >> 2)) * P + 32 * dt + 16 * g1 + 4 * (lanes & 3)
+    return np.concatenate([ds_read_tr16_b64(flat, addr), ds_read_tr16_b64(flat, addr + 8 * P)], 1)
 
 
 def _own_frags(X, rows, ok, DP):
@@ -273,7 +272,7 @@ def attention_bwd_dq_wave_sim(Q, K, V, O, dO, lse2, scale, DP):
     DT, KSTEPS = DP // 32, DP // 16
     dqT = np.zeros((DT, 64, 16))
     for j in range((Skv + 63) // 64):
-        kb, vb, ktb = _stage_rows(K, 64 * j, DP), _stage_rows(V, 64 * j, DP), _stage_transposed(K, 64 * j, DP)
+        kb, vb = _stage_rows(K, 64 * j, DP), _stage_rows(V, 64 * j, DP)
         dsf = [None] * 4
         for t in range(2):
             s = np.zeros((64, 16)); dp = np.zeros((64, 16))
@@ -286,7 +285,7 @@ def attention_bwd_dq_wave_sim(Q, K, V, O, dO, lse2, scale, DP):
             dsf[2 * t], dsf[2 * t + 1] = ds[:, :8], ds[:, 8:]
         for dt in range(DT):
             for ks in range(4):
-                dqT[dt] = _mfma_fast(_a_frag(ktb, 32 * dt, 16 * ks), dsf[ks], dqT[dt])
+                dqT[dt] = _mfma_fast(_tr_a_frag(kb, ks, dt), dsf[ks], dqT[dt])
     return _store_own(dqT, scale, D, DP)[:n], delta_q[:n]
 
 
@@ -304,7 +303,6 @@ def attention_bwd_dkv_wave_sim(Q, K, V, dO, lse2, delta, scale, DP):
     for j in range((Sq + 63) // 64):
         q0 = 64 * j
         qb, dob = _stage_rows(Q, q0, DP), _stage_rows(dO, q0, DP)
-        qtb, dotb = _stage_transposed(Q, q0, DP), _stage_transposed(dO, q0, DP)
         lds_l = np.array([lse2[q0 + r] if q0 + r < Sq else np.inf for r in range(64)])
         lds_d = np.array([delta[q0 + r] if q0 + r < Sq else 0.0 for r in range(64)])
         pf, dsf = [None] * 4, [None] * 4
@@ -324,8 +322,8 @@ def attention_bwd_dkv_wave_sim(Q, K, V, dO, lse2, delta, scale, DP):
             dsf[2 * t], dsf[2 * t + 1] = dp[:, :8], dp[:, 8:]
         for dt in range(DT):
             for ks in range(4):
-                dvT[dt] = _mfma_fast(_a_frag(dotb, 32 * dt, 16 * ks), pf[ks], dvT[dt])
-                dkT[dt] = _mfma_fast(_a_frag(qtb, 32 * dt, 16 * ks), dsf[ks], dkT[dt])
+                dvT[dt] = _mfma_fast(_tr_a_frag(dob, ks, dt), pf[ks], dvT[dt])
+                dkT[dt] = _mfma_fast(_tr_a_frag(qb, ks, dt), dsf[ks], dkT[dt])
     return _store_own(dkT, scale, D, DP)[:n], _store_own(dvT, 1.0, D, DP)[:n]
 
 

@@ -253,9 +253,10 @@ def test_attention_v3_index_math_and_rebase_logic_on_mfma_model():
 
 
 def test_attention_backward_index_math_on_mfma_model():
-    """k_attn_bwd_dq / k_attn_bwd_dkv (csrc/attn_bwd.hip): the staging (row-major + transposed copy with the accumulator row
-    order), the fragment reads, the accumulator -> B-operand packing and the row statistics, followed literally on the
-    numpy MFMA model, against the closed-form gradient of softmax(QK^T.scale)V; ragged sequences, D < DP."""
+    """k_attn_bwd_dq / k_attn_bwd_dkv (csrc/attn_bwd.hip): the row-major staging, the plain and the transposing fragment
+    reads (ds_read_b64_tr_b16 as measured by tools/tr_probe.cpp, rows in accumulator order), the accumulator -> B-operand
+    packing and the row statistics, followed literally on the numpy MFMA model, against the closed-form gradient of
+    softmax(QK^T.scale)V; ragged sequences, D < DP."""
     from tests.mfma_sim import attention_bwd_dkv_wave_sim, attention_bwd_dq_wave_sim
     rng = np.random.default_rng(2)
     for D, DP, Sq, Skv in ((64, 64, 100, 77), (32, 32, 64, 130), (40, 64, 70, 64)):

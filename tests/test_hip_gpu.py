@@ -1428,10 +1428,10 @@ def test_exporter_bake_on_apple_obj_vs_oracle(dev):
 
 def test_controlnet_training_step_on_the_gpu_vs_fp32_oracle(dev):
     """f-4 (controlnet_train/diffusers_train_controlnet.py:858-915) on the GPU at 64^2 with the tiny architecture: the bf16
-    production modules (implicit-GEMM conv data gradients, GroupNorm backward, fused GEMMs) under autograd against the
-    functional fp32 CPU oracle differentiated by autograd -- loss and the gradient of every ControlNet parameter that
-    receives one -- and a few optimiser steps that must lower the loss.  (The UNet's attention runs matmul-softmax under
-    autograd: the MFMA attention kernels are forward-only.)"""
+    production modules (implicit-GEMM conv data gradients, GroupNorm backward, fused GEMMs, the MFMA attention forward +
+    backward of csrc/attn_bwd.hip, and -- where a layer has whole 64-channel tiles -- the trainable-conv route with the
+    weight-gradient kernel) under autograd against the functional fp32 CPU oracle differentiated by autograd -- loss and
+    the gradient of every ControlNet parameter that receives one -- and a few optimiser steps that must lower the loss."""
     from dreammat_amd import controlnet_train as ct
     from dreammat_amd.sd import ARCHS, AutoencoderKLEncoder, UNet2DConditionModel
     from oracle import sd_nets as osd
