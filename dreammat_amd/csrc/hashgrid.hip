@@ -317,10 +317,10 @@ __global__ __launch_bounds__(LH_THREADS) void k_hashgrid_bwd_lds(HashArgs a, int
 //                       16384 consecutive table entries); a workgroup ranks its tuples per bin with LDS counters and
 //                       reserves the bin space with ONE global atomic per (workgroup, bin) -- 128x fewer than per tuple;
 //   pass 2  k_hg_acc    one workgroup per (level, bin, split) sums its share of the bin's tuples into a 128 KB LDS table
-//                       and writes the table to a partial slab.  The table is 64-bit FIXED POINT (value * 2^44 / max|dL/denc|
+//                       and writes the table to a partial slab.  The table is 64-bit FIXED POINT (value * 2^shift / max|dL/denc|, shift <= 44: hb_pow2_scale,
 //                       of the level, found by pass 1): ds_add_u64 retires 8.6x the tuples per second of two ds_add_f32
 //                       (855 vs 99 G tuples/s, tools/lds_atomic_probe.cpp -- LDS float atomics are a slow path on this
-//                       chip), resolves 6e-14 of the level's largest gradient, and makes the sums order-independent;
+//                       chip), resolves ~1e-13 of the level's largest gradient, cannot wrap, and makes the sums order-independent;
 //   pass 3  k_hg_sum    dtable += sum over the splits' slabs (plain read-modify-write, no atomics).
 // A tuple that finds its bin full (capacity = 1.3 x the uniform share) falls back to the global atomic: time, not
 // correctness.  Bytes: 8 B per tuple written and read once = 0.13 GB per level and pass at 1 M points.
@@ -354,6 +354,15 @@ __device__ __forceinline__ uint2 hb_pack(unsigned e, float v0, float v1) {
 __device__ __forceinline__ long long hb_fixed(double d) {
     const double magic = 6755399441055744.0;               // 1.5 * 2^52
     return __double_as_longlong(d + magic) - __double_as_longlong(magic);
+}
+// Fixed-point scale of a level = 2^shift / max|g| with shift = min(44, 62 - ceil(log2(cap))): an entry receives at most `cap`
+// tuples (one bin's capacity, over all splits), each |q| <= 2^shift, so the int64 sums of k_hg_acc + k_hg_sum cannot wrap
+// however many points fall into one cell (flat / degenerate geometry); 2^-43 of the level's largest gradient at the bench
+// size is far below the fp32 result's own rounding.
+__device__ __forceinline__ double hb_pow2_scale(long long cap) {
+    const int bits = cap > 1 ? 64 - __clzll(cap - 1) : 0;
+    const int shift = min(44, 62 - bits);
+    return __longlong_as_double((long long)(1023 + shift) << 52);
 }
 __device__ __forceinline__ void hb_unpack(unsigned lo, unsigned hi, unsigned& e, float& v0, float& v1) {
     const unsigned long long w = (unsigned long long)lo | ((unsigned long long)hi << 32);
@@ -443,7 +452,7 @@ __global__ __launch_bounds__(HB_ACC_THREADS) void k_hg_acc(BinArgs a) {
     if ((long long)bin * HB_ENTRIES >= (long long)size) return;      // this level has fewer bins
     for (int i = tid; i < HB_ENTRIES; i += HB_ACC_THREADS) reinterpret_cast<uint4*>(tab)[i] = make_uint4(0u, 0u, 0u, 0u);
     const float gmax = __uint_as_float(a.gmax_bits[li]);
-    const double S = gmax > 0.f ? 17592186044416.0 / (double)gmax : 0.0;       // 2^44 / max: |q| <= 2^44, 2^19 terms of headroom
+    const double S = gmax > 0.f ? hb_pow2_scale(a.cap) / (double)gmax : 0.0;   // |q| <= 2^shift, cap terms at most: no wrap
     __syncthreads();
     const long long n = min((long long)a.counts[li * HB_MAX_BINS + bin], a.cap);
     const long long lo = n * split / HB_SPLITS, hi = n * (split + 1) / HB_SPLITS;
@@ -488,7 +497,7 @@ __global__ __launch_bounds__(256) void k_hg_sum(BinArgs a) {
         const longlong2 p = reinterpret_cast<const longlong2*>(a.partial + ((long long)li * HB_SPLITS + s) * a.max_size * 2)[e];
         q0 += p.x; q1 += p.y;
     }
-    const double inv = (double)__uint_as_float(a.gmax_bits[li]) / 17592186044416.0;
+    const double inv = (double)__uint_as_float(a.gmax_bits[li]) / hb_pow2_scale(a.cap);
     const float2 acc = make_float2((float)((double)q0 * inv), (float)((double)q1 * inv));
     float2* dst = reinterpret_cast<float2*>(a.h.dtable) + off + e;
     float2 cur = *dst;

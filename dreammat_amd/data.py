@@ -104,7 +104,7 @@ class FixCameraIterableDataset:
         self.gen = torch.Generator().manual_seed(cfg.seed + 1000003 * (rank + 1))   # per-rank draws
         self._prerender = None
         self._cond_renderer = None
-        self.resident = (self.device.type == "cuda") if cfg.resident is None else bool(cfg.resident)
+        self.resident = self._resident_default() if cfg.resident is None else bool(cfg.resident)
         self._cam_table = None          # device copies of camera_for(all views), built on first use
         self._cond_table = None         # [n_views * n_envs, H, W, 22] fp32 on the device (synthetic / prerender)
         self._cond_cache = {}           # condition_source=render: maps rendered so far, keyed by (view, env)
@@ -158,6 +158,22 @@ class FixCameraIterableDataset:
         return torch.stack(out)
 
     # ---- resident tables (HBM) --------------------------------------------------------------------------------------
+    def resident_table_bytes(self):
+        """HBM the resident tables take: the 22-channel fp32 condition maps of every (view, env) pair + the per-view rays."""
+        n, ne = self.cfg.fix_view_num, self.cfg.fix_env_num
+        cond = n * ne * self.height * self.width * 22 * 4 if self.cfg.condition_source in ("synthetic", "prerender") else 0
+        return cond + n * self.height * self.width * 3 * 4
+
+    def _resident_default(self, free_bytes=None):
+        """resident = None: on when the dataset lives on a GPU AND the tables fit in a quarter of the HBM that is free now
+        (14.8 GB at 512^2 and 59 GB at 1024^2 for 128 views x 5 envs: fine on 288 GB, not on a small or busy device);
+        otherwise the per-step host collate + copy."""
+        if self.device.type != "cuda":
+            return False
+        if free_bytes is None:
+            free_bytes = torch.cuda.mem_get_info(self.device)[0]
+        return self.resident_table_bytes() * 4 <= free_bytes
+
     def _build_tables(self):
         n, ne = self.cfg.fix_view_num, self.cfg.fix_env_num
         dev = self.device

@@ -456,3 +456,20 @@ def test_per_triangle_atlas_fallback_and_gif_writer(monkeypatch, tmp_path):
     assert im.n_frames == 5 and im.size == (12, 8)
     with pytest.raises(FileNotFoundError):
         saving.save_gif(str(tmp_path / "nothing"))
+
+
+def test_resident_condition_tables_are_gated_on_free_hbm():
+    """data.RandomCameraDataModule: `resident: null` keeps the (view, env) condition maps in HBM only when they fit in a
+    quarter of the memory that is free; an explicit true / false is obeyed; a CPU dataset is never resident."""
+    import types
+
+    from dreammat_amd.data import RandomCameraDataModule
+    dm = RandomCameraDataModule(cfg={"height": 512, "width": 512, "batch_size": 1, "use_fix_views": True})
+    dm.setup("fit")
+    ds = dm.train_dataset
+    assert ds.resident is False                                       # lives on the CPU here
+    n, ne = ds.cfg.fix_view_num, ds.cfg.fix_env_num
+    assert ds.resident_table_bytes() == n * ne * 512 * 512 * 22 * 4 + n * 512 * 512 * 3 * 4
+    fake = types.SimpleNamespace(device=types.SimpleNamespace(type="cuda"), resident_table_bytes=ds.resident_table_bytes)
+    assert type(ds)._resident_default(fake, free_bytes=280 << 30) is True       # an idle MI355X
+    assert type(ds)._resident_default(fake, free_bytes=32 << 30) is False       # 14.9 GB of tables in 32 GB free: host collate
