@@ -473,3 +473,50 @@ def test_resident_condition_tables_are_gated_on_free_hbm():
     fake = types.SimpleNamespace(device=types.SimpleNamespace(type="cuda"), resident_table_bytes=ds.resident_table_bytes)
     assert type(ds)._resident_default(fake, free_bytes=280 << 30) is True       # an idle MI355X
     assert type(ds)._resident_default(fake, free_bytes=32 << 30) is False       # 14.9 GB of tables in 32 GB free: host collate
+
+
+def test_prompt_processor_runs_the_real_clip_path_on_a_locally_built_checkpoint(tmp_path, monkeypatch):
+    """stable_diffusion_prompt_processor.py:56-106 (tokenizer + CLIPTextModel through transformers, cached per prompt): no CLIP
+    weights exist on this box, so every other test runs on md5-seeded pseudo embeddings -- here a one-layer CLIP text model with
+    random weights and a character-level byte-pair vocabulary is written in the `from_pretrained` layout and the processor's
+    REAL branch encodes the prompt, the negative prompt, "" and the four view-dependent prompts, caches them as `.pt` (not
+    `.synthetic.pt`), and a second processor is served from the cache without touching the encoder."""
+    import json
+
+    from transformers import AutoTokenizer, CLIPTextConfig, CLIPTextModel, CLIPTokenizer
+
+    from dreammat_amd.prompt import StableDiffusionPromptProcessor
+    root = tmp_path / "SD" / "runwayml" / "stable-diffusion-v1-5"
+    (root / "tokenizer").mkdir(parents=True)
+    chars = list("abcdefghijklmnopqrstuvwxyz0123456789,.' ")
+    vocab = {c: i for i, c in enumerate(chars)}
+    vocab.update({c + "</w>": len(chars) + i for i, c in enumerate(chars)})
+    vocab["<|startoftext|>"], vocab["<|endoftext|>"] = len(vocab), len(vocab) + 1
+    (root / "tokenizer" / "vocab.json").write_text(json.dumps(vocab))
+    (root / "tokenizer" / "merges.txt").write_text("#version: 0.2\n")
+    CLIPTokenizer(str(root / "tokenizer" / "vocab.json"), str(root / "tokenizer" / "merges.txt"),
+                  model_max_length=77).save_pretrained(str(root / "tokenizer"))
+    torch.manual_seed(0)
+    CLIPTextModel(CLIPTextConfig(vocab_size=len(vocab), hidden_size=768, intermediate_size=64, num_hidden_layers=1,
+                                 num_attention_heads=2, max_position_embeddings=77, bos_token_id=vocab["<|startoftext|>"],
+                                 eos_token_id=vocab["<|endoftext|>"], pad_token_id=vocab["<|endoftext|>"])
+                  ).save_pretrained(str(root / "text_encoder"))
+    cfg = {"prompt": "a wooden chair", "negative_prompt": "ugly", "pretrained_model_name_or_path": "runwayml/stable-diffusion-v1-5",
+           "pretrained_model_cache_dir": str(tmp_path / "SD"), "cache_dir": str(tmp_path / "cache")}
+    pp = StableDiffusionPromptProcessor(dict(cfg))
+    files = sorted(os.listdir(tmp_path / "cache"))
+    assert len(files) == 7 and all(f.endswith(".pt") and not f.endswith(".synthetic.pt") for f in files)   # prompt, "ugly", "", 4 views
+    tok = AutoTokenizer.from_pretrained(str(root / "tokenizer"))
+    enc = CLIPTextModel.from_pretrained(str(root / "text_encoder"))
+    with torch.no_grad():
+        want = enc(tok(["a wooden chair", "a wooden chair, back view"], padding="max_length", max_length=77,
+                       return_tensors="pt").input_ids)[0]
+    assert pp.text_embeddings.shape == (1, 77, 768) and torch.allclose(pp.text_embeddings[0], want[0], atol=1e-6)
+    assert torch.allclose(pp.text_embeddings_vd[pp.direction2idx["back"]], want[1], atol=1e-6)
+    assert not torch.allclose(want[0], want[1])                       # the view suffix reaches the encoder
+    out = pp()
+    emb = out.get_text_embeddings(torch.tensor([10.0]), torch.tensor([170.0]), torch.tensor([3.0]))
+    assert torch.allclose(emb[0], want[1], atol=1e-6)                 # azimuth 170 degrees: the "back" prompt
+    monkeypatch.setattr(StableDiffusionPromptProcessor, "_encode", lambda self, p: (_ for _ in ()).throw(AssertionError("cache miss")))
+    pp2 = StableDiffusionPromptProcessor(dict(cfg))
+    assert torch.equal(pp2.text_embeddings, pp.text_embeddings)
