@@ -16,7 +16,7 @@ if os.environ.get("DREAMMAT_LIB"):       # development aid (tools/grad_budget.py
     LIB_PATH = os.environ["DREAMMAT_LIB"]
 
 _lib = None
-ABI_VERSION = 6      # dm_abi_version() of the library this binding was written for (csrc/host.cpp, include/dreammat_hip.h)
+ABI_VERSION = 7      # dm_abi_version() of the library this binding was written for (csrc/host.cpp, include/dreammat_hip.h)
 
 DM_ERRORS = {-1: "DM_ERR_ARG", -2: "DM_ERR_WORKSPACE", -3: "DM_ERR_UNSUPPORTED"}
 
@@ -135,6 +135,8 @@ _SIGS = {
                                         c_int, c_void_p]),
     "dm_groupnorm_nhwc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                       c_float, c_int, c_void_p]),
+    "dm_groupnorm_affine_rows": (c_int, [c_int, c_int, c_int]),
+    "dm_groupnorm_nhwc_bwd_affine": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dm_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _LL, c_int, c_float, c_void_p]),
     "dm_geglu_bf16": (c_int, [c_void_p, c_void_p, _LL, c_int, c_void_p]),
     "dm_cat_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _LL, c_int, c_int, c_float, c_void_p]),

@@ -24,6 +24,7 @@ struct GnArgs {
     const __bf16* x; const __bf16* gamma; const __bf16* beta; const __bf16* dy;
     __bf16* y;            // forward output / backward dx
     float* part; float* bpart; float* coef;
+    float* cpart;         // MODE 2 of k_gn_stats: per-(b, workgroup) channel sums [B*nblk][2][C] (dbeta, dgamma partials)
     int B, HW, C, act, nblk;
     float eps;
     int rows_per_block;
@@ -84,6 +85,8 @@ __global__ __launch_bounds__(64 * GN_COEF_SLICES) void k_gn_coef(GnArgs a) {
 }
 
 // MODE 0: forward statistics (sum x, sum x^2).  MODE 1: backward statistics (sum dxhat, sum dxhat*xhat).
+// MODE 2 (trainable affine parameters, ControlNet training): per-CHANNEL sums of dz and dz*xhat -- the partials of dbeta /
+// dgamma -- written per workgroup (the caller adds them: fixed order, no atomics).
 template <int MODE>
 __global__ __launch_bounds__(256) void k_gn_stats(GnArgs a) {
     extern __shared__ float sh[];          // [row_par][2*C] per-thread partial sums (each slot written once)
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(256) void k_gn_stats(GnArgs a) {
                             float xh = xf * rs[k] - mrs[k];
                             float dz = (float)d[u][k];
                             if (a.act) dz *= silu_grad(xf * A[k] + S[k]);
-                            float dxh = dz * gm[k];
+                            float dxh = MODE == 2 ? dz : dz * gm[k];
                             s0[k] += dxh; s1[k] += dxh * xh;
                         }
                     }
@@ -148,6 +151,15 @@ __global__ __launch_bounds__(256) void k_gn_stats(GnArgs a) {
         }
     }
     __syncthreads();
+    if (MODE == 2) {
+        float* out = a.cpart + ((long long)b * a.nblk + blockIdx.x) * 2 * C;
+        for (int c = threadIdx.x; c < 2 * C; c += 256) {
+            float t = 0.f;
+            for (int rp = 0; rp < row_par; ++rp) t += sh[(long long)rp * 2 * C + c];
+            out[c] = t;
+        }
+        return;
+    }
     // fixed-order reduction: thread t < 64 -> (group t>>1, statistic t&1)
     if (threadIdx.x < 64) {
         const int g = threadIdx.x >> 1, which = threadIdx.x & 1;
@@ -332,6 +344,32 @@ int dm_groupnorm_nhwc_bwd(const void* x, const void* gamma, const void* beta, co
     hipLaunchKernelGGL(k_gn_stats<1>, g, dim3(256), stats_lds_bytes(C), stream, a);
     hipLaunchKernelGGL(k_gn_coef<1>, dim3(dm_div_up(C, 64 * GN_COEF_SLICES), B), dim3(64 * GN_COEF_SLICES), 0, stream, a);
     hipLaunchKernelGGL(k_gn_apply<1>, g, dim3(256), 0, stream, a);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+// dbeta / dgamma partials of a GroupNorm with TRAINABLE affine parameters (the ControlNet copy in the training loop), after
+// dm_groupnorm_nhwc_fwd left its workspace: cpart [B * dm_groupnorm_affine_rows(B, HW, C) / B][2][C] fp32 --
+// dbeta = cpart[:, 0].sum(0), dgamma = cpart[:, 1].sum(0).  dx comes from dm_groupnorm_nhwc_bwd as before.
+int dm_groupnorm_affine_rows(int B, int HW, int C) {
+    if (!check_args(B, HW, C)) return 0;
+    dim3 g; int rpb;
+    launch_cfg(B, HW, C, g, rpb);
+    return (int)g.x * B;
+}
+int dm_groupnorm_nhwc_bwd_affine(const void* x, const void* gamma, const void* beta, const void* dy, float* ws, float* cpart,
+                                 int B, int HW, int C, float eps, int act, hipStream_t stream) {
+    if (!x || !gamma || !beta || !dy || !ws || !cpart || !check_args(B, HW, C)) return DM_ERR_ARG;
+    GnArgs a = {};
+    a.x = (const __bf16*)x; a.gamma = (const __bf16*)gamma; a.beta = (const __bf16*)beta; a.dy = (const __bf16*)dy;
+    bind_ws(a, ws, B, C);
+    a.cpart = cpart;
+    a.B = B; a.HW = HW; a.C = C; a.act = act; a.eps = eps;
+    dim3 g;
+    launch_cfg(B, HW, C, g, a.rows_per_block);
+    a.nblk = (int)g.x;
+    DM_ENTER();
+    hipLaunchKernelGGL(k_gn_stats<2>, g, dim3(256), stats_lds_bytes(C), stream, a);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }

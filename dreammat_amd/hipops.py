@@ -858,14 +858,24 @@ class _GroupNormAct(torch.autograd.Function):
         check(_lib.lib().dm_groupnorm_nhwc_bwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), g.data_ptr(),
                                                dx.data_ptr(), ws.data_ptr(), B, H * W, C, float(ctx.eps), int(ctx.act),
                                                _stream()), "dm_groupnorm_nhwc_bwd")
-        return dx, None, None, None, None
+        dgamma = dbeta = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            # trainable affine parameters (ControlNet training): per-workgroup channel sums of dz and dz * xhat, added here
+            rows = int(_lib.lib().dm_groupnorm_affine_rows(B, H * W, C))
+            cpart = torch.empty(rows, 2, C, device=x.device, dtype=torch.float32)
+            check(_lib.lib().dm_groupnorm_nhwc_bwd_affine(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), g.data_ptr(),
+                                                          ws.data_ptr(), cpart.data_ptr(), B, H * W, C, float(ctx.eps),
+                                                          int(ctx.act), _stream()), "dm_groupnorm_nhwc_bwd_affine")
+            sums = cpart.sum(0)
+            dbeta, dgamma = sums[0].to(beta.dtype), sums[1].to(gamma.dtype)
+        return dx, dgamma, dbeta, None, None
 
 
 def groupnorm_nhwc(x_nhwc, gamma, beta, eps, act):
-    """x [B,H,W,C] bf16 contiguous -> act(GroupNorm32(x)) [B,H,W,C]; differentiable wrt x."""
+    """x [B,H,W,C] bf16 contiguous -> act(GroupNorm32(x)) [B,H,W,C]; differentiable wrt x, gamma and beta."""
     _need_cuda(x_nhwc, gamma, beta)
     assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous() and gamma.dtype == torch.bfloat16
-    if torch.is_grad_enabled() and x_nhwc.requires_grad:
+    if torch.is_grad_enabled() and (x_nhwc.requires_grad or gamma.requires_grad or beta.requires_grad):
         return _GroupNormAct.apply(x_nhwc, gamma, beta, eps, act)
     return _gn_fwd(x_nhwc, gamma, beta, eps, act, keep_for_backward=False)[0]
 

@@ -30,6 +30,11 @@ from .. import hipops
 # "miopen" = torch's default conv, unusable in this image (no gfx950 kernel database: every shape JIT-compiles, ~25 min).
 # Tensors that are not on the GPU (the CPU test tier: fp32 plumbing of the same modules) take the ATen path.
 CONV_BACKEND = "mfma"
+# Differentiated layers with TRAINABLE parameters (the ControlNet training loop, row f-4): MFMA attention forward + backward,
+# 3x3 convolutions with the weight-gradient kernel, GroupNorm with affine gradients.  tools/train_step_probe.py assigns False
+# to time the torch-autograd lowering the kernels replace (im2col + hipBLASLt, matmul-softmax, ATen GroupNorm); no
+# environment switch.
+TRAIN_KERNELS = True
 
 
 class Conv2d(nn.Conv2d):
@@ -153,7 +158,7 @@ class Conv2d(nn.Conv2d):
               and (Cout % 64 == 0 or narrow) and self.stride[0] == self.stride[1] and self._frozen()
               and (not needs_grad or (self.stride[0] == 1 and self.padding == (1, 1) and Cin % 64 == 0)))
         if not ok:
-            if CONV_BACKEND == "mfma" and not self._frozen():
+            if CONV_BACKEND == "mfma" and TRAIN_KERNELS and not self._frozen():
                 xn = x.permute(0, 2, 3, 1).contiguous()
                 if hipops.conv3x3_train_ok(xn, self.weight, self.stride, self.padding):
                     # trainable layer (ControlNet training): forward, data gradient and weight gradient on the MFMA kernels
@@ -178,7 +183,8 @@ def group_norm_act(norm: nn.GroupNorm, x, silu: bool):
     """act(GroupNorm(x)) for a logical-NCHW tensor.  GPU bf16 (32 groups) -> fused NHWC HIP kernel (the
     activation stays channels-last, which is what the implicit-GEMM conv consumes); otherwise torch."""
     if (x.is_cuda and x.dtype == torch.bfloat16 and norm.num_groups == 32 and CONV_BACKEND == "mfma"
-            and not (torch.is_grad_enabled() and norm.weight.requires_grad)):
+            and norm.weight.dtype == torch.bfloat16
+            and (TRAIN_KERNELS or not (torch.is_grad_enabled() and norm.weight.requires_grad))):
         xn = x.permute(0, 2, 3, 1).contiguous()                  # no-op for channels-last activations
         y = hipops.groupnorm_nhwc(xn, norm.weight, norm.bias, norm.eps, 1 if silu else 0)
         return y.permute(0, 3, 1, 2)
@@ -289,7 +295,7 @@ def attention_core(q, k, v_weight, v_bias, kv_src, heads, kv_len):
     if q.is_cuda and q.dtype == torch.bfloat16 and not needs_grad:     # inference: V arrives transposed from its projection
         return hipops.attention(q, k[:, :kv_len], project_vt(v_weight, v_bias, kv_src, kv_len), heads)
     v = F.linear(kv_src, v_weight, v_bias)
-    if q.is_cuda and hipops.attention_train_ok(q, k, v, heads):        # differentiated (ControlNet training): MFMA fwd + bwd
+    if q.is_cuda and TRAIN_KERNELS and hipops.attention_train_ok(q, k, v, heads):     # differentiated (ControlNet training): MFMA fwd + bwd
         return hipops.attention_train(q, k[:, :kv_len], v[:, :kv_len], heads)
     qh = q.view(B, Sq, heads, D).transpose(1, 2)
     kh = k[:, :kv_len].reshape(B, kv_len, heads, D).transpose(1, 2)

@@ -342,12 +342,18 @@ int dm_groupnorm_nhwc_infer(const void* x, const void* gamma, const void* beta, 
                             float eps, int act, dm_stream_t stream);
 /* GroupNorm(32) [+ SiLU] of the ResnetBlock2D / Transformer2DModel / conv_norm_out layers of the same nets,
  * NHWC bf16: x,y [B,HW,C], gamma/beta [C] bf16.  ws: dm_groupnorm_workspace_floats(B,C) fp32, kept by the caller
- * between fwd and bwd.  act: 0 = none, 1 = SiLU.  bwd returns dx only (weights are frozen on this path). */
+ * between fwd and bwd.  act: 0 = none, 1 = SiLU.  bwd returns dx (the frozen nets of the SDS step need nothing else). */
 size_t dm_groupnorm_workspace_floats(int B, int C);
 int dm_groupnorm_nhwc_fwd(const void* x, const void* gamma, const void* beta, void* y, float* ws, int B, int HW,
                           int C, float eps, int act, dm_stream_t stream);
 int dm_groupnorm_nhwc_bwd(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* ws,
                           int B, int HW, int C, float eps, int act, dm_stream_t stream);
+/* GroupNorm with TRAINABLE affine parameters (the ControlNet copy in controlnet_train/diffusers_train_controlnet.py:858-915):
+ * per-workgroup partials of dbeta / dgamma after dm_groupnorm_nhwc_fwd, cpart [dm_groupnorm_affine_rows(B,HW,C)][2][C] fp32:
+ * dbeta = cpart[:, 0].sum(0), dgamma = cpart[:, 1].sum(0) (the caller's fixed-order sum: no atomics). */
+int dm_groupnorm_affine_rows(int B, int HW, int C);
+int dm_groupnorm_nhwc_bwd_affine(const void* x, const void* gamma, const void* beta, const void* dy, float* ws, float* cpart,
+                                 int B, int HW, int C, float eps, int act, dm_stream_t stream);
 
 /* LayerNorm and the GEGLU gate of diffusers' BasicTransformerBlock (norm1/2/3, ff.net.0) inside the same nets,
  * forward only (the diffusion nets run without autograd in SDS, dreammat_guidance.py:385-397).

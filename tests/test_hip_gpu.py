@@ -485,6 +485,35 @@ def test_conv2d_module_with_trainable_weights_takes_the_mfma_route(dev):
     assert "_Conv3x3Train" not in type(yo.grad_fn).__name__ and yo.grad_fn is not None
 
 
+@pytest.mark.parametrize("B,C,H,silu", [(2, 320, 32, True), (3, 64, 8, False), (1, 1280, 8, True), (2, 128, 64, True)])
+def test_groupnorm_trainable_affine_gradients_vs_fp32(dev, B, C, H, silu):
+    """GroupNorm(32) [+ SiLU] with TRAINABLE weight / bias (the ControlNet copy in the training loop): dx from
+    dm_groupnorm_nhwc_bwd, dgamma / dbeta from the per-workgroup channel sums of dm_groupnorm_nhwc_bwd_affine, against fp32
+    autograd on the bf16-rounded inputs; bit-reproducible."""
+    from dreammat_amd.sd import layers
+    torch.manual_seed(6)
+    norm = torch.nn.GroupNorm(32, C).to(dev).bfloat16()
+    with torch.no_grad():
+        norm.weight.copy_(1 + 0.3 * torch.randn(C)); norm.bias.copy_(0.2 * torch.randn(C))
+    x = (torch.randn(B, C, H, H) * 1.5 + 0.3).to(dev).bfloat16().requires_grad_(True)
+    g = torch.randn(B, C, H, H).to(dev).bfloat16()
+    y = layers.group_norm_act(norm, x, silu)
+    assert "_GroupNormAct" in type(y.grad_fn.next_functions[0][0]).__name__
+    y.backward(g)
+    n32 = torch.nn.GroupNorm(32, C)
+    n32.load_state_dict({k: v.float().cpu() for k, v in norm.state_dict().items()})
+    x32 = x.detach().float().cpu().requires_grad_(True)
+    r = n32(x32)
+    (torch.nn.functional.silu(r) if silu else r).backward(g.float().cpu())
+    for name, got, want in (("dx", x.grad, x32.grad), ("dgamma", norm.weight.grad, n32.weight.grad), ("dbeta", norm.bias.grad, n32.bias.grad)):
+        rel = ((got.float().cpu() - want).norm() / want.norm()).item()
+        assert rel < 6e-3, (name, rel)
+    first = (norm.weight.grad.clone(), norm.bias.grad.clone())
+    norm.weight.grad = norm.bias.grad = x.grad = None
+    layers.group_norm_act(norm, x, silu).backward(g)
+    assert torch.equal(first[0], norm.weight.grad) and torch.equal(first[1], norm.bias.grad)
+
+
 ATTN_BWD_CASES = [  # (B, heads, Sq, Skv, D): self / cross attention of the SD-2.1 and tiny nets, ragged tails, padded head sizes
     (2, 2, 256, 256, 64), (1, 5, 1024, 1024, 64), (2, 5, 1024, 77, 64), (1, 1, 100, 77, 32), (1, 2, 300, 130, 64),
     (2, 2, 64, 64, 32), (1, 2, 200, 136, 40), (1, 1, 130, 200, 80), (1, 2, 129, 65, 128)]
