@@ -816,7 +816,7 @@ class _Conv3x3Train(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = conv3x3_wgrad(x, g, ctx.stride).to(wd.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = g.float().sum((0, 1, 2)).to(wd.dtype)
+            db = g.sum((0, 1, 2), dtype=torch.float32).to(wd.dtype)       # fp32 accumulation without an fp32 copy of g
         return dx, dw, db, None
 
 
