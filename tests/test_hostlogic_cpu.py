@@ -520,3 +520,35 @@ def test_prompt_processor_runs_the_real_clip_path_on_a_locally_built_checkpoint(
     monkeypatch.setattr(StableDiffusionPromptProcessor, "_encode", lambda self, p: (_ for _ in ()).throw(AssertionError("cache miss")))
     pp2 = StableDiffusionPromptProcessor(dict(cfg))
     assert torch.equal(pp2.text_embeddings, pp.text_embeddings)
+
+
+def conv3x3_wgrad_contract(x_nhwc, dy_nhwc, stride):
+    """dm_conv3x3_wgrad_nhwc_bf16's contract as hipops.conv3x3_wgrad hands it on: dW [Cout, Cin, 3, 3] (fp32 there) of a 3x3 /
+    pad 1 convolution from its NHWC input and output gradient."""
+    with torch.enable_grad():                       # called from inside an autograd backward
+        x = x_nhwc.detach().permute(0, 3, 1, 2)
+        w = torch.zeros(dy_nhwc.shape[3], x_nhwc.shape[3], 3, 3, dtype=x.dtype, requires_grad=True)
+        F.conv2d(x, w, stride=stride, padding=1).backward(dy_nhwc.detach().permute(0, 3, 1, 2))
+    return w.grad
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_trainable_conv_autograd_algebra_around_the_three_kernels(contract, monkeypatch, stride):
+    """hipops._Conv3x3Train (the trainable convolutions of the ControlNet training loop): with the forward / data-gradient kernel
+    and the weight-gradient kernel replaced by their torch contracts, the host algebra -- tap-major weights, flipped and
+    channel-swapped weights for the data gradient, the zero-inserted output gradient at stride 2, dW layout, bias gradient --
+    reproduces F.conv2d's autograd for x, weight and bias."""
+    monkeypatch.setattr(hipops, "conv3x3_wgrad", conv3x3_wgrad_contract)
+    torch.manual_seed(7)
+    x = torch.randn(2, 6, 5, 8, dtype=torch.float64, requires_grad=True)          # NHWC
+    w = torch.randn(7, x.shape[3], 3, 3, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(7, dtype=torch.float64, requires_grad=True)
+    y = hipops.conv3x3_train(x, w, b, stride)
+    g = torch.randn_like(y)
+    y.backward(g)
+    x2, w2, b2 = (t.detach().clone().requires_grad_(True) for t in (x, w, b))
+    ref = F.conv2d(x2.permute(0, 3, 1, 2), w2, b2, stride=stride, padding=1).permute(0, 2, 3, 1)
+    assert torch.allclose(y.detach(), ref.detach(), atol=1e-12)
+    ref.backward(g)
+    for got, want in ((x.grad, x2.grad), (w.grad, w2.grad), (b.grad, b2.grad)):
+        assert torch.allclose(got, want, atol=1e-11)
