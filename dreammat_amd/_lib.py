@@ -16,7 +16,7 @@ if os.environ.get("DREAMMAT_LIB"):       # development aid (tools/grad_budget.py
     LIB_PATH = os.environ["DREAMMAT_LIB"]
 
 _lib = None
-ABI_VERSION = 7      # dm_abi_version() of the library this binding was written for (csrc/host.cpp, include/dreammat_hip.h)
+ABI_VERSION = 8      # dm_abi_version() of the library this binding was written for (csrc/host.cpp, include/dreammat_hip.h)
 
 DM_ERRORS = {-1: "DM_ERR_ARG", -2: "DM_ERR_WORKSPACE", -3: "DM_ERR_UNSUPPORTED"}
 
@@ -120,7 +120,7 @@ _SIGS = {
     "dm_attention_selected": (ctypes.c_char_p, []),
     "dm_attention_fwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]
                               + [_LL] * 12 + [c_float, c_void_p]),
-    "dm_attention_fwd_lse_bf16": (c_int, [c_void_p] * 5 + [c_int] * 5 + [_LL] * 12 + [c_float, c_void_p]),
+    "dm_attention_fwd_lse_bf16": (c_int, [c_void_p] * 5 + [c_int] * 5 + [_LL] * 9 + [c_float, c_void_p]),
     "dm_attention_bwd_bf16": (c_int, [c_void_p] * 10 + [c_int] * 5 + [_LL] * 6 + [c_float, c_void_p]),
     "dm_conv3x3_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 10 + [c_void_p]),
     "dm_conv3x3_nhwc_bf16_fused": (c_int, [c_void_p] * 6 + [c_int] * 10 + [c_void_p]),

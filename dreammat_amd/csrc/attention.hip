@@ -34,18 +34,22 @@ constexpr int kKvTile = 64;
 
 __device__ __forceinline__ uint4 ld16(const __bf16* p) { return *reinterpret_cast<const uint4*>(p); }
 
-template <int DP>
+// VNAT: V arrives as [kv][d] rows (the differentiated path, dm_attention_fwd_lse_bf16): staged row-major like K and consumed
+// through the transposing LDS read (ds_read_b64_tr_b16: two reads per V^T fragment, rows in accumulator order).
+template <int DP, bool VNAT>
 __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
     constexpr int KSTEPS = DP / 16;       // MFMA k-steps over head_dim
     constexpr int DT = DP / 32;           // 32-wide output d tiles
     constexpr int KROW = DP * 2 + 16;     // bytes per K row in LDS (padded)
     constexpr int VROW = kKvTile * 2 + 16;
     constexpr int KBYTES = kKvTile * KROW;
-    constexpr int VBYTES = DP * VROW;
+    constexpr int VBYTES = VNAT ? kKvTile * KROW : DP * VROW;
     constexpr int CPR = DP / 8;           // 16 B chunks per K row
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    // source address of this lane in a transposing read: row 4 hi + (i >> 2), columns 16 g1 + 4 (i & 3)
+    const int tr_off = (4 * hi + ((lane & 15) >> 2)) * KROW + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
     const int bh = blockIdx.y, b = bh / a.Hh, h = bh - b * a.Hh;
     const int q_row = blockIdx.x * (kWaves * kQRowsPerWave) + wave * kQRowsPerWave + l31;
     const bool q_ok = q_row < a.Sq;
@@ -65,7 +69,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
     }
 
     const __bf16* kp = a.k + (long long)b * a.k_bs + (long long)h * a.k_hs;
-    const __bf16* vp = a.vt + (long long)b * a.vt_bs + (long long)h * a.vt_hs;
+    const __bf16* vp = VNAT ? a.v_nat + (long long)b * a.k_bs + (long long)h * a.k_hs
+                            : a.vt + (long long)b * a.vt_bs + (long long)h * a.vt_hs;
 
     uint4 kreg[DT], vreg[DT];
     auto load_tile = [&](int kv0) {
@@ -79,7 +84,11 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
             kreg[i] = v;
             int d = c >> 3, kc = c & 7;
             uint4 w = make_uint4(0, 0, 0, 0);
-            if (d < a.D && kv0 + kc * 8 < skv_pad8) w = ld16(vp + (long long)d * a.vt_ds + kv0 + kc * 8);
+            if (VNAT) {
+                if (kv < a.Skv && col8 * 8 < a.D) w = ld16(vp + (long long)kv * a.k_ss + col8 * 8);
+            } else if (d < a.D && kv0 + kc * 8 < skv_pad8) {
+                w = ld16(vp + (long long)d * a.vt_ds + kv0 + kc * 8);
+            }
             vreg[i] = w;
         }
     };
@@ -91,6 +100,10 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
             int c = tid + 256 * i;
             int row = c / CPR, col8 = c - row * CPR;
             *reinterpret_cast<uint4*>(kb + row * KROW + col8 * 16) = kreg[i];
+            if (VNAT) {
+                *reinterpret_cast<uint4*>(vb + row * KROW + col8 * 16) = vreg[i];
+                continue;
+            }
             int d = c >> 3, kc = c & 7;
             // kv permutation inside each 16-group: [0-3, 8-11, 4-7, 12-15]
             char* dst = vb + d * VROW + (kc >> 1) * 32 + (kc & 1) * 8;
@@ -197,7 +210,16 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + (32 * dt + l31) * VROW + 32 * ks + 16 * hi);
+                bf16x8 vf;
+                if (VNAT) {
+                    typedef bf16x4 __attribute__((address_space(3))) * lds4;
+                    const char* p = vb + tr_off + ks * 16 * KROW + dt * 64;
+                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)const_cast<char*>(p));
+                    const bf16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)const_cast<char*>(p + 8 * KROW));
+                    vf = bf16x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+                } else {
+                    vf = *reinterpret_cast<const bf16x8*>(vb + (32 * dt + l31) * VROW + 32 * ks + 16 * hi);
+                }
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[dt], 0, 0, 0);
             }
 
@@ -566,22 +588,26 @@ static bool attn_v3_ok(const AttnArgs& a) {
     return kb < 0x40000000LL && vb < 0x40000000LL && a.k_ss >= a.D && a.vt_ds >= skv_pad8;
 }
 
-template <int DP>
-int launch_attn(const AttnArgs& a, hipStream_t stream) {
+template <int DP, bool VNAT>
+int launch_attn_t(const AttnArgs& a, hipStream_t stream) {
     constexpr int KROW = DP * 2 + 16, VROW = kKvTile * 2 + 16;
-    constexpr int LDS = 2 * (kKvTile * KROW + DP * VROW);
+    constexpr int LDS = 2 * (kKvTile * KROW + (VNAT ? kKvTile * KROW : DP * VROW));
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_fwd<DP>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_fwd<DP, VNAT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid(dm_div_up(a.Sq, kWaves * kQRowsPerWave), a.B * a.Hh);
     DM_ENTER();
-    hipLaunchKernelGGL(k_attn_fwd<DP>, grid, dim3(256), LDS, stream, a);
+    hipLaunchKernelGGL((k_attn_fwd<DP, VNAT>), grid, dim3(256), LDS, stream, a);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? DM_OK : (int)e;
+}
+template <int DP>
+int launch_attn(const AttnArgs& a, hipStream_t stream) {
+    return a.v_nat ? launch_attn_t<DP, true>(a, stream) : launch_attn_t<DP, false>(a, stream);
 }
 
 }  // namespace
@@ -608,13 +634,13 @@ const char* dm_attention_selected(void) { return kAttnNames[attn_mode()]; }
 //     multiple of 8 kv (vt_ds % 8 == 0)
 // out [B, Sq, Hh, D]  via strides.  All pointers 16 B aligned, all strides multiples of 8 elements
 // (out: multiples of 4).  D % 8 == 0, D <= 160.  scale = softmax scale (1/sqrt(D) for diffusers).
-static int attention_fwd(const void* q, const void* k, const void* vt, void* out, float* lse, int B, int Hh, int Sq, int Skv,
+static int attention_fwd(const void* q, const void* k, const void* vt, const void* v_nat, void* out, float* lse, int B, int Hh, int Sq, int Skv,
                          int D, long long q_bs, long long q_ss, long long q_hs, long long k_bs, long long k_ss,
                          long long k_hs, long long vt_bs, long long vt_hs, long long vt_ds, long long o_bs,
                          long long o_ss, long long o_hs, float scale, hipStream_t stream) {
-    if (!q || !k || !vt || !out || B <= 0 || Hh <= 0 || Sq <= 0 || Skv <= 0 || D <= 0) return DM_ERR_ARG;
+    if (!q || !k || (!vt && !v_nat) || !out || B <= 0 || Hh <= 0 || Sq <= 0 || Skv <= 0 || D <= 0) return DM_ERR_ARG;
     if (D % 8 != 0 || D > 160) return DM_ERR_UNSUPPORTED;
-    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15 || ((uintptr_t)out & 7)) return DM_ERR_ARG;
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)v_nat) & 15 || ((uintptr_t)out & 7)) return DM_ERR_ARG;
     if ((q_bs | q_ss | q_hs | k_bs | k_ss | k_hs | vt_bs | vt_hs | vt_ds) & 7) return DM_ERR_ARG;
     if ((o_bs | o_ss | o_hs) & 3) return DM_ERR_ARG;
     if ((long long)B * Hh > 65535) return DM_ERR_UNSUPPORTED;
@@ -626,7 +652,8 @@ static int attention_fwd(const void* q, const void* k, const void* vt, void* out
     a.scale_log2 = scale * 1.4426950408889634f;
     a.timeline = nullptr;
     a.lse = lse;
-    const int mode = lse ? kAttnStaged : attn_mode();     // the row statistics are an output of the generic kernel only
+    a.v_nat = (const __bf16*)v_nat;
+    const int mode = (lse || v_nat) ? kAttnStaged : attn_mode();     // row statistics / natural V: the generic kernel only
     // auto: the one-wave-per-SIMD kernel wherever a workgroup's 256 query rows are (nearly) filled and the sequence is long
     // enough to amortise its prologue (S >= 1024: 756 vs 738 TF/s at S = 1024, 1021 vs 980 at 4096, 981 vs 780 at batch 3;
     // v3l wins at S = 256: 375 vs 343, profiles/r03_probe_attn.json); cross-attention (77 keys) and short sequences: v3l
@@ -644,20 +671,21 @@ int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* ou
                           int D, long long q_bs, long long q_ss, long long q_hs, long long k_bs, long long k_ss,
                           long long k_hs, long long vt_bs, long long vt_hs, long long vt_ds, long long o_bs,
                           long long o_ss, long long o_hs, float scale, hipStream_t stream) {
-    return attention_fwd(q, k, vt, out, nullptr, B, Hh, Sq, Skv, D, q_bs, q_ss, q_hs, k_bs, k_ss, k_hs, vt_bs, vt_hs, vt_ds,
-                         o_bs, o_ss, o_hs, scale, stream);
+    return attention_fwd(q, k, vt, nullptr, out, nullptr, B, Hh, Sq, Skv, D, q_bs, q_ss, q_hs, k_bs, k_ss, k_hs, vt_bs, vt_hs,
+                         vt_ds, o_bs, o_ss, o_hs, scale, stream);
 }
 
-// The forward of a DIFFERENTIATED attention (dm_attention_bwd_bf16, attn_bwd.hip): same arguments plus
+// The forward of a DIFFERENTIATED attention (dm_attention_bwd_bf16, attn_bwd.hip): v is [B, Skv, Hh, D] with k's strides (NOT
+// transposed: the generic kernel reads its V^T fragments with the transposing LDS read), plus
 // lse [B, Hh, Sq] fp32 = rowmax + log2(rowsum) of the scaled scores in the log2 domain, from which the backward recomputes
 // the probabilities.  Always the register-staged generic kernel (the only one that keeps the unscaled running maximum).
-int dm_attention_fwd_lse_bf16(const void* q, const void* k, const void* vt, void* out, float* lse, int B, int Hh, int Sq,
+int dm_attention_fwd_lse_bf16(const void* q, const void* k, const void* v, void* out, float* lse, int B, int Hh, int Sq,
                               int Skv, int D, long long q_bs, long long q_ss, long long q_hs, long long k_bs,
-                              long long k_ss, long long k_hs, long long vt_bs, long long vt_hs, long long vt_ds,
-                              long long o_bs, long long o_ss, long long o_hs, float scale, hipStream_t stream) {
-    if (!lse) return DM_ERR_ARG;
-    return attention_fwd(q, k, vt, out, lse, B, Hh, Sq, Skv, D, q_bs, q_ss, q_hs, k_bs, k_ss, k_hs, vt_bs, vt_hs, vt_ds,
-                         o_bs, o_ss, o_hs, scale, stream);
+                              long long k_ss, long long k_hs, long long o_bs, long long o_ss, long long o_hs, float scale,
+                              hipStream_t stream) {
+    if (!lse || !v) return DM_ERR_ARG;
+    return attention_fwd(q, k, nullptr, v, out, lse, B, Hh, Sq, Skv, D, q_bs, q_ss, q_hs, k_bs, k_ss, k_hs, 8, 8, 8, o_bs, o_ss,
+                         o_hs, scale, stream);
 }
 
 }  // extern "C"

@@ -20,6 +20,7 @@ struct AttnArgs {
     long long o_bs, o_ss, o_hs;
     int B, Hh, Sq, Skv, D;
     float scale_log2;                 // softmax scale * log2(e)
+    const __bf16* v_nat;              // training forward: V as [B, Skv, Hh, D] with K's strides (transposing LDS reads), else null -> vt
     float* lse;                       // training forward (dm_attention_fwd_lse_bf16): rowmax + log2(rowsum), log2 domain, [B, Hh, Sq]; else null
     unsigned long long* timeline;     // DREAMMAT_ATTN_TIMELINE (development): s_memtime stamps of the w64 kernel, else null
 };

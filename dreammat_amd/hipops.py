@@ -550,15 +550,12 @@ def _attention_fwd_lse(q, k, v, heads, scale):
     q = q if q.stride(2) == 1 and q.stride(1) % 8 == 0 and q.stride(0) % 8 == 0 else q.contiguous()
     if not (k.stride(2) == 1 and k.stride() == v.stride() and k.stride(1) % 8 == 0 and k.stride(0) % 8 == 0):
         k, v = k.contiguous(), v.contiguous()
-    vt = torch.zeros(B, C, (Skv + 7) // 8 * 8, device=q.device, dtype=torch.bfloat16)
-    vt[:, :, :Skv] = v.transpose(1, 2)
     out = torch.empty(B, Sq, C, device=q.device, dtype=torch.bfloat16)
     lse = torch.empty(B, heads, Sq, device=q.device, dtype=torch.float32)
     with _Timed(f"attention_fwd_lse_bf16[Sq={Sq},Skv={Skv},h={heads},D={D}]", 4.0 * B * Sq * Skv * C):
-        check(_lib.lib().dm_attention_fwd_lse_bf16(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), lse.data_ptr(),
+        check(_lib.lib().dm_attention_fwd_lse_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), lse.data_ptr(),
                                                    B, heads, Sq, Skv, D, q.stride(0), q.stride(1), D, k.stride(0),
-                                                   k.stride(1), D, vt.stride(0), D * vt.stride(1), vt.stride(1),
-                                                   out.stride(0), out.stride(1), D, scale, _stream()),
+                                                   k.stride(1), D, out.stride(0), out.stride(1), D, scale, _stream()),
               "dm_attention_fwd_lse_bf16")
     return q, k, v, out, lse
 

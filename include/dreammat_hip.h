@@ -271,14 +271,15 @@ int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* ou
                           long long o_ss, long long o_hs, float scale, dm_stream_t stream);
 /* Differentiated attention (the trainable transformer blocks of the ControlNet training loop,
  * controlnet_train/diffusers_train_controlnet.py:858-915 -- there torch autograd runs diffusers' attention processors).
- * Forward: dm_attention_fwd_bf16 plus lse [B,Hh,Sq] fp32 = rowmax + log2(rowsum) of the scaled scores (log2 domain).
+ * Forward: as dm_attention_fwd_bf16 but v is [B,Skv,Hh,D] with k's strides (not transposed), plus lse [B,Hh,Sq] fp32 =
+ * rowmax + log2(rowsum) of the scaled scores (log2 domain).
  * Backward: q, out, dout, dq share (q_bs,q_ss,q_hs); k, v, dk, dv share (k_bs,k_ss,k_hs); v is [B,Skv,Hh,D] (not
  * transposed); delta [B,Hh,Sq] fp32 is scratch.  Nothing S x S is stored, no atomics (bit-reproducible).
  * D % 8 == 0, D <= 128 (DM_ERR_UNSUPPORTED above); pointers 16 B aligned, strides multiples of 8 elements. */
-int dm_attention_fwd_lse_bf16(const void* q, const void* k, const void* vt, void* out, float* lse, int B, int Hh, int Sq,
+int dm_attention_fwd_lse_bf16(const void* q, const void* k, const void* v, void* out, float* lse, int B, int Hh, int Sq,
                               int Skv, int D, long long q_bs, long long q_ss, long long q_hs, long long k_bs,
-                              long long k_ss, long long k_hs, long long vt_bs, long long vt_hs, long long vt_ds,
-                              long long o_bs, long long o_ss, long long o_hs, float scale, dm_stream_t stream);
+                              long long k_ss, long long k_hs, long long o_bs, long long o_ss, long long o_hs, float scale,
+                              dm_stream_t stream);
 int dm_attention_bwd_bf16(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse,
                           float* delta, void* dq, void* dk, void* dv, int B, int Hh, int Sq, int Skv, int D,
                           long long q_bs, long long q_ss, long long q_hs, long long k_bs, long long k_ss, long long k_hs,
