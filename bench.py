@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--raytracing", action="store_true",
                     help="the reference's DEFAULT material branch (use_raytracing: true, 200 + 128 Monte-Carlo directions per pixel with "
                          "occlusion rays) instead of the split-sum branch BASELINE.json's metric is quoted on: not a BASELINE config")
+    ap.add_argument("--sharded-adam", action="store_true",
+                    help="optimizer.sharded: reduce-scatter + Adam on this rank's slice + all-gather instead of all-reduce + full Adam")
     ap.add_argument("--dump-kernels", default=None, help="write the per-kernel HIP-event table of the timed region (JSON) here")
     return ap.parse_args()
 
@@ -84,7 +86,7 @@ def system_config(a, views_per_rank):
                              # shared by all ranks of one job (rank 0 writes, the others read after the barrier)
                              "cache_dir": os.path.join("/tmp", f"dm_text_cache_{os.environ.get('MASTER_PORT', os.getpid())}")},
         "loss": {"lambda_sds": 1.0, "lambda_mat_reg": 1.0},
-        "optimizer": {"name": "Adam", "args": {"lr": 0.01, "betas": [0.9, 0.99], "eps": 1e-15}},
+        "optimizer": {"name": "Adam", "args": {"lr": 0.01, "betas": [0.9, 0.99], "eps": 1e-15}, "sharded": bool(a.sharded_adam)},
     }
 
 
@@ -361,7 +363,9 @@ def main():
                           "noise_pred_hip_graph": bool(getattr(system.guidance, "_graphs", None)),
                           "process_group": (dist.get_backend() if use_dist else None),
                           "peak_hbm_gb": torch.cuda.max_memory_allocated() / 1e9,
-                          "parallelism": f"dp{world} (views sharded, 1 all-reduce of {system.flat.numel * 4 / 1e6:.1f} MB fp32 grads)",
+                          "parallelism": (f"dp{world} (views sharded, reduce-scatter + sharded Adam + all-gather of {system.flat.numel * 4 / 1e6:.1f} MB fp32)"
+                                          if a.sharded_adam else
+                                          f"dp{world} (views sharded, 1 all-reduce of {system.flat.numel * 4 / 1e6:.1f} MB fp32 grads)"),
                           "final_loss": float(loss)}}
         # ---- rooflines from HIP events around the launches: `roofline` (conv) live in the timed region, the others on the
         # extra steps that follow it (same workload, same streams)

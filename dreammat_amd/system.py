@@ -4,7 +4,8 @@ training loop that replaces Lightning's Trainer for this path (launch.py:172-193
 One process per GPU.  Per optimizer step:
   update_step schedules -> collate (views of this rank) -> renderer -> guidance -> loss ->
   backward (VAE-enc bwd -> antialias bwd -> shade bwd -> MLP bwd -> hash-grid scatter) ->
-  ONE all-reduce (RCCL over xGMI) of the flat fp32 gradient buffer -> fused Adam (mean folded in).
+  ONE all-reduce (RCCL over xGMI) of the flat fp32 gradient buffer -> fused Adam (mean folded in); or, with
+  `optimizer.sharded: true`, reduce-scatter -> Adam on this rank's slice -> all-gather of the parameters.
 All trainable parameters (hash table + 2 MLP matrices) live in one flat, 16 B-aligned buffer whose
 slices back the module parameters, so the collective and the optimizer each touch memory once.
 """
@@ -27,10 +28,10 @@ from .config import C, parse_structured
 class FlatParams:
     """Re-homes the given parameters into one flat fp32 buffer (+ matching flat grad buffer)."""
 
-    def __init__(self, params):
+    def __init__(self, params, pad_to=4):
         self.params = [p for p in params if p.requires_grad]
         n = sum(p.numel() for p in self.params)
-        n_pad = (n + 3) // 4 * 4
+        n_pad = (n + pad_to - 1) // pad_to * pad_to          # 16-byte vectors; 4 x world for the sharded optimizer
         dev = self.params[0].device
         self.flat = torch.zeros(n_pad, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(n_pad, device=dev, dtype=torch.float32)
@@ -89,11 +90,70 @@ class FusedAdam:
         hipops.adam_step(self.fp.flat, self.fp.grad, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr,
                          self.betas[0], self.betas[1], self.eps, grad_scale=1.0 / world, zero_grad=True)
 
+    def sync_and_step(self):
+        """the step's data-path collective + the update: ONE all-reduce (SUM) of the flat gradient, mean folded into Adam"""
+        self.step(allreduce_sum_(self.fp.grad))
+
     def state_dict(self):
         return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count}
 
     def load_state_dict(self, sd):
         self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"]); self.step_count = sd["step"]
+
+
+class ShardedFusedAdam:
+    """`optimizer.sharded: true` -- SURVEY 8(e)'s preferred exchange: reduce-scatter of the flat gradient, Adam on this
+    rank's 1/world slice (moments held for that slice only), all-gather of the updated parameters.  Same bytes on the wire as
+    the all-reduce (each of the 7 xGMI links carries 1/8 of the buffer per phase), 1/world of the optimizer's work and state.
+    Same result as FusedAdam up to the summation order of the collective (identical at world 2).  `adam_fn` = the update of
+    one contiguous slice (the HIP kernel; the CPU tests pass a torch restatement)."""
+
+    def __init__(self, fp: FlatParams, lr=0.01, betas=(0.9, 0.99), eps=1e-15, adam_fn=None):
+        on = dist.is_available() and dist.is_initialized()
+        self.world, self.rank = (dist.get_world_size(), dist.get_rank()) if on else (1, 0)
+        self.collective = on                 # a process group of one rank still goes through RCCL (bench.py DREAMMAT_FORCE_DIST)
+        n = fp.flat.numel()
+        assert n % (4 * self.world) == 0, "FlatParams(pad_to=4 * world) is required for the sharded optimizer"
+        self.fp, self.lr, self.betas, self.eps = fp, lr, tuple(betas), eps
+        self.adam_fn = adam_fn or hipops.adam_step
+        self.shard = n // self.world
+        self.lo = self.rank * self.shard
+        self.p_shard = fp.flat[self.lo:self.lo + self.shard].clone()      # this rank's master copy of its slice
+        self.g_shard = torch.zeros_like(self.p_shard)
+        self.exp_avg = torch.zeros_like(self.p_shard)
+        self.exp_avg_sq = torch.zeros_like(self.p_shard)
+        self.step_count = 0
+
+    def sync_and_step(self):
+        self.step_count += 1
+        if self.collective:
+            dist.reduce_scatter_tensor(self.g_shard, self.fp.grad, op=dist.ReduceOp.SUM)
+        else:
+            self.g_shard.copy_(self.fp.grad)
+        self.fp.grad.zero_()                                              # autograd accumulates into it next step
+        self.adam_fn(self.p_shard, self.g_shard, self.exp_avg, self.exp_avg_sq, self.step_count, self.lr, self.betas[0],
+                     self.betas[1], self.eps, grad_scale=1.0 / self.world, zero_grad=True)
+        if self.collective:
+            dist.all_gather_into_tensor(self.fp.flat, self.p_shard)
+        else:
+            self.fp.flat.copy_(self.p_shard)
+
+    def _gathered(self, t):
+        if not self.collective:
+            return t.clone()
+        full = torch.empty(self.shard * self.world, device=t.device, dtype=t.dtype)
+        dist.all_gather_into_tensor(full, t)
+        return full
+
+    def state_dict(self):
+        """the FULL moments, gathered (same layout as FusedAdam's: a checkpoint resumes under either optimizer, any world size
+        that divides the padded buffer) -- a collective: every rank calls it"""
+        return {"exp_avg": self._gathered(self.exp_avg), "exp_avg_sq": self._gathered(self.exp_avg_sq), "step": self.step_count}
+
+    def load_state_dict(self, sd):
+        sl = slice(self.lo, self.lo + self.shard)
+        self.exp_avg.copy_(sd["exp_avg"][sl]); self.exp_avg_sq.copy_(sd["exp_avg_sq"][sl]); self.step_count = sd["step"]
+        self.p_shard.copy_(self.fp.flat[sl])                              # the parameters were restored just before
 
 
 @dreammat_amd.register("dreammat-system")
@@ -165,11 +225,13 @@ class DreamMat(nn.Module, Updateable):
         opt = self.cfg.optimizer or {"name": "Adam", "args": {"lr": 0.01, "betas": [0.9, 0.99], "eps": 1e-15}}
         if opt.get("name", "Adam") != "Adam":
             raise NotImplementedError("only the Adam of dreammat.yaml:110-115 is implemented (fused HIP kernel)")
-        self.flat = FlatParams(list(self.parameters()))
+        sharded = bool(opt.get("sharded", False))
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.flat = FlatParams(list(self.parameters()), pad_to=4 * world if sharded else 4)
         sync_parameters_(self.flat.flat)
         args = opt.get("args", {})
-        self.optimizer = FusedAdam(self.flat, lr=args.get("lr", 0.01), betas=args.get("betas", (0.9, 0.99)),
-                                   eps=args.get("eps", 1e-15))
+        cls = ShardedFusedAdam if sharded else FusedAdam
+        self.optimizer = cls(self.flat, lr=args.get("lr", 0.01), betas=args.get("betas", (0.9, 0.99)), eps=args.get("eps", 1e-15))
         return self.optimizer
 
     def forward(self, batch):
@@ -221,10 +283,11 @@ class Trainer:
         self.rank = get_rank()
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
-    def save_checkpoint(self, path):
+    def save_checkpoint(self, path, optimizer_state=None):
         s = self.system
         torch.save({"state_dict": {k: v for k, v in s.state_dict().items()},
-                    "optimizer": s.optimizer.state_dict(), "global_step": s.true_global_step,
+                    "optimizer": optimizer_state if optimizer_state is not None else s.optimizer.state_dict(),
+                    "global_step": s.true_global_step,
                     "epoch": s.true_current_epoch}, path)
 
     def load_checkpoint(self, path):
@@ -253,8 +316,10 @@ class Trainer:
             batch = to_device(self.dm.train_dataset.collate(), s.device_)
         loss, logs = s.training_step(batch, rng=rng)
         loss.backward()
-        world = allreduce_sum_(s.flat.grad)
-        s.optimizer.step(world)
+        if hasattr(s.optimizer, "sync_and_step"):
+            s.optimizer.sync_and_step()           # all-reduce + Adam, or reduce-scatter + sharded Adam + all-gather
+        else:
+            s.optimizer.step(allreduce_sum_(s.flat.grad))
         s.true_global_step += 1
         return loss, logs
 
@@ -278,8 +343,10 @@ class Trainer:
                 row.update({k: float(v) for k, v in logs.items()})
                 self.csv.write(json.dumps(row) + "\n")
                 self.csv.flush()
-            if self.rank == 0 and self.checkpoint_every and step % self.checkpoint_every == 0:
-                self.save_checkpoint(os.path.join(self.trial_dir, "ckpts", f"step={step}.ckpt"))
+            if self.checkpoint_every and step % self.checkpoint_every == 0:
+                opt_state = s.optimizer.state_dict()          # gathers the moments under the sharded optimizer: every rank calls it
+                if self.rank == 0:
+                    self.save_checkpoint(os.path.join(self.trial_dir, "ckpts", f"step={step}.ckpt"), opt_state)
             if self.rank == 0 and self.val_check_interval and step % self.val_check_interval == 0:
                 self.validate()
             if self.checkpoint_every and step % self.checkpoint_every == 0 and os.environ.get("DREAMMAT_CHECK_REPLICAS"):

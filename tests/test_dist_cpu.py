@@ -162,3 +162,73 @@ def test_replicas_start_identical_stay_identical_and_draw_different_noise(tmp_pa
     assert torch.equal(r0["before"][:r0["built"].numel()], r0["built"])       #     ... and they are rank 0's
     assert torch.equal(r0["after"], r1["after"]) and not torch.equal(r0["after"], r0["before"])   # ... and after N
     assert not torch.equal(r0["t"], r1["t"]) and not torch.equal(r0["noise"], r1["noise"])       # (ii) per-rank draws
+
+
+# ---- optimizer.sharded: reduce-scatter + Adam on the rank's slice + all-gather (SURVEY 8e "prefer") against all-reduce + full Adam
+def _cpu_adam_step(param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, grad_scale=1.0, zero_grad=True):
+    """dm_adam_step's contract (csrc/adam.hip) restated in torch: torch.optim.Adam semantics, mean folded in, grad zeroed."""
+    g = grad * grad_scale
+    exp_avg.mul_(beta1).add_(g, alpha=1 - beta1)
+    exp_avg_sq.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    mh, vh = exp_avg / (1 - beta1 ** step), exp_avg_sq / (1 - beta2 ** step)
+    param.sub_(lr * mh / (vh.sqrt() + eps))
+    if zero_grad:
+        grad.zero_()
+
+
+def _sharded_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dreammat_amd import system as sysm
+
+    def make(sharded):
+        torch.manual_seed(0)
+        params = [torch.nn.Parameter(torch.randn(1001)), torch.nn.Parameter(torch.randn(7, 5)), torch.nn.Parameter(torch.randn(3))]
+        fp = sysm.FlatParams(params, pad_to=4 * world if sharded else 4)
+        if sharded:
+            opt = sysm.ShardedFusedAdam(fp, lr=0.01, betas=(0.9, 0.99), eps=1e-15, adam_fn=_cpu_adam_step)
+        else:
+            opt = sysm.FusedAdam(fp, lr=0.01, betas=(0.9, 0.99), eps=1e-15)
+            opt.step = lambda w, o=opt: (setattr(o, "step_count", o.step_count + 1),
+                                         _cpu_adam_step(fp.flat, fp.grad, o.exp_avg, o.exp_avg_sq, o.step_count, o.lr, *o.betas, o.eps,
+                                                        grad_scale=1.0 / w))
+        return params, fp, opt
+
+    def run(params, fp, opt, steps, g):
+        for _ in range(steps):
+            loss = sum((p * torch.randn(p.shape, generator=g)).sum() + (p ** 2).sum() * (rank + 1) for p in params)   # rank-dependent
+            loss.backward()
+            opt.sync_and_step()
+        return fp.flat[:fp.numel].clone()
+
+    ga, gb = torch.Generator().manual_seed(100 + rank), torch.Generator().manual_seed(100 + rank)
+    pa, fa, oa = make(False)
+    pb, fb, ob = make(True)
+    ref = run(pa, fa, oa, 3, ga)
+    got = run(pb, fb, ob, 3, gb)
+    assert ob.exp_avg.numel() * world == fb.flat.numel() and fb.flat.numel() % (4 * world) == 0      # 1/world of the state
+    assert pb[1].data.data_ptr() == fb.flat[1001:].data_ptr()                                    # parameters still live in the flat buffer
+    assert float(fb.grad.abs().max()) == 0.0                                                       # zeroed for the next accumulation
+    # checkpoint round trip through the gathered state: resume under the sharded optimizer and continue identically
+    sd = ob.state_dict()
+    assert sd["exp_avg"].numel() == fb.flat.numel() and torch.allclose(sd["exp_avg"][:fa.numel], oa.exp_avg[:fa.numel], atol=1e-7)
+    pc, fc, oc = make(True)
+    fc.flat.copy_(fb.flat)
+    oc.load_state_dict(sd)
+    cont_b = run(pb, fb, ob, 2, gb)
+    gc = torch.Generator().manual_seed(100 + rank); [torch.randn(p.shape, generator=gc) for _ in range(3) for p in pc]   # same stream position
+    cont_c = run(pc, fc, oc, 2, gc)
+    torch.save({"ref": ref, "got": got, "cont_b": cont_b, "cont_c": cont_c}, os.path.join(out_dir, f"s{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_sharded_adam_matches_allreduce_adam_on_two_ranks(tmp_path):
+    """system.ShardedFusedAdam over gloo at world size 2: three steps with rank-dependent gradients give the parameters of
+    all-reduce + full Adam (the two-term sums are order-independent), every rank ends with the same full parameter buffer,
+    and a checkpoint taken from the gathered moments resumes to the same trajectory."""
+    port = _free_port()
+    mp.spawn(_sharded_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "s0.pt"), torch.load(tmp_path / "s1.pt")
+    assert torch.equal(r0["got"], r1["got"]) and torch.equal(r0["ref"], r1["ref"])
+    assert torch.allclose(r0["got"], r0["ref"], atol=1e-6, rtol=1e-6)
+    assert torch.equal(r0["cont_b"], r0["cont_c"]) and torch.equal(r0["cont_b"], r1["cont_b"])

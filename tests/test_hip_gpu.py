@@ -1306,9 +1306,11 @@ def test_controlnet_cond_embedding_stem_kernels_vs_aten(dev):
     assert (y - ref).abs().max().item() < 3e-2 * ref.abs().max().item() + 3e-2
 
 
-def test_rccl_world1_step_through_bench(dev):
+@pytest.mark.parametrize("sharded", [False, True])
+def test_rccl_world1_step_through_bench(dev, sharded):
     """RCCL in the GPU test tier: bench.py with DREAMMAT_FORCE_DIST=1 initialises the `nccl` (= RCCL) process group at world
-    size 1 and runs real optimisation steps whose flat-gradient all-reduce / barriers go through it (tiny nets, 64^2)."""
+    size 1 and runs real optimisation steps whose flat-gradient all-reduce / barriers go through it (tiny nets, 64^2); with
+    `--sharded-adam` the exchange is RCCL's reduce-scatter + all-gather around the sharded fused Adam (optimizer.sharded)."""
     import json
     import subprocess
     import sys
@@ -1316,12 +1318,14 @@ def test_rccl_world1_step_through_bench(dev):
     env = dict(os.environ, DREAMMAT_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", RANK="0", WORLD_SIZE="1",
                LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--views", "2", "--res", "64",
-                        "--sd", "tiny", "--mesh", "sphere:24:24", "--env-res", "32", "--no-cpu-baseline"],
+                        "--sd", "tiny", "--mesh", "sphere:24:24", "--env-res", "32", "--no-cpu-baseline"]
+                       + (["--sharded-adam"] if sharded else []),
                        cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1]
     res = json.loads(line)
-    assert res["n_gpus"] == 1 and res["value"] > 0 and "all-reduce" in res["config"]["parallelism"]
+    assert res["n_gpus"] == 1 and res["value"] > 0
+    assert ("reduce-scatter" if sharded else "all-reduce") in res["config"]["parallelism"]
     assert "ProcessGroupNCCL" in r.stderr or "NCCL" in r.stderr.upper() or res["config"].get("process_group") == "nccl"
 
 
