@@ -232,3 +232,45 @@ def test_sharded_adam_matches_allreduce_adam_on_two_ranks(tmp_path):
     assert torch.equal(r0["got"], r1["got"]) and torch.equal(r0["ref"], r1["ref"])
     assert torch.allclose(r0["got"], r0["ref"], atol=1e-6, rtol=1e-6)
     assert torch.equal(r0["cont_b"], r0["cont_c"]) and torch.equal(r0["cont_b"], r1["cont_b"])
+
+
+def _sharded_fit_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dreammat_amd import launch
+    from dreammat_amd.data import RandomCameraDataModule
+    from dreammat_amd.system import FlatParams, ShardedFusedAdam, Trainer, replicas_in_sync, sync_parameters_
+
+    def build(trial, max_steps, resume=None):
+        launch.seed_for_build(5)
+        system = _stub_system()
+
+        def configure_optimizers(s=system):
+            s.flat = FlatParams(list(s.parameters()), pad_to=4 * world)
+            sync_parameters_(s.flat.flat)
+            s.optimizer = ShardedFusedAdam(s.flat, lr=0.01, betas=(0.9, 0.99), eps=1e-15, adam_fn=_cpu_adam_step)
+        system.configure_optimizers = configure_optimizers
+        dm = RandomCameraDataModule(cfg={"height": 8, "width": 8, "batch_size": 2, "use_fix_views": True, "seed": 5}, rank=rank)
+        return system, Trainer(system, dm, max_steps=max_steps, trial_dir=os.path.join(out_dir, trial), val_check_interval=0,
+                               checkpoint_every=2, seed=5, resume=resume)
+
+    system, trainer = build("run", 4)
+    trainer.fit()                                        # checkpoints at steps 2 and 4: the moment gather is a collective
+    assert replicas_in_sync(system.flat.flat)
+    ck = os.path.join(out_dir, "run", "ckpts", "step=2.ckpt")
+    dist.barrier()
+    assert os.path.exists(ck) or rank != 0
+    saved = torch.load(ck, map_location="cpu")
+    assert saved["optimizer"]["exp_avg"].numel() == system.flat.flat.numel() and saved["global_step"] == 2
+    torch.save({"after4": system.flat.flat.clone()}, os.path.join(out_dir, f"fit{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_fit_loop_with_the_sharded_optimizer_checkpoints_without_deadlock(tmp_path):
+    """Trainer.fit over gloo at world size 2 with optimizer.sharded semantics: the checkpoint's moment gather runs on EVERY rank
+    (rank 0 alone writes the file), replicas stay bit-identical, and the checkpoint holds the full-size moments."""
+    port = _free_port()
+    mp.spawn(_sharded_fit_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "fit0.pt"), torch.load(tmp_path / "fit1.pt")
+    assert torch.equal(r0["after4"], r1["after4"])
+    assert sorted(os.listdir(tmp_path / "run" / "ckpts")) == ["step=2.ckpt", "step=4.ckpt"]
