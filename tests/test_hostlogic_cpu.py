@@ -552,3 +552,30 @@ def test_trainable_conv_autograd_algebra_around_the_three_kernels(contract, monk
     ref.backward(g)
     for got, want in ((x.grad, x2.grad), (w.grad, w2.grad), (b.grad, b2.grad)):
         assert torch.allclose(got, want, atol=1e-11)
+
+
+def test_training_route_gates_accept_the_kernel_domains_only():
+    """hipops.attention_train_ok / conv3x3_train_ok (pure host logic): what the differentiated MFMA routes serve, and what is
+    handed back to torch autograd (im2col, matmul-softmax) -- decided before any kernel is called, never by a failing launch."""
+    from types import SimpleNamespace as NS
+
+    def t(shape, dtype=torch.bfloat16, cuda=True):
+        return NS(shape=torch.Size(shape), dtype=dtype, is_cuda=cuda)
+    q, k = t((2, 256, 320)), t((2, 77, 320))
+    assert hipops.attention_train_ok(q, k, t((2, 77, 320)), 5)                       # D = 64
+    assert hipops.attention_train_ok(t((2, 64, 1280)), t((2, 64, 1280)), t((2, 64, 1280)), 10)     # D = 128
+    assert not hipops.attention_train_ok(q, k, t((2, 77, 320)), 2)                   # D = 160: beyond the backward's head sizes
+    assert not hipops.attention_train_ok(q, k, t((2, 77, 320), torch.float32), 5)    # fp32 values
+    assert not hipops.attention_train_ok(t((2, 256, 320), cuda=False), k, t((2, 77, 320)), 5)
+    assert not hipops.attention_train_ok(q, k, t((2, 80, 320)), 5)                   # k / v of different lengths
+    w = lambda co, ci, dtype=torch.bfloat16: NS(shape=torch.Size((co, ci, 3, 3)), dtype=dtype)
+    x = lambda b, h, wd, c: NS(shape=torch.Size((b, h, wd, c)), dtype=torch.bfloat16, is_cuda=True)
+    ok = hipops.conv3x3_train_ok
+    assert ok(x(4, 64, 64, 320), w(320, 320), (1, 1), (1, 1)) and ok(x(4, 64, 64, 320), w(640, 320), (2, 2), (1, 1))
+    assert ok(x(2, 8, 8, 1280), w(1280, 1280), (1, 1), (1, 1))                       # 64 pixels per image: one chunk
+    assert not ok(x(4, 64, 64, 320), w(320, 320), (1, 1), (0, 0))                    # padding other than 1
+    assert not ok(x(4, 64, 64, 96), w(256, 96), (2, 2), (1, 1))                      # Cin not a multiple of 64 (conditioning embedding)
+    assert not ok(x(4, 4, 4, 1280), w(1280, 1280), (1, 1), (1, 1))                   # 16 pixels per image: below one chunk
+    assert not ok(x(1, 128, 128, 64), w(64, 64), (1, 1), (1, 1))                     # rows wider than one 64-pixel chunk
+    assert not ok(x(4, 64, 64, 320), w(320, 320, torch.float32), (1, 1), (1, 1))     # fp32 master weights
+    assert not ok(x(1, 64, 48, 64), w(64, 64), (1, 1), (1, 1))                       # width not a power of two
