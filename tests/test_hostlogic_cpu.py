@@ -579,3 +579,32 @@ def test_training_route_gates_accept_the_kernel_domains_only():
     assert not ok(x(1, 128, 128, 64), w(64, 64), (1, 1), (1, 1))                     # rows wider than one 64-pixel chunk
     assert not ok(x(4, 64, 64, 320), w(320, 320, torch.float32), (1, 1), (1, 1))     # fp32 master weights
     assert not ok(x(1, 64, 48, 64), w(64, 64), (1, 1), (1, 1))                       # width not a power of two
+
+
+def test_static_isa_guards_on_the_lds_dma_main_loops():
+    """No GPU needed: the steady-state blocks of the two LDS-DMA kernels that carry the step must keep their counted waits.
+    hipcc inserts `s_waitcnt vmcnt(0)` in front of any LDS read it believes may alias a `buffer_load ... lds` destination, which
+    silently drains the DMA ring every tile (round 1: 620 -> 815 TF/s when removed; round 3: the untransposed-V attention
+    experiment, profiles/r03_experiments/attn_w64_natural_v.json) -- a source edit that brings it back fails here."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("isa_waits", os.path.join(root, "tools", "isa_waits.py"))
+    iw = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(iw)
+
+    def steady_blocks(src, pattern, n_mfma):
+        (name, body), = list(iw.kernels(iw.assembly(os.path.join(root, "dreammat_amd", "csrc", src)), pattern))
+        return [ins for _, ins in iw.blocks(body) if sum(i.startswith("v_mfma") for i in ins) == n_mfma]
+    tiles = steady_blocks("attn_w64.hip", "k_attn_fwd_w64ILi2E", 32)
+    tiles = [t for t in tiles if len(t) < 300]                      # the unrolled ring of the main loop (not the exact path)
+    assert len(tiles) >= 5
+    for t in tiles:
+        waits = [i.split(None, 1)[1] for i in t if i.startswith("s_waitcnt")]
+        assert not any("vmcnt(0)" in w for w in waits), waits
+        assert 12 <= sum(i.startswith("ds_read_b128") for i in t) <= 16 and sum(i.startswith("buffer_load") for i in t) <= 4
+    for pattern in ("k_conv3x3_dmaILi512ELi128ELi8ELi4ELi2ELi9ELi0", "k_conv3x3_dmaILi256ELi256ELi8ELi2ELi2ELi9ELi0"):
+        chunks = steady_blocks("conv.hip", pattern, 8)
+        assert chunks
+        for c in chunks:
+            assert not any(i.startswith("s_waitcnt") and "vmcnt(0)" in i for i in c)
+            assert not any("scratch_" in i for i in c)
