@@ -13,8 +13,10 @@ diffusers_dataset.py:10-159) and a one-process-per-GPU launcher (`python -m drea
 uses HF accelerate, diffusers_train_controlnet.py:858-915: same loop, gradients all-reduced over RCCL).  What is NOT here: the CLIP
 text encoder (text embeddings come from prompt.py's encoder or its synthetic stand-in) and Blender (the tree is an input).  The frozen UNet / VAE run on the same HIP
 kernels as the SDS path wherever those are differentiable (implicit-GEMM conv data gradients, GroupNorm backward); the
-attention of the UNet falls back to the matmul-softmax path under autograd (the MFMA attention kernel is forward-only)
-and the trainable ControlNet convolutions use the im2col lowering, so this is a correctness-first implementation.
+differentiated attention runs the MFMA forward-with-statistics + backward kernels (csrc/attn_bwd.hip), the trainable 3x3
+convolutions forward / data gradient / weight gradient on the conv kernels (csrc/conv_wgrad.hip; layers with whole 64-channel
+tiles, the others through im2col) and GroupNorm returns its affine gradients; Linear / LayerNorm / GEGLU are torch autograd
+(hipBLASLt + ATen).  A full-size step (batch 4, 512^2): tools/train_step_probe.py.
 """
 import json
 import os
