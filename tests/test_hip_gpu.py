@@ -1314,8 +1314,12 @@ def test_rccl_world1_step_through_bench(dev, sharded):
     import json
     import subprocess
     import sys
+    import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DREAMMAT_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", RANK="0", WORLD_SIZE="1",
+    with socket.socket() as sk:                       # a free port per run: the two parametrisations follow each other closely
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, DREAMMAT_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
                LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--views", "2", "--res", "64",
                         "--sd", "tiny", "--mesh", "sphere:24:24", "--env-res", "32", "--no-cpu-baseline"]
