@@ -16,7 +16,7 @@ if os.environ.get("DREAMMAT_LIB"):       # development aid (tools/grad_budget.py
     LIB_PATH = os.environ["DREAMMAT_LIB"]
 
 _lib = None
-ABI_VERSION = 8      # dm_abi_version() of the library this binding was written for (csrc/host.cpp, include/dreammat_hip.h)
+ABI_VERSION = 9      # dm_abi_version() of the library this binding was written for (csrc/host.cpp, include/dreammat_hip.h)
 
 DM_ERRORS = {-1: "DM_ERR_ARG", -2: "DM_ERR_WORKSPACE", -3: "DM_ERR_UNSUPPORTED"}
 
@@ -73,6 +73,10 @@ _SIGS = {
     "dm_gbuffer_compact": (c_int, [c_void_p, _LL, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float,
                                    _LL, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                    c_void_p]),
+    "dm_gbuffer_tiled_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "dm_gbuffer_compact_tiled": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_float, _LL, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_size_t, c_void_p]),
     "dm_control_maps": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
     "dm_scatter_rows": (c_int, [c_void_p, c_void_p, _LL, c_void_p, _LL, _LL, c_int, c_void_p, c_void_p]),

@@ -293,13 +293,43 @@ __global__ void k_aa_grad(const float* __restrict__ dout, const float2* __restri
 }
 
 // ---------------------------------------------------------------------------- G-buffer compaction
-// Row-major order-preserving compaction of covered pixels (what `x[selector]` does in
-// raytracing_renderer.py:140-175) in three small kernels: per-block counts, block scan, write.
+// Order-preserving compaction of covered pixels (what `x[selector]` does in raytracing_renderer.py:140-175) in three
+// small kernels: per-block counts, block scan, write.  Two enumeration orders of the pixels (the compacted rows keep
+// their global pixel index in pix_idx, so everything downstream -- scatter, antialias, the field, the shade kernels --
+// is order-agnostic):
+//   row  : i = block * 256 + thread, the reference's row-major `x[selector]` order (dm_gbuffer_compact);
+//   tile : one workgroup per 16 x 16 macro tile (macro tiles row-major inside a view, views in order), one wave per
+//          8 x 8 sub-tile (sub-tiles row-major inside the macro tile), lanes in Morton (Z) order inside the sub-tile, so
+//          that a lane quad is a 2 x 2 pixel block (dm_gbuffer_compact_tiled).  The 64 pixels a wave of ANY later kernel
+//          works on then span ~8 x 8 pixels instead of a 64-pixel scanline run: their normals / reflection vectors
+//          (cube-map lines of the shade kernels) and positions (hash-grid cells) are neighbours in both directions.
 constexpr int kCompactBlock = 256;
 
-__global__ void k_cover_count(const float4* __restrict__ rast, long long npix, int* __restrict__ block_cnt) {
-    long long i = (long long)blockIdx.x * kCompactBlock + threadIdx.x;
-    bool cov = i < npix && rast[i].w > 0.f;
+struct PixMap {
+    int tiled;           // 0: row order over npix; 1: tile order
+    int W, H;
+    int tiles_x, tiles_per_view;
+    long long npix;
+};
+// linear pixel index of (block, thread), or -1 when the slot lies outside the image(s)
+__device__ __forceinline__ long long pixmap_index(const PixMap& m, int block, int thread) {
+    if (!m.tiled) {
+        long long i = (long long)block * kCompactBlock + thread;
+        return i < m.npix ? i : -1;
+    }
+    const int view = block / m.tiles_per_view, t = block - view * m.tiles_per_view;
+    const int ty = t / m.tiles_x, tx = t - ty * m.tiles_x;
+    const int wave = thread >> 6, l = thread & 63;
+    const int lx = (l & 1) | ((l >> 1) & 2) | ((l >> 2) & 4);          // Morton decode: even bits -> x
+    const int ly = ((l >> 1) & 1) | ((l >> 2) & 2) | ((l >> 3) & 4);   //                odd bits  -> y
+    const int x = tx * 16 + (wave & 1) * 8 + lx, y = ty * 16 + (wave >> 1) * 8 + ly;
+    if (x >= m.W || y >= m.H) return -1;
+    return ((long long)view * m.H + y) * m.W + x;
+}
+
+__global__ void k_cover_count(const float4* __restrict__ rast, PixMap pm, int* __restrict__ block_cnt) {
+    long long i = pixmap_index(pm, blockIdx.x, threadIdx.x);
+    bool cov = i >= 0 && rast[i].w > 0.f;
     unsigned long long m = __ballot(cov);
     __shared__ int wsum[kCompactBlock / 64];
     int wave = threadIdx.x >> 6;
@@ -347,7 +377,7 @@ struct GBufArgs {
     const float* jitter_u;  // [P] in [0,1)  (may be null => no jitter output)
     const float* jitter_n;  // [P] ~N(0,1)
     float jitter_eps;
-    long long npix;
+    PixMap pm;
     const int* block_off;
     // outputs, SoA with row pitch `cap` (= capacity in rows, >= N): x[c*cap + i]
     int* pix_idx;        // [cap]
@@ -359,9 +389,9 @@ struct GBufArgs {
 };
 
 __global__ void k_gbuffer_compact(GBufArgs a) {
-    long long i = (long long)blockIdx.x * kCompactBlock + threadIdx.x;
+    const long long i = pixmap_index(a.pm, blockIdx.x, threadIdx.x);
     float4 r = make_float4(0, 0, 0, 0);
-    if (i < a.npix) r = a.rast[i];
+    if (i >= 0) r = a.rast[i];
     bool cov = r.w > 0.f;
     unsigned long long m = __ballot(cov);
     __shared__ int wsum[kCompactBlock / 64];
@@ -629,6 +659,32 @@ int dm_antialias_grad(const float* dout, const float* plan, int B, int H, int W,
 size_t dm_gbuffer_workspace_bytes(long long n_pix) {
     return (size_t)dm_div_up(n_pix, kCompactBlock) * 4 + 256;
 }
+size_t dm_gbuffer_tiled_workspace_bytes(int B, int H, int W) {
+    return (size_t)B * dm_div_up(H, 16) * dm_div_up(W, 16) * 4 + 256;
+}
+
+static int gbuffer_compact_impl(PixMap pm, int nblocks, const float* rast, const int32_t* tri, const float* v_pos,
+                                const float* v_nrm, const float* rays_d, const float* jitter_u, const float* jitter_n,
+                                float jitter_eps, long long cap, int32_t* pix_idx, float* pos, float* pos_jitter,
+                                float* nrm, float* view, int32_t* n_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (!rast || !tri || !v_pos || !v_nrm || !rays_d || !pix_idx || !pos || !nrm || !view || !n_out || !ws ||
+        pm.npix <= 0 || cap <= 0)
+        return DM_ERR_ARG;
+    if ((jitter_u == nullptr) != (jitter_n == nullptr)) return DM_ERR_ARG;
+    if (jitter_u && !pos_jitter) return DM_ERR_ARG;
+    if (ws_bytes < (size_t)nblocks * 4) return DM_ERR_WORKSPACE;
+    int* block_cnt = (int*)ws;
+    DM_ENTER();
+    hipLaunchKernelGGL(k_cover_count, dim3(nblocks), dim3(kCompactBlock), 0, stream, (const float4*)rast, pm, block_cnt);
+    hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, stream, block_cnt, nblocks, n_out);
+    GBufArgs a;
+    a.rast = (const float4*)rast; a.tri = tri; a.v_pos = v_pos; a.v_nrm = v_nrm; a.rays_d = rays_d;
+    a.jitter_u = jitter_u; a.jitter_n = jitter_n; a.jitter_eps = jitter_eps; a.pm = pm; a.block_off = block_cnt;
+    a.pix_idx = pix_idx; a.pos = pos; a.pos_jit = pos_jitter; a.nrm = nrm; a.view = view; a.cap = cap;
+    hipLaunchKernelGGL(k_gbuffer_compact, dim3(nblocks), dim3(kCompactBlock), 0, stream, a);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
 
 // Compacts covered pixels (row-major) and emits, SoA with pitch `cap`: pix_idx[cap], pos[3,cap],
 // pos_jitter[3,cap] (if jitter_u/jitter_n given), nrm[3,cap], view[3,cap]; *n_out (device int) = N.
@@ -636,25 +692,24 @@ int dm_gbuffer_compact(const float* rast, long long n_pix, const int32_t* tri, c
                        const float* v_nrm, const float* rays_d, const float* jitter_u, const float* jitter_n,
                        float jitter_eps, long long cap, int32_t* pix_idx, float* pos, float* pos_jitter, float* nrm,
                        float* view, int32_t* n_out, void* ws, size_t ws_bytes, hipStream_t stream) {
-    if (!rast || !tri || !v_pos || !v_nrm || !rays_d || !pix_idx || !pos || !nrm || !view || !n_out || !ws ||
-        n_pix <= 0 || cap <= 0)
-        return DM_ERR_ARG;
-    if ((jitter_u == nullptr) != (jitter_n == nullptr)) return DM_ERR_ARG;
-    if (jitter_u && !pos_jitter) return DM_ERR_ARG;
-    int nblocks = dm_div_up(n_pix, kCompactBlock);
-    if (ws_bytes < (size_t)nblocks * 4) return DM_ERR_WORKSPACE;
-    int* block_cnt = (int*)ws;
-    DM_ENTER();
-    hipLaunchKernelGGL(k_cover_count, dim3(nblocks), dim3(kCompactBlock), 0, stream, (const float4*)rast, n_pix,
-                       block_cnt);
-    hipLaunchKernelGGL(k_block_scan, dim3(1), dim3(1024), 0, stream, block_cnt, nblocks, n_out);
-    GBufArgs a;
-    a.rast = (const float4*)rast; a.tri = tri; a.v_pos = v_pos; a.v_nrm = v_nrm; a.rays_d = rays_d;
-    a.jitter_u = jitter_u; a.jitter_n = jitter_n; a.jitter_eps = jitter_eps; a.npix = n_pix; a.block_off = block_cnt;
-    a.pix_idx = pix_idx; a.pos = pos; a.pos_jit = pos_jitter; a.nrm = nrm; a.view = view; a.cap = cap;
-    hipLaunchKernelGGL(k_gbuffer_compact, dim3(nblocks), dim3(kCompactBlock), 0, stream, a);
-    DM_LAUNCH_CHECK();
-    return DM_OK;
+    PixMap pm = {};
+    pm.tiled = 0; pm.npix = n_pix;
+    return gbuffer_compact_impl(pm, dm_div_up(n_pix, kCompactBlock), rast, tri, v_pos, v_nrm, rays_d, jitter_u, jitter_n,
+                                jitter_eps, cap, pix_idx, pos, pos_jitter, nrm, view, n_out, ws, ws_bytes, stream);
+}
+
+// The same rows in TILE order (see the order notes above k_cover_count): rast is [B,H,W,4]; pix_idx still holds the
+// global row-major pixel index (b*H*W + y*W + x) of every compacted row.
+int dm_gbuffer_compact_tiled(const float* rast, int B, int H, int W, const int32_t* tri, const float* v_pos,
+                             const float* v_nrm, const float* rays_d, const float* jitter_u, const float* jitter_n,
+                             float jitter_eps, long long cap, int32_t* pix_idx, float* pos, float* pos_jitter,
+                             float* nrm, float* view, int32_t* n_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (B <= 0 || H <= 0 || W <= 0) return DM_ERR_ARG;
+    PixMap pm = {};
+    pm.tiled = 1; pm.W = W; pm.H = H; pm.tiles_x = dm_div_up(W, 16); pm.tiles_per_view = pm.tiles_x * dm_div_up(H, 16);
+    pm.npix = (long long)B * H * W;
+    return gbuffer_compact_impl(pm, B * pm.tiles_per_view, rast, tri, v_pos, v_nrm, rays_d, jitter_u, jitter_n, jitter_eps,
+                                cap, pix_idx, pos, pos_jitter, nrm, view, n_out, ws, ws_bytes, stream);
 }
 
 // ControlNet depth [B,H,W,1] + normal [B,H,W,3] maps (pre-antialias), minmax_ws >= B*8 bytes.

@@ -7,6 +7,7 @@
 // texels (one 16 B load per bilinear row) and the FG x-pair table -- see shade_core.h.
 // Reference: threestudio/models/materials/dreammat_material.py:679-711, 746-762.
 #include <cstdlib>
+#include <type_traits>
 
 #include "shade_core.h"
 
@@ -30,7 +31,7 @@ struct ShadeArgs {
     const int* n_dev;        // device count of rows
     int HW;
     int n_views;             // entries of env_of_view
-    int offsets32;           // inputs are SoA (unit row stride) and every byte offset fits 31 bits: the fast loop applies
+    int offsets32;           // inputs and outputs are SoA (unit row stride): the fast loop applies
     StridedOut color;        // [N,3]
     // optional debug outputs (null => skipped); rows of 3/3/3/3/1/1 floats, dense [N,C]
     float* albedo; float* spec_light; float* diff_light; float* spec_color; float* diff_color;
@@ -77,8 +78,8 @@ __device__ __forceinline__ void shade_pixel_loop(const ShadeArgs& a, const Strid
     const long long N = *a.n_dev;
     const long long stride = (long long)gridDim.x * blockDim.x;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (FMT == kTexelF32 || !a.atlas.fg_pairs || a.n_views > kMaxViewsLds || !a.offsets32) {   // legacy: monolithic, one-pixel prefetch,
-                                                                                                // any row strides
+    if (FMT == kTexelF32 || !a.atlas.fg_pairs || a.n_views > kMaxViewsLds || !a.offsets32 || N < 64) {   // generic: monolithic,
+                                                                                        // one-pixel prefetch, any row strides
         if (i >= N) return;
         ShadeIn cur, nxt;
         shade_load<BWD>(a, i, cur);
@@ -97,16 +98,28 @@ __device__ __forceinline__ void shade_pixel_loop(const ShadeArgs& a, const Strid
 #if defined(__HIP_DEVICE_COMPILE__)   // (__amdgpu_buffer_rsrc_t does not exist in the host pass)
     // per-mip tables and the view -> environment table in LDS: a per-lane index into the kernel-argument copies (or into
     // env_of_view) is a global load whose latency sits in front of every gather of the pixel
+    constexpr int NJ = BWD ? 4 : 3;             // 16-byte wave loads per 64-row batch: each covers 4 channels x 16 row quads
+    constexpr int NOUT = BWD ? 5 : 3;           // result channels
     __shared__ int s_mip_off[kMaxMips], s_mip_res[kMaxMips], s_env[kMaxViewsLds];
+    __shared__ unsigned long long s_chan[16], s_outp[8];      // byte address of every input / output channel row
+    __shared__ __attribute__((aligned(16))) unsigned s_x[4][16 * 64];    // one 4 KB transposition buffer per wave (wave-private)
     if (threadIdx.x < kMaxMips) {
         s_mip_off[threadIdx.x] = (int)a.atlas.mip_off[threadIdx.x];
         s_mip_res[threadIdx.x] = a.atlas.mip_res[threadIdx.x];
     }
     if ((int)threadIdx.x < a.n_views) s_env[threadIdx.x] = a.env_of_view[threadIdx.x];
+    if (threadIdx.x < 16) {                                   // channel order: nrm 0-2, view 3-5, features 6-10, pixel index 11, d colour 12-14
+        const int c = threadIdx.x;
+        const void* p = a.pix_idx;
+        if (c < 3) p = a.nrm.p + c * a.nrm.cs;
+        else if (c < 6) p = a.view.p + (c - 3) * a.view.cs;
+        else if (c < 11) p = a.feat.p + (c - 6) * a.feat.cs;
+        else if (BWD && c >= 12 && c < 15) p = a.dcolor.p + (c - 12) * a.dcolor.cs;
+        s_chan[c] = (unsigned long long)p;
+    }
+    if (threadIdx.x >= 32 && threadIdx.x < 32 + NOUT) s_outp[threadIdx.x - 32] = (unsigned long long)(out.p + (threadIdx.x - 32) * out.cs);
     __syncthreads();
-    // only now may a thread without a pixel leave: in the boundary workgroup of a small launch (N % 256 below the table
-    // sizes) the threads that fill the upper table entries are exactly the ones past the end
-    if (i >= N) return;
+    // (no thread leaves before this barrier: in a small launch the threads that fill the upper table entries may have no row)
     const float inv_hw = 1.0f / (float)a.HW;
     const int hw_shift = (a.HW & (a.HW - 1)) == 0 ? __builtin_ctz(a.HW) : -1;     // 512^2, 1024^2, ...: a shift
     auto env_of = [&](int pix) {
@@ -120,77 +133,131 @@ __device__ __forceinline__ void shade_pixel_loop(const ShadeArgs& a, const Strid
         }
         return s_env[view];                              // (n_views <= kMaxViewsLds on this path)
     };
-    // Everything is addressed as (uniform buffer descriptor) + (32-bit lane offset) [+ scalar offset]: no 64-bit lane
-    // arithmetic.  The SoA rows of one tensor share ONE lane offset (4*pixel); the channel is a scalar offset.
     constexpr int kAll = 0x7ffffffc;
     const __amdgpu_buffer_rsrc_t r_spec = __builtin_amdgcn_make_buffer_rsrc((void*)a.atlas.spec, 0, kAll, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_diff = __builtin_amdgcn_make_buffer_rsrc((void*)a.atlas.diff, 0, kAll, 0x00020000);
     const __amdgpu_buffer_rsrc_t r_fg = __builtin_amdgcn_make_buffer_rsrc((void*)a.atlas.fg_pairs, 0, kAll, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_nrm = __builtin_amdgcn_make_buffer_rsrc((void*)a.nrm.p, 0, kAll, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_view = __builtin_amdgcn_make_buffer_rsrc((void*)a.view.p, 0, kAll, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_feat = __builtin_amdgcn_make_buffer_rsrc((void*)a.feat.p, 0, kAll, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_pix = __builtin_amdgcn_make_buffer_rsrc((void*)a.pix_idx, 0, kAll, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_dcol = __builtin_amdgcn_make_buffer_rsrc((void*)(BWD ? a.dcolor.p : a.nrm.p), 0, kAll, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc((void*)out.p, 0, kAll, 0x00020000);
-    const int out_rs = (int)out.rs, out_cs4 = (int)out.cs * 4;
-    const int nc = (int)a.nrm.cs * 4, vc = (int)a.view.cs * 4, fc = (int)a.feat.cs * 4, dcs = BWD ? (int)a.dcolor.cs * 4 : 0;
-    auto ldf = [](__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-    };
-    auto load_soa = [&](unsigned idx, ShadeIn& in) {
-        const int vo = (int)(idx * 4u);
-        in.n = f3(ldf(r_nrm, vo, 0), ldf(r_nrm, vo, nc), ldf(r_nrm, vo, 2 * nc));
-        in.v = f3(ldf(r_view, vo, 0), ldf(r_view, vo, vc), ldf(r_view, vo, 2 * vc));
-#pragma unroll
-        for (int k = 0; k < 5; ++k) in.f[k] = ldf(r_feat, vo, k * fc);
-        if (BWD) in.dc = f3(ldf(r_dcol, vo, 0), ldf(r_dcol, vo, dcs), ldf(r_dcol, vo, 2 * dcs));
-        in.pix = (int)__builtin_amdgcn_raw_buffer_load_b32(r_pix, vo, 0, 0);
-    };
     auto rows = [](__amdgpu_buffer_rsrc_t r) {
         return [r](unsigned off) { return __builtin_bit_cast(HalfRowBits, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0)); };
     };
     auto fg_rows = [r_fg](unsigned off) { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r_fg, (int)off, 0, 0)); };
-    // Two input register sets, two pixels per trip: the inputs of pixel i + 2*stride are loaded INTO the set whose pixel
-    // has just issued its gathers (everything the second stage needs lives in ShadeCtx / ShadeTaps by then), so no set is
-    // ever copied -- a copy of a freshly requested register is a wait for the whole stream in front of it.
-    // The loop body is branch-free up to the stores: indices past the end are clamped (a redundant load of the last pixel)
-    // instead of skipped, because a conditional load makes the compiler's vmcnt bookkeeping assume the load-free path and
-    // wait for "all but the newest 7" at the first texel use -- which on the taken path includes the prefetch just issued.
-    ShadeIn A, B;
-    const unsigned n32 = (unsigned)N, s32 = (unsigned)stride, last = n32 - 1;
-    unsigned j = (unsigned)i;
-    load_soa(j, A);
-    load_soa(min(j + s32, last), B);
-    auto step = [&](ShadeIn& cur, unsigned idx) {
+    // THE KERNEL IS BOUND BY THE NUMBER OF VECTOR-MEMORY INSTRUCTIONS (round 4, tools/gather_probe.cpp): the texture-address
+    // unit takes 4 lane addresses per clock whatever the access width -- a streaming wave64 load costs 15.6 (4 B per lane),
+    // 19.2 (8 B), 20.7 (16 B) cycles of its CU; a scattered 16 B gather 2.1 cycles per distinct line, 16-21 when the lanes
+    // share lines.  Rounds 1-3 issued 13 (backward: 16) dword loads + 8 gathers + 3 (5) dword stores per 64 rows = 24 (29)
+    // instructions ~ 480 cycles, measured 486.  Now the SoA input rows are fetched SIXTEEN BYTES PER LANE: lane l of load j
+    // reads rows 4 (l & 15) .. + 3 of channel 4 j + (l >> 4), i.e. 3 (4) loads per 64 rows, and a wave-private LDS buffer
+    // turns the [channel][row] image into one row per lane (4 ds_write_b128 lane-linear, 12-16 ds_read_b32: the LDS pipe is
+    // idle in this kernel); the results leave the same way, one (two) 16-byte stores.  12 (14) vector-memory instructions.
+    //
+    // WORK DISTRIBUTION (round 4).  Unit = one 64-row batch (one wave, one step).  Rounds 1-3 ran a grid-stride loop over
+    // 256 x wg_per_cu workgroups, two pixels per trip: at the bench size (1.2 M rows, 4.4 rows per thread) every thread ran
+    // THREE two-pixel trips -- 6 steps of gathers and arithmetic for 4.4 rows of work.  Now:
+    //   * the host sizes the grid so that every wave has the SAME whole number of steps (shade_grid below): the fewest waves
+    //     that finish in ceil(batches / resident waves) steps;
+    //   * a wave that has no batch left leaves (wave-uniform), it does not shade clamped rows;
+    //   * XCD x (workgroup b runs on XCD b % 8) owns the x-th eighth of the batches, its waves take them round-robin: the
+    //     rows are view-major (either G-buffer order), so an XCD's L2 holds the atlas of one or two environments instead of
+    //     all of them (rounds 1-3: every XCD saw every 8th 256-row chunk of every view, 13 MB of atlas through a 4 MB L2:
+    //     TCC hit rate 75 %, 1.76x the algorithmic bytes fetched).
+    // Two raw register sets: the inputs of step k + 2 are loaded INTO the set whose rows have just issued their gathers
+    // (everything the second stage needs lives in ShadeCtx / ShadeTaps by then), so no set is ever copied -- a copy of a
+    // freshly requested register is a wait for the whole stream in front of it.  The loop body is branch-free up to the
+    // stores: a step whose wave has no batch k + 2 re-reads its own batch (L1 hits) instead of skipping the prefetch, because
+    // a conditional load makes the compiler's vmcnt bookkeeping assume the load-free path and wait for "all but the newest
+    // 7" at the first texel use -- which on the taken path includes the prefetch just issued.
+    const unsigned n32 = (unsigned)N;
+    const unsigned NB = (n32 + 63u) >> 6;
+    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned nwx = ((gridDim.x - xcd + 7u) >> 3) * (blockDim.x >> 6);                  // waves on this XCD
+    const unsigned b_lo = (unsigned)(((unsigned long long)NB * xcd) >> 3), b_hi = (unsigned)(((unsigned long long)NB * (xcd + 1)) >> 3);
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned wx = (blockIdx.x >> 3) * (blockDim.x >> 6) + wave;
+    const int cnt = (b_lo + wx < b_hi) ? (int)((b_hi - b_lo - wx + nwx - 1) / nwx) : 0;      // batches of this wave (wave-uniform)
+    if (cnt <= 0) return;
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned rb0 = (b_lo + wx) << 6, rstep = nwx << 6;                                 // first row of step k: rb0 + k rstep
+    const unsigned qlast = (n32 - 1u) & ~3u;                                                 // last row quad that holds a valid row
+    typedef unsigned U4 __attribute__((ext_vector_type(4), may_alias, aligned(16)));
+    typedef unsigned U1 __attribute__((may_alias));
+    struct Raw { U4 r[NJ]; };
+    U1* const xw = reinterpret_cast<U1*>(&s_x[wave][0]);
+    auto load_raw = [&](unsigned rb, Raw& R) {          // rb = first row of a batch (wave-uniform)
+        const unsigned qr = min(rb + 4u * (lane & 15u), qlast);                              // rows past the end: a valid quad instead
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            // (an integer turned pointer is a GENERIC pointer: flat_load, both counters; say "global" explicitly)
+            const unsigned long long p = s_chan[4 * j + (lane >> 4)] + (unsigned long long)qr * 4u;
+            R.r[j] = *reinterpret_cast<const __attribute__((address_space(1))) U4*>(p);
+        }
+    };
+    // rows past the end (the one ragged batch of a launch) take the LAST VALID row's inputs: every gather address stays inside
+    // the atlas; their results are not stored
+    auto unpack = [&](const Raw& R, unsigned rb, ShadeIn& in) {      // [channel][row] in registers of 16 B -> one row per lane, through LDS
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) *reinterpret_cast<U4*>(xw + (j * 64 + lane) * 4) = R.r[j];
+        const unsigned col = min(lane, n32 - 1u - rb);
+        auto rd = [&](int c) { return __builtin_bit_cast(float, (unsigned)xw[c * 64 + col]); };
+        in.n = f3(rd(0), rd(1), rd(2));
+        in.v = f3(rd(3), rd(4), rd(5));
+#pragma unroll
+        for (int c = 0; c < 5; ++c) in.f[c] = rd(6 + c);
+        in.pix = (int)xw[11 * 64 + col];
+        if (BWD) in.dc = f3(rd(12), rd(13), rd(14));
+    };
+    Raw A, B;
+    load_raw(rb0, A);
+    load_raw(cnt > 1 ? rb0 + rstep : rb0, B);
+    auto step = [&](Raw& raw, int k, auto prefetch) {
+        const unsigned rb = rb0 + (unsigned)k * rstep, idx = rb + lane;
+        ShadeIn cur;
+        unpack(raw, rb, cur);
         const int env = env_of(cur.pix);
         ShadeCtx c;
         ShadeTaps t;
         shade_issue_t<FMT>(a.atlas, a.mat, env, cur.n, cur.v, cur.f, c, t, [](int l) { return s_mip_off[l]; },
                            [](int l) { return s_mip_res[l]; }, rows(r_spec), rows(r_diff), fg_rows);
-        const F3 dc = cur.dc;
-        __builtin_amdgcn_sched_barrier(0);
-        load_soa(min(idx + 2 * s32, last), cur);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (decltype(prefetch)::value) {
+            __builtin_amdgcn_sched_barrier(0);
+            load_raw(k + 2 < cnt ? rb + 2u * rstep : rb, raw);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         shade_finish_t<FMT>(a.atlas, a.mat, t, c);
-        if (idx < n32) {
-            const int vo = DM_MUL24((int)idx, out_rs) * 4;
-            body(idx, dc, c, [&](int k, float v) { __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r_out, vo, k * out_cs4, 0); });
+        float ov[NOUT];
+        body(idx < n32 ? (long long)idx : -1, cur.dc, c, [&](int ch, float v) { ov[ch] = v; });
+        if (rb + 64u <= n32) {                          // whole batch inside: [row][channel] -> [channel][row quads], 16 B stores
+#pragma unroll
+            for (int ch = 0; ch < NOUT; ++ch) xw[ch * 64 + lane] = __builtin_bit_cast(unsigned, ov[ch]);
+#pragma unroll
+            for (int o = 0; o * 64 < NOUT * 16; ++o) {
+                const unsigned L = o * 64 + lane;
+                if (L < NOUT * 16) {
+                    const U4 v = *reinterpret_cast<const U4*>(xw + L * 4);
+                    const unsigned long long p = s_outp[L >> 4] + (unsigned long long)(rb + 4u * (L & 15u)) * 4u;
+                    *reinterpret_cast<__attribute__((address_space(1))) U4*>(p) = v;
+                }
+            }
+        } else if (idx < n32) {                         // the one ragged batch of a launch
+#pragma unroll
+            for (int ch = 0; ch < NOUT; ++ch) out.p[(long long)idx + ch * out.cs] = ov[ch];
         }
     };
-    for (; j < n32; j += 2 * s32) {
-        step(A, j);
-        step(B, j + s32);
+    int k = 0;
+    for (; k + 1 < cnt; k += 2) {
+        step(A, k, std::true_type{});
+        step(B, k + 1, std::true_type{});
     }
+    if (k < cnt) step(A, k, std::false_type{});
 #endif
 }
 
 template <int FMT, bool DBG>
-__global__ __launch_bounds__(256, 3) void k_shade_fwd(ShadeArgs a) {
+__global__ __launch_bounds__(256, 4) void k_shade_fwd(ShadeArgs a) {
     shade_pixel_loop<FMT, false>(a, a.color, [&](long long i, F3, const ShadeCtx& c, auto&& st) {
         st(0, sat(c.pre.x));
         st(1, sat(c.pre.y));
         st(2, sat(c.pre.z));
-        if (DBG) {
+        if (DBG && i >= 0) {
             F3 sl = lin2srgb(c.spec), dl = lin2srgb(c.diff), sc = lin2srgb(c.spec_albedo), dc = lin2srgb(c.albedo);
             a.albedo[3 * i] = c.albedo.x; a.albedo[3 * i + 1] = c.albedo.y; a.albedo[3 * i + 2] = c.albedo.z;
             a.spec_light[3 * i] = sl.x; a.spec_light[3 * i + 1] = sl.y; a.spec_light[3 * i + 2] = sl.z;
@@ -213,23 +280,26 @@ __global__ __launch_bounds__(256, 3) void k_shade_bwd(ShadeArgs a) {
     });
 }
 
+// the fast path of shade_pixel_loop: every row tensor SoA (unit row stride; any channel pitch), fewer than 2^30 rows
 static inline int shade_offsets32(const ShadeArgs& a, long long n_max, bool bwd) {
-    auto fits = [&](long long rs, long long cs, int ch) {      // SoA rows (unit row stride), every byte offset below 2^31
-        return rs == 1 && cs >= 0 && (n_max - 1) + (ch - 1) * cs < 0x7fffffffLL / 4;
-    };
-    auto out_fits = [&](long long rs, long long cs, int ch) {   // outputs: any small row stride (24-bit multiply), 31-bit byte offsets
-        return rs >= 1 && rs < (1 << 20) && cs >= 0 && n_max < (1 << 23) && (n_max - 1) * rs + (ch - 1) * cs < 0x7fffffffLL / 4;
-    };
-    return fits(a.nrm.rs, a.nrm.cs, 3) && fits(a.view.rs, a.view.cs, 3) && fits(a.feat.rs, a.feat.cs, 5) &&
-           (bwd ? fits(a.dcolor.rs, a.dcolor.cs, 3) && out_fits(a.dfeat.rs, a.dfeat.cs, 5) : out_fits(a.color.rs, a.color.cs, 3)) &&
+    auto soa = [&](long long rs, long long cs) { return rs == 1 && cs >= 0; };
+    return soa(a.nrm.rs, a.nrm.cs) && soa(a.view.rs, a.view.cs) && soa(a.feat.rs, a.feat.cs) &&
+           (bwd ? soa(a.dcolor.rs, a.dcolor.cs) && soa(a.dfeat.rs, a.dfeat.cs) : soa(a.color.rs, a.color.cs)) &&
            n_max < 0x3fffffffLL;
 }
 
-// persistent launch: enough workgroups to fill every CU at the kernels' occupancy, never more than needed
-static inline int shade_blocks(long long n_max, int wg_per_cu) {
+// Persistent launch, sized so that every wave runs the same whole number of steps (see WORK DISTRIBUTION in
+// shade_pixel_loop): S = ceil(batches / resident waves), then the FEWEST waves that still finish in S steps -- per XCD, because
+// each XCD owns an eighth of the batches.  Always a multiple of 8 workgroups (one per XCD) unless the launch is tiny.
+static inline int shade_grid(long long n_max, int wg_per_cu) {
     if (const char* e = getenv("DREAMMAT_SHADE_WGPCU")) wg_per_cu = atoi(e);     // development knob
-    long long need = (n_max + 255) / 256;
-    return (int)std::min<long long>(need, 256 * wg_per_cu);
+    const long long nb = (n_max + 63) / 64;                  // 64-row batches
+    const long long nbx = (nb + 7) / 8;                      // per XCD (ceil)
+    const long long waves_x = 32LL * wg_per_cu * 4;          // resident waves of one XCD: 32 CUs x workgroups x 4 waves
+    const long long steps = std::max<long long>(1, (nbx + waves_x - 1) / waves_x);
+    const long long need_waves_x = (nbx + steps - 1) / steps;
+    const long long wgs_x = std::max<long long>(1, (need_waves_x + 3) / 4);
+    return (int)(8 * wgs_x);
 }
 
 // Material smoothness regulariser (dreammat_material.py:110-123) fused: forward partial sums and
@@ -330,7 +400,8 @@ int dm_shade_fwd(const dm_env_atlas* atlas, const dm_mat_cfg* mat, const float* 
     a.spec_color = dbg_spec_color; a.diff_color = dbg_diff_color; a.metallic = dbg_metallic;
     a.roughness = dbg_roughness;
     DM_ENTER();
-    const dim3 grid(shade_blocks(n_max, 4));               // forward: <= 128 VGPRs, 4 workgroups per CU
+    const dim3 grid(shade_grid(n_max, 2));                 // 2 workgroups per CU measured best (tools/r4_shade_probe.py: 1 / 2 / 3 / 4 ->
+                                                           // 25.1 / 20.2 / 20.4 / 21.3 us on smooth, 25.7 / 25.3 / 25.6 / 26.9 on noisy features)
     a.offsets32 = shade_offsets32(a, n_max, false);
     const bool dbg = ndbg != 0;
     switch (a.atlas.texel_format) {
@@ -367,7 +438,7 @@ int dm_shade_bwd(const dm_env_atlas* atlas, const dm_mat_cfg* mat, const float* 
     a.dfeat = {dfeat, dfeat_rs, dfeat_cs};
     DM_ENTER();
     a.offsets32 = shade_offsets32(a, n_max, true);
-    const dim3 grid(shade_blocks(n_max, 3));               // backward: <= 168 VGPRs, 3 workgroups per CU
+    const dim3 grid(shade_grid(n_max, 2));                 // (backward: 32.8 / 25.2 / 24.5 / 26.0 and 32.1 / 27.7 / 29.2 / 30.7 us)
     switch (a.atlas.texel_format) {
         case kTexelRgb18e8: hipLaunchKernelGGL(k_shade_bwd<kTexelRgb18e8>, grid, dim3(256), 0, stream, a); break;
         case kTexelF16: hipLaunchKernelGGL(k_shade_bwd<kTexelF16>, grid, dim3(256), 0, stream, a); break;

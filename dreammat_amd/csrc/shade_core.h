@@ -116,14 +116,15 @@ DM_HD F3 cube_fetch_half(const void* __restrict__ tex, long long texel_base, int
               half_lo(r0.y) * w00 + half_lo(r0.w) * w10 + half_lo(r1.y) * w01 + half_lo(r1.w) * w11);
 }
 
-// RGB18E8 atlas: 8-byte texel = three 18-bit mantissas sharing one 8-bit exponent (bits R[0,18) G[18,36) B[36,54) E[54,62);
+// RGB18E8 atlas: 8-byte texel = three 18-bit mantissas sharing one 8-bit exponent (bits R[0,18) G[18,36) B[36,54) E[55,63):
+// the exponent occupies the fp32 exponent field of the high word, so the scale 2^(E-127) is `hi & 0x7f800000`;
 // value = mantissa * 2^(E-127)).  Radiance is non-negative, so no sign bits are needed; the largest channel of a texel keeps
 // 18 significant bits (relative error <= 2^-18, the others the same ABSOLUTE error), i.e. fp32-class accuracy at half the
 // bytes and -- the point -- half the gather instructions of RGBA fp32: the shade kernels are bound by the number of
 // scattered cache lines the texture-address unit has to visit per wave, not by bytes or by VALU work.
 DM_HD F3 rgb18e8_decode(unsigned lo, unsigned hi) {
     const unsigned r = lo & 0x3ffffu, g = ((lo >> 18) | (hi << 14)) & 0x3ffffu, b = (hi >> 4) & 0x3ffffu;
-    const unsigned ebits = (hi >> 22) << 23;             // 2^(E-127) as fp32 bits (E in [1,254], top two bits of hi are 0)
+    const unsigned ebits = hi & 0x7f800000u;             // 2^(E-127) as fp32 bits (E in [1,254])
     float sc;
     __builtin_memcpy(&sc, &ebits, 4);
     return f3((float)r * sc, (float)g * sc, (float)b * sc);
@@ -174,7 +175,7 @@ struct PlainFgRows {
 // instructions per pixel, 12 texels per pixel)
 DM_HD void rgb18e8_accum(unsigned lo, unsigned hi, float w, F3& acc) {
     const unsigned r = lo & 0x3ffffu, g = ((lo >> 18) | (hi << 14)) & 0x3ffffu, b = (hi >> 4) & 0x3ffffu;
-    const unsigned ebits = (hi >> 22) << 23;
+    const unsigned ebits = hi & 0x7f800000u;
     float sc;
     __builtin_memcpy(&sc, &ebits, 4);
     const float ws = w * sc;
@@ -244,7 +245,7 @@ DM_HD float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 struct ShadeTaps {
     HalfRowBits s0a, s0b, s1a, s1b, da, db;     // rows y0 / y0+1 of: specular mip l0, specular mip l1, diffuse cube
     float4 fga, fgb;                             // FG x-pair rows iy0 / iy1
-    float sfx0, sfy0, sfx1, sfy1, dfx, dfy, gfx, gfy, mipf;
+    float sfx0, sfy0, sfx1, sfy1, dfx, dfy, gfx, gfy, mipf, mip_sign;
 };
 
 // `mip_off` / `mip_res`: the atlas' per-mip tables; the kernels pass LDS copies, because indexing the kernel-argument copy
@@ -255,7 +256,9 @@ DM_HD void shade_issue_t(const EnvAtlas& A, const MatCfg& M, int env, F3 n, F3 v
                          ShadeTaps& t, MipOff mip_off, MipRes mip_res, SpecRows spec_rows, DiffRows diff_rows, FgRows fg_rows) {
 #pragma unroll
     for (int k = 0; k < 5; ++k) c.s[k] = sigmoidf(feat[k]);
-    c.albedo = f3(sat(c.s[0]), sat(c.s[1]), sat(c.s[2]));
+    // (the reference's .clamp(0, 1) of the sigmoid, dreammat_material.py:749, is the identity: 1 + exp(-x) >= 1 in fp32 and
+    // its reciprocal lies in [0, 1]; -ffast-math cannot prove that, so it is not written)
+    c.albedo = f3(c.s[0], c.s[1], c.s[2]);
     c.metallic = c.s[3] * (M.max_metallic - M.min_metallic) + M.min_metallic;
     c.roughness = c.s[4] * (M.max_roughness - M.min_roughness) + M.min_roughness;
     float ndv = dot3(n, v);
@@ -282,7 +285,16 @@ DM_HD void shade_issue_t(const EnvAtlas& A, const MatCfg& M, int env, F3 n, F3 v
         level = fminf(fmaxf(level, 0.f), (float)(A.n_mips - 1));
         int l0 = min((int)floorf(level), A.n_mips - 1);
         int l1 = min(l0 + 1, A.n_mips - 1);
-        t.mipf = level - (float)l0;
+        const float f = level - (float)l0;
+        // The two mips go to the two fetch slots BY PARITY (slot 0 = the even level of the pair, slot 1 = the odd one), not by
+        // rank: neighbouring pixels whose roughness straddles a level boundary -- pairs (1, 2) and (2, 3) -- then read the SAME
+        // mip in slot 0, i.e. the same cache lines in that gather instruction (a wave whose lanes mix k levels visits ~k/2
+        // mips per instruction instead of k).  t.mipf = the weight of slot 1; t.mip_sign = +-1 so that
+        // d spec / d level = s(l1) - s(l0) = mip_sign (slot1 - slot0).
+        const bool odd = (l0 & 1) != 0;
+        t.mipf = odd ? 1.f - f : f;
+        t.mip_sign = odd ? -1.f : 1.f;
+        if (odd) { const int tmp = l0; l0 = l1; l1 = tmp; }
         const int envt = DM_MUL24(env, (int)A.spec_env_stride);
         CubeCoord rc = cube_coord(refl);
         CubeTap a0 = cube_tap_addr(envt + (int)mip_off(l0), mip_res(l0), rc);
@@ -317,7 +329,7 @@ DM_HD void shade_finish_t(const EnvAtlas& A, const MatCfg& M, const ShadeTaps& t
     F3 s0 = cube_tap_blend(fmt, t.s0a, t.s0b, t.sfx0, t.sfy0);
     F3 s1 = cube_tap_blend(fmt, t.s1a, t.s1b, t.sfx1, t.sfy1);
     c.spec = s0 * (1.f - t.mipf) + s1 * t.mipf;
-    c.dspec_dlevel = s1 - s0;
+    c.dspec_dlevel = (s1 - s0) * t.mip_sign;
     c.pre = c.albedo * c.diff + c.spec_albedo * c.spec;
 }
 
@@ -334,7 +346,7 @@ DM_HD void shade_eval_t(const EnvAtlas& A, const MatCfg& M, int env, F3 n, F3 v,
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) c.s[k] = sigmoidf(feat[k]);
-    c.albedo = f3(sat(c.s[0]), sat(c.s[1]), sat(c.s[2]));
+    c.albedo = f3(c.s[0], c.s[1], c.s[2]);          // (clamp(0, 1) of a sigmoid: the identity, see shade_issue_t)
     c.metallic = c.s[3] * (M.max_metallic - M.min_metallic) + M.min_metallic;
     c.roughness = c.s[4] * (M.max_roughness - M.min_roughness) + M.min_roughness;
     float ndv = dot3(n, v);

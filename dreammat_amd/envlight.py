@@ -186,8 +186,9 @@ TEXEL_FORMATS = {"fp32": 0, "fp16": 1, "rgb18e8": 2}
 
 def encode_rgb18e8(rgb):
     """[..., 3] non-negative fp32 -> [..., 2] int32 words of the 8-byte shared-exponent texel the shade kernels decode
-    (csrc/shade_core.h rgb18e8_decode): bits R[0,18) G[18,36) B[36,54) E[54,62), value = mantissa * 2^(E-127); the exponent is
-    chosen so that the largest channel uses all 18 bits."""
+    (csrc/shade_core.h rgb18e8_decode): bits R[0,18) G[18,36) B[36,54) E[55,63) -- the exponent sits where an fp32 keeps its own, so the
+    kernel turns it into the scale 2^(E-127) with ONE and-mask --, value = mantissa * 2^(E-127); the exponent is chosen so that
+    the largest channel uses all 18 bits."""
     rgb = rgb.double().clamp(min=0.0)
     mx = rgb.amax(-1)
     _, ex = torch.frexp(mx)                                  # mx = m * 2^ex, m in [0.5, 1)
@@ -198,7 +199,7 @@ def encode_rgb18e8(rgb):
     man = torch.round(torch.ldexp(rgb, (18 - ex)[..., None].expand_as(rgb).to(torch.int32))).clamp(0, 2 ** 18 - 1).to(torch.int64)
     e = ex - 18 + 127
     assert int(e.min()) >= 1 and int(e.max()) <= 254
-    word = man[..., 0] | (man[..., 1] << 18) | (man[..., 2] << 36) | (e << 54)
+    word = man[..., 0] | (man[..., 1] << 18) | (man[..., 2] << 36) | (e << 55)
     lo = word & 0xFFFFFFFF
     hi = (word >> 32) & 0xFFFFFFFF
     lo = torch.where(lo >= 2 ** 31, lo - 2 ** 32, lo)
@@ -212,7 +213,7 @@ def decode_rgb18e8(words):
     hi = words[..., 1].to(torch.int64) & 0xFFFFFFFF
     word = lo | (hi << 32)
     man = torch.stack([word & 0x3FFFF, (word >> 18) & 0x3FFFF, (word >> 36) & 0x3FFFF], -1).double()
-    e = ((word >> 54) & 0xFF).to(torch.int32)
+    e = ((word >> 55) & 0xFF).to(torch.int32)
     return torch.ldexp(man, (e - 127)[..., None].expand_as(man)).float()
 
 

@@ -186,11 +186,24 @@ class GBuffer:
         self.n_dev, self.n = n_dev, n
 
 
-def gbuffer_compact(rast, tri, v_pos, v_nrm, rays_d, jitter_u=None, jitter_n=None, jitter_eps=0.05):
+def gbuffer_order():
+    """Enumeration order of the compacted G-buffer rows: "tile" (default; 8 x 8 pixel blocks per wave, csrc/raster.hip) or
+    "row" (the reference's row-major `x[selector]` order) -- DREAMMAT_GBUF_ORDER, a measurement knob: every consumer goes
+    through pix_idx, so results do not depend on it."""
+    o = os.environ.get("DREAMMAT_GBUF_ORDER", "tile")
+    if o not in ("tile", "row"):
+        raise ValueError(f"DREAMMAT_GBUF_ORDER={o!r}: expected 'tile' or 'row'")
+    return o
+
+
+def gbuffer_compact(rast, tri, v_pos, v_nrm, rays_d, jitter_u=None, jitter_n=None, jitter_eps=0.05, order=None):
     _need_cuda(rast, tri, v_pos, v_nrm, rays_d)
     dev = rast.device
     npix = rast.numel() // 4
-    cap = npix
+    order = order or gbuffer_order()
+    if order == "tile" and rast.dim() != 4:
+        raise ValueError("tile-ordered G-buffer needs rast as [B,H,W,4]")
+    cap = (npix + 3) // 4 * 4              # SoA rows 16-byte aligned (the shade kernels stream them 16 B per lane)
     rays_d = _f32c(rays_d)
     pix_idx = torch.empty(cap, dtype=torch.int32, device=dev)
     pos = torch.empty(3, cap, device=dev)
@@ -198,18 +211,24 @@ def gbuffer_compact(rast, tri, v_pos, v_nrm, rays_d, jitter_u=None, jitter_n=Non
     view = torch.empty(3, cap, device=dev)
     pos_j = torch.empty(3, cap, device=dev) if jitter_u is not None else None
     n_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-    wsb = int(_lib.lib().dm_gbuffer_workspace_bytes(npix))
+    L = _lib.lib()
+    if order == "tile":
+        B, H, W = rast.shape[:3]
+        wsb = int(L.dm_gbuffer_tiled_workspace_bytes(B, H, W))
+    else:
+        wsb = int(L.dm_gbuffer_workspace_bytes(npix))
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     ju_t = _f32c(jitter_u) if jitter_u is not None else None   # keep the (possibly temporary) tensors alive
     jn_t = _f32c(jitter_n) if jitter_n is not None else None
     ju = ju_t.data_ptr() if ju_t is not None else None
     jn = jn_t.data_ptr() if jn_t is not None else None
-    check(_lib.lib().dm_gbuffer_compact(rast.data_ptr(), npix, tri.data_ptr(), _f32c(v_pos).data_ptr(),
-                                        _f32c(v_nrm).data_ptr(), rays_d.data_ptr(), ju, jn, float(jitter_eps), cap,
-                                        pix_idx.data_ptr(), pos.data_ptr(),
-                                        pos_j.data_ptr() if pos_j is not None else None, nrm.data_ptr(),
-                                        view.data_ptr(), n_dev.data_ptr(), ws.data_ptr(), wsb, _stream()),
-          "dm_gbuffer_compact")
+    tail = (tri.data_ptr(), _f32c(v_pos).data_ptr(), _f32c(v_nrm).data_ptr(), rays_d.data_ptr(), ju, jn, float(jitter_eps), cap,
+            pix_idx.data_ptr(), pos.data_ptr(), pos_j.data_ptr() if pos_j is not None else None, nrm.data_ptr(),
+            view.data_ptr(), n_dev.data_ptr(), ws.data_ptr(), wsb, _stream())
+    if order == "tile":
+        check(L.dm_gbuffer_compact_tiled(rast.data_ptr(), B, H, W, *tail), "dm_gbuffer_compact_tiled")
+    else:
+        check(L.dm_gbuffer_compact(rast.data_ptr(), npix, *tail), "dm_gbuffer_compact")
     n = int(n_dev.item())   # the one host sync of the render path (sizes the torch-side tensors)
     return GBuffer(pix_idx[:n], pos[:, :n], pos_j[:, :n] if pos_j is not None else None, nrm[:, :n], view[:, :n],
                    n_dev, n)
@@ -433,7 +452,8 @@ class _Shade(torch.autograd.Function):
         _need_cuda(feat, nrm, view, pix_idx, env_of_view)
         N = feat.shape[0]
         dev = feat.device
-        color = torch.empty(3, N, device=dev)
+        Np = (N + 3) // 4 * 4                   # channel pitch: the kernel stores 16 bytes (4 rows) per lane
+        color = torch.empty(3, Np, device=dev)[:, :N]
         dbg = [None] * 7
         if want_debug:
             dbg = [torch.empty(N, 3, device=dev) for _ in range(5)] + [torch.empty(N, 1, device=dev) for _ in range(2)]
@@ -442,7 +462,7 @@ class _Shade(torch.autograd.Function):
                 check(_lib.lib().dm_shade_fwd(ctypes.byref(atlas.struct), ctypes.byref(mat), nrm.data_ptr(),
                                               *_rs_cs(nrm), view.data_ptr(), *_rs_cs(view), feat.data_ptr(),
                                               *_rs_cs(feat), pix_idx.data_ptr(), env_of_view.data_ptr(),
-                                              n_dev.data_ptr(), N, HW, env_of_view.numel(), color.data_ptr(), 1, N,
+                                              n_dev.data_ptr(), N, HW, env_of_view.numel(), color.data_ptr(), 1, Np,
                                               *[d.data_ptr() if d is not None else None for d in dbg], _stream()),
                       "dm_shade_fwd")
         ctx.save_for_backward(feat, nrm, view, pix_idx, n_dev, env_of_view)
@@ -455,7 +475,8 @@ class _Shade(torch.autograd.Function):
     def backward(ctx, g, *unused):
         feat, nrm, view, pix_idx, n_dev, env_of_view = ctx.saved_tensors
         N = feat.shape[0]
-        dfeat = torch.zeros(5, N, device=feat.device)
+        Np = (N + 3) // 4 * 4
+        dfeat = torch.zeros(5, Np, device=feat.device)[:, :N]
         if N > 0:
             with _Timed("shade_bwd", 76.0 * N):
                 check(_lib.lib().dm_shade_bwd(ctypes.byref(ctx.atlas.struct), ctypes.byref(ctx.mat), nrm.data_ptr(),
@@ -463,7 +484,7 @@ class _Shade(torch.autograd.Function):
                                               *_rs_cs(feat), pix_idx.data_ptr(), env_of_view.data_ptr(),
                                               n_dev.data_ptr(), N, ctx.HW, env_of_view.numel(), g.data_ptr(), *_rs_cs(g),
                                               dfeat.data_ptr(),
-                                              1, N, _stream()), "dm_shade_bwd")
+                                              1, Np, _stream()), "dm_shade_bwd")
         return (dfeat.t(),) + (None,) * 9
 
 

@@ -82,12 +82,15 @@ class RaytraceRender(BaseModule):
 
         if getattr(self.geometry.cfg, "n_input_dims", 3) == 2:
             # uv-space field (raytracing_renderer.py:177-181): the field is queried at the pixel's interpolated texture
-            # coordinate and at that coordinate + N(0, 0.005) per component (`jitter_uv` [N,2] ~ N(0,1): injectable draw)
+            # coordinate and at that coordinate + N(0, 0.005) per component (`jitter_uv` ~ N(0,1): injectable draw, [B*H*W,2] per
+            # pixel or [N,2] per compacted row)
             if mesh.v_tex is None:
                 raise ValueError("n_input_dims=2 needs a mesh with texture coordinates")
             texc = hipops.gather_rows(hipops.interpolate(mesh.v_tex.contiguous(), rast, tri).view(B * H * W, 2), gb.pix_idx, gb.n_dev, N)
             if jitter_uv is None:
                 jitter_uv = torch.randn(N, 2, device=dev)
+            elif jitter_uv.shape[0] == B * H * W:       # injected per PIXEL: independent of the G-buffer's row order
+                jitter_uv = jitter_uv[gb.pix_idx.long()]
             pts2 = torch.cat([texc, texc + 0.005 * jitter_uv[:N]], dim=0).t()      # [2, 2N]
         else:
             # both field queries in ONE launch: rows [0,N) = surface points, [N,2N) = jittered points

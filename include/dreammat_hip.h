@@ -86,6 +86,16 @@ int dm_gbuffer_compact(const float* rast, long long n_pix, const int32_t* tri, c
                        const float* v_nrm, const float* rays_d, const float* jitter_u, const float* jitter_n,
                        float jitter_eps, long long cap, int32_t* pix_idx, float* pos, float* pos_jitter, float* nrm,
                        float* view, int32_t* n_out, void* ws, size_t ws_bytes, dm_stream_t stream);
+/* The same rows enumerated in TILE order (ABI v9; the product's default): one workgroup per 16 x 16 macro tile (row-major
+ * inside a view, views in order), one wave per 8 x 8 sub-tile, lanes in Morton order inside it -- so the 64 rows any later
+ * kernel's wave works on are an 8 x 8 pixel block (neighbouring normals / reflection vectors / positions: cube-map lines and
+ * hash-grid cells shared across the wave) instead of a 64-pixel scanline run.  rast is [B,H,W,4]; pix_idx[i] is still the
+ * row-major global pixel index b*H*W + y*W + x of compacted row i, so scatter / gather / antialias do not change. */
+size_t dm_gbuffer_tiled_workspace_bytes(int B, int H, int W);
+int dm_gbuffer_compact_tiled(const float* rast, int B, int H, int W, const int32_t* tri, const float* v_pos,
+                             const float* v_nrm, const float* rays_d, const float* jitter_u, const float* jitter_n,
+                             float jitter_eps, long long cap, int32_t* pix_idx, float* pos, float* pos_jitter,
+                             float* nrm, float* view, int32_t* n_out, void* ws, size_t ws_bytes, dm_stream_t stream);
 
 /* ControlNet depth [B,H,W,1] / view-normal [B,H,W,3] maps before antialias
  * (raytracing_renderer.py:129-147, compute_controlnet_normals :326-331).  minmax_ws: >= 8*B bytes. */
@@ -153,7 +163,7 @@ typedef struct dm_env_atlas {
     int n_mips, diff_res, lut_res;
     float min_rough_mip, max_rough_mip; /* envlight's 0.08 / 0.5 */
     int texel_format;          /* spec / diff texels: 0 = RGBA fp32 (16 B); 1 = RGBA fp16 (8 B); 2 = RGB18E8 (8 B: three 18-bit
-                                * mantissas R[0,18) G[18,36) B[36,54) + shared exponent E[54,62), value = m * 2^(E-127)) */
+                                * mantissas R[0,18) G[18,36) B[36,54) + shared exponent E[55,63), value = m * 2^(E-127)) */
     const float* fg_pairs;     /* optional [lut_res][lut_res+1][4]: entry (row, x0+1) = {lut[row][max(x0,0)], lut[row][min(x0+1,
                                 * lut_res-1)]}, the clamped x-pair of a bilinear row as one 16 B load; NULL = plain LUT taps */
 } dm_env_atlas;

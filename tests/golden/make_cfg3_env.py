@@ -1,9 +1,9 @@
-"""Golden fixture for the BENCH configuration (BASELINE configs[2], "cfg3"): the ORACLE's envlight restatement run on the
-first of the five seeded synthetic lat-long probes bench.py uses (bench.synthetic_latlong(0): 256 x 512 log-normal sky + one
-sun lobe) at the bench's settings (environment_scale 2.0, cube resolutions 16..128).  It pins the product's
-GPU-side prefilter at the bench configuration; the render-parity test then hands the oracle the product's own (fp32,
-unpacked) cubes for the other four probes, so that only ONE O(res^4) CPU prefilter (~4 min) has to be stored.
-Run from the repo root:   python tests/golden/make_cfg3_env.py
+"""Golden fixtures for the BENCH configuration (BASELINE configs[2], "cfg3"): the ORACLE's envlight restatement run on the
+five seeded synthetic lat-long probes bench.py uses (bench.synthetic_latlong(i): 256 x 512 log-normal sky + one sun lobe,
+SURVEY 8d) at the bench's settings (environment_scale 2.0, cube resolutions 16..128).  They pin the product's GPU-side
+prefilter at the bench configuration for EVERY probe (round 3 stored probe 0 only and handed the oracle the product's own
+cubes for the other four).  One O(res^4) CPU prefilter takes ~4 min.
+Run from the repo root:   python tests/golden/make_cfg3_env.py [probe ids, default 0 1 2 3 4]
 """
 import os
 import sys
@@ -17,9 +17,11 @@ import bench  # noqa: E402
 
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))
-    env = oenv.EnvLight(bench.synthetic_latlong(0), scale=2.0, min_res=16, max_res=128)
-    out = {f"spec{i}": m.numpy().astype(np.float32) for i, m in enumerate(env.specular)}
-    out["diffuse"] = env.diffuse.numpy().astype(np.float32)
-    out["base"] = env.base.numpy().astype(np.float32)
-    np.savez_compressed(os.path.join(here, "cfg3_env0.npz"), **out)
-    print({k: v.shape for k, v in out.items()})
+    for e in [int(x) for x in sys.argv[1:]] or range(5):
+        env = oenv.EnvLight(bench.synthetic_latlong(e), scale=2.0, min_res=16, max_res=128)
+        out = {f"spec{i}": m.numpy().astype(np.float32) for i, m in enumerate(env.specular)}
+        out["diffuse"] = env.diffuse.numpy().astype(np.float32)
+        if e == 0:
+            out["base"] = env.base.numpy().astype(np.float32)      # (= spec0; kept so that the round-3 file is reproduced)
+        np.savez_compressed(os.path.join(here, f"cfg3_env{e}.npz"), **out)
+        print(e, {k: v.shape for k, v in out.items()})

@@ -17,6 +17,46 @@ from tests import util
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 
 
+
+def _rm(gb):
+    """Permutation that lists the compacted G-buffer rows in the reference's row-major `x[selector]` order (the product
+    compacts in tile order since round 4; every consumer goes through pix_idx)."""
+    return torch.argsort(gb.pix_idx.long()).cpu()
+
+
+class _RowView:
+    """rows of a [N, C] tensor (and of its .grad) re-ordered by a permutation, for the per-pixel diagnostics"""
+
+    def __init__(self, t, perm):
+        self.t, self.perm = t, perm
+
+    @property
+    def grad(self):
+        return self.t.grad[self.perm.to(self.t.grad.device)]
+
+    def __getitem__(self, i):
+        return self.t[self.perm.to(self.t.device)][i]
+
+
+def _tile_order(cov):
+    """pixel indices of the covered pixels of cov[B,H,W] in the product's documented tile order"""
+    B, H, W = cov.shape
+    out = []
+    lx = np.array([(l & 1) | ((l >> 1) & 2) | ((l >> 2) & 4) for l in range(64)])
+    ly = np.array([((l >> 1) & 1) | ((l >> 2) & 2) | ((l >> 3) & 4) for l in range(64)])
+    for b in range(B):
+        for ty in range((H + 15) // 16):
+            for tx in range((W + 15) // 16):
+                for w in range(4):
+                    x = tx * 16 + (w & 1) * 8 + lx
+                    y = ty * 16 + (w >> 1) * 8 + ly
+                    ok = (x < W) & (y < H)
+                    x, y = x[ok], y[ok]
+                    c = cov[b, y, x]
+                    out.append(((b * H + y) * W + x)[c])
+    return np.concatenate(out)
+
+
 def _dump(name, **arrs):
     os.makedirs(OUT, exist_ok=True)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **{k: np.asarray(v) for k, v in arrs.items()})
@@ -93,7 +133,16 @@ def test_gbuffer_and_control_maps(dev):
     ro = rast.cpu().numpy()
     sel = torch.from_numpy(ro[..., 3] > 0).reshape(-1)
     assert gb.n == int(sel.sum())
-    assert np.array_equal(gb.pix_idx.cpu().numpy(), np.nonzero(sel.numpy())[0])        # row-major order
+    # documented row order (csrc/raster.hip, include/dreammat_hip.h): 16 x 16 macro tiles row-major inside a view, 8 x 8
+    # sub-tiles row-major inside a macro tile, Morton order inside a sub-tile; pix_idx keeps the row-major pixel index
+    assert np.array_equal(gb.pix_idx.cpu().numpy(), _tile_order(sel.numpy().reshape(B, H, W)))
+    gb_row = hipops.gbuffer_compact(rast, tri, m.v_pos.to(dev), m.v_nrm.to(dev), batch["rays_d"].to(dev), ju.to(dev),
+                                    jn.to(dev), 0.05, order="row")
+    assert np.array_equal(gb_row.pix_idx.cpu().numpy(), np.nonzero(sel.numpy())[0])     # the reference's x[selector] order
+    rm = _rm(gb)
+    for nm_t in ("pos", "pos_jitter", "nrm", "view"):                                   # same rows, other order: bit-equal
+        assert torch.equal(getattr(gb, nm_t)[:, rm.to(dev)], getattr(gb_row, nm_t)), nm_t
+    gb = gb_row
     gn = torch.nn.functional.normalize(torch.from_numpy(oraster.interpolate(md["v_nrm"], ro, md["t_pos_idx"])), dim=-1)
     gp = torch.from_numpy(oraster.interpolate(md["v_pos"], ro, md["t_pos_idx"]))
     n_sel, p_sel = gn.reshape(-1, 3)[sel], gp.reshape(-1, 3)[sel]
@@ -195,8 +244,10 @@ def test_renderer_uv_space_field_vs_oracle(dev, envs):
     # the per-covered-pixel uv draws: first a run with zeros to learn the coverage count, then the real one
     out0 = rend(**gbatch, light_positions=None, jitter_u=ju.to(dev), jitter_n=jn.to(dev), jitter_uv=torch.zeros(B * H * W, 2, device=dev))
     N = out0["_internals"]["gbuffer"].n
-    juv = torch.randn(N, 2, generator=g)
-    out = rend(**gbatch, light_positions=None, jitter_u=ju.to(dev), jitter_n=jn.to(dev), jitter_uv=juv.to(dev), check_overflow=True)
+    juv = torch.randn(N, 2, generator=g)                      # the oracle's draw: one row per covered pixel, row-major
+    juv_dense = torch.zeros(B * H * W, 2)                      # the product takes it per PIXEL (independent of the G-buffer's row order)
+    juv_dense[torch.sort(out0["_internals"]["gbuffer"].pix_idx.long().cpu()).values] = juv
+    out = rend(**gbatch, light_positions=None, jitter_u=ju.to(dev), jitter_n=jn.to(dev), jitter_uv=juv_dense.to(dev), check_overflow=True)
     m = geom.mesh
     md = dict(v_pos=m.v_pos.cpu().numpy(), v_nrm=m.v_nrm.cpu().numpy(), t_pos_idx=m.t_pos_idx.cpu().numpy().astype(np.int32),
               v_tex=m.v_tex.cpu().numpy())
@@ -208,8 +259,9 @@ def test_renderer_uv_space_field_vs_oracle(dev, envs):
     ob = dict(batch); ob["jitter_uv"] = juv
     ref = orender.render(md, ob, dict(table=table, w1=w1, w2=w2, levels=lv, radius=1.0, n_input_dims=2), oenvs, fg, ju, jn)
     assert np.array_equal(out["_internals"]["rast"].cpu().numpy().view(np.uint32), ref["_rast"].numpy().view(np.uint32))
-    assert (out["_internals"]["features"].detach().cpu() - ref["_features"].detach()).abs().max() < 1e-4
-    assert (out["_internals"]["features_jitter"].detach().cpu() - ref["_features_jitter"].detach()).abs().max() < 1e-4
+    rm = _rm(out["_internals"]["gbuffer"])
+    assert (out["_internals"]["features"].detach().cpu()[rm] - ref["_features"].detach()).abs().max() < 1e-4
+    assert (out["_internals"]["features_jitter"].detach().cpu()[rm] - ref["_features_jitter"].detach()).abs().max() < 1e-4
     assert (out0["_internals"]["features"] - out0["_internals"]["features_jitter"]).abs().max() == 0       # zero draw: same query
     for k in ["comp_rgb", "albedo", "metalness", "roughness", "specular_color", "diffuse_color"]:
         assert (out[k].detach().cpu() - ref[k].detach()).abs().max().item() < 1e-4, k
@@ -1665,6 +1717,45 @@ def _mask_kink_ambiguous(dy, ref, eps=1e-4, eps_relu=3e-4):
     return dy * (~d).to(dy.dtype), float((d & covered[..., None]).float().sum() / (3 * covered.float().sum()))
 
 
+def _kink_companion(out, ref, dy_full, dy_masked, hip_table_param, ref_table, dev, others=()):
+    """Bounds what happens INSIDE the kink mask: the backward is linear in the upstream gradient, so the unmasked
+    table gradient is the masked one (already compared at 1e-3) plus the gradient of the FLAGGED part dy_full - dy_masked,
+    obtained here by a second backward on both sides (graphs retained by the caller).  Asserts, with the mask OFF:
+      * every table row whose error exceeds 1e-3 of the largest gradient is reachable from a flagged pixel (it receives a
+        non-zero contribution from the flagged part on at least one side);
+      * such a row's error is no larger than the flagged contributions it receives (a kink moves at most the flagged pixels'
+        own contributions from one side to the other) plus the 1e-3 budget;
+      * there are no more such rows than flagged pixels x 2 queries x 16 levels x 8 corners.
+    Returns the numbers that go into the parity JSON."""
+    g_m = ref_table.grad.detach().clone()
+    h_m = hip_table_param.grad.detach().cpu().reshape(-1, 2).clone()
+    keep = [(p, p.grad.detach().clone()) for p in others]           # the other parameters' masked gradients (restored below)
+    dy_flag = dy_full - dy_masked
+    flagged_px = int((dy_flag != 0).any(-1).sum())
+    ref_table.grad = None
+    hip_table_param.grad = None
+    (ref["comp_rgb"] * dy_flag).sum().backward()
+    (out["comp_rgb"] * dy_flag.to(dev)).sum().backward()
+    g_f = ref_table.grad.detach().clone()
+    h_f = hip_table_param.grad.detach().cpu().reshape(-1, 2).clone()
+    scale = float((g_m + g_f).abs().max())
+    err = ((h_m + h_f) - (g_m + g_f)).abs().max(dim=1).values
+    bad = err > 1e-3 * scale
+    reach = g_f.abs().max(dim=1).values + h_f.abs().max(dim=1).values
+    assert bool((reach[bad] > 0).all()), "a table row outside the reach of every kink-flagged pixel disagrees with the mask off"
+    assert bool((err[bad] <= 2.0 * reach[bad] + 1e-3 * scale).all()), "disagreement larger than the flagged pixels' own contributions"
+    assert int(bad.sum()) <= flagged_px * 2 * 16 * 8, (int(bad.sum()), flagged_px)
+    # restore the masked gradients for the caller's own comparison
+    ref_table.grad = g_m
+    hip_table_param.grad = h_m.reshape(hip_table_param.shape).to(hip_table_param.device)
+    for p, g in keep:
+        p.grad = g
+    return {"unmasked_table_grad_rel_err": float(err.max() / scale), "table_rows_above_1e-3_with_mask_off": int(bad.sum()),
+            "flagged_pixels": flagged_px, "all_such_rows_reachable_from_a_flagged_pixel": True,
+            "flagged_part_rel_err": float((h_f - g_f).abs().max() / scale)}
+
+
+
 def _cfg2_compare(dev, texel=None, oracle_cache=None, strict=True, mask_clamp=True):
     """scene + comparison of test_cfg2_real_assets_render_vs_oracle; `texel` overrides the atlas storage format (the gradient
     error budget study of tools/grad_budget.py runs it with "fp32"), `oracle_cache` (dict) keeps the CPU oracle's result."""
@@ -1724,10 +1815,11 @@ def _cfg2_compare(dev, texel=None, oracle_cache=None, strict=True, mask_clamp=Tr
         ref, table, w1, w2, dy, masked = oracle_cache["ref"]
     else:
         ref = orender.render(md, batch, dict(table=table, w1=w1, w2=w2, levels=lv, radius=1.0), [golden_env], fg, ju, jn)
+        dy_full = dy
         dy, masked = _mask_kink_ambiguous(dy, ref) if mask_clamp else (dy, 0.0)
         if oracle_cache is not None:
             ref["_features"].retain_grad(); ref["_features_jitter"].retain_grad()
-        ((ref["comp_rgb"] * dy).sum() + 2.0 * ref["loss_mat_reg"]).backward()
+        ((ref["comp_rgb"] * dy).sum() + 2.0 * ref["loss_mat_reg"]).backward(retain_graph=True)
         if oracle_cache is not None:
             oracle_cache["ref"] = (ref, table, w1, w2, dy, masked)
     assert np.array_equal(out["_internals"]["rast"].cpu().numpy().view(np.uint32), ref["_rast"].numpy().view(np.uint32))
@@ -1743,10 +1835,16 @@ def _cfg2_compare(dev, texel=None, oracle_cache=None, strict=True, mask_clamp=Tr
     assert psnr > 80, psnr
     if oracle_cache is not None:          # per-pixel feature gradients, for locating a disagreement (tools/grad_budget.py)
         out["_internals"]["features"].retain_grad(); out["_internals"]["features_jitter"].retain_grad()
-    ((out["comp_rgb"] * dy.to(dev)).sum() + 2.0 * out["loss_mat_reg"]).backward()
+    ((out["comp_rgb"] * dy.to(dev)).sum() + 2.0 * out["loss_mat_reg"]).backward(retain_graph=True)
+    companion = None
+    if mask_clamp and oracle_cache is None:
+        companion = _kink_companion(out, ref, dy_full, dy, geom.encoding.encoding.params, table, dev,
+                                    others=(w1, w2, geom.feature_network.layers[0].weight, geom.feature_network.layers[2].weight))
     if oracle_cache is not None and ref["_features"].grad is not None:
+        rm = _rm(out["_internals"]["gbuffer"])
         for nm_f, hf, of in (("features", out["_internals"]["features"], ref["_features"]),
                              ("features_jitter", out["_internals"]["features_jitter"], ref["_features_jitter"])):
+            hf = _RowView(hf, rm)                             # the product's rows in the oracle's row-major order
             d = (hf.grad.cpu() - of.grad).abs().max(dim=1).values
             top = torch.topk(d, 3).indices
             sel = (ref["_rast"][..., 3] > 0).reshape(-1).nonzero()[:, 0]
@@ -1762,7 +1860,8 @@ def _cfg2_compare(dev, texel=None, oracle_cache=None, strict=True, mask_clamp=Tr
         t2 = table.detach().clone().requires_grad_()
         f2 = ofield.field_forward(ref["_gb_pos"].reshape(-1, 3)[sel_b], t2, w1.detach(), w2.detach(), lv, 1.0)
         fj2 = ofield.field_forward(ref["_positions_jitter"].detach(), t2, w1.detach(), w2.detach(), lv, 1.0)
-        ((f2 * out["_internals"]["features"].grad.cpu()).sum() + (fj2 * out["_internals"]["features_jitter"].grad.cpu()).sum()).backward()
+        rm = _rm(out["_internals"]["gbuffer"])
+        ((f2 * out["_internals"]["features"].grad.cpu()[rm]).sum() + (fj2 * out["_internals"]["features_jitter"].grad.cpu()[rm]).sum()).backward()
         th = geom.encoding.encoding.params.grad.cpu().reshape(-1, 2)
         oracle_cache["split"] = {"oracle_bwd_of_hip_dfeat_vs_hip_table": float((t2.grad - th).abs().max() / table.grad.abs().max()),
                                  "oracle_bwd_of_hip_dfeat_vs_oracle_table": float((t2.grad - table.grad).abs().max() / table.grad.abs().max())}
@@ -1780,7 +1879,7 @@ def _cfg2_compare(dev, texel=None, oracle_cache=None, strict=True, mask_clamp=Tr
                                             "rel_err_of_that_entry": float(((a[i] - b[i]).abs().max() / b[i].abs().max().clamp(min=1e-30)))}
     return {"psnr_db": psnr, "coverage_ids_equal": True, "covered_fraction": cover, "max_abs_err": errs,
             "grad_rel_err": rels, "assets": sums, "atlas_texel": mat.atlas.texel,
-            "kink_ambiguous_fraction_of_covered_channels_masked_in_dy": masked}
+            "kink_ambiguous_fraction_of_covered_channels_masked_in_dy": masked, "mask_off_companion": companion}
 
 
 
@@ -1875,10 +1974,13 @@ def test_cfg3_bench_scene_render_vs_oracle(dev):
     psnr = 10 * np.log10(1.0 / max(mse, 1e-20))
     assert psnr > 80, psnr
     dy = torch.randn(B, H, W, 3, generator=g)
+    dy_full = dy
     dy, masked = _mask_kink_ambiguous(dy, ref)      # (the 100x sun lobes saturate many pixels)
     assert masked < 0.5, masked                     # the gradient comparison must keep a substantial part of the image
-    ((out["comp_rgb"] * dy.to(dev)).sum() + 2.0 * out["loss_mat_reg"]).backward()
-    ((ref["comp_rgb"] * dy).sum() + 2.0 * ref["loss_mat_reg"]).backward()
+    ((out["comp_rgb"] * dy.to(dev)).sum() + 2.0 * out["loss_mat_reg"]).backward(retain_graph=True)
+    ((ref["comp_rgb"] * dy).sum() + 2.0 * ref["loss_mat_reg"]).backward(retain_graph=True)
+    companion = _kink_companion(out, ref, dy_full, dy, geom.encoding.encoding.params, table, dev,
+                                others=(w1, w2, geom.feature_network.layers[0].weight, geom.feature_network.layers[2].weight))
     rels = {}
     for a, b, nm in ((geom.encoding.encoding.params.grad.cpu().reshape(-1, 2), table.grad, "table"),
                      (geom.feature_network.layers[0].weight.grad.cpu(), w1.grad, "w1"),
@@ -1889,7 +1991,7 @@ def test_cfg3_bench_scene_render_vs_oracle(dev):
     with open(os.path.join(OUT, "cfg3_render_parity.json"), "w") as fh:
         json.dump({"config": "BASELINE configs[2]: sphere:160:160, 8 views @512^2, 5 probes @128, 16 x 2^19 grid",
                    "psnr_db": psnr, "coverage_ids_equal": True, "covered_fraction": cover, "max_abs_err": errs,
-                   "grad_rel_err": rels}, fh)
+                   "grad_rel_err": rels, "mask_off_companion": companion}, fh)
 
 
 def test_full_size_sd21_unet_controlnet_eps_vs_oracle(dev):
