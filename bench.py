@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--sharded-adam", action="store_true",
                     help="optimizer.sharded: reduce-scatter + Adam on this rank's slice + all-gather instead of all-reduce + full Adam")
     ap.add_argument("--dump-kernels", default=None, help="write the per-kernel HIP-event table of the timed region (JSON) here")
+    ap.add_argument("--dump-shade", default=None,
+                    help="after the clock has stopped, run one more step and save the shade kernels' REAL in-step inputs (G-buffer, "
+                         "features, atlas) here as a .pt (tools/r4_shade_probe.py --case replays them)")
     return ap.parse_args()
 
 
@@ -341,6 +344,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kt = hipops.kernel_times()
+    if a.dump_shade and rank == 0:
+        hipops.SHADE_DUMP["path"] = a.dump_shade
+        trainer.train_one_step()
+        sync()
     if a.dump_kernels and rank == 0:
         with open(a.dump_kernels, "w") as fh:
             json.dump({"steps": roof_steps, "kernels": kt}, fh, indent=1)
@@ -413,6 +420,25 @@ def main():
                            "frac": gbs / 8000.0, "traffic": None, "avg_us": r["avg_ms"] * 1e3,
                            "covered_pixels": r["work_per_launch"] / (56.0 if key == "shade_fwd" else 76.0)}
                 res[nm].update(shade_traffic(key, system.material.atlas.texel) or {})
+        # SURVEY 8d "report, do not gate" rows: rasterize (+ interpolate, fused into the G-buffer pass), antialias, hash grid --
+        # algorithmic bytes per launch / HIP-event time per launch, from the same extra steps as the shade rows
+        def hbm_row(kernel, keys):
+            rows = [kt[k] for k in keys if k in kt]
+            if not rows:
+                return None
+            t = sum(r["avg_ms"] * r["launches"] for r in rows) * 1e-3
+            w = sum(r["work_per_launch"] * r["launches"] for r in rows)
+            n = sum(r["launches"] for r in rows)
+            return {"kernel": kernel, "bound": "hbm", "achieved": w / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": w / t / 8e12,
+                    "traffic": None, "avg_us": t / n * 1e6, "launches_timed": n, "algorithmic_bytes": w / n, "gated": False}
+        for nm, kernel, keys in (("roofline_rasterize", "k_vertex_transform + k_bin + k_raster_fine", ["rasterize"]),
+                                 ("roofline_antialias", "k_aa_plan + k_aa_apply<C> + k_aa_grad<C>",
+                                  [k for k in kt if k.startswith("antialias")]),
+                                 ("roofline_hashgrid_fwd", "k_hashgrid<false>", ["hashgrid_fwd"]),
+                                 ("roofline_hashgrid_bwd", "k_hg_bin / k_hg_acc / k_hg_sum", [k for k in kt if k.startswith("hashgrid_bwd")])):
+            row = hbm_row(kernel, keys)
+            if row:
+                res[nm] = row
         if world == 1 and not a.no_cpu_baseline:
             import signal
 

@@ -74,6 +74,22 @@ class BaseModule(nn.Module, Updateable):
     # state_dict key prefixes of reference modules that exist in its checkpoints but are never used on the path
     IGNORED_REFERENCE_KEYS = ("metallic_predictor.", "roughness_predictor.", "albedo_predictor.", "inner_light.",
                               "light_pts", "FG_LUT", "sdf_network.", "normal_network.")
+    # the reference ALWAYS stores these buffers (dreammat_mesh.py:188-199); this repo registers them only when the mesh has the
+    # attribute, so a reference checkpoint of a UV-carrying mesh must still load into a UV-less local mesh
+    OPTIONAL_REFERENCE_BUFFERS = ("vtex_buffer", "ttex_buffer")
+
+    @classmethod
+    def check_state_dict_match(cls, what, res, own_keys=()):
+        """shared by `weights:` loading and Trainer.load_checkpoint: any missing key, or an unexpected key outside the two
+        allow-lists, raises (instead of silently leaving parameters at their random initialisation)"""
+        skip = cls.IGNORED_REFERENCE_KEYS
+
+        def allowed(k):         # (substring match: the keys carry module prefixes in a whole-system checkpoint)
+            return any(s in k for s in skip) or (k.rsplit(".", 1)[-1] in cls.OPTIONAL_REFERENCE_BUFFERS and k not in own_keys)
+        unexpected = [k for k in res.unexpected_keys if not allowed(k)]
+        if res.missing_keys or unexpected:
+            raise RuntimeError(f"{what}: missing {list(res.missing_keys)}, unexpected {unexpected}")
+        return [k for k in res.unexpected_keys if allowed(k)]
 
     def __init__(self, cfg=None, *args, **kwargs):
         super().__init__()
@@ -91,12 +107,10 @@ class BaseModule(nn.Module, Updateable):
             # allow-list (wrong module prefix, truncated or mismatched checkpoint), raises instead of silently leaving
             # parameters at their random initialisation.
             res = self.load_state_dict(sd, strict=False)
-            unexpected = [k for k in res.unexpected_keys if not k.startswith(self.IGNORED_REFERENCE_KEYS)]
-            if res.missing_keys or unexpected:
-                raise RuntimeError(f"weights '{self.cfg.weights}' do not match {type(self).__name__}: "
-                                   f"missing {list(res.missing_keys)}, unexpected {unexpected}")
-            if res.unexpected_keys:
-                print(f"[dreammat_amd] weights '{self.cfg.weights}': ignored reference-only keys {list(res.unexpected_keys)}")
+            ignored = self.check_state_dict_match(f"weights '{self.cfg.weights}' do not match {type(self).__name__}", res,
+                                                  own_keys=set(self.state_dict()))
+            if ignored:
+                print(f"[dreammat_amd] weights '{self.cfg.weights}': ignored reference-only keys {ignored}")
             self.do_update_step(ckpt.get("epoch", 0), ckpt.get("global_step", 0), on_load_weights=True)
         self._dummy: torch.Tensor
         self.register_buffer("_dummy", torch.zeros(0).float(), persistent=False)

@@ -84,17 +84,69 @@ def controlnet_training_loss(vae, unet, controlnet, scheduler, pixel_values, con
 
 class ControlNetTrainer:
     """AdamW(lr 1e-5 by default in the reference's train.sh) over the ControlNet parameters only; gradient clipping at
-    max_grad_norm (:899-902)."""
+    max_grad_norm (:899-902).
 
-    def __init__(self, vae, unet, controlnet=None, lr=1e-5, weight_decay=1e-2, max_grad_norm=1.0):
+    Mixed precision as the reference's `accelerate --mixed_precision` does it: when the ControlNet computes in bf16 (the MFMA
+    training kernels need bf16 weights), the optimizer runs on fp32 MASTER copies of its parameters -- pure bf16 parameters
+    under AdamW at lr 1e-5 lose most updates to rounding (a bf16 ulp at |w| = 0.02 is 1.2e-4).  The masters are created the
+    first time gradients are applied, from whatever dtype the module has then (so `trainer.controlnet.bfloat16()` after
+    construction works); the state dict is the masters' values."""
+
+    def __init__(self, vae, unet, controlnet=None, lr=1e-5, weight_decay=1e-2, max_grad_norm=1.0, compute_dtype=None):
         freeze(vae, unet)
         self.vae, self.unet = vae, unet
         self.controlnet = controlnet if controlnet is not None else init_controlnet(unet)
+        if compute_dtype is not None:
+            self.controlnet.to(dtype=compute_dtype)
         self.scheduler = DDIMScheduler()
-        self.opt = torch.optim.AdamW([p for p in self.controlnet.parameters() if p.requires_grad], lr=lr,
-                                     weight_decay=weight_decay)
+        self.lr, self.weight_decay = lr, weight_decay
+        self.opt, self.master = None, None
         self.max_grad_norm = max_grad_norm
         self.global_step = 0
+        self._build_optimizer()
+
+    def _params(self):
+        return [p for p in self.controlnet.parameters() if p.requires_grad]
+
+    def _build_optimizer(self):
+        params = self._params()
+        self._opt_dtype = params[0].dtype
+        self._opt_device = params[0].device
+        if any(p.dtype != torch.float32 for p in params):
+            self.master = [p.detach().float().clone().requires_grad_() for p in params]
+            target = self.master
+        else:
+            self.master, target = None, params
+        self.opt = torch.optim.AdamW(target, lr=self.lr, weight_decay=self.weight_decay)
+
+    def apply_gradients(self, world=1):
+        """all-reduce (ONE flat collective) -> clip -> AdamW on the fp32 masters -> cast back; called after loss.backward()."""
+        params = self._params()
+        if params[0].dtype != self._opt_dtype or params[0].device != self._opt_device:     # module cast / moved after construction
+            assert self.global_step == 0, "the ControlNet changed dtype / device after the first optimizer step"
+            self._build_optimizer()
+        targets = self.master if self.master is not None else params
+        if self.master is not None:
+            for m, p in zip(self.master, params):
+                m.grad = None if p.grad is None else p.grad.float()
+                p.grad = None
+        if world > 1:
+            import torch.distributed as dist
+            live = [t for t in targets if t.grad is not None]
+            flat = torch.cat([t.grad.reshape(-1) for t in live])
+            dist.all_reduce(flat)
+            flat /= world
+            o = 0
+            for t in live:
+                t.grad.copy_(flat[o:o + t.numel()].view_as(t.grad)); o += t.numel()
+        torch.nn.utils.clip_grad_norm_(targets, self.max_grad_norm)
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+        if self.master is not None:
+            with torch.no_grad():
+                for m, p in zip(self.master, params):
+                    p.copy_(m)
+        self.global_step += 1
 
     def step(self, pixel_values, cond, text_emb, null_emb=None, generator=None, **fixed):
         if null_emb is not None:
@@ -102,15 +154,19 @@ class ControlNetTrainer:
         loss = controlnet_training_loss(self.vae, self.unet, self.controlnet, self.scheduler, pixel_values, cond, text_emb,
                                         generator=generator, **fixed)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(self.controlnet.parameters(), self.max_grad_norm)
-        self.opt.step()
-        self.opt.zero_grad(set_to_none=True)
-        self.global_step += 1
+        self.apply_gradients()
         return loss.detach()
 
     def state_dict(self):
-        """diffusers key layout (loadable by dreammat_amd.sd.loading and by diffusers' ControlNetModel)."""
-        return self.controlnet.state_dict()
+        """diffusers key layout (loadable by dreammat_amd.sd.loading and by diffusers' ControlNetModel); trainable tensors
+        come from the fp32 masters when there are any."""
+        sd = self.controlnet.state_dict()
+        if self.master is not None:
+            by_id = {id(p): m for p, m in zip(self._params(), self.master)}
+            for k, p in self.controlnet.named_parameters():
+                if id(p) in by_id:
+                    sd[k] = by_id[id(p)].detach()
+        return sd
 
 
 # ------------------------------------------------------------------------------------------------ dataset
@@ -252,6 +308,8 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0"))) if torch.cuda.is_available() else torch.device("cpu")
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)                    # before the process group: RCCL binds to the current device
     if world > 1:
         dist.init_process_group("nccl" if dev.type == "cuda" else "gloo")
     arch = arch_for(a.pretrained_model_name_or_path)
@@ -262,34 +320,32 @@ def main(argv=None):
         load_component(unet, a.pretrained_model_name_or_path, "unet")
     dt = torch.bfloat16 if dev.type == "cuda" else torch.float32
     vae.to(dev, dt); unet.to(dev, dt)
-    tr = ControlNetTrainer(vae, unet, lr=a.learning_rate)
-    tr.controlnet.to(dev)
+    cn = init_controlnet(unet).to(dev, dt)            # the compute dtype of the frozen nets; fp32 masters live in the trainer
+    tr = ControlNetTrainer(vae, unet, cn, lr=a.learning_rate)
     ds = ControlNetRenderDataset(a.train_data_dir, a.prompt_file, a.resolution, a.use_cfg)
     sampler = torch.utils.data.distributed.DistributedSampler(ds, world, rank, shuffle=True, seed=0) if world > 1 else None
     dl = torch.utils.data.DataLoader(ds, batch_size=a.train_batch_size, shuffle=sampler is None, sampler=sampler,
                                      collate_fn=collate, drop_last=True)
     embed = {}
+    pp = StableDiffusionPromptProcessor({"prompt": " ", "pretrained_model_name_or_path": a.pretrained_model_name_or_path,
+                                         "synthetic": a.synthetic, "use_perp_neg": False})      # ONE text encoder front-end
 
     def text(prompts):
-        for p in set(prompts):
-            if p not in embed:
-                pp = StableDiffusionPromptProcessor({"prompt": p or " ", "pretrained_model_name_or_path": a.pretrained_model_name_or_path,
-                                                     "synthetic": a.synthetic, "use_perp_neg": False})
-                embed[p] = pp.text_embeddings[:1].to(dev)
+        todo = [p for p in dict.fromkeys(prompts) if p not in embed]
+        if todo:
+            for p, e in zip(todo, pp._encode([p or " " for p in todo])):
+                embed[p] = e[None].to(dev)
         return torch.cat([embed[p] for p in prompts])
+    epoch = 0
     while tr.global_step < a.max_train_steps:
+        if sampler is not None:
+            sampler.set_epoch(epoch)                  # a new shuffle every pass
+        epoch += 1
         for batch in dl:
             loss = controlnet_training_loss(tr.vae, tr.unet, tr.controlnet, tr.scheduler, batch["pixel_values"].to(dev, dt),
                                             batch["conditioning_pixel_values"].to(dev), text(batch["prompts"]))
             loss.backward()
-            if world > 1:
-                for p in tr.controlnet.parameters():
-                    if p.grad is not None:
-                        dist.all_reduce(p.grad)
-                        p.grad /= world
-            torch.nn.utils.clip_grad_norm_(tr.controlnet.parameters(), tr.max_grad_norm)
-            tr.opt.step(); tr.opt.zero_grad(set_to_none=True)
-            tr.global_step += 1
+            tr.apply_gradients(world)
             if rank == 0 and tr.global_step % 10 == 0:
                 print(json.dumps({"step": tr.global_step, "loss": float(loss)}), flush=True)
             if rank == 0 and tr.global_step % a.checkpointing_steps == 0:

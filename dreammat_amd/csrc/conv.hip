@@ -205,15 +205,15 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     //   <256, 256, 8, 2, 2>     wave tile 128 x 64: 24 ds_read_b128 per 32 MFMA instead of 16 per 16, and half the
     //   <256, 320, 8, 4, 2>     wave tile 64 x 160    DMA bytes per FLOP (Cout = 320 without a ragged N tile)
     //   <512, 128, 8, 4, 2>     wave tile 128 x 64 for Cout = 128 (the 512^2 VAE layers)
-    constexpr int BK = 64;
+    [[maybe_unused]] constexpr int BK = 64;         // (the constants below are used by the device pass only)
     constexpr int ROWB = 128;                          // bytes per tile row (64 bf16), unpadded
     constexpr int WNW = NW / WMW;
     constexpr int TM = BMT / WMW, TN = BN / WNW;       // wave tile
-    constexpr int MT = TM / 32, NT = TN / 32;          // 32x32 accumulator fragments per wave
-    constexpr int A_BYTES = BMT * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    [[maybe_unused]] constexpr int MT = TM / 32, NT = TN / 32;     // 32x32 accumulator fragments per wave
+    [[maybe_unused]] constexpr int A_BYTES = BMT * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
     constexpr int A_INSTR = BMT / 8 / NW;              // wave-instructions (8 rows each) per wave
     constexpr int B_INSTR = BN / 8 / NW;
-    constexpr int L = A_INSTR + B_INSTR;               // DMA instructions per wave per tile
+    [[maybe_unused]] constexpr int L = A_INSTR + B_INSTR;    // DMA instructions per wave per tile
     static_assert(TM % 32 == 0 && TN % 32 == 0 && BMT % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile shape");
     static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // NSTAGE * STAGE
@@ -273,7 +273,6 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     int issue_tile = first;                            // work item the cursor is in
     int issue_on = 1;                                  // 0 once the last item's last step has been requested
     int n_ahead = 0;                                   // K-steps requested but not yet consumed
-    const int lrow = lane >> 3, lslot = lane & 7;      // this lane's row / 16 B slot inside one DMA instruction
 
     // ---- issue side: buffer-addressed DMA (buffer_load_dwordx4 ... lds).  Both operands are described by a raw buffer
     // resource (the launcher admits tensors below 4 GB), so a lane's source is a 32-bit byte offset and an out-of-image
@@ -736,10 +735,16 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
 // stream capture must be preceded by an eager run of the same shapes (torch's capture warm-up does that).  A buffer that has
 // been handed out is NEVER freed: a captured hipGraph (guidance `hip_graph`) keeps replaying kernels that hold its address,
 // so growing means allocating a larger one (at least 2x) next to it -- the dead ones add up to less than the live one.
-static float* splitk_workspace(size_t floats) {
+static float* splitk_workspace(size_t floats, hipStream_t stream) {
     static float* buf = nullptr;
     static size_t cap = 0;
     if (floats > cap) {
+        // hipMalloc is not capturable: growing under an active stream capture would invalidate the capture (or, worse, succeed
+        // on another runtime version and leave the graph with a buffer a later eager call may outgrow).  Refuse instead -- the
+        // caller reports DM_ERR_UNSUPPORTED and the message of hipops says to run the shape eagerly once first.
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone) return nullptr;
+        (void)hipGetLastError();
         size_t got = std::max(floats, 2 * cap);
         float* nb = nullptr;
         if (hipMalloc(&nb, got * sizeof(float)) != hipSuccess) {
@@ -799,7 +804,7 @@ int launch_conv_dma(const ConvArgs& a_in, hipStream_t stream) {
         if (ksplit > 1 && ((long long)ksplit * a.M * a.Cout * 4 > 0xffffff00LL || a.Cout % 8)) ksplit = 1;
     }
     float* ws = nullptr;
-    if (ksplit > 1 && !(ws = splitk_workspace((size_t)ksplit * a.M * a.Cout))) return DM_ERR_UNSUPPORTED;
+    if (ksplit > 1 && !(ws = splitk_workspace((size_t)ksplit * a.M * a.Cout, stream))) return DM_ERR_UNSUPPORTED;
     const long long total = n_mt * n_nt * ksplit, per_xcd = (total + 7) / 8;
     long long wpx = std::min<long long>(per_xcd, (long long)n_cu * wg_per_cu / 8);
     long long blocks = 8 * std::max<long long>(wpx, 1);

@@ -292,7 +292,7 @@ static inline int shade_offsets32(const ShadeArgs& a, long long n_max, bool bwd)
 // shade_pixel_loop): S = ceil(batches / resident waves), then the FEWEST waves that still finish in S steps -- per XCD, because
 // each XCD owns an eighth of the batches.  Always a multiple of 8 workgroups (one per XCD) unless the launch is tiny.
 static inline int shade_grid(long long n_max, int wg_per_cu) {
-    if (const char* e = getenv("DREAMMAT_SHADE_WGPCU")) wg_per_cu = atoi(e);     // development knob
+    if (const char* e = getenv("DREAMMAT_SHADE_WGPCU")) { if (atoi(e) > 0) wg_per_cu = atoi(e); }     // development knob
     const long long nb = (n_max + 63) / 64;                  // 64-row batches
     const long long nbx = (nb + 7) / 8;                      // per XCD (ceil)
     const long long waves_x = 32LL * wg_per_cu * 4;          // resident waves of one XCD: 32 CUs x workgroups x 4 waves
@@ -438,7 +438,8 @@ int dm_shade_bwd(const dm_env_atlas* atlas, const dm_mat_cfg* mat, const float* 
     a.dfeat = {dfeat, dfeat_rs, dfeat_cs};
     DM_ENTER();
     a.offsets32 = shade_offsets32(a, n_max, true);
-    const dim3 grid(shade_grid(n_max, 2));                 // (backward: 32.8 / 25.2 / 24.5 / 26.0 and 32.1 / 27.7 / 29.2 / 30.7 us)
+    const dim3 grid(shade_grid(n_max, 3));                 // (backward: 32.8 / 25.2 / 24.5 / 26.0 and 32.1 / 27.7 / 29.2 / 30.7 us; in the
+                                                           // step itself 3 beat 2: 30.6 vs 33.5 us)
     switch (a.atlas.texel_format) {
         case kTexelRgb18e8: hipLaunchKernelGGL(k_shade_bwd<kTexelRgb18e8>, grid, dim3(256), 0, stream, a); break;
         case kTexelF16: hipLaunchKernelGGL(k_shade_bwd<kTexelF16>, grid, dim3(256), 0, stream, a); break;

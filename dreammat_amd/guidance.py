@@ -236,9 +236,16 @@ class StableDiffusionLightGuidance(BaseObject):
     def _bank_cast(self, bank):
         """the bank in the nets' dtype, converted once per bank tensor"""
         key = (bank.data_ptr(), bank._version, self.weights_dtype)
-        if getattr(self, "_bank_key", None) != key:
-            self._bank_t, self._bank_key = bank.to(self.weights_dtype), key
-        return self._bank_t
+        casts = self.__dict__.setdefault("_bank_casts", {})
+        if key not in casts:
+            # every live cast stays alive: a captured hipGraph replays against the address of the one it was captured with.
+            # When the pool overflows, the graphs go with the evicted tensors (they would replay against freed memory).
+            if len(casts) >= 4:
+                casts.clear()
+                if hasattr(self, "_graphs"):
+                    self._graphs.clear()
+            casts[key] = bank.to(self.weights_dtype)
+        return casts[key]
 
     def _noise_pred(self, latents_noisy, t, text_embeddings, image_cond, condition_scales, bank_ids=None, n_branch=3):
         ctx = PaddedContext(text_embeddings.to(self.weights_dtype), *(bank_ids or (None, None)))

@@ -119,8 +119,10 @@ class RasterContext:
         rast = torch.empty(B, H, W, 4, device=pos_clip.device, dtype=torch.float32)
         while True:
             ws = self._workspace(B, tri.shape[0], H, W)
-            check(_lib.lib().dm_rasterize(pos_clip.data_ptr(), B, Nv, tri.data_ptr(), tri.shape[0], H, W,
-                                          rast.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "dm_rasterize")
+            # read pos B Nv 16 + tri Nf 12, write rast P 16 (reported, not gated: binning / latency bound)
+            with _Timed("rasterize", 16.0 * B * Nv + 12.0 * tri.shape[0] + 16.0 * B * H * W):
+                check(_lib.lib().dm_rasterize(pos_clip.data_ptr(), B, Nv, tri.data_ptr(), tri.shape[0], H, W,
+                                              rast.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "dm_rasterize")
             if not check_overflow:
                 return rast
             flag = ctypes.c_int(0)
@@ -146,8 +148,9 @@ def antialias_plan(pos_clip, tri, opp, rast):
     _need_cuda(pos_clip, tri, opp, rast)
     B, H, W, _ = rast.shape
     plan = torch.empty(B, H, W, 2, device=rast.device, dtype=torch.float32)
-    check(_lib.lib().dm_antialias_plan(pos_clip.data_ptr(), B, pos_clip.shape[1], tri.data_ptr(), opp.data_ptr(),
-                                       rast.data_ptr(), H, W, plan.data_ptr(), _stream()), "dm_antialias_plan")
+    with _Timed("antialias_plan", 24.0 * B * H * W):                          # read rast 16, write plan 8 per pixel
+        check(_lib.lib().dm_antialias_plan(pos_clip.data_ptr(), B, pos_clip.shape[1], tri.data_ptr(), opp.data_ptr(),
+                                           rast.data_ptr(), H, W, plan.data_ptr(), _stream()), "dm_antialias_plan")
     return plan
 
 
@@ -158,8 +161,10 @@ class _Antialias(torch.autograd.Function):
         color = _f32c(color)
         B, H, W, C = color.shape
         out = torch.empty_like(color)
-        check(_lib.lib().dm_antialias_apply(color.data_ptr(), plan.data_ptr(), B, H, W, C, out.data_ptr(), _stream()),
-              "dm_antialias_apply")
+        # read colour + rast P (4 C + 16), write P 4 C (the kernel reads the 8-byte plan instead of rast)
+        with _Timed(f"antialias_apply[C={C}]", float(B * H * W) * (8 * C + 16)):
+            check(_lib.lib().dm_antialias_apply(color.data_ptr(), plan.data_ptr(), B, H, W, C, out.data_ptr(), _stream()),
+                  "dm_antialias_apply")
         ctx.save_for_backward(plan)
         return out
 
@@ -169,8 +174,9 @@ class _Antialias(torch.autograd.Function):
         g = _f32c(g)
         B, H, W, C = g.shape
         dcolor = torch.empty_like(g)
-        check(_lib.lib().dm_antialias_grad(g.data_ptr(), plan.data_ptr(), B, H, W, C, dcolor.data_ptr(), _stream()),
-              "dm_antialias_grad")
+        with _Timed(f"antialias_grad[C={C}]", float(B * H * W) * (8 * C + 16)):
+            check(_lib.lib().dm_antialias_grad(g.data_ptr(), plan.data_ptr(), B, H, W, C, dcolor.data_ptr(), _stream()),
+                  "dm_antialias_grad")
         return dcolor, None
 
 
@@ -350,8 +356,10 @@ class _HashGrid(torch.autograd.Function):
             rs, cs = _rs_cs(x)
             fwd, name = ((_lib.lib().dm_hashgrid_fwd, "dm_hashgrid_fwd") if spec.n_dims == 3
                          else (_lib.lib().dm_hashgrid2d_fwd, "dm_hashgrid2d_fwd"))
-            check(fwd(x.data_ptr(), rs, cs, None, M, table.data_ptr(), spec.n_levels, spec.c_scale, spec.c_res, spec.c_size,
-                      spec.c_offset, float(radius), enc.data_ptr(), 1, M, _stream()), name)
+            # M (12 + levels x 2^d corners x 8 B gathered) read, M x 4 F written -- reported as gather-bound
+            with _Timed("hashgrid_fwd", float(M) * (4 * spec.n_dims + spec.n_levels * (1 << spec.n_dims) * 8 + 4 * F)):
+                check(fwd(x.data_ptr(), rs, cs, None, M, table.data_ptr(), spec.n_levels, spec.c_scale, spec.c_res, spec.c_size,
+                          spec.c_offset, float(radius), enc.data_ptr(), 1, M, _stream()), name)
         ctx.save_for_backward(x, table)
         ctx.spec, ctx.radius, ctx.grad_sink = spec, radius, grad_sink
         return enc.t()
@@ -446,12 +454,24 @@ def field_mlp(x_fm, w1, w2):
 
 
 # ------------------------------------------------------------------------------------------ shading
+SHADE_DUMP = {"path": None}      # measurement aid (bench.py --dump-shade): the next shade forward saves its inputs here, once
+
+
 class _Shade(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, nrm, view, pix_idx, n_dev, env_of_view, atlas, mat, HW, want_debug):
         _need_cuda(feat, nrm, view, pix_idx, env_of_view)
         N = feat.shape[0]
         dev = feat.device
+        if SHADE_DUMP["path"]:
+            torch.save({"feat": feat.detach().cpu(), "nrm": nrm.cpu(), "view": view.cpu(), "pix_idx": pix_idx.cpu(),
+                        "env_of_view": env_of_view.cpu(), "HW": HW, "mat": [mat.min_metallic, mat.max_metallic, mat.min_roughness,
+                                                                             mat.max_roughness],
+                        "spec_packed": atlas.spec_packed.cpu(), "diff_packed": atlas.diff_packed.cpu(), "fg_lut": atlas.fg_lut.cpu(),
+                        "atlas_fields": {k: (list(getattr(atlas.struct, k)) if k in ("mip_off", "mip_res") else getattr(atlas.struct, k))
+                                         for k in ("spec_env_stride", "diff_env_stride", "mip_off", "mip_res", "n_mips", "diff_res",
+                                                   "lut_res", "min_rough_mip", "max_rough_mip", "texel_format")}}, SHADE_DUMP["path"])
+            SHADE_DUMP["path"] = None
         Np = (N + 3) // 4 * 4                   # channel pitch: the kernel stores 16 bytes (4 rows) per lane
         color = torch.empty(3, Np, device=dev)[:, :N]
         dbg = [None] * 7

@@ -330,12 +330,18 @@ class Attention(nn.Module):
             # frozen projections of a fixed bank of prompt embeddings: computed once, gathered per step
             key = (context.bank_key, self.to_k.weight.data_ptr(), self.to_k.weight._version, self.to_v.weight.data_ptr(),
                    self.to_v.weight._version)
-            if getattr(self, "_kv_bank_key", None) != key:
+            # keyed by (bank, weights): EVERY entry stays alive, because a captured hipGraph (guidance.hip_graph) bakes the raw
+            # addresses of the entry it was captured with -- replacing a single slot when a second bank shows up ("vd" vs
+            # "plain", a re-created prompt processor) would let an older graph replay against freed memory.
+            # A bank is ~9 x 77 x C values per layer; reloading the weights changes the key and drops the stale entries.
+            cache = self.__dict__.setdefault("_kv_banks", {})
+            if key not in cache:
+                for old in [k for k in cache if k[1:] != key[1:]]:      # other weights: those entries can never be hit again
+                    del cache[old]
                 with torch.no_grad():
-                    self._kv_bank = (linear_fused(context.bank, self.to_k.weight, self.to_k.bias),
-                                     project_vt(self.to_v.weight, self.to_v.bias, context.bank, kv_len))
-                self._kv_bank_key = key
-            kb, vtb = self._kv_bank
+                    cache[key] = (linear_fused(context.bank, self.to_k.weight, self.to_k.bias),
+                                  project_vt(self.to_v.weight, self.to_v.bias, context.bank, kv_len))
+            kb, vtb = cache[key]
             o = hipops.attention(q, kb.index_select(0, context.ids)[:, :kv_len], vtb.index_select(0, context.ids), self.heads)
         else:
             k = linear_fused(src, self.to_k.weight, self.to_k.bias)

@@ -95,10 +95,22 @@ class FusedAdam:
         self.step(allreduce_sum_(self.fp.grad))
 
     def state_dict(self):
-        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "step": self.step_count}
+        """moments WITHOUT the alignment padding (fp.numel entries): the same file loads under either optimizer at any world
+        size, whatever each pads the flat buffer to"""
+        n = self.fp.numel
+        return {"exp_avg": self.exp_avg[:n], "exp_avg_sq": self.exp_avg_sq[:n], "step": self.step_count}
 
     def load_state_dict(self, sd):
-        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"]); self.step_count = sd["step"]
+        _copy_padded(self.exp_avg, sd["exp_avg"], 0); _copy_padded(self.exp_avg_sq, sd["exp_avg_sq"], 0)
+        self.step_count = sd["step"]
+
+
+def _copy_padded(dst, src_full, lo):
+    """dst[:] = src_full[lo : lo + len(dst)], zeros where src_full (stored without padding, or with another padding) ends"""
+    k = max(0, min(dst.numel(), src_full.numel() - lo))
+    dst.zero_()
+    if k:
+        dst[:k].copy_(src_full[lo:lo + k])
 
 
 class ShardedFusedAdam:
@@ -146,14 +158,16 @@ class ShardedFusedAdam:
         return full
 
     def state_dict(self):
-        """the FULL moments, gathered (same layout as FusedAdam's: a checkpoint resumes under either optimizer, any world size
-        that divides the padded buffer) -- a collective: every rank calls it"""
-        return {"exp_avg": self._gathered(self.exp_avg), "exp_avg_sq": self._gathered(self.exp_avg_sq), "step": self.step_count}
+        """the FULL moments, gathered and cut to fp.numel entries (same layout as FusedAdam's: a checkpoint resumes under
+        either optimizer at ANY world size -- the padding to 4 x world is never stored) -- a collective: every rank calls it"""
+        n = self.fp.numel
+        return {"exp_avg": self._gathered(self.exp_avg)[:n], "exp_avg_sq": self._gathered(self.exp_avg_sq)[:n],
+                "step": self.step_count}
 
     def load_state_dict(self, sd):
-        sl = slice(self.lo, self.lo + self.shard)
-        self.exp_avg.copy_(sd["exp_avg"][sl]); self.exp_avg_sq.copy_(sd["exp_avg_sq"][sl]); self.step_count = sd["step"]
-        self.p_shard.copy_(self.fp.flat[sl])                              # the parameters were restored just before
+        _copy_padded(self.exp_avg, sd["exp_avg"], self.lo); _copy_padded(self.exp_avg_sq, sd["exp_avg_sq"], self.lo)
+        self.step_count = sd["step"]
+        self.p_shard.copy_(self.fp.flat[self.lo:self.lo + self.shard])    # the parameters were restored just before
 
 
 @dreammat_amd.register("dreammat-system")
@@ -293,11 +307,11 @@ class Trainer:
     def load_checkpoint(self, path):
         s = self.system
         ck = torch.load(path, map_location=s.device_)
-        with torch.no_grad():
-            own = s.state_dict()
-            for k, v in ck["state_dict"].items():
-                if k in own:
-                    own[k].copy_(v)
+        # the same rule as `weights:` loading (base.BaseObject.check_state_dict_match): missing keys, or unexpected keys outside
+        # the reference-only allow-lists, raise -- a resumed run must not silently keep random parameters
+        from .base import BaseModule
+        res = s.load_state_dict(ck["state_dict"], strict=False)
+        BaseModule.check_state_dict_match(f"checkpoint '{path}' does not match {type(s).__name__}", res, own_keys=set(s.state_dict()))
         s.optimizer.load_state_dict(ck["optimizer"])
         s.true_global_step, s.true_current_epoch = ck["global_step"], ck["epoch"]
 

@@ -12,7 +12,15 @@ Restates, from their published behaviour (un-vendored deps => PARITY UNPINNED):
 
 Cube-seam rule of THIS restatement (nvdiffrast's own wrap tables are not reproduced): a bilinear
 tap that falls outside its face is replaced by the nearest texel, in whichever face it lands,
-along the direction through that tap's centre on the extended face plane.
+along the direction through that tap's centre on the extended face plane (SEAM_MODE = "nearest",
+the rule the product's atlas borders implement).
+
+SEAM_MODE = "edge_wrap" is an ALTERNATE mode that follows nvdiffrast's documented seam filtering
+(texture.cu wrapCubeMap, restated from its published behaviour): a tap that leaves the face across
+ONE edge reads the adjacent face's edge texel with the SAME index along the shared edge, and a tap
+that leaves across a corner (both coordinates out: no such texel exists on a cube) is dropped and
+the remaining three weights are renormalised.  It exists to MEASURE how far the product's rule is
+from that behaviour (tools/seam_delta.py) -- it is not what the parity tests use.
 """
 import math
 
@@ -114,18 +122,34 @@ def cube_index(d):
     return face, u, v
 
 
+SEAM_MODE = "nearest"      # "nearest" (the parity contract) | "edge_wrap" (measurement only, see the module docstring)
+
+
 def _resolve_tap(face, ix, iy, R):
-    """Seam rule: out-of-face taps -> nearest texel along the extended-plane direction."""
-    oob = (ix < 0) | (ix >= R) | (iy < 0) | (iy >= R)
+    """Seam rule: out-of-face taps -> nearest texel along the extended-plane direction.
+    Returns (face, ix, iy, keep): keep = False only in "edge_wrap" mode for corner taps (dropped, weights renormalised)."""
+    oobx = (ix < 0) | (ix >= R)
+    ooby = (iy < 0) | (iy >= R)
+    oob = oobx | ooby
+    keep = torch.ones_like(oob)
     if not oob.any():
-        return face, ix, iy
+        return face, ix, iy, keep
     gx = (2.0 * (ix.float() + 0.5) / R - 1.0)
     gy = (2.0 * (iy.float() + 0.5) / R - 1.0)
+    if SEAM_MODE == "edge_wrap":
+        # the out coordinate becomes the new major axis (magnitude 1 + 1/R): scaling the in-range coordinate by the same
+        # factor keeps its position ALONG the shared edge after the re-projection, i.e. the same texel index there
+        s = 1.0 + 1.0 / R
+        gx = torch.where(ooby & ~oobx, gx * s, gx)
+        gy = torch.where(oobx & ~ooby, gy * s, gy)
+        keep = ~(oobx & ooby)
+    elif SEAM_MODE != "nearest":
+        raise ValueError(SEAM_MODE)
     d = cube_dirs_all(face, gx, gy)
     f2, u2, v2 = cube_index(d)
     ix2 = (u2 * R).floor().long().clamp(0, R - 1)
     iy2 = (v2 * R).floor().long().clamp(0, R - 1)
-    return torch.where(oob, f2, face), torch.where(oob, ix2, ix), torch.where(oob, iy2, iy)
+    return torch.where(oob, f2, face), torch.where(oob, ix2, ix), torch.where(oob, iy2, iy), keep
 
 
 def cube_bilinear(tex, d):
@@ -137,12 +161,16 @@ def cube_bilinear(tex, d):
     x0 = x.floor(); y0 = y.floor()
     fx = (x - x0)[..., None]; fy = (y - y0)[..., None]
     ix0 = x0.long(); iy0 = y0.long()
-    out = 0
+    out, wsum = 0, 0
     for dy, wy in ((0, 1 - fy), (1, fy)):
         for dx, wx in ((0, 1 - fx), (1, fx)):
-            f, ix, iy = _resolve_tap(face, ix0 + dx, iy0 + dy, R)
-            out = out + tex[f, iy, ix] * (wx * wy)
-    return out
+            f, ix, iy, keep = _resolve_tap(face, ix0 + dx, iy0 + dy, R)
+            w = wx * wy
+            if SEAM_MODE != "nearest":
+                w = w * keep[..., None].to(w.dtype)
+                wsum = wsum + w
+            out = out + tex[f, iy, ix] * w
+    return out if SEAM_MODE == "nearest" else out / wsum
 
 
 def texture2d_linear_clamp(tex, uv):

@@ -183,7 +183,7 @@ def _sharded_worker(rank, world, port, out_dir):
 
     def make(sharded):
         torch.manual_seed(0)
-        params = [torch.nn.Parameter(torch.randn(1001)), torch.nn.Parameter(torch.randn(7, 5)), torch.nn.Parameter(torch.randn(3))]
+        params = [torch.nn.Parameter(torch.randn(1001)), torch.nn.Parameter(torch.randn(7, 5)), torch.nn.Parameter(torch.randn(5))]   # 1041: pads to 1044 (4) / 1048 (4 x world)
         fp = sysm.FlatParams(params, pad_to=4 * world if sharded else 4)
         if sharded:
             opt = sysm.ShardedFusedAdam(fp, lr=0.01, betas=(0.9, 0.99), eps=1e-15, adam_fn=_cpu_adam_step)
@@ -211,7 +211,14 @@ def _sharded_worker(rank, world, port, out_dir):
     assert float(fb.grad.abs().max()) == 0.0                                                       # zeroed for the next accumulation
     # checkpoint round trip through the gathered state: resume under the sharded optimizer and continue identically
     sd = ob.state_dict()
-    assert sd["exp_avg"].numel() == fb.flat.numel() and torch.allclose(sd["exp_avg"][:fa.numel], oa.exp_avg[:fa.numel], atol=1e-7)
+    assert fa.flat.numel() != fb.flat.numel()                        # the two optimizers pad the buffer differently ...
+    assert sd["exp_avg"].numel() == fa.numel == 1041 and torch.allclose(sd["exp_avg"], oa.exp_avg[:fa.numel], atol=1e-7)
+    pd, fd, od = make(False)                                         # ... and the same file loads under the un-sharded one
+    od.load_state_dict(sd)
+    assert torch.equal(od.exp_avg[:fa.numel], sd["exp_avg"]) and float(od.exp_avg[fa.numel:].abs().sum()) == 0 and od.step_count == 3
+    oe = make(True)[2]
+    oe.load_state_dict(oa.state_dict())                              # and the un-sharded optimizer's file under the sharded one
+    assert torch.allclose(oe._gathered(oe.exp_avg)[:fa.numel], oa.exp_avg[:fa.numel])
     pc, fc, oc = make(True)
     fc.flat.copy_(fb.flat)
     oc.load_state_dict(sd)
@@ -261,7 +268,7 @@ def _sharded_fit_worker(rank, world, port, out_dir):
     dist.barrier()
     assert os.path.exists(ck) or rank != 0
     saved = torch.load(ck, map_location="cpu")
-    assert saved["optimizer"]["exp_avg"].numel() == system.flat.flat.numel() and saved["global_step"] == 2
+    assert saved["optimizer"]["exp_avg"].numel() == system.flat.numel and saved["global_step"] == 2
     torch.save({"after4": system.flat.flat.clone()}, os.path.join(out_dir, f"fit{rank}.pt"))
     dist.destroy_process_group()
 

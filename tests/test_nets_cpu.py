@@ -137,7 +137,7 @@ def test_controlnet_training_step_and_cfg_dropout():
     assert all(p.grad is None for p in unet.parameters())
     got = [n for n, p in tr.controlnet.named_parameters() if p.grad is not None and p.grad.abs().sum() > 0]
     assert any(n.startswith("controlnet_down_blocks") for n in got) and any(n.startswith("controlnet_mid_block") for n in got)
-    tr.opt.zero_grad(set_to_none=True)
+    tr.controlnet.zero_grad(set_to_none=True)
     losses = [float(tr.step(img, cond, text, **fixed)) for _ in range(12)]
     assert losses[-1] < losses[0] and tr.global_step == 12
     assert set(tr.state_dict()) == set(tr.controlnet.state_dict())
@@ -156,6 +156,72 @@ def test_controlnet_training_step_and_cfg_dropout():
     assert int((z.any(1) & ~(all0 | depth0 | normal0 | light0)).sum()) == 0
     dt = (t2.view(-1) == 0)
     assert abs(float(dt.float().mean()) - 0.30) < 0.01 and int((dt & z.any(1)).sum()) == 0   # never both
+
+
+def _tiny_render_tree(root, prompts_path, S=64, n_views=16):
+    """a complete object directory in the reference's render-tree layout (random images)"""
+    import json
+
+    import numpy as np
+    from PIL import Image
+    rs = np.random.RandomState(0)
+    for sub in ("color", "depth", "normal", "light"):
+        (root / "obj_a" / sub).mkdir(parents=True)
+    for view in range(n_views):
+        d = np.zeros((S, S), np.uint16); d[8:56, 8:56] = rs.randint(1500, 2500, (48, 48))
+        Image.fromarray(d).save(root / "obj_a" / "depth" / f"{view:03d}.png")
+        n = rs.randint(0, 255, (S, S, 4)).astype(np.uint8); n[..., 3] = 255
+        Image.fromarray(n, "RGBA").save(root / "obj_a" / "normal" / f"{view:03d}.png")
+        for env in range(1, 6):
+            Image.fromarray(rs.randint(0, 255, (S, S, 3)).astype(np.uint8), "RGB").save(root / "obj_a" / "color" / f"{view:03d}_color_env{env}.png")
+            for m in ("0.0", "1.0"):
+                for r in ("0.0", "0.5", "1.0"):
+                    Image.fromarray(rs.randint(0, 255, (S, S, 3)).astype(np.uint8), "RGB").save(
+                        root / "obj_a" / "light" / f"{view:03d}_m{m}r{r}_env{env}.png")
+    prompts_path.write_text(json.dumps({"obj_a": "a red teapot"}))
+
+
+def test_controlnet_launcher_main_runs_two_steps(tmp_path):
+    """nothing called controlnet_train.main(); its first step crashed on a GPU (bf16 latents against an
+    fp32 ControlNet).  Here on the CPU (fp32 throughout), tests/test_hip_gpu.py runs the same launcher in bf16 on the GPU."""
+    from dreammat_amd import controlnet_train as ct
+    root = tmp_path / "data"
+    _tiny_render_tree(root, tmp_path / "prompts.json")
+    tr = ct.main(["--synthetic", "--pretrained_model_name_or_path", "tiny", "--train_data_dir", str(root),
+                  "--prompt_file", str(tmp_path / "prompts.json"), "--resolution", "64", "--train_batch_size", "2",
+                  "--max_train_steps", "2", "--output_dir", str(tmp_path / "out"), "--checkpointing_steps", "2"])
+    assert tr.global_step == 2 and tr.master is None
+    assert (tmp_path / "out" / "controlnet_step2.pt").exists()
+
+
+def test_controlnet_trainer_keeps_fp32_master_weights_under_bf16_compute():
+    """bf16 ControlNet parameters + AdamW at lr 1e-5 lose most updates to rounding: the trainer keeps fp32 masters (created
+    when gradients are first applied, also when the module was cast AFTER construction), steps them, casts back, and its
+    state dict carries the fp32 values."""
+    from dreammat_amd import controlnet_train as ct
+    from dreammat_amd.sd import ARCHS, AutoencoderKLEncoder, UNet2DConditionModel
+    torch.manual_seed(0)
+    a = ARCHS["tiny"]
+    unet, vae = UNet2DConditionModel(a).bfloat16(), AutoencoderKLEncoder(a).bfloat16()
+    tr = ct.ControlNetTrainer(vae, unet, lr=1e-5)
+    assert tr.master is None                                    # built in fp32 ...
+    tr.controlnet.bfloat16()                                    # ... and cast by hand afterwards, as the round-3 tests did
+    g = torch.Generator().manual_seed(1)
+    img = (torch.rand(2, 3, 64, 64, generator=g) * 2 - 1).bfloat16()
+    cond = torch.rand(2, 22, 64, 64, generator=g)
+    text = torch.randn(2, 77, a.cross_dim, generator=g)
+    fixed = dict(timesteps=torch.tensor([300, 700]), noise=torch.randn(2, 4, 8, 8, generator=g),
+                 posterior_noise=torch.randn(2, 4, 8, 8, generator=g))
+    w0 = [p.detach().float().clone() for p in tr.controlnet.parameters()]
+    for _ in range(3):
+        tr.step(img, cond, text, **fixed)
+    assert tr.master is not None and all(m.dtype == torch.float32 for m in tr.master)
+    params = [p for p in tr.controlnet.parameters() if p.requires_grad]
+    assert all(p.dtype == torch.bfloat16 and torch.equal(p, m.bfloat16()) for p, m in zip(params, tr.master))
+    moved = sum(float((m - w).abs().sum()) for m, w in zip(tr.master, w0))
+    assert moved > 0                                            # updates of ~1e-5 survive in the masters ...
+    sd = tr.state_dict()
+    assert all(sd[k].dtype == torch.float32 for k, p in tr.controlnet.named_parameters() if p.requires_grad)
 
 
 def test_controlnet_render_dataset_reads_the_reference_tree(tmp_path):

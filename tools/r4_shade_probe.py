@@ -59,12 +59,102 @@ def load_r3():
     return L
 
 
+def case_section(a):
+    """replay of the bench's REAL in-step shade inputs (bench.py --dump-shade): what regime is the step in?"""
+    c = torch.load(a.case)
+    N = c["feat"].shape[0]
+    soa = lambda t: t.t().contiguous().to(dev)                  # [N,C] -> [C,N] storage
+    feat, nrm, view = soa(c["feat"].float()), soa(c["nrm"].float()), soa(c["view"].float())
+    pix, env_of_view = c["pix_idx"].to(dev), c["env_of_view"].to(dev)
+    n_dev = torch.tensor([N], dtype=torch.int32, device=dev)
+    spec, diff, fg = c["spec_packed"].to(dev), c["diff_packed"].to(dev), c["fg_lut"].to(dev)
+    pairs = penv.fg_pair_table(fg).contiguous()
+    st = _lib.EnvAtlasStruct()
+    f = c["atlas_fields"]
+    st.spec, st.diff, st.fg_lut, st.fg_pairs = spec.data_ptr(), diff.data_ptr(), fg.data_ptr(), pairs.data_ptr()
+    st.spec_env_stride, st.diff_env_stride = f["spec_env_stride"], f["diff_env_stride"]
+    for i in range(8):
+        st.mip_off[i], st.mip_res[i] = f["mip_off"][i], f["mip_res"][i]
+    st.n_mips, st.diff_res, st.lut_res = f["n_mips"], f["diff_res"], f["lut_res"]
+    st.min_rough_mip, st.max_rough_mip, st.texel_format = f["min_rough_mip"], f["max_rough_mip"], f["texel_format"]
+    mat = _lib.MatCfgStruct(*c["mat"])
+    rough = torch.sigmoid(feat[4]) * (c["mat"][3] - c["mat"][2]) + c["mat"][2]
+    n2 = st.n_mips - 2
+    level = torch.where(rough < 0.5, (rough.clamp(0.08, 0.5) - 0.08) / 0.42 * n2, (rough.clamp(0.5, 1.0) - 0.5) / 0.5 + n2)
+    l0 = level.floor().clamp(0, st.n_mips - 1).long()
+    w = l0.reshape(-1)[: N // 64 * 64].reshape(-1, 64)
+    stats = {"N": N, "feature_std_per_channel": [float(x) for x in feat.std(dim=1)], "roughness_mean": float(rough.mean()),
+             "roughness_std": float(rough.std()), "mip_l0_histogram": [int((l0 == k).sum()) for k in range(st.n_mips)],
+             "waves_with_mixed_l0_fraction": float((w.min(1).values != w.max(1).values).float().mean())}
+    print(json.dumps({"op": "bench_case_stats", **stats}), flush=True)
+    dcol = torch.randn(3, N, device=dev)
+    out = torch.zeros(3, N, device=dev); dfe = torch.zeros(5, N, device=dev)
+    HW, B = c["HW"], env_of_view.numel()
+    fns_f, fns_b = {}, {}
+    for libname, L, wg in (("r3", load_r3(), None), ("r4", _lib.lib(), "1"), ("r4", _lib.lib(), "2"), ("r4", _lib.lib(), "3"), ("r4", _lib.lib(), "4")):
+        if L is None:
+            continue
+        key = f"{libname}{'/wg' + wg if wg else ''}"
+
+        def fwd(L=L, wg=wg):
+            os.environ["DREAMMAT_SHADE_WGPCU"] = wg if wg else ""
+            if not wg:
+                os.environ.pop("DREAMMAT_SHADE_WGPCU", None)
+            _lib.check(L.dm_shade_fwd(ctypes.byref(st), ctypes.byref(mat), nrm.data_ptr(), 1, N, view.data_ptr(), 1, N, feat.data_ptr(), 1, N,
+                                      pix.data_ptr(), env_of_view.data_ptr(), n_dev.data_ptr(), N, HW, B, out.data_ptr(), 1, N,
+                                      None, None, None, None, None, None, None, hipops._stream()))
+
+        def bwd(L=L, wg=wg):
+            os.environ["DREAMMAT_SHADE_WGPCU"] = wg if wg else ""
+            if not wg:
+                os.environ.pop("DREAMMAT_SHADE_WGPCU", None)
+            _lib.check(L.dm_shade_bwd(ctypes.byref(st), ctypes.byref(mat), nrm.data_ptr(), 1, N, view.data_ptr(), 1, N, feat.data_ptr(), 1, N,
+                                      pix.data_ptr(), env_of_view.data_ptr(), n_dev.data_ptr(), N, HW, B, dcol.data_ptr(), 1, N,
+                                      dfe.data_ptr(), 1, N, hipops._stream()))
+        fns_f[key], fns_b[key] = fwd, bwd
+    tf, tb = ab(fns_f, a.rounds, a.iters), ab(fns_b, a.rounds, a.iters)
+    rows = []
+    for key in fns_f:
+        r = {"op": "shade_bench_case", "case": key, "N": N, "fwd_us": tf[key] * 1e6, "bwd_us": tb[key] * 1e6,
+             "fwd_frac_8TBs": 56.0 * N / tf[key] / 8e12, "bwd_frac_8TBs": 76.0 * N / tb[key] / 8e12}
+        rows.append(r)
+        print(json.dumps(r), flush=True)
+    # the same launches ONE AT A TIME (HIP events around a single launch, as bench.py's in-step timing does), hot (the previous
+    # launch left everything in L2 / MALL) and cold (512 MB written in between: L2 and the 256 MB MALL hold none of the inputs,
+    # the atlas or the LUT -- the state the kernel finds inside a real step, 80 ms and several GB of traffic after its last run)
+    flush = torch.empty(128 * 1024 * 1024, dtype=torch.float32, device=dev)
+
+    def single(fn, cold, n=12):
+        ts = []
+        for _ in range(n):
+            if cold:
+                flush.fill_(1.0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3)
+        return float(np.median(ts))
+    for key in fns_f:
+        r = {"op": "shade_bench_case_single_launch", "case": key, "fwd_hot_us": single(fns_f[key], False), "fwd_cold_us": single(fns_f[key], True),
+             "bwd_hot_us": single(fns_b[key], False), "bwd_cold_us": single(fns_b[key], True)}
+        rows.append(r)
+        print(json.dumps(r), flush=True)
+    os.environ.pop("DREAMMAT_SHADE_WGPCU", None)
+    with open(os.path.join(OUT, "r4_shade_bench_case.jsonl"), "w") as fh:
+        fh.write(json.dumps({"op": "bench_case_stats", **stats}) + "\n")
+        for r in rows:
+            fh.write(json.dumps(r) + "\n")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--case", default=None, help="a bench.py --dump-shade file: time the kernels on the step's real inputs only")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
+    if a.case:
+        return case_section(a)
     B, H, W = 8, 512, 512
     m = pmesh.displaced_sphere(160, 160)
     batch = util.make_views(B, H, W, seed=0)
