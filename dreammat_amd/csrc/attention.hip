@@ -559,14 +559,17 @@ int launch_attn_v3(const AttnArgs& a, hipStream_t stream) {
 }
 
 // Kernel families: "auto" (default: the dispatch below), or one family forced for A/B runs and the parity tests --
+//   "w128"   one wave per SIMD, 512 query rows per workgroup (attn_w128.hip, round 4): 64-wide heads, whole 64-row kv tiles,
+//            Sq a multiple of 512
 //   "w64"    one wave per SIMD, 256 query rows per workgroup (attn_w64.hip): 64-wide heads, whole 64-row kv tiles
 //   "v3l"    4 waves x 32 query rows, LDS-DMA ring (k_attn_fwd_v3): D <= 64 or 96 < D <= 128, any sequence lengths
 //   "staged" register-staged generic kernel (k_attn_fwd): any D <= 160 (the SD-1.5 heads of 40 / 80 / 160)
 // A forced family falls through to the next one when a shape is outside its domain.
-enum { kAttnAuto = 0, kAttnW64 = 1, kAttnV3l = 2, kAttnStaged = 3 };
+enum { kAttnAuto = 0, kAttnW128 = 1, kAttnW64 = 2, kAttnV3l = 3, kAttnStaged = 4 };
 static int g_attn_mode = -1;
 static int attn_mode_from_name(const char* e) {
     if (!e || !strcmp(e, "auto")) return kAttnAuto;
+    if (!strcmp(e, "w128")) return kAttnW128;
     if (!strcmp(e, "w64")) return kAttnW64;
     if (!strcmp(e, "v3l")) return kAttnV3l;
     if (!strcmp(e, "staged")) return kAttnStaged;
@@ -579,7 +582,7 @@ static int attn_mode() {
     }
     return g_attn_mode;
 }
-static const char* const kAttnNames[] = {"auto", "w64", "v3l", "staged"};
+static const char* const kAttnNames[] = {"auto", "w128", "w64", "v3l", "staged"};
 
 // the buffer-descriptor DMA addresses one (batch, head) operand with 32-bit byte offsets
 static bool attn_v3_ok(const AttnArgs& a) {
@@ -614,7 +617,7 @@ int launch_attn(const AttnArgs& a, hipStream_t stream) {
 
 extern "C" {
 
-// Selects the attention kernel family by name ("auto", "w64", "v3l", "staged"; NULL = DREAMMAT_ATTN_KERNEL / "auto") for
+// Selects the attention kernel family by name ("auto", "w128", "w64", "v3l", "staged"; NULL = DREAMMAT_ATTN_KERNEL / "auto") for
 // every later dm_attention_fwd_bf16 call of the process.  Returns DM_OK or DM_ERR_ARG for an unknown name.  Meant for
 // A/B measurements and for the parity tests, which run every family.
 int dm_attention_select(const char* name) {
@@ -657,6 +660,10 @@ static int attention_fwd(const void* q, const void* k, const void* vt, const voi
     // auto: the one-wave-per-SIMD kernel wherever a workgroup's 256 query rows are (nearly) filled and the sequence is long
     // enough to amortise its prologue (S >= 1024: 756 vs 738 TF/s at S = 1024, 1021 vs 980 at 4096, 981 vs 780 at batch 3;
     // v3l wins at S = 256: 375 vs 343, profiles/r03_probe_attn.json); cross-attention (77 keys) and short sequences: v3l
+    // auto: 128 rows per wave (attn_w128.hip) when the halved workgroup count still covers the chip at least once
+    if (mode <= kAttnW128 && attn_w128_ok(a) &&
+        (mode == kAttnW128 || (a.Skv >= 1024 && (long long)a.B * a.Hh * (a.Sq / 512) >= 256)))
+        return launch_attn_w128(a, stream);
     if (mode <= kAttnW64 && attn_w64_ok(a) && (mode == kAttnW64 ? a.Sq >= 128 : (a.Sq >= 1024 && a.Skv >= 1024)))
         return launch_attn_w64(a, stream);
     if (mode <= kAttnV3l && attn_v3_ok(a) && (D <= 64 || (D > 96 && D <= 128)))

@@ -28,5 +28,8 @@ struct AttnArgs {
 // attn_w64.hip: the one-wave-per-SIMD kernel (D = 64, Skv % 64 == 0)
 bool attn_w64_ok(const AttnArgs& a);
 int launch_attn_w64(const AttnArgs& a, hipStream_t stream);
+// attn_w128.hip: the same with 128 query rows per wave (D = 64, Skv % 64 == 0, Sq % 512 == 0)
+bool attn_w128_ok(const AttnArgs& a);
+int launch_attn_w128(const AttnArgs& a, hipStream_t stream);
 
 }  // namespace dm_attn

@@ -20,6 +20,7 @@ SOURCES = {
     # 127 v_accvgpr_read/write per KV tile
     "attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "attn_w64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    "attn_w128.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "attn_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "conv.hip": [],
     "conv_small.hip": [],

@@ -544,7 +544,7 @@ def material_smoothness(feat, featj, n_dev):
 
 # ------------------------------------------------------------------------------------------ attention
 def attention_select(name=None):
-    """Kernel family of every later attention() call: "auto" (default) | "w64" (one wave per SIMD; 64-wide heads, whole kv
+    """Kernel family of every later attention() call: "auto" (default) | "w128" (one wave per SIMD, 128 query rows per wave; 64-wide heads, Sq % 512 == 0) | "w64" (one wave per SIMD; 64-wide heads, whole kv
     tiles) | "v3l" | "staged"; None restores the DREAMMAT_ATTN_KERNEL / default choice (dm_attention_select)."""
     check(_lib.lib().dm_attention_select(name.encode() if name is not None else None), "dm_attention_select")
 

@@ -449,10 +449,13 @@ ATTN_CASES = [  # (B, heads, Sq, Skv, D)
     (2, 5, 1024, 77, 64), (2, 20, 256, 77, 64), (2, 8, 256, 256, 40), (1, 8, 192, 77, 80), (1, 8, 128, 128, 160),
     (1, 2, 100, 130, 128),
     # the one-wave-per-SIMD kernel (w64): ragged query blocks, fewer than 256 queries, odd / even tile counts, one tile
-    (1, 2, 320, 256, 64), (1, 3, 128, 192, 64), (2, 2, 256, 64, 64), (1, 1, 700, 128, 64)]
+    (1, 2, 320, 256, 64), (1, 3, 128, 192, 64), (2, 2, 256, 64, 64), (1, 1, 700, 128, 64),
+    # whole 512-row workgroups (the 128-rows-per-wave kernel's domain): 1 tile (prologue + last tile only), 3, 9 (one trip of
+    # the unrolled ring + remainder), 16 tiles
+    (1, 1, 512, 64, 64), (1, 2, 512, 192, 64), (2, 3, 512, 576, 64), (1, 2, 1024, 1024, 64)]
 
 
-ATTN_VARIANTS = ["auto", "w64", "v3l", "staged"]
+ATTN_VARIANTS = ["auto", "w128", "w64", "v3l", "staged"]
 
 
 @pytest.fixture
@@ -656,7 +659,7 @@ def test_attention_online_softmax_rescale_branch(dev, attn_variant):
     assert (out - ref).abs().max() < 3e-2
 
 
-@pytest.mark.parametrize("attn_variant", ["w64", "v3l"], indirect=True)
+@pytest.mark.parametrize("attn_variant", ["w128", "w64", "v3l"], indirect=True)
 def test_attention_lazy_shift_overflow_takes_the_exact_path(dev, attn_variant):
     """The w64 kernel keeps the row shift of the FIRST kv tile and re-bases lazily; a score that outgrows it by more than
     2^100 inside one tile cannot be represented and must send the workgroup through its exact (textbook online softmax) path.
@@ -677,7 +680,7 @@ def test_attention_lazy_shift_overflow_takes_the_exact_path(dev, attn_variant):
     assert (out[0, 37, :D] - vf[0, 0, 200]).abs().max() < 2e-2        # that row is its spiked key's value
 
 
-@pytest.mark.parametrize("attn_variant", ["w64", "v3l"], indirect=True)
+@pytest.mark.parametrize("attn_variant", ["w128", "w64", "v3l"], indirect=True)
 def test_attention_cfg5_sequence_16384_vs_chunked_fp32(dev, attn_variant):
     """BASELINE configs[4] (1024^2 renders -> 128^2 latents): S = 16384, 5 heads of 64 -- 256 kv tiles per row, the longest
     accumulation the kernels see.  Reference: fp32 softmax(QK^T)V on the bf16-rounded inputs, query chunks of 2048
