@@ -268,8 +268,14 @@ __device__ __forceinline__ int attn_swap23(int r) { return (r & ~12) | ((r & 4) 
 
 // VLATE: the V^T fragments are read inside the P.V loop (16 VGPRs at a time) instead of ahead of the softmax (32 VGPRs
 // across it): the difference between 2 and 3 resident waves per SIMD.
-template <int DP, bool VLATE>
-__global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a) {
+// KVRES (round 4): the cross-attention form.  The 77 prompt tokens of a (batch, head) are two kv tiles -- 32 KB of LDS --, and the
+// plain form spends more on them than on the scores: every 128-row workgroup zero-fills its ring, DMAs both tiles, and passes two
+// counted waits and barriers for 2 x 8 + 2 x 8 MFMAs per wave (46 us for 24 x 5 heads x 4096 rows: 2.7 TB/s of Q / O streaming).
+// Here a workgroup loads the (at most 3) kv tiles of its (batch, head) ONCE, keeps them in the three ring stages, and walks its
+// share of the query blocks with the next block's Q rows prefetched into registers: no DMA, wait or barrier inside the loop.
+// Grid = (batch x heads) x `kvres_groups` workgroups (launcher: enough to fill the chip 2-3 times).
+template <int DP, bool VLATE, bool KVRES = false>
+__global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a, int kvres_groups) {
 #if defined(__HIP_DEVICE_COMPILE__)   // __amdgpu_buffer_rsrc_t does not exist in the host pass (the stub needs no body)
     static_assert(DP == 64 || DP == 128, "power-of-two row sizes only");
     constexpr int KSTEPS = DP / 16, DT = DP / 32;
@@ -285,8 +291,9 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a) 
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bh, qb;
+    const int nq_all = (a.Sq + kWaves * kQRowsPerWave - 1) / (kWaves * kQRowsPerWave);
     {
-        const int nq = (a.Sq + kWaves * kQRowsPerWave - 1) / (kWaves * kQRowsPerWave);
+        const int nq = KVRES ? kvres_groups : nq_all;       // KVRES: `qb` is this workgroup's FIRST query block, stride kvres_groups
         const int BH = a.B * a.Hh, id = blockIdx.x;
         if ((BH & 7) == 0) {
             const int j = id >> 3;
@@ -298,8 +305,8 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a) 
         }
     }
     const int b = bh / a.Hh, h = bh - b * a.Hh;
-    const int q_row = qb * (kWaves * kQRowsPerWave) + wave * kQRowsPerWave + l31;
-    const bool q_ok = q_row < a.Sq;
+    int q_row = qb * (kWaves * kQRowsPerWave) + wave * kQRowsPerWave + l31;
+    bool q_ok = q_row < a.Sq;
     const int skv_pad8 = (a.Skv + 7) & ~7;
     const int n_tiles = (a.Skv + kKvTile - 1) / kKvTile;
     auto kswz = [](int r) { return KCH == 8 ? ((r >> 1) & 7) : (r & 15); };
@@ -312,25 +319,57 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a) 
     }
 
     bf16x8 qf[KSTEPS];
-    {
-        const __bf16* qp = a.q + (long long)b * a.q_bs + (long long)q_row * a.q_ss + (long long)h * a.q_hs;
+    uint4 qraw[KSTEPS];
+    // KVRES: whole 128-byte rows, 16 B per lane (8 lanes per row, 8 rows per instruction: 8 cache lines instead of the 32 a
+    // "one row per lane pair" access touches -- tools/gather_probe.cpp: 21 vs ~70 cycles of the CU's address unit per wave
+    // instruction; Q and O of a cross-attention are ALL its traffic), turned into / out of the MFMA fragment layout through a
+    // wave-private 4 KB of the ring's third stage (two kv tiles are resident: the launcher's contract).
+    char* const xw = smem + 2 * STAGE + wave * 4096;
+    auto q_load = [&](int row, bool ok) {                // raw rows of one query block (KVRES: requested a block ahead)
+        if constexpr (KVRES) {
+            const int row0 = row - l31;                  // the block's first row (row = first + l31 for this lane)
 #pragma unroll
-        for (int kk = 0; kk < KSTEPS; ++kk) {
-            int d = 16 * kk + 8 * hi;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (q_ok && d < a.D) v = ld16(qp + d);
-            qf[kk] = __builtin_bit_cast(bf16x8, v);
-            {
+            for (int i = 0; i < KSTEPS; ++i) {
+                const int r = row0 + 8 * i + (lane >> 3);
+                qraw[i] = make_uint4(0, 0, 0, 0);
+                if (ok && r < a.Sq)
+                    qraw[i] = ld16(a.q + (long long)b * a.q_bs + (long long)r * a.q_ss + (long long)h * a.q_hs + (lane & 7) * 8);
+            }
+        } else {
+            const __bf16* qp = a.q + (long long)b * a.q_bs + (long long)row * a.q_ss + (long long)h * a.q_hs;
 #pragma unroll
-                for (int e = 0; e < 8; e += 2) {
-                    f32x2 two = {(float)qf[kk][e] * a.scale_log2, (float)qf[kk][e + 1] * a.scale_log2};
-                    bf16x2 pk = __builtin_convertvector(two, bf16x2);
-                    qf[kk][e] = pk[0];
-                    qf[kk][e + 1] = pk[1];
-                }
+            for (int kk = 0; kk < KSTEPS; ++kk) {
+                const int d = 16 * kk + 8 * hi;
+                qraw[kk] = make_uint4(0, 0, 0, 0);
+                if (ok && d < a.D) qraw[kk] = ld16(qp + d);
             }
         }
-    }
+    };
+    auto q_scale = [&]() {                               // Q' = Q * scale * log2 e, rounded to bf16 once
+        if constexpr (KVRES) {                           // [row][chunk ^ (row & 7)] image -> fragment (row l31, chunk 2 kk + hi)
+#pragma unroll
+            for (int i = 0; i < KSTEPS; ++i) {
+                const int r = 8 * i + (lane >> 3);
+                *reinterpret_cast<uint4*>(xw + r * 128 + (((lane & 7) ^ (r & 7)) << 4)) = qraw[i];
+            }
+#pragma unroll
+            for (int kk = 0; kk < KSTEPS; ++kk)
+                qraw[kk] = *reinterpret_cast<const uint4*>(xw + l31 * 128 + (((2 * kk + hi) ^ (l31 & 7)) << 4));
+        }
+#pragma unroll
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+            qf[kk] = __builtin_bit_cast(bf16x8, qraw[kk]);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                f32x2 two = {(float)qf[kk][e] * a.scale_log2, (float)qf[kk][e + 1] * a.scale_log2};
+                bf16x2 pk = __builtin_convertvector(two, bf16x2);
+                qf[kk][e] = pk[0];
+                qf[kk][e + 1] = pk[1];
+            }
+        }
+    };
+    q_load(q_row, KVRES ? true : q_ok);                  // (KVRES checks every loaded row against Sq itself)
+    if (!KVRES) q_scale();
     // ---- DMA descriptors: one per operand, base = this (batch, head)
     const __bf16* kp = a.k + (long long)b * a.k_bs + (long long)h * a.k_hs;
     const __bf16* vp = a.vt + (long long)b * a.vt_bs + (long long)h * a.vt_hs;
@@ -488,11 +527,88 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a) 
         __builtin_amdgcn_s_setprio(0);
     };
 
+    f32x16 sA[2];
+    auto store_out = [&]() {
+        float l_tot = l_run + __shfl_xor(l_run, 32);
+        float inv = 1.0f / l_tot;
+        if constexpr (KVRES) {                           // (D == DP == 64: the launcher's contract)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x2 x0 = {o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv};
+                    f32x2 x1 = {o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
+                    bf16x2 y0 = __builtin_convertvector(x0, bf16x2), y1 = __builtin_convertvector(x1, bf16x2);
+                    bf16x4 y = {y0[0], y0[1], y1[0], y1[1]};
+                    // head_dim 32 dt + 8 g + 4 hi .. +3: 16 B chunk 4 dt + g (swizzled by the row), half hi
+                    *reinterpret_cast<bf16x4*>(xw + l31 * 128 + (((4 * dt + g) ^ (l31 & 7)) << 4) + 8 * hi) = y;
+                }
+            const int row0 = q_row - l31;
+            __bf16* op = a.out + (long long)b * a.o_bs + (long long)h * a.o_hs;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 8 * i + (lane >> 3);
+                const uint4 v = *reinterpret_cast<const uint4*>(xw + r * 128 + (((lane & 7) ^ (r & 7)) << 4));
+                if (row0 + r < a.Sq) *reinterpret_cast<uint4*>(op + (long long)(row0 + r) * a.o_ss + (lane & 7) * 8) = v;
+            }
+            return;
+        }
+        if (q_ok) {
+            __bf16* op = a.out + (long long)b * a.o_bs + (long long)q_row * a.o_ss + (long long)h * a.o_hs;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int d = 32 * dt + 8 * g + 4 * hi;
+                    if (d < a.D) {
+                        f32x2 x0 = {o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv};
+                        f32x2 x1 = {o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
+                        bf16x2 y0 = __builtin_convertvector(x0, bf16x2), y1 = __builtin_convertvector(x1, bf16x2);
+                        bf16x4 y = {y0[0], y0[1], y1[0], y1[1]};
+                        *reinterpret_cast<bf16x4*>(op + d) = y;
+                    }
+                }
+        }
+    };
+    if constexpr (KVRES) {
+        // every kv tile of this (batch, head) into its own stage, once (n_tiles <= 2 by the launcher's contract: the third
+        // stage is the waves' Q / O staging space)
+        for (int t = 0; t < n_tiles; ++t) {
+            if (t + 1 == n_tiles) issue(t, t, std::true_type{}); else issue(t, t, std::false_type{});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int blk = qb; blk < nq_all; blk += kvres_groups) {
+            q_scale();                                   // this block's rows (requested one block ago)
+            const int row_now = q_row;
+            const bool ok_now = q_ok;
+            {   // request the next block's rows; they land while this block computes
+                const int nrow = (blk + kvres_groups) * (kWaves * kQRowsPerWave) + wave * kQRowsPerWave + l31;
+                q_load(nrow, blk + kvres_groups < nq_all);
+                q_row = nrow; q_ok = blk + kvres_groups < nq_all && nrow < a.Sq;
+            }
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
+            m_run = 0.f; l_run = 0.f;
+            for (int t = 0; t < n_tiles; ++t) {
+                qk(t, sA);
+                softmax_pv(t, t, t == 0, sA, std::true_type{});
+            }
+            const int keep_row = q_row; const bool keep_ok = q_ok;
+            q_row = row_now; q_ok = ok_now;
+            store_out();
+            q_row = keep_row; q_ok = keep_ok;
+        }
+        return;
+    }
     // prologue: tiles 0 and 1 (the last tile of the sequence is always issued through the guarded form)
     if (n_tiles == 1) issue(0, 0, std::true_type{}); else issue(0, 0, std::false_type{});
     if (n_tiles == 2) issue(1, 1, std::true_type{}); else if (n_tiles > 2) issue(1, 1, std::false_type{});
     int stage = 0, j = 0;
-    f32x16 sA[2];
     {
         // main loop: tile j computes while tiles j+1, j+2 are in flight; every tile touched here is a full one
         for (; j + 3 < n_tiles; ++j) {
@@ -518,25 +634,7 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a) 
             stage = stage + 1; if (stage >= 3) stage = 0;
         }
     }
-
-    float l_tot = l_run + __shfl_xor(l_run, 32);
-    float inv = 1.0f / l_tot;
-    if (q_ok) {
-        __bf16* op = a.out + (long long)b * a.o_bs + (long long)q_row * a.o_ss + (long long)h * a.o_hs;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                int d = 32 * dt + 8 * g + 4 * hi;
-                if (d < a.D) {
-                    f32x2 x0 = {o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv};
-                    f32x2 x1 = {o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
-                    bf16x2 y0 = __builtin_convertvector(x0, bf16x2), y1 = __builtin_convertvector(x1, bf16x2);
-                    bf16x4 y = {y0[0], y0[1], y1[0], y1[1]};
-                    *reinterpret_cast<bf16x4*>(op + d) = y;
-                }
-            }
-    }
+    store_out();
 #endif
 }
 
@@ -545,15 +643,34 @@ int launch_attn_v3(const AttnArgs& a, hipStream_t stream) {
     constexpr int LDS = 3 * (kKvTile * DP * 2 + DP * kKvTile * 2);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_fwd_v3<DP, VLATE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_fwd_v3<DP, VLATE, false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    const long long n_blocks = (long long)dm_div_up(a.Sq, kWaves * kQRowsPerWave) * a.B * a.Hh;
+    const long long nq = dm_div_up(a.Sq, kWaves * kQRowsPerWave);
+    const long long n_blocks = nq * a.B * a.Hh;
     if (n_blocks > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
     DM_ENTER();
-    hipLaunchKernelGGL((k_attn_fwd_v3<DP, VLATE>), dim3((unsigned)n_blocks), dim3(256), LDS, stream, a);
+    // the kv-resident form (cross-attention: <= 3 kv tiles) when a (batch, head) has enough query blocks to amortise over:
+    // groups per (batch, head) so that the grid covers the chip ~2.5 times (2-3 workgroups are resident per CU)
+    static const bool kvres_off = getenv("DREAMMAT_ATTN_KVRES") && !strcmp(getenv("DREAMMAT_ATTN_KVRES"), "0");
+    if (!kvres_off && DP == 64 && a.D == 64 && a.Skv <= 2 * kKvTile && nq >= 4 && (a.o_ss & 7) == 0 && (a.o_hs & 7) == 0 && (a.o_bs & 7) == 0 &&
+        (((uintptr_t)a.out) & 15) == 0) {
+        const long long bh = (long long)a.B * a.Hh;
+        long long groups = std::max<long long>(1, std::min<long long>(nq / 2, (640 + bh - 1) / bh));
+        static bool attr2 = false;
+        if (!attr2) {
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_fwd_v3<DP, VLATE, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+            if (e2 != hipSuccess) return (int)e2;
+            attr2 = true;
+        }
+        hipLaunchKernelGGL((k_attn_fwd_v3<DP, VLATE, true>), dim3((unsigned)(bh * groups)), dim3(256), LDS, stream, a, (int)groups);
+        hipError_t e2 = hipGetLastError();
+        return e2 == hipSuccess ? DM_OK : (int)e2;
+    }
+    hipLaunchKernelGGL((k_attn_fwd_v3<DP, VLATE, false>), dim3((unsigned)n_blocks), dim3(256), LDS, stream, a, 0);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? DM_OK : (int)e;
 }

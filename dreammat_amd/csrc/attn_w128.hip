@@ -83,38 +83,6 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
     const int n_tiles = a.Skv / kTile;
     const int row0 = qblk * kRowsPerWg + wave * kRowsPerWave;          // first query row of this wave
 
-    // ---- Q' fragments (B operand of S^T = K.Q'^T): lane holds Q'[row0 + 32 qb + l31][16 kk + 8 hi .. +7]
-    bf16x8 qf[NQ][4];
-#pragma unroll
-    for (int qb = 0; qb < NQ; ++qb) {
-        const int row = min(row0 + 32 * qb + l31, a.Sq - 1);     // rows past the end duplicate the last one (never stored)
-        const __bf16* qp = a.q + (long long)b * a.q_bs + (long long)row * a.q_ss + (long long)h * a.q_hs;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            qf[qb][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qp + 16 * kk + 8 * hi));
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                f32x2 two = {(float)qf[qb][kk][e] * a.scale_log2, (float)qf[qb][kk][e + 1] * a.scale_log2};
-                bf16x2 pk = __builtin_convertvector(two, bf16x2);
-                qf[qb][kk][e] = pk[0];
-                qf[qb][kk][e + 1] = pk[1];
-            }
-        }
-    }
-
-    // Q' moves to the accumulator half ONCE, explicitly: every later use is an "a" operand of an asm MFMA.  (Left to the register
-    // allocator, a value with one VGPR-class use -- a builtin MFMA in the prologue -- stayed in VGPRs / scratch and was copied
-    // into AGPRs in front of every tile: 64 v_accvgpr_write + 1200 scratch accesses per tile at NQ = 4.)
-    bf16x8 qa[NQ][4];
-#pragma unroll
-    for (int qb = 0; qb < NQ; ++qb)
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            // (an empty statement whose output is tied to its input in class "a": the compiler emits the four v_accvgpr_write,
-            // with their hazards, and the value is an accumulator-file value from here on)
-            asm volatile("" : "=a"(qa[qb][kk]) : "0"(qf[qb][kk]));
-        }
-
     // ---- LDS-DMA: one descriptor per operand (base = this batch / head), per-lane offsets loop-invariant
     const __bf16* kp = a.k + (long long)b * a.k_bs + (long long)h * a.k_hs;
     const __bf16* vp = a.vt + (long long)b * a.vt_bs + (long long)h * a.vt_hs;
@@ -147,6 +115,42 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) issue_piece(tile, stage, i);
     };
+    // the first PD + 2 tiles are requested BEFORE the Q rows: the K / V^T stream and the (row-strided, latency-bound) Q loads
+    // of a fresh workgroup overlap instead of queueing (prologue 12.2 k cycles of a 197 k-cycle workgroup with Q first)
+#pragma unroll
+    for (int t = 0; t < PD + 2; ++t) issue(t, t);
+    // ---- Q' fragments (B operand of S^T = K.Q'^T): lane holds Q'[row0 + 32 qb + l31][16 kk + 8 hi .. +7]
+    bf16x8 qf[NQ][4];
+#pragma unroll
+    for (int qb = 0; qb < NQ; ++qb) {
+        const int row = min(row0 + 32 * qb + l31, a.Sq - 1);     // rows past the end duplicate the last one (never stored)
+        const __bf16* qp = a.q + (long long)b * a.q_bs + (long long)row * a.q_ss + (long long)h * a.q_hs;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            qf[qb][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qp + 16 * kk + 8 * hi));
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                f32x2 two = {(float)qf[qb][kk][e] * a.scale_log2, (float)qf[qb][kk][e + 1] * a.scale_log2};
+                bf16x2 pk = __builtin_convertvector(two, bf16x2);
+                qf[qb][kk][e] = pk[0];
+                qf[qb][kk][e + 1] = pk[1];
+            }
+        }
+    }
+
+    // Q' moves to the accumulator half ONCE, explicitly: every later use is an "a" operand of an asm MFMA.  (Left to the register
+    // allocator, a value with one VGPR-class use -- a builtin MFMA in the prologue -- stayed in VGPRs / scratch and was copied
+    // into AGPRs in front of every tile: 64 v_accvgpr_write + 1200 scratch accesses per tile at NQ = 4.)
+    bf16x8 qa[NQ][4];
+#pragma unroll
+    for (int qb = 0; qb < NQ; ++qb)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            // (an empty statement whose output is tied to its input in class "a": the compiler emits the four v_accvgpr_write,
+            // with their hazards, and the value is an accumulator-file value from here on)
+            asm volatile("" : "=a"(qa[qb][kk]) : "0"(qf[qb][kk]));
+        }
+
     // fragment addresses inside a stage: K (t, kk) at t*4096 + off4[kk], V^T (dt, ks) at 8192 + dt*4096 + off4[ks]
     int off4[4];
 #pragma unroll
@@ -220,8 +224,6 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
     auto settle_a = [](f32x16& d) { asm volatile("s_nop 15\n\ts_nop 3" : "+a"(d)); };
 
     // ---- prologue: tiles 0 .. PD+1 in flight; S'(0), first kv half, with the exact row maximum over those 32 keys as the shift
-#pragma unroll
-    for (int t = 0; t < PD + 2; ++t) issue(t, t);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * kL) : "memory");       // tiles 0 and 1 have landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();
 #pragma unroll

@@ -80,25 +80,6 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
     const int n_tiles = a.Skv / kTile;
     const int row0 = qblk * kRowsPerWg + wave * 64;          // first query row of this wave
 
-    // ---- Q' fragments (B operand of S^T = K.Q'^T): lane holds Q'[row0 + 32 qb + l31][16 kk + 8 hi .. +7]
-    bf16x8 qf[2][4];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        const int row = min(row0 + 32 * qb + l31, a.Sq - 1);     // rows past the end duplicate the last one (never stored)
-        const __bf16* qp = a.q + (long long)b * a.q_bs + (long long)row * a.q_ss + (long long)h * a.q_hs;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            qf[qb][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qp + 16 * kk + 8 * hi));
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                f32x2 two = {(float)qf[qb][kk][e] * a.scale_log2, (float)qf[qb][kk][e + 1] * a.scale_log2};
-                bf16x2 pk = __builtin_convertvector(two, bf16x2);
-                qf[qb][kk][e] = pk[0];
-                qf[qb][kk][e + 1] = pk[1];
-            }
-        }
-    }
-
     // ---- LDS-DMA: one descriptor per operand (base = this batch / head), per-lane offsets loop-invariant
     const __bf16* kp = a.k + (long long)b * a.k_bs + (long long)h * a.k_hs;
     const __bf16* vp = a.vt + (long long)b * a.vt_bs + (long long)h * a.vt_hs;
@@ -131,6 +112,29 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) issue_piece(tile, stage, i);
     };
+    // the first PD + 2 tiles are requested BEFORE the Q rows (round 4): the K / V^T stream and the row-strided, latency-bound Q
+    // loads of a fresh workgroup overlap instead of queueing
+#pragma unroll
+    for (int t = 0; t < PD + 2; ++t) issue(t, t);
+    // ---- Q' fragments (B operand of S^T = K.Q'^T): lane holds Q'[row0 + 32 qb + l31][16 kk + 8 hi .. +7]
+    bf16x8 qf[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int row = min(row0 + 32 * qb + l31, a.Sq - 1);     // rows past the end duplicate the last one (never stored)
+        const __bf16* qp = a.q + (long long)b * a.q_bs + (long long)row * a.q_ss + (long long)h * a.q_hs;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            qf[qb][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qp + 16 * kk + 8 * hi));
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                f32x2 two = {(float)qf[qb][kk][e] * a.scale_log2, (float)qf[qb][kk][e + 1] * a.scale_log2};
+                bf16x2 pk = __builtin_convertvector(two, bf16x2);
+                qf[qb][kk][e] = pk[0];
+                qf[qb][kk][e + 1] = pk[1];
+            }
+        }
+    }
+
     // fragment addresses inside a stage: K (t, kk) at t*4096 + off4[kk], V^T (dt, ks) at 8192 + dt*4096 + off4[ks]
     int off4[4];
 #pragma unroll
@@ -165,8 +169,6 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
     bool bad = false;
 
     // ---- prologue: tiles 0 .. PD+1 in flight; S'(0), first kv half, with the exact row maximum over those 32 keys as the shift
-#pragma unroll
-    for (int t = 0; t < PD + 2; ++t) issue(t, t);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PD * kL) : "memory");       // tiles 0 and 1 have landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();
 #pragma unroll

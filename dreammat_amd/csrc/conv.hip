@@ -940,6 +940,8 @@ int dm_conv3x3_nhwc_bf16_fused(const void* x, const void* w, const void* bias, c
             return launch_conv_dma<256, 128, 8, 4, 3>(a, stream);            // runtime refused the full-LDS variant
         }
         case 320: return launch_conv_dma<256, 320, 8, 4, 2>(a, stream);      // wave tile 64 x 160
+        case 5124: return launch_conv_dma<256, 256, 4, 2, 2>(a, stream);     // ONE wave per SIMD: wave tile 128 x 128 (round 4)
+        case 6404: return launch_conv_dma<512, 128, 4, 4, 2>(a, stream);     // ONE wave per SIMD: wave tile 128 x 128
         case 512: return launch_conv_dma<256, 256, 8, 2, 2>(a, stream);      // wave tile 128 x 64
         case 256: return launch_conv_dma<256, 128, 8, 4, 3>(a, stream);      // wave tile 64 x 64
         default:

@@ -35,6 +35,9 @@ CONV_BACKEND = "mfma"
 # to time the torch-autograd lowering the kernels replace (im2col + hipBLASLt, matmul-softmax, ATen GroupNorm); no
 # environment switch.
 TRAIN_KERNELS = True
+# V^T projections of the self-attention layers through the fused GEMM kernel with swapped operands (project_vt); tools may
+# assign False to time the hipBLASLt strided-batched product it replaces.
+VT_BY_FUSED_GEMM = os.environ.get("DREAMMAT_VT_GEMM", "fused") != "blas"
 
 
 class Conv2d(nn.Conv2d):
@@ -276,6 +279,14 @@ def project_vt(v_weight, v_bias, kv_src, kv_len):
         # and is transposed by a copy
         vt = linear_fused(kv_src, v_weight, v_bias).transpose(1, 2).contiguous()
         return vt if kv_len == Sk else _zero_tail(vt, kv_len)
+    if (VT_BY_FUSED_GEMM and v_bias is None and kv_len == Sk and kv_src.is_contiguous()
+            and _rows_kernel_ok(kv_src, v_weight) and hipops.gemm_fused_ok(C, kv_src.shape[2], Bk * Sk)):
+        # V^T straight from the hand-written GEMM with the operands swapped (round 4): Y[C, B S] = W_v . X_all^T -- the weight
+        # matrix plays the activations ([M = C, K]) and the token rows of ALL batch items play the weights ([N = B S, K]), so
+        # row c of Y is channel c of V for every token, i.e. batch item b's V^T is the column block [b S, (b + 1) S) with a
+        # row pitch of B S: exactly the strided [B, C, S] view the attention kernels take.  One launch per layer, no hipBLASLt.
+        y = hipops.gemm_fused(v_weight.detach().contiguous(), kv_src.view(Bk * Sk, kv_src.shape[2]), None, None)      # [C, B S]
+        return y.view(C, Bk, Sk).permute(1, 0, 2)
     vt = torch.matmul(v_weight, kv_src.transpose(1, 2))           # [B, C, Skv_pad]: V^T for free
     if v_bias is not None:
         vt = vt + v_bias[None, :, None]
