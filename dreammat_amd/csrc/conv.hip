@@ -940,8 +940,10 @@ int dm_conv3x3_nhwc_bf16_fused(const void* x, const void* w, const void* bias, c
             return launch_conv_dma<256, 128, 8, 4, 3>(a, stream);            // runtime refused the full-LDS variant
         }
         case 320: return launch_conv_dma<256, 320, 8, 4, 2>(a, stream);      // wave tile 64 x 160
-        case 5124: return launch_conv_dma<256, 256, 4, 2, 2>(a, stream);     // ONE wave per SIMD: wave tile 128 x 128 (round 4)
-        case 6404: return launch_conv_dma<512, 128, 4, 4, 2>(a, stream);     // ONE wave per SIMD: wave tile 128 x 128
+        // (round 4: the SAME K-step schedule instantiated with ONE wave per SIMD -- <256, 256, 4, 2, 2> / <512, 128, 4, 4, 2>, wave
+        // tile 128 x 128, 256 accumulator registers -- is 12-20 % SLOWER, 937 -> 816 and 785 -> 670 TF/s
+        // (profiles/r04_experiments/conv_one_wave_per_simd.txt): a lone wave stalls on every batch of 8 fragment reads that two
+        // waves hide for each other; one wave per SIMD needs its own hand-interleaved stream, as attn_w64.hip has)
         case 512: return launch_conv_dma<256, 256, 8, 2, 2>(a, stream);      // wave tile 128 x 64
         case 256: return launch_conv_dma<256, 128, 8, 4, 3>(a, stream);      // wave tile 64 x 64
         default:
