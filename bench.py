@@ -399,7 +399,7 @@ def main():
             if roof_key in kt_live:
                 res["roofline"]["launches_timed"] = kt_live[roof_key]["launches"]
         if attn:      # north_star target: >= 50 % MFMA
-            res["roofline_attention"] = mfma_entry("k_attn_fwd_w64 / k_attn_fwd_v3 (dispatch: " + hipops.attention_variant() + ")", attn)
+            res["roofline_attention"] = mfma_entry("k_attn_fwd_w128 / k_attn_fwd_w64 / k_attn_fwd_v3 (dispatch: " + hipops.attention_variant() + ")", attn)
             if "roofline" not in res:
                 res["roofline"] = res["roofline_attention"]
         if gemm:      # Linear / 1x1 layers + GEGLU on the 1-tap instantiation of the conv kernel
