@@ -16,7 +16,7 @@ if os.environ.get("DREAMMAT_LIB"):       # development aid (tools/grad_budget.py
     LIB_PATH = os.environ["DREAMMAT_LIB"]
 
 _lib = None
-ABI_VERSION = 9      # dm_abi_version() of the library this binding was written for (csrc/host.cpp, include/dreammat_hip.h)
+ABI_VERSION = 10     # dm_abi_version() of the library this binding was written for (csrc/host.cpp, include/dreammat_hip.h)
 
 DM_ERRORS = {-1: "DM_ERR_ARG", -2: "DM_ERR_WORKSPACE", -3: "DM_ERR_UNSUPPORTED"}
 
@@ -144,6 +144,8 @@ _SIGS = {
     "dm_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _LL, c_int, c_float, c_void_p]),
     "dm_geglu_bf16": (c_int, [c_void_p, c_void_p, _LL, c_int, c_void_p]),
     "dm_cat_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _LL, c_int, c_int, c_float, c_void_p]),
+    "dm_softmax_rows_bf16": (c_int, [c_void_p, c_void_p, _LL, c_int, c_float, c_void_p]),
+    "dm_softmax_rows_bwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, _LL, c_int, c_float, c_void_p]),
     "dm_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _LL, c_int, c_float, c_float, c_float, c_float,
                              c_float, c_int, c_void_p]),
 }

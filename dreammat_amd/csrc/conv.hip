@@ -940,10 +940,17 @@ int dm_conv3x3_nhwc_bf16_fused(const void* x, const void* w, const void* bias, c
             return launch_conv_dma<256, 128, 8, 4, 3>(a, stream);            // runtime refused the full-LDS variant
         }
         case 320: return launch_conv_dma<256, 320, 8, 4, 2>(a, stream);      // wave tile 64 x 160
-        // (round 4: the SAME K-step schedule instantiated with ONE wave per SIMD -- <256, 256, 4, 2, 2> / <512, 128, 4, 4, 2>, wave
-        // tile 128 x 128, 256 accumulator registers -- is 12-20 % SLOWER, 937 -> 816 and 785 -> 670 TF/s
-        // (profiles/r04_experiments/conv_one_wave_per_simd.txt): a lone wave stalls on every batch of 8 fragment reads that two
-        // waves hide for each other; one wave per SIMD needs its own hand-interleaved stream, as attn_w64.hip has)
+        // (round 4: ONE wave per SIMD -- <256, 256, 4, 2, 2> / <512, 128, 4, 4, 2>, wave tile 128 x 128, the 256 accumulators in
+        // the AGPR half -- is SLOWER twice over.  With the K-step schedule below as it is: 12-20 % (937 -> 816, 785 -> 670 TF/s,
+        // profiles/r04_experiments/conv_one_wave_per_simd.txt).  With every fragment read and DMA piece woven behind an MFMA
+        // (sched_group_barrier pipeline, branch-free pieces, accumulator reads pinned to their use so nothing spills: the patch
+        // and its numbers are profiles/r04_experiments/conv_one_wave_weave.*): still 6-7 % (971 -> 902, 808 -> 755 TF/s).  Its
+        // timeline says why: 3330 cycles of body per K-step for 2048 cycles of MFMA + 460 of DMA wait -- a wave is held ~60
+        // cycles per LDS-DMA instruction (four waves in lockstep ask the CU's one address unit at once; 80 KB per K-step is
+        // 1280 of its cycles whoever asks), and with one wave per SIMD nobody multiplies meanwhile.  The same weave applied to the
+        // two-wave kernels is 0-10 % slower than their burst order (conv_two_wave_weave_ab.txt).  What bounds this kernel is
+        // the address unit's 64 B/clk against 9 taps re-requesting the same activation rows; the lever left is a halo patch in
+        // LDS read at 9 shifted offsets (one DMA of the patch per 64-channel block), a different kernel.)
         case 512: return launch_conv_dma<256, 256, 8, 2, 2>(a, stream);      // wave tile 128 x 64
         case 256: return launch_conv_dma<256, 128, 8, 4, 3>(a, stream);      // wave tile 64 x 64
         default:

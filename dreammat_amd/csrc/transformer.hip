@@ -96,6 +96,83 @@ __global__ __launch_bounds__(256) void k_geglu(const __bf16* __restrict__ h, __b
 }
 
 
+// Row softmax of a score matrix that exists in memory (the VAE encoder's mid-block attention: one head of width 512 over
+// 4096 tokens, differentiated -- dreammat_guidance.py:284-292 -> diffusers AttnProcessor: baddbmm, softmax, bmm).  The ATen
+// sequence around the two matrix products was: scale (1 pass), bf16 -> fp32 copy, softmax, fp32 -> bf16 copy forward and
+// softmax backward, two copies and a scale backward, all over a [B, 4096, 4096] tensor: 1.5 ms of the step.  Here: one pass
+// each way, 16-byte accesses, fp32 arithmetic on bf16 storage.  One workgroup per row, NCH chunks of 8 columns per thread.
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+template <int NCH, bool BWD>
+__global__ __launch_bounds__(256) void k_softmax_rows(const __bf16* __restrict__ a, const __bf16* __restrict__ b, __bf16* __restrict__ y,
+                                                      long long rows, int cols, float scale) {
+    // forward:  a = scores s,         y = softmax(scale * s)
+    // backward: a = probabilities p,  b = dL/dp,  y = dL/ds = scale * p * (dp - sum_j p_j dp_j)
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunks = cols / 8;
+    constexpr float kLog2e = 1.4426950408889634f;
+    int it = 0;
+    for (long long r = blockIdx.x; r < rows; r += gridDim.x, ++it) {
+        const __bf16* ar = a + r * cols;
+        float v[NCH][8], w[NCH][8];
+        float m = -INFINITY, acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = tid + 256 * c;
+            const bool ok = ch < chunks;
+            const bf16x8 av = *reinterpret_cast<const bf16x8*>(ar + (ok ? ch : 0) * 8);
+            if (BWD) {
+                const bf16x8 bv = *reinterpret_cast<const bf16x8*>(b + r * cols + (ok ? ch : 0) * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v[c][k] = ok ? (float)av[k] : 0.f;
+                    w[c][k] = (float)bv[k];
+                    acc += v[c][k] * w[c][k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v[c][k] = ok ? (float)av[k] * (scale * kLog2e) : -INFINITY;
+                    m = fmaxf(m, v[c][k]);
+                }
+            }
+        }
+        float* rd = red[it & 1];              // (two slots: a fast wave may start the next row before a slow one has read)
+        if (!BWD) {
+            m = wave_max(m);
+            if (lane == 0) rd[wave] = m;
+            __syncthreads();
+            m = fmaxf(fmaxf(rd[0], rd[1]), fmaxf(rd[2], rd[3]));
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { v[c][k] = exp2f(v[c][k] - m); acc += v[c][k]; }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) rd[wave] = acc;
+        __syncthreads();
+        const float tot = (rd[0] + rd[1]) + (rd[2] + rd[3]);
+        const float inv = BWD ? 0.f : 1.f / tot;
+        __bf16* yr = y + r * cols;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = tid + 256 * c;
+            if (ch < chunks) {
+                bf16x8 o;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = (__bf16)(BWD ? scale * v[c][k] * (w[c][k] - tot) : v[c][k] * inv);
+                *reinterpret_cast<bf16x8*>(yr + ch * 8) = o;
+            }
+        }
+    }
+}
+
 // Skip connection of a UNet up block with the ControlNet residual folded in (diffusers UNet2DConditionModel.forward:
 // `down_block_res_samples = [s + r ...]` then `torch.cat([hidden, res_sample], dim=1)` in every up-block resnet):
 // y[row, 0:Cx] = x[row], y[row, Cx:Cx+Cs] = s[row] (+ r[row] * r_scale) -- one pass instead of an add pass and a cat pass.
@@ -159,6 +236,48 @@ int dm_geglu_bf16(const void* h, void* y, long long rows, int inner, hipStream_t
     const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 256 * 32);
     DM_ENTER();
     hipLaunchKernelGGL(k_geglu, dim3(grid), dim3(256), 0, stream, (const __bf16*)h, (__bf16*)y, rows, inner);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+// s, p [rows, cols] bf16 row-contiguous: p = softmax(scale * s) over the columns, fp32 arithmetic.  cols % 8 == 0, cols <= 8192.
+int dm_softmax_rows_bf16(const void* s, void* p, long long rows, int cols, float scale, hipStream_t stream) {
+    if (!s || !p || rows < 0 || cols <= 0) return DM_ERR_ARG;
+    if (cols % 8 != 0 || cols > 8192) return DM_ERR_UNSUPPORTED;
+    if (((uintptr_t)s | (uintptr_t)p) & 15) return DM_ERR_ARG;
+    if (rows == 0) return DM_OK;
+    const int nch = (cols / 8 + 255) / 256;
+    const unsigned grid = (unsigned)std::min<long long>(rows, 256 * 8);
+    DM_ENTER();
+#define DM_SM(N) hipLaunchKernelGGL((k_softmax_rows<N, false>), dim3(grid), dim3(256), 0, stream, (const __bf16*)s, \
+                                    (const __bf16*)nullptr, (__bf16*)p, rows, cols, scale)
+    switch (nch) {
+    case 1: DM_SM(1); break;
+    case 2: DM_SM(2); break;
+    default: DM_SM(4); break;
+    }
+#undef DM_SM
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+// Backward of the above: ds = scale * p * (dp - rowsum(p * dp)); p, dp, ds [rows, cols] bf16 (ds may alias dp).
+int dm_softmax_rows_bwd_bf16(const void* p, const void* dp, void* ds, long long rows, int cols, float scale, hipStream_t stream) {
+    if (!p || !dp || !ds || rows < 0 || cols <= 0) return DM_ERR_ARG;
+    if (cols % 8 != 0 || cols > 8192) return DM_ERR_UNSUPPORTED;
+    if (((uintptr_t)p | (uintptr_t)dp | (uintptr_t)ds) & 15) return DM_ERR_ARG;
+    if (rows == 0) return DM_OK;
+    const int nch = (cols / 8 + 255) / 256;
+    const unsigned grid = (unsigned)std::min<long long>(rows, 256 * 8);
+    DM_ENTER();
+#define DM_SM(N) hipLaunchKernelGGL((k_softmax_rows<N, true>), dim3(grid), dim3(256), 0, stream, (const __bf16*)p, \
+                                    (const __bf16*)dp, (__bf16*)ds, rows, cols, scale)
+    switch (nch) {
+    case 1: DM_SM(1); break;
+    case 2: DM_SM(2); break;
+    default: DM_SM(4); break;
+    }
+#undef DM_SM
     DM_LAUNCH_CHECK();
     return DM_OK;
 }

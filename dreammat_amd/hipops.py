@@ -765,6 +765,31 @@ def conv3x3_s1_autograd(x_nhwc, w_fwd, w_dgrad, bias, residual=None):
     return _Conv3x3S1.apply(x_nhwc, w_fwd, w_dgrad, bias, residual)
 
 
+class _ConvStemS1(torch.autograd.Function):
+    """stride-1, pad-1 3x3 conv of a FEW-channel image (Cin <= 4) with frozen weights, differentiable wrt the image: the VAE
+    encoder's conv_in under SDS (dreammat_guidance.py:284-292 -- the render is the leaf).  Forward = the direct stem kernel on the
+    image padded to 4 channels (the im2col + GEMM + bias-add lowering it replaces wrote a 9x copy of the image and took three
+    passes over the 128-channel output); backward = the adjoint of that lowering, g W folded back (27 columns: GEMM-library work)."""
+
+    @staticmethod
+    def forward(ctx, x_nhwc, w4, w_cols, bias):
+        B, H, W, Cin = x_nhwc.shape
+        x4 = torch.nn.functional.pad(x_nhwc, (0, 4 - Cin)) if Cin < 4 else x_nhwc.contiguous()
+        ctx.w_cols, ctx.cin = w_cols, Cin
+        return conv3x3_small_nhwc(x4, w4, bias, 1, (1, 1), 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W, Cout = g.shape
+        cols = torch.matmul(g.reshape(B, H * W, Cout), ctx.w_cols)                       # [B, HW, Cin*9], (ci, ky, kx) order
+        dx = torch.nn.functional.fold(cols.transpose(1, 2), (H, W), 3, padding=1)        # [B, Cin, H, W]
+        return dx.permute(0, 2, 3, 1), None, None, None
+
+
+def conv3x3_stem_autograd(x_nhwc, w4, w_cols, bias):
+    return _ConvStemS1.apply(x_nhwc, w4, w_cols, bias)
+
+
 class _Conv3x3S2(torch.autograd.Function):
     """stride-2 3x3 conv with leading pad p (0: AutoencoderKL's F.pad(0,1,0,1) downsampler; 1: UNet's) and frozen
     weights.  Backward = transposed conv, computed by the SAME stride-1 kernel on the zero-inserted gradient
@@ -1128,6 +1153,47 @@ def layernorm_rows(x, gamma, beta, eps):
         check(_lib.lib().dm_layernorm_bf16(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), rows, C,
                                            float(eps), _stream()), "dm_layernorm_bf16")
     return y
+
+
+class _SoftmaxRows(torch.autograd.Function):
+    """p = softmax(scale * s) over the last dim of a bf16 score tensor, fp32 arithmetic, with its backward (the differentiated
+    VAE mid-block attention, sd/models.py VaeAttention; dm_softmax_rows_bf16 / dm_softmax_rows_bwd_bf16)."""
+
+    @staticmethod
+    def forward(ctx, s, scale):
+        s = s.contiguous()
+        cols = s.shape[-1]
+        rows = s.numel() // cols
+        p = torch.empty_like(s)
+        with _Timed(f"softmax_rows[{cols}]", 4.0 * rows * cols):
+            check(_lib.lib().dm_softmax_rows_bf16(s.data_ptr(), p.data_ptr(), rows, cols, float(scale), _stream()),
+                  "dm_softmax_rows_bf16")
+        ctx.save_for_backward(p)
+        ctx.scale = float(scale)
+        return p
+
+    @staticmethod
+    def backward(ctx, dp):
+        (p,) = ctx.saved_tensors
+        dp = dp.contiguous()
+        cols = p.shape[-1]
+        rows = p.numel() // cols
+        ds = torch.empty_like(p)
+        with _Timed(f"softmax_rows_bwd[{cols}]", 6.0 * rows * cols):
+            check(_lib.lib().dm_softmax_rows_bwd_bf16(p.data_ptr(), dp.data_ptr(), ds.data_ptr(), rows, cols, ctx.scale, _stream()),
+                  "dm_softmax_rows_bwd_bf16")
+        return ds, None
+
+
+def softmax_rows_ok(s):
+    return s.is_cuda and s.dtype == torch.bfloat16 and s.shape[-1] % 8 == 0 and s.shape[-1] <= 8192
+
+
+def softmax_rows(s, scale):
+    """softmax(scale * s, dim=-1) of a bf16 tensor in one pass each way (differentiable)."""
+    _need_cuda(s)
+    assert softmax_rows_ok(s)
+    return _SoftmaxRows.apply(s, scale)
 
 
 def geglu_rows(h):

@@ -147,6 +147,20 @@ class Conv2d(nn.Conv2d):
             y = hipops.conv3x3_nhwc(xn, w_fwd, self._bias_p, 2, (0, 0), (H // 2, W // 2))
         return y.permute(0, 3, 1, 2)
 
+    def _stem_prepared(self):
+        """weights of a <= 4-channel stem layer for the direct kernel (input padded to 4 channels) and for its backward."""
+        w = self.weight
+        key = (w.data_ptr(), w._version, w.dtype)
+        if getattr(self, "_stem_key", None) != key:
+            Cout, Cin = w.shape[:2]
+            wd = w.detach()
+            w4 = wd.new_zeros(Cout, 3, 3, 4)
+            w4[..., :Cin] = wd.permute(0, 2, 3, 1)
+            self._w_stem4 = w4.reshape(Cout, 36).contiguous()
+            self._w_stem_cols = wd.reshape(Cout, Cin * 9).contiguous()
+            self._stem_key = key
+        return self._w_stem4, self._w_stem_cols
+
     def forward(self, x):
         if CONV_BACKEND == "miopen" or not x.is_cuda:
             return super().forward(x)
@@ -154,6 +168,12 @@ class Conv2d(nn.Conv2d):
         needs_grad = torch.is_grad_enabled() and x.requires_grad
         if self.small_ok(x):
             return self.forward_small(x, 0)
+        if (needs_grad and CONV_BACKEND == "mfma" and x.dtype == torch.bfloat16 and kh == 3 and kw == 3 and Cin <= 4
+                and Cout % 16 == 0 and self.stride == (1, 1) and self.padding == (1, 1) and self._frozen()):
+            # the VAE encoder's conv_in on the rendered image (the only few-channel layer that needs a gradient)
+            w4, w_cols = self._stem_prepared()
+            bias = self.bias.detach() if self.bias is not None else None
+            return hipops.conv3x3_stem_autograd(x.permute(0, 2, 3, 1), w4, w_cols, bias).permute(0, 3, 1, 2)
         # zero-padded to whole 64-wide tiles (_prepared): always for the LDS-DMA kernel's shapes, and for the register-staged
         # kernel (Cin % 64 != 0) when nothing needs a gradient
         narrow = Cout % 64 != 0 and (Cin % 64 == 0 or (Cin % 32 == 0 and not needs_grad))

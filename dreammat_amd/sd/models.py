@@ -275,8 +275,13 @@ class VaeAttention(nn.Module):
         B, C, H, W = x.shape
         h = group_norm_act(self.group_norm, x, False).permute(0, 2, 3, 1).reshape(B, H * W, C)
         q, k, v = self.to_q(h), self.to_k(h), self.to_v(h)
-        s = torch.matmul(q, k.transpose(1, 2)) * (C ** -0.5)
-        p = torch.softmax(s.float(), dim=-1).to(q.dtype)
+        from .. import hipops
+        from . import layers
+        s = torch.matmul(q, k.transpose(1, 2))
+        if hipops.softmax_rows_ok(s) and layers.CONV_BACKEND == "mfma":
+            p = hipops.softmax_rows(s, C ** -0.5)       # scale, fp32 softmax and the rounding in one pass (and one pass back)
+        else:
+            p = torch.softmax((s * (C ** -0.5)).float(), dim=-1).to(q.dtype)
         o = self.to_out[0](torch.matmul(p, v))
         return o.reshape(B, H, W, C).permute(0, 3, 1, 2) + x
 

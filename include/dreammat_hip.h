@@ -379,6 +379,14 @@ int dm_geglu_bf16(const void* h, void* y, long long rows, int inner, dm_stream_t
 int dm_cat_add_bf16(const void* x, const void* s, const void* r, void* y, long long rows, int Cx, int Cs, float r_scale,
                     dm_stream_t stream);
 
+/* Row softmax over a materialised score matrix, forward and backward (ABI v10): the VAE encoder's mid-block attention (one
+ * head of width 512, differentiated: dreammat_guidance.py:284-292 -> diffusers' Attention in AutoencoderKL's mid block) keeps
+ * its two matrix products on the GEMM library and replaces the scale / cast / softmax / cast chain between them.
+ * fwd: p = softmax(scale * s) per row; bwd: ds = scale * p * (dp - rowsum(p * dp)).  [rows, cols] bf16 row-contiguous, fp32
+ * arithmetic, cols % 8 == 0, cols <= 8192; ds may alias dp. */
+int dm_softmax_rows_bf16(const void* s, void* p, long long rows, int cols, float scale, dm_stream_t stream);
+int dm_softmax_rows_bwd_bf16(const void* p, const void* dp, void* ds, long long rows, int cols, float scale, dm_stream_t stream);
+
 /* ---- optimiser ---------------------------------------------------------------------------- */
 /* torch.optim.Adam step (configs/dreammat.yaml:110-115 via systems/utils.py:34-53) over one flat
  * fp32 buffer; grad is multiplied by grad_scale first (1/world after a sum all-reduce) and

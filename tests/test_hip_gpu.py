@@ -1178,6 +1178,56 @@ def test_layernorm_rows_vs_torch(dev, rows, C):
     assert (y - ref_bf).abs().max() <= 1.6e-2 * ref.abs().max()
 
 
+def test_conv_stem_with_image_gradient_vs_torch(dev):
+    """the VAE encoder's conv_in (3 -> 128) when the image needs a gradient: direct stem kernel forward, folded g W backward."""
+    from dreammat_amd.sd import layers
+    torch.manual_seed(0)
+    conv = layers.Conv2d(3, 128, 3, padding=1)
+    ref = torch.nn.Conv2d(3, 128, 3, padding=1)
+    ref.load_state_dict(conv.state_dict())
+    ref.weight.data = ref.weight.data.bfloat16().float(); ref.bias.data = ref.bias.data.bfloat16().float()
+    conv = conv.to(dev).bfloat16().requires_grad_(False)
+    x = torch.randn(2, 40, 56, 3).bfloat16()
+    xg = x.to(dev).permute(0, 3, 1, 2).requires_grad_(True)              # logical NCHW over NHWC memory, like the render
+    hipops.enable_kernel_timing(True)
+    y = conv(xg)
+    torch.cuda.synchronize()
+    keys = hipops.kernel_times().keys()
+    hipops.enable_kernel_timing(False)
+    assert any(k.startswith("conv3x3_small[4->128") for k in keys), keys
+    g = torch.randn(2, 128, 40, 56).bfloat16()
+    y.backward(g.to(dev))
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = ref(xr)
+    yr.backward(g.float())
+    assert (y.float().cpu() - yr).abs().max() <= 1e-2 * yr.abs().max()
+    assert (xg.grad.float().cpu() - xr.grad).abs().max() <= 2e-2 * xr.grad.abs().max()
+
+
+@pytest.mark.parametrize("shape", [(2, 512, 4096), (3, 77, 2048), (1, 5, 8), (700, 264), (2, 9, 8192)])
+def test_softmax_rows_fwd_bwd_vs_torch(dev, shape):
+    """dm_softmax_rows_bf16 / _bwd (the VAE mid-block attention's softmax, differentiated) against fp32 autograd of
+    softmax(scale * s); more than one row per workgroup at the larger shapes (the grid is capped at 2048 workgroups)."""
+    torch.manual_seed(0)
+    scale = 512 ** -0.5
+    s = (torch.randn(*shape) * 30).bfloat16()
+    dp = torch.randn(*shape).bfloat16()
+    sg = s.to(dev).requires_grad_(True)
+    p = hipops.softmax_rows(sg, scale)
+    p.backward(dp.to(dev))
+    sr = s.float().requires_grad_(True)
+    pr = torch.softmax(sr * scale, dim=-1)
+    pr.backward(dp.float())
+    assert (p.float().cpu() - pr).abs().max() <= 2 ** -8 * pr.abs().max() + 1e-6            # one bf16 rounding
+    assert abs(p.float().sum(-1).mean().item() - 1.0) < 2e-3
+    # the backward works from the ROUNDED probabilities (what the second matrix product saw): compare on those too
+    pq = p.detach().float().cpu()
+    ds_ref_q = scale * pq * (dp.float() - (pq * dp.float()).sum(-1, keepdim=True))
+    ds = sg.grad.float().cpu()
+    assert (ds - ds_ref_q).abs().max() <= 2 ** -7 * ds_ref_q.abs().max() + 1e-7
+    assert (ds - sr.grad).abs().max() <= 2e-2 * sr.grad.abs().max() + 1e-7
+
+
 @pytest.mark.parametrize("rows,inner", [(4096, 1280), (77, 2560), (3, 8)])
 def test_geglu_rows_vs_torch(dev, rows, inner):
     torch.manual_seed(0)

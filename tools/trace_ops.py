@@ -9,9 +9,9 @@ from dreammat_amd.data import RandomCameraDataModule
 from dreammat_amd.system import Trainer, to_device
 from torch.profiler import profile, ProfilerActivity
 
-a = bench.parse() if len(sys.argv) > 1 else None
-import argparse
-a = argparse.Namespace(gpus=1, steps=1, warmup=2, views=8, res=512, sd="sd21-base", mesh="sphere:160:160", env_res=128)
+_argv, sys.argv = sys.argv, sys.argv[:1]
+a = bench.parse()                      # the bench defaults: BASELINE configs[2]
+sys.argv = _argv
 dev = torch.device("cuda:0")
 torch.cuda.set_device(0)
 dreammat_amd._import_plugins()
