@@ -139,6 +139,7 @@ _SIGS = {
                                         c_int, c_void_p]),
     "dm_groupnorm_nhwc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                       c_float, c_int, c_void_p]),
+    "dm_groupnorm_nhwc_bwd_res": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dm_groupnorm_affine_rows": (c_int, [c_int, c_int, c_int]),
     "dm_groupnorm_nhwc_bwd_affine": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_float, c_int, c_void_p]),
     "dm_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _LL, c_int, c_float, c_void_p]),

@@ -22,6 +22,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 //              5 rstd*mean_g(dxhat)   6 rstd*mean_g(dxhat*xhat)
 struct GnArgs {
     const __bf16* x; const __bf16* gamma; const __bf16* beta; const __bf16* dy;
+    const __bf16* dres;   // backward only, may be NULL: a second gradient of x (the skip branch of a ResnetBlock2D), added into dx
     __bf16* y;            // forward output / backward dx
     float* part; float* bpart; float* coef;
     float* cpart;         // MODE 2 of k_gn_stats: per-(b, workgroup) channel sums [B*nblk][2][C] (dbeta, dgamma partials)
@@ -207,6 +208,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnArgs a) {
     }
     const __bf16* __restrict__ xb = a.x + (long long)b * a.HW * C;
     const __bf16* __restrict__ dyb = MODE ? a.dy + (long long)b * a.HW * C : nullptr;
+    const __bf16* __restrict__ drb = (MODE && a.dres) ? a.dres + (long long)b * a.HW * C : nullptr;
     __bf16* __restrict__ yb = a.y + (long long)b * a.HW * C;
     const float* co = a.coef + (long long)b * 7 * C;
     const int lanes_per_row = min(chunks, 256);
@@ -246,13 +248,15 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnArgs a) {
                 }
             } else {
                 bf16x8 d = *reinterpret_cast<const bf16x8*>(dyb + r * C + ch * 8);
+                bf16x8 e = {};
+                if (drb) e = *reinterpret_cast<const bf16x8*>(drb + r * C + ch * 8);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     float xf = (float)v[k];
                     float xh = xf * rs[k] - mrs[k];
                     float dz = (float)d[k];
                     if (a.act) dz *= silu_grad(xf * A[k] + S[k]);
-                    o[k] = (__bf16)(rs[k] * (dz * gm[k]) - c1[k] - c2[k] * xh);
+                    o[k] = (__bf16)(rs[k] * (dz * gm[k]) - c1[k] - c2[k] * xh + (float)e[k]);
                 }
             }
             *reinterpret_cast<bf16x8*>(yb + r * C + ch * 8) = o;
@@ -329,11 +333,14 @@ int dm_groupnorm_nhwc_infer(const void* x, const void* gamma, const void* beta, 
 }
 
 // dx from dy; ws = the workspace left by the matching dm_groupnorm_nhwc_fwd call (statistics + coefficients).
-int dm_groupnorm_nhwc_bwd(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* ws,
-                          int B, int HW, int C, float eps, int act, hipStream_t stream) {
+// dres (may be NULL, [B,HW,C] bf16): dx = GroupNorm^T(dy) + dres in the same pass, one rounding -- x of a ResnetBlock2D feeds
+// norm1 AND the skip connection, and the sum of its two gradients was an ATen add pass per block of the VAE encoder's backward.
+int dm_groupnorm_nhwc_bwd_res(const void* x, const void* gamma, const void* beta, const void* dy, const void* dres, void* dx,
+                              float* ws, int B, int HW, int C, float eps, int act, hipStream_t stream) {
     if (!x || !gamma || !beta || !dy || !dx || !ws || !check_args(B, HW, C)) return DM_ERR_ARG;
     GnArgs a = {};
     a.x = (const __bf16*)x; a.gamma = (const __bf16*)gamma; a.beta = (const __bf16*)beta; a.dy = (const __bf16*)dy;
+    a.dres = (const __bf16*)dres;
     a.y = (__bf16*)dx;
     bind_ws(a, ws, B, C);
     a.B = B; a.HW = HW; a.C = C; a.act = act; a.eps = eps;
@@ -346,6 +353,11 @@ int dm_groupnorm_nhwc_bwd(const void* x, const void* gamma, const void* beta, co
     hipLaunchKernelGGL(k_gn_apply<1>, g, dim3(256), 0, stream, a);
     DM_LAUNCH_CHECK();
     return DM_OK;
+}
+
+int dm_groupnorm_nhwc_bwd(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* ws,
+                          int B, int HW, int C, float eps, int act, hipStream_t stream) {
+    return dm_groupnorm_nhwc_bwd_res(x, gamma, beta, dy, nullptr, dx, ws, B, HW, C, eps, act, stream);
 }
 
 // dbeta / dgamma partials of a GroupNorm with TRAINABLE affine parameters (the ControlNet copy in the training loop), after

@@ -905,22 +905,32 @@ def _gn_fwd(x_nhwc, gamma, beta, eps, act, keep_for_backward=True):
 
 
 class _GroupNormAct(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x_nhwc, gamma, beta, eps, act):
-        y, ws = _gn_fwd(x_nhwc, gamma, beta, eps, act)
-        ctx.save_for_backward(x_nhwc, gamma, beta, ws)
-        ctx.eps, ctx.act = eps, act
-        return y
+    """act(GroupNorm32(x)); with_skip: also hands x back as a second output, so that a caller that uses x twice (norm1 and the
+    skip connection of a ResnetBlock2D) receives BOTH gradients here and the backward kernel adds them in its own pass instead
+    of autograd in a separate one."""
 
     @staticmethod
-    def backward(ctx, g):
+    def forward(ctx, x_nhwc, gamma, beta, eps, act, with_skip=False):
+        y, ws = _gn_fwd(x_nhwc, gamma, beta, eps, act)
+        ctx.save_for_backward(x_nhwc, gamma, beta, ws)
+        ctx.eps, ctx.act, ctx.with_skip = eps, act, with_skip
+        ctx.set_materialize_grads(False)       # an unused output's gradient arrives as None, not as a tensor of zeros
+        return (y, x_nhwc.view_as(x_nhwc)) if with_skip else y
+
+    @staticmethod
+    def backward(ctx, g, g_skip=None):
         x, gamma, beta, ws = ctx.saved_tensors
         B, H, W, C = x.shape
+        if g is None:                          # only the skip branch reached the loss
+            return g_skip, None, None, None, None, None
         g = g.contiguous()
+        if g_skip is not None:
+            g_skip = g_skip.contiguous()
         dx = torch.empty_like(x)
-        check(_lib.lib().dm_groupnorm_nhwc_bwd(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), g.data_ptr(),
-                                               dx.data_ptr(), ws.data_ptr(), B, H * W, C, float(ctx.eps), int(ctx.act),
-                                               _stream()), "dm_groupnorm_nhwc_bwd")
+        check(_lib.lib().dm_groupnorm_nhwc_bwd_res(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), g.data_ptr(),
+                                                   g_skip.data_ptr() if g_skip is not None else None,
+                                                   dx.data_ptr(), ws.data_ptr(), B, H * W, C, float(ctx.eps), int(ctx.act),
+                                                   _stream()), "dm_groupnorm_nhwc_bwd_res")
         dgamma = dbeta = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             # trainable affine parameters (ControlNet training): per-workgroup channel sums of dz and dz * xhat, added here
@@ -931,7 +941,7 @@ class _GroupNormAct(torch.autograd.Function):
                                                           int(ctx.act), _stream()), "dm_groupnorm_nhwc_bwd_affine")
             sums = cpart.sum(0)
             dbeta, dgamma = sums[0].to(beta.dtype), sums[1].to(gamma.dtype)
-        return dx, dgamma, dbeta, None, None
+        return dx, dgamma, dbeta, None, None, None
 
 
 def groupnorm_nhwc(x_nhwc, gamma, beta, eps, act):
@@ -941,6 +951,13 @@ def groupnorm_nhwc(x_nhwc, gamma, beta, eps, act):
     if torch.is_grad_enabled() and (x_nhwc.requires_grad or gamma.requires_grad or beta.requires_grad):
         return _GroupNormAct.apply(x_nhwc, gamma, beta, eps, act)
     return _gn_fwd(x_nhwc, gamma, beta, eps, act, keep_for_backward=False)[0]
+
+
+def groupnorm_nhwc_skip(x_nhwc, gamma, beta, eps, act):
+    """(act(GroupNorm32(x)), x): the second output IS x, routed through the same autograd node (see _GroupNormAct)."""
+    _need_cuda(x_nhwc, gamma, beta)
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous() and gamma.dtype == torch.bfloat16
+    return _GroupNormAct.apply(x_nhwc, gamma, beta, eps, act, True)
 
 
 # ------------------------------------------------------------------------------------------ ray queries (row f-1)

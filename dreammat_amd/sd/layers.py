@@ -202,12 +202,16 @@ class Conv2d(nn.Conv2d):
         return y.permute(0, 3, 1, 2)
 
 
+def _gn_kernel_ok(norm: nn.GroupNorm, x):
+    return (x.is_cuda and x.dtype == torch.bfloat16 and norm.num_groups == 32 and CONV_BACKEND == "mfma"
+            and norm.weight.dtype == torch.bfloat16
+            and (TRAIN_KERNELS or not (torch.is_grad_enabled() and norm.weight.requires_grad)))
+
+
 def group_norm_act(norm: nn.GroupNorm, x, silu: bool):
     """act(GroupNorm(x)) for a logical-NCHW tensor.  GPU bf16 (32 groups) -> fused NHWC HIP kernel (the
     activation stays channels-last, which is what the implicit-GEMM conv consumes); otherwise torch."""
-    if (x.is_cuda and x.dtype == torch.bfloat16 and norm.num_groups == 32 and CONV_BACKEND == "mfma"
-            and norm.weight.dtype == torch.bfloat16
-            and (TRAIN_KERNELS or not (torch.is_grad_enabled() and norm.weight.requires_grad))):
+    if _gn_kernel_ok(norm, x):
         xn = x.permute(0, 2, 3, 1).contiguous()                  # no-op for channels-last activations
         y = hipops.groupnorm_nhwc(xn, norm.weight, norm.bias, norm.eps, 1 if silu else 0)
         return y.permute(0, 3, 1, 2)
@@ -471,7 +475,13 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = Conv2d(in_ch, out_ch, 1) if in_ch != out_ch else None
 
     def forward(self, x, temb=None):
-        h = group_norm_act(self.norm1, x, True)
+        if torch.is_grad_enabled() and x.requires_grad and _gn_kernel_ok(self.norm1, x) and not self.norm1.weight.requires_grad:
+            # differentiated (VAE encoder) and x feeds norm1 AND the skip (directly or through conv_shortcut): both gradients meet
+            # in the GroupNorm backward kernel
+            h, x = hipops.groupnorm_nhwc_skip(x.permute(0, 2, 3, 1).contiguous(), self.norm1.weight, self.norm1.bias, self.norm1.eps, 1)
+            h, x = h.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2)
+        else:
+            h = group_norm_act(self.norm1, x, True)
         tproj = self.time_emb_proj(F.silu(temb)) if self.time_emb_proj is not None else None
         if self.conv1.fused_ok(h) and self.conv2.fused_ok(h):
             # inference path (diffusion nets in SDS): both adds ride in the conv epilogues

@@ -273,10 +273,17 @@ class VaeAttention(nn.Module):
 
     def forward(self, x):
         B, C, H, W = x.shape
-        h = group_norm_act(self.group_norm, x, False).permute(0, 2, 3, 1).reshape(B, H * W, C)
-        q, k, v = self.to_q(h), self.to_k(h), self.to_v(h)
-        from .. import hipops
         from . import layers
+        from .. import hipops
+        if torch.is_grad_enabled() and x.requires_grad and layers._gn_kernel_ok(self.group_norm, x):
+            # x feeds the norm and the residual: both gradients meet in the GroupNorm backward kernel (see ResnetBlock2D)
+            h, x = hipops.groupnorm_nhwc_skip(x.permute(0, 2, 3, 1).contiguous(), self.group_norm.weight, self.group_norm.bias,
+                                              self.group_norm.eps, 0)
+            x = x.permute(0, 3, 1, 2)
+            h = h.reshape(B, H * W, C)
+        else:
+            h = group_norm_act(self.group_norm, x, False).permute(0, 2, 3, 1).reshape(B, H * W, C)
+        q, k, v = self.to_q(h), self.to_k(h), self.to_v(h)
         s = torch.matmul(q, k.transpose(1, 2))
         if hipops.softmax_rows_ok(s) and layers.CONV_BACKEND == "mfma":
             p = hipops.softmax_rows(s, C ** -0.5)       # scale, fp32 softmax and the rounding in one pass (and one pass back)

@@ -359,6 +359,11 @@ int dm_groupnorm_nhwc_fwd(const void* x, const void* gamma, const void* beta, vo
                           int C, float eps, int act, dm_stream_t stream);
 int dm_groupnorm_nhwc_bwd(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* ws,
                           int B, int HW, int C, float eps, int act, dm_stream_t stream);
+/* the same with a second gradient of x added in the pass (ABI v10; dres [B,HW,C] bf16 or NULL): x of a ResnetBlock2D feeds norm1
+ * and the skip connection -- diffusers ResnetBlock2D.forward `output = input_tensor + hidden_states` under AutoencoderKL's
+ * encoder, differentiated at dreammat_guidance.py:284-292. */
+int dm_groupnorm_nhwc_bwd_res(const void* x, const void* gamma, const void* beta, const void* dy, const void* dres, void* dx,
+                              float* ws, int B, int HW, int C, float eps, int act, dm_stream_t stream);
 /* GroupNorm with TRAINABLE affine parameters (the ControlNet copy in controlnet_train/diffusers_train_controlnet.py:858-915):
  * per-workgroup partials of dbeta / dgamma after dm_groupnorm_nhwc_fwd, cpart [dm_groupnorm_affine_rows(B,HW,C)][2][C] fp32:
  * dbeta = cpart[:, 0].sum(0), dgamma = cpart[:, 1].sum(0) (the caller's fixed-order sum: no atomics). */

@@ -1178,6 +1178,35 @@ def test_layernorm_rows_vs_torch(dev, rows, C):
     assert (y - ref_bf).abs().max() <= 1.6e-2 * ref.abs().max()
 
 
+@pytest.mark.parametrize("act", [0, 1])
+def test_groupnorm_skip_output_gathers_both_gradients(dev, act):
+    """groupnorm_nhwc_skip: x leaves the node a second time; the backward kernel adds the skip branch's gradient in its own pass
+    (dm_groupnorm_nhwc_bwd_res) -- against fp32 autograd of act(GN(x)) * a + x * b, and with either branch unused."""
+    torch.manual_seed(0)
+    B, H, W, C = 2, 12, 10, 64
+    x = torch.randn(B, H, W, C).bfloat16()
+    gamma, beta = torch.randn(C).bfloat16(), torch.randn(C).bfloat16()
+    wa, wb = torch.randn(B, H, W, C).bfloat16(), torch.randn(B, H, W, C).bfloat16()
+    for use_y, use_skip in ((True, True), (True, False), (False, True)):
+        xg = x.to(dev).requires_grad_(True)
+        y, xs = hipops.groupnorm_nhwc_skip(xg, gamma.to(dev), beta.to(dev), 1e-6, act)
+        loss = (y.float() * wa.to(dev).float()).sum() * float(use_y) + (xs.float() * wb.to(dev).float()).sum() * float(use_skip)
+        if not use_y:
+            loss = (xs.float() * wb.to(dev).float()).sum()
+        if not use_skip:
+            loss = (y.float() * wa.to(dev).float()).sum()
+        loss.backward()
+        xr = x.float().requires_grad_(True)
+        yr = torch.nn.functional.group_norm(xr.permute(0, 3, 1, 2), 32, gamma.float(), beta.float(), 1e-6).permute(0, 2, 3, 1)
+        if act:
+            yr = torch.nn.functional.silu(yr)
+        lr = (yr * wa.float()).sum() * float(use_y) + (xr * wb.float()).sum() * float(use_skip)
+        lr.backward()
+        assert (y.float().cpu() - yr).abs().max() <= 2e-2 * yr.abs().max()
+        err = (xg.grad.float().cpu() - xr.grad).abs().max().item()
+        assert err <= 2e-2 * xr.grad.abs().max().item(), (use_y, use_skip, err)
+
+
 def test_conv_stem_with_image_gradient_vs_torch(dev):
     """the VAE encoder's conv_in (3 -> 128) when the image needs a gradient: direct stem kernel forward, folded g W backward."""
     from dreammat_amd.sd import layers
