@@ -279,6 +279,7 @@ class PaddedContext:
         pad = (-S) % 8
         self.t = F.pad(ctx, (0, 0, 0, pad)) if pad else ctx
         self.bank, self.ids = None, None
+        self.gathered = {}                     # id(Attention) -> (bank entry key, K rows, V^T rows) of this step (NetPrologue)
         if bank is not None and ids is not None:
             self.bank = F.pad(bank, (0, 0, 0, pad)) if pad else bank
             self.ids = ids
@@ -376,8 +377,13 @@ class Attention(nn.Module):
                 with torch.no_grad():
                     cache[key] = (linear_fused(context.bank, self.to_k.weight, self.to_k.bias),
                                   project_vt(self.to_v.weight, self.to_v.bias, context.bank, kv_len))
-            kb, vtb = cache[key]
-            o = hipops.attention(q, kb.index_select(0, context.ids)[:, :kv_len], vtb.index_select(0, context.ids), self.heads)
+            pre = context.gathered.pop(id(self), None)
+            if pre is not None and pre[0] == key:
+                # this step's rows of the bank, gathered for all layers of one width at once (NetPrologue.gather_kv)
+                o = hipops.attention(q, pre[1][:, :kv_len], pre[2], self.heads)
+            else:
+                kb, vtb = cache[key]
+                o = hipops.attention(q, kb.index_select(0, context.ids)[:, :kv_len], vtb.index_select(0, context.ids), self.heads)
         else:
             k = linear_fused(src, self.to_k.weight, self.to_k.bias)
             o = attention_core(q, k, self.to_v.weight, self.to_v.bias, src, self.heads, kv_len)
@@ -464,6 +470,73 @@ class Transformer2DModel(nn.Module):
         return h + res
 
 
+class NetPrologue:
+    """Work that every block of a frozen UNet / ControlNet would otherwise launch for itself, done once per forward for the whole
+    net (diffusers computes both per block: ResnetBlock2D.forward `self.time_emb_proj(self.nonlinearity(temb))`, Attention's
+    to_k / to_v on encoder_hidden_states; reached from dreammat_guidance.py:205-292).  At one view per rank a step is ~1400
+    launches of 5-20 us: 34 SiLU + 34 M = 3 B GEMMs and 46 row gathers are 114 of them.
+      project_temb: the time-embedding projections of all ResnetBlock2D of one output width in ONE batched product
+      gather_kv:    this step's rows of the cross-attention K / V^T banks (Attention.forward) of all layers of one width in ONE
+                    index_select each
+    Weights are read through per-net caches keyed by (data_ptr, _version) of every tensor involved, like Conv2d._prepared."""
+
+    def __init__(self, net: nn.Module):
+        self.net = net
+        self.resnets = [m for m in net.modules() if isinstance(m, ResnetBlock2D) and m.time_emb_proj is not None]
+        self.cross = [m for n, m in net.named_modules() if isinstance(m, Attention) and n.endswith("attn2")]
+        self._temb_key, self._temb_groups = None, []
+        self._kv = {}                          # key -> groups; every entry stays alive (captured hipGraphs bake addresses)
+
+    @staticmethod
+    def usable(t):
+        return t.is_cuda and t.dtype == torch.bfloat16 and CONV_BACKEND == "mfma"
+
+    def project_temb(self, temb):
+        if not self.resnets or not self.usable(temb):
+            return
+        if torch.is_grad_enabled() and (temb.requires_grad or any(m.time_emb_proj.weight.requires_grad for m in self.resnets)):
+            return                              # (ControlNet training: the layers run themselves, under autograd)
+        key = tuple((m.time_emb_proj.weight.data_ptr(), m.time_emb_proj.weight._version) for m in self.resnets) + (temb.dtype,)
+        if key != self._temb_key:
+            by_width = {}
+            for m in self.resnets:
+                by_width.setdefault(m.time_emb_proj.out_features, []).append(m)
+            with torch.no_grad():
+                self._temb_groups = [(ms, torch.stack([m.time_emb_proj.weight.detach().t() for m in ms]).contiguous(),
+                                      torch.stack([m.time_emb_proj.bias.detach() for m in ms]).unsqueeze(1).contiguous())
+                                     for ms in by_width.values()]
+            self._temb_key = key
+        act = F.silu(temb)
+        for ms, w, b in self._temb_groups:
+            out = torch.baddbmm(b, act.unsqueeze(0).expand(len(ms), -1, -1), w)       # [G, B, C]
+            for g, m in enumerate(ms):
+                m._tproj = out[g]
+
+    def gather_kv(self, context):
+        if (not self.cross or context is None or context.bank is None or not self.usable(context.bank)
+                or torch.is_grad_enabled() and any(m.to_k.weight.requires_grad or m.to_v.weight.requires_grad for m in self.cross)):
+            return
+        keys = [(context.bank_key, m.to_k.weight.data_ptr(), m.to_k.weight._version, m.to_v.weight.data_ptr(),
+                 m.to_v.weight._version) for m in self.cross]
+        if any(k not in m.__dict__.get("_kv_banks", {}) for k, m in zip(keys, self.cross)):
+            return                              # first forward with this bank: the layers build their entries, the next one groups them
+        gkey = tuple(keys)
+        if gkey not in self._kv:
+            for old in [k for k in self._kv if tuple(e[1:] for e in k) != tuple(e[1:] for e in gkey)]:   # other weights
+                del self._kv[old]
+            by_width = {}
+            for k, m in zip(keys, self.cross):
+                by_width.setdefault(m.to_q.out_features, []).append((k, m))
+            with torch.no_grad():
+                self._kv[gkey] = [([k for k, _ in km], [m for _, m in km],
+                                   torch.stack([m._kv_banks[k][0] for k, m in km]).contiguous(),
+                                   torch.stack([m._kv_banks[k][1] for k, m in km]).contiguous()) for km in by_width.values()]
+        for ks, ms, kb, vtb in self._kv[gkey]:
+            kr, vr = kb.index_select(1, context.ids), vtb.index_select(1, context.ids)    # [L, B, S, C], [L, B, C, S]
+            for l, (k, m) in enumerate(zip(ks, ms)):
+                context.gathered[id(m)] = (k, kr[l], vr[l])
+
+
 class ResnetBlock2D(nn.Module):
     def __init__(self, in_ch, out_ch, temb_ch=1280, eps=1e-5):
         super().__init__()
@@ -482,7 +555,9 @@ class ResnetBlock2D(nn.Module):
             h, x = h.permute(0, 3, 1, 2), x.permute(0, 3, 1, 2)
         else:
             h = group_norm_act(self.norm1, x, True)
-        tproj = self.time_emb_proj(F.silu(temb)) if self.time_emb_proj is not None else None
+        tproj = self.__dict__.pop("_tproj", None)                  # left here by NetPrologue.project_temb for this forward
+        if tproj is None and self.time_emb_proj is not None:
+            tproj = self.time_emb_proj(F.silu(temb))
         if self.conv1.fused_ok(h) and self.conv2.fused_ok(h):
             # inference path (diffusion nets in SDS): both adds ride in the conv epilogues
             h = self.conv1.forward_fused(h, rowbias=tproj)

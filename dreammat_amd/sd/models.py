@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .layers import (Attention, Conv2d, Downsample2D, group_norm_act, PaddedContext, ResnetBlock2D, TimestepEmbedding,
+from .layers import (Attention, Conv2d, Downsample2D, group_norm_act, NetPrologue, PaddedContext, ResnetBlock2D, TimestepEmbedding,
                      Transformer2DModel, Upsample2D, attention_core, timestep_embedding)
 
 
@@ -147,6 +147,14 @@ class _Encoder(nn.Module):
     def _temb(self, t, dtype):
         return self.time_embedding(timestep_embedding(t, self.arch.block_out[0]).to(dtype))
 
+    def _prologue(self, temb, ctx):
+        """the per-block time-embedding projections and K / V^T bank gathers of this forward, batched (layers.NetPrologue)"""
+        pro = self.__dict__.get("_net_prologue")
+        if pro is None:
+            pro = self.__dict__["_net_prologue"] = NetPrologue(self)
+        pro.project_temb(temb)
+        pro.gather_kv(ctx)
+
 
 class UNet2DConditionModel(_Encoder):
     def __init__(self, arch: SDArch):
@@ -172,6 +180,7 @@ class UNet2DConditionModel(_Encoder):
                 mid_block_additional_residual=None):
         ctx = encoder_hidden_states if isinstance(encoder_hidden_states, PaddedContext) else PaddedContext(encoder_hidden_states)
         temb = self._temb(timestep, sample.dtype)
+        self._prologue(temb, ctx)
         x = self.conv_in(sample)
         skips = [x]
         for blk in self.down_blocks:
@@ -229,6 +238,7 @@ class ControlNetModel(_Encoder):
     def forward(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0):
         ctx = encoder_hidden_states if isinstance(encoder_hidden_states, PaddedContext) else PaddedContext(encoder_hidden_states)
         temb = self._temb(timestep, sample.dtype)
+        self._prologue(temb, ctx)
         x = self.conv_in(sample)
         emb = self.controlnet_cond_embedding(controlnet_cond)
         if emb.shape[0] != x.shape[0]:

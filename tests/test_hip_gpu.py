@@ -767,6 +767,46 @@ def test_renderer_end_to_end_vs_oracle(dev, envs):
         json.dump({"psnr_db": psnr, "coverage_ids_equal": True}, fh)
 
 
+def test_net_prologue_batched_projections_and_bank_gathers(dev, monkeypatch):
+    """layers.NetPrologue: the time-embedding projections of all ResnetBlock2D (one batched product per width) and this step's rows
+    of the cross-attention K / V^T banks (one gather per width) against the per-block path, same weights, same bank context:
+    the gathered rows are bit-equal, the projections differ by GEMM summation order only; and far fewer launches."""
+    from dreammat_amd.sd import ARCHS, ControlNetModel, UNet2DConditionModel, layers
+    a = ARCHS["tiny"]
+    torch.manual_seed(0)
+    unet = UNet2DConditionModel(a).eval()
+    cn = ControlNetModel.from_unet(unet).eval()
+    for conv in list(cn.controlnet_down_blocks) + [cn.controlnet_mid_block, cn.controlnet_cond_embedding.conv_out]:
+        torch.nn.init.normal_(conv.weight, std=0.05)
+    unet.to(dev).bfloat16().requires_grad_(False); cn.to(dev).bfloat16().requires_grad_(False)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(6, 4, 32, 32, generator=g).to(dev).bfloat16(); t = torch.tensor([37, 801, 500, 37, 801, 500]).to(dev)
+    bank = torch.randn(5, 77, a.cross_dim, generator=g).to(dev).bfloat16()
+    ids = torch.tensor([4, 0, 2, 2, 1, 0]).to(dev)
+    cond = torch.rand(6, 22, 256, 256, generator=g).to(dev).bfloat16()
+
+    def run():
+        ctx = layers.PaddedContext(bank[ids], bank, ids)
+        d, m = cn(x, t, ctx, cond, 1.0)
+        return unet(x, t, ctx, d, m).float().cpu()
+
+    with torch.no_grad():
+        monkeypatch.setattr(layers.NetPrologue, "usable", staticmethod(lambda t_: False))
+        run()                                                   # builds the per-layer bank entries
+        ref = run()
+        monkeypatch.undo()
+        from torch.profiler import ProfilerActivity, profile
+        run()                                                   # groups the entries
+        with profile(activities=[ProfilerActivity.CPU]) as prof:
+            y = run()
+        names = [e.key for e in prof.key_averages() for _ in range(e.count)]
+    assert sum(n == "aten::index_select" for n in names) <= 12, sum(n == "aten::index_select" for n in names)  # K and V^T x 3 widths x 2 nets (per layer: 46)
+    assert sum(n == "aten::silu" for n in names) <= 10                    # one per net + the time-embedding MLPs / stem layers (per block: +34)
+    rel = ((y - ref).abs().max() / ref.abs().max()).item()
+    assert rel < 1e-2, rel
+    assert not any("_tproj" in m.__dict__ for m in list(unet.modules()) + list(cn.modules()))      # every projection was consumed
+
+
 def test_unet_controlnet_gpu_fp32_and_bf16_hip_attention(dev):
     """fp32 on the GPU vs the CPU functional oracle (north_star: noise-pred within 1e-3 rel), and the
     bf16 + MFMA-attention production path vs that fp32 result (bf16 rounding only)."""
