@@ -1,0 +1,16 @@
+#!/bin/bash
+# step time of this tree against an older copy of it (git archive <rev> into _ab_old/, built there) on ONE box, alternating:
+#   tools/ab_step.sh [bench args]   -> gpurun_out/ab_step.txt
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+mkdir -p $R/gpurun_out
+: > $R/gpurun_out/ab_step.txt
+for pass in 1 2 3; do
+  for which in old new; do
+    if [ $which = old ]; then d=$R/_ab_old; else d=$R; fi
+    (cd $d && timeout 200 python bench.py --steps 15 --warmup 3 --no-cpu-baseline "$@" 2>/dev/null | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print('$which', $pass, 'steps/s %.3f  ms %.2f  conv %.3f attn %.3f' % (d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline_attention']['frac']))") >> $R/gpurun_out/ab_step.txt
+  done
+done
+cat $R/gpurun_out/ab_step.txt
