@@ -44,6 +44,8 @@ struct ConvArgs {
     // LDS-DMA kernels: an M tile is a 2-D patch of TW x (BMT/TW) output pixels of the "tall image" [B*Hout, Wout]
     int tw_log2;         // log2(TW)
     int tiles_x;         // ceil(Wout / TW)
+    int y_off;           // first row of the tall image this launch covers (0; > 0: the second launch of launch_320_balanced)
+    long long mt_cap;    // at most this many M tiles from y_off on (0 = to the end)
     unsigned long long* timeline;   // DREAMMAT_CONV_TIMELINE=1 (development): s_memtime stamps per tile, else null
     int timeline_steps;             // DREAMMAT_CONV_TIMELINE=2: stamp every K-step instead; 4: per-wave sums of body / waits / barrier
 };
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
         const unsigned mt = uid / (unsigned)n_nt;
         const unsigned nt = uid - mt * (unsigned)n_nt;
         const unsigned tile_y = mt / (unsigned)a.tiles_x;
-        Y0 = (int)(tile_y * (unsigned)(BMT >> a.tw_log2));
+        Y0 = a.y_off + (int)(tile_y * (unsigned)(BMT >> a.tw_log2));
         X0 = (int)((mt - tile_y * (unsigned)a.tiles_x) << a.tw_log2);
         n0 = (int)nt * BN;
     };
@@ -758,6 +760,17 @@ static float* splitk_workspace(size_t floats, hipStream_t stream) {
     return buf;
 }
 
+int cu_count() {
+    static int n_cu = 0;
+    if (!n_cu) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return n_cu;
+}
+
 template <int BMT, int BN, int NW, int WMW, int NSTAGE, int TAPS = 9, int EPI = 0>
 int launch_conv_dma(const ConvArgs& a_in, hipStream_t stream) {
     constexpr int LDS = NSTAGE * (BMT + BN) * 128;
@@ -780,16 +793,12 @@ int launch_conv_dma(const ConvArgs& a_in, hipStream_t stream) {
     if ((long long)a.B * a.Hin * a.Win * a.Cin * 2 > 0xffffff00LL || (long long)a.Cout * TAPS * a.Cin * 2 > 0xffffff00LL)
         return DM_ERR_UNSUPPORTED;                                                    // 32-bit buffer offsets
     if (a.M * a.Cout * 2 > 0xffffff00LL) return DM_ERR_UNSUPPORTED;
-    long long n_mt = (((long long)a.B * a.Hout + TH - 1) / TH) * a.tiles_x;
+    long long n_mt = (((long long)a.B * a.Hout - a.y_off + TH - 1) / TH) * a.tiles_x;
+    if (a.mt_cap > 0) n_mt = std::min(n_mt, a.mt_cap);
     int n_nt = (a.Cout + BN - 1) / BN;
     // persistent grid: as many workgroups as the chip holds at once (LDS- and thread-limited), never more than tiles
-    static int n_cu = 0;
-    if (!n_cu) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return DM_ERR_UNSUPPORTED;
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
+    const int n_cu = cu_count();
+    if (n_cu <= 0) return DM_ERR_UNSUPPORTED;
     const int wg_per_cu = std::max(1, std::min((160 * 1024) / LDS, 2048 / (NW * 64)));
     // split-K when the output tiles alone would leave most of the chip idle: enough K ranges to fill it, each at least 6
     // K-steps long (DREAMMAT_CONV_SPLITK = 0 disables, = S forces S)
@@ -868,6 +877,35 @@ int launch_conv_dma(const ConvArgs& a_in, hipStream_t stream) {
     return e == hipSuccess ? DM_OK : (int)e;
 }
 
+// Cout = 320 with 256-row tiles is ONE N tile and one workgroup per CU: the SD-2.1 layers at 64 x 64 x 24 images are 384 M tiles,
+// 1.5 rounds of 256 CUs -- half the chip idles through the second round (0.206 ms where 1.5 balanced rounds are 0.155).  When the
+// last round would be at most 60 % full, the rows of that round go to a second launch with 128-row tiles (twice as many, half
+// as long): 1 + ~0.55 rounds.  (128-row tiles for everything is only 3 % faster than 256-row tiles: the narrow wave tile re-reads
+// its weights twice as often.)
+template <int TAPS>
+int launch_320_balanced(const ConvArgs& a_in, hipStream_t stream) {
+    ConvArgs a = a_in;
+    a.y_off = 0; a.mt_cap = 0;
+    const int n_cu = cu_count();
+    int tw_log2 = 4;
+    while (tw_log2 > 0 && (1 << (tw_log2 - 1)) >= a.Wout) --tw_log2;
+    const int tiles_x = (a.Wout + (1 << tw_log2) - 1) >> tw_log2, TH = 256 >> tw_log2;
+    const long long rows = (long long)a.B * a.Hout, bands = (rows + TH - 1) / TH, n_mt = bands * tiles_x;
+    static const bool off = getenv("DREAMMAT_CONV_BALANCE") && !strcmp(getenv("DREAMMAT_CONV_BALANCE"), "0");
+    if (!off && n_cu > 0 && a.Cout <= 320 && n_mt > n_cu && n_mt % n_cu != 0 && (n_mt % n_cu) * 5 <= (long long)n_cu * 3) {
+        const long long full_bands = (n_mt / n_cu) * n_cu / tiles_x;          // whole row bands inside the full rounds
+        if (full_bands > 0 && full_bands < bands) {
+            a.mt_cap = full_bands * tiles_x;
+            int rc = launch_conv_dma<256, 320, 8, 4, 2, TAPS, 0>(a, stream);
+            if (rc != DM_OK) return rc;
+            a.mt_cap = 0;
+            a.y_off = (int)(full_bands * TH);
+            return launch_conv_dma<128, 320, 8, 4, 2, TAPS, 0>(a, stream);
+        }
+    }
+    return launch_conv_dma<256, 320, 8, 4, 2, TAPS, 0>(a, stream);
+}
+
 template <int BN, int BK>
 int launch_conv(const ConvArgs& a, hipStream_t stream) {
     constexpr int LDS = 2 * (BM + BN) * (BK * 2 + 16);
@@ -905,7 +943,7 @@ int dm_conv3x3_nhwc_bf16_fused(const void* x, const void* w, const void* bias, c
     if (Cin % 32 != 0 || Cout % 64 != 0) return DM_ERR_UNSUPPORTED;
     if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return DM_ERR_ARG;
     if (((uintptr_t)bias | (uintptr_t)rowbias | (uintptr_t)residual) & 7) return DM_ERR_ARG;
-    ConvArgs a;
+    ConvArgs a = {};
     a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const __bf16*)bias; a.y = (__bf16*)y;
     a.rowbias = (const __bf16*)rowbias; a.res = (const __bf16*)residual; a.timeline = nullptr; a.timeline_steps = 0;
     a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
@@ -939,7 +977,8 @@ int dm_conv3x3_nhwc_bf16_fused(const void* x, const void* w, const void* bias, c
             if (rc <= 0 || tile_env) return rc;
             return launch_conv_dma<256, 128, 8, 4, 3>(a, stream);            // runtime refused the full-LDS variant
         }
-        case 320: return launch_conv_dma<256, 320, 8, 4, 2>(a, stream);      // wave tile 64 x 160
+        case 320: return tile_env ? launch_conv_dma<256, 320, 8, 4, 2>(a, stream) : launch_320_balanced<9>(a, stream);   // wave tile 64 x 160
+        case 1320: return launch_conv_dma<128, 320, 8, 4, 2>(a, stream);     // wave tile 32 x 160
         // (round 4: ONE wave per SIMD -- <256, 256, 4, 2, 2> / <512, 128, 4, 4, 2>, wave tile 128 x 128, the 256 accumulators in
         // the AGPR half -- is SLOWER twice over.  With the K-step schedule below as it is: 12-20 % (937 -> 816, 785 -> 670 TF/s,
         // profiles/r04_experiments/conv_one_wave_per_simd.txt).  With every fragment read and DMA piece woven behind an MFMA
@@ -983,7 +1022,7 @@ int dm_gemm_bf16_fused(const void* x, const void* w, const void* bias, const voi
     if (M / 16 >= (1 << 22)) return DM_ERR_UNSUPPORTED;
     if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return DM_ERR_ARG;
     if (((uintptr_t)bias | (uintptr_t)residual) & 7) return DM_ERR_ARG;
-    ConvArgs a;
+    ConvArgs a = {};
     a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const __bf16*)bias; a.y = (__bf16*)y;
     a.rowbias = nullptr; a.res = (const __bf16*)residual; a.timeline = nullptr; a.timeline_steps = 0;
     a.B = 1; a.Hin = a.Hout = (int)(M / 16); a.Win = a.Wout = 16; a.Cin = K; a.Cout = N;
@@ -995,7 +1034,7 @@ int dm_gemm_bf16_fused(const void* x, const void* w, const void* bias, const voi
     if (!tile) {
         if (!(N >= 128 && M >= 2048)) tile = 128;
         else if (N % 256 == 0 && n_wg(256, 256) >= 200) tile = 512;
-        else if (!geglu && N == 320 && K <= 640 && n_wg(256, 320) >= 160) tile = 320;   // no ragged N tile, x read once (64 -> 59 us)
+        else if (!geglu && N == 320 && n_wg(256, 320) >= 160) tile = 320;   // no ragged N tile, x read once (K = 320: 64 -> 59 us, K = 1280: 163 -> 152)
         else tile = 256;
     }
     if (geglu) {
@@ -1008,7 +1047,8 @@ int dm_gemm_bf16_fused(const void* x, const void* w, const void* bias, const voi
     }
     switch (tile) {
     case 512: return launch_conv_dma<256, 256, 8, 2, 2, 1, 0>(a, stream);
-    case 320: return launch_conv_dma<256, 320, 8, 4, 2, 1, 0>(a, stream);
+    case 320: return tile_env ? launch_conv_dma<256, 320, 8, 4, 2, 1, 0>(a, stream) : launch_320_balanced<1>(a, stream);
+    case 1320: return launch_conv_dma<128, 320, 8, 4, 2, 1, 0>(a, stream);
     case 256: return launch_conv_dma<256, 128, 8, 4, 3, 1, 0>(a, stream);
     default:
         // 2-stage ring (64 KB): TWO workgroups per CU, one's epilogue under the other's K loop -- 25 % faster than the 3-stage
