@@ -18,6 +18,7 @@ constexpr int CO = 16;                         // output channels per thread
 
 struct SmallConvArgs {
     const __bf16* x; const __bf16* w; const __bf16* bias; __bf16* y;
+    const __bf16* res; int res_B;              // optional [res_B, Hout, Wout, Cout] added before the rounding, image b takes b % res_B
     int B, Hin, Win, Hout, Wout, Cout, stride, pad_y, pad_x, act;
     long long n_pix;                           // B*Hout*Wout
 };
@@ -54,6 +55,15 @@ __global__ __launch_bounds__(256) void k_conv3x3_small(SmallConvArgs a) {
             for (int k = 0; k < CP; ++k) acc[c] = __builtin_amdgcn_fdot2_f32_bf16(v[k], wr[k], acc[c], false);
         }
     }
+    if (a.res) {                                // (ControlNet: conv_in(sample) + conditioning embedding, the embedding of the B views
+        __bf16 rv[CO];                          //  shared by the text / negative / null branches)
+        const long long pr = ((long long)(b % a.res_B) * a.Hout + yo) * a.Wout + xo;
+        const uint4* rp = reinterpret_cast<const uint4*>(a.res + pr * a.Cout + cog * CO);
+        *reinterpret_cast<uint4*>(rv) = rp[0];
+        *reinterpret_cast<uint4*>(rv + 8) = rp[1];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[c] += (float)rv[c];
+    }
     __bf16 o[CO];
 #pragma unroll
     for (int c = 0; c < CO; ++c) {
@@ -80,13 +90,17 @@ int launch_small(const SmallConvArgs& a, hipStream_t stream) {
 
 extern "C" {
 
-// act: 0 none, 1 SiLU (applied to conv + bias before the rounding to bf16).  Cin in {4, 8, 16, 22, 32}.
-int dm_conv3x3_small_nhwc_bf16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin,
-                               int Hout, int Wout, int Cout, int stride, int pad_y, int pad_x, int act, hipStream_t stream) {
+// act: 0 none, 1 SiLU (applied to conv + bias (+ residual) before the rounding to bf16).  Cin in {4, 8, 16, 22, 32}.
+// residual (may be NULL): [res_B, Hout, Wout, Cout] bf16 added in the same pass, image b takes residual image b % res_B.
+int dm_conv3x3_small_res_nhwc_bf16(const void* x, const void* w, const void* bias, const void* residual, int res_B, void* y, int B,
+                                   int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int stride, int pad_y, int pad_x, int act,
+                                   hipStream_t stream) {
     if (!x || !w || !y || B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || stride <= 0) return DM_ERR_ARG;
     if (Cout % CO != 0 || (((uintptr_t)x | (uintptr_t)w) & 3) || ((uintptr_t)y & 15)) return DM_ERR_UNSUPPORTED;
+    if (residual && (res_B <= 0 || ((uintptr_t)residual & 15))) return DM_ERR_ARG;
     SmallConvArgs a;
     a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const __bf16*)bias; a.y = (__bf16*)y;
+    a.res = (const __bf16*)residual; a.res_B = residual ? res_B : 1;
     a.B = B; a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout; a.stride = stride;
     a.pad_y = pad_y; a.pad_x = pad_x; a.act = act;
     a.n_pix = (long long)B * Hout * Wout;
@@ -98,6 +112,11 @@ int dm_conv3x3_small_nhwc_bf16(const void* x, const void* w, const void* bias, v
     case 32: return launch_small<32>(a, stream);
     default: return DM_ERR_UNSUPPORTED;
     }
+}
+
+int dm_conv3x3_small_nhwc_bf16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin,
+                               int Hout, int Wout, int Cout, int stride, int pad_y, int pad_x, int act, hipStream_t stream) {
+    return dm_conv3x3_small_res_nhwc_bf16(x, w, bias, nullptr, 0, y, B, Hin, Win, Cin, Hout, Wout, Cout, stride, pad_y, pad_x, act, stream);
 }
 
 }  // extern "C"

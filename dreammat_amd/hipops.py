@@ -687,19 +687,25 @@ def conv3x3_nhwc(x_nhwc, w_tap_major, bias, stride=1, pad=(1, 1), out_hw=None, r
 SMALL_CONV_CIN = (4, 8, 16, 22, 32)
 
 
-def conv3x3_small_nhwc(x_nhwc, w_tap_major, bias, stride=1, pad=(1, 1), act=0):
-    """few-channel stem convs (Cin in SMALL_CONV_CIN, Cout % 16 == 0): direct kernel, optional fused SiLU (forward only)."""
-    _need_cuda(x_nhwc, w_tap_major, bias)
+def conv3x3_small_nhwc(x_nhwc, w_tap_major, bias, stride=1, pad=(1, 1), act=0, residual=None):
+    """few-channel stem convs (Cin in SMALL_CONV_CIN, Cout % 16 == 0): direct kernel, optional fused SiLU (forward only).
+    residual [Br, Ho, Wo, Cout] (B % Br == 0): added before the rounding, image b takes residual image b % Br."""
+    _need_cuda(x_nhwc, w_tap_major, bias, residual)
     assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous() and w_tap_major.is_contiguous()
     B, H, W, Cin = x_nhwc.shape
     Cout = w_tap_major.shape[0]
     Ho, Wo = (H + 2 * pad[0] - 3) // stride + 1, (W + 2 * pad[1] - 3) // stride + 1
+    Br = 0
+    if residual is not None:
+        Br = residual.shape[0]
+        assert residual.dtype == torch.bfloat16 and residual.is_contiguous() and tuple(residual.shape[1:]) == (Ho, Wo, Cout) and B % Br == 0
     y = torch.empty(B, Ho, Wo, Cout, device=x_nhwc.device, dtype=torch.bfloat16)
-    with _Timed(f"conv3x3_small[{Cin}->{Cout}@{Ho}x{Wo},s{stride}]", 2.0 * B * Ho * Wo * (Cin + Cout)):
-        check(_lib.lib().dm_conv3x3_small_nhwc_bf16(x_nhwc.data_ptr(), w_tap_major.data_ptr(),
-                                                    bias.data_ptr() if bias is not None else None, y.data_ptr(), B, H, W, Cin,
-                                                    Ho, Wo, Cout, stride, pad[0], pad[1], int(act), _stream()),
-              "dm_conv3x3_small_nhwc_bf16")
+    with _Timed(f"conv3x3_small[{Cin}->{Cout}@{Ho}x{Wo},s{stride}]", 2.0 * B * Ho * Wo * (Cin + Cout * (2 if Br else 1))):
+        check(_lib.lib().dm_conv3x3_small_res_nhwc_bf16(x_nhwc.data_ptr(), w_tap_major.data_ptr(),
+                                                        bias.data_ptr() if bias is not None else None,
+                                                        residual.data_ptr() if Br else None, Br, y.data_ptr(), B, H, W, Cin,
+                                                        Ho, Wo, Cout, stride, pad[0], pad[1], int(act), _stream()),
+              "dm_conv3x3_small_res_nhwc_bf16")
     return y
 
 

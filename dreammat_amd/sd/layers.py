@@ -123,13 +123,15 @@ class Conv2d(nn.Conv2d):
                 and Cin in hipops.SMALL_CONV_CIN and Cout % 16 == 0 and self.stride[0] == self.stride[1]
                 and self.padding[0] == self.padding[1] and self._frozen() and not (torch.is_grad_enabled() and x.requires_grad))
 
-    def forward_small(self, x, act):
-        """act(conv(x) + bias) with act = 0 none / 1 SiLU fused before the rounding (ControlNetConditioningEmbedding)."""
+    def forward_small(self, x, act, residual=None):
+        """act(conv(x) + bias (+ residual)) with act = 0 none / 1 SiLU fused before the rounding (ControlNetConditioningEmbedding);
+        residual: logical [Br, Cout, Ho, Wo] with B % Br == 0, image b takes residual image b % Br."""
         w_fwd, _ = self._prepared()
         Cout = self.weight.shape[0]
         xn = x.permute(0, 2, 3, 1).contiguous()
+        rn = residual.permute(0, 2, 3, 1).contiguous() if residual is not None else None
         y = hipops.conv3x3_small_nhwc(xn, w_fwd[:Cout], self._bias_p[:Cout] if self._bias_p is not None else None,
-                                      self.stride[0], tuple(self.padding), act)
+                                      self.stride[0], tuple(self.padding), act, rn)
         return y.permute(0, 3, 1, 2)
 
     def forward_silu(self, x):

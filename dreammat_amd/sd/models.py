@@ -239,13 +239,16 @@ class ControlNetModel(_Encoder):
         ctx = encoder_hidden_states if isinstance(encoder_hidden_states, PaddedContext) else PaddedContext(encoder_hidden_states)
         temb = self._temb(timestep, sample.dtype)
         self._prologue(temb, ctx)
-        x = self.conv_in(sample)
+        # the conditioning stem depends on the image only: the B views are embedded once, the (text / negative / null) branches
+        # share the result instead of embedding the same image three times
         emb = self.controlnet_cond_embedding(controlnet_cond)
-        if emb.shape[0] != x.shape[0]:
-            # the conditioning stem depends on the image only: embed the B views once and tile the result over
-            # the (text / negative / null) branches instead of embedding the same image three times
-            emb = emb.repeat(x.shape[0] // emb.shape[0], 1, 1, 1)
-        x = x + emb
+        if self.conv_in.small_ok(sample) and emb.dtype == sample.dtype and sample.shape[0] % emb.shape[0] == 0:
+            x = self.conv_in.forward_small(sample, 0, emb)          # conv_in + bias + emb[b % B] in one pass, one rounding
+        else:
+            x = self.conv_in(sample)
+            if emb.shape[0] != x.shape[0]:
+                emb = emb.repeat(x.shape[0] // emb.shape[0], 1, 1, 1)
+            x = x + emb
         outs = [x]
         for blk in self.down_blocks:
             x, o = blk(x, temb, ctx)

@@ -335,6 +335,12 @@ int dm_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* part, int B
  * layers in ControlNetConditioningEmbedding.forward before the rounding to bf16. */
 int dm_conv3x3_small_nhwc_bf16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin,
                                int Hout, int Wout, int Cout, int stride, int pad_y, int pad_x, int act, dm_stream_t stream);
+/* the same with a residual added before the rounding (ABI v10): residual [res_B, Hout, Wout, Cout] bf16 or NULL, image b takes
+ * residual image b % res_B -- ControlNetModel.forward `sample = conv_in(sample) + controlnet_cond_embedding(cond)` with the
+ * embedding of the B views shared by the three guidance branches (dreammat_guidance.py:205-241 -> diffusers ControlNetModel). */
+int dm_conv3x3_small_res_nhwc_bf16(const void* x, const void* w, const void* bias, const void* residual, int res_B, void* y, int B,
+                                   int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int stride, int pad_y, int pad_x, int act,
+                                   dm_stream_t stream);
 
 /* Linear / 1x1-convolution layers of the same nets (diffusers Attention.to_q/to_k/to_out, FeedForward, Transformer2DModel
  * proj_in/proj_out, ResnetBlock2D.conv_shortcut: the F.linear / 1x1 F.conv2d calls under

@@ -1247,6 +1247,20 @@ def test_groupnorm_skip_output_gathers_both_gradients(dev, act):
         assert err <= 2e-2 * xr.grad.abs().max().item(), (use_y, use_skip, err)
 
 
+def test_conv_stem_residual_shared_by_branches(dev):
+    """dm_conv3x3_small_res_nhwc_bf16: ControlNet's conv_in(sample) + conditioning embedding in one pass, the embedding of
+    the B views shared by the 3 guidance branches (image b takes residual b % B)."""
+    from dreammat_amd.sd import layers
+    torch.manual_seed(0)
+    conv = layers.Conv2d(4, 320, 3, padding=1).to(dev).bfloat16().requires_grad_(False)
+    x = torch.randn(6, 4, 24, 40).bfloat16().to(dev)
+    emb = torch.randn(2, 320, 24, 40).bfloat16().to(dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y = conv.forward_small(x, 0, emb).float().cpu()
+        ref = torch.nn.functional.conv2d(x.float().cpu(), conv.weight.float().cpu(), conv.bias.float().cpu(), padding=1) + emb.float().cpu().repeat(3, 1, 1, 1)
+    assert (y - ref).abs().max() <= 1e-2 * ref.abs().max()
+
+
 def test_conv_stem_with_image_gradient_vs_torch(dev):
     """the VAE encoder's conv_in (3 -> 128) when the image needs a gradient: direct stem kernel forward, folded g W backward."""
     from dreammat_amd.sd import layers
