@@ -30,6 +30,11 @@ for v in 8 1; do
   f=$(find /tmp/prof_final_$v -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 tools/step_window.py "$f" 3 6 > gpurun_out/final_step_kernels_${v}views.csv
   head -1 gpurun_out/final_step_kernels_${v}views.csv | cut -c40-160
 done
+for v in 8 4 2 1; do timeout 200 python bench.py --views $v --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null < /dev/null | grep '^{"metric' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'views': $v, 'steps_per_s': d['value'], 'ms_per_step': d['ms_per_step']}))"; done > gpurun_out/final_views_table.jsonl
+timeout 200 bash tools/gemm_fit.sh > gpurun_out/final_gemm_shapes.txt 2>&1
+[ -d _ab_old ] && tools/ab_step.sh > /dev/null 2>&1      # step time against the older tree in _ab_old/, same box -> gpurun_out/ab_step.txt
+# FINAL_SKIP_PMC=1: no probes / counter passes (the conv, attention and shade kernels have not changed since the last collection)
+[ "${FINAL_SKIP_PMC:-0}" = 1 ] && { python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1; exit 0; }
 PYTHONPATH=$R timeout 400 python tools/r2_probe.py --rounds 3 --iters 10 --skip-shade --variants auto,w128,w64,v3l,staged --out final_probe.json > gpurun_out/final_r2_probe.log 2>&1 < /dev/null
 # round 4: the shade kernels on the bench scene (row / tile order, round-3 loop vs round-4 loop) + on the step's REAL inputs; the
 # probe also dumps the tile-ordered case for the counter passes
@@ -41,9 +46,7 @@ tools/_gather_probe > gpurun_out/final_gather_probe.jsonl 2>&1
 PMC_SECTIONS="conv attn shade" SHADE_CASES="rgb18e8" ATTN_VARIANTS="w128 w64" ATTN_MAIN=w128 timeout 900 bash tools/pmc_r2.sh > gpurun_out/final_pmc.log 2>&1
 DREAMMAT_ATTN_TIMELINE=1 tools/_abi_pmc attn 24 5 4096 4096 64 1 w128 2>&1 | grep "wg 300" | tail -4 > gpurun_out/final_attn_timeline.txt
 DREAMMAT_ATTN_TIMELINE=1 tools/_abi_pmc attn 24 5 4096 4096 64 1 w64 2>&1 | grep "wg 300" | tail -4 >> gpurun_out/final_attn_timeline.txt
-for v in 8 4 2 1; do timeout 200 python bench.py --views $v --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null < /dev/null | grep '^{"metric' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'views': $v, 'steps_per_s': d['value'], 'ms_per_step': d['ms_per_step']}))"; done > gpurun_out/final_views_table.jsonl
 tools/_issue_probe > gpurun_out/final_issue_probe.jsonl 2>&1
 bash tools/conv_b3.sh > gpurun_out/final_conv_batch3.txt 2>&1
-timeout 200 bash tools/gemm_fit.sh > gpurun_out/final_gemm_shapes.txt 2>&1
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 ls gpurun_out/pmc_r2 | wc -l
