@@ -10,6 +10,8 @@
 //   x [B,Hin,Win,Cin] bf16, w [Cout,9,Cin] bf16 (tap-major, the layout of dm_conv3x3_nhwc_bf16), bias [Cout] bf16 or NULL,
 //   y [B,Hout,Wout,Cout] bf16; Cin even, <= 32; Cout % 16 == 0.  Algorithmic bytes: (Cin + Cout) * 2 per output pixel.
 #include "dm_common.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -86,24 +88,230 @@ int launch_small(const SmallConvArgs& a, hipStream_t stream) {
     return DM_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The same layers on the matrix pipe (round 4).  The direct kernel above runs 22 -> 16 on 8 x 512^2 in 0.20 ms and 4 -> 128 in
+// 0.52 ms where their bytes take 0.03 / 0.06: per (pixel, 16 channels) it pays nine bounds tests, nine 64-bit address products
+// and one LDS read per MAC pair.  Here a workgroup owns a 16 x 16 tile of output pixels: the (15 s + 3)^2-pixel input patch goes
+// to LDS ONCE (zero-filled outside the image and beyond Cin: CP = 16 / 32 / 128 channels per pixel row), the weights of 32 output
+// channels at a time as [cout][tap][CP], and each wave multiplies its 64 pixels (four tile rows) by them with
+// v_mfma_f32_32x32x16_bf16, nine taps = nine shifted views of the patch.  Rows are XOR-swizzled by 16-byte chunk so that the 16
+// pixels of a tile row (consecutive patch rows) read 16 different bank groups.  Operand roles as in csrc/conv.hip: weights = A,
+// pixels = B, so a lane holds 16 channels of ONE pixel and the epilogue (bias, residual, SiLU, one rounding) stores whole 8- or
+// 16-byte channel runs.  Cin = 128 -> Cout = 4 is the data gradient of the VAE encoder's conv_in (the rendered image is the leaf).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int CP, int STRIDE>
+struct PatchCfg {
+    static constexpr int TW = 16, TH = 16, PW = (TW - 1) * STRIDE + 3, PH = (TH - 1) * STRIDE + 3;
+    static constexpr int RB = CP * 2, NC = CP / 8, RPL = 16 / NC;          // row bytes, 16-byte chunks per row, rows per 256 bytes
+    static constexpr int PATCH_BYTES = ((PH * PW * RB + 255) / 256) * 256, W_BYTES = 32 * 9 * RB;     // W_BYTES: one block of 32 output channels
+    __device__ __host__ static int swz(int row) { return (row / RPL) & (NC - 1); }
+};
+
+// Persistent workgroups: the weights of ALL output-channel blocks are loaded once per workgroup when they fit beside the patch
+// (`w_res` blocks resident; otherwise one block at a time, reloaded per tile), then the workgroup walks tiles -- per tile one patch
+// load between two barriers and no other synchronisation.  (Per-tile, per-block weight loads -- a barrier pair and an L2 round trip
+// in front of 18-36 MFMAs -- were most of the first version's time.)
+template <int CP, int STRIDE>
+__global__ __launch_bounds__(256) void k_conv3x3_patch(SmallConvArgs a, int cin, int tiles_x, int tiles_y, int n_tiles, int w_res) {
+    using C = PatchCfg<CP, STRIDE>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n_cb = (a.Cout + 31) / 32;
+    char* const patch = smem;
+    char* const wl0 = smem + C::PATCH_BYTES;                              // w_res blocks of W_BYTES
+    float* const sbias = reinterpret_cast<float*>(wl0 + w_res * C::W_BYTES);      // n_cb * 32 floats
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+    // 8 channels (one 16-byte chunk) of a [.., cin] row from channel ch0 on; zeros beyond cin
+    auto chunk_of = [&](const __bf16* rowp, int ch0) {
+        unsigned v[4] = {0u, 0u, 0u, 0u};
+        if (ch0 < cin) {
+            const __bf16* src = rowp + ch0;
+            if (ch0 + 8 <= cin && (cin & 7) == 0) {
+                const uint4 q = *reinterpret_cast<const uint4*>(src);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (ch0 + 2 * k < cin) v[k] = reinterpret_cast<const unsigned*>(src)[k];           // (Cin is even)
+            }
+        }
+        return make_uint4(v[0], v[1], v[2], v[3]);
+    };
+    auto load_weights = [&](int cb, char* wl) {                           // block cb as [cout_local][tap][CP], zero rows past Cout
+        for (int i = tid; i < 32 * 9 * C::NC; i += 256) {
+            const int row = i / C::NC, c = i - row * C::NC;
+            const int co = cb * 32 + row / 9, tap = row - (row / 9) * 9;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (co < a.Cout) v = chunk_of(a.w + ((long long)co * 9 + tap) * cin, 8 * c);
+            *reinterpret_cast<uint4*>(wl + row * C::RB + ((c ^ C::swz(row)) << 4)) = v;
+        }
+    };
+    for (int i = tid; i < n_cb * 32; i += 256) sbias[i] = (a.bias && i < a.Cout) ? (float)a.bias[i] : 0.f;
+    if (w_res >= n_cb)
+        for (int cb = 0; cb < n_cb; ++cb) load_weights(cb, wl0 + cb * C::W_BYTES);
+    const int trow0 = 4 * wave + (l31 >> 4), tcol = l31 & 15;             // this lane's pixel of M block 0 (block 1: two tile rows down)
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        int t = tile;
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        const int b = t / tiles_y;
+        const int oy0 = ty * C::TH, ox0 = tx * C::TW;
+        const int iy0 = oy0 * STRIDE - a.pad_y, ix0 = ox0 * STRIDE - a.pad_x;
+        __syncthreads();                                                   // the previous tile's patch is no longer read
+        for (int i = tid; i < C::PH * C::PW * C::NC; i += 256) {          // the patch: one chunk per thread and trip
+            const int row = i / C::NC, c = i - row * C::NC;
+            const int py = row / C::PW, px = row - py * C::PW;
+            const int yy = iy0 + py, xx = ix0 + px;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if ((unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)a.Win)
+                v = chunk_of(a.x + (((long long)b * a.Hin + yy) * a.Win + xx) * cin, 8 * c);
+            *reinterpret_cast<uint4*>(patch + row * C::RB + ((c ^ C::swz(row)) << 4)) = v;
+        }
+        __syncthreads();
+        for (int cb = 0; cb < n_cb; ++cb) {
+            const char* wl = wl0 + (w_res >= n_cb ? cb : 0) * C::W_BYTES;
+            if (w_res < n_cb) {                                            // (the weights do not all fit: one block at a time)
+                if (cb) __syncthreads();
+                load_weights(cb, wl0);
+                __syncthreads();
+            }
+            f32x16 acc[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int dy = tap / 3, dx = tap - 3 * dy;
+                const int wrow = l31 * 9 + tap;
+                int prow[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) prow[m] = ((trow0 + 2 * m) * STRIDE + dy) * C::PW + tcol * STRIDE + dx;
+#pragma unroll
+                for (int kk = 0; kk < CP / 16; ++kk) {
+                    const int ch = 2 * kk + hi;
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wl + wrow * C::RB + ((ch ^ C::swz(wrow)) << 4));
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(patch + prow[m] * C::RB + ((ch ^ C::swz(prow[m])) << 4));
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, pf, acc[m], 0, 0, 0);
+                    }
+                }
+            }
+            // ---- epilogue: register r of a lane = channel cb*32 + (r & 3) + 8 (r >> 2) + 4 hi of its pixel
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int oy = oy0 + trow0 + 2 * m, ox = ox0 + tcol;
+                const bool pix_ok = oy < a.Hout && ox < a.Wout;
+                const long long po = (((long long)b * a.Hout + oy) * a.Wout + ox) * a.Cout;
+                const long long pr = (((long long)(b % a.res_B) * a.Hout + oy) * a.Wout + ox) * a.Cout;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int cl = 8 * g + 4 * hi, c0 = cb * 32 + cl;     // four consecutive channels
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[m][4 * g + e] + sbias[c0 + e];
+                    const bool ok = pix_ok && c0 < a.Cout;                 // (Cout % 4 == 0: a run is inside or outside as a whole)
+                    if (a.res && ok) {
+                        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.res + pr + c0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                    }
+                    if (a.act) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.f + __expf(-v[e]));
+                    }
+                    if (ok) {
+                        f32x2 lo = {v[0], v[1]}, hi2 = {v[2], v[3]};
+                        const bf16x2 plo = __builtin_convertvector(lo, bf16x2), phi = __builtin_convertvector(hi2, bf16x2);
+                        const bf16x4 o = {plo[0], plo[1], phi[0], phi[1]};
+                        *reinterpret_cast<bf16x4*>(a.y + po + c0) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int CP, int STRIDE>
+int launch_patch(const SmallConvArgs& a, int cin, hipStream_t stream) {
+    using C = PatchCfg<CP, STRIDE>;
+    const int n_cb = (a.Cout + 31) / 32;
+    const size_t fixed = (size_t)C::PATCH_BYTES + (size_t)n_cb * 32 * 4;
+    static_assert(C::PATCH_BYTES + C::W_BYTES + 128 <= 160 * 1024, "LDS budget");
+    if (fixed + C::W_BYTES > 160 * 1024) return DM_ERR_UNSUPPORTED;
+    // all blocks resident when that leaves room for two workgroups per CU (or fits at all for a single one), else one block
+    int w_res = 1;
+    if (fixed + (size_t)n_cb * C::W_BYTES <= 80 * 1024 || (fixed + (size_t)n_cb * C::W_BYTES <= 160 * 1024 && n_cb > 1)) w_res = n_cb;
+    const size_t lds = fixed + (size_t)w_res * C::W_BYTES;
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_patch<CP, STRIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        lds_set = lds;
+    }
+    const int tiles_x = (a.Wout + C::TW - 1) / C::TW, tiles_y = (a.Hout + C::TH - 1) / C::TH;
+    const long long n_tiles = (long long)a.B * tiles_x * tiles_y;
+    if (n_tiles > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
+    static int n_cu = 0;
+    if (!n_cu) {
+        hipDeviceProp_t prop; int dev = 0;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
+    const long long blocks = std::min<long long>(n_tiles, (long long)n_cu * wg_per_cu);
+    DM_ENTER();
+    hipLaunchKernelGGL((k_conv3x3_patch<CP, STRIDE>), dim3((unsigned)blocks), dim3(256), lds, stream, a, cin, tiles_x, tiles_y, (int)n_tiles, w_res);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+// the patch kernel when the shape is inside its domain: stride 1 | 2, Cin even and <= 32, or Cin = 128 with Cout <= 32 (stride 1), Cout % 4 == 0,
+// the input patch of a tile inside 2^31 elements.  DREAMMAT_STEM_KERNEL=direct keeps the direct kernel (A/B runs).
+int try_patch(const SmallConvArgs& a, int cin, hipStream_t stream) {
+    static const bool direct = getenv("DREAMMAT_STEM_KERNEL") && getenv("DREAMMAT_STEM_KERNEL")[0] == 'd';
+    if (direct || (cin & 1) || a.Cout % 4 != 0 || (a.stride != 1 && a.stride != 2)) return DM_ERR_UNSUPPORTED;
+    if ((((uintptr_t)a.y | (uintptr_t)a.res) & 7) || ((uintptr_t)a.bias & 1)) return DM_ERR_UNSUPPORTED;
+    if (cin > 32 && ((((uintptr_t)a.x | (uintptr_t)a.w) & 15) || cin != 128 || a.Cout > 32)) return DM_ERR_UNSUPPORTED;
+    if (a.stride == 1) {
+        if (cin <= 16) return launch_patch<16, 1>(a, cin, stream);
+        if (cin <= 32) return launch_patch<32, 1>(a, cin, stream);
+        return launch_patch<128, 1>(a, cin, stream);             // (the image gradient of the VAE encoder's conv_in)
+    } else {
+        if (cin <= 16) return launch_patch<16, 2>(a, cin, stream);
+        if (cin <= 32) return launch_patch<32, 2>(a, cin, stream);
+    }
+    return DM_ERR_UNSUPPORTED;
+}
+
 }  // namespace
 
 extern "C" {
 
-// act: 0 none, 1 SiLU (applied to conv + bias (+ residual) before the rounding to bf16).  Cin in {4, 8, 16, 22, 32}.
+// act: 0 none, 1 SiLU (applied to conv + bias (+ residual) before the rounding to bf16).  Cin even and <= 32, or 128 at stride 1; Cout % 4 == 0
+// (the patch kernel; the direct kernel behind it: Cin in {4, 8, 16, 22, 32}, Cout % 16 == 0).
 // residual (may be NULL): [res_B, Hout, Wout, Cout] bf16 added in the same pass, image b takes residual image b % res_B.
 int dm_conv3x3_small_res_nhwc_bf16(const void* x, const void* w, const void* bias, const void* residual, int res_B, void* y, int B,
                                    int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int stride, int pad_y, int pad_x, int act,
                                    hipStream_t stream) {
     if (!x || !w || !y || B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || stride <= 0) return DM_ERR_ARG;
-    if (Cout % CO != 0 || (((uintptr_t)x | (uintptr_t)w) & 3) || ((uintptr_t)y & 15)) return DM_ERR_UNSUPPORTED;
-    if (residual && (res_B <= 0 || ((uintptr_t)residual & 15))) return DM_ERR_ARG;
+    if ((((uintptr_t)x | (uintptr_t)w) & 3) || ((uintptr_t)y & 7)) return DM_ERR_UNSUPPORTED;
+    if (residual && (res_B <= 0 || ((uintptr_t)residual & 7))) return DM_ERR_ARG;
     SmallConvArgs a;
     a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const __bf16*)bias; a.y = (__bf16*)y;
     a.res = (const __bf16*)residual; a.res_B = residual ? res_B : 1;
     a.B = B; a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout; a.stride = stride;
     a.pad_y = pad_y; a.pad_x = pad_x; a.act = act;
     a.n_pix = (long long)B * Hout * Wout;
+    {
+        const int rc = try_patch(a, Cin, stream);
+        if (rc != DM_ERR_UNSUPPORTED) return rc;
+    }
+    if (Cout % CO != 0 || ((uintptr_t)y & 15) || ((uintptr_t)residual & 15)) return DM_ERR_UNSUPPORTED;      // the direct kernel's domain
     switch (Cin) {
     case 4: return launch_small<4>(a, stream);
     case 8: return launch_small<8>(a, stream);

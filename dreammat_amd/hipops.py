@@ -773,27 +773,26 @@ def conv3x3_s1_autograd(x_nhwc, w_fwd, w_dgrad, bias, residual=None):
 
 class _ConvStemS1(torch.autograd.Function):
     """stride-1, pad-1 3x3 conv of a FEW-channel image (Cin <= 4) with frozen weights, differentiable wrt the image: the VAE
-    encoder's conv_in under SDS (dreammat_guidance.py:284-292 -- the render is the leaf).  Forward = the direct stem kernel on the
-    image padded to 4 channels (the im2col + GEMM + bias-add lowering it replaces wrote a 9x copy of the image and took three
-    passes over the 128-channel output); backward = the adjoint of that lowering, g W folded back (27 columns: GEMM-library work)."""
+    encoder's conv_in under SDS (dreammat_guidance.py:284-292 -- the render is the leaf).  Forward = the stem kernel on the image
+    padded to 4 channels (the im2col + GEMM + bias-add lowering it replaces wrote a 9x copy of the image and took three passes
+    over the 128-channel output); backward = the same kernel on the flipped weights, Cout -> 4 channels (the patch form of
+    dm_conv3x3_small_nhwc_bf16 takes 128 input channels), instead of a [B HW, 128] x [128, 27] product + col2im."""
 
     @staticmethod
-    def forward(ctx, x_nhwc, w4, w_cols, bias):
+    def forward(ctx, x_nhwc, w4, w_dgrad4, bias):
         B, H, W, Cin = x_nhwc.shape
         x4 = torch.nn.functional.pad(x_nhwc, (0, 4 - Cin)) if Cin < 4 else x_nhwc.contiguous()
-        ctx.w_cols, ctx.cin = w_cols, Cin
+        ctx.w_dgrad4, ctx.cin = w_dgrad4, Cin
         return conv3x3_small_nhwc(x4, w4, bias, 1, (1, 1), 0)
 
     @staticmethod
     def backward(ctx, g):
-        B, H, W, Cout = g.shape
-        cols = torch.matmul(g.reshape(B, H * W, Cout), ctx.w_cols)                       # [B, HW, Cin*9], (ci, ky, kx) order
-        dx = torch.nn.functional.fold(cols.transpose(1, 2), (H, W), 3, padding=1)        # [B, Cin, H, W]
-        return dx.permute(0, 2, 3, 1), None, None, None
+        dx4 = conv3x3_small_nhwc(g.contiguous(), ctx.w_dgrad4, None, 1, (1, 1), 0)        # [B, H, W, 4]
+        return dx4[..., :ctx.cin], None, None, None
 
 
-def conv3x3_stem_autograd(x_nhwc, w4, w_cols, bias):
-    return _ConvStemS1.apply(x_nhwc, w4, w_cols, bias)
+def conv3x3_stem_autograd(x_nhwc, w4, w_dgrad4, bias):
+    return _ConvStemS1.apply(x_nhwc, w4, w_dgrad4, bias)
 
 
 class _Conv3x3S2(torch.autograd.Function):

@@ -159,9 +159,11 @@ class Conv2d(nn.Conv2d):
             w4 = wd.new_zeros(Cout, 3, 3, 4)
             w4[..., :Cin] = wd.permute(0, 2, 3, 1)
             self._w_stem4 = w4.reshape(Cout, 36).contiguous()
-            self._w_stem_cols = wd.reshape(Cout, Cin * 9).contiguous()
+            wg = wd.new_zeros(4, 3, 3, Cout)                       # data gradient = the same conv on the flipped weights, Cout -> Cin (padded to 4)
+            wg[:Cin] = wd.flip(2, 3).permute(1, 2, 3, 0)
+            self._w_stem_dgrad4 = wg.reshape(4, 9 * Cout).contiguous()
             self._stem_key = key
-        return self._w_stem4, self._w_stem_cols
+        return self._w_stem4, self._w_stem_dgrad4
 
     def forward(self, x):
         if CONV_BACKEND == "miopen" or not x.is_cuda:
@@ -171,11 +173,11 @@ class Conv2d(nn.Conv2d):
         if self.small_ok(x):
             return self.forward_small(x, 0)
         if (needs_grad and CONV_BACKEND == "mfma" and x.dtype == torch.bfloat16 and kh == 3 and kw == 3 and Cin <= 4
-                and Cout % 16 == 0 and self.stride == (1, 1) and self.padding == (1, 1) and self._frozen()):
+                and Cout % 8 == 0 and (Cout <= 32 or Cout == 128) and self.stride == (1, 1) and self.padding == (1, 1) and self._frozen()):
             # the VAE encoder's conv_in on the rendered image (the only few-channel layer that needs a gradient)
-            w4, w_cols = self._stem_prepared()
+            w4, w_dgrad4 = self._stem_prepared()
             bias = self.bias.detach() if self.bias is not None else None
-            return hipops.conv3x3_stem_autograd(x.permute(0, 2, 3, 1), w4, w_cols, bias).permute(0, 3, 1, 2)
+            return hipops.conv3x3_stem_autograd(x.permute(0, 2, 3, 1), w4, w_dgrad4, bias).permute(0, 3, 1, 2)
         # zero-padded to whole 64-wide tiles (_prepared): always for the LDS-DMA kernel's shapes, and for the register-staged
         # kernel (Cin % 64 != 0) when nothing needs a gradient
         narrow = Cout % 64 != 0 and (Cin % 64 == 0 or (Cin % 32 == 0 and not needs_grad))
