@@ -688,7 +688,9 @@ SMALL_CONV_CIN = (4, 8, 16, 22, 32)
 
 
 def conv3x3_small_nhwc(x_nhwc, w_tap_major, bias, stride=1, pad=(1, 1), act=0, residual=None):
-    """few-channel stem convs (Cin in SMALL_CONV_CIN, Cout % 16 == 0): direct kernel, optional fused SiLU (forward only).
+    """few-channel stem convs with bias, optional residual and SiLU fused (forward only; dm_conv3x3_small_res_nhwc_bf16): the patch
+    kernel on the matrix pipe for Cin even and <= 32 (or Cin = 128 with Cout <= 32: a data gradient) and Cout % 4 == 0 at stride
+    1 | 2, the direct kernel behind it for Cin in SMALL_CONV_CIN, Cout % 16 == 0.
     residual [Br, Ho, Wo, Cout] (B % Br == 0): added before the rounding, image b takes residual image b % Br."""
     _need_cuda(x_nhwc, w_tap_major, bias, residual)
     assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous() and w_tap_major.is_contiguous()

@@ -150,7 +150,7 @@ class Conv2d(nn.Conv2d):
         return y.permute(0, 3, 1, 2)
 
     def _stem_prepared(self):
-        """weights of a <= 4-channel stem layer for the direct kernel (input padded to 4 channels) and for its backward."""
+        """weights of a <= 4-channel stem layer for the stem kernel (input padded to 4 channels) and for its data gradient."""
         w = self.weight
         key = (w.data_ptr(), w._version, w.dtype)
         if getattr(self, "_stem_key", None) != key:

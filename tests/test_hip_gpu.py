@@ -1249,6 +1249,41 @@ def test_groupnorm_skip_output_gathers_both_gradients(dev, act):
         assert err <= 2e-2 * xr.grad.abs().max().item(), (use_y, use_skip, err)
 
 
+def test_conv_and_gemm_balanced_last_round_equals_single_launch(dev, monkeypatch):
+    """Cout = 320 at 24 x 64 x 64 is 384 M tiles of 256 rows = 1.5 rounds of 256 CUs: the rows of the under-filled round go to a second
+    launch with 128-row tiles (conv.hip launch_320_balanced).  Same arithmetic per output element as the single launch (forced
+    through DREAMMAT_CONV_TILE / DREAMMAT_GEMM_TILE, whose kernels the tile-variant tests pin against torch): bit-equal."""
+    torch.manual_seed(0)
+    x = torch.randn(24, 64, 64, 320, device=dev).bfloat16()
+    w = (torch.randn(320, 9 * 320, device=dev) * 0.02).bfloat16()
+    b = torch.randn(320, device=dev).bfloat16()
+    res = torch.randn(24, 64, 64, 320, device=dev).bfloat16()
+    rb = torch.randn(24, 320, device=dev).bfloat16()
+    y_bal = hipops.conv3x3_nhwc(x, w, b, 1, (1, 1), None, rb, res)
+    monkeypatch.setenv("DREAMMAT_CONV_TILE", "320")
+    y_one = hipops.conv3x3_nhwc(x, w, b, 1, (1, 1), None, rb, res)
+    monkeypatch.delenv("DREAMMAT_CONV_TILE")
+    assert torch.equal(y_bal, y_one)
+    ref = torch.nn.functional.conv2d(x[5:6].float().permute(0, 3, 1, 2).cpu(), w.float().view(320, 3, 3, 320).permute(0, 3, 1, 2).cpu(),
+                                     b.float().cpu(), padding=1).permute(0, 2, 3, 1) + rb[5].float().cpu() + res[5:6].float().cpu()
+    assert (y_bal[5:6].float().cpu() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    # the image that straddles the two launches (rows 1024.. of the tall image = image 16) and the last one
+    for img in (15, 16, 23):
+        ref = torch.nn.functional.conv2d(x[img:img + 1].float().permute(0, 3, 1, 2).cpu(), w.float().view(320, 3, 3, 320).permute(0, 3, 1, 2).cpu(),
+                                         b.float().cpu(), padding=1).permute(0, 2, 3, 1) + rb[img].float().cpu() + res[img:img + 1].float().cpu()
+        assert (y_bal[img:img + 1].float().cpu() - ref).abs().max() <= 2e-2 * ref.abs().max(), img
+    xm = torch.randn(98304, 320, device=dev).bfloat16()
+    wm = (torch.randn(320, 320, device=dev) * 0.05).bfloat16()
+    rm = torch.randn(98304, 320, device=dev).bfloat16()
+    g_bal = hipops.gemm_fused(xm, wm, b, rm)
+    monkeypatch.setenv("DREAMMAT_GEMM_TILE", "320")
+    g_one = hipops.gemm_fused(xm, wm, b, rm)
+    monkeypatch.delenv("DREAMMAT_GEMM_TILE")
+    assert torch.equal(g_bal, g_one)
+    refm = xm[-300:].float() @ wm.float().t() + b.float() + rm[-300:].float()
+    assert (g_bal[-300:].float() - refm).abs().max() <= 2e-2 * refm.abs().max()
+
+
 def test_conv_stem_residual_shared_by_branches(dev):
     """dm_conv3x3_small_res_nhwc_bf16: ControlNet's conv_in(sample) + conditioning embedding in one pass, the embedding of
     the B views shared by the 3 guidance branches (image b takes residual b % B)."""
