@@ -30,7 +30,7 @@ namespace {
 
 constexpr int kTile = 64;          // kv rows per tile
 constexpr int kStage = 16384;      // K tile (64 x 64 bf16) + V^T tile (64 x 64 bf16)
-constexpr int kKBytes = 8192;
+[[maybe_unused]] constexpr int kKBytes = 8192;
 [[maybe_unused]] constexpr int kL = 4;              // LDS-DMA instructions per wave per tile: 2 K + 2 V^T
 
 // compile-time loop: the tile body is 8 NQ + 1 chunks whose register indices must all be constants -- `#pragma unroll` gave up
