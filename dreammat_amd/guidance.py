@@ -297,6 +297,9 @@ class StableDiffusionLightGuidance(BaseObject):
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
+                # twice: the first run builds the per-layer K / V^T bank entries, the second the per-net grouped caches of
+                # layers.NetPrologue -- nothing that outlives the capture may be first allocated inside it
+                self._noise_pred(st["lat"], st["t"], st["emb"], st["cond"], scales, sb)
                 self._noise_pred(st["lat"], st["t"], st["emb"], st["cond"], scales, sb)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
