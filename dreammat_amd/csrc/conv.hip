@@ -194,6 +194,8 @@ __global__ __launch_bounds__(256) void k_conv3x3(ConvArgs a, long long n_mt, int
 //    address on the way in and to the ds_read address on the way out (same involution both sides).
 //  * out-of-image taps are buffer offsets beyond num_records (the descriptor's range check returns zeros).
 //  * counted s_waitcnt vmcnt(L) + raw s_barrier: one barrier per K-step, loads span the barrier.
+// TAPS = 4: a 2 x 2 window (taps (0,0) (0,1) (1,0) (1,1) from the leading pad on): the sub-pixel form of a stride-2 convolution's
+// DATA GRADIENT (dm_conv2x2_nhwc_bf16 below).
 // TAPS = 9: 3x3 convolution.  TAPS = 1: the same machine as a plain GEMM y[M, N] = x[M, K] w[N, K]^T (the launcher presents
 // x as a [1, M/16, 16, K] image, no padding) -- the Linear / 1x1 layers of the UNet, with the same fused epilogues.
 // EPI = 1 (TAPS = 1 only): GEGLU epilogue.  The weight rows arrive interleaved in blocks of 32 (32 value rows, then their
@@ -332,12 +334,13 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
             // mod 2^32 on purpose (see above): every product wraps consistently
             a_off[i] = ((((unsigned)b * (unsigned)a.Hin + (unsigned)y0) * (unsigned)a.Win + (unsigned)x0) * (unsigned)a.Cin +
                         (unsigned)((lslot ^ ((row >> 1) & 7)) * 8)) * 2u;
-            // taps (dy, dx) inside the image: 3 column bits replicated into the valid rows
+            // taps (dy, dx) inside the image: 3 (TAPS == 4: 2) column bits replicated into the valid rows; bit index = tap
+            constexpr int TWX = TAPS == 4 ? 2 : 3;
             unsigned xb = ((unsigned)x0 < (unsigned)a.Win ? 1u : 0u) | ((unsigned)(x0 + 1) < (unsigned)a.Win ? 2u : 0u) |
-                          ((unsigned)(x0 + 2) < (unsigned)a.Win ? 4u : 0u);
+                          (TWX == 3 && (unsigned)(x0 + 2) < (unsigned)a.Win ? 4u : 0u);
             if (!ok) xb = 0;
-            a_mask[i] = ((unsigned)y0 < (unsigned)a.Hin ? xb : 0u) | ((unsigned)(y0 + 1) < (unsigned)a.Hin ? xb << 3 : 0u) |
-                        ((unsigned)(y0 + 2) < (unsigned)a.Hin ? xb << 6 : 0u);
+            a_mask[i] = ((unsigned)y0 < (unsigned)a.Hin ? xb : 0u) | ((unsigned)(y0 + 1) < (unsigned)a.Hin ? xb << TWX : 0u) |
+                        (TWX == 3 && (unsigned)(y0 + 2) < (unsigned)a.Hin ? xb << 6 : 0u);
         }
         // weight rows past Cout (ragged last tile, e.g. 320 = 2.5 x 128) re-read row Cout-1: finite values that
         // only reach accumulator rows the epilogue never stores
@@ -351,7 +354,8 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     unsigned toff = 0, woff = 0;                       // byte offsets of the step being issued
     unsigned bit = 1u;
     auto cursor_set = [&]() __attribute__((always_inline)) {
-        const int dy = (i_tap * 11) >> 5, dx = i_tap - 3 * dy;                      // tap / 3, tap % 3 for tap < 9
+        // tap -> (dy, dx): 3 x 3 window (tap / 3, tap % 3 for tap < 9) or, TAPS == 4, the 2 x 2 window of the stride-2 data gradient
+        const int dy = TAPS == 4 ? (i_tap >> 1) : ((i_tap * 11) >> 5), dx = TAPS == 4 ? (i_tap & 1) : (i_tap - 3 * dy);
         toff = (unsigned)(((dy * a.Win + dx) * a.Cin + i_kc * BK) * 2);              // from a_off
         woff = (unsigned)((i_tap * a.Cin + i_kc * BK) * 2);                          // weights are [Cout][tap][Cin]
         bit = 1u << i_tap;
@@ -1009,6 +1013,28 @@ int dm_conv3x3_nhwc_bf16(const void* x, const void* w, const void* bias, void* y
                          int Hout, int Wout, int Cout, int stride, int pad_y, int pad_x, hipStream_t stream) {
     return dm_conv3x3_nhwc_bf16_fused(x, w, bias, nullptr, nullptr, y, B, Hin, Win, Cin, Hout, Wout, Cout, stride, pad_y,
                                       pad_x, stream);
+}
+
+// 2 x 2 "convolution": y[b, yo, xo, n] = sum_{dy, dx in {0, 1}} sum_c x[b, yo - pad_y + dy, xo - pad_x + dx, c] w[n][2 dy + dx][c]
+// (zero outside the image), x [B,Hin,Win,Cin], w [Cout, 4, Cin], y [B,Hout,Wout,Cout] NHWC bf16; Cin % 64 == 0, Cout % 256 == 0.
+// What it is for: the data gradient of a stride-2 3x3 convolution, sub-pixel form.  dx[2u + py, 2v + px] of
+// `y = conv3x3(F.pad(x, (0,1,0,1)), stride 2)` (AutoencoderKL's Downsample2D, differentiated at dreammat_guidance.py:284-292) only
+// involves g[u - 1 .. u, v - 1 .. v]: 4, 2, 2 and 1 of the nine taps for the four parities.  With the four parities as four blocks of
+// output channels (Cout = 4 Cin_x; the caller interleaves the result back to full resolution) this is ONE 2 x 2 convolution at
+// the gradient's resolution with pad 1: 16 tap-blocks per gradient pixel, where the zero-inserted form (a 3x3 convolution over a
+// 4x larger tensor that is 3/4 zeros: dm_conv3x3_nhwc_bf16 on g_up) runs 36 and needs the zero tensor built first.
+int dm_conv2x2_nhwc_bf16(const void* x, const void* w, void* y, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
+                         int pad_y, int pad_x, hipStream_t stream) {
+    if (!x || !w || !y || B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0) return DM_ERR_ARG;
+    if (Cin % 64 != 0 || Cout % 256 != 0) return DM_ERR_UNSUPPORTED;
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return DM_ERR_ARG;
+    ConvArgs a = {};
+    a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = nullptr; a.y = (__bf16*)y;
+    a.rowbias = nullptr; a.res = nullptr; a.timeline = nullptr; a.timeline_steps = 0;
+    a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
+    a.stride = 1; a.pad_y = pad_y; a.pad_x = pad_x;
+    a.M = (long long)B * Hout * Wout;
+    return launch_conv_dma<256, 256, 8, 2, 2, 4, 0>(a, stream);
 }
 
 // y[M, N] = x[M, K] w[N, K]^T + bias[N] (+ residual[M, N]); all bf16 row-major, fp32 accumulate, one rounding.

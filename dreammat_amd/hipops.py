@@ -797,23 +797,57 @@ def conv3x3_stem_autograd(x_nhwc, w4, w_dgrad4, bias):
     return _ConvStemS1.apply(x_nhwc, w4, w_dgrad4, bias)
 
 
+def subpixel_dgrad_weights(w_fwd, Cin):
+    """weights of dm_conv2x2_nhwc_bf16 for the data gradient of `conv3x3(F.pad(x, (0,1,0,1)), stride=2)` with forward weights
+    w_fwd [Cout, 9 * Cin] (tap-major): [4 * Cin, 4 * Cout], output channel (py, px, ci), tap (dy, dx) of the 2 x 2 window over
+    g[u - 1 .. u, v - 1 .. v].  dx[2u + py, ..] takes g[u] through ky = py (dy = 1) and, for py = 0 only, g[u - 1] through ky = 2
+    (dy = 0); likewise in x."""
+    Cout = w_fwd.shape[0]
+    w = w_fwd.view(Cout, 3, 3, Cin)
+    ws = w.new_zeros(2, 2, Cin, 2, 2, Cout)                     # [py, px, ci, dy, dx, co]
+    ky = {(0, 1): 0, (0, 0): 2, (1, 1): 1}                      # (parity, window row) -> forward tap row
+    for (py, dy), kyy in ky.items():
+        for (px, dx), kxx in ky.items():
+            ws[py, px, :, dy, dx, :] = w[:, kyy, kxx, :].t()
+    return ws.reshape(4 * Cin, 4 * Cout).contiguous()
+
+
 class _Conv3x3S2(torch.autograd.Function):
     """stride-2 3x3 conv with leading pad p (0: AutoencoderKL's F.pad(0,1,0,1) downsampler; 1: UNet's) and frozen
-    weights.  Backward = transposed conv, computed by the SAME stride-1 kernel on the zero-inserted gradient
-    (G_up[2i,2j] = g[i,j]) with leading pad 2-p and the flipped / channel-swapped weights: 4x the minimal MFMA
-    work on three small layers instead of an im2col + col2im round trip through HBM."""
+    weights.  Backward, p = 0 with even sizes and whole 64-channel blocks: the sub-pixel form -- ONE 2 x 2 convolution at the
+    gradient's resolution whose 4 Cin output channels are the four parities of dx (dm_conv2x2_nhwc_bf16, 16 tap-blocks per
+    gradient pixel), then the interleave.  Otherwise: the stride-1 3x3 kernel on the zero-inserted gradient (G_up[2i,2j] = g[i,j])
+    with leading pad 2-p and the flipped / channel-swapped weights (36 tap-blocks and a zero tensor 4x the gradient's size)."""
 
     @staticmethod
     def forward(ctx, x_nhwc, w_fwd, w_dgrad, bias, p):
-        B, H, W, _ = x_nhwc.shape
+        B, H, W, Cin = x_nhwc.shape
         Ho, Wo = (H + 2 * p - 3 + (1 - p)) // 2 + 1, (W + 2 * p - 3 + (1 - p)) // 2 + 1   # p=0: trailing pad 1
         ctx.w_dgrad, ctx.p, ctx.hw = w_dgrad, p, (H, W)
+        ctx.w_fwd, ctx.cin = w_fwd, Cin
         return conv3x3_nhwc(x_nhwc, w_fwd, bias, 2, (p, p), (Ho, Wo))
+
+    _sub_cache = {}
 
     @staticmethod
     def backward(ctx, g):
         B, Ho, Wo, C = g.shape
         H, W = ctx.hw
+        Cin = ctx.cin
+        if ctx.p == 0 and H == 2 * Ho and W == 2 * Wo and C % 64 == 0 and Cin % 64 == 0 and os.environ.get("DREAMMAT_S2_DGRAD", "subpixel") != "zeroins":
+            key = (ctx.w_fwd.data_ptr(), ctx.w_fwd._version)
+            ws = _Conv3x3S2._sub_cache.get(key)
+            if ws is None:
+                if len(_Conv3x3S2._sub_cache) > 16:
+                    _Conv3x3S2._sub_cache.clear()
+                ws = _Conv3x3S2._sub_cache[key] = subpixel_dgrad_weights(ctx.w_fwd[:C], Cin)      # (rows past C: zero padding to whole MFMA tiles)
+            g = g.contiguous()
+            y = torch.empty(B, Ho, Wo, 4 * Cin, device=g.device, dtype=g.dtype)
+            with _Timed(f"conv2x2_dgrad[{C}->4x{Cin}@{Ho}x{Wo}]", 2.0 * B * Ho * Wo * 16.0 * C * Cin):
+                check(_lib.lib().dm_conv2x2_nhwc_bf16(g.data_ptr(), ws.data_ptr(), y.data_ptr(), B, Ho, Wo, C, Ho, Wo, 4 * Cin, 1, 1,
+                                                      _stream()), "dm_conv2x2_nhwc_bf16")
+            dx = y.view(B, Ho, Wo, 2, 2, Cin).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, Cin)       # (u, py, v, px) -> (2u + py, 2v + px)
+            return dx, None, None, None, None
         g_up = torch.zeros(B, H, W, C, device=g.device, dtype=g.dtype)
         g_up[:, 0:2 * Ho:2, 0:2 * Wo:2] = g
         q = 2 - ctx.p

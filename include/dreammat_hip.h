@@ -329,6 +329,14 @@ int dm_conv3x3_wgrad_splits(int B, int Ho, int Wo, int Cin, int Cout);
 int dm_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* part, int B, int H, int W, int Cin, int Cout, int stride,
                                dm_stream_t stream);
 
+/* 2 x 2 window "convolution" (ABI v10): y[b,yo,xo,n] = sum_{dy,dx in {0,1}} sum_c x[b, yo - pad_y + dy, xo - pad_x + dx, c] w[n][2 dy + dx][c],
+ * zero outside the image; x [B,Hin,Win,Cin], w [Cout,4,Cin], y [B,Hout,Wout,Cout] NHWC bf16, Cin % 64 == 0, Cout % 256 == 0.
+ * The sub-pixel form of the DATA GRADIENT of a stride-2 3x3 convolution (AutoencoderKL's Downsample2D,
+ * `F.pad(x, (0,1,0,1))` + `conv(stride=2)`, differentiated at dreammat_guidance.py:284-292): the four output parities are four
+ * blocks of Cin_x output channels over the gradient's own resolution (pad 1), see csrc/conv.hip; the caller interleaves them. */
+int dm_conv2x2_nhwc_bf16(const void* x, const void* w, void* y, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
+                         int pad_y, int pad_x, dm_stream_t stream);
+
 /* The few-channel stem convolutions of the same nets (ControlNetConditioningEmbedding 22->16, 16->16, 16->32 s2, 32->32,
  * 32->96 s2; conv_in 4->320): direct form, one thread per output pixel x 16 output channels, no im2col.  Same tensor
  * layouts as dm_conv3x3_nhwc_bf16; Cin in {4, 8, 16, 22, 32}, Cout % 16 == 0; act = 1 applies the SiLU that follows these

@@ -1155,12 +1155,15 @@ def test_renderer_empty_view_and_determinism(dev, envs):
     assert float((o3["comp_rgb"] - 1).abs().max()) == 0.0 and float(o3["loss_mat_reg"]) == 0.0
 
 
-def test_strided_asym_conv_autograd_vs_reference(dev):
+@pytest.mark.parametrize("dgrad", ["subpixel", "zeroins"])
+def test_strided_asym_conv_autograd_vs_reference(dev, monkeypatch, dgrad):
     """AutoencoderKL downsampler: conv3x3 stride 2 over F.pad(x,(0,1,0,1)); forward on the MFMA kernel with an
-    implied trailing pad, backward = same kernel on the zero-inserted gradient."""
+    implied trailing pad; backward = the sub-pixel form (one 2 x 2 convolution at the gradient's resolution,
+    dm_conv2x2_nhwc_bf16) or, forced, the 3x3 kernel on the zero-inserted gradient."""
     from dreammat_amd.sd import layers
+    monkeypatch.setenv("DREAMMAT_S2_DGRAD", dgrad)
     torch.manual_seed(0)
-    for (B, C, H, W) in [(2, 64, 16, 24), (1, 128, 32, 32)]:
+    for (B, C, H, W) in [(2, 64, 16, 24), (1, 128, 32, 32), (3, 64, 70, 38)]:
         ds = layers.Downsample2D(C, asymmetric_pad=True).to(dev, torch.bfloat16)
         for p in ds.parameters():
             p.requires_grad_(False)
@@ -1173,7 +1176,12 @@ def test_strided_asym_conv_autograd_vs_reference(dev):
         assert y.shape == ref.shape
         assert (y.float().cpu() - ref).abs().max() < 2e-2 * ref.abs().max() + 1e-2
         dy = torch.randn_like(ref).bfloat16()
+        hipops.enable_kernel_timing(True)
         y.backward(dy.to(dev))
+        torch.cuda.synchronize()
+        keys = list(hipops.kernel_times())
+        hipops.enable_kernel_timing(False)
+        assert any(k.startswith("conv2x2_dgrad")for k in keys) == (dgrad == "subpixel"), keys
         ref.backward(dy.float())
         assert (xg.grad.float().cpu() - xr.grad).abs().max() < 2e-2 * xr.grad.abs().max() + 1e-2
 
