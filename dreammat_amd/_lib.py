@@ -130,7 +130,7 @@ _SIGS = {
     "dm_conv3x3_nhwc_bf16_fused": (c_int, [c_void_p] * 6 + [c_int] * 10 + [c_void_p]),
     "dm_conv3x3_wgrad_splits": (c_int, [c_int] * 5),
     "dm_conv3x3_wgrad_nhwc_bf16": (c_int, [c_void_p] * 3 + [c_int] * 6 + [c_void_p]),
-    "dm_conv2x2_nhwc_bf16": (c_int, [c_void_p] * 3 + [c_int] * 9 + [c_void_p]),
+    "dm_conv2x2_nhwc_bf16": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
     "dm_conv3x3_small_nhwc_bf16": (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p]),
     "dm_conv3x3_small_res_nhwc_bf16": (c_int, [c_void_p] * 4 + [c_int, c_void_p] + [c_int] * 11 + [c_void_p]),
     "dm_gemm_bf16_fused": (c_int, [c_void_p] * 5 + [_LL, c_int, c_int, c_int, c_void_p]),

@@ -1023,13 +1023,18 @@ int dm_conv3x3_nhwc_bf16(const void* x, const void* w, const void* bias, void* y
 // output channels (Cout = 4 Cin_x; the caller interleaves the result back to full resolution) this is ONE 2 x 2 convolution at
 // the gradient's resolution with pad 1: 16 tap-blocks per gradient pixel, where the zero-inserted form (a 3x3 convolution over a
 // 4x larger tensor that is 3/4 zeros: dm_conv3x3_nhwc_bf16 on g_up) runs 36 and needs the zero tensor built first.
-int dm_conv2x2_nhwc_bf16(const void* x, const void* w, void* y, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
-                         int pad_y, int pad_x, hipStream_t stream) {
+// The same machine runs nearest-2x upsampling + 3x3 convolution (diffusers Upsample2D in the UNet's up blocks) without the 4x
+// larger tensor: output pixel (2u + py, 2v + px) sees the source through a 2 x 2 window whose weights are SUMS of the 3x3 taps
+// that fall on the same source pixel; evaluated with pad 1 on a (h + 1) x (w + 1) grid, parity (py, px) of output (u, v) is
+// channel block 2 py + px at grid position (u + py, v + px) (hipops.subpixel_upsample_weights / conv3x3_upsampled_nhwc).
+// bias [Cout] bf16 or NULL.
+int dm_conv2x2_nhwc_bf16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin, int Hout, int Wout,
+                         int Cout, int pad_y, int pad_x, hipStream_t stream) {
     if (!x || !w || !y || B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0) return DM_ERR_ARG;
     if (Cin % 64 != 0 || Cout % 256 != 0) return DM_ERR_UNSUPPORTED;
-    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return DM_ERR_ARG;
+    if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) || ((uintptr_t)bias & 7)) return DM_ERR_ARG;
     ConvArgs a = {};
-    a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = nullptr; a.y = (__bf16*)y;
+    a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const __bf16*)bias; a.y = (__bf16*)y;
     a.rowbias = nullptr; a.res = nullptr; a.timeline = nullptr; a.timeline_steps = 0;
     a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
     a.stride = 1; a.pad_y = pad_y; a.pad_x = pad_x;

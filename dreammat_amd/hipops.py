@@ -797,6 +797,45 @@ def conv3x3_stem_autograd(x_nhwc, w4, w_dgrad4, bias):
     return _ConvStemS1.apply(x_nhwc, w4, w_dgrad4, bias)
 
 
+def subpixel_upsample_weights(w, bias):
+    """nearest-2x upsampling followed by a 3x3 convolution (pad 1) with weights w [Cout, Cin, 3, 3], as ONE 2 x 2 convolution at
+    the source resolution: output (2u + py, 2v + px) reads source rows (2u + py + ky - 1) >> 1 = u + py - 1 + dy with dy in {0, 1}:
+    taps ky in S(py, dy) fall on window row dy, S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2}; likewise in x.
+    -> (w4 [4 * Cout, 4 * Cin] for dm_conv2x2_nhwc_bf16: output channel (py, px, co), tap (dy, dx); bias tiled x 4)."""
+    Cout, Cin = w.shape[:2]
+    S = {(0, 0): (0,), (0, 1): (1, 2), (1, 0): (0, 1), (1, 1): (2,)}
+    wf = w.float()
+    w4 = wf.new_zeros(2, 2, Cout, 2, 2, Cin)                    # [py, px, co, dy, dx, ci]
+    for (py, dy), kys in S.items():
+        for (px, dx), kxs in S.items():
+            acc = 0
+            for ky in kys:
+                for kx in kxs:
+                    acc = acc + wf[:, :, ky, kx]
+            w4[py, px, :, dy, dx, :] = acc
+    b4 = bias.repeat(4).contiguous() if bias is not None else None
+    return w4.reshape(4 * Cout, 4 * Cin).to(w.dtype).contiguous(), b4
+
+
+def conv3x3_upsampled_nhwc(x_nhwc, w4, b4):
+    """conv3x3(pad 1)(nearest-2x upsample(x)) from subpixel_upsample_weights: x [B,h,w,Cin] -> [B,2h,2w,Cout] (forward only)."""
+    _need_cuda(x_nhwc, w4, b4)
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous() and w4.is_contiguous()
+    B, h, w, Cin = x_nhwc.shape
+    C4 = w4.shape[0]
+    Cout = C4 // 4
+    y = torch.empty(B, h + 1, w + 1, C4, device=x_nhwc.device, dtype=torch.bfloat16)
+    with _Timed(f"conv2x2_upsample[{Cin}->4x{Cout}@{h}x{w}]", 2.0 * B * (h + 1) * (w + 1) * 4.0 * Cin * C4):
+        check(_lib.lib().dm_conv2x2_nhwc_bf16(x_nhwc.data_ptr(), w4.data_ptr(), b4.data_ptr() if b4 is not None else None, y.data_ptr(),
+                                              B, h, w, Cin, h + 1, w + 1, C4, 1, 1, _stream()), "dm_conv2x2_nhwc_bf16")
+    out = torch.empty(B, h, 2, w, 2, Cout, device=x_nhwc.device, dtype=torch.bfloat16)
+    for py in range(2):
+        for px in range(2):
+            blk = (2 * py + px) * Cout
+            out[:, :, py, :, px] = y[:, py:py + h, px:px + w, blk:blk + Cout]
+    return out.view(B, 2 * h, 2 * w, Cout)
+
+
 def subpixel_dgrad_weights(w_fwd, Cin):
     """weights of dm_conv2x2_nhwc_bf16 for the data gradient of `conv3x3(F.pad(x, (0,1,0,1)), stride=2)` with forward weights
     w_fwd [Cout, 9 * Cin] (tap-major): [4 * Cin, 4 * Cout], output channel (py, px, ci), tap (dy, dx) of the 2 x 2 window over
@@ -844,7 +883,7 @@ class _Conv3x3S2(torch.autograd.Function):
             g = g.contiguous()
             y = torch.empty(B, Ho, Wo, 4 * Cin, device=g.device, dtype=g.dtype)
             with _Timed(f"conv2x2_dgrad[{C}->4x{Cin}@{Ho}x{Wo}]", 2.0 * B * Ho * Wo * 16.0 * C * Cin):
-                check(_lib.lib().dm_conv2x2_nhwc_bf16(g.data_ptr(), ws.data_ptr(), y.data_ptr(), B, Ho, Wo, C, Ho, Wo, 4 * Cin, 1, 1,
+                check(_lib.lib().dm_conv2x2_nhwc_bf16(g.data_ptr(), ws.data_ptr(), None, y.data_ptr(), B, Ho, Wo, C, Ho, Wo, 4 * Cin, 1, 1,
                                                       _stream()), "dm_conv2x2_nhwc_bf16")
             dx = y.view(B, Ho, Wo, 2, 2, Cin).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, Cin)       # (u, py, v, px) -> (2u + py, 2v + px)
             return dx, None, None, None, None

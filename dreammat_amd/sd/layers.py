@@ -599,4 +599,21 @@ class Upsample2D(nn.Module):
         self.conv = Conv2d(ch, ch, 3, padding=1)
 
     def forward(self, x):
+        conv = self.conv
+        Cout, Cin = conv.weight.shape[:2]
+        mode = os.environ.get("DREAMMAT_UPSAMPLE", "auto")          # auto | subpixel | materialize (tests, tools/upsample_time.py)
+        # measured (24 images): 640 @32 -> 64: 463-542 us against 763-801 for upsample + 3x3; 1280 @16 -> 32 equal; 1280 @8 -> 16 slower
+        # (1944 rows against N = K = 5120 leave the 256 x 256 tiles a fraction of the chip) -- so only from 16 k source pixels on
+        big = x.shape[0] * x.shape[2] * x.shape[3] >= 16384
+        if (conv.mfma_ok(x) and Cin % 64 == 0 and Cout % 64 == 0 and not (torch.is_grad_enabled() and x.requires_grad)
+                and (mode == "subpixel" or (mode == "auto" and big))):
+            # no 4x larger tensor: the 3x3 taps that fall on one source pixel are summed into a 2 x 2 window at the source
+            # resolution, the four output parities are four channel blocks (hipops.subpixel_upsample_weights)
+            w = conv.weight
+            key = (w.data_ptr(), w._version, w.dtype)
+            if getattr(self, "_sub_key", None) != key:
+                with torch.no_grad():
+                    self._w4, self._b4 = hipops.subpixel_upsample_weights(w.detach(), conv.bias.detach() if conv.bias is not None else None)
+                self._sub_key = key
+            return hipops.conv3x3_upsampled_nhwc(x.permute(0, 2, 3, 1).contiguous(), self._w4, self._b4).permute(0, 3, 1, 2)
         return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))

@@ -333,9 +333,12 @@ int dm_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* part, int B
  * zero outside the image; x [B,Hin,Win,Cin], w [Cout,4,Cin], y [B,Hout,Wout,Cout] NHWC bf16, Cin % 64 == 0, Cout % 256 == 0.
  * The sub-pixel form of the DATA GRADIENT of a stride-2 3x3 convolution (AutoencoderKL's Downsample2D,
  * `F.pad(x, (0,1,0,1))` + `conv(stride=2)`, differentiated at dreammat_guidance.py:284-292): the four output parities are four
- * blocks of Cin_x output channels over the gradient's own resolution (pad 1), see csrc/conv.hip; the caller interleaves them. */
-int dm_conv2x2_nhwc_bf16(const void* x, const void* w, void* y, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout,
-                         int pad_y, int pad_x, dm_stream_t stream);
+ * blocks of Cin_x output channels over the gradient's own resolution (pad 1), see csrc/conv.hip; the caller interleaves them.
+ * Also nearest-2x upsampling + 3x3 convolution (diffusers Upsample2D, UNet up blocks via dreammat_guidance.py:261-282) at the
+ * SOURCE resolution: weights = sums of the 3x3 taps that fall on one source pixel, (h + 1) x (w + 1) output grid, parity (py, px)
+ * of output (u, v) = channel block 2 py + px at grid (u + py, v + px).  bias [Cout] bf16 or NULL. */
+int dm_conv2x2_nhwc_bf16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin, int Hout, int Wout,
+                         int Cout, int pad_y, int pad_x, dm_stream_t stream);
 
 /* The few-channel stem convolutions of the same nets (ControlNetConditioningEmbedding 22->16, 16->16, 16->32 s2, 32->32,
  * 32->96 s2; conv_in 4->320): direct form, one thread per output pixel x 16 output channels, no im2col.  Same tensor

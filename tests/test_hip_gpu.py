@@ -1186,6 +1186,31 @@ def test_strided_asym_conv_autograd_vs_reference(dev, monkeypatch, dgrad):
         assert (xg.grad.float().cpu() - xr.grad).abs().max() < 2e-2 * xr.grad.abs().max() + 1e-2
 
 
+@pytest.mark.parametrize("B,C,h,w", [(2, 64, 8, 8), (3, 128, 13, 9), (1, 64, 32, 16)])
+def test_upsample2d_subpixel_conv_vs_torch(dev, monkeypatch, B, C, h, w):
+    """diffusers Upsample2D (nearest 2x + conv3x3) without the upsampled tensor: one 2 x 2 convolution at the source resolution
+    with summed taps (dm_conv2x2_nhwc_bf16 + interleave) against torch fp32 and against the materialised path."""
+    from dreammat_amd.sd import layers
+    torch.manual_seed(0)
+    up = layers.Upsample2D(C).to(dev, torch.bfloat16).requires_grad_(False)
+    x = torch.randn(B, C, h, w).bfloat16()
+    monkeypatch.setenv("DREAMMAT_UPSAMPLE", "subpixel")
+    with torch.no_grad():
+        hipops.enable_kernel_timing(True)
+        y = up(x.to(dev).contiguous(memory_format=torch.channels_last)).float().cpu()
+        torch.cuda.synchronize()
+        keys = list(hipops.kernel_times())
+        hipops.enable_kernel_timing(False)
+        monkeypatch.setenv("DREAMMAT_UPSAMPLE", "materialize")
+        y_mat = up(x.to(dev).contiguous(memory_format=torch.channels_last)).float().cpu()
+    assert any(k.startswith("conv2x2_upsample") for k in keys), keys
+    ref = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x.float(), scale_factor=2.0, mode="nearest"),
+                                     up.conv.weight.float().cpu(), up.conv.bias.float().cpu(), padding=1)
+    assert y.shape == ref.shape
+    assert (y - ref).abs().max() <= 2e-2 * ref.abs().max()            # bf16 output + bf16-rounded summed taps
+    assert (y - y_mat).abs().max() <= 2e-2 * ref.abs().max()
+
+
 def test_vae_encoder_bf16_gradient_vs_fp32_oracle(dev):
     """the differentiated bf16 VAE-encoder path (MFMA convs incl. data gradients, fused GroupNorm fwd/bwd,
     strided downsamplers) against the fp32 CPU functional oracle."""
