@@ -859,42 +859,37 @@ class _Conv3x3S2(torch.autograd.Function):
     with leading pad 2-p and the flipped / channel-swapped weights (36 tap-blocks and a zero tensor 4x the gradient's size)."""
 
     @staticmethod
-    def forward(ctx, x_nhwc, w_fwd, w_dgrad, bias, p):
+    def forward(ctx, x_nhwc, w_fwd, w_dgrad, bias, p, w_sub=None):
         B, H, W, Cin = x_nhwc.shape
         Ho, Wo = (H + 2 * p - 3 + (1 - p)) // 2 + 1, (W + 2 * p - 3 + (1 - p)) // 2 + 1   # p=0: trailing pad 1
         ctx.w_dgrad, ctx.p, ctx.hw = w_dgrad, p, (H, W)
-        ctx.w_fwd, ctx.cin = w_fwd, Cin
+        ctx.w_sub, ctx.cin = w_sub, Cin
         return conv3x3_nhwc(x_nhwc, w_fwd, bias, 2, (p, p), (Ho, Wo))
-
-    _sub_cache = {}
 
     @staticmethod
     def backward(ctx, g):
         B, Ho, Wo, C = g.shape
         H, W = ctx.hw
         Cin = ctx.cin
-        if ctx.p == 0 and H == 2 * Ho and W == 2 * Wo and C % 64 == 0 and Cin % 64 == 0 and os.environ.get("DREAMMAT_S2_DGRAD", "subpixel") != "zeroins":
-            key = (ctx.w_fwd.data_ptr(), ctx.w_fwd._version)
-            ws = _Conv3x3S2._sub_cache.get(key)
-            if ws is None:
-                if len(_Conv3x3S2._sub_cache) > 16:
-                    _Conv3x3S2._sub_cache.clear()
-                ws = _Conv3x3S2._sub_cache[key] = subpixel_dgrad_weights(ctx.w_fwd[:C], Cin)      # (rows past C: zero padding to whole MFMA tiles)
+        ws = ctx.w_sub                          # subpixel_dgrad_weights of the layer (the caller's cache, tied to the layer's lifetime)
+        if (ws is not None and ctx.p == 0 and H == 2 * Ho and W == 2 * Wo and C % 64 == 0 and Cin % 64 == 0
+                and tuple(ws.shape) == (4 * Cin, 4 * C) and os.environ.get("DREAMMAT_S2_DGRAD", "subpixel") != "zeroins"):
             g = g.contiguous()
             y = torch.empty(B, Ho, Wo, 4 * Cin, device=g.device, dtype=g.dtype)
             with _Timed(f"conv2x2_dgrad[{C}->4x{Cin}@{Ho}x{Wo}]", 2.0 * B * Ho * Wo * 16.0 * C * Cin):
                 check(_lib.lib().dm_conv2x2_nhwc_bf16(g.data_ptr(), ws.data_ptr(), None, y.data_ptr(), B, Ho, Wo, C, Ho, Wo, 4 * Cin, 1, 1,
                                                       _stream()), "dm_conv2x2_nhwc_bf16")
             dx = y.view(B, Ho, Wo, 2, 2, Cin).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, Cin)       # (u, py, v, px) -> (2u + py, 2v + px)
-            return dx, None, None, None, None
+            return dx, None, None, None, None, None
         g_up = torch.zeros(B, H, W, C, device=g.device, dtype=g.dtype)
         g_up[:, 0:2 * Ho:2, 0:2 * Wo:2] = g
         q = 2 - ctx.p
-        return conv3x3_nhwc(g_up, ctx.w_dgrad, None, 1, (q, q), (H, W)), None, None, None, None
+        return conv3x3_nhwc(g_up, ctx.w_dgrad, None, 1, (q, q), (H, W)), None, None, None, None, None
 
 
-def conv3x3_s2_autograd(x_nhwc, w_fwd, w_dgrad, bias, lead_pad):
-    return _Conv3x3S2.apply(x_nhwc, w_fwd, w_dgrad, bias, lead_pad)
+def conv3x3_s2_autograd(x_nhwc, w_fwd, w_dgrad, bias, lead_pad, w_sub=None):
+    """w_sub: subpixel_dgrad_weights(w_fwd[:Cout], Cin) for the data gradient's 2 x 2 form (lead_pad 0), or None."""
+    return _Conv3x3S2.apply(x_nhwc, w_fwd, w_dgrad, bias, lead_pad, w_sub)
 
 
 def conv3x3_train_ok(x_nhwc, weight, stride, padding):

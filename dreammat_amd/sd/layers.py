@@ -143,7 +143,13 @@ class Conv2d(nn.Conv2d):
         w_fwd, w_dgrad = self._prepared()
         xn = x.permute(0, 2, 3, 1).contiguous()
         if torch.is_grad_enabled() and x.requires_grad:
-            y = hipops.conv3x3_s2_autograd(xn, w_fwd, w_dgrad, self._bias_p, 0)
+            Cout, Cin = self.weight.shape[:2]
+            key = (self.weight.data_ptr(), self.weight._version, self.weight.dtype)
+            if getattr(self, "_sub_key", None) != key:           # sub-pixel weights of the data gradient, cached on the layer
+                with torch.no_grad():
+                    self._w_sub = hipops.subpixel_dgrad_weights(w_fwd[:Cout], Cin) if Cin % 64 == 0 and Cout % 64 == 0 else None
+                self._sub_key = key
+            y = hipops.conv3x3_s2_autograd(xn, w_fwd, w_dgrad, self._bias_p, 0, self._w_sub)
         else:
             H, W = x.shape[2], x.shape[3]
             y = hipops.conv3x3_nhwc(xn, w_fwd, self._bias_p, 2, (0, 0), (H // 2, W // 2))
