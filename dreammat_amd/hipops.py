@@ -797,6 +797,27 @@ def conv3x3_stem_autograd(x_nhwc, w4, w_dgrad4, bias):
     return _ConvStemS1.apply(x_nhwc, w4, w_dgrad4, bias)
 
 
+def conv2x2_nhwc(x_nhwc, w4, bias, out_hw, pad=(1, 1), label="conv2x2"):
+    """dm_conv2x2_nhwc_bf16: y[b, yo, xo, n] = sum over the 2 x 2 window from (yo - pad, xo - pad) of x . w4[n][2 dy + dx]; x [B,H,W,Cin],
+    w4 [Cout, 4 * Cin], y [B, Ho, Wo, Cout] bf16.  Like conv3x3_nhwc, batches whose tensors pass the kernel's 32-bit byte offsets
+    run as consecutive image chunks."""
+    _need_cuda(x_nhwc, w4, bias)
+    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous() and w4.is_contiguous()
+    B, H, W, Cin = x_nhwc.shape
+    Cout = w4.shape[0]
+    Ho, Wo = out_hw
+    y = torch.empty(B, Ho, Wo, Cout, device=x_nhwc.device, dtype=torch.bfloat16)
+    per_img = 2 * max(H * W * Cin, Ho * Wo * Cout)
+    step = B if B * per_img <= CONV_MAX_TENSOR_BYTES else max(1, CONV_MAX_TENSOR_BYTES // per_img)
+    for b0 in range(0, B, step):
+        b1 = min(B, b0 + step)
+        with _Timed(f"{label}[{Cin}->{Cout}@{Ho}x{Wo}]", 2.0 * (b1 - b0) * Ho * Wo * 4.0 * Cin * Cout):
+            check(_lib.lib().dm_conv2x2_nhwc_bf16(x_nhwc[b0:b1].data_ptr(), w4.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                                  y[b0:b1].data_ptr(), b1 - b0, H, W, Cin, Ho, Wo, Cout, pad[0], pad[1], _stream()),
+                  "dm_conv2x2_nhwc_bf16")
+    return y
+
+
 def subpixel_upsample_weights(w, bias):
     """nearest-2x upsampling followed by a 3x3 convolution (pad 1) with weights w [Cout, Cin, 3, 3], as ONE 2 x 2 convolution at
     the source resolution: output (2u + py, 2v + px) reads source rows (2u + py + ky - 1) >> 1 = u + py - 1 + dy with dy in {0, 1}:
@@ -824,10 +845,7 @@ def conv3x3_upsampled_nhwc(x_nhwc, w4, b4):
     B, h, w, Cin = x_nhwc.shape
     C4 = w4.shape[0]
     Cout = C4 // 4
-    y = torch.empty(B, h + 1, w + 1, C4, device=x_nhwc.device, dtype=torch.bfloat16)
-    with _Timed(f"conv2x2_upsample[{Cin}->4x{Cout}@{h}x{w}]", 2.0 * B * (h + 1) * (w + 1) * 4.0 * Cin * C4):
-        check(_lib.lib().dm_conv2x2_nhwc_bf16(x_nhwc.data_ptr(), w4.data_ptr(), b4.data_ptr() if b4 is not None else None, y.data_ptr(),
-                                              B, h, w, Cin, h + 1, w + 1, C4, 1, 1, _stream()), "dm_conv2x2_nhwc_bf16")
+    y = conv2x2_nhwc(x_nhwc, w4, b4, (h + 1, w + 1), (1, 1), "conv2x2_upsample")
     out = torch.empty(B, h, 2, w, 2, Cout, device=x_nhwc.device, dtype=torch.bfloat16)
     for py in range(2):
         for px in range(2):
@@ -874,11 +892,7 @@ class _Conv3x3S2(torch.autograd.Function):
         ws = ctx.w_sub                          # subpixel_dgrad_weights of the layer (the caller's cache, tied to the layer's lifetime)
         if (ws is not None and ctx.p == 0 and H == 2 * Ho and W == 2 * Wo and C % 64 == 0 and Cin % 64 == 0
                 and tuple(ws.shape) == (4 * Cin, 4 * C) and os.environ.get("DREAMMAT_S2_DGRAD", "subpixel") != "zeroins"):
-            g = g.contiguous()
-            y = torch.empty(B, Ho, Wo, 4 * Cin, device=g.device, dtype=g.dtype)
-            with _Timed(f"conv2x2_dgrad[{C}->4x{Cin}@{Ho}x{Wo}]", 2.0 * B * Ho * Wo * 16.0 * C * Cin):
-                check(_lib.lib().dm_conv2x2_nhwc_bf16(g.data_ptr(), ws.data_ptr(), None, y.data_ptr(), B, Ho, Wo, C, Ho, Wo, 4 * Cin, 1, 1,
-                                                      _stream()), "dm_conv2x2_nhwc_bf16")
+            y = conv2x2_nhwc(g.contiguous(), ws, None, (Ho, Wo), (1, 1), "conv2x2_dgrad")
             dx = y.view(B, Ho, Wo, 2, 2, Cin).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, Cin)       # (u, py, v, px) -> (2u + py, 2v + px)
             return dx, None, None, None, None, None
         g_up = torch.zeros(B, H, W, C, device=g.device, dtype=g.dtype)
