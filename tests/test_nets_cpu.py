@@ -392,3 +392,79 @@ def test_guidance_multi_controlnet_light_depth_normal(tmp_path, monkeypatch):
     assert (e3 - eps).abs().max() <= 1e-3 * eps.abs().max()
     # the three nets must actually differ in what they contribute
     assert float((gd.controlnets[1].controlnet_cond_embedding.conv_in.weight).abs().sum()) > 0
+
+
+def _conv2x2_ref(x_nhwc, w4, bias, out_hw, pad):
+    """what dm_conv2x2_nhwc_bf16 computes, in torch: y[b,yo,xo,n] = sum_{dy,dx} x[b, yo - pad + dy, xo - pad + dx, :] . w4[n][2 dy + dx]."""
+    B, H, W, Cin = x_nhwc.shape
+    Ho, Wo = out_hw
+    N = w4.shape[0]
+    wv = w4.view(N, 2, 2, Cin)
+    xp = torch.nn.functional.pad(x_nhwc, (0, 0, pad, Wo + 1 - W, pad, Ho + 1 - H))
+    y = torch.zeros(B, Ho, Wo, N)
+    for dy in range(2):
+        for dx in range(2):
+            y += torch.einsum("bhwc,nc->bhwn", xp[:, dy:dy + Ho, dx:dx + Wo], wv[:, dy, dx])
+    return y if bias is None else y + bias
+
+
+def test_subpixel_dgrad_weights_reproduce_the_strided_convs_data_gradient():
+    """hipops.subpixel_dgrad_weights: the data gradient of conv3x3(F.pad(x, (0,1,0,1)), stride 2) as ONE 2 x 2 convolution at the
+    gradient's resolution whose 4 Cin output channels are the four parities of dx (host logic of _Conv3x3S2.backward)."""
+    from dreammat_amd import hipops
+    torch.manual_seed(0)
+    B, Cin, Cout, H, W = 2, 6, 10, 8, 12
+    x = torch.randn(B, Cin, H, W, requires_grad=True)
+    w = torch.randn(Cout, Cin, 3, 3)
+    y = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (0, 1, 0, 1)), w, stride=2)
+    g = torch.randn_like(y)
+    y.backward(g)
+    w_fwd = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)                    # tap-major, as Conv2d._prepared builds it
+    ws = hipops.subpixel_dgrad_weights(w_fwd, Cin)
+    assert tuple(ws.shape) == (4 * Cin, 4 * Cout)
+    Ho, Wo = H // 2, W // 2
+    yy = _conv2x2_ref(g.permute(0, 2, 3, 1), ws, None, (Ho, Wo), 1)
+    dx = yy.view(B, Ho, Wo, 2, 2, Cin).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, Cin).permute(0, 3, 1, 2)
+    assert (dx - x.grad).abs().max() < 1e-4
+
+
+def test_subpixel_upsample_weights_reproduce_upsample_plus_conv():
+    """hipops.subpixel_upsample_weights: conv3x3(nearest-2x(x)) as a 2 x 2 convolution at the source resolution on an (h+1) x (w+1)
+    grid, parity (py, px) of output (u, v) = channel block 2 py + px at grid (u + py, v + px) (host logic of Upsample2D)."""
+    from dreammat_amd import hipops
+    torch.manual_seed(1)
+    B, Cin, Cout, h, w_ = 2, 5, 7, 6, 9
+    x = torch.randn(B, Cin, h, w_)
+    w = torch.randn(Cout, Cin, 3, 3)
+    b = torch.randn(Cout)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x, scale_factor=2.0, mode="nearest"), w, b, padding=1)
+    w4, b4 = hipops.subpixel_upsample_weights(w, b)
+    assert tuple(w4.shape) == (4 * Cout, 4 * Cin) and tuple(b4.shape) == (4 * Cout,)
+    y = _conv2x2_ref(x.permute(0, 2, 3, 1), w4, b4, (h + 1, w_ + 1), 1)
+    out = torch.zeros(B, h, 2, w_, 2, Cout)
+    for py in range(2):
+        for px in range(2):
+            blk = (2 * py + px) * Cout
+            out[:, :, py, :, px] = y[:, py:py + h, px:px + w_, blk:blk + Cout]
+    out = out.view(B, 2 * h, 2 * w_, Cout).permute(0, 3, 1, 2)
+    assert (out - ref).abs().max() < 1e-4
+
+
+def test_net_prologue_batched_time_embedding_projections_equal_the_per_block_ones(monkeypatch):
+    """layers.NetPrologue.project_temb on the CPU (the device check lifted): every ResnetBlock2D consumes the projection the
+    prologue left for it, and the net's output equals the per-block path."""
+    from dreammat_amd.sd import ARCHS, UNet2DConditionModel, layers
+    torch.manual_seed(0)
+    a = ARCHS["tiny"]
+    unet = UNet2DConditionModel(a).eval().requires_grad_(False)
+    x = torch.randn(2, 4, 16, 16); t = torch.tensor([37, 801]); ctx = torch.randn(2, 77, a.cross_dim)
+    with torch.no_grad():
+        ref = unet(x, t, ctx)
+        monkeypatch.setattr(layers.NetPrologue, "usable", staticmethod(lambda t_: True))
+        calls = []
+        orig = layers.NetPrologue.project_temb
+        monkeypatch.setattr(layers.NetPrologue, "project_temb", lambda self, temb: (calls.append(len(self.resnets)), orig(self, temb))[1])
+        y = unet(x, t, ctx)
+    assert calls and calls[0] == sum(1 for m in unet.modules() if isinstance(m, layers.ResnetBlock2D))
+    assert not any("_tproj" in m.__dict__ for m in unet.modules())          # every projection was consumed
+    assert (y - ref).abs().max() <= 1e-4 * ref.abs().max() + 1e-6
