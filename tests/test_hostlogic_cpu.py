@@ -602,9 +602,18 @@ def test_static_isa_guards_on_the_lds_dma_main_loops():
         waits = [i.split(None, 1)[1] for i in t if i.startswith("s_waitcnt")]
         assert not any("vmcnt(0)" in w for w in waits), waits
         assert 12 <= sum(i.startswith("ds_read_b128") for i in t) <= 16 and sum(i.startswith("buffer_load") for i in t) <= 4
-    for pattern in ("k_conv3x3_dmaILi512ELi128ELi8ELi4ELi2ELi9ELi0", "k_conv3x3_dmaILi256ELi256ELi8ELi2ELi2ELi9ELi0"):
+    # (round 4: + the 2 x 2 instance of the stride-2 data gradients / upsample convs, the 128-row tile of the balanced Cout = 320 launches)
+    for pattern in ("k_conv3x3_dmaILi512ELi128ELi8ELi4ELi2ELi9ELi0", "k_conv3x3_dmaILi256ELi256ELi8ELi2ELi2ELi9ELi0",
+                    "k_conv3x3_dmaILi256ELi256ELi8ELi2ELi2ELi4ELi0"):
         chunks = steady_blocks("conv.hip", pattern, 8)
         assert chunks
         for c in chunks:
             assert not any(i.startswith("s_waitcnt") and "vmcnt(0)" in i for i in c)
             assert not any("scratch_" in i for i in c)
+    # the 128-row attention kernel: one unrolled block of five tiles, 64 MFMAs each, no scratch, no drained DMA ring
+    (name, body), = list(iw.kernels(iw.assembly(os.path.join(root, "dreammat_amd", "csrc", "attn_w128.hip")), "k_attn_fwd_w128ILi2ELi4E"))
+    main = max((ins for _, ins in iw.blocks(body)), key=lambda ins: sum(i.startswith("v_mfma") for i in ins))
+    assert sum(i.startswith("v_mfma") for i in main) == 320
+    assert not any("scratch_" in i for i in body)
+    assert not any(i.startswith("s_waitcnt") and "vmcnt(0)" in i for i in main)
+    assert sum(i.startswith("v_accvgpr") for i in main) <= 8, "register copies in the main loop: the AGPR / VGPR split of attn_w128 broke"
