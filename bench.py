@@ -48,6 +48,9 @@ def parse():
                          "occlusion rays) instead of the split-sum branch BASELINE.json's metric is quoted on: not a BASELINE config")
     ap.add_argument("--sharded-adam", action="store_true",
                     help="optimizer.sharded: reduce-scatter + Adam on this rank's slice + all-gather instead of all-reduce + full Adam")
+    ap.add_argument("--no-debug-outputs", action="store_true",
+                    help="renderer returns only the 5 keys the loss needs (the default writes all 12 keys of RaytraceRender.forward "
+                         "every step, as the reference does: raytracing_renderer.py:209-222)")
     ap.add_argument("--dump-kernels", default=None, help="write the per-kernel HIP-event table of the timed region (JSON) here")
     ap.add_argument("--dump-shade", default=None,
                     help="after the clock has stopped, run one more step and save the shade kernels' REAL in-step inputs (G-buffer, "
@@ -91,6 +94,12 @@ def system_config(a, views_per_rank):
         "loss": {"lambda_sds": 1.0, "lambda_mat_reg": 1.0},
         "optimizer": {"name": "Adam", "args": {"lr": 0.01, "betas": [0.9, 0.99], "eps": 1e-15}, "sharded": bool(a.sharded_adam)},
     }
+
+
+def _layer_fallbacks():
+    """16-bit CUDA calls of the nets that ran on ATen / hipBLASLt instead of the kernels of csrc/ (sd/layers.note_fallback)"""
+    from dreammat_amd.sd import layers
+    return layers.fallbacks()
 
 
 def baseline_config_name(a, n_tris):
@@ -292,7 +301,9 @@ def main():
     torch.manual_seed(0)          # identical initial parameters on every rank (DDP broadcast equivalent)
     lat = [synthetic_latlong(i) for i in range(5)]
     system = dreammat_amd.find("dreammat-system")(system_config(a, vpr), material_kwargs={"latlongs": lat})
-    system.renderer.debug_outputs = False       # the 7 logging buffers are written every 1000 steps only
+    # all 12 keys of RaytraceRender.forward every step, like the reference (round 4 timed 5 of them; --no-debug-outputs
+    # restores that for the A/B: the 7 logging buffers are ~140 MB of scatters)
+    system.renderer.debug_outputs = not a.no_debug_outputs
     dm = RandomCameraDataModule(cfg={"height": a.res, "width": a.res, "batch_size": vpr, "use_fix_views": True,
                                      "camera_distance_range": [3.0, 4.0], "fovy_range": [25, 45], "camera_perturb": 0.0,
                                      "center_perturb": 0.0, "up_perturb": 0.0, "elevation_range": [-20, 45],
@@ -364,7 +375,8 @@ def main():
                                       ", hash-grid field 16x2 2^19",
                           "views_per_step": a.views, "views_per_rank": vpr, "resolution": a.res, "sd_arch": a.sd,
                           "timed_region": "collate (draw + HBM gather of cameras and condition maps) + render + VAE/ControlNet/UNet + "
-                                          "SDS + backward + all-reduce + Adam; debug buffers off (written every 1000 steps only)",
+                                          "SDS + backward + all-reduce + Adam; renderer outputs: "
+                                          + ("the 5 keys the loss needs" if a.no_debug_outputs else "all 12 keys of the reference's render dict"),
                           "fg_lut": "reference bsdf_256_256.bin" if system.material.real_fg_lut else "analytic stand-in (file absent)",
                           "atlas_texel": system.material.atlas.texel,
                           "noise_pred_hip_graph": bool(getattr(system.guidance, "_graphs", None)),
@@ -373,7 +385,8 @@ def main():
                           "parallelism": (f"dp{world} (views sharded, reduce-scatter + sharded Adam + all-gather of {system.flat.numel * 4 / 1e6:.1f} MB fp32)"
                                           if a.sharded_adam else
                                           f"dp{world} (views sharded, 1 all-reduce of {system.flat.numel * 4 / 1e6:.1f} MB fp32 grads)"),
-                          "final_loss": float(loss)}}
+                          "left_hand_written_kernels": sorted(f"{k} {d}" for (k, d) in _layer_fallbacks()),
+                          "final_loss": float(loss.detach())}}
         # ---- rooflines from HIP events around the launches: `roofline` (conv) live in the timed region, the others on the
         # extra steps that follow it (same workload, same streams)
         def mfma_entry(name, group, n_steps=roof_steps, where="extra steps after the timed region"):

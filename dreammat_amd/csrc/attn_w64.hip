@@ -44,7 +44,7 @@ namespace {
 
 constexpr int kTile = 64;          // kv rows per tile
 constexpr int kStage = 16384;      // K tile (64 x 64 bf16) + V^T tile (64 x 64 bf16)
-constexpr int kKBytes = 8192;
+[[maybe_unused]] constexpr int kKBytes = 8192;
 [[maybe_unused]] constexpr int kL = 4;              // LDS-DMA instructions per wave per tile: 2 K + 2 V^T
 constexpr int kRowsPerWg = 256;
 

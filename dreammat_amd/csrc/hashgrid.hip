@@ -452,11 +452,11 @@ __global__ __launch_bounds__(HB_ACC_THREADS) void k_hg_acc(BinArgs a) {
     if ((long long)bin * HB_ENTRIES >= (long long)size) return;      // this level has fewer bins
     for (int i = tid; i < HB_ENTRIES; i += HB_ACC_THREADS) reinterpret_cast<uint4*>(tab)[i] = make_uint4(0u, 0u, 0u, 0u);
     const float gmax = __uint_as_float(a.gmax_bits[li]);
-    const double S = gmax > 0.f ? hb_pow2_scale(a.cap) / (double)gmax : 0.0;   // |q| <= 2^shift, cap terms at most: no wrap
+    [[maybe_unused]] const double S = gmax > 0.f ? hb_pow2_scale(a.cap) / (double)gmax : 0.0;   // |q| <= 2^shift, cap terms at most: no wrap
     __syncthreads();
     const long long n = min((long long)a.counts[li * HB_MAX_BINS + bin], a.cap);
-    const long long lo = n * split / HB_SPLITS, hi = n * (split + 1) / HB_SPLITS;
-    const uint2* src = a.tuples + ((long long)li * a.bins + bin) * a.cap;
+    [[maybe_unused]] const long long lo = n * split / HB_SPLITS, hi = n * (split + 1) / HB_SPLITS;      // (host pass: unused)
+    [[maybe_unused]] const uint2* src = a.tuples + ((long long)li * a.bins + bin) * a.cap;
     // eight independent 16-byte loads in flight per thread.  They are BUFFER loads whose descriptor ends at this split's
     // last tuple: lanes past the end read zeros (index 0, value 0: adds nothing) without a branch -- a conditional
     // `i < hi ? src[i] : 0` compiles to a branch and an s_waitcnt vmcnt(0) per load (the waitcnt pass assumes the load-free

@@ -233,19 +233,40 @@ class StableDiffusionLightGuidance(BaseObject):
             accum = accum + neg_w[:, i].view(-1, 1, 1, 1).to(e_pos.dtype) * perpendicular_component(e_i - e_uncond, e_pos)
         return e_text, e_uncond, e_null, accum
 
+    BANK_CAST_POOL = 4
+
     def _bank_cast(self, bank):
-        """the bank in the nets' dtype, converted once per bank tensor"""
-        key = (bank.data_ptr(), bank._version, self.weights_dtype)
-        casts = self.__dict__.setdefault("_bank_casts", {})
-        if key not in casts:
-            # every live cast stays alive: a captured hipGraph replays against the address of the one it was captured with.
-            # When the pool overflows, the graphs go with the evicted tensors (they would replay against freed memory).
-            if len(casts) >= 4:
-                casts.clear()
-                if hasattr(self, "_graphs"):
-                    self._graphs.clear()
-            casts[key] = bank.to(self.weights_dtype)
-        return casts[key]
+        """the bank in the nets' dtype, converted once per bank TENSOR.  An entry holds the source bank itself and is matched
+        by identity + version: an address can be handed to a new bank after the old one is freed (a re-created prompt
+        processor), and a key of (data_ptr, _version) alone then served the OLD prompt's cast."""
+        casts = self.__dict__.setdefault("_bank_casts", [])
+        for src, ver, dt, cast in casts:
+            if src is bank and ver == bank._version and dt == self.weights_dtype:
+                return cast
+        # every live cast stays alive: a captured hipGraph replays against the address of the one it was captured with.
+        # When the pool overflows, everything that was derived from the evicted tensors goes with them: the graphs (they would
+        # replay against freed memory), the per-layer K / V^T projections of the banks and the per-net grouped gathers (keyed by
+        # the CAST's address, which the allocator may hand to the next cast).
+        if len(casts) >= self.BANK_CAST_POOL:
+            casts.clear()
+            if hasattr(self, "_graphs"):
+                self._graphs.clear()
+            self._drop_bank_projections()
+        cast = bank.to(self.weights_dtype)
+        if cast is bank:                       # (already in the nets' dtype: .to() returns the tensor itself)
+            cast = bank
+        casts.append((bank, bank._version, self.weights_dtype, cast))
+        return cast
+
+    def _drop_bank_projections(self):
+        from .sd.layers import Attention
+        for net in [self.unet] + list(self.controlnets):
+            for m in net.modules():
+                if isinstance(m, Attention):
+                    m.__dict__.pop("_kv_banks", None)
+            pro = net.__dict__.get("_net_prologue")
+            if pro is not None:
+                pro._kv.clear()
 
     def _noise_pred(self, latents_noisy, t, text_embeddings, image_cond, condition_scales, bank_ids=None, n_branch=3):
         ctx = PaddedContext(text_embeddings.to(self.weights_dtype), *(bank_ids or (None, None)))

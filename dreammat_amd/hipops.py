@@ -404,7 +404,7 @@ def hashgrid_encode(x, table, spec, radius=1.0, grad_sink=None):
 
 
 # ------------------------------------------------------------------------------------------ feature network
-FIELD_MLP_FUSED = os.environ.get("DREAMMAT_FIELD_MLP", "fused") != "torch"
+FIELD_MLP_FUSED = True       # tools/field_mlp_probe.py assigns False to time the torch path the kernels replace; no environment switch
 
 
 def field_mlp_ok(x_fm, w1, w2):

@@ -247,7 +247,7 @@ class StableDiffusionPromptProcessor(BaseObject):
         barrier()   # other ranks wait for rank 0's cache (base.py:416)
 
     def _load(self, p):
-        return torch.load(self._cache_path(p), map_location=self.device)
+        return torch.load(self._cache_path(p), map_location=self.device, weights_only=True)     # a cache file is data, never code
 
     def load_text_embeddings(self):
         self.text_embeddings = self._load(self.prompt)[None]

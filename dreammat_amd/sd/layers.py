@@ -9,12 +9,15 @@ hand-written gfx950 kernels of csrc/ (DESIGN.md sections 1 and 3): 3x3 convs and
 implicit-GEMM kernel (conv.hip / conv_small.hip), Linear / 1x1 layers with bias / residual / GEGLU epilogues in its 1-tap
 instantiation, GroupNorm(+SiLU) fwd / bwd (groupnorm.hip), LayerNorm / GEGLU / the skip concat (transformer.hip), the
 QK^T.softmax.V of every transformer block in attn_w64.hip / attention.hip.  What stays on ATen / hipBLASLt is listed in
-DESIGN.md section 1 (V^T projections, the VAE mid-block attention, anything differentiated that has no hand-written backward).
+DESIGN.md section 1 (the VAE mid-block attention's projections, anything differentiated that has no hand-written backward).
 fp32 / CPU execution (BASELINE config 1: fp32 plumbing run, the fp32 legs of the parity tests) uses the plain torch paths
-below; a CUDA bf16 call NEVER falls back to them silently.
+below.  A CUDA 16-bit call that leaves the hand-written kernels (a shape outside their gates, a differentiated layer without a
+hand-written backward) is RECORDED and announced once per (layer kind, shape) on stderr -- `fallbacks()` returns the record,
+`DREAMMAT_STRICT_KERNELS=1` turns the first such call into an error (tests pin the set a step is allowed to contain).
 """
 import math
 import os
+import sys
 
 import torch
 import torch.nn as nn
@@ -30,6 +33,32 @@ from .. import hipops
 # "miopen" = torch's default conv, unusable in this image (no gfx950 kernel database: every shape JIT-compiles, ~25 min).
 # Tensors that are not on the GPU (the CPU test tier: fp32 plumbing of the same modules) take the ATen path.
 CONV_BACKEND = "mfma"
+
+_FALLBACKS = {}
+
+
+def note_fallback(kind, detail):
+    """a CUDA bf16 / f16 call is about to run on ATen / hipBLASLt instead of the kernels of csrc/: record it, say so once."""
+    key = (kind, detail)
+    n = _FALLBACKS.get(key, 0)
+    _FALLBACKS[key] = n + 1
+    if os.environ.get("DREAMMAT_STRICT_KERNELS") == "1":
+        raise RuntimeError(f"[dreammat_amd] {kind} {detail}: no hand-written kernel for this call (DREAMMAT_STRICT_KERNELS=1)")
+    if n == 0:
+        print(f"[dreammat_amd] {kind} {detail}: outside the hand-written kernels, running on ATen / hipBLASLt", file=sys.stderr)
+
+
+def fallbacks(clear=False):
+    """{(layer kind, shape / reason): calls} of every 16-bit CUDA call that left the hand-written kernels in this process"""
+    out = dict(_FALLBACKS)
+    if clear:
+        _FALLBACKS.clear()
+    return out
+
+
+def _native_expected(x):
+    """the product lowering is selected and the tensor is one the kernels of csrc/ exist for"""
+    return CONV_BACKEND == "mfma" and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16)
 # Differentiated layers with TRAINABLE parameters (the ControlNet training loop, row f-4): MFMA attention forward + backward,
 # 3x3 convolutions with the weight-gradient kernel, GroupNorm with affine gradients.  tools/train_step_probe.py assigns False
 # to time the torch-autograd lowering the kernels replace (im2col + hipBLASLt, matmul-softmax, ATen GroupNorm); no
@@ -37,7 +66,7 @@ CONV_BACKEND = "mfma"
 TRAIN_KERNELS = True
 # V^T projections of the self-attention layers through the fused GEMM kernel with swapped operands (project_vt); tools may
 # assign False to time the hipBLASLt strided-batched product it replaces.
-VT_BY_FUSED_GEMM = os.environ.get("DREAMMAT_VT_GEMM", "fused") != "blas"
+VT_BY_FUSED_GEMM = True
 
 
 class Conv2d(nn.Conv2d):
@@ -196,6 +225,9 @@ class Conv2d(nn.Conv2d):
                 if hipops.conv3x3_train_ok(xn, self.weight, self.stride, self.padding):
                     # trainable layer (ControlNet training): forward, data gradient and weight gradient on the MFMA kernels
                     return hipops.conv3x3_train(xn, self.weight, self.bias, self.stride[0]).permute(0, 3, 1, 2)
+            if _native_expected(x) and not (kh == 1 and kw == 1):      # (1 x 1 layers: linear_fused below records its own exits)
+                note_fallback("conv", f"{kh}x{kw} {Cin}->{Cout} s{self.stride[0]} p{self.padding[0]}"
+                                      f"{' autograd' if needs_grad else ''}{'' if self._frozen() else ' trainable'}")
             return self._forward_gemm(x)
         w_fwd, w_dgrad = self._prepared()
         bias = self._bias_p
@@ -225,6 +257,8 @@ def group_norm_act(norm: nn.GroupNorm, x, silu: bool):
         xn = x.permute(0, 2, 3, 1).contiguous()                  # no-op for channels-last activations
         y = hipops.groupnorm_nhwc(xn, norm.weight, norm.bias, norm.eps, 1 if silu else 0)
         return y.permute(0, 3, 1, 2)
+    if _native_expected(x):
+        note_fallback("groupnorm", f"C={x.shape[1]} groups={norm.num_groups} affine={norm.weight.dtype}")
     y = norm(x)
     return F.silu(y) if silu else y
 
@@ -244,6 +278,9 @@ def linear_fused(x, weight, bias, residual=None):
             and (residual is None or residual.dtype == torch.bfloat16)):
         r = residual.contiguous() if residual is not None else None
         return hipops.gemm_fused(x.contiguous(), weight.detach().contiguous(), bias.detach() if bias is not None else None, r)
+    if _native_expected(x):
+        grad = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)
+        note_fallback("linear", f"K={K} N={N} M={x.numel() // K}{' autograd' if grad else ''}")
     y = F.linear(x, weight, bias)
     return y + residual if residual is not None else y
 
@@ -252,6 +289,8 @@ def layer_norm(norm: nn.LayerNorm, x):
     C = x.shape[-1]
     if _rows_kernel_ok(x, norm.weight) and C % 8 == 0 and C <= 2048:
         return hipops.layernorm_rows(x.contiguous(), norm.weight, norm.bias, norm.eps)
+    if _native_expected(x):
+        note_fallback("layernorm", f"C={C}{' autograd' if torch.is_grad_enabled() and x.requires_grad else ''}")
     return norm(x)
 
 
@@ -343,6 +382,8 @@ def attention_core(q, k, v_weight, v_bias, kv_src, heads, kv_len):
     v = F.linear(kv_src, v_weight, v_bias)
     if q.is_cuda and TRAIN_KERNELS and hipops.attention_train_ok(q, k, v, heads):     # differentiated (ControlNet training): MFMA fwd + bwd
         return hipops.attention_train(q, k[:, :kv_len], v[:, :kv_len], heads)
+    if _native_expected(q):
+        note_fallback("attention", f"heads={heads} D={D} Sq={Sq} Skv={kv_len} autograd")
     qh = q.view(B, Sq, heads, D).transpose(1, 2)
     kh = k[:, :kv_len].reshape(B, kv_len, heads, D).transpose(1, 2)
     vh = v[:, :kv_len].reshape(B, kv_len, heads, D).transpose(1, 2)
@@ -421,6 +462,8 @@ class GEGLU(nn.Module):
                 and hipops.gemm_fused_ok(x.numel() // K, K, N, geglu=True)):
             w_il, b_il = self._interleaved()                       # GEMM + GEGLU in one kernel: the 2x wide tensor never exists
             return hipops.gemm_fused(x.contiguous(), w_il, b_il, None, geglu=True)
+        if _native_expected(x):
+            note_fallback("geglu", f"K={K} N={N} M={x.numel() // K}{' autograd' if torch.is_grad_enabled() and x.requires_grad else ''}")
         h = self.proj(x)
         if _rows_kernel_ok(h) and h.shape[-1] % 16 == 0:
             return hipops.geglu_rows(h.contiguous())
@@ -502,11 +545,14 @@ class NetPrologue:
         return t.is_cuda and t.dtype == torch.bfloat16 and CONV_BACKEND == "mfma"
 
     def project_temb(self, temb):
+        for m in self.resnets:                  # a projection left behind by a forward that raised midway must never be consumed
+            m.__dict__.pop("_tproj", None)
         if not self.resnets or not self.usable(temb):
             return
         if torch.is_grad_enabled() and (temb.requires_grad or any(m.time_emb_proj.weight.requires_grad for m in self.resnets)):
             return                              # (ControlNet training: the layers run themselves, under autograd)
-        key = tuple((m.time_emb_proj.weight.data_ptr(), m.time_emb_proj.weight._version) for m in self.resnets) + (temb.dtype,)
+        key = tuple((m.time_emb_proj.weight.data_ptr(), m.time_emb_proj.weight._version, m.time_emb_proj.bias.data_ptr(),
+                     m.time_emb_proj.bias._version) for m in self.resnets) + (temb.dtype,)
         if key != self._temb_key:
             by_width = {}
             for m in self.resnets:
