@@ -48,6 +48,14 @@ def parse():
                          "occlusion rays) instead of the split-sum branch BASELINE.json's metric is quoted on: not a BASELINE config")
     ap.add_argument("--sharded-adam", action="store_true",
                     help="optimizer.sharded: reduce-scatter + Adam on this rank's slice + all-gather instead of all-reduce + full Adam")
+    ap.add_argument("--dtype", choices=["bf16", "f16"], default="bf16",
+                    help="16-bit type of the nets (guidance.weights_dtype): bf16 = BASELINE's 1-GPU configurations, f16 = the reference's "
+                         "half_precision_weights (dreammat_guidance.py:56) and BASELINE configs[4]")
+    ap.add_argument("--attention", choices=["16bit", "fp8"], default="16bit",
+                    help="fp8: the S >= 1024 self-attention of the frozen nets on the MX-FP8 matrix instruction (BASELINE configs[4])")
+    ap.add_argument("--cfg5", action="store_true",
+                    help="preset = the shape and precisions of BASELINE configs[4]: --res 1024 --views 16 --mesh sphere:320:314 "
+                         "--dtype f16 --attention fp8 (200 320 triangles)")
     ap.add_argument("--no-debug-outputs", action="store_true",
                     help="renderer returns only the 5 keys the loss needs (the default writes all 12 keys of RaytraceRender.forward "
                          "every step, as the reference does: raytracing_renderer.py:209-222)")
@@ -55,7 +63,10 @@ def parse():
     ap.add_argument("--dump-shade", default=None,
                     help="after the clock has stopped, run one more step and save the shade kernels' REAL in-step inputs (G-buffer, "
                          "features, atlas) here as a .pt (tools/r4_shade_probe.py --case replays them)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.cfg5:
+        a.res, a.views, a.mesh, a.dtype, a.attention = 1024, 16, "sphere:320:314", "f16", "fp8"
+    return a
 
 
 def synthetic_latlong(seed, h=256, w=512):
@@ -84,6 +95,7 @@ def system_config(a, views_per_rank):
         "guidance": {"use_controlnet": True, "control_types": ["light"], "condition_scales": [1.0],
                      "condition_scales_anneal": [0.8], "control_anneal_start_step": 700, "width": a.res,
                      "height": a.res, "pretrained_model_name_or_path": a.sd, "synthetic": True, "cond_scale": 1.05,
+                     "weights_dtype": {"bf16": "bfloat16", "f16": "float16"}[a.dtype], "attention_precision": a.attention,
                      "hip_graph": {"on": True, "off": False, "auto": "auto"}[a.graph],
                      "uncond_scale": [0, -1.0, -0.5, 2000], "null_scale": [0, 0.0, -0.5, 2000], "noise_scale": 0.0,
                      "min_step_percent": [500, 0.2, 0.02, 501], "max_step_percent": [500, 0.8, 0.5, 501]},
@@ -111,7 +123,9 @@ def baseline_config_name(a, n_tris):
     if a.res == 512 and a.views == 4 and n_tris < 12000:
         return "BASELINE configs[1]"
     if a.res == 1024 and a.views == 16 and n_tris >= 190000:
-        return "BASELINE configs[4] shape (bf16 nets and bf16 MFMA attention: the fp8 attention of that entry is not built)"
+        if a.dtype == "f16" and a.attention == "fp8":
+            return "BASELINE configs[4] (f16 nets, MX-FP8 self-attention) on 1 GPU"
+        return f"BASELINE configs[4] shape ({a.dtype} nets, {a.attention} attention: the entry names fp16 + fp8)"
     return "custom shape (no BASELINE.json entry)"
 
 
@@ -367,7 +381,7 @@ def main():
         ms = elapsed / a.steps * 1e3
         res = {"metric": f"SDS steps/sec ({a.res}^2, {a.views} views)", "value": a.steps / elapsed, "unit": "steps/s",
                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True,
-               "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "scaling": "strong", "vs_baseline": None, "dtype": a.dtype + ("+fp8attn" if a.attention == "fp8" else ""), "data": "synthetic",
                "config": {"workload": f"{baseline_config_name(a, system.geometry.mesh.t_pos_idx.shape[0])}: "
                                       f"{system.geometry.mesh.t_pos_idx.shape[0]}-tri displaced sphere, "
                                       f"{a.res}^2, {a.views} views/step, 5 synthetic env maps, {a.sd} UNet+22ch ControlNet "
@@ -390,14 +404,17 @@ def main():
         # ---- rooflines from HIP events around the launches: `roofline` (conv) live in the timed region, the others on the
         # extra steps that follow it (same workload, same streams)
         def mfma_entry(name, group, n_steps=roof_steps, where="extra steps after the timed region"):
+            # dense MFMA peak of the launch's operand type (MI355X_MICROARCH.md): 2.5 PF/s bf16 / f16, 5 PF/s for the MX-FP8 products
+            peak = lambda k: 5000.0 if "fp8" in k else 2500.0
             key = max(group, key=lambda k: group[k]["avg_ms"] * group[k]["launches"])
             r = group[key]
             tf = r["work_per_launch"] / (r["avg_ms"] * 1e-3) / 1e12
             tot_fl = sum(v["work_per_launch"] * v["launches"] for v in group.values())
             tot_ms = sum(v["avg_ms"] * v["launches"] for v in group.values())
-            return {"kernel": name + " " + key, "bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s",
-                    "frac": tf / 2500.0, "traffic": None, "launches_timed": r["launches"], "avg_us": r["avg_ms"] * 1e3,
-                    "all_shapes": {"TFLOP/s": tot_fl / (tot_ms * 1e-3) / 1e12, "frac": tot_fl / (tot_ms * 1e-3) / 2.5e15,
+            tot_peak_fl = sum(v["avg_ms"] * 1e-3 * v["launches"] * peak(k) * 1e12 for k, v in group.items())
+            return {"kernel": name + " " + key, "bound": "mfma", "achieved": tf, "peak": peak(key), "unit": "TFLOP/s",
+                    "frac": tf / peak(key), "traffic": None, "launches_timed": r["launches"], "avg_us": r["avg_ms"] * 1e3,
+                    "all_shapes": {"TFLOP/s": tot_fl / (tot_ms * 1e-3) / 1e12, "frac": tot_fl / tot_peak_fl,
                                    "ms_per_step": tot_ms / n_steps,
                                    "launches_per_step": sum(v["launches"] for v in group.values()) / n_steps},
                     "events": where}
@@ -412,7 +429,7 @@ def main():
             if roof_key in kt_live:
                 res["roofline"]["launches_timed"] = kt_live[roof_key]["launches"]
         if attn:      # north_star target: >= 50 % MFMA
-            res["roofline_attention"] = mfma_entry("k_attn_fwd_w128 / k_attn_fwd_w64 / k_attn_fwd_v3 (dispatch: " + hipops.attention_variant() + ")", attn)
+            res["roofline_attention"] = mfma_entry(("k_attn_fwd_fp8 (S >= 1024) + " if a.attention == "fp8" else "") + "k_attn_fwd_w128 / k_attn_fwd_w64 / k_attn_fwd_v3 (dispatch: " + hipops.attention_variant() + ")", attn)
             if "roofline" not in res:
                 res["roofline"] = res["roofline_attention"]
         if gemm:      # Linear / 1x1 layers + GEGLU on the 1-tap instantiation of the conv kernel

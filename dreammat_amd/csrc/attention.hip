@@ -32,7 +32,7 @@ constexpr int kQRowsPerWave = 32;
 constexpr int kWaves = 4;
 constexpr int kKvTile = 64;
 
-__device__ __forceinline__ uint4 ld16(const __bf16* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ uint4 ld16(const elem_t* p) { return *reinterpret_cast<const uint4*>(p); }
 
 // VNAT: V arrives as [kv][d] rows (the differentiated path, dm_attention_fwd_lse_bf16): staged row-major like K and consumed
 // through the transposing LDS read (ds_read_b64_tr_b16: two reads per V^T fragment, rows in accumulator order).
@@ -56,20 +56,20 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
     const int skv_pad8 = (a.Skv + 7) & ~7;
 
     // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q][16kk + 8hi .. +7]
-    bf16x8 qf[KSTEPS];
+    elem8 qf[KSTEPS];
     {
-        const __bf16* qp = a.q + (long long)b * a.q_bs + (long long)q_row * a.q_ss + (long long)h * a.q_hs;
+        const elem_t* qp = a.q + (long long)b * a.q_bs + (long long)q_row * a.q_ss + (long long)h * a.q_hs;
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
             int d = 16 * kk + 8 * hi;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (q_ok && d < a.D) v = ld16(qp + d);
-            qf[kk] = __builtin_bit_cast(bf16x8, v);
+            qf[kk] = __builtin_bit_cast(elem8, v);
         }
     }
 
-    const __bf16* kp = a.k + (long long)b * a.k_bs + (long long)h * a.k_hs;
-    const __bf16* vp = VNAT ? a.v_nat + (long long)b * a.k_bs + (long long)h * a.k_hs
+    const elem_t* kp = a.k + (long long)b * a.k_bs + (long long)h * a.k_hs;
+    const elem_t* vp = VNAT ? a.v_nat + (long long)b * a.k_bs + (long long)h * a.k_hs
                             : a.vt + (long long)b * a.vt_bs + (long long)h * a.vt_hs;
 
     uint4 kreg[DT], vreg[DT];
@@ -140,8 +140,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
             for (int r = 0; r < 16; ++r) s[t][r] = 0.f;
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk) {
-                bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + (32 * t + l31) * KROW + 32 * kk + 16 * hi);
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[t], 0, 0, 0);
+                elem8 kf = *reinterpret_cast<const elem8*>(kb + (32 * t + l31) * KROW + 32 * kk + 16 * hi);
+                s[t] = DM_MFMA_32x32x16(kf, qf[kk], s[t]);
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -192,14 +192,14 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
         m_run = m_new;
 
         // ---- P -> bf16 B-operand fragments (no data movement: accumulator order == k-slot order)
-        bf16x8 pf[4];
+        elem8 pf[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int t = ks >> 1, u = ks & 1;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 f32x2 two = {s[t][8 * u + 2 * e], s[t][8 * u + 2 * e + 1]};
-                bf16x2 pk = __builtin_convertvector(two, bf16x2);
+                elem2 pk = __builtin_convertvector(two, elem2);
                 pf[ks][2 * e] = pk[0];
                 pf[ks][2 * e + 1] = pk[1];
             }
@@ -210,17 +210,16 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                bf16x8 vf;
+                elem8 vf;
                 if (VNAT) {
-                    typedef bf16x4 __attribute__((address_space(3))) * lds4;
                     const char* p = vb + tr_off + ks * 16 * KROW + dt * 64;
-                    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)const_cast<char*>(p));
-                    const bf16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)const_cast<char*>(p + 8 * KROW));
-                    vf = bf16x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+                    const elem4 lo = dm_ds_read_tr16_b64(p);
+                    const elem4 up = dm_ds_read_tr16_b64(p + 8 * KROW);
+                    vf = elem8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
                 } else {
-                    vf = *reinterpret_cast<const bf16x8*>(vb + (32 * dt + l31) * VROW + 32 * ks + 16 * hi);
+                    vf = *reinterpret_cast<const elem8*>(vb + (32 * dt + l31) * VROW + 32 * ks + 16 * hi);
                 }
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[dt], 0, 0, 0);
+                o[dt] = DM_MFMA_32x32x16(vf, pf[ks], o[dt]);
             }
 
         __builtin_amdgcn_s_setprio(0);
@@ -233,7 +232,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
     float inv = 1.0f / l_tot;
     if (a.lse && q_ok && hi == 0) a.lse[((long long)b * a.Hh + h) * a.Sq + q_row] = m_run + __builtin_amdgcn_logf(l_tot);
     if (q_ok) {
-        __bf16* op = a.out + (long long)b * a.o_bs + (long long)q_row * a.o_ss + (long long)h * a.o_hs;
+        elem_t* op = a.out + (long long)b * a.o_bs + (long long)q_row * a.o_ss + (long long)h * a.o_hs;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -242,9 +241,9 @@ __global__ __launch_bounds__(256) void k_attn_fwd(AttnArgs a) {
                 if (d < a.D) {
                     f32x2 x0 = {o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv};
                     f32x2 x1 = {o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
-                    bf16x2 y0 = __builtin_convertvector(x0, bf16x2), y1 = __builtin_convertvector(x1, bf16x2);
-                    bf16x4 y = {y0[0], y0[1], y1[0], y1[1]};
-                    *reinterpret_cast<bf16x4*>(op + d) = y;
+                    elem2 y0 = __builtin_convertvector(x0, elem2), y1 = __builtin_convertvector(x1, elem2);
+                    elem4 y = {y0[0], y0[1], y1[0], y1[1]};
+                    *reinterpret_cast<elem4*>(op + d) = y;
                 }
             }
     }
@@ -318,7 +317,7 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a, 
         __syncthreads();
     }
 
-    bf16x8 qf[KSTEPS];
+    elem8 qf[KSTEPS];
     uint4 qraw[KSTEPS];
     // KVRES: whole 128-byte rows, 16 B per lane (8 lanes per row, 8 rows per instruction: 8 cache lines instead of the 32 a
     // "one row per lane pair" access touches -- tools/gather_probe.cpp: 21 vs ~70 cycles of the CU's address unit per wave
@@ -336,7 +335,7 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a, 
                     qraw[i] = ld16(a.q + (long long)b * a.q_bs + (long long)r * a.q_ss + (long long)h * a.q_hs + (lane & 7) * 8);
             }
         } else {
-            const __bf16* qp = a.q + (long long)b * a.q_bs + (long long)row * a.q_ss + (long long)h * a.q_hs;
+            const elem_t* qp = a.q + (long long)b * a.q_bs + (long long)row * a.q_ss + (long long)h * a.q_hs;
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk) {
                 const int d = 16 * kk + 8 * hi;
@@ -358,11 +357,11 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a, 
         }
 #pragma unroll
         for (int kk = 0; kk < KSTEPS; ++kk) {
-            qf[kk] = __builtin_bit_cast(bf16x8, qraw[kk]);
+            qf[kk] = __builtin_bit_cast(elem8, qraw[kk]);
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
                 f32x2 two = {(float)qf[kk][e] * a.scale_log2, (float)qf[kk][e + 1] * a.scale_log2};
-                bf16x2 pk = __builtin_convertvector(two, bf16x2);
+                elem2 pk = __builtin_convertvector(two, elem2);
                 qf[kk][e] = pk[0];
                 qf[kk][e + 1] = pk[1];
             }
@@ -371,8 +370,8 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a, 
     q_load(q_row, KVRES ? true : q_ok);                  // (KVRES checks every loaded row against Sq itself)
     if (!KVRES) q_scale();
     // ---- DMA descriptors: one per operand, base = this (batch, head)
-    const __bf16* kp = a.k + (long long)b * a.k_bs + (long long)h * a.k_hs;
-    const __bf16* vp = a.vt + (long long)b * a.vt_bs + (long long)h * a.vt_hs;
+    const elem_t* kp = a.k + (long long)b * a.k_bs + (long long)h * a.k_hs;
+    const elem_t* vp = a.vt + (long long)b * a.vt_bs + (long long)h * a.vt_hs;
     const int k_bytes = (int)((((long long)a.Skv - 1) * a.k_ss + a.D) * 2);
     const int v_bytes = (int)((((long long)a.D - 1) * a.vt_ds + skv_pad8) * 2);
     const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, k_bytes, 0x00020000);
@@ -419,17 +418,17 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a, 
 #pragma unroll
     for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
     float m_run = 0.f, l_run = 0.f;                      // cinit == -m_run at all times
-    bf16x8 pf[4];
+    elem8 pf[4];
 
     // S^T = K.Q^T (+ C operand) of the tile in `stage`
     auto qk = [&](int stage, f32x16 (&s)[2]) {
         const char* kb = smem + stage * STAGE;
-        bf16x8 kf[2][KSTEPS];
+        elem8 kf[2][KSTEPS];
         auto read_k = [&](int t) {
             const int row = 32 * t + l31;
 #pragma unroll
             for (int kk = 0; kk < KSTEPS; ++kk)
-                kf[t][kk] = *reinterpret_cast<const bf16x8*>(kb + row * KROW + (((2 * kk + hi) ^ kswz(row)) << 4));
+                kf[t][kk] = *reinterpret_cast<const elem8*>(kb + row * KROW + (((2 * kk + hi) ^ kswz(row)) << 4));
         };
         read_k(0);
         if (!VLATE) read_k(1);
@@ -437,10 +436,10 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a, 
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             if (VLATE && t == 0) read_k(1);
-            s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][0], qf[0], cinit, 0, 0, 0);
+            s[t] = DM_MFMA_32x32x16(kf[t][0], qf[0], cinit);
 #pragma unroll
             for (int kk = 1; kk < KSTEPS; ++kk)
-                s[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t][kk], qf[kk], s[t], 0, 0, 0);
+                s[t] = DM_MFMA_32x32x16(kf[t][kk], qf[kk], s[t]);
         }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -448,13 +447,13 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a, 
     auto softmax_pv = [&](int j, int stage, bool first, f32x16 (&s)[2], auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         const char* vb = smem + stage * STAGE + KBYTES;
-        bf16x8 vf[DT][4];
+        elem8 vf[DT][4];
         auto read_v = [&](int dt) {
             const int row = 32 * dt + l31;
             const int sw = (row >> 1) & 7;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                vf[dt][ks] = *reinterpret_cast<const bf16x8*>(vb + row * VROW + (((2 * ks + hi) ^ sw) << 4));
+                vf[dt][ks] = *reinterpret_cast<const elem8*>(vb + row * VROW + (((2 * ks + hi) ^ sw) << 4));
         };
         if (!VLATE) {
 #pragma unroll
@@ -510,7 +509,7 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a, 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 f32x2 two = {s[t][8 * u + 2 * e], s[t][8 * u + 2 * e + 1]};
-                bf16x2 pk = __builtin_convertvector(two, bf16x2);
+                elem2 pk = __builtin_convertvector(two, elem2);
                 pf[ks][2 * e] = pk[0];
                 pf[ks][2 * e + 1] = pk[1];
             }
@@ -522,7 +521,7 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a, 
             if (VLATE && dt + 1 < DT) read_v(dt + 1);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][ks], pf[ks], o[dt], 0, 0, 0);
+                o[dt] = DM_MFMA_32x32x16(vf[dt][ks], pf[ks], o[dt]);
         }
         __builtin_amdgcn_s_setprio(0);
     };
@@ -538,13 +537,13 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a, 
                 for (int g = 0; g < 4; ++g) {
                     f32x2 x0 = {o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv};
                     f32x2 x1 = {o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
-                    bf16x2 y0 = __builtin_convertvector(x0, bf16x2), y1 = __builtin_convertvector(x1, bf16x2);
-                    bf16x4 y = {y0[0], y0[1], y1[0], y1[1]};
+                    elem2 y0 = __builtin_convertvector(x0, elem2), y1 = __builtin_convertvector(x1, elem2);
+                    elem4 y = {y0[0], y0[1], y1[0], y1[1]};
                     // head_dim 32 dt + 8 g + 4 hi .. +3: 16 B chunk 4 dt + g (swizzled by the row), half hi
-                    *reinterpret_cast<bf16x4*>(xw + l31 * 128 + (((4 * dt + g) ^ (l31 & 7)) << 4) + 8 * hi) = y;
+                    *reinterpret_cast<elem4*>(xw + l31 * 128 + (((4 * dt + g) ^ (l31 & 7)) << 4) + 8 * hi) = y;
                 }
             const int row0 = q_row - l31;
-            __bf16* op = a.out + (long long)b * a.o_bs + (long long)h * a.o_hs;
+            elem_t* op = a.out + (long long)b * a.o_bs + (long long)h * a.o_hs;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 8 * i + (lane >> 3);
@@ -554,7 +553,7 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a, 
             return;
         }
         if (q_ok) {
-            __bf16* op = a.out + (long long)b * a.o_bs + (long long)q_row * a.o_ss + (long long)h * a.o_hs;
+            elem_t* op = a.out + (long long)b * a.o_bs + (long long)q_row * a.o_ss + (long long)h * a.o_hs;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -563,9 +562,9 @@ __global__ __launch_bounds__(256, VLATE ? 3 : 2) void k_attn_fwd_v3(AttnArgs a, 
                     if (d < a.D) {
                         f32x2 x0 = {o[dt][4 * g] * inv, o[dt][4 * g + 1] * inv};
                         f32x2 x1 = {o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv};
-                        bf16x2 y0 = __builtin_convertvector(x0, bf16x2), y1 = __builtin_convertvector(x1, bf16x2);
-                        bf16x4 y = {y0[0], y0[1], y1[0], y1[1]};
-                        *reinterpret_cast<bf16x4*>(op + d) = y;
+                        elem2 y0 = __builtin_convertvector(x0, elem2), y1 = __builtin_convertvector(x1, elem2);
+                        elem4 y = {y0[0], y0[1], y1[0], y1[1]};
+                        *reinterpret_cast<elem4*>(op + d) = y;
                     }
                 }
         }
@@ -683,7 +682,9 @@ int launch_attn_v3(const AttnArgs& a, hipStream_t stream) {
 //   "staged" register-staged generic kernel (k_attn_fwd): any D <= 160 (the SD-1.5 heads of 40 / 80 / 160)
 // A forced family falls through to the next one when a shape is outside its domain.
 enum { kAttnAuto = 0, kAttnW128 = 1, kAttnW64 = 2, kAttnV3l = 3, kAttnStaged = 4 };
+#if !defined(DM_F16)
 static int g_attn_mode = -1;
+#endif
 static int attn_mode_from_name(const char* e) {
     if (!e || !strcmp(e, "auto")) return kAttnAuto;
     if (!strcmp(e, "w128")) return kAttnW128;
@@ -692,6 +693,11 @@ static int attn_mode_from_name(const char* e) {
     if (!strcmp(e, "staged")) return kAttnStaged;
     return -1;
 }
+#if defined(DM_F16)
+// one selection for the process: the f16 instantiation follows what dm_attention_select / the environment chose (bf16 object)
+extern "C" const char* dm_attention_selected(void);
+static int attn_mode() { return attn_mode_from_name(dm_attention_selected()); }
+#else
 static int attn_mode() {
     if (g_attn_mode < 0) {
         g_attn_mode = attn_mode_from_name(getenv("DREAMMAT_ATTN_KERNEL"));
@@ -700,6 +706,7 @@ static int attn_mode() {
     return g_attn_mode;
 }
 static const char* const kAttnNames[] = {"auto", "w128", "w64", "v3l", "staged"};
+#endif
 
 // the buffer-descriptor DMA addresses one (batch, head) operand with 32-bit byte offsets
 static bool attn_v3_ok(const AttnArgs& a) {
@@ -734,6 +741,7 @@ int launch_attn(const AttnArgs& a, hipStream_t stream) {
 
 extern "C" {
 
+#if !defined(DM_F16)
 // Selects the attention kernel family by name ("auto", "w128", "w64", "v3l", "staged"; NULL = DREAMMAT_ATTN_KERNEL / "auto") for
 // every later dm_attention_fwd_bf16 call of the process.  Returns DM_OK or DM_ERR_ARG for an unknown name.  Meant for
 // A/B measurements and for the parity tests, which run every family.
@@ -747,6 +755,7 @@ int dm_attention_select(const char* name) {
 
 // Name of the family the next dm_attention_fwd_bf16 call dispatches from (what dm_attention_select / the environment chose).
 const char* dm_attention_selected(void) { return kAttnNames[attn_mode()]; }
+#endif
 
 // q   [B, Sq, Hh, D]  via strides (q_bs, q_ss, q_hs), d contiguous
 // k   [B, Skv, Hh, D] via strides
@@ -765,14 +774,14 @@ static int attention_fwd(const void* q, const void* k, const void* vt, const voi
     if ((o_bs | o_ss | o_hs) & 3) return DM_ERR_ARG;
     if ((long long)B * Hh > 65535) return DM_ERR_UNSUPPORTED;
     AttnArgs a;
-    a.q = (const __bf16*)q; a.k = (const __bf16*)k; a.vt = (const __bf16*)vt; a.out = (__bf16*)out;
+    a.q = (const elem_t*)q; a.k = (const elem_t*)k; a.vt = (const elem_t*)vt; a.out = (elem_t*)out;
     a.q_bs = q_bs; a.q_ss = q_ss; a.q_hs = q_hs; a.k_bs = k_bs; a.k_ss = k_ss; a.k_hs = k_hs;
     a.vt_bs = vt_bs; a.vt_hs = vt_hs; a.vt_ds = vt_ds; a.o_bs = o_bs; a.o_ss = o_ss; a.o_hs = o_hs;
     a.B = B; a.Hh = Hh; a.Sq = Sq; a.Skv = Skv; a.D = D;
     a.scale_log2 = scale * 1.4426950408889634f;
     a.timeline = nullptr;
     a.lse = lse;
-    a.v_nat = (const __bf16*)v_nat;
+    a.v_nat = (const elem_t*)v_nat;
     const int mode = (lse || v_nat) ? kAttnStaged : attn_mode();     // row statistics / natural V: the generic kernel only
     // auto: the one-wave-per-SIMD kernel wherever a workgroup's 256 query rows are (nearly) filled and the sequence is long
     // enough to amortise its prologue (S >= 1024: 756 vs 738 TF/s at S = 1024, 1021 vs 980 at 4096, 981 vs 780 at batch 3;
@@ -791,7 +800,7 @@ static int attention_fwd(const void* q, const void* k, const void* vt, const voi
     return launch_attn<160>(a, stream);
 }
 
-int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* out, int B, int Hh, int Sq, int Skv,
+int DM_T(dm_attention_fwd_, )(const void* q, const void* k, const void* vt, void* out, int B, int Hh, int Sq, int Skv,
                           int D, long long q_bs, long long q_ss, long long q_hs, long long k_bs, long long k_ss,
                           long long k_hs, long long vt_bs, long long vt_hs, long long vt_ds, long long o_bs,
                           long long o_ss, long long o_hs, float scale, hipStream_t stream) {
@@ -803,7 +812,7 @@ int dm_attention_fwd_bf16(const void* q, const void* k, const void* vt, void* ou
 // transposed: the generic kernel reads its V^T fragments with the transposing LDS read), plus
 // lse [B, Hh, Sq] fp32 = rowmax + log2(rowsum) of the scaled scores in the log2 domain, from which the backward recomputes
 // the probabilities.  Always the register-staged generic kernel (the only one that keeps the unscaled running maximum).
-int dm_attention_fwd_lse_bf16(const void* q, const void* k, const void* v, void* out, float* lse, int B, int Hh, int Sq,
+int DM_T(dm_attention_fwd_lse_, )(const void* q, const void* k, const void* v, void* out, float* lse, int B, int Hh, int Sq,
                               int Skv, int D, long long q_bs, long long q_ss, long long q_hs, long long k_bs,
                               long long k_ss, long long k_hs, long long o_bs, long long o_ss, long long o_hs, float scale,
                               hipStream_t stream) {

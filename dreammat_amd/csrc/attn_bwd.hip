@@ -31,9 +31,9 @@ constexpr int kTile = 64;    // rows of the streamed operand per step
 constexpr int kOwn = 128;    // rows a workgroup owns (4 waves x 32)
 
 struct AttnBwdArgs {
-    const __bf16* q; const __bf16* k; const __bf16* v; const __bf16* o; const __bf16* dout;
+    const elem_t* q; const elem_t* k; const elem_t* v; const elem_t* o; const elem_t* dout;
     const float* lse; float* delta;
-    __bf16* dq; __bf16* dk; __bf16* dv;
+    elem_t* dq; elem_t* dk; elem_t* dv;
     long long q_bs, q_ss, q_hs;   // q, o, dout, dq  [B, Sq, Hh, D] by strides, d contiguous
     long long k_bs, k_ss, k_hs;   // k, v, dk, dv    [B, Skv, Hh, D]
     int B, Hh, Sq, Skv, D;
@@ -48,16 +48,15 @@ struct Lay {
     static constexpr int NCH = kTile * CPR / 256;   // 16 B chunks per thread per operand
 };
 
-__device__ __forceinline__ uint4 ld16g(const __bf16* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ uint4 ld16g(const elem_t* p) { return *reinterpret_cast<const uint4*>(p); }
 // A-operand fragment of X^T from the row-major tile of X: lane (m = column, hi) receives rows k0 .. k0 + 3 (first read) and
 // k0 + 8 .. k0 + 11 (second read) with k0 = 4 hi: the accumulator row order of one 16-wide k-step.  `p` = the lane's SOURCE
 // address (row 4 hi + (i >> 2), columns 16 g1 + 4 (i & 3) of the k-step / column tile), RROW = bytes per row.
 template <int RROW>
-__device__ __forceinline__ bf16x8 tr_frag(const char* p) {
-    typedef bf16x4 __attribute__((address_space(3))) * lds4;
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)const_cast<char*>(p));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4)const_cast<char*>(p + 8 * RROW));
-    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+__device__ __forceinline__ elem8 tr_frag(const char* p) {
+    const elem4 lo = dm_ds_read_tr16_b64(p);
+    const elem4 hi = dm_ds_read_tr16_b64(p + 8 * RROW);
+    return elem8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 template <int DP>
 __device__ __forceinline__ void write_rowmajor(char* dst, const uint4 (&reg)[Lay<DP>::NCH], int tid) {
@@ -70,7 +69,7 @@ __device__ __forceinline__ void write_rowmajor(char* dst, const uint4 (&reg)[Lay
 }
 // 64 rows x DP of a [rows, D] operand starting at row r0 (zeros past n_rows / past D)
 template <int DP>
-__device__ __forceinline__ void load_rows(uint4 (&reg)[Lay<DP>::NCH], const __bf16* base, long long row_stride, int r0,
+__device__ __forceinline__ void load_rows(uint4 (&reg)[Lay<DP>::NCH], const elem_t* base, long long row_stride, int r0,
                                           int n_rows, int D, int tid) {
     using L = Lay<DP>;
 #pragma unroll
@@ -83,28 +82,28 @@ __device__ __forceinline__ void load_rows(uint4 (&reg)[Lay<DP>::NCH], const __bf
 }
 // B-operand fragments of the rows a lane owns: X[row][16 kk + 8 hi .. + 7]
 template <int DP>
-__device__ __forceinline__ void load_own(bf16x8 (&f)[Lay<DP>::KSTEPS], const __bf16* rowp, bool ok, int D, int hi) {
+__device__ __forceinline__ void load_own(elem8 (&f)[Lay<DP>::KSTEPS], const elem_t* rowp, bool ok, int D, int hi) {
 #pragma unroll
     for (int kk = 0; kk < Lay<DP>::KSTEPS; ++kk) {
         const int d = 16 * kk + 8 * hi;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (ok && d < D) v = ld16g(rowp + d);
-        f[kk] = __builtin_bit_cast(bf16x8, v);
+        f[kk] = __builtin_bit_cast(elem8, v);
     }
 }
 // accumulator (32 rows x lane's column) -> two B-operand fragments (rows 0-15, 16-31 in accumulator order)
-__device__ __forceinline__ void pack_acc(const f32x16& s, bf16x8& lo, bf16x8& hi8) {
+__device__ __forceinline__ void pack_acc(const f32x16& s, elem8& lo, elem8& hi8) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         f32x2 a = {s[2 * e], s[2 * e + 1]}, b = {s[8 + 2 * e], s[8 + 2 * e + 1]};
-        bf16x2 pa = __builtin_convertvector(a, bf16x2), pb = __builtin_convertvector(b, bf16x2);
+        elem2 pa = __builtin_convertvector(a, elem2), pb = __builtin_convertvector(b, elem2);
         lo[2 * e] = pa[0]; lo[2 * e + 1] = pa[1];
         hi8[2 * e] = pb[0]; hi8[2 * e + 1] = pb[1];
     }
 }
 // lane's column of a [32 d-rows x 32] accumulator -> X[row][32 dt + ...] (bf16), scaled
 template <int DP>
-__device__ __forceinline__ void store_own(__bf16* rowp, const f32x16 (&acc)[Lay<DP>::DT], float scale, int D, int hi) {
+__device__ __forceinline__ void store_own(elem_t* rowp, const f32x16 (&acc)[Lay<DP>::DT], float scale, int D, int hi) {
 #pragma unroll
     for (int dt = 0; dt < Lay<DP>::DT; ++dt)
 #pragma unroll
@@ -113,9 +112,9 @@ __device__ __forceinline__ void store_own(__bf16* rowp, const f32x16 (&acc)[Lay<
             if (d < D) {
                 f32x2 x0 = {acc[dt][4 * g] * scale, acc[dt][4 * g + 1] * scale};
                 f32x2 x1 = {acc[dt][4 * g + 2] * scale, acc[dt][4 * g + 3] * scale};
-                bf16x2 y0 = __builtin_convertvector(x0, bf16x2), y1 = __builtin_convertvector(x1, bf16x2);
-                bf16x4 y = {y0[0], y0[1], y1[0], y1[1]};
-                *reinterpret_cast<bf16x4*>(rowp + d) = y;
+                elem2 y0 = __builtin_convertvector(x0, elem2), y1 = __builtin_convertvector(x1, elem2);
+                elem4 y = {y0[0], y0[1], y1[0], y1[1]};
+                *reinterpret_cast<elem4*>(rowp + d) = y;
             }
         }
 }
@@ -133,12 +132,12 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnBwdArgs a) {
     const bool q_ok = q_row < a.Sq;
     const long long q_off = (long long)b * a.q_bs + (long long)q_row * a.q_ss + (long long)h * a.q_hs;
 
-    bf16x8 qf[L::KSTEPS], dof[L::KSTEPS];
+    elem8 qf[L::KSTEPS], dof[L::KSTEPS];
     load_own<DP>(qf, a.q + q_off, q_ok, a.D, hi);
     load_own<DP>(dof, a.dout + q_off, q_ok, a.D, hi);
     float delta_q;
     {
-        bf16x8 of[L::KSTEPS];
+        elem8 of[L::KSTEPS];
         load_own<DP>(of, a.o + q_off, q_ok, a.D, hi);
         float part = 0.f;
 #pragma unroll
@@ -154,8 +153,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnBwdArgs a) {
         if (hi == 0) a.delta[row_id] = delta_q;
     }
 
-    const __bf16* kp = a.k + (long long)b * a.k_bs + (long long)h * a.k_hs;
-    const __bf16* vp = a.v + (long long)b * a.k_bs + (long long)h * a.k_hs;
+    const elem_t* kp = a.k + (long long)b * a.k_bs + (long long)h * a.k_hs;
+    const elem_t* vp = a.v + (long long)b * a.k_bs + (long long)h * a.k_hs;
     uint4 kreg[L::NCH], vreg[L::NCH];
     f32x16 dqT[L::DT];
 #pragma unroll
@@ -177,7 +176,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnBwdArgs a) {
             load_rows<DP>(kreg, kp, a.k_ss, (j + 1) * kTile, a.Skv, a.D, tid);
             load_rows<DP>(vreg, vp, a.k_ss, (j + 1) * kTile, a.Skv, a.D, tid);
         }
-        bf16x8 dsf[4];
+        elem8 dsf[4];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x16 s, dp;
@@ -185,13 +184,13 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnBwdArgs a) {
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int kk = 0; kk < L::KSTEPS; ++kk) {
-                bf16x8 kf = *reinterpret_cast<const bf16x8*>(kb + (32 * t + l31) * L::RROW + 32 * kk + 16 * hi);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s, 0, 0, 0);
+                elem8 kf = *reinterpret_cast<const elem8*>(kb + (32 * t + l31) * L::RROW + 32 * kk + 16 * hi);
+                s = DM_MFMA_32x32x16(kf, qf[kk], s);
             }
 #pragma unroll
             for (int kk = 0; kk < L::KSTEPS; ++kk) {
-                bf16x8 vf = *reinterpret_cast<const bf16x8*>(vb + (32 * t + l31) * L::RROW + 32 * kk + 16 * hi);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[kk], dp, 0, 0, 0);
+                elem8 vf = *reinterpret_cast<const elem8*>(vb + (32 * t + l31) * L::RROW + 32 * kk + 16 * hi);
+                dp = DM_MFMA_32x32x16(vf, dof[kk], dp);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -204,8 +203,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(AttnBwdArgs a) {
         for (int dt = 0; dt < L::DT; ++dt)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 ktf = tr_frag<L::RROW>(kb + tr_off + ks * 16 * L::RROW + dt * 64);
-                dqT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf[ks], dqT[dt], 0, 0, 0);
+                const elem8 ktf = tr_frag<L::RROW>(kb + tr_off + ks * 16 * L::RROW + dt * 64);
+                dqT[dt] = DM_MFMA_32x32x16(ktf, dsf[ks], dqT[dt]);
             }
         if (j + 1 < n_tiles) {
             char* nb = smem + ((j + 1) & 1) * BUF;
@@ -230,12 +229,12 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnBwdArgs a) {
     const bool kv_ok = kv_row < a.Skv;
     const long long k_off = (long long)b * a.k_bs + (long long)kv_row * a.k_ss + (long long)h * a.k_hs;
 
-    bf16x8 kf[L::KSTEPS], vf[L::KSTEPS];
+    elem8 kf[L::KSTEPS], vf[L::KSTEPS];
     load_own<DP>(kf, a.k + k_off, kv_ok, a.D, hi);
     load_own<DP>(vf, a.v + k_off, kv_ok, a.D, hi);
 
-    const __bf16* qp = a.q + (long long)b * a.q_bs + (long long)h * a.q_hs;
-    const __bf16* dop = a.dout + (long long)b * a.q_bs + (long long)h * a.q_hs;
+    const elem_t* qp = a.q + (long long)b * a.q_bs + (long long)h * a.q_hs;
+    const elem_t* dop = a.dout + (long long)b * a.q_bs + (long long)h * a.q_hs;
     const float* lsep = a.lse + ((long long)b * a.Hh + h) * a.Sq;
     const float* delp = a.delta + ((long long)b * a.Hh + h) * a.Sq;
     uint4 qreg[L::NCH], doreg[L::NCH];
@@ -275,7 +274,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnBwdArgs a) {
             load_rows<DP>(doreg, dop, a.q_ss, (j + 1) * kTile, a.Sq, a.D, tid);
             load_stat((j + 1) * kTile);
         }
-        bf16x8 pf[4], dsf[4];
+        elem8 pf[4], dsf[4];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             f32x16 s, dp;
@@ -283,13 +282,13 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnBwdArgs a) {
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int kk = 0; kk < L::KSTEPS; ++kk) {
-                bf16x8 qa = *reinterpret_cast<const bf16x8*>(qb + (32 * t + l31) * L::RROW + 32 * kk + 16 * hi);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], s, 0, 0, 0);
+                elem8 qa = *reinterpret_cast<const elem8*>(qb + (32 * t + l31) * L::RROW + 32 * kk + 16 * hi);
+                s = DM_MFMA_32x32x16(qa, kf[kk], s);
             }
 #pragma unroll
             for (int kk = 0; kk < L::KSTEPS; ++kk) {
-                bf16x8 da = *reinterpret_cast<const bf16x8*>(dob + (32 * t + l31) * L::RROW + 32 * kk + 16 * hi);
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kk], dp, 0, 0, 0);
+                elem8 da = *reinterpret_cast<const elem8*>(dob + (32 * t + l31) * L::RROW + 32 * kk + 16 * hi);
+                dp = DM_MFMA_32x32x16(da, vf[kk], dp);
             }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {       // accumulator register 4g + e = query row 32t + 8g + 4hi + e
@@ -309,10 +308,10 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(AttnBwdArgs a) {
         for (int dt = 0; dt < L::DT; ++dt)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 dta = tr_frag<L::RROW>(dob + tr_off + ks * 16 * L::RROW + dt * 64);
-                dvT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dta, pf[ks], dvT[dt], 0, 0, 0);
-                const bf16x8 qta = tr_frag<L::RROW>(qb + tr_off + ks * 16 * L::RROW + dt * 64);
-                dkT[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qta, dsf[ks], dkT[dt], 0, 0, 0);
+                const elem8 dta = tr_frag<L::RROW>(dob + tr_off + ks * 16 * L::RROW + dt * 64);
+                dvT[dt] = DM_MFMA_32x32x16(dta, pf[ks], dvT[dt]);
+                const elem8 qta = tr_frag<L::RROW>(qb + tr_off + ks * 16 * L::RROW + dt * 64);
+                dkT[dt] = DM_MFMA_32x32x16(qta, dsf[ks], dkT[dt]);
             }
         if (j + 1 < n_tiles) {
             char* nb = smem + ((j + 1) & 1) * BUF;
@@ -370,9 +369,9 @@ int dm_attention_bwd_bf16(const void* q, const void* k, const void* v, const voi
     if ((q_bs | q_ss | q_hs | k_bs | k_ss | k_hs) & 7) return DM_ERR_ARG;
     if ((long long)B * Hh > 65535) return DM_ERR_UNSUPPORTED;
     AttnBwdArgs a;
-    a.q = (const __bf16*)q; a.k = (const __bf16*)k; a.v = (const __bf16*)v; a.o = (const __bf16*)out;
-    a.dout = (const __bf16*)dout; a.lse = lse; a.delta = delta;
-    a.dq = (__bf16*)dq; a.dk = (__bf16*)dk; a.dv = (__bf16*)dv;
+    a.q = (const elem_t*)q; a.k = (const elem_t*)k; a.v = (const elem_t*)v; a.o = (const elem_t*)out;
+    a.dout = (const elem_t*)dout; a.lse = lse; a.delta = delta;
+    a.dq = (elem_t*)dq; a.dk = (elem_t*)dk; a.dv = (elem_t*)dv;
     a.q_bs = q_bs; a.q_ss = q_ss; a.q_hs = q_hs; a.k_bs = k_bs; a.k_ss = k_ss; a.k_hs = k_hs;
     a.B = B; a.Hh = Hh; a.Sq = Sq; a.Skv = Skv; a.D = D;
     a.scale = scale; a.scale_log2 = scale * 1.4426950408889634f;

@@ -1,0 +1,361 @@
+// MX-FP8 flash attention forward for 64-wide heads on the block-scaled matrix instruction of gfx950
+// (v_mfma_scale_f32_32x32x64_f8f6f4, 2x the bf16 / f16 MFMA rate) -- BASELINE.json configs[4] "fp16 UNet + fp8 MFMA attention":
+// the S = 16384 self-attention of the UNet / ControlNet at 1024^2 (diffusers' Attention, reached from
+// threestudio/models/guidance/dreammat_guidance.py:205-241, 261-282).  Same interface as dm_attention_fwd_bf16 / _f16: Q, K
+// [B, S, Hh, 64] and V^T [B, Hh, 64, Skv] arrive as 16-bit tensors, the output is a 16-bit tensor; the 8-bit operands are an
+// internal format.
+//
+// Format.  OCP e4m3 elements with one power-of-two scale (E8M0 byte) per 32 consecutive elements ALONG THE CONTRACTED
+// DIMENSION -- the MX block the instruction dequantises in hardware: lane l of a 32x32x64 operand holds row l % 32, 32 bytes =
+// k-block l / 32, and its scale byte multiplies exactly those 32 bytes.
+//   Q' = Q * softmax_scale * log2 e and K: blocks of 32 along the head dimension (2 per row), scale = 2^(E - 8) with E the
+//        exponent of the block's largest magnitude, so that the scaled block lies in [128, 256) < 448 (no saturation);
+//   V^T: blocks of 32 kv positions of one channel;
+//   P:   exp2(s - m + 8) in [0, 256] with the constant scale 2^-8 (values below 2^-17 of the row maximum flush to zero).
+// Two pre-passes (k_fp8_quant_rows for Q and K, k_fp8_quant_vt for V^T) write the 8-bit operands + scale bytes into a
+// workspace: 1 byte per element instead of 2 on every re-read of K / V by the query blocks.  V^T is stored tile-major
+// ([kv tile of 64][channel][64 bytes]) with the 32 bytes of a block PERMUTED to the order in which the probabilities come
+// out of the first product (below), so that the second product needs no data movement beyond one v_permlane32_swap per dword.
+//
+// Kernel.  A workgroup = 4 waves x 32 query rows, no LDS, no barrier: K / V^T tiles are 4 KB each and come straight from L2 as
+// two 16-byte loads per lane and operand (the 4 waves of a workgroup and the workgroups of a (batch, head) on one XCD share
+// them there), double-buffered in registers.  Per 64-row kv tile and wave: 2 MFMAs form S^T = K.Q'^T (two 32 x 32 tiles, the
+// whole head dimension in one instruction each), the textbook online softmax runs on the 32 scores a lane holds, the
+// probabilities are packed 4 per dword, and 2 MFMAs add V^T.P^T to the two 32 x 32 halves of O^T.
+//   S^T lane (q = l % 32, hi = l / 32) register r of tile t  <->  kv = 32 t + 4 hi + (r & 3) + 8 (r >> 2):
+//   the B operand of V^T.P^T wants, in lane (q, H), the 32 probabilities of kv block H.  Lane (q, 0) owns half of block 0 and
+//   half of block 1, lane (q, 1) the other halves: v_permlane32_swap(tile-0 dword g, tile-1 dword g) hands each lane the
+//   missing half.  Byte position 4 g + e of the operand then is kv 8 g + e, position 16 + 4 g + e is kv 8 g + 4 + e -- the
+//   permutation k_fp8_quant_vt applies to V^T's bytes (a contraction only needs A and B to agree position by position).
+// What bounds it: per tile a wave issues 4 MFMAs of 64 cycles (256) beside 64 v_exp_f32, 64 v_sub, 64 v_max, 64 v_add and 32
+// v_cvt_pk_fp8_f32 -- the softmax, not the matrix pipe (DESIGN.md section 3e has the measurement).
+#include <algorithm>
+#include <cstdint>
+
+#include "dm_common.h"
+
+namespace {
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct Fp8Args {
+    const void* q; const void* k; const void* vt; void* out;
+    long long q_bs, q_ss, q_hs, k_bs, k_ss, k_hs, vt_bs, vt_hs, vt_ds, o_bs, o_ss, o_hs;       // element strides
+    int B, Hh, Sq, Skv;
+    float scale_log2;
+    unsigned char *q8, *qs, *k8, *ks, *v8, *vs;
+};
+
+template <typename T> struct Vec8 { typedef T type __attribute__((ext_vector_type(8))); };
+template <typename T> struct Vec4 { typedef T type __attribute__((ext_vector_type(4))); };
+
+// E8M0 byte of the block scale 2^e that brings a block with largest magnitude `amax` into [128, 256)
+__device__ __forceinline__ int mx_scale_exp(float amax) {
+    return amax > 0.f ? __builtin_amdgcn_frexp_expf(amax) - 8 : 0;       // amax = f 2^E, f in [0.5, 1): amax 2^-(E-8) = f 2^8
+}
+__device__ __forceinline__ int e8m0(int e) { return min(max(e + 127, 0), 254); }
+
+// 32 fp32 values of one MX block -> 8 dwords of e4m3, byte i = value order[i]
+template <bool PERMUTE>
+__device__ __forceinline__ void pack_block(const float (&v)[32], int e, int (&out)[8]) {
+    // (the E8M0 byte may have been clamped: scale with the exponent the byte really encodes)
+    const int eb = e8m0(e) - 127;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        float x[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int pos = 4 * d + b;
+            // PERMUTE: position 4 g + b <- element 8 g + b, position 16 + 4 g + b <- element 8 g + 4 + b (see the header)
+            const int src = PERMUTE ? (pos < 16 ? 8 * (pos >> 2) + (pos & 3) : 8 * ((pos - 16) >> 2) + 4 + (pos & 3)) : pos;
+            x[b] = __builtin_ldexpf(v[src], -eb);
+        }
+        int w = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], 0, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], w, true);
+        out[d] = w;
+    }
+}
+
+// Q / K: src [B, S, Hh, 64] through (bs, ss, hs) -> dst8 [B Hh][S][64] bytes, scales [B Hh][S][2].  One thread = one (row, half).
+template <typename T>
+__global__ __launch_bounds__(256) void k_fp8_quant_rows(const T* __restrict__ src, long long bs, long long ss, long long hs, int B, int Hh,
+                                                         int S, float mult, unsigned char* __restrict__ dst8, unsigned char* __restrict__ dsts) {
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = (long long)B * Hh * S * 2;
+    if (id >= n) return;
+    const int half = (int)(id & 1);
+    const long long row = id >> 1;                        // (b Hh + h) S + s
+    const int s = (int)(row % S);
+    const long long bh = row / S;
+    const int h = (int)(bh % Hh), b = (int)(bh / Hh);
+    const T* p = src + b * bs + (long long)s * ss + (long long)h * hs + 32 * half;
+    typedef typename Vec8<T>::type T8;
+    float v[32];
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const T8 t = *reinterpret_cast<const T8*>(p + 8 * c);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[8 * c + i] = (float)t[i] * mult; amax = fmaxf(amax, fabsf(v[8 * c + i])); }
+    }
+    const int e = mx_scale_exp(amax);
+    int w[8];
+    pack_block<false>(v, e, w);
+    i32x4* o = reinterpret_cast<i32x4*>(dst8 + row * 64 + 32 * half);
+    o[0] = i32x4{w[0], w[1], w[2], w[3]};
+    o[1] = i32x4{w[4], w[5], w[6], w[7]};
+    dsts[row * 2 + half] = (unsigned char)e8m0(e);
+}
+
+// V^T: src [B, Hh, 64, Skv] through (bs, hs, ds), kv contiguous -> dst8 [B Hh][Skv / 64][64 channels][64 bytes] (block bytes
+// permuted), scales [B Hh][Skv / 64][64][2].  One thread = one (channel, block of 32 kv).
+template <typename T>
+__global__ __launch_bounds__(256) void k_fp8_quant_vt(const T* __restrict__ src, long long bs, long long hs, long long ds, int B, int Hh, int Skv,
+                                                       unsigned char* __restrict__ dst8, unsigned char* __restrict__ dsts) {
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int nblk = Skv / 32;
+    const long long n = (long long)B * Hh * 64 * nblk;
+    if (id >= n) return;
+    // consecutive threads walk the kv blocks of one channel (coalesced 64-byte reads)
+    const int blk = (int)(id % nblk);
+    const long long r = id / nblk;
+    const int d = (int)(r & 63);
+    const long long bh = r >> 6;
+    const int h = (int)(bh % Hh), b = (int)(bh / Hh);
+    const T* p = src + b * bs + (long long)h * hs + (long long)d * ds + 32LL * blk;
+    typedef typename Vec8<T>::type T8;
+    float v[32];
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const T8 t = *reinterpret_cast<const T8*>(p + 8 * c);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v[8 * c + i] = (float)t[i]; amax = fmaxf(amax, fabsf(v[8 * c + i])); }
+    }
+    const int e = mx_scale_exp(amax);
+    int w[8];
+    pack_block<true>(v, e, w);
+    const int tile = blk >> 1, hh = blk & 1;
+    const long long slot = (bh * (Skv / 64) + tile) * 64 + d;
+    i32x4* o = reinterpret_cast<i32x4*>(dst8 + slot * 64 + 32 * hh);
+    o[0] = i32x4{w[0], w[1], w[2], w[3]};
+    o[1] = i32x4{w[4], w[5], w[6], w[7]};
+    dsts[slot * 2 + hh] = (unsigned char)e8m0(e);
+}
+
+constexpr int kRowsPerWg = 128;      // 4 waves x 32 query rows
+constexpr int kPScaleByte = 127 - 8; // E8M0 of the constant 2^-8 that undoes the 2^8 inside the stored probabilities
+
+struct KvFrag {
+    i32x8 k[2]; int ks[2];           // K rows 32 t + l31 of the tile, bytes 32 hi ..; their scale bytes
+    i32x8 v[2]; int vs[2];           // V^T channels 32 f + l31, (permuted) bytes of kv block hi; their scale bytes
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_attn_fwd_fp8(Fp8Args a) {
+    const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // 1-D grid, XCD-aware (block b runs on XCD b % 8): all query blocks of one (batch, head) run on one XCD, whose L2 then serves
+    // that head's 8-bit K / V^T to every one of them
+    int bh, qblk;
+    {
+        const int nq = a.Sq / kRowsPerWg;
+        const int BH = a.B * a.Hh, id = blockIdx.x;
+        if ((BH & 7) == 0) {
+            const int j = id >> 3;
+            bh = (j / nq) * 8 + (id & 7);
+            qblk = j - (j / nq) * nq;
+        } else {
+            bh = id / nq;
+            qblk = id - bh * nq;
+        }
+    }
+    const int n_tiles = a.Skv / 64;
+    const long long qrow = (long long)bh * a.Sq + qblk * kRowsPerWg + wave * 32 + l31;
+
+    const i32x4* qp = reinterpret_cast<const i32x4*>(a.q8 + qrow * 64 + 32 * hi);
+    const i32x4 q0 = qp[0], q1 = qp[1];
+    const i32x8 qB = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+    const int qsc = a.qs[qrow * 2 + hi];
+
+    const unsigned char* k8 = a.k8 + ((long long)bh * a.Skv + l31) * 64 + 32 * hi;
+    const unsigned char* ksc = a.ks + ((long long)bh * a.Skv + l31) * 2 + hi;
+    const unsigned char* v8 = a.v8 + ((long long)bh * n_tiles * 64 + l31) * 64 + 32 * hi;
+    const unsigned char* vsc = a.vs + ((long long)bh * n_tiles * 64 + l31) * 2 + hi;
+    auto load_tile = [&](int j, KvFrag& f) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const i32x4* p = reinterpret_cast<const i32x4*>(k8 + ((long long)j * 64 + 32 * t) * 64);
+            const i32x4 lo = p[0], up = p[1];
+            f.k[t] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+            f.ks[t] = ksc[((long long)j * 64 + 32 * t) * 2];
+            const i32x4* pv = reinterpret_cast<const i32x4*>(v8 + ((long long)j * 64 + 32 * t) * 64);
+            const i32x4 vlo = pv[0], vup = pv[1];
+            f.v[t] = i32x8{vlo[0], vlo[1], vlo[2], vlo[3], vup[0], vup[1], vup[2], vup[3]};
+            f.vs[t] = vsc[((long long)j * 64 + 32 * t) * 2];
+        }
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[f][r] = 0.f;
+    float m = -INFINITY, l = 0.f;        // running maximum (log2 domain) and sum of this lane's query row; both lanes of a row agree on m
+
+    auto tile_body = [&](const KvFrag& f) __attribute__((always_inline)) {
+        f32x16 s[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            // S^T[kv][q] = sum_d K[kv][d] Q'[q][d]: A = K rows (fp8), B = Q' rows (fp8), both with their block scales
+            s[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f.k[t], qB, z, 0, 0, 0, f.ks[t], 0, qsc);
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m, mx);
+        if (__any(m_new > m)) {          // (first tile: every row; later: only when a row's maximum moves)
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+#pragma unroll
+            for (int ff = 0; ff < 2; ++ff)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[ff][r] *= alpha;
+            l *= alpha;
+            m = m_new;
+        }
+        const float shift = m - 8.f;     // the stored probability is exp2(s - m) 2^8
+        int pt[2][4];
+        float ls = 0.f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float p[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { p[e] = __builtin_amdgcn_exp2f(s[t][4 * g + e] - shift); ls += p[e]; }
+                int w = __builtin_amdgcn_cvt_pk_fp8_f32(p[0], p[1], 0, false);
+                pt[t][g] = __builtin_amdgcn_cvt_pk_fp8_f32(p[2], p[3], w, true);
+            }
+        l += ls;
+        // lanes 0-31 keep their tile-0 dwords and receive the partner's, lanes 32-63 likewise for tile 1 (see the header)
+        i32x8 pB;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)pt[0][g], (unsigned)pt[1][g], false, false);
+            pB[g] = (int)sw[0];
+            pB[4 + g] = (int)sw[1];
+        }
+#pragma unroll
+        for (int ff = 0; ff < 2; ++ff)   // O^T[d][q] += sum_kv V^T[d][kv] P[q][kv]
+            o[ff] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f.v[ff], pB, o[ff], 0, 0, 0, f.vs[ff], 0, kPScaleByte);
+    };
+
+    KvFrag fa, fb;
+    load_tile(0, fa);
+    int j = 0;
+    for (; j + 2 <= n_tiles; j += 2) {
+        load_tile(j + 1, fb);
+        tile_body(fa);
+        if (j + 2 < n_tiles) load_tile(j + 2, fa);
+        tile_body(fb);
+    }
+    if (j < n_tiles) tile_body(fa);
+
+    const float lt = l + __shfl_xor(l, 32);
+    const float inv = 256.f / lt;         // the probabilities carried 2^8
+    // O^T lane (q, hi), fragment f, register r = channel 32 f + 8 (r >> 2) + 4 hi + (r & 3): four consecutive channels per group
+    const int bq = bh / a.Hh, hq = bh - bq * a.Hh;
+    T* op = reinterpret_cast<T*>(a.out) + bq * a.o_bs + (long long)(qblk * kRowsPerWg + wave * 32 + l31) * a.o_ss + (long long)hq * a.o_hs;
+    typedef typename Vec4<T>::type T4;
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            T4 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[e] = (T)(o[f][4 * g + e] * inv);
+            *reinterpret_cast<T4*>(op + 32 * f + 8 * g + 4 * hi) = w;
+        }
+}
+
+size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+struct Fp8Ws { size_t q8, qs, k8, ks, v8, vs, total; };
+Fp8Ws ws_layout(int B, int Hh, int Sq, int Skv) {
+    const size_t bh = (size_t)B * Hh;
+    Fp8Ws w;
+    size_t off = 0;
+    w.q8 = off; off += align256(bh * Sq * 64);
+    w.qs = off; off += align256(bh * Sq * 2);
+    w.k8 = off; off += align256(bh * Skv * 64);
+    w.ks = off; off += align256(bh * Skv * 2);
+    w.v8 = off; off += align256(bh * Skv * 64);
+    w.vs = off; off += align256(bh * Skv * 2);
+    w.total = off;
+    return w;
+}
+
+template <typename T>
+int launch_fp8(Fp8Args& a, hipStream_t stream) {
+    DM_ENTER();
+    const long long nq = (long long)a.B * a.Hh * a.Sq * 2, nk = (long long)a.B * a.Hh * a.Skv * 2, nv = (long long)a.B * a.Hh * 64 * (a.Skv / 32);
+    hipLaunchKernelGGL(k_fp8_quant_rows<T>, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, (const T*)a.q, a.q_bs, a.q_ss, a.q_hs, a.B,
+                       a.Hh, a.Sq, a.scale_log2, a.q8, a.qs);
+    hipLaunchKernelGGL(k_fp8_quant_rows<T>, dim3((unsigned)((nk + 255) / 256)), dim3(256), 0, stream, (const T*)a.k, a.k_bs, a.k_ss, a.k_hs, a.B,
+                       a.Hh, a.Skv, 1.0f, a.k8, a.ks);
+    hipLaunchKernelGGL(k_fp8_quant_vt<T>, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, stream, (const T*)a.vt, a.vt_bs, a.vt_hs, a.vt_ds, a.B,
+                       a.Hh, a.Skv, a.v8, a.vs);
+    DM_LAUNCH_CHECK();
+    const long long blocks = (long long)a.B * a.Hh * (a.Sq / kRowsPerWg);
+    hipLaunchKernelGGL(k_attn_fwd_fp8<T>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// bytes of the 8-bit operand workspace of dm_attention_fwd_fp8 for these sizes (0: the shape is not served)
+size_t dm_attention_fp8_workspace_bytes(int B, int Hh, int Sq, int Skv) {
+    if (B <= 0 || Hh <= 0 || Sq <= 0 || Skv <= 0 || Sq % kRowsPerWg != 0 || Skv % 64 != 0) return 0;
+    return ws_layout(B, Hh, Sq, Skv).total;
+}
+
+// softmax(q k^T scale) v with the two matrix products on the MX-FP8 matrix instruction.  q, k, vt, out: the tensors and strides of
+// dm_attention_fwd_bf16 (include/dreammat_hip.h) with D = 64; elem_f16 = 0: bf16 tensors, 1: IEEE half.  Sq % 128 == 0,
+// Skv % 64 == 0 (self-attention of the 64-wide SD-2.1 heads; anything else: DM_ERR_UNSUPPORTED, the caller keeps the 16-bit
+// kernels).  ws: dm_attention_fp8_workspace_bytes(B, Hh, Sq, Skv) bytes, 256-byte aligned, scratch.
+int dm_attention_fwd_fp8(const void* q, const void* k, const void* vt, void* out, int B, int Hh, int Sq, int Skv, int D, long long q_bs,
+                         long long q_ss, long long q_hs, long long k_bs, long long k_ss, long long k_hs, long long vt_bs, long long vt_hs,
+                         long long vt_ds, long long o_bs, long long o_ss, long long o_hs, float scale, int elem_f16, void* ws, size_t ws_bytes,
+                         hipStream_t stream) {
+    if (!q || !k || !vt || !out || !ws || B <= 0 || Hh <= 0 || Sq <= 0 || Skv <= 0) return DM_ERR_ARG;
+    if (D != 64 || Sq % kRowsPerWg != 0 || Skv % 64 != 0) return DM_ERR_UNSUPPORTED;
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt | (uintptr_t)ws) & 15 || ((uintptr_t)out & 7)) return DM_ERR_ARG;
+    if ((q_bs | q_ss | q_hs | k_bs | k_ss | k_hs | vt_bs | vt_hs | vt_ds) & 7) return DM_ERR_ARG;
+    if ((o_bs | o_ss | o_hs) & 3) return DM_ERR_ARG;
+    if ((long long)B * Hh * (Sq / kRowsPerWg) > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
+    const Fp8Ws w = ws_layout(B, Hh, Sq, Skv);
+    if (ws_bytes < w.total) return DM_ERR_WORKSPACE;
+    Fp8Args a;
+    a.q = q; a.k = k; a.vt = vt; a.out = out;
+    a.q_bs = q_bs; a.q_ss = q_ss; a.q_hs = q_hs; a.k_bs = k_bs; a.k_ss = k_ss; a.k_hs = k_hs;
+    a.vt_bs = vt_bs; a.vt_hs = vt_hs; a.vt_ds = vt_ds; a.o_bs = o_bs; a.o_ss = o_ss; a.o_hs = o_hs;
+    a.B = B; a.Hh = Hh; a.Sq = Sq; a.Skv = Skv;
+    a.scale_log2 = scale * 1.4426950408889634f;
+    unsigned char* base = (unsigned char*)ws;
+    a.q8 = base + w.q8; a.qs = base + w.qs; a.k8 = base + w.k8; a.ks = base + w.ks; a.v8 = base + w.v8; a.vs = base + w.vs;
+    return elem_f16 ? launch_fp8<_Float16>(a, stream) : launch_fp8<__bf16>(a, stream);
+}
+
+}  // extern "C"

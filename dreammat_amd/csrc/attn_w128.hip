@@ -84,8 +84,8 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
     const int row0 = qblk * kRowsPerWg + wave * kRowsPerWave;          // first query row of this wave
 
     // ---- LDS-DMA: one descriptor per operand (base = this batch / head), per-lane offsets loop-invariant
-    const __bf16* kp = a.k + (long long)b * a.k_bs + (long long)h * a.k_hs;
-    const __bf16* vp = a.vt + (long long)b * a.vt_bs + (long long)h * a.vt_hs;
+    const elem_t* kp = a.k + (long long)b * a.k_bs + (long long)h * a.k_hs;
+    const elem_t* vp = a.vt + (long long)b * a.vt_bs + (long long)h * a.vt_hs;
     const int k_bytes = (int)((((long long)a.Skv - 1) * a.k_ss + 64) * 2);
     const int v_bytes = (int)((63LL * a.vt_ds + a.Skv) * 2);
     const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, k_bytes, 0x00020000);
@@ -120,18 +120,18 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
 #pragma unroll
     for (int t = 0; t < PD + 2; ++t) issue(t, t);
     // ---- Q' fragments (B operand of S^T = K.Q'^T): lane holds Q'[row0 + 32 qb + l31][16 kk + 8 hi .. +7]
-    bf16x8 qf[NQ][4];
+    elem8 qf[NQ][4];
 #pragma unroll
     for (int qb = 0; qb < NQ; ++qb) {
         const int row = min(row0 + 32 * qb + l31, a.Sq - 1);     // rows past the end duplicate the last one (never stored)
-        const __bf16* qp = a.q + (long long)b * a.q_bs + (long long)row * a.q_ss + (long long)h * a.q_hs;
+        const elem_t* qp = a.q + (long long)b * a.q_bs + (long long)row * a.q_ss + (long long)h * a.q_hs;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            qf[qb][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qp + 16 * kk + 8 * hi));
+            qf[qb][kk] = __builtin_bit_cast(elem8, *reinterpret_cast<const uint4*>(qp + 16 * kk + 8 * hi));
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
                 f32x2 two = {(float)qf[qb][kk][e] * a.scale_log2, (float)qf[qb][kk][e + 1] * a.scale_log2};
-                bf16x2 pk = __builtin_convertvector(two, bf16x2);
+                elem2 pk = __builtin_convertvector(two, elem2);
                 qf[qb][kk][e] = pk[0];
                 qf[qb][kk][e + 1] = pk[1];
             }
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
     // Q' moves to the accumulator half ONCE, explicitly: every later use is an "a" operand of an asm MFMA.  (Left to the register
     // allocator, a value with one VGPR-class use -- a builtin MFMA in the prologue -- stayed in VGPRs / scratch and was copied
     // into AGPRs in front of every tile: 64 v_accvgpr_write + 1200 scratch accesses per tile at NQ = 4.)
-    bf16x8 qa[NQ][4];
+    elem8 qa[NQ][4];
 #pragma unroll
     for (int qb = 0; qb < NQ; ++qb)
 #pragma unroll
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
     int off4[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) off4[i] = l31 * 128 + ((((2 * i + hi) ^ ((l31 >> 1) & 7))) << 4);
-    auto frag = [&](const char* base, int off) { return *reinterpret_cast<const bf16x8*>(base + off); };
+    auto frag = [&](const char* base, int off) { return *reinterpret_cast<const elem8*>(base + off); };
     // The loop is unrolled over the ring so that every stage is a compile-time constant: a fragment read is then ONE
     // ds_read_b128 with an immediate offset on a loop-invariant address register (8 v_add_u32 + ~20 SALU per tile before).
     // A DS offset has 16 bits; stage 4 lies past it and gets its own address registers.
@@ -165,8 +165,8 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
     for (int i = 0; i < 4; ++i) { fb[i] = smem + off4[i]; fb4[i] = smem + off4[i] + 65536; }
     auto sfrag = [&](auto stage_tag, int i, int off) __attribute__((always_inline)) {       // fragment i of `stage`, `off` bytes into the stage
         constexpr int ST = decltype(stage_tag)::value;
-        if (ST * kStage + 12288 + 4096 <= 65536) return *reinterpret_cast<const bf16x8*>(fb[i] + ST * kStage + off);
-        return *reinterpret_cast<const bf16x8*>(fb4[i] + (ST * kStage - 65536) + off);
+        if (ST * kStage + 12288 + 4096 <= 65536) return *reinterpret_cast<const elem8*>(fb[i] + ST * kStage + off);
+        return *reinterpret_cast<const elem8*>(fb4[i] + (ST * kStage - 65536) + off);
     };
 
     // ---- state
@@ -193,30 +193,30 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
     // fragment multiplies four query blocks in consecutive chunks and then idles for most of a tile.  JIT = a rotation of 4 K
     // fragments (the one of "pair" g = 2 p / NQ sits in kr[g & 3] and is loaded two pairs = 16 chunks ahead) and a double buffer
     // of the two V^T fragments of a k-step (vr[ks & 1][dt], loaded a k-step ahead): 32 registers.
-    bf16x8 kf[JIT ? 1 : 8], vf[2][JIT ? 1 : 4], pf[2];   // K fragments (t*4+kk), V^T fragments [dt][ks], packed P of the slice in flight (two buffers)
-    bf16x8 kr[4], vr[2][2];
+    elem8 kf[JIT ? 1 : 8], vf[2][JIT ? 1 : 4], pf[2];   // K fragments (t*4+kk), V^T fragments [dt][ks], packed P of the slice in flight (two buffers)
+    elem8 kr[4], vr[2][2];
     float lA[NQ], lB[NQ];
 #pragma unroll
     for (int qb = 0; qb < NQ; ++qb) lA[qb] = lB[qb] = 0.f;
     bool bad = false;
     // every MFMA of the kernel: A / B operands from the accumulator half ("a"), so that hipcc keeps Q', K and V^T there
-    auto qk_head = [](f32x16& d, const bf16x8& ka, const bf16x8& qb_, const f32x16& c) {     // chain head: D = K.Q'^T + C (distinct registers)
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "a"(ka), "a"(qb_), "v"(c));
+    auto qk_head = [](f32x16& d, const elem8& ka, const elem8& qb_, const f32x16& c) {     // chain head: D = K.Q'^T + C (distinct registers)
+        asm volatile(DM_MFMA_ASM " %0, %1, %2, %3" : "=&v"(d) : "a"(ka), "a"(qb_), "v"(c));
     };
-    auto qk_acc = [](f32x16& d, const bf16x8& ka, const bf16x8& qb_) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "a"(ka), "a"(qb_));
+    auto qk_acc = [](f32x16& d, const elem8& ka, const elem8& qb_) {
+        asm volatile(DM_MFMA_ASM " %0, %1, %2, %0" : "+v"(d) : "a"(ka), "a"(qb_));
     };
     // NQ = 4: the shared shift vector leaves ~90 VALU-addressable registers free while O + Q' fill 192 of the 256 accumulator
     // registers -- the K / V^T fragments therefore live in VGPRs there ("v"), which gives the allocator slack on BOTH sides
     // (with them in AGPRs it spilled Q' fragments and shuffled ~110 registers at the loop's back edge).
-    auto qk_head_v = [](f32x16& d, const bf16x8& ka, const bf16x8& qb_, const f32x16& c) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(ka), "a"(qb_), "v"(c));
+    auto qk_head_v = [](f32x16& d, const elem8& ka, const elem8& qb_, const f32x16& c) {
+        asm volatile(DM_MFMA_ASM " %0, %1, %2, %3" : "=&v"(d) : "v"(ka), "a"(qb_), "v"(c));
     };
-    auto qk_acc_v = [](f32x16& d, const bf16x8& ka, const bf16x8& qb_) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(ka), "a"(qb_));
+    auto qk_acc_v = [](f32x16& d, const elem8& ka, const elem8& qb_) {
+        asm volatile(DM_MFMA_ASM " %0, %1, %2, %0" : "+v"(d) : "v"(ka), "a"(qb_));
     };
-    auto pv_mfma_v = [](f32x16& acc, const bf16x8& va, const bf16x8& pb) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(va), "v"(pb));
+    auto pv_mfma_v = [](f32x16& acc, const elem8& va, const elem8& pb) {
+        asm volatile(DM_MFMA_ASM " %0, %1, %2, %0" : "+a"(acc) : "v"(va), "v"(pb));
     };
     // a 16-pass MFMA result read (or overwritten) by a VALU instruction needs 18 wait states after the MFMA's issue; hipcc
     // pads that for its own MFMAs only.  Used outside the main loop (there every consumer is >= a chunk of MFMAs away).
@@ -286,8 +286,8 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
     // O^T += V^T.P^T with the accumulator and the V^T fragment pinned to the AGPR half of the register file (VALU instructions
     // address only the 256 architectural VGPRs; O is touched by nothing but these MFMAs and the rare re-base until the
     // epilogue).  Operands are at least one chunk old.
-    auto pv_mfma = [](f32x16& acc, const bf16x8& va, const bf16x8& pb) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(va), "v"(pb));
+    auto pv_mfma = [](f32x16& acc, const elem8& va, const elem8& pb) {
+        asm volatile(DM_MFMA_ASM " %0, %1, %2, %0" : "+a"(acc) : "a"(va), "v"(pb));
     };
     // One tile j, 8 NQ + 1 "chunks" of one MFMA + two exponentials (scores 2c, 2c+1 of the tile; slice p = c / 4 is query block
     // p % NQ, 16-wide k-step ks = p / NQ, kv half t = ks >> 1) + the sums and the bf16 pack of chunk c-1 (skewed by one: nothing
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
                 constexpr int qb = pq % NQ, ks = pq / NQ, t = ks >> 1, r = 8 * (ks & 1) + 2 * e;
                 const float v0 = s[qb][t][r], v1 = s[qb][t][r + 1];
                 f32x2 two = {v0, v1};
-                bf16x2 pk = __builtin_convertvector(two, bf16x2);
+                elem2 pk = __builtin_convertvector(two, elem2);
                 pf[pq & 1][2 * e] = pk[0];
                 pf[pq & 1][2 * e + 1] = pk[1];
                 lA[qb] += v0;
@@ -379,10 +379,10 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
         // (s_nop 1: the pack of the last chunk may sit directly in front -- a VALU-written register needs two wait states before
         // an MFMA reads it, and hipcc pads nothing around an asm statement)
         if constexpr (JIT) {
-            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o[NQ - 1][0]) : "v"(vr[1][0]), "v"(pf[(NS - 1) & 1]));
+            asm volatile("s_nop 1\n\t" DM_MFMA_ASM " %0, %1, %2, %0" : "+a"(o[NQ - 1][0]) : "v"(vr[1][0]), "v"(pf[(NS - 1) & 1]));
             pv_mfma_v(o[NQ - 1][1], vr[1][1], pf[(NS - 1) & 1]);
         } else {
-            asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o[NQ - 1][0]) : "a"(vf[0][3]), "v"(pf[(NS - 1) & 1]));
+            asm volatile("s_nop 1\n\t" DM_MFMA_ASM " %0, %1, %2, %0" : "+a"(o[NQ - 1][0]) : "a"(vf[0][3]), "v"(pf[(NS - 1) & 1]));
             pv_mfma(o[NQ - 1][1], vf[1][3], pf[(NS - 1) & 1]);
             if (!LAST) {
                 vf[0][3] = sfrag(s1_tag, 3, kKBytes);
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
     for (int qb = 0; qb < NQ; ++qb) {
         const float lt = row_sum(qb);
         l_tot[qb] = lt + __shfl_xor(lt, 32);
-        bad = bad || !(l_tot[qb] < 0x1p100f) || !(l_tot[qb] > 0x1p-100f);     // overflow, NaN, or a row underflowed by a shared shift
+        bad = bad || !(l_tot[qb] < DM_P_SUM_MAX) || !(l_tot[qb] > DM_P_SUM_MIN);     // overflow, NaN, or a row underflowed by a shared shift
     }
     // ---- exact path (rare): some row overflowed the lazy shift.  The whole workgroup redoes its block with the textbook
     // online softmax, one tile at a time through stage 0.
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
                 for (int d = 0; d < 2; ++d)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[qb][d][r] *= alpha;
-                bf16x8 px[4];
+                elem8 px[4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
                         const float p0 = __builtin_amdgcn_exp2f(sx[t][r] - m_new), p1 = __builtin_amdgcn_exp2f(sx[t][r + 1] - m_new);
                         l_run[qb] += p0 + p1;
                         f32x2 two = {p0, p1};
-                        bf16x2 pk = __builtin_convertvector(two, bf16x2);
+                        elem2 pk = __builtin_convertvector(two, elem2);
                         px[ks][2 * e] = pk[0];
                         px[ks][2 * e + 1] = pk[1];
                     }
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
                     vr[0][1] = frag(smem + kKBytes, 4096 + off4[ks]);
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt)     // (s_nop 1: O and the packed P were just written by the VALU)
-                        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o[qb][dt]) : "v"(vr[0][dt]), "v"(px[ks]));
+                        asm volatile("s_nop 1\n\t" DM_MFMA_ASM " %0, %1, %2, %0" : "+a"(o[qb][dt]) : "v"(vr[0][dt]), "v"(px[ks]));
                     settle_a(o[qb][1]);                             // (keeps the next reload of vr behind these MFMAs)
                 }
             }
@@ -516,14 +516,14 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
             for (int g = 0; g < 4; ++g) {
                 f32x2 x0 = {o[qb][dt][4 * g] * inv, o[qb][dt][4 * g + 1] * inv};
                 f32x2 x1 = {o[qb][dt][4 * g + 2] * inv, o[qb][dt][4 * g + 3] * inv};
-                bf16x2 y0 = __builtin_convertvector(x0, bf16x2), y1 = __builtin_convertvector(x1, bf16x2);
-                bf16x4 y = {y0[0], y0[1], y1[0], y1[1]};
+                elem2 y0 = __builtin_convertvector(x0, elem2), y1 = __builtin_convertvector(x1, elem2);
+                elem4 y = {y0[0], y0[1], y1[0], y1[1]};
                 // head_dim 32 dt + 8 g + 4 hi .. +3: 16 B chunk 4 dt + g (swizzled by the row), half hi
-                *reinterpret_cast<bf16x4*>(ob + row * 128 + (((4 * dt + g) ^ (row & 7)) << 4) + 8 * hi) = y;
+                *reinterpret_cast<elem4*>(ob + row * 128 + (((4 * dt + g) ^ (row & 7)) << 4) + 8 * hi) = y;
             }
     }
     {
-        __bf16* op = a.out + (long long)b * a.o_bs + (long long)h * a.o_hs;
+        elem_t* op = a.out + (long long)b * a.o_bs + (long long)h * a.o_hs;
         const int chunk = lane & 7;
 #pragma unroll
         for (int i = 0; i < kRowsPerWave / 8; ++i) {

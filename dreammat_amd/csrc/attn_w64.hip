@@ -81,8 +81,8 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
     const int row0 = qblk * kRowsPerWg + wave * 64;          // first query row of this wave
 
     // ---- LDS-DMA: one descriptor per operand (base = this batch / head), per-lane offsets loop-invariant
-    const __bf16* kp = a.k + (long long)b * a.k_bs + (long long)h * a.k_hs;
-    const __bf16* vp = a.vt + (long long)b * a.vt_bs + (long long)h * a.vt_hs;
+    const elem_t* kp = a.k + (long long)b * a.k_bs + (long long)h * a.k_hs;
+    const elem_t* vp = a.vt + (long long)b * a.vt_bs + (long long)h * a.vt_hs;
     const int k_bytes = (int)((((long long)a.Skv - 1) * a.k_ss + 64) * 2);
     const int v_bytes = (int)((63LL * a.vt_ds + a.Skv) * 2);
     const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, k_bytes, 0x00020000);
@@ -117,18 +117,18 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
 #pragma unroll
     for (int t = 0; t < PD + 2; ++t) issue(t, t);
     // ---- Q' fragments (B operand of S^T = K.Q'^T): lane holds Q'[row0 + 32 qb + l31][16 kk + 8 hi .. +7]
-    bf16x8 qf[2][4];
+    elem8 qf[2][4];
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         const int row = min(row0 + 32 * qb + l31, a.Sq - 1);     // rows past the end duplicate the last one (never stored)
-        const __bf16* qp = a.q + (long long)b * a.q_bs + (long long)row * a.q_ss + (long long)h * a.q_hs;
+        const elem_t* qp = a.q + (long long)b * a.q_bs + (long long)row * a.q_ss + (long long)h * a.q_hs;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            qf[qb][kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(qp + 16 * kk + 8 * hi));
+            qf[qb][kk] = __builtin_bit_cast(elem8, *reinterpret_cast<const uint4*>(qp + 16 * kk + 8 * hi));
 #pragma unroll
             for (int e = 0; e < 8; e += 2) {
                 f32x2 two = {(float)qf[qb][kk][e] * a.scale_log2, (float)qf[qb][kk][e + 1] * a.scale_log2};
-                bf16x2 pk = __builtin_convertvector(two, bf16x2);
+                elem2 pk = __builtin_convertvector(two, elem2);
                 qf[qb][kk][e] = pk[0];
                 qf[qb][kk][e + 1] = pk[1];
             }
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
     int off4[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) off4[i] = l31 * 128 + ((((2 * i + hi) ^ ((l31 >> 1) & 7))) << 4);
-    auto frag = [&](const char* base, int off) { return *reinterpret_cast<const bf16x8*>(base + off); };
+    auto frag = [&](const char* base, int off) { return *reinterpret_cast<const elem8*>(base + off); };
     // The loop is unrolled over the ring so that every stage is a compile-time constant: a fragment read is then ONE
     // ds_read_b128 with an immediate offset on a loop-invariant address register (8 v_add_u32 + ~20 SALU per tile before).
     // A DS offset has 16 bits; stage 4 lies past it and gets its own address registers.
@@ -149,8 +149,8 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
     for (int i = 0; i < 4; ++i) { fb[i] = smem + off4[i]; fb4[i] = smem + off4[i] + 65536; }
     auto sfrag = [&](auto stage_tag, int i, int off) {       // fragment i of `stage`, `off` bytes into the stage
         constexpr int ST = decltype(stage_tag)::value;
-        if (ST * kStage + 12288 + 4096 <= 65536) return *reinterpret_cast<const bf16x8*>(fb[i] + ST * kStage + off);
-        return *reinterpret_cast<const bf16x8*>(fb4[i] + (ST * kStage - 65536) + off);
+        if (ST * kStage + 12288 + 4096 <= 65536) return *reinterpret_cast<const elem8*>(fb[i] + ST * kStage + off);
+        return *reinterpret_cast<const elem8*>(fb4[i] + (ST * kStage - 65536) + off);
     };
 
     // ---- state
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
     f32x16 s[2][2];                  // scores [query block][kv half] -- ONE set: half t = 0 of tile j+1 is formed while half
                                      // t = 1 of tile j is consumed, and the other way round (see tile_body)
     f32x16 cin[2];                   // C operand of the first QK^T MFMA of a chain: -m of the lane's row, in all 16 registers
-    bf16x8 kf[8], vf[2][4], pf[2];   // K fragments (t*4+kk), V^T fragments [dt][ks], packed P of the slice in flight (two buffers)
+    elem8 kf[8], vf[2][4], pf[2];   // K fragments (t*4+kk), V^T fragments [dt][ks], packed P of the slice in flight (two buffers)
     float lA[2] = {0.f, 0.f}, lB[2] = {0.f, 0.f};
     bool bad = false;
 
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
         for (int r = 0; r < 16; ++r) s[qb][0][r] = 0.f;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
-            s[qb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[qb][kk], s[qb][0], 0, 0, 0);
+            s[qb][0] = DM_MFMA_32x32x16(kf[kk], qf[qb][kk], s[qb][0]);
     }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -206,8 +206,8 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
     // O^T += V^T.P^T with the accumulator and the V^T fragment pinned to the AGPR half of the register file (VALU instructions
     // address only the 256 architectural VGPRs; O is touched by nothing but these MFMAs and the rare re-base until the
     // epilogue).  Operands are at least one chunk old.
-    auto pv_mfma = [](f32x16& acc, const bf16x8& va, const bf16x8& pb) {
-        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(va), "v"(pb));
+    auto pv_mfma = [](f32x16& acc, const elem8& va, const elem8& pb) {
+        asm volatile(DM_MFMA_ASM " %0, %1, %2, %0" : "+a"(acc) : "a"(va), "v"(pb));
     };
     // One tile j, 33 "chunks" of one MFMA + two exponentials (scores 2c, 2c+1 of the tile; slice p = c / 4 is query block
     // p & 1, 16-wide k-step p >> 1, kv half t = p >> 2) + the sums and the bf16 pack of chunk c-1 (skewed by one: nothing
@@ -234,9 +234,9 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
                         if (kq == 0) {
                             // chain head: D = s, C = the loop-invariant C-operand vector.  Through the builtin hipcc ties D
                             // to C and first copies 16 registers; the instruction itself takes distinct ones.
-                            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(s[qb][tq]) : "v"(kf[f]), "v"(qf[qb][0]), "v"(cin[qb]));
+                            asm volatile(DM_MFMA_ASM " %0, %1, %2, %3" : "=&v"(s[qb][tq]) : "v"(kf[f]), "v"(qf[qb][0]), "v"(cin[qb]));
                         } else {
-                            s[qb][tq] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[f], qf[qb][kq], s[qb][tq], 0, 0, 0);
+                            s[qb][tq] = DM_MFMA_32x32x16(kf[f], qf[qb][kq], s[qb][tq]);
                         }
                         if (!LAST && c4 == 1) kf[f] = p < 4 ? sfrag(s1_tag, kq, 4096) : sfrag(s2_tag, kq, 0);
                     }
@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
                 const int qb = pq & 1, ks = pq >> 1, t = ks >> 1, r = 8 * (ks & 1) + 2 * e;
                 const float v0 = s[qb][t][r], v1 = s[qb][t][r + 1];
                 f32x2 two = {v0, v1};
-                bf16x2 pk = __builtin_convertvector(two, bf16x2);
+                elem2 pk = __builtin_convertvector(two, elem2);
                 pf[pq & 1][2 * e] = pk[0];
                 pf[pq & 1][2 * e + 1] = pk[1];
                 lA[qb] += v0;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
         // P.V of the last slice (query block 1, k-step 3)
         // (s_nop 1: the pack of chunk 31 may sit directly in front -- a VALU-written register needs two wait states before an
         // MFMA reads it, and hipcc pads nothing around an asm statement)
-        asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o[1][0]) : "a"(vf[0][3]), "v"(pf[1]));
+        asm volatile("s_nop 1\n\t" DM_MFMA_ASM " %0, %1, %2, %0" : "+a"(o[1][0]) : "a"(vf[0][3]), "v"(pf[1]));
         pv_mfma(o[1][1], vf[1][3], pf[1]);
         if (!LAST) {
             vf[0][3] = sfrag(s1_tag, 3, kKBytes);
@@ -285,14 +285,14 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
     // the old C operand are the first kv half of the next tile.
     auto maybe_rebase = [&]() {
         const float l0 = row_sum(0), l1 = row_sum(1);
-        if (__builtin_expect(__any(!(l0 <= 0x1p30f) || !(l1 <= 0x1p30f)), 0)) {     // (also true for NaN)
+        if (__builtin_expect(__any(!(l0 <= DM_P_REBASE_AT) || !(l1 <= DM_P_REBASE_AT)), 0)) {     // (also true for NaN)
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
                 const float lt = qb ? l1 : l0;
                 const float lp = lt + __shfl_xor(lt, 32);                      // both lanes of a row must take the same shift
-                const bool fin = lp < 0x1p100f;
+                const bool fin = lp < DM_P_SUM_MAX;            // (f16: a numerator of this tile may have passed 65504)
                 bad = bad || !fin;
-                const int e = (fin && lp > 0x1p20f) ? __builtin_amdgcn_frexp_expf(lp) : 0;
+                const int e = (fin && lp > DM_P_REBASE_IF) ? __builtin_amdgcn_frexp_expf(lp) : 0;
                 const float fe = (float)e;
 #pragma unroll
                 for (int d = 0; d < 2; ++d)
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
     for (int qb = 0; qb < 2; ++qb) {
         const float lt = row_sum(qb);
         l_tot[qb] = lt + __shfl_xor(lt, 32);
-        bad = bad || !(l_tot[qb] < 0x1p100f);
+        bad = bad || !(l_tot[qb] < DM_P_SUM_MAX);
     }
     // ---- exact path (rare): some row overflowed the lazy shift.  The whole workgroup redoes its block with the textbook
     // online softmax, one tile at a time through stage 0.
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
                     for (int r = 0; r < 16; ++r) sx[t][r] = 0.f;
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk)
-                        sx[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[t * 4 + kk], qf[qb][kk], sx[t], 0, 0, 0);
+                        sx[t] = DM_MFMA_32x32x16(kf[t * 4 + kk], qf[qb][kk], sx[t]);
                 }
                 float mx = sx[0][0];
 #pragma unroll
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
                 for (int d = 0; d < 2; ++d)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) o[qb][d][r] *= alpha;
-                bf16x8 px[4];
+                elem8 px[4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
                         const float p0 = __builtin_amdgcn_exp2f(sx[t][r] - m_new), p1 = __builtin_amdgcn_exp2f(sx[t][r + 1] - m_new);
                         l_run[qb] += p0 + p1;
                         f32x2 two = {p0, p1};
-                        bf16x2 pk = __builtin_convertvector(two, bf16x2);
+                        elem2 pk = __builtin_convertvector(two, elem2);
                         px[ks][2 * e] = pk[0];
                         px[ks][2 * e + 1] = pk[1];
                     }
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
                 for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                     for (int ks = 0; ks < 4; ++ks)
-                        o[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dt][ks], px[ks], o[qb][dt], 0, 0, 0);
+                        o[qb][dt] = DM_MFMA_32x32x16(vf[dt][ks], px[ks], o[qb][dt]);
             }
         }
 #pragma unroll
@@ -422,14 +422,14 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w64(AttnArgs a) {
             for (int g = 0; g < 4; ++g) {
                 f32x2 x0 = {o[qb][dt][4 * g] * inv, o[qb][dt][4 * g + 1] * inv};
                 f32x2 x1 = {o[qb][dt][4 * g + 2] * inv, o[qb][dt][4 * g + 3] * inv};
-                bf16x2 y0 = __builtin_convertvector(x0, bf16x2), y1 = __builtin_convertvector(x1, bf16x2);
-                bf16x4 y = {y0[0], y0[1], y1[0], y1[1]};
+                elem2 y0 = __builtin_convertvector(x0, elem2), y1 = __builtin_convertvector(x1, elem2);
+                elem4 y = {y0[0], y0[1], y1[0], y1[1]};
                 // head_dim 32 dt + 8 g + 4 hi .. +3: 16 B chunk 4 dt + g (swizzled by the row), half hi
-                *reinterpret_cast<bf16x4*>(ob + row * 128 + (((4 * dt + g) ^ (row & 7)) << 4) + 8 * hi) = y;
+                *reinterpret_cast<elem4*>(ob + row * 128 + (((4 * dt + g) ^ (row & 7)) << 4) + 8 * hi) = y;
             }
     }
     {
-        __bf16* op = a.out + (long long)b * a.o_bs + (long long)h * a.o_hs;
+        elem_t* op = a.out + (long long)b * a.o_bs + (long long)h * a.o_hs;
         const int chunk = lane & 7;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {

@@ -22,6 +22,7 @@ SOURCES = {
     "attn_w64.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "attn_w128.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "attn_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    "attn_fp8.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
     "conv.hip": [],
     "conv_small.hip": [],
     "conv_wgrad.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
@@ -32,7 +33,9 @@ SOURCES = {
     "mc_shade.hip": [],
     "host.cpp": [],
 }
-HEADERS = ["dm_common.h", "attn_common.h", "raster_core.h", "shade_core.h", "bvh_core.h", "grid_core.h", "mc_shade_core.h"]
+# the net kernels are compiled a second time with -DDM_F16 (dm_elem.h): IEEE-half instantiations, exported with f16 in their names
+F16_SOURCES = ["conv.hip", "conv_small.hip", "groupnorm.hip", "transformer.hip", "attention.hip", "attn_w64.hip", "attn_w128.hip"]
+HEADERS = ["dm_common.h", "dm_elem.h", "attn_common.h", "raster_core.h", "shade_core.h", "bvh_core.h", "grid_core.h", "mc_shade_core.h"]
 
 
 def _newer(src, dst):
@@ -50,6 +53,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if force or _newer(s, o) or hdr_time > os.path.getmtime(o):
             jobs.append([hipcc] + COMMON + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o])
         objs.append(o)
+        if src in F16_SOURCES:
+            o16 = os.path.join(OBJ, src + ".f16.o")
+            if force or _newer(s, o16) or hdr_time > os.path.getmtime(o16):
+                jobs.append([hipcc] + COMMON + extra + ["-DDM_F16", "-c", s, "-o", o16])
+            objs.append(o16)
     rebuilt = bool(jobs)
     if jobs:
         # the translation units are independent: compile them side by side (a full build is ~17 files of 5-40 s each)

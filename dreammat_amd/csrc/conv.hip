@@ -21,23 +21,22 @@
 #include <type_traits>
 
 #include "dm_common.h"
+#include "dm_elem.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgs {
-    const __bf16* x;     // [B, Hin, Win, Cin]
-    const __bf16* w;     // [Cout, 9, Cin]
-    const __bf16* bias;  // [Cout] or null
-    const __bf16* rowbias;   // [B, Cout] or null: per-image channel bias (the ResnetBlock2D time embedding)
-    const __bf16* res;       // [B, Hout, Wout, Cout] or null: residual added in the epilogue
-    __bf16* y;           // [B, Hout, Wout, Cout]
+    const elem_t* x;     // [B, Hin, Win, Cin]
+    const elem_t* w;     // [Cout, 9, Cin]
+    const elem_t* bias;  // [Cout] or null
+    const elem_t* rowbias;   // [B, Cout] or null: per-image channel bias (the ResnetBlock2D time embedding)
+    const elem_t* res;       // [B, Hout, Wout, Cout] or null: residual added in the epilogue
+    elem_t* y;           // [B, Hout, Wout, Cout]
     int B, Hin, Win, Cin, Hout, Wout, Cout;
     int stride, pad_y, pad_x;
     long long M;         // B*Hout*Wout
@@ -152,18 +151,18 @@ __global__ __launch_bounds__(256) void k_conv3x3(ConvArgs a, long long n_mt, int
         const char* bb = ab + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
-            bf16x8 af[2], bf[NT];
+            elem8 af[2], bf[NT];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                af[i] = *reinterpret_cast<const bf16x8*>(ab + (64 * wm + 32 * i + l31) * ROWB + 32 * kk + 16 * hi);
+                af[i] = *reinterpret_cast<const elem8*>(ab + (64 * wm + 32 * i + l31) * ROWB + 32 * kk + 16 * hi);
 #pragma unroll
             for (int j = 0; j < NT; ++j)
-                bf[j] = *reinterpret_cast<const bf16x8*>(bb + ((BN / 2) * wn + 32 * j + l31) * ROWB + 32 * kk + 16 * hi);
+                bf[j] = *reinterpret_cast<const elem8*>(bb + ((BN / 2) * wn + 32 * j + l31) * ROWB + 32 * kk + 16 * hi);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = DM_MFMA_32x32x16(af[i], bf[j], acc[i][j]);
         }
         if (s + 1 < n_steps) write_step(buf ^ 1);
         __syncthreads();
@@ -179,7 +178,7 @@ __global__ __launch_bounds__(256) void k_conv3x3(ConvArgs a, long long n_mt, int
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 long long m = m0 + 64 * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (m < a.M) a.y[m * a.Cout + n] = (__bf16)(acc[i][j][r] + bv);
+                if (m < a.M) a.y[m * a.Cout + n] = (elem_t)(acc[i][j][r] + bv);
             }
     }
 }
@@ -413,28 +412,28 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     // one chunk earlier -- so LDS latency and the DMA issue time (60-180 cycles per 1 KB piece) sit under MFMA
     // execution instead of in front of it (the first version issued all pieces, then read, then multiplied:
     // SQ_WAIT_ANY 39 %, MFMA busy 29 %, profiles/r01_pmc_conv_v0.json).
-    auto read_frags = [&](int stage, int kk, bf16x8 (&af)[MT], bf16x8 (&bf)[NT]) {
+    auto read_frags = [&](int stage, int kk, elem8 (&af)[MT], elem8 (&bf)[NT]) {
         const char* ab = smem + stage * STAGE;
         const char* bb = ab + A_BYTES;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             int r = TM * wm + 32 * i + l31;
-            af[i] = *reinterpret_cast<const bf16x8*>(ab + r * ROWB + (((2 * kk + hi) ^ ((r >> 1) & 7)) << 4));
+            af[i] = *reinterpret_cast<const elem8*>(ab + r * ROWB + (((2 * kk + hi) ^ ((r >> 1) & 7)) << 4));
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             int r = TN * wn + 32 * j + l31;
-            bf[j] = *reinterpret_cast<const bf16x8*>(bb + r * ROWB + (((2 * kk + hi) ^ ((r >> 1) & 7)) << 4));
+            bf[j] = *reinterpret_cast<const elem8*>(bb + r * ROWB + (((2 * kk + hi) ^ ((r >> 1) & 7)) << 4));
         }
     };
-    auto mma = [&](const bf16x8 (&af)[MT], const bf16x8 (&bf)[NT]) {
+    auto mma = [&](const elem8 (&af)[MT], const elem8 (&bf)[NT]) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j)
                 // weights as the A operand, pixels as B: the accumulator fragment is D^T[n][m] -- lane = pixel, registers =
                 // channels, so the epilogue can store 16 contiguous bytes (8 channels of one pixel) per lane
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = DM_MFMA_32x32x16(bf[j], af[i], acc[i][j]);
     };
     // ONE body for steps that issue and steps that only drain (`issue_on` is wave-uniform and only guards the DMA pieces):
     // two instantiations in one loop made the register allocator give each its own accumulator set.
@@ -444,7 +443,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     // (profiles/r02_pmc_conv_*.json).  The fragments are in registers by then (lgkmcnt(0) before the barrier), so the
     // stage they came from may be overwritten.
     constexpr bool PEND = MT * NT < 10;                // (the 64 x 160 wave tile has no registers left to carry a set across)
-    bf16x8 a0[MT], b0[NT], a1[MT], b1[NT];             // two fragment sets, used alternately (named, not indexed:
+    elem8 a0[MT], b0[NT], a1[MT], b1[NT];             // two fragment sets, used alternately (named, not indexed:
                                                        // a parity-indexed array is not promoted to registers)
     auto kstep = [&](int stage, int st_next, bool pending) __attribute__((always_inline)) {
         // 3-deep ring: the pieces have a whole extra step to land, spread them over all 4 chunks.  2-deep ring:
@@ -549,8 +548,8 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
             rboff[i] = (unsigned)(min(img, a.B - 1) * a.Cout * 2);
         }
         auto unpack_add = [](float (&v)[4], const u32x2 p) __attribute__((always_inline)) {
-            v[0] += __builtin_bit_cast(float, p[0] << 16); v[1] += __builtin_bit_cast(float, p[0] & 0xffff0000u);
-            v[2] += __builtin_bit_cast(float, p[1] << 16); v[3] += __builtin_bit_cast(float, p[1] & 0xffff0000u);
+            v[0] += dm_elem_lo(p[0]); v[1] += dm_elem_hi(p[0]);
+            v[2] += dm_elem_lo(p[1]); v[3] += dm_elem_hi(p[1]);
         };
         const bool has_res = a.res != nullptr, has_rb = a.rowbias != nullptr;
         // Loads are issued ahead of the stores (the compiler keeps program order between a buffer load and a buffer store
@@ -614,11 +613,11 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
                             // the Linear output is a bf16 tensor in the unfused path: round value and gate before the gate function
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float vr = (float)(__bf16)v[e], gr = (float)(__bf16)gt[e];
+                                const float vr = (float)(elem_t)v[e], gr = (float)(elem_t)gt[e];
                                 v[e] = vr * (0.5f * gr * (1.f + erff(gr * 0.70710678118654752f)));
                             }
                             f32x2 lo = {v[0], v[1]}, hi2 = {v[2], v[3]};
-                            bf16x2 plo = __builtin_convertvector(lo, bf16x2), phi = __builtin_convertvector(hi2, bf16x2);
+                            elem2 plo = __builtin_convertvector(lo, elem2), phi = __builtin_convertvector(hi2, elem2);
                             w[q][0] = __builtin_bit_cast(unsigned, plo);
                             w[q][1] = __builtin_bit_cast(unsigned, phi);
                         }
@@ -674,7 +673,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
                         unpack_add(v, pre[f & 1][g]);
                         unpack_add(v, pre[f & 1][4 + g]);
                         f32x2 lo = {v[0], v[1]}, hi2 = {v[2], v[3]};
-                        bf16x2 plo = __builtin_convertvector(lo, bf16x2), phi = __builtin_convertvector(hi2, bf16x2);
+                        elem2 plo = __builtin_convertvector(lo, elem2), phi = __builtin_convertvector(hi2, elem2);
                         w[q][0] = __builtin_bit_cast(unsigned, plo);
                         w[q][1] = __builtin_bit_cast(unsigned, phi);
                     }
@@ -701,8 +700,8 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
 
 // split-K reduction: y[m][n] = sum_ks ws[ks][m][n] + bias[n] + rowbias[image(m)][n] + res[m][n], 8 channels per thread
 __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ ws, int ksplit, long long M, int Cout, long long hw,
-                                                        const __bf16* __restrict__ bias, const __bf16* __restrict__ rowbias,
-                                                        const __bf16* __restrict__ res, __bf16* __restrict__ y) {
+                                                        const elem_t* __restrict__ bias, const elem_t* __restrict__ rowbias,
+                                                        const elem_t* __restrict__ res, elem_t* __restrict__ y) {
     const long long idx = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
     if (idx >= M * Cout) return;
     const long long m = idx / Cout;
@@ -715,13 +714,13 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
         const float4 lo = p[0], hi = p[1];
         v[0] += lo.x; v[1] += lo.y; v[2] += lo.z; v[3] += lo.w; v[4] += hi.x; v[5] += hi.y; v[6] += hi.z; v[7] += hi.w;
     }
-    auto add8 = [&](const __bf16* src) {
+    auto add8 = [&](const elem_t* src) {
         const uint4 u = *reinterpret_cast<const uint4*>(src);
         const unsigned w[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v[2 * e] += __builtin_bit_cast(float, w[e] << 16);
-            v[2 * e + 1] += __builtin_bit_cast(float, w[e] & 0xffff0000u);
+            v[2 * e] += dm_elem_lo(w[e]);
+            v[2 * e + 1] += dm_elem_hi(w[e]);
         }
     };
     if (bias) add8(bias + n);
@@ -731,7 +730,7 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         f32x2 pr = {v[2 * e], v[2 * e + 1]};
-        o[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, bf16x2));
+        o[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, elem2));
     }
     *reinterpret_cast<uint4*>(y + idx) = make_uint4(o[0], o[1], o[2], o[3]);
 }
@@ -940,7 +939,7 @@ extern "C" {
 // (pad_y / pad_x are the leading pads; trailing pads are implied by Hout/Wout and zero-filled).
 // rowbias [B,Cout] / residual [B,Hout,Wout,Cout] (bf16, either may be NULL) are added in the epilogue
 // (LDS-DMA kernels only: Cin % 64 == 0).
-int dm_conv3x3_nhwc_bf16_fused(const void* x, const void* w, const void* bias, const void* rowbias, const void* residual,
+int DM_T(dm_conv3x3_nhwc_, _fused)(const void* x, const void* w, const void* bias, const void* rowbias, const void* residual,
                                void* y, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int stride,
                                int pad_y, int pad_x, hipStream_t stream) {
     if (!x || !w || !y || B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || stride <= 0) return DM_ERR_ARG;
@@ -948,8 +947,8 @@ int dm_conv3x3_nhwc_bf16_fused(const void* x, const void* w, const void* bias, c
     if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return DM_ERR_ARG;
     if (((uintptr_t)bias | (uintptr_t)rowbias | (uintptr_t)residual) & 7) return DM_ERR_ARG;
     ConvArgs a = {};
-    a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const __bf16*)bias; a.y = (__bf16*)y;
-    a.rowbias = (const __bf16*)rowbias; a.res = (const __bf16*)residual; a.timeline = nullptr; a.timeline_steps = 0;
+    a.x = (const elem_t*)x; a.w = (const elem_t*)w; a.bias = (const elem_t*)bias; a.y = (elem_t*)y;
+    a.rowbias = (const elem_t*)rowbias; a.res = (const elem_t*)residual; a.timeline = nullptr; a.timeline_steps = 0;
     a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
     a.stride = stride; a.pad_y = pad_y; a.pad_x = pad_x;
     a.M = (long long)B * Hout * Wout;
@@ -1009,9 +1008,9 @@ int dm_conv3x3_nhwc_bf16_fused(const void* x, const void* w, const void* bias, c
     return (Cin % 64 == 0) ? launch_conv<64, 64>(a, stream) : launch_conv<64, 32>(a, stream);
 }
 
-int dm_conv3x3_nhwc_bf16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin,
+int DM_T(dm_conv3x3_nhwc_, )(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin,
                          int Hout, int Wout, int Cout, int stride, int pad_y, int pad_x, hipStream_t stream) {
-    return dm_conv3x3_nhwc_bf16_fused(x, w, bias, nullptr, nullptr, y, B, Hin, Win, Cin, Hout, Wout, Cout, stride, pad_y,
+    return DM_T(dm_conv3x3_nhwc_, _fused)(x, w, bias, nullptr, nullptr, y, B, Hin, Win, Cin, Hout, Wout, Cout, stride, pad_y,
                                       pad_x, stream);
 }
 
@@ -1028,13 +1027,13 @@ int dm_conv3x3_nhwc_bf16(const void* x, const void* w, const void* bias, void* y
 // that fall on the same source pixel; evaluated with pad 1 on a (h + 1) x (w + 1) grid, parity (py, px) of output (u, v) is
 // channel block 2 py + px at grid position (u + py, v + px) (hipops.subpixel_upsample_weights / conv3x3_upsampled_nhwc).
 // bias [Cout] bf16 or NULL.
-int dm_conv2x2_nhwc_bf16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin, int Hout, int Wout,
+int DM_T(dm_conv2x2_nhwc_, )(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin, int Hout, int Wout,
                          int Cout, int pad_y, int pad_x, hipStream_t stream) {
     if (!x || !w || !y || B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0) return DM_ERR_ARG;
     if (Cin % 64 != 0 || Cout % 256 != 0) return DM_ERR_UNSUPPORTED;
     if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) || ((uintptr_t)bias & 7)) return DM_ERR_ARG;
     ConvArgs a = {};
-    a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const __bf16*)bias; a.y = (__bf16*)y;
+    a.x = (const elem_t*)x; a.w = (const elem_t*)w; a.bias = (const elem_t*)bias; a.y = (elem_t*)y;
     a.rowbias = nullptr; a.res = nullptr; a.timeline = nullptr; a.timeline_steps = 0;
     a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
     a.stride = 1; a.pad_y = pad_y; a.pad_x = pad_x;
@@ -1046,7 +1045,7 @@ int dm_conv2x2_nhwc_bf16(const void* x, const void* w, const void* bias, void* y
 // geglu != 0: w / bias rows are interleaved in blocks of 32 (32 value rows, their 32 gate rows, ...) and
 // y[M, N/2] = value * gelu(gate) with value and gate rounded to bf16 first (what the unfused Linear -> GEGLU pair computes).
 // Runs the 1-tap instantiation of the LDS-DMA convolution kernel above (M % 16 == 0, K % 64 == 0, N % 64 == 0; geglu: N % 128).
-int dm_gemm_bf16_fused(const void* x, const void* w, const void* bias, const void* residual, void* y, long long M, int K,
+int DM_T(dm_gemm_, _fused)(const void* x, const void* w, const void* bias, const void* residual, void* y, long long M, int K,
                        int N, int geglu, hipStream_t stream) {
     if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0) return DM_ERR_ARG;
     if (M % 16 != 0 || K % 64 != 0 || N % 64 != 0 || (geglu && (N % 128 != 0 || residual))) return DM_ERR_UNSUPPORTED;
@@ -1054,8 +1053,8 @@ int dm_gemm_bf16_fused(const void* x, const void* w, const void* bias, const voi
     if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return DM_ERR_ARG;
     if (((uintptr_t)bias | (uintptr_t)residual) & 7) return DM_ERR_ARG;
     ConvArgs a = {};
-    a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const __bf16*)bias; a.y = (__bf16*)y;
-    a.rowbias = nullptr; a.res = (const __bf16*)residual; a.timeline = nullptr; a.timeline_steps = 0;
+    a.x = (const elem_t*)x; a.w = (const elem_t*)w; a.bias = (const elem_t*)bias; a.y = (elem_t*)y;
+    a.rowbias = nullptr; a.res = (const elem_t*)residual; a.timeline = nullptr; a.timeline_steps = 0;
     a.B = 1; a.Hin = a.Hout = (int)(M / 16); a.Win = a.Wout = 16; a.Cin = K; a.Cout = N;
     a.stride = 1; a.pad_y = 0; a.pad_x = 0;
     a.M = M;

@@ -10,17 +10,17 @@
 //   x [B,Hin,Win,Cin] bf16, w [Cout,9,Cin] bf16 (tap-major, the layout of dm_conv3x3_nhwc_bf16), bias [Cout] bf16 or NULL,
 //   y [B,Hout,Wout,Cout] bf16; Cin even, <= 32; Cout % 16 == 0.  Algorithmic bytes: (Cin + Cout) * 2 per output pixel.
 #include "dm_common.h"
+#include "dm_elem.h"
 #include <algorithm>
 #include <cstdlib>
 
 namespace {
 
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 constexpr int CO = 16;                         // output channels per thread
 
 struct SmallConvArgs {
-    const __bf16* x; const __bf16* w; const __bf16* bias; __bf16* y;
-    const __bf16* res; int res_B;              // optional [res_B, Hout, Wout, Cout] added before the rounding, image b takes b % res_B
+    const elem_t* x; const elem_t* w; const elem_t* bias; elem_t* y;
+    const elem_t* res; int res_B;              // optional [res_B, Hout, Wout, Cout] added before the rounding, image b takes b % res_B
     int B, Hin, Win, Hout, Wout, Cout, stride, pad_y, pad_x, act;
     long long n_pix;                           // B*Hout*Wout
 };
@@ -28,10 +28,10 @@ struct SmallConvArgs {
 template <int CIN>
 __global__ __launch_bounds__(256) void k_conv3x3_small(SmallConvArgs a) {
     constexpr int CP = CIN / 2;                // channel pairs
-    __shared__ bf16x2 wl[CO * 9 * CP];         // [co][tap][pair]
+    __shared__ elem2 wl[CO * 9 * CP];         // [co][tap][pair]
     const int cog = blockIdx.y;
     for (int i = threadIdx.x; i < CO * 9 * CP; i += 256)
-        wl[i] = reinterpret_cast<const bf16x2*>(a.w + (long long)cog * CO * 9 * CIN)[i];
+        wl[i] = reinterpret_cast<const elem2*>(a.w + (long long)cog * CO * 9 * CIN)[i];
     __syncthreads();
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
     if (p >= a.n_pix) return;
@@ -46,19 +46,19 @@ __global__ __launch_bounds__(256) void k_conv3x3_small(SmallConvArgs a) {
     for (int t = 0; t < 9; ++t) {
         const int yy = y0 + t / 3, xx = x0 + t % 3;
         if ((unsigned)yy >= (unsigned)a.Hin || (unsigned)xx >= (unsigned)a.Win) continue;      // zero padding
-        const bf16x2* src = reinterpret_cast<const bf16x2*>(a.x + (((long long)b * a.Hin + yy) * a.Win + xx) * CIN);
-        bf16x2 v[CP];
+        const elem2* src = reinterpret_cast<const elem2*>(a.x + (((long long)b * a.Hin + yy) * a.Win + xx) * CIN);
+        elem2 v[CP];
 #pragma unroll
         for (int k = 0; k < CP; ++k) v[k] = src[k];
 #pragma unroll
         for (int c = 0; c < CO; ++c) {
-            const bf16x2* wr = wl + (c * 9 + t) * CP;
+            const elem2* wr = wl + (c * 9 + t) * CP;
 #pragma unroll
-            for (int k = 0; k < CP; ++k) acc[c] = __builtin_amdgcn_fdot2_f32_bf16(v[k], wr[k], acc[c], false);
+            for (int k = 0; k < CP; ++k) acc[c] = DM_FDOT2(v[k], wr[k], acc[c]);
         }
     }
     if (a.res) {                                // (ControlNet: conv_in(sample) + conditioning embedding, the embedding of the B views
-        __bf16 rv[CO];                          //  shared by the text / negative / null branches)
+        elem_t rv[CO];                          //  shared by the text / negative / null branches)
         const long long pr = ((long long)(b % a.res_B) * a.Hout + yo) * a.Wout + xo;
         const uint4* rp = reinterpret_cast<const uint4*>(a.res + pr * a.Cout + cog * CO);
         *reinterpret_cast<uint4*>(rv) = rp[0];
@@ -66,12 +66,12 @@ __global__ __launch_bounds__(256) void k_conv3x3_small(SmallConvArgs a) {
 #pragma unroll
         for (int c = 0; c < CO; ++c) acc[c] += (float)rv[c];
     }
-    __bf16 o[CO];
+    elem_t o[CO];
 #pragma unroll
     for (int c = 0; c < CO; ++c) {
         float z = acc[c];
         if (a.act) z = z / (1.f + __expf(-z));
-        o[c] = (__bf16)z;
+        o[c] = (elem_t)z;
     }
     uint4* dst = reinterpret_cast<uint4*>(a.y + p * a.Cout + cog * CO);
     dst[0] = *reinterpret_cast<const uint4*>(o);
@@ -99,8 +99,6 @@ int launch_small(const SmallConvArgs& a, hipStream_t stream) {
 // pixels of a tile row (consecutive patch rows) read 16 different bank groups.  Operand roles as in csrc/conv.hip: weights = A,
 // pixels = B, so a lane holds 16 channels of ONE pixel and the epilogue (bias, residual, SiLU, one rounding) stores whole 8- or
 // 16-byte channel runs.  Cin = 128 -> Cout = 4 is the data gradient of the VAE encoder's conv_in (the rendered image is the leaf).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -126,10 +124,10 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(SmallConvArgs a, int cin,
     float* const sbias = reinterpret_cast<float*>(wl0 + w_res * C::W_BYTES);      // n_cb * 32 floats
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
     // 8 channels (one 16-byte chunk) of a [.., cin] row from channel ch0 on; zeros beyond cin
-    auto chunk_of = [&](const __bf16* rowp, int ch0) {
+    auto chunk_of = [&](const elem_t* rowp, int ch0) {
         unsigned v[4] = {0u, 0u, 0u, 0u};
         if (ch0 < cin) {
-            const __bf16* src = rowp + ch0;
+            const elem_t* src = rowp + ch0;
             if (ch0 + 8 <= cin && (cin & 7) == 0) {
                 const uint4 q = *reinterpret_cast<const uint4*>(src);
                 v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
@@ -194,11 +192,11 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(SmallConvArgs a, int cin,
 #pragma unroll
                 for (int kk = 0; kk < CP / 16; ++kk) {
                     const int ch = 2 * kk + hi;
-                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wl + wrow * C::RB + ((ch ^ C::swz(wrow)) << 4));
+                    const elem8 wf = *reinterpret_cast<const elem8*>(wl + wrow * C::RB + ((ch ^ C::swz(wrow)) << 4));
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
-                        const bf16x8 pf = *reinterpret_cast<const bf16x8*>(patch + prow[m] * C::RB + ((ch ^ C::swz(prow[m])) << 4));
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, pf, acc[m], 0, 0, 0);
+                        const elem8 pf = *reinterpret_cast<const elem8*>(patch + prow[m] * C::RB + ((ch ^ C::swz(prow[m])) << 4));
+                        acc[m] = DM_MFMA_32x32x16(wf, pf, acc[m]);
                     }
                 }
             }
@@ -217,7 +215,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(SmallConvArgs a, int cin,
                     for (int e = 0; e < 4; ++e) v[e] = acc[m][4 * g + e] + sbias[c0 + e];
                     const bool ok = pix_ok && c0 < a.Cout;                 // (Cout % 4 == 0: a run is inside or outside as a whole)
                     if (a.res && ok) {
-                        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(a.res + pr + c0);
+                        const elem4 rv = *reinterpret_cast<const elem4*>(a.res + pr + c0);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
                     }
@@ -227,9 +225,9 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(SmallConvArgs a, int cin,
                     }
                     if (ok) {
                         f32x2 lo = {v[0], v[1]}, hi2 = {v[2], v[3]};
-                        const bf16x2 plo = __builtin_convertvector(lo, bf16x2), phi = __builtin_convertvector(hi2, bf16x2);
-                        const bf16x4 o = {plo[0], plo[1], phi[0], phi[1]};
-                        *reinterpret_cast<bf16x4*>(a.y + po + c0) = o;
+                        const elem2 plo = __builtin_convertvector(lo, elem2), phi = __builtin_convertvector(hi2, elem2);
+                        const elem4 o = {plo[0], plo[1], phi[0], phi[1]};
+                        *reinterpret_cast<elem4*>(a.y + po + c0) = o;
                     }
                 }
             }
@@ -295,15 +293,15 @@ extern "C" {
 // act: 0 none, 1 SiLU (applied to conv + bias (+ residual) before the rounding to bf16).  Cin even and <= 32, or 128 at stride 1; Cout % 4 == 0
 // (the patch kernel; the direct kernel behind it: Cin in {4, 8, 16, 22, 32}, Cout % 16 == 0).
 // residual (may be NULL): [res_B, Hout, Wout, Cout] bf16 added in the same pass, image b takes residual image b % res_B.
-int dm_conv3x3_small_res_nhwc_bf16(const void* x, const void* w, const void* bias, const void* residual, int res_B, void* y, int B,
+int DM_T(dm_conv3x3_small_res_nhwc_, )(const void* x, const void* w, const void* bias, const void* residual, int res_B, void* y, int B,
                                    int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int stride, int pad_y, int pad_x, int act,
                                    hipStream_t stream) {
     if (!x || !w || !y || B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0 || stride <= 0) return DM_ERR_ARG;
     if ((((uintptr_t)x | (uintptr_t)w) & 3) || ((uintptr_t)y & 7)) return DM_ERR_UNSUPPORTED;
     if (residual && (res_B <= 0 || ((uintptr_t)residual & 7))) return DM_ERR_ARG;
     SmallConvArgs a;
-    a.x = (const __bf16*)x; a.w = (const __bf16*)w; a.bias = (const __bf16*)bias; a.y = (__bf16*)y;
-    a.res = (const __bf16*)residual; a.res_B = residual ? res_B : 1;
+    a.x = (const elem_t*)x; a.w = (const elem_t*)w; a.bias = (const elem_t*)bias; a.y = (elem_t*)y;
+    a.res = (const elem_t*)residual; a.res_B = residual ? res_B : 1;
     a.B = B; a.Hin = Hin; a.Win = Win; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout; a.stride = stride;
     a.pad_y = pad_y; a.pad_x = pad_x; a.act = act;
     a.n_pix = (long long)B * Hout * Wout;
@@ -322,9 +320,9 @@ int dm_conv3x3_small_res_nhwc_bf16(const void* x, const void* w, const void* bia
     }
 }
 
-int dm_conv3x3_small_nhwc_bf16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin,
+int DM_T(dm_conv3x3_small_nhwc_, )(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin,
                                int Hout, int Wout, int Cout, int stride, int pad_y, int pad_x, int act, hipStream_t stream) {
-    return dm_conv3x3_small_res_nhwc_bf16(x, w, bias, nullptr, 0, y, B, Hin, Win, Cin, Hout, Wout, Cout, stride, pad_y, pad_x, act, stream);
+    return DM_T(dm_conv3x3_small_res_nhwc_, )(x, w, bias, nullptr, 0, y, B, Hin, Win, Cin, Hout, Wout, Cout, stride, pad_y, pad_x, act, stream);
 }
 
 }  // extern "C"

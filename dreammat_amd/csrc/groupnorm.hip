@@ -12,18 +12,18 @@
 // Backward (the VAE encoder is differentiated through; weights are frozen => only dx):
 //   dz = dy * act'(z);  dxhat = dz * gamma;  dx = rstd * (dxhat - mean_g(dxhat) - xhat * mean_g(dxhat * xhat)).
 #include "dm_common.h"
+#include "dm_elem.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // workspace (fp32): coef [B,7,C] | part [B*nblk,32,2] | bpart [B*nblk,32,2]   (nblk = workgroups per batch item)
 //   coef rows: 0 A = rstd*gamma   1 S = beta - mean*rstd*gamma   2 rstd   3 mean*rstd   4 gamma
 //              5 rstd*mean_g(dxhat)   6 rstd*mean_g(dxhat*xhat)
 struct GnArgs {
-    const __bf16* x; const __bf16* gamma; const __bf16* beta; const __bf16* dy;
-    const __bf16* dres;   // backward only, may be NULL: a second gradient of x (the skip branch of a ResnetBlock2D), added into dx
-    __bf16* y;            // forward output / backward dx
+    const elem_t* x; const elem_t* gamma; const elem_t* beta; const elem_t* dy;
+    const elem_t* dres;   // backward only, may be NULL: a second gradient of x (the skip branch of a ResnetBlock2D), added into dx
+    elem_t* y;            // forward output / backward dx
     float* part; float* bpart; float* coef;
     float* cpart;         // MODE 2 of k_gn_stats: per-(b, workgroup) channel sums [B*nblk][2][C] (dbeta, dgamma partials)
     int B, HW, C, act, nblk;
@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256) void k_gn_stats(GnArgs a) {
     const int chunks = C / 8;              // 16 B chunks per pixel row
     const long long row0 = (long long)blockIdx.x * a.rows_per_block;
     const long long row1 = min((long long)a.HW, row0 + a.rows_per_block);
-    const __bf16* __restrict__ xb = a.x + (long long)b * a.HW * C;
-    const __bf16* __restrict__ dyb = MODE ? a.dy + (long long)b * a.HW * C : nullptr;
+    const elem_t* __restrict__ xb = a.x + (long long)b * a.HW * C;
+    const elem_t* __restrict__ dyb = MODE ? a.dy + (long long)b * a.HW * C : nullptr;
     const float* co = a.coef + (long long)b * 7 * C;
     // thread -> fixed channel chunk(s); rows are strided over the threads that share a chunk
     const int lanes_per_row = min(chunks, 256);
@@ -115,17 +115,17 @@ __global__ __launch_bounds__(256) void k_gn_stats(GnArgs a) {
             // 4 rows per trip: four independent 16 B loads in flight per thread (the single-load loop was
             // latency-bound at ~1.3 TB/s on the UNet-sized tensors)
             for (long long r = row0 + my_row; r < row1; r += 4LL * row_par) {
-                bf16x8 v[4], d[4];
+                elem8 v[4], d[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     long long rr = r + (long long)u * row_par;
                     bool ok = rr < row1;
                     long long rc = ok ? rr : row0;
-                    v[u] = *reinterpret_cast<const bf16x8*>(xb + rc * C + ch * 8);
-                    if (MODE) d[u] = *reinterpret_cast<const bf16x8*>(dyb + rc * C + ch * 8);
+                    v[u] = *reinterpret_cast<const elem8*>(xb + rc * C + ch * 8);
+                    if (MODE) d[u] = *reinterpret_cast<const elem8*>(dyb + rc * C + ch * 8);
                     if (!ok) {
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) { v[u][k] = (__bf16)0.f; if (MODE) d[u][k] = (__bf16)0.f; }
+                        for (int k = 0; k < 8; ++k) { v[u][k] = (elem_t)0.f; if (MODE) d[u][k] = (elem_t)0.f; }
                     }
                 }
 #pragma unroll
@@ -206,10 +206,10 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnArgs a) {
         }
         __syncthreads();
     }
-    const __bf16* __restrict__ xb = a.x + (long long)b * a.HW * C;
-    const __bf16* __restrict__ dyb = MODE ? a.dy + (long long)b * a.HW * C : nullptr;
-    const __bf16* __restrict__ drb = (MODE && a.dres) ? a.dres + (long long)b * a.HW * C : nullptr;
-    __bf16* __restrict__ yb = a.y + (long long)b * a.HW * C;
+    const elem_t* __restrict__ xb = a.x + (long long)b * a.HW * C;
+    const elem_t* __restrict__ dyb = MODE ? a.dy + (long long)b * a.HW * C : nullptr;
+    const elem_t* __restrict__ drb = (MODE && a.dres) ? a.dres + (long long)b * a.HW * C : nullptr;
+    elem_t* __restrict__ yb = a.y + (long long)b * a.HW * C;
     const float* co = a.coef + (long long)b * 7 * C;
     const int lanes_per_row = min(chunks, 256);
     const int row_par = 256 / lanes_per_row;
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnArgs a) {
     for (int ch = threadIdx.x % lanes_per_row; ch < chunks; ch += lanes_per_row) {
         float A[8], S[8], rs[8], mrs[8], gm[8], c1[8], c2[8];
         if (FUSED) {
-            const bf16x8 gv = *reinterpret_cast<const bf16x8*>(a.gamma + ch * 8), bv = *reinterpret_cast<const bf16x8*>(a.beta + ch * 8);
+            const elem8 gv = *reinterpret_cast<const elem8*>(a.gamma + ch * 8), bv = *reinterpret_cast<const elem8*>(a.beta + ch * 8);
             const int cpg = C / 32;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -238,28 +238,28 @@ __global__ __launch_bounds__(256) void k_gn_apply(GnArgs a) {
         }
 #pragma unroll 4
         for (long long r = row0 + my_row; r < row1; r += row_par) {
-            bf16x8 v = *reinterpret_cast<const bf16x8*>(xb + r * C + ch * 8);
-            bf16x8 o;
+            elem8 v = *reinterpret_cast<const elem8*>(xb + r * C + ch * 8);
+            elem8 o;
             if (!MODE) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     float z = (float)v[k] * A[k] + S[k];
-                    o[k] = (__bf16)(a.act ? siluf(z) : z);
+                    o[k] = (elem_t)(a.act ? siluf(z) : z);
                 }
             } else {
-                bf16x8 d = *reinterpret_cast<const bf16x8*>(dyb + r * C + ch * 8);
-                bf16x8 e = {};
-                if (drb) e = *reinterpret_cast<const bf16x8*>(drb + r * C + ch * 8);
+                elem8 d = *reinterpret_cast<const elem8*>(dyb + r * C + ch * 8);
+                elem8 e = {};
+                if (drb) e = *reinterpret_cast<const elem8*>(drb + r * C + ch * 8);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     float xf = (float)v[k];
                     float xh = xf * rs[k] - mrs[k];
                     float dz = (float)d[k];
                     if (a.act) dz *= silu_grad(xf * A[k] + S[k]);
-                    o[k] = (__bf16)(rs[k] * (dz * gm[k]) - c1[k] - c2[k] * xh + (float)e[k]);
+                    o[k] = (elem_t)(rs[k] * (dz * gm[k]) - c1[k] - c2[k] * xh + (float)e[k]);
                 }
             }
-            *reinterpret_cast<bf16x8*>(yb + r * C + ch * 8) = o;
+            *reinterpret_cast<elem8*>(yb + r * C + ch * 8) = o;
         }
     }
 }
@@ -291,14 +291,17 @@ void bind_ws(GnArgs& a, float* ws, int B, int C) {
 
 extern "C" {
 
+#if !defined(DM_F16)      // (dtype-independent: exported once)
 size_t dm_groupnorm_workspace_floats(int B, int C) { return (size_t)B * 7 * (size_t)C + 2 * part_floats(B); }
 
+#endif
+
 // ws: dm_groupnorm_workspace_floats(B,C) fp32 (kept by the caller for the backward).  act: 0 none, 1 SiLU.
-int dm_groupnorm_nhwc_fwd(const void* x, const void* gamma, const void* beta, void* y, float* ws, int B, int HW,
+int DM_S(dm_groupnorm_nhwc_fwd)(const void* x, const void* gamma, const void* beta, void* y, float* ws, int B, int HW,
                           int C, float eps, int act, hipStream_t stream) {
     if (!x || !gamma || !beta || !y || !ws || !check_args(B, HW, C)) return DM_ERR_ARG;
     GnArgs a = {};
-    a.x = (const __bf16*)x; a.gamma = (const __bf16*)gamma; a.beta = (const __bf16*)beta; a.y = (__bf16*)y;
+    a.x = (const elem_t*)x; a.gamma = (const elem_t*)gamma; a.beta = (const elem_t*)beta; a.y = (elem_t*)y;
     bind_ws(a, ws, B, C);
     a.B = B; a.HW = HW; a.C = C; a.act = act; a.eps = eps;
     dim3 g;
@@ -314,12 +317,12 @@ int dm_groupnorm_nhwc_fwd(const void* x, const void* gamma, const void* beta, vo
 
 // Forward only (frozen nets under no_grad: nothing will ask for the backward): statistics + apply, the coefficient kernel
 // folded into the apply kernel.  Same arithmetic as dm_groupnorm_nhwc_fwd; ws is scratch of the same size.
-int dm_groupnorm_nhwc_infer(const void* x, const void* gamma, const void* beta, void* y, float* ws, int B, int HW,
+int DM_S(dm_groupnorm_nhwc_infer)(const void* x, const void* gamma, const void* beta, void* y, float* ws, int B, int HW,
                             int C, float eps, int act, hipStream_t stream) {
     if (!x || !gamma || !beta || !y || !ws || !check_args(B, HW, C)) return DM_ERR_ARG;
     if (C % 8 != 0 || (((uintptr_t)gamma | (uintptr_t)beta) & 15)) return DM_ERR_UNSUPPORTED;
     GnArgs a = {};
-    a.x = (const __bf16*)x; a.gamma = (const __bf16*)gamma; a.beta = (const __bf16*)beta; a.y = (__bf16*)y;
+    a.x = (const elem_t*)x; a.gamma = (const elem_t*)gamma; a.beta = (const elem_t*)beta; a.y = (elem_t*)y;
     bind_ws(a, ws, B, C);
     a.B = B; a.HW = HW; a.C = C; a.act = act; a.eps = eps;
     dim3 g;
@@ -335,13 +338,13 @@ int dm_groupnorm_nhwc_infer(const void* x, const void* gamma, const void* beta, 
 // dx from dy; ws = the workspace left by the matching dm_groupnorm_nhwc_fwd call (statistics + coefficients).
 // dres (may be NULL, [B,HW,C] bf16): dx = GroupNorm^T(dy) + dres in the same pass, one rounding -- x of a ResnetBlock2D feeds
 // norm1 AND the skip connection, and the sum of its two gradients was an ATen add pass per block of the VAE encoder's backward.
-int dm_groupnorm_nhwc_bwd_res(const void* x, const void* gamma, const void* beta, const void* dy, const void* dres, void* dx,
+int DM_S(dm_groupnorm_nhwc_bwd_res)(const void* x, const void* gamma, const void* beta, const void* dy, const void* dres, void* dx,
                               float* ws, int B, int HW, int C, float eps, int act, hipStream_t stream) {
     if (!x || !gamma || !beta || !dy || !dx || !ws || !check_args(B, HW, C)) return DM_ERR_ARG;
     GnArgs a = {};
-    a.x = (const __bf16*)x; a.gamma = (const __bf16*)gamma; a.beta = (const __bf16*)beta; a.dy = (const __bf16*)dy;
-    a.dres = (const __bf16*)dres;
-    a.y = (__bf16*)dx;
+    a.x = (const elem_t*)x; a.gamma = (const elem_t*)gamma; a.beta = (const elem_t*)beta; a.dy = (const elem_t*)dy;
+    a.dres = (const elem_t*)dres;
+    a.y = (elem_t*)dx;
     bind_ws(a, ws, B, C);
     a.B = B; a.HW = HW; a.C = C; a.act = act; a.eps = eps;
     dim3 g;
@@ -355,11 +358,12 @@ int dm_groupnorm_nhwc_bwd_res(const void* x, const void* gamma, const void* beta
     return DM_OK;
 }
 
-int dm_groupnorm_nhwc_bwd(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* ws,
+int DM_S(dm_groupnorm_nhwc_bwd)(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* ws,
                           int B, int HW, int C, float eps, int act, hipStream_t stream) {
-    return dm_groupnorm_nhwc_bwd_res(x, gamma, beta, dy, nullptr, dx, ws, B, HW, C, eps, act, stream);
+    return DM_S(dm_groupnorm_nhwc_bwd_res)(x, gamma, beta, dy, nullptr, dx, ws, B, HW, C, eps, act, stream);
 }
 
+#if !defined(DM_F16)      // (the ControlNet training loop, row f-4, runs in bf16)
 // dbeta / dgamma partials of a GroupNorm with TRAINABLE affine parameters (the ControlNet copy in the training loop), after
 // dm_groupnorm_nhwc_fwd left its workspace: cpart [B * dm_groupnorm_affine_rows(B, HW, C) / B][2][C] fp32 --
 // dbeta = cpart[:, 0].sum(0), dgamma = cpart[:, 1].sum(0).  dx comes from dm_groupnorm_nhwc_bwd as before.
@@ -373,7 +377,7 @@ int dm_groupnorm_nhwc_bwd_affine(const void* x, const void* gamma, const void* b
                                  int B, int HW, int C, float eps, int act, hipStream_t stream) {
     if (!x || !gamma || !beta || !dy || !ws || !cpart || !check_args(B, HW, C)) return DM_ERR_ARG;
     GnArgs a = {};
-    a.x = (const __bf16*)x; a.gamma = (const __bf16*)gamma; a.beta = (const __bf16*)beta; a.dy = (const __bf16*)dy;
+    a.x = (const elem_t*)x; a.gamma = (const elem_t*)gamma; a.beta = (const elem_t*)beta; a.dy = (const elem_t*)dy;
     bind_ws(a, ws, B, C);
     a.cpart = cpart;
     a.B = B; a.HW = HW; a.C = C; a.act = act; a.eps = eps;
@@ -385,5 +389,6 @@ int dm_groupnorm_nhwc_bwd_affine(const void* x, const void* gamma, const void* b
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
+#endif
 
 }  // extern "C"

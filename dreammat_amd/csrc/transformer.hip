@@ -5,10 +5,10 @@
 // accesses.  Forward only: the diffusion nets run without autograd in score distillation (the SDS gradient is
 // injected at the latents, dreammat_guidance.py:385-397).
 #include "dm_common.h"
+#include "dm_elem.h"
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -19,8 +19,8 @@ __device__ __forceinline__ float wave_sum(float v) {
 // One wave per row, NCH 16-byte chunks per lane held in registers between the two passes (mean, then the
 // centred second moment: the same two-pass arithmetic as ATen's fp32-accumulating kernel).
 template <int NCH>
-__global__ __launch_bounds__(256) void k_layernorm(const __bf16* __restrict__ x, const __bf16* __restrict__ gamma,
-                                                   const __bf16* __restrict__ beta, __bf16* __restrict__ y,
+__global__ __launch_bounds__(256) void k_layernorm(const elem_t* __restrict__ x, const elem_t* __restrict__ gamma,
+                                                   const elem_t* __restrict__ beta, elem_t* __restrict__ y,
                                                    long long rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -31,21 +31,21 @@ __global__ __launch_bounds__(256) void k_layernorm(const __bf16* __restrict__ x,
     for (int c = 0; c < NCH; ++c) {
         int ch = lane + 64 * c;
         bool ok = ch < chunks;
-        bf16x8 gv = *reinterpret_cast<const bf16x8*>(gamma + (ok ? ch : 0) * 8);
-        bf16x8 bv = *reinterpret_cast<const bf16x8*>(beta + (ok ? ch : 0) * 8);
+        elem8 gv = *reinterpret_cast<const elem8*>(gamma + (ok ? ch : 0) * 8);
+        elem8 bv = *reinterpret_cast<const elem8*>(beta + (ok ? ch : 0) * 8);
 #pragma unroll
         for (int k = 0; k < 8; ++k) { g[c][k] = (float)gv[k]; b[c][k] = (float)bv[k]; }
     }
     const float inv_c = 1.f / (float)C;
     for (long long r = wave0; r < rows; r += nwaves) {
-        const __bf16* xr = x + r * C;
+        const elem_t* xr = x + r * C;
         float v[NCH][8];
         float s = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             int ch = lane + 64 * c;
             bool ok = ch < chunks;
-            bf16x8 xv = *reinterpret_cast<const bf16x8*>(xr + (ok ? ch : 0) * 8);
+            elem8 xv = *reinterpret_cast<const elem8*>(xr + (ok ? ch : 0) * 8);
 #pragma unroll
             for (int k = 0; k < 8; ++k) { v[c][k] = ok ? (float)xv[k] : 0.f; s += v[c][k]; }
         }
@@ -58,15 +58,15 @@ __global__ __launch_bounds__(256) void k_layernorm(const __bf16* __restrict__ x,
             for (int k = 0; k < 8; ++k) { float d = v[c][k] - mean; q += ok ? d * d : 0.f; }
         }
         const float rstd = rsqrtf(wave_sum(q) * inv_c + eps);
-        __bf16* yr = y + r * C;
+        elem_t* yr = y + r * C;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             int ch = lane + 64 * c;
             if (ch < chunks) {
-                bf16x8 o;
+                elem8 o;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) o[k] = (__bf16)((v[c][k] - mean) * rstd * g[c][k] + b[c][k]);
-                *reinterpret_cast<bf16x8*>(yr + ch * 8) = o;
+                for (int k = 0; k < 8; ++k) o[k] = (elem_t)((v[c][k] - mean) * rstd * g[c][k] + b[c][k]);
+                *reinterpret_cast<elem8*>(yr + ch * 8) = o;
             }
         }
     }
@@ -74,24 +74,24 @@ __global__ __launch_bounds__(256) void k_layernorm(const __bf16* __restrict__ x,
 
 // y[r, c] = h[r, c] * gelu(h[r, inner + c])  (exact erf GELU).  The gate is rounded to bf16 before the product,
 // which is what the two-kernel ATen sequence F.gelu(gate) -> mul produces.
-__global__ __launch_bounds__(256) void k_geglu(const __bf16* __restrict__ h, __bf16* __restrict__ y, long long rows,
+__global__ __launch_bounds__(256) void k_geglu(const elem_t* __restrict__ h, elem_t* __restrict__ y, long long rows,
                                                int inner) {
     const int cpr = inner / 8;
     const long long total = rows * cpr;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         long long r = i / cpr;
         int c = (int)(i - r * cpr);
-        const __bf16* hr = h + r * 2LL * inner;
-        bf16x8 xv = *reinterpret_cast<const bf16x8*>(hr + c * 8);
-        bf16x8 gv = *reinterpret_cast<const bf16x8*>(hr + inner + c * 8);
-        bf16x8 o;
+        const elem_t* hr = h + r * 2LL * inner;
+        elem8 xv = *reinterpret_cast<const elem8*>(hr + c * 8);
+        elem8 gv = *reinterpret_cast<const elem8*>(hr + inner + c * 8);
+        elem8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             float gf = (float)gv[k];
-            float ge = (float)(__bf16)(0.5f * gf * (1.f + erff(gf * 0.70710678118654752440f)));
-            o[k] = (__bf16)((float)xv[k] * ge);
+            float ge = (float)(elem_t)(0.5f * gf * (1.f + erff(gf * 0.70710678118654752440f)));
+            o[k] = (elem_t)((float)xv[k] * ge);
         }
-        *reinterpret_cast<bf16x8*>(y + r * inner + c * 8) = o;
+        *reinterpret_cast<elem8*>(y + r * inner + c * 8) = o;
     }
 }
 
@@ -108,7 +108,7 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 template <int NCH, bool BWD>
-__global__ __launch_bounds__(256) void k_softmax_rows(const __bf16* __restrict__ a, const __bf16* __restrict__ b, __bf16* __restrict__ y,
+__global__ __launch_bounds__(256) void k_softmax_rows(const elem_t* __restrict__ a, const elem_t* __restrict__ b, elem_t* __restrict__ y,
                                                       long long rows, int cols, float scale) {
     // forward:  a = scores s,         y = softmax(scale * s)
     // backward: a = probabilities p,  b = dL/dp,  y = dL/ds = scale * p * (dp - sum_j p_j dp_j)
@@ -118,16 +118,16 @@ __global__ __launch_bounds__(256) void k_softmax_rows(const __bf16* __restrict__
     constexpr float kLog2e = 1.4426950408889634f;
     int it = 0;
     for (long long r = blockIdx.x; r < rows; r += gridDim.x, ++it) {
-        const __bf16* ar = a + r * cols;
+        const elem_t* ar = a + r * cols;
         float v[NCH][8], w[NCH][8];
         float m = -INFINITY, acc = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int ch = tid + 256 * c;
             const bool ok = ch < chunks;
-            const bf16x8 av = *reinterpret_cast<const bf16x8*>(ar + (ok ? ch : 0) * 8);
+            const elem8 av = *reinterpret_cast<const elem8*>(ar + (ok ? ch : 0) * 8);
             if (BWD) {
-                const bf16x8 bv = *reinterpret_cast<const bf16x8*>(b + r * cols + (ok ? ch : 0) * 8);
+                const elem8 bv = *reinterpret_cast<const elem8*>(b + r * cols + (ok ? ch : 0) * 8);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     v[c][k] = ok ? (float)av[k] : 0.f;
@@ -159,15 +159,15 @@ __global__ __launch_bounds__(256) void k_softmax_rows(const __bf16* __restrict__
         __syncthreads();
         const float tot = (rd[0] + rd[1]) + (rd[2] + rd[3]);
         const float inv = BWD ? 0.f : 1.f / tot;
-        __bf16* yr = y + r * cols;
+        elem_t* yr = y + r * cols;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int ch = tid + 256 * c;
             if (ch < chunks) {
-                bf16x8 o;
+                elem8 o;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) o[k] = (__bf16)(BWD ? scale * v[c][k] * (w[c][k] - tot) : v[c][k] * inv);
-                *reinterpret_cast<bf16x8*>(yr + ch * 8) = o;
+                for (int k = 0; k < 8; ++k) o[k] = (elem_t)(BWD ? scale * v[c][k] * (w[c][k] - tot) : v[c][k] * inv);
+                *reinterpret_cast<elem8*>(yr + ch * 8) = o;
             }
         }
     }
@@ -176,26 +176,26 @@ __global__ __launch_bounds__(256) void k_softmax_rows(const __bf16* __restrict__
 // Skip connection of a UNet up block with the ControlNet residual folded in (diffusers UNet2DConditionModel.forward:
 // `down_block_res_samples = [s + r ...]` then `torch.cat([hidden, res_sample], dim=1)` in every up-block resnet):
 // y[row, 0:Cx] = x[row], y[row, Cx:Cx+Cs] = s[row] (+ r[row] * r_scale) -- one pass instead of an add pass and a cat pass.
-__global__ __launch_bounds__(256) void k_cat_add(const __bf16* __restrict__ x, const __bf16* __restrict__ s, const __bf16* __restrict__ r,
-                                                 __bf16* __restrict__ y, long long rows, int Cx, int Cs, float r_scale) {
+__global__ __launch_bounds__(256) void k_cat_add(const elem_t* __restrict__ x, const elem_t* __restrict__ s, const elem_t* __restrict__ r,
+                                                 elem_t* __restrict__ y, long long rows, int Cx, int Cs, float r_scale) {
     const int cx8 = Cx / 8, c8 = (Cx + Cs) / 8;
     const long long total = rows * c8;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long row = i / c8;
         const int c = (int)(i - row * c8);
-        bf16x8 v;
+        elem8 v;
         if (c < cx8) {
-            v = *reinterpret_cast<const bf16x8*>(x + row * Cx + c * 8);
+            v = *reinterpret_cast<const elem8*>(x + row * Cx + c * 8);
         } else {
             const long long o = row * Cs + (long long)(c - cx8) * 8;
-            v = *reinterpret_cast<const bf16x8*>(s + o);
+            v = *reinterpret_cast<const elem8*>(s + o);
             if (r) {
-                const bf16x8 w = *reinterpret_cast<const bf16x8*>(r + o);
+                const elem8 w = *reinterpret_cast<const elem8*>(r + o);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = (__bf16)((float)v[k] + (float)w[k] * r_scale);
+                for (int k = 0; k < 8; ++k) v[k] = (elem_t)((float)v[k] + (float)w[k] * r_scale);
             }
         }
-        *reinterpret_cast<bf16x8*>(y + row * (long long)(Cx + Cs) + c * 8) = v;
+        *reinterpret_cast<elem8*>(y + row * (long long)(Cx + Cs) + c * 8) = v;
     }
 }
 
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void k_cat_add(const __bf16* __restrict__ x, c
 extern "C" {
 
 // x, y [rows, C] bf16 (row-contiguous), gamma/beta [C] bf16; C % 8 == 0, C <= 2048.
-int dm_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, long long rows, int C, float eps,
+int DM_T(dm_layernorm_, )(const void* x, const void* gamma, const void* beta, void* y, long long rows, int C, float eps,
                       hipStream_t stream) {
     if (!x || !gamma || !beta || !y || rows < 0 || C <= 0) return DM_ERR_ARG;
     if (C % 8 != 0 || C > 2048) return DM_ERR_UNSUPPORTED;
@@ -213,8 +213,8 @@ int dm_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* 
     const int nch = (C / 8 + 63) / 64;
     const unsigned grid = (unsigned)std::min<long long>((rows + 3) / 4, 256 * 16);
     DM_ENTER();
-#define DM_LN(N) hipLaunchKernelGGL(k_layernorm<N>, dim3(grid), dim3(256), 0, stream, (const __bf16*)x, \
-                                    (const __bf16*)gamma, (const __bf16*)beta, (__bf16*)y, rows, C, eps)
+#define DM_LN(N) hipLaunchKernelGGL(k_layernorm<N>, dim3(grid), dim3(256), 0, stream, (const elem_t*)x, \
+                                    (const elem_t*)gamma, (const elem_t*)beta, (elem_t*)y, rows, C, eps)
     switch (nch) {
     case 1: DM_LN(1); break;
     case 2: DM_LN(2); break;
@@ -227,7 +227,7 @@ int dm_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* 
 }
 
 // h [rows, 2*inner] bf16 (value half | gate half), y [rows, inner] bf16; inner % 8 == 0.
-int dm_geglu_bf16(const void* h, void* y, long long rows, int inner, hipStream_t stream) {
+int DM_T(dm_geglu_, )(const void* h, void* y, long long rows, int inner, hipStream_t stream) {
     if (!h || !y || rows < 0 || inner <= 0) return DM_ERR_ARG;
     if (inner % 8 != 0) return DM_ERR_UNSUPPORTED;
     if (((uintptr_t)h | (uintptr_t)y) & 15) return DM_ERR_ARG;
@@ -235,13 +235,13 @@ int dm_geglu_bf16(const void* h, void* y, long long rows, int inner, hipStream_t
     const long long total = rows * (inner / 8);
     const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 256 * 32);
     DM_ENTER();
-    hipLaunchKernelGGL(k_geglu, dim3(grid), dim3(256), 0, stream, (const __bf16*)h, (__bf16*)y, rows, inner);
+    hipLaunchKernelGGL(k_geglu, dim3(grid), dim3(256), 0, stream, (const elem_t*)h, (elem_t*)y, rows, inner);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
 
 // s, p [rows, cols] bf16 row-contiguous: p = softmax(scale * s) over the columns, fp32 arithmetic.  cols % 8 == 0, cols <= 8192.
-int dm_softmax_rows_bf16(const void* s, void* p, long long rows, int cols, float scale, hipStream_t stream) {
+int DM_T(dm_softmax_rows_, )(const void* s, void* p, long long rows, int cols, float scale, hipStream_t stream) {
     if (!s || !p || rows < 0 || cols <= 0) return DM_ERR_ARG;
     if (cols % 8 != 0 || cols > 8192) return DM_ERR_UNSUPPORTED;
     if (((uintptr_t)s | (uintptr_t)p) & 15) return DM_ERR_ARG;
@@ -249,8 +249,8 @@ int dm_softmax_rows_bf16(const void* s, void* p, long long rows, int cols, float
     const int nch = (cols / 8 + 255) / 256;
     const unsigned grid = (unsigned)std::min<long long>(rows, 256 * 8);
     DM_ENTER();
-#define DM_SM(N) hipLaunchKernelGGL((k_softmax_rows<N, false>), dim3(grid), dim3(256), 0, stream, (const __bf16*)s, \
-                                    (const __bf16*)nullptr, (__bf16*)p, rows, cols, scale)
+#define DM_SM(N) hipLaunchKernelGGL((k_softmax_rows<N, false>), dim3(grid), dim3(256), 0, stream, (const elem_t*)s, \
+                                    (const elem_t*)nullptr, (elem_t*)p, rows, cols, scale)
     switch (nch) {
     case 1: DM_SM(1); break;
     case 2: DM_SM(2); break;
@@ -262,7 +262,7 @@ int dm_softmax_rows_bf16(const void* s, void* p, long long rows, int cols, float
 }
 
 // Backward of the above: ds = scale * p * (dp - rowsum(p * dp)); p, dp, ds [rows, cols] bf16 (ds may alias dp).
-int dm_softmax_rows_bwd_bf16(const void* p, const void* dp, void* ds, long long rows, int cols, float scale, hipStream_t stream) {
+int DM_T(dm_softmax_rows_bwd_, )(const void* p, const void* dp, void* ds, long long rows, int cols, float scale, hipStream_t stream) {
     if (!p || !dp || !ds || rows < 0 || cols <= 0) return DM_ERR_ARG;
     if (cols % 8 != 0 || cols > 8192) return DM_ERR_UNSUPPORTED;
     if (((uintptr_t)p | (uintptr_t)dp | (uintptr_t)ds) & 15) return DM_ERR_ARG;
@@ -270,8 +270,8 @@ int dm_softmax_rows_bwd_bf16(const void* p, const void* dp, void* ds, long long 
     const int nch = (cols / 8 + 255) / 256;
     const unsigned grid = (unsigned)std::min<long long>(rows, 256 * 8);
     DM_ENTER();
-#define DM_SM(N) hipLaunchKernelGGL((k_softmax_rows<N, true>), dim3(grid), dim3(256), 0, stream, (const __bf16*)p, \
-                                    (const __bf16*)dp, (__bf16*)ds, rows, cols, scale)
+#define DM_SM(N) hipLaunchKernelGGL((k_softmax_rows<N, true>), dim3(grid), dim3(256), 0, stream, (const elem_t*)p, \
+                                    (const elem_t*)dp, (elem_t*)ds, rows, cols, scale)
     switch (nch) {
     case 1: DM_SM(1); break;
     case 2: DM_SM(2); break;
@@ -284,7 +284,7 @@ int dm_softmax_rows_bwd_bf16(const void* p, const void* dp, void* ds, long long 
 
 // x [rows, Cx], s [rows, Cs], r [rows, Cs] or NULL, y [rows, Cx + Cs], all bf16 row-contiguous, Cx % 8 == Cs % 8 == 0.
 // The sum is rounded to bf16 once (the unfused pair rounded s + r to bf16 as well: same values when r_scale == 1).
-int dm_cat_add_bf16(const void* x, const void* s, const void* r, void* y, long long rows, int Cx, int Cs, float r_scale,
+int DM_T(dm_cat_add_, )(const void* x, const void* s, const void* r, void* y, long long rows, int Cx, int Cs, float r_scale,
                     hipStream_t stream) {
     if (!x || !s || !y || rows < 0 || Cx <= 0 || Cs <= 0) return DM_ERR_ARG;
     if (Cx % 8 != 0 || Cs % 8 != 0) return DM_ERR_UNSUPPORTED;
@@ -293,7 +293,7 @@ int dm_cat_add_bf16(const void* x, const void* s, const void* r, void* y, long l
     const long long total = rows * ((Cx + Cs) / 8);
     const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 256 * 32);
     DM_ENTER();
-    hipLaunchKernelGGL(k_cat_add, dim3(grid), dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)s, (const __bf16*)r, (__bf16*)y,
+    hipLaunchKernelGGL(k_cat_add, dim3(grid), dim3(256), 0, stream, (const elem_t*)x, (const elem_t*)s, (const elem_t*)r, (elem_t*)y,
                        rows, Cx, Cs, r_scale);
     DM_LAUNCH_CHECK();
     return DM_OK;

@@ -61,7 +61,9 @@ class StableDiffusionLightGuidance(BaseObject):
         grad_clip_val: Optional[float] = None
         grad_normalize: Optional[bool] = False
         # additions: compute dtype on the accelerator and the init seed used when no weights are on disk
-        weights_dtype: str = "bfloat16"
+        weights_dtype: str = "bfloat16"      # "bfloat16" | "float16" (the reference's half_precision_weights) on the accelerator
+        # "16bit" | "fp8": the S >= 1024 self-attention of the frozen nets on the MX-FP8 matrix instruction (BASELINE configs[4])
+        attention_precision: str = "16bit"
         synthetic_seed: int = 1234
         # seeded random UNet / VAE / ControlNet when no checkpoint is on disk: allowed only when asked for (bench, tests;
         # the 'tiny*' architectures have no checkpoints at all) -- a 30k-step run on random nets must not start silently
@@ -82,6 +84,10 @@ class StableDiffusionLightGuidance(BaseObject):
             self.weights_dtype = getattr(torch, self.cfg.weights_dtype)
         else:
             self.weights_dtype = torch.float32
+        if self.cfg.attention_precision not in ("16bit", "fp8"):
+            raise ValueError(f"guidance.attention_precision must be '16bit' or 'fp8', got '{self.cfg.attention_precision}'")
+        from .sd import layers as _layers
+        _layers.ATTENTION_PRECISION = self.cfg.attention_precision if on_gpu and self.cfg.half_precision_weights else "16bit"
         arch = arch_for(self.cfg.pretrained_model_name_or_path)
         self.arch = arch
         root = self._model_root()

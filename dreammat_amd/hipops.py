@@ -60,6 +60,25 @@ def kernel_times():
     return out
 
 
+HALF_DTYPES = (torch.bfloat16, torch.float16)     # element types the net kernels are built for (csrc/dm_elem.h)
+
+
+def _sym(name, dtype):
+    """entry point of `name` (a bf16 name of include/dreammat_hip.h) for `dtype`: the IEEE-half instantiation of a net kernel
+    carries f16 in place of bf16, or an _f16 suffix where the name has no dtype token -> (callable, symbol name)"""
+    if dtype == torch.float16:
+        name = name.replace("bf16", "f16") if "bf16" in name else name + "_f16"
+    elif dtype != torch.bfloat16:
+        raise TypeError(f"{name}: bf16 or f16 tensors expected, got {dtype}")
+    return getattr(_lib.lib(), name), name
+
+
+def _same_half(*ts):
+    dt = ts[0].dtype
+    assert dt in HALF_DTYPES and all(t is None or t.dtype == dt for t in ts), [None if t is None else t.dtype for t in ts]
+    return dt
+
+
 def _need_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -558,18 +577,53 @@ def attention(q, k, vt, heads, scale=None):
     """q [B,Sq,C], k [B,Skv,C] bf16 (C = heads*D, last dim contiguous), vt [B,C,Skv_pad] bf16
     (V transposed, rows zero-padded to a multiple of 8) -> out [B,Sq,C] bf16."""
     _need_cuda(q, k, vt)
-    assert q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and vt.dtype == torch.bfloat16
+    fn, name = _sym("dm_attention_fwd_bf16", _same_half(q, k, vt))
     B, Sq, C = q.shape
     Skv = k.shape[1]
     D = C // heads
     assert q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1
-    out = torch.empty(B, Sq, C, device=q.device, dtype=torch.bfloat16)
+    out = torch.empty(B, Sq, C, device=q.device, dtype=q.dtype)
     sc = float(scale) if scale is not None else float(D) ** -0.5
     with _Timed(f"attention_fwd_bf16[Sq={Sq},Skv={Skv},h={heads},D={D}]", 4.0 * B * Sq * Skv * C):
-        check(_lib.lib().dm_attention_fwd_bf16(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, heads,
+        check(fn(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, heads,
                                                Sq, Skv, D, q.stride(0), q.stride(1), D, k.stride(0), k.stride(1), D,
                                                vt.stride(0), D * vt.stride(1), vt.stride(1), out.stride(0),
-                                               out.stride(1), D, sc, _stream()), "dm_attention_fwd_bf16")
+                 out.stride(1), D, sc, _stream()), name)
+    return out
+
+
+_FP8_WS = {}
+
+
+def attention_fp8_ok(q, k, heads):
+    """dm_attention_fwd_fp8 serves this call: 64-wide heads, whole 128-row query blocks and 64-row kv tiles"""
+    D = q.shape[-1] // heads
+    return q.is_cuda and q.dtype in HALF_DTYPES and D == 64 and q.shape[1] % 128 == 0 and k.shape[1] % 64 == 0
+
+
+def attention_fp8(q, k, vt, heads, scale=None):
+    """attention() with both matrix products on the MX-FP8 matrix instruction (csrc/attn_fp8.hip: BASELINE configs[4]); the same
+    16-bit tensors in and out, the 8-bit operands live in a per-device scratch buffer (stream order, grow-only)."""
+    _need_cuda(q, k, vt)
+    dt = _same_half(q, k, vt)
+    assert attention_fp8_ok(q, k, heads) and q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1
+    B, Sq, C = q.shape
+    Skv = k.shape[1]
+    D = C // heads
+    need = int(_lib.lib().dm_attention_fp8_workspace_bytes(B, heads, Sq, Skv))
+    ws = _FP8_WS.get(q.device)
+    if ws is None or ws.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.DmError("attention_fp8: the 8-bit operand workspace must exist before a stream capture (run the shape eagerly once)")
+        ws = _FP8_WS[q.device] = torch.empty(need, device=q.device, dtype=torch.uint8)
+    out = torch.empty(B, Sq, C, device=q.device, dtype=dt)
+    sc = float(scale) if scale is not None else float(D) ** -0.5
+    with _Timed(f"attention_fwd_fp8[Sq={Sq},Skv={Skv},h={heads},D={D}]", 4.0 * B * Sq * Skv * C):
+        check(_lib.lib().dm_attention_fwd_fp8(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, heads, Sq, Skv, D,
+                                              q.stride(0), q.stride(1), D, k.stride(0), k.stride(1), D, vt.stride(0),
+                                              D * vt.stride(1), vt.stride(1), out.stride(0), out.stride(1), D, sc,
+                                              1 if dt == torch.float16 else 0, ws.data_ptr(), ws.numel(), _stream()),
+              "dm_attention_fwd_fp8")
     return out
 
 
@@ -654,17 +708,18 @@ def conv3x3_nhwc(x_nhwc, w_tap_major, bias, stride=1, pad=(1, 1), out_hw=None, r
     """x [B,H,W,Cin] bf16 contiguous, w [Cout, 9*Cin] bf16 (tap-major) -> y [B,Ho,Wo,Cout] bf16.
     rowbias [B,Cout] / residual [B,Ho,Wo,Cout] (bf16) are added in the kernel epilogue (Cin % 64 == 0)."""
     _need_cuda(x_nhwc, w_tap_major, rowbias, residual)
-    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous() and w_tap_major.is_contiguous()
+    assert x_nhwc.is_contiguous() and w_tap_major.is_contiguous()
+    fn, name = _sym("dm_conv3x3_nhwc_bf16_fused", _same_half(x_nhwc, w_tap_major, bias, rowbias, residual))
     B, H, W, Cin = x_nhwc.shape
     Cout = w_tap_major.shape[0]
     if out_hw is None:
         out_hw = ((H + 2 * pad[0] - 3) // stride + 1, (W + 2 * pad[1] - 3) // stride + 1)
     Ho, Wo = out_hw
-    y = torch.empty(B, Ho, Wo, Cout, device=x_nhwc.device, dtype=torch.bfloat16)
+    y = torch.empty(B, Ho, Wo, Cout, device=x_nhwc.device, dtype=x_nhwc.dtype)
     if rowbias is not None:
-        assert rowbias.dtype == torch.bfloat16 and rowbias.is_contiguous() and tuple(rowbias.shape) == (B, Cout)
+        assert rowbias.is_contiguous() and tuple(rowbias.shape) == (B, Cout)
     if residual is not None:
-        assert residual.dtype == torch.bfloat16 and residual.is_contiguous() and residual.shape == y.shape
+        assert residual.is_contiguous() and residual.shape == y.shape
     # the LDS-DMA kernel addresses a tensor with 32-bit byte offsets: batches whose activations pass 4 GB (16 views at
     # 1024^2 through the VAE) run as consecutive image chunks of the same contiguous buffers
     per_img = 2 * max(H * W * Cin, Ho * Wo * Cout)
@@ -677,10 +732,10 @@ def conv3x3_nhwc(x_nhwc, w_tap_major, bias, stride=1, pad=(1, 1), out_hw=None, r
                                     residual[b0:b1] if residual is not None else None)
         return y
     with _Timed(f"conv3x3[{Cin}->{Cout}@{Ho}x{Wo},s{stride}]", 2.0 * B * Ho * Wo * Cout * 9 * Cin):
-        check(_lib.lib().dm_conv3x3_nhwc_bf16_fused(
+        check(fn(
             x_nhwc.data_ptr(), w_tap_major.data_ptr(), bias.data_ptr() if bias is not None else None,
             rowbias.data_ptr() if rowbias is not None else None, residual.data_ptr() if residual is not None else None,
-            y.data_ptr(), B, H, W, Cin, Ho, Wo, Cout, stride, pad[0], pad[1], _stream()), "dm_conv3x3_nhwc_bf16_fused")
+            y.data_ptr(), B, H, W, Cin, Ho, Wo, Cout, stride, pad[0], pad[1], _stream()), name)
     return y
 
 
@@ -693,21 +748,20 @@ def conv3x3_small_nhwc(x_nhwc, w_tap_major, bias, stride=1, pad=(1, 1), act=0, r
     1 | 2, the direct kernel behind it for Cin in SMALL_CONV_CIN, Cout % 16 == 0.
     residual [Br, Ho, Wo, Cout] (B % Br == 0): added before the rounding, image b takes residual image b % Br."""
     _need_cuda(x_nhwc, w_tap_major, bias, residual)
-    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous() and w_tap_major.is_contiguous()
+    assert x_nhwc.is_contiguous() and w_tap_major.is_contiguous()
+    fn, name = _sym("dm_conv3x3_small_res_nhwc_bf16", _same_half(x_nhwc, w_tap_major, bias, residual))
     B, H, W, Cin = x_nhwc.shape
     Cout = w_tap_major.shape[0]
     Ho, Wo = (H + 2 * pad[0] - 3) // stride + 1, (W + 2 * pad[1] - 3) // stride + 1
     Br = 0
     if residual is not None:
         Br = residual.shape[0]
-        assert residual.dtype == torch.bfloat16 and residual.is_contiguous() and tuple(residual.shape[1:]) == (Ho, Wo, Cout) and B % Br == 0
-    y = torch.empty(B, Ho, Wo, Cout, device=x_nhwc.device, dtype=torch.bfloat16)
+        assert residual.is_contiguous() and tuple(residual.shape[1:]) == (Ho, Wo, Cout) and B % Br == 0
+    y = torch.empty(B, Ho, Wo, Cout, device=x_nhwc.device, dtype=x_nhwc.dtype)
     with _Timed(f"conv3x3_small[{Cin}->{Cout}@{Ho}x{Wo},s{stride}]", 2.0 * B * Ho * Wo * (Cin + Cout * (2 if Br else 1))):
-        check(_lib.lib().dm_conv3x3_small_res_nhwc_bf16(x_nhwc.data_ptr(), w_tap_major.data_ptr(),
-                                                        bias.data_ptr() if bias is not None else None,
-                                                        residual.data_ptr() if Br else None, Br, y.data_ptr(), B, H, W, Cin,
-                                                        Ho, Wo, Cout, stride, pad[0], pad[1], int(act), _stream()),
-              "dm_conv3x3_small_res_nhwc_bf16")
+        check(fn(x_nhwc.data_ptr(), w_tap_major.data_ptr(), bias.data_ptr() if bias is not None else None,
+                 residual.data_ptr() if Br else None, Br, y.data_ptr(), B, H, W, Cin, Ho, Wo, Cout, stride, pad[0], pad[1],
+                 int(act), _stream()), name)
     return y
 
 
@@ -715,12 +769,13 @@ def gemm_fused(x, w, bias=None, residual=None, geglu=False):
     """y[..., N] = x[..., K] @ w[N, K]^T + bias (+ residual[..., N]) on the 1-tap LDS-DMA kernel (forward only).
     geglu: `w` / `bias` rows interleaved by `geglu_interleave`; returns value * gelu(gate), [..., N/2]."""
     _need_cuda(x, w, bias, residual)
-    assert x.dtype == torch.bfloat16 and x.is_contiguous() and w.dtype == torch.bfloat16 and w.is_contiguous()
+    assert x.is_contiguous() and w.is_contiguous()
+    fn, name = _sym("dm_gemm_bf16_fused", _same_half(x, w, bias, residual))
     N, K = w.shape
     M = x.numel() // K
     assert x.shape[-1] == K
     No = N // 2 if geglu else N
-    y = torch.empty(*x.shape[:-1], No, device=x.device, dtype=torch.bfloat16)
+    y = torch.empty(*x.shape[:-1], No, device=x.device, dtype=x.dtype)
     if 2 * M * max(K, No) > CONV_MAX_TENSOR_BYTES:           # same 32-bit addressing limit: row chunks of the same buffers
         rows = max(16, (CONV_MAX_TENSOR_BYTES // (2 * max(K, No))) // 16 * 16)
         x2, y2 = x.reshape(M, K), y.view(M, No)
@@ -730,13 +785,12 @@ def gemm_fused(x, w, bias=None, residual=None, geglu=False):
             y2[m0:m1] = gemm_fused(x2[m0:m1], w, bias, r2[m0:m1] if r2 is not None else None, geglu)
         return y
     if bias is not None:
-        assert bias.dtype == torch.bfloat16 and bias.is_contiguous() and bias.numel() == N
+        assert bias.is_contiguous() and bias.numel() == N
     if residual is not None:
-        assert residual.dtype == torch.bfloat16 and residual.is_contiguous() and residual.shape == y.shape
+        assert residual.is_contiguous() and residual.shape == y.shape
     with _Timed(f"gemm{'+geglu' if geglu else ''}{'+res' if residual is not None else ''}[M={M},K={K},N={N}]", 2.0 * M * K * N):
-        check(_lib.lib().dm_gemm_bf16_fused(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                            residual.data_ptr() if residual is not None else None, y.data_ptr(), M, K, N,
-                                            1 if geglu else 0, _stream()), "dm_gemm_bf16_fused")
+        check(fn(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
+                 residual.data_ptr() if residual is not None else None, y.data_ptr(), M, K, N, 1 if geglu else 0, _stream()), name)
     return y
 
 
@@ -802,19 +856,19 @@ def conv2x2_nhwc(x_nhwc, w4, bias, out_hw, pad=(1, 1), label="conv2x2"):
     w4 [Cout, 4 * Cin], y [B, Ho, Wo, Cout] bf16.  Like conv3x3_nhwc, batches whose tensors pass the kernel's 32-bit byte offsets
     run as consecutive image chunks."""
     _need_cuda(x_nhwc, w4, bias)
-    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous() and w4.is_contiguous()
+    assert x_nhwc.is_contiguous() and w4.is_contiguous()
+    fn, name = _sym("dm_conv2x2_nhwc_bf16", _same_half(x_nhwc, w4, bias))
     B, H, W, Cin = x_nhwc.shape
     Cout = w4.shape[0]
     Ho, Wo = out_hw
-    y = torch.empty(B, Ho, Wo, Cout, device=x_nhwc.device, dtype=torch.bfloat16)
+    y = torch.empty(B, Ho, Wo, Cout, device=x_nhwc.device, dtype=x_nhwc.dtype)
     per_img = 2 * max(H * W * Cin, Ho * Wo * Cout)
     step = B if B * per_img <= CONV_MAX_TENSOR_BYTES else max(1, CONV_MAX_TENSOR_BYTES // per_img)
     for b0 in range(0, B, step):
         b1 = min(B, b0 + step)
         with _Timed(f"{label}[{Cin}->{Cout}@{Ho}x{Wo}]", 2.0 * (b1 - b0) * Ho * Wo * 4.0 * Cin * Cout):
-            check(_lib.lib().dm_conv2x2_nhwc_bf16(x_nhwc[b0:b1].data_ptr(), w4.data_ptr(), bias.data_ptr() if bias is not None else None,
-                                                  y[b0:b1].data_ptr(), b1 - b0, H, W, Cin, Ho, Wo, Cout, pad[0], pad[1], _stream()),
-                  "dm_conv2x2_nhwc_bf16")
+            check(fn(x_nhwc[b0:b1].data_ptr(), w4.data_ptr(), bias.data_ptr() if bias is not None else None,
+                     y[b0:b1].data_ptr(), b1 - b0, H, W, Cin, Ho, Wo, Cout, pad[0], pad[1], _stream()), name)
     return y
 
 
@@ -841,12 +895,12 @@ def subpixel_upsample_weights(w, bias):
 def conv3x3_upsampled_nhwc(x_nhwc, w4, b4):
     """conv3x3(pad 1)(nearest-2x upsample(x)) from subpixel_upsample_weights: x [B,h,w,Cin] -> [B,2h,2w,Cout] (forward only)."""
     _need_cuda(x_nhwc, w4, b4)
-    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous() and w4.is_contiguous()
+    assert x_nhwc.dtype in HALF_DTYPES and x_nhwc.is_contiguous() and w4.is_contiguous()
     B, h, w, Cin = x_nhwc.shape
     C4 = w4.shape[0]
     Cout = C4 // 4
     y = conv2x2_nhwc(x_nhwc, w4, b4, (h + 1, w + 1), (1, 1), "conv2x2_upsample")
-    out = torch.empty(B, h, 2, w, 2, Cout, device=x_nhwc.device, dtype=torch.bfloat16)
+    out = torch.empty(B, h, 2, w, 2, Cout, device=x_nhwc.device, dtype=x_nhwc.dtype)
     for py in range(2):
         for px in range(2):
             blk = (2 * py + px) * Cout
@@ -985,8 +1039,7 @@ def _gn_fwd(x_nhwc, gamma, beta, eps, act, keep_for_backward=True):
     ws = torch.empty(int(_lib.lib().dm_groupnorm_workspace_floats(B, C)), device=x_nhwc.device, dtype=torch.float32)
     infer = (not keep_for_backward and C % 8 == 0 and gamma.is_contiguous() and beta.is_contiguous()
              and gamma.data_ptr() % 16 == 0 and beta.data_ptr() % 16 == 0)
-    fn, name = ((_lib.lib().dm_groupnorm_nhwc_infer, "dm_groupnorm_nhwc_infer") if infer
-                else (_lib.lib().dm_groupnorm_nhwc_fwd, "dm_groupnorm_nhwc_fwd"))
+    fn, name = _sym("dm_groupnorm_nhwc_infer" if infer else "dm_groupnorm_nhwc_fwd", _same_half(x_nhwc, gamma, beta))
     with _Timed(f"groupnorm_fwd[C={C},HW={H * W}]", 6.0 * B * H * W * C):
         check(fn(x_nhwc.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), ws.data_ptr(), B, H * W, C, float(eps),
                  int(act), _stream()), name)
@@ -1016,13 +1069,13 @@ class _GroupNormAct(torch.autograd.Function):
         if g_skip is not None:
             g_skip = g_skip.contiguous()
         dx = torch.empty_like(x)
-        check(_lib.lib().dm_groupnorm_nhwc_bwd_res(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), g.data_ptr(),
-                                                   g_skip.data_ptr() if g_skip is not None else None,
-                                                   dx.data_ptr(), ws.data_ptr(), B, H * W, C, float(ctx.eps), int(ctx.act),
-                                                   _stream()), "dm_groupnorm_nhwc_bwd_res")
+        fn, name = _sym("dm_groupnorm_nhwc_bwd_res", _same_half(x, gamma, beta, g, g_skip))
+        check(fn(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), g.data_ptr(), g_skip.data_ptr() if g_skip is not None else None,
+                 dx.data_ptr(), ws.data_ptr(), B, H * W, C, float(ctx.eps), int(ctx.act), _stream()), name)
         dgamma = dbeta = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            # trainable affine parameters (ControlNet training): per-workgroup channel sums of dz and dz * xhat, added here
+            # trainable affine parameters (ControlNet training, bf16): per-workgroup channel sums of dz and dz * xhat, added here
+            assert x.dtype == torch.bfloat16, "GroupNorm affine gradients: the training loop runs in bf16"
             rows = int(_lib.lib().dm_groupnorm_affine_rows(B, H * W, C))
             cpart = torch.empty(rows, 2, C, device=x.device, dtype=torch.float32)
             check(_lib.lib().dm_groupnorm_nhwc_bwd_affine(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), g.data_ptr(),
@@ -1036,7 +1089,7 @@ class _GroupNormAct(torch.autograd.Function):
 def groupnorm_nhwc(x_nhwc, gamma, beta, eps, act):
     """x [B,H,W,C] bf16 contiguous -> act(GroupNorm32(x)) [B,H,W,C]; differentiable wrt x, gamma and beta."""
     _need_cuda(x_nhwc, gamma, beta)
-    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous() and gamma.dtype == torch.bfloat16
+    assert x_nhwc.dtype in HALF_DTYPES and x_nhwc.is_contiguous() and gamma.dtype == x_nhwc.dtype
     if torch.is_grad_enabled() and (x_nhwc.requires_grad or gamma.requires_grad or beta.requires_grad):
         return _GroupNormAct.apply(x_nhwc, gamma, beta, eps, act)
     return _gn_fwd(x_nhwc, gamma, beta, eps, act, keep_for_backward=False)[0]
@@ -1045,7 +1098,7 @@ def groupnorm_nhwc(x_nhwc, gamma, beta, eps, act):
 def groupnorm_nhwc_skip(x_nhwc, gamma, beta, eps, act):
     """(act(GroupNorm32(x)), x): the second output IS x, routed through the same autograd node (see _GroupNormAct)."""
     _need_cuda(x_nhwc, gamma, beta)
-    assert x_nhwc.dtype == torch.bfloat16 and x_nhwc.is_contiguous() and gamma.dtype == torch.bfloat16
+    assert x_nhwc.dtype in HALF_DTYPES and x_nhwc.is_contiguous() and gamma.dtype == x_nhwc.dtype
     return _GroupNormAct.apply(x_nhwc, gamma, beta, eps, act, True)
 
 
@@ -1251,13 +1304,13 @@ def mc_shade(feat, pos, nrm, view, pix_idx, n_dev, env_of_view, scene, mat, HW, 
 def layernorm_rows(x, gamma, beta, eps):
     """LayerNorm over the last dim of a contiguous bf16 tensor [..., C] (forward only)."""
     _need_cuda(x, gamma, beta)
-    assert x.dtype == torch.bfloat16 and x.is_contiguous() and gamma.dtype == torch.bfloat16
+    assert x.is_contiguous()
+    fn, name = _sym("dm_layernorm_bf16", _same_half(x, gamma, beta))
     C = x.shape[-1]
     rows = x.numel() // C
     y = torch.empty_like(x)
     with _Timed(f"layernorm[C={C}]", 4.0 * rows * C):
-        check(_lib.lib().dm_layernorm_bf16(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), rows, C,
-                                           float(eps), _stream()), "dm_layernorm_bf16")
+        check(fn(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), rows, C, float(eps), _stream()), name)
     return y
 
 
@@ -1272,8 +1325,8 @@ class _SoftmaxRows(torch.autograd.Function):
         rows = s.numel() // cols
         p = torch.empty_like(s)
         with _Timed(f"softmax_rows[{cols}]", 4.0 * rows * cols):
-            check(_lib.lib().dm_softmax_rows_bf16(s.data_ptr(), p.data_ptr(), rows, cols, float(scale), _stream()),
-                  "dm_softmax_rows_bf16")
+            fn, name = _sym("dm_softmax_rows_bf16", s.dtype)
+            check(fn(s.data_ptr(), p.data_ptr(), rows, cols, float(scale), _stream()), name)
         ctx.save_for_backward(p)
         ctx.scale = float(scale)
         return p
@@ -1281,18 +1334,18 @@ class _SoftmaxRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dp):
         (p,) = ctx.saved_tensors
-        dp = dp.contiguous()
+        dp = dp.to(p.dtype).contiguous()
         cols = p.shape[-1]
         rows = p.numel() // cols
         ds = torch.empty_like(p)
         with _Timed(f"softmax_rows_bwd[{cols}]", 6.0 * rows * cols):
-            check(_lib.lib().dm_softmax_rows_bwd_bf16(p.data_ptr(), dp.data_ptr(), ds.data_ptr(), rows, cols, ctx.scale, _stream()),
-                  "dm_softmax_rows_bwd_bf16")
+            fn, name = _sym("dm_softmax_rows_bwd_bf16", p.dtype)
+            check(fn(p.data_ptr(), dp.data_ptr(), ds.data_ptr(), rows, cols, ctx.scale, _stream()), name)
         return ds, None
 
 
 def softmax_rows_ok(s):
-    return s.is_cuda and s.dtype == torch.bfloat16 and s.shape[-1] % 8 == 0 and s.shape[-1] <= 8192
+    return s.is_cuda and s.dtype in HALF_DTYPES and s.shape[-1] % 8 == 0 and s.shape[-1] <= 8192
 
 
 def softmax_rows(s, scale):
@@ -1305,12 +1358,13 @@ def softmax_rows(s, scale):
 def geglu_rows(h):
     """h [..., 2*inner] bf16 contiguous -> h[..., :inner] * gelu(h[..., inner:]) (forward only)."""
     _need_cuda(h)
-    assert h.dtype == torch.bfloat16 and h.is_contiguous() and h.shape[-1] % 2 == 0
+    assert h.dtype in HALF_DTYPES and h.is_contiguous() and h.shape[-1] % 2 == 0
     inner = h.shape[-1] // 2
     rows = h.numel() // (2 * inner)
     y = torch.empty(*h.shape[:-1], inner, device=h.device, dtype=h.dtype)
     with _Timed(f"geglu[inner={inner}]", 6.0 * rows * inner):
-        check(_lib.lib().dm_geglu_bf16(h.data_ptr(), y.data_ptr(), rows, inner, _stream()), "dm_geglu_bf16")
+        fn, name = _sym("dm_geglu_bf16", h.dtype)
+        check(fn(h.data_ptr(), y.data_ptr(), rows, inner, _stream()), name)
     return y
 
 
@@ -1322,11 +1376,12 @@ def cat_add_nhwc(x, s, r=None, r_scale=1.0):
     Cs = s.shape[1]
     xn, sn = x.permute(0, 2, 3, 1), s.permute(0, 2, 3, 1)
     rn = r.permute(0, 2, 3, 1) if r is not None else None
-    assert xn.is_contiguous() and sn.is_contiguous() and (rn is None or rn.is_contiguous()) and x.dtype == torch.bfloat16
+    assert xn.is_contiguous() and sn.is_contiguous() and (rn is None or rn.is_contiguous())
+    fn, name = _sym("dm_cat_add_bf16", _same_half(x, s, r))
     y = torch.empty(B, H, W, Cx + Cs, device=x.device, dtype=x.dtype)
     with _Timed(f"cat_add[Cx={Cx},Cs={Cs}]", 2.0 * B * H * W * (2 * Cx + (3 if r is not None else 2) * Cs)):
-        check(_lib.lib().dm_cat_add_bf16(xn.data_ptr(), sn.data_ptr(), rn.data_ptr() if rn is not None else None, y.data_ptr(),
-                                         B * H * W, Cx, Cs, float(r_scale), _stream()), "dm_cat_add_bf16")
+        check(fn(xn.data_ptr(), sn.data_ptr(), rn.data_ptr() if rn is not None else None, y.data_ptr(), B * H * W, Cx, Cs,
+                 float(r_scale), _stream()), name)
     return y.permute(0, 3, 1, 2)
 
 

@@ -34,6 +34,8 @@ from .. import hipops
 # Tensors that are not on the GPU (the CPU test tier: fp32 plumbing of the same modules) take the ATen path.
 CONV_BACKEND = "mfma"
 
+HALF = (torch.bfloat16, torch.float16)       # element types the net kernels are built for (csrc/dm_elem.h; the reference's nets
+#                                               run in fp16, dreammat_guidance.py:56,92-94; bf16 is BASELINE's 1-GPU configuration)
 _FALLBACKS = {}
 
 
@@ -58,7 +60,7 @@ def fallbacks(clear=False):
 
 def _native_expected(x):
     """the product lowering is selected and the tensor is one the kernels of csrc/ exist for"""
-    return CONV_BACKEND == "mfma" and x.is_cuda and x.dtype in (torch.bfloat16, torch.float16)
+    return CONV_BACKEND == "mfma" and x.is_cuda and x.dtype in HALF
 # Differentiated layers with TRAINABLE parameters (the ControlNet training loop, row f-4): MFMA attention forward + backward,
 # 3x3 convolutions with the weight-gradient kernel, GroupNorm with affine gradients.  tools/train_step_probe.py assigns False
 # to time the torch-autograd lowering the kernels replace (im2col + hipBLASLt, matmul-softmax, ATen GroupNorm); no
@@ -67,6 +69,10 @@ TRAIN_KERNELS = True
 # V^T projections of the self-attention layers through the fused GEMM kernel with swapped operands (project_vt); tools may
 # assign False to time the hipBLASLt strided-batched product it replaces.
 VT_BY_FUSED_GEMM = True
+# "fp8": the self-attention of the frozen nets (64-wide heads, S >= 1024) on the MX-FP8 matrix instruction (csrc/attn_fp8.hip) --
+# BASELINE configs[4] "fp8 MFMA attention"; guidance.attention_precision sets it.  "16bit" (default): the bf16 / f16 kernels.
+ATTENTION_PRECISION = "16bit"
+FP8_MIN_SEQ = 1024
 
 
 class Conv2d(nn.Conv2d):
@@ -113,7 +119,7 @@ class Conv2d(nn.Conv2d):
 
     def mfma_ok(self, x):
         Cout, Cin, kh, kw = self.weight.shape
-        return (CONV_BACKEND == "mfma" and x.is_cuda and x.dtype == torch.bfloat16 and kh == 3 and kw == 3
+        return (CONV_BACKEND == "mfma" and x.is_cuda and x.dtype in HALF and kh == 3 and kw == 3
                 and Cin % 32 == 0 and Cout % 64 == 0 and self._frozen())
 
     def fused_ok(self, x):
@@ -148,7 +154,7 @@ class Conv2d(nn.Conv2d):
     def small_ok(self, x):
         """few-channel stem layers on the direct kernel (forward only, frozen nets)."""
         Cout, Cin, kh, kw = self.weight.shape
-        return (CONV_BACKEND == "mfma" and x.is_cuda and x.dtype == torch.bfloat16 and kh == 3 and kw == 3
+        return (CONV_BACKEND == "mfma" and x.is_cuda and x.dtype in HALF and kh == 3 and kw == 3
                 and Cin in hipops.SMALL_CONV_CIN and Cout % 16 == 0 and self.stride[0] == self.stride[1]
                 and self.padding[0] == self.padding[1] and self._frozen() and not (torch.is_grad_enabled() and x.requires_grad))
 
@@ -207,7 +213,7 @@ class Conv2d(nn.Conv2d):
         needs_grad = torch.is_grad_enabled() and x.requires_grad
         if self.small_ok(x):
             return self.forward_small(x, 0)
-        if (needs_grad and CONV_BACKEND == "mfma" and x.dtype == torch.bfloat16 and kh == 3 and kw == 3 and Cin <= 4
+        if (needs_grad and CONV_BACKEND == "mfma" and x.dtype in HALF and kh == 3 and kw == 3 and Cin <= 4
                 and Cout % 8 == 0 and (Cout <= 32 or Cout == 128) and self.stride == (1, 1) and self.padding == (1, 1) and self._frozen()):
             # the VAE encoder's conv_in on the rendered image (the only few-channel layer that needs a gradient)
             w4, w_dgrad4 = self._stem_prepared()
@@ -216,7 +222,7 @@ class Conv2d(nn.Conv2d):
         # zero-padded to whole 64-wide tiles (_prepared): always for the LDS-DMA kernel's shapes, and for the register-staged
         # kernel (Cin % 64 != 0) when nothing needs a gradient
         narrow = Cout % 64 != 0 and (Cin % 64 == 0 or (Cin % 32 == 0 and not needs_grad))
-        ok = (CONV_BACKEND == "mfma" and x.dtype == torch.bfloat16 and kh == 3 and kw == 3 and Cin % 32 == 0
+        ok = (CONV_BACKEND == "mfma" and x.dtype in HALF and kh == 3 and kw == 3 and Cin % 32 == 0
               and (Cout % 64 == 0 or narrow) and self.stride[0] == self.stride[1] and self._frozen()
               and (not needs_grad or (self.stride[0] == 1 and self.padding == (1, 1) and Cin % 64 == 0)))
         if not ok:
@@ -245,9 +251,10 @@ class Conv2d(nn.Conv2d):
 
 
 def _gn_kernel_ok(norm: nn.GroupNorm, x):
-    return (x.is_cuda and x.dtype == torch.bfloat16 and norm.num_groups == 32 and CONV_BACKEND == "mfma"
-            and norm.weight.dtype == torch.bfloat16
-            and (TRAIN_KERNELS or not (torch.is_grad_enabled() and norm.weight.requires_grad)))
+    return (x.is_cuda and x.dtype in HALF and norm.num_groups == 32 and CONV_BACKEND == "mfma"
+            and norm.weight.dtype == x.dtype
+            # trainable affine parameters (ControlNet training): the affine-gradient kernel exists for bf16 only
+            and (not (torch.is_grad_enabled() and norm.weight.requires_grad) or (TRAIN_KERNELS and x.dtype == torch.bfloat16)))
 
 
 def group_norm_act(norm: nn.GroupNorm, x, silu: bool):
@@ -267,15 +274,15 @@ def _rows_kernel_ok(x, *params):
     """token-matrix HIP kernels (LayerNorm, GEGLU) are forward-only: used when nothing on this path needs autograd
     (the diffusion nets in score distillation); otherwise the ATen ops run on the same device."""
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
-    return x.is_cuda and x.dtype == torch.bfloat16 and CONV_BACKEND == "mfma" and not needs_grad
+    return x.is_cuda and x.dtype in HALF and CONV_BACKEND == "mfma" and not needs_grad
 
 
 def linear_fused(x, weight, bias, residual=None):
     """F.linear(x, weight, bias) (+ residual): frozen bf16 layers on the GPU run the hand-written MFMA GEMM with the adds in
     its epilogue (csrc/conv.hip, 1-tap instantiation); everything else is the ATen call."""
     N, K = weight.shape
-    if (_rows_kernel_ok(x, weight) and weight.dtype == torch.bfloat16 and hipops.gemm_fused_ok(x.numel() // K, K, N)
-            and (residual is None or residual.dtype == torch.bfloat16)):
+    if (_rows_kernel_ok(x, weight) and weight.dtype == x.dtype and hipops.gemm_fused_ok(x.numel() // K, K, N)
+            and (residual is None or residual.dtype == x.dtype)):
         r = residual.contiguous() if residual is not None else None
         return hipops.gemm_fused(x.contiguous(), weight.detach().contiguous(), bias.detach() if bias is not None else None, r)
     if _native_expected(x):
@@ -377,8 +384,12 @@ def attention_core(q, k, v_weight, v_bias, kv_src, heads, kv_len):
     D = C // heads
     needs_grad = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or kv_src.requires_grad
                                               or v_weight.requires_grad)
-    if q.is_cuda and q.dtype == torch.bfloat16 and not needs_grad:     # inference: V arrives transposed from its projection
-        return hipops.attention(q, k[:, :kv_len], project_vt(v_weight, v_bias, kv_src, kv_len), heads)
+    if q.is_cuda and q.dtype in HALF and not needs_grad:     # inference: V arrives transposed from its projection
+        vt = project_vt(v_weight, v_bias, kv_src, kv_len)
+        if (ATTENTION_PRECISION == "fp8" and kv_len == k.shape[1] and kv_len >= FP8_MIN_SEQ and Sq >= FP8_MIN_SEQ
+                and hipops.attention_fp8_ok(q, k, heads)):
+            return hipops.attention_fp8(q, k, vt, heads)
+        return hipops.attention(q, k[:, :kv_len], vt, heads)
     v = F.linear(kv_src, v_weight, v_bias)
     if q.is_cuda and TRAIN_KERNELS and hipops.attention_train_ok(q, k, v, heads):     # differentiated (ControlNet training): MFMA fwd + bwd
         return hipops.attention_train(q, k[:, :kv_len], v[:, :kv_len], heads)
@@ -412,7 +423,7 @@ class Attention(nn.Module):
             src, kv_len = context.t, context.len
         q = linear_fused(x, self.to_q.weight, self.to_q.bias)
         frozen = not (torch.is_grad_enabled() and (self.to_k.weight.requires_grad or self.to_v.weight.requires_grad))
-        if (context is not None and context.bank is not None and frozen and x.is_cuda and x.dtype == torch.bfloat16
+        if (context is not None and context.bank is not None and frozen and x.is_cuda and x.dtype in HALF
                 and not (torch.is_grad_enabled() and x.requires_grad)):
             # frozen projections of a fixed bank of prompt embeddings: computed once, gathered per step
             key = (context.bank_key, self.to_k.weight.data_ptr(), self.to_k.weight._version, self.to_v.weight.data_ptr(),
@@ -458,7 +469,7 @@ class GEGLU(nn.Module):
     def forward(self, x):
         w = self.proj.weight
         N, K = w.shape
-        if (_rows_kernel_ok(x, w) and w.dtype == torch.bfloat16 and (N // 2) % 32 == 0
+        if (_rows_kernel_ok(x, w) and w.dtype == x.dtype and (N // 2) % 32 == 0
                 and hipops.gemm_fused_ok(x.numel() // K, K, N, geglu=True)):
             w_il, b_il = self._interleaved()                       # GEMM + GEGLU in one kernel: the 2x wide tensor never exists
             return hipops.gemm_fused(x.contiguous(), w_il, b_il, None, geglu=True)
@@ -542,7 +553,7 @@ class NetPrologue:
 
     @staticmethod
     def usable(t):
-        return t.is_cuda and t.dtype == torch.bfloat16 and CONV_BACKEND == "mfma"
+        return t.is_cuda and t.dtype in HALF and CONV_BACKEND == "mfma"
 
     def project_temb(self, temb):
         for m in self.resnets:                  # a projection left behind by a forward that raised midway must never be consumed

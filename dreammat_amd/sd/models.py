@@ -93,7 +93,7 @@ class MidBlock(nn.Module):
 def _cat_skip(x, skip):
     """torch.cat([x, skip], dim=1) with skip = s or the pair (s, ControlNet residual r) -> s + r"""
     s, r = skip if isinstance(skip, tuple) else (skip, None)
-    fused = (x.is_cuda and x.dtype == torch.bfloat16 and not (torch.is_grad_enabled() and (x.requires_grad or s.requires_grad
+    fused = (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and not (torch.is_grad_enabled() and (x.requires_grad or s.requires_grad
              or (r is not None and r.requires_grad))) and x.shape[1] % 8 == 0 and s.shape[1] % 8 == 0
              and x.permute(0, 2, 3, 1).is_contiguous() and s.permute(0, 2, 3, 1).is_contiguous()
              and (r is None or (r.dtype == x.dtype and r.permute(0, 2, 3, 1).is_contiguous())))
@@ -296,6 +296,10 @@ class VaeAttention(nn.Module):
             h = h.reshape(B, H * W, C)
         else:
             h = group_norm_act(self.group_norm, x, False).permute(0, 2, 3, 1).reshape(B, H * W, C)
+        if layers._native_expected(h):
+            # the one differentiated attention of the path (1 head of 512): projections and the two products on hipBLASLt under
+            # autograd, the softmax between them on the row kernels
+            layers.note_fallback("vae_attention", f"C={C} S={H * W} autograd: 4 projections + QK^T + PV")
         q, k, v = self.to_q(h), self.to_k(h), self.to_v(h)
         s = torch.matmul(q, k.transpose(1, 2))
         if hipops.softmax_rows_ok(s) and layers.CONV_BACKEND == "mfma":

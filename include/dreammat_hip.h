@@ -409,6 +409,64 @@ int dm_cat_add_bf16(const void* x, const void* s, const void* r, void* y, long l
 int dm_softmax_rows_bf16(const void* s, void* p, long long rows, int cols, float scale, dm_stream_t stream);
 int dm_softmax_rows_bwd_bf16(const void* p, const void* dp, void* ds, long long rows, int cols, float scale, dm_stream_t stream);
 
+/* ---- IEEE-half instantiations of the net kernels (ABI v11) --------------------------------- */
+/* The reference's nets run in fp16 (`half_precision_weights`, threestudio/models/guidance/dreammat_guidance.py:56,92-94;
+ * BASELINE.json configs[4] "fp16 UNet").  Every entry point of the sections above whose tensors are bf16 exists a second time for
+ * `_Float16` tensors -- the same sources compiled with -DDM_F16 (csrc/dm_elem.h), v_mfma_f32_32x32x16_f16 in place of the bf16
+ * instruction, identical tiles / layouts / arguments / error behaviour.  Names: f16 in place of bf16, or an _f16 suffix where the
+ * bf16 name carries no dtype.  (The attention kernels that keep un-normalised probabilities in 16 bits bound them by half's
+ * exponent range and send a workgroup whose rows leave it to their exact path.)  The training-only entry points
+ * (dm_attention_bwd_bf16, dm_conv3x3_wgrad_nhwc_bf16, dm_groupnorm_nhwc_bwd_affine) stay bf16: row f-4 trains in bf16. */
+int dm_attention_fwd_f16(const void* q, const void* k, const void* vt, void* out, int B, int Hh, int Sq, int Skv,
+                          int D, long long q_bs, long long q_ss, long long q_hs, long long k_bs, long long k_ss,
+                          long long k_hs, long long vt_bs, long long vt_hs, long long vt_ds, long long o_bs,
+                          long long o_ss, long long o_hs, float scale, dm_stream_t stream);
+int dm_attention_fwd_lse_f16(const void* q, const void* k, const void* v, void* out, float* lse, int B, int Hh, int Sq,
+                              int Skv, int D, long long q_bs, long long q_ss, long long q_hs, long long k_bs,
+                              long long k_ss, long long k_hs, long long o_bs, long long o_ss, long long o_hs, float scale,
+                              dm_stream_t stream);
+int dm_conv3x3_nhwc_f16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin,
+                         int Hout, int Wout, int Cout, int stride, int pad_y, int pad_x, dm_stream_t stream);
+int dm_conv3x3_nhwc_f16_fused(const void* x, const void* w, const void* bias, const void* rowbias, const void* residual,
+                               void* y, int B, int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int stride,
+                               int pad_y, int pad_x, dm_stream_t stream);
+int dm_conv2x2_nhwc_f16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin, int Hout, int Wout,
+                         int Cout, int pad_y, int pad_x, dm_stream_t stream);
+int dm_conv3x3_small_nhwc_f16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin,
+                               int Hout, int Wout, int Cout, int stride, int pad_y, int pad_x, int act, dm_stream_t stream);
+int dm_conv3x3_small_res_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, int res_B, void* y, int B,
+                                   int Hin, int Win, int Cin, int Hout, int Wout, int Cout, int stride, int pad_y, int pad_x, int act,
+                                   dm_stream_t stream);
+int dm_gemm_f16_fused(const void* x, const void* w, const void* bias, const void* residual, void* y, long long M, int K,
+                       int N, int geglu, dm_stream_t stream);
+int dm_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, long long rows, int C, float eps,
+                      dm_stream_t stream);
+int dm_geglu_f16(const void* h, void* y, long long rows, int inner, dm_stream_t stream);
+int dm_cat_add_f16(const void* x, const void* s, const void* r, void* y, long long rows, int Cx, int Cs, float r_scale,
+                    dm_stream_t stream);
+int dm_softmax_rows_f16(const void* s, void* p, long long rows, int cols, float scale, dm_stream_t stream);
+int dm_softmax_rows_bwd_f16(const void* p, const void* dp, void* ds, long long rows, int cols, float scale, dm_stream_t stream);
+int dm_groupnorm_nhwc_fwd_f16(const void* x, const void* gamma, const void* beta, void* y, float* ws, int B, int HW,
+                          int C, float eps, int act, dm_stream_t stream);
+int dm_groupnorm_nhwc_infer_f16(const void* x, const void* gamma, const void* beta, void* y, float* ws, int B, int HW, int C,
+                            float eps, int act, dm_stream_t stream);
+int dm_groupnorm_nhwc_bwd_f16(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* ws,
+                          int B, int HW, int C, float eps, int act, dm_stream_t stream);
+int dm_groupnorm_nhwc_bwd_res_f16(const void* x, const void* gamma, const void* beta, const void* dy, const void* dres, void* dx,
+                              float* ws, int B, int HW, int C, float eps, int act, dm_stream_t stream);
+
+/* ---- MX-FP8 attention (ABI v11) ------------------------------------------------------------- */
+/* BASELINE.json configs[4] "fp8 MFMA attention": softmax(q k^T scale) v of the 64-wide SD-2.1 heads with both matrix products
+ * on v_mfma_scale_f32_32x32x64_f8f6f4 (OCP e4m3 elements, one E8M0 scale per 32 elements of the contracted dimension).
+ * q, k, vt, out and their strides: as dm_attention_fwd_bf16 with D = 64; elem_f16 = 0: bf16 tensors, 1: IEEE half.
+ * Sq % 128 == 0, Skv % 64 == 0 (else DM_ERR_UNSUPPORTED: the caller keeps the 16-bit kernels).
+ * ws: dm_attention_fp8_workspace_bytes(B, Hh, Sq, Skv) bytes of scratch (the quantised operands), 256-byte aligned. */
+size_t dm_attention_fp8_workspace_bytes(int B, int Hh, int Sq, int Skv);
+int dm_attention_fwd_fp8(const void* q, const void* k, const void* vt, void* out, int B, int Hh, int Sq, int Skv, int D,
+                         long long q_bs, long long q_ss, long long q_hs, long long k_bs, long long k_ss, long long k_hs,
+                         long long vt_bs, long long vt_hs, long long vt_ds, long long o_bs, long long o_ss, long long o_hs,
+                         float scale, int elem_f16, void* ws, size_t ws_bytes, dm_stream_t stream);
+
 /* ---- optimiser ---------------------------------------------------------------------------- */
 /* torch.optim.Adam step (configs/dreammat.yaml:110-115 via systems/utils.py:34-53) over one flat
  * fp32 buffer; grad is multiplied by grad_scale first (1/world after a sum all-reduce) and

@@ -592,28 +592,31 @@ def test_static_isa_guards_on_the_lds_dma_main_loops():
     iw = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(iw)
 
-    def steady_blocks(src, pattern, n_mfma):
-        (name, body), = list(iw.kernels(iw.assembly(os.path.join(root, "dreammat_amd", "csrc", src)), pattern))
-        return [ins for _, ins in iw.blocks(body) if sum(i.startswith("v_mfma") for i in ins) == n_mfma]
-    tiles = steady_blocks("attn_w64.hip", "k_attn_fwd_w64ILi2E", 32)
-    tiles = [t for t in tiles if len(t) < 300]                      # the unrolled ring of the main loop (not the exact path)
-    assert len(tiles) >= 5
-    for t in tiles:
-        waits = [i.split(None, 1)[1] for i in t if i.startswith("s_waitcnt")]
-        assert not any("vmcnt(0)" in w for w in waits), waits
-        assert 12 <= sum(i.startswith("ds_read_b128") for i in t) <= 16 and sum(i.startswith("buffer_load") for i in t) <= 4
-    # (round 4: + the 2 x 2 instance of the stride-2 data gradients / upsample convs, the 128-row tile of the balanced Cout = 320 launches)
-    for pattern in ("k_conv3x3_dmaILi512ELi128ELi8ELi4ELi2ELi9ELi0", "k_conv3x3_dmaILi256ELi256ELi8ELi2ELi2ELi9ELi0",
-                    "k_conv3x3_dmaILi256ELi256ELi8ELi2ELi2ELi4ELi0"):
-        chunks = steady_blocks("conv.hip", pattern, 8)
-        assert chunks
-        for c in chunks:
-            assert not any(i.startswith("s_waitcnt") and "vmcnt(0)" in i for i in c)
-            assert not any("scratch_" in i for i in c)
-    # the 128-row attention kernel: one unrolled block of five tiles, 64 MFMAs each, no scratch, no drained DMA ring
-    (name, body), = list(iw.kernels(iw.assembly(os.path.join(root, "dreammat_amd", "csrc", "attn_w128.hip")), "k_attn_fwd_w128ILi2ELi4E"))
-    main = max((ins for _, ins in iw.blocks(body)), key=lambda ins: sum(i.startswith("v_mfma") for i in ins))
-    assert sum(i.startswith("v_mfma") for i in main) == 320
-    assert not any("scratch_" in i for i in body)
-    assert not any(i.startswith("s_waitcnt") and "vmcnt(0)" in i for i in main)
-    assert sum(i.startswith("v_accvgpr") for i in main) <= 8, "register copies in the main loop: the AGPR / VGPR split of attn_w128 broke"
+    for defines in ((), ("-DDM_F16",)):         # the bf16 build and the IEEE-half instantiation of the same sources (csrc/dm_elem.h)
+        asm = {src: iw.assembly(os.path.join(root, "dreammat_amd", "csrc", src), defines) for src in ("attn_w64.hip", "conv.hip", "attn_w128.hip")}
+
+        def steady_blocks(src, pattern, n_mfma):
+            (name, body), = list(iw.kernels(asm[src], pattern))
+            return [ins for _, ins in iw.blocks(body) if sum(i.startswith("v_mfma") for i in ins) == n_mfma]
+        tiles = steady_blocks("attn_w64.hip", "k_attn_fwd_w64ILi2E", 32)
+        tiles = [t for t in tiles if len(t) < 300]                      # the unrolled ring of the main loop (not the exact path)
+        assert len(tiles) >= 5
+        for t in tiles:
+            waits = [i.split(None, 1)[1] for i in t if i.startswith("s_waitcnt")]
+            assert not any("vmcnt(0)" in w for w in waits), waits
+            assert 12 <= sum(i.startswith("ds_read_b128") for i in t) <= 16 and sum(i.startswith("buffer_load") for i in t) <= 4
+        # (round 4: + the 2 x 2 instance of the stride-2 data gradients / upsample convs, the 128-row tile of the balanced Cout = 320 launches)
+        for pattern in ("k_conv3x3_dmaILi512ELi128ELi8ELi4ELi2ELi9ELi0", "k_conv3x3_dmaILi256ELi256ELi8ELi2ELi2ELi9ELi0",
+                        "k_conv3x3_dmaILi256ELi256ELi8ELi2ELi2ELi4ELi0"):
+            chunks = steady_blocks("conv.hip", pattern, 8)
+            assert chunks
+            for c in chunks:
+                assert not any(i.startswith("s_waitcnt") and "vmcnt(0)" in i for i in c)
+                assert not any("scratch_" in i for i in c)
+        # the 128-row attention kernel: one unrolled block of five tiles, 64 MFMAs each, no scratch, no drained DMA ring
+        (name, body), = list(iw.kernels(asm["attn_w128.hip"], "k_attn_fwd_w128ILi2ELi4E"))
+        main = max((ins for _, ins in iw.blocks(body)), key=lambda ins: sum(i.startswith("v_mfma") for i in ins))
+        assert sum(i.startswith("v_mfma") for i in main) == 320
+        assert not any("scratch_" in i for i in body)
+        assert not any(i.startswith("s_waitcnt") and "vmcnt(0)" in i for i in main)
+        assert sum(i.startswith("v_accvgpr") for i in main) <= 8, "register copies in the main loop: the AGPR / VGPR split of attn_w128 broke"

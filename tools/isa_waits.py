@@ -17,8 +17,9 @@ sys.path.insert(0, ROOT)
 from dreammat_amd.csrc import build as hip_build  # noqa: E402
 
 
-def assembly(src):
-    extra = hip_build.SOURCES.get(os.path.basename(src), [])
+def assembly(src, defines=()):
+    """defines: e.g. ("-DDM_F16",) for the IEEE-half instantiation of a net kernel (csrc/dm_elem.h)"""
+    extra = hip_build.SOURCES.get(os.path.basename(src), []) + list(defines)
     out = os.path.join(tempfile.mkdtemp(), "k.s")
     cmd = [os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")] + hip_build.COMMON + extra + ["-S", "--cuda-device-only", src, "-o", out]
     subprocess.check_call([c for c in cmd if c != "-fPIC"], stderr=subprocess.DEVNULL)
