@@ -207,7 +207,8 @@ def test_f16_row_kernels_vs_fp32(dev):
     h = torch.randn(4096, 2560).to(H16)
     y = hipops.geglu_rows(h.to(dev)).float().cpu()
     val, gate = h.float().chunk(2, -1)
-    assert (y - val * torch.nn.functional.gelu(gate)).abs().max().item() < 4e-3
+    refg = val * torch.nn.functional.gelu(gate)
+    assert (y - refg).abs().max().item() < 2e-3 * refg.abs().max().item() + 1e-3        # gelu(gate) and the product are each rounded to half
     x = torch.randn(3, 640, 16, 16).to(dev).to(H16).contiguous(memory_format=torch.channels_last)
     s = torch.randn(3, 320, 16, 16).to(dev).to(H16).contiguous(memory_format=torch.channels_last)
     r = torch.randn(3, 320, 16, 16).to(dev).to(H16).contiguous(memory_format=torch.channels_last)
