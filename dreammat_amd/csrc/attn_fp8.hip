@@ -19,16 +19,20 @@
 //
 // Kernel.  A workgroup = 4 waves x 32 query rows, no LDS, no barrier: K / V^T tiles are 4 KB each and come straight from L2 as
 // two 16-byte loads per lane and operand (the 4 waves of a workgroup and the workgroups of a (batch, head) on one XCD share
-// them there), double-buffered in registers.  Per 64-row kv tile and wave: 2 MFMAs form S^T = K.Q'^T (two 32 x 32 tiles, the
-// whole head dimension in one instruction each), the textbook online softmax runs on the 32 scores a lane holds, the
-// probabilities are packed 4 per dword, and 2 MFMAs add V^T.P^T to the two 32 x 32 halves of O^T.
+// them there); K double-buffered in registers, V^T requested at the top of its tile.  Per 64-row kv tile and wave: 2 MFMAs form
+// S^T = K.Q'^T - shift (two 32 x 32 tiles, the whole head dimension in one instruction each; the row shift enters through the C
+// operand), the probabilities are ONE v_exp_f32 each, packed 4 per dword, and 3 MFMAs add V^T.P^T to the two 32 x 32 halves of
+// O^T and to the row sums (a 33rd channel of ones).
 //   S^T lane (q = l % 32, hi = l / 32) register r of tile t  <->  kv = 32 t + 4 hi + (r & 3) + 8 (r >> 2):
 //   the B operand of V^T.P^T wants, in lane (q, H), the 32 probabilities of kv block H.  Lane (q, 0) owns half of block 0 and
 //   half of block 1, lane (q, 1) the other halves: v_permlane32_swap(tile-0 dword g, tile-1 dword g) hands each lane the
 //   missing half.  Byte position 4 g + e of the operand then is kv 8 g + e, position 16 + 4 g + e is kv 8 g + 4 + e -- the
 //   permutation k_fp8_quant_vt applies to V^T's bytes (a contraction only needs A and B to agree position by position).
-// What bounds it: per tile a wave issues 4 MFMAs of 64 cycles (256) beside 64 v_exp_f32, 64 v_sub, 64 v_max, 64 v_add and 32
-// v_cvt_pk_fp8_f32 -- the softmax, not the matrix pipe (DESIGN.md section 3e has the measurement).
+// What bounds it: the softmax on the vector pipe, not the matrix pipe.  Per tile a wave issues 5 MFMAs of 64 cycles (320) beside
+// 64 v_exp_f32, 32 v_cvt_pk_fp8_f32 and 32 v_max3_f32 (~9.4 / 6.4 / 5.5 issue cycles each from one wave, tools/issue_probe.cpp:
+// ~1000 cycles); the first version (running maximum, subtraction and row sum as VALU code: 64 more v_sub, 64 v_add, 32 v_max)
+// measured 725 us at 24 x 5 x 4096^2 against 419 us of the bf16 kernel.  At D = 64 a score costs the vector pipe more than it
+// costs the fp8 matrix pipe four times over, so the 2x MFMA rate cannot show.
 #include <algorithm>
 #include <cstdint>
 
@@ -149,9 +153,8 @@ __global__ __launch_bounds__(256) void k_fp8_quant_vt(const T* __restrict__ src,
 constexpr int kRowsPerWg = 128;      // 4 waves x 32 query rows
 constexpr int kPScaleByte = 127 - 8; // E8M0 of the constant 2^-8 that undoes the 2^8 inside the stored probabilities
 
-struct KvFrag {
+struct KFrag {
     i32x8 k[2]; int ks[2];           // K rows 32 t + l31 of the tile, bytes 32 hi ..; their scale bytes
-    i32x8 v[2]; int vs[2];           // V^T channels 32 f + l31, (permuted) bytes of kv block hi; their scale bytes
 };
 
 template <typename T>
@@ -185,67 +188,75 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_fp8(Fp8Args a) {
     const unsigned char* ksc = a.ks + ((long long)bh * a.Skv + l31) * 2 + hi;
     const unsigned char* v8 = a.v8 + ((long long)bh * n_tiles * 64 + l31) * 64 + 32 * hi;
     const unsigned char* vsc = a.vs + ((long long)bh * n_tiles * 64 + l31) * 2 + hi;
-    auto load_tile = [&](int j, KvFrag& f) __attribute__((always_inline)) {
+    auto load_k = [&](int j, KFrag& f) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const i32x4* p = reinterpret_cast<const i32x4*>(k8 + ((long long)j * 64 + 32 * t) * 64);
             const i32x4 lo = p[0], up = p[1];
             f.k[t] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
             f.ks[t] = ksc[((long long)j * 64 + 32 * t) * 2];
-            const i32x4* pv = reinterpret_cast<const i32x4*>(v8 + ((long long)j * 64 + 32 * t) * 64);
-            const i32x4 vlo = pv[0], vup = pv[1];
-            f.v[t] = i32x8{vlo[0], vlo[1], vlo[2], vlo[3], vup[0], vup[1], vup[2], vup[3]};
-            f.vs[t] = vsc[((long long)j * 64 + 32 * t) * 2];
         }
     };
 
-    f32x16 o[2];
+    // O^T accumulators: fragments 0 / 1 = channels 0-31 / 32-63; fragment 2 = a 33rd "channel" of ones in row 0 (lanes 0-31,
+    // register 0), whose product with P^T is the row sum of the probabilities AS ROUNDED to e4m3 -- numerator and denominator see
+    // the same rounding, and the 64 v_add_f32 per tile the sum would cost on the vector pipe (5.5 cycles each, beside 4 MFMAs of
+    // 64) become one more MFMA
+    f32x16 o[3];
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int f = 0; f < 3; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[f][r] = 0.f;
-    float m = -INFINITY, l = 0.f;        // running maximum (log2 domain) and sum of this lane's query row; both lanes of a row agree on m
+    const int one_w = l31 == 0 ? 0x38383838 : 0;       // e4m3 1.0 = 0x38
+    const i32x8 onesA = {one_w, one_w, one_w, one_w, one_w, one_w, one_w, one_w};
+    // C operand of the first product: -shift of this lane's query row, so that the MFMA delivers s - shift and a probability is
+    // ONE v_exp_f32.  shift = (row maximum so far) - 8: the stored probability exp2(s - shift) <= 2^8 < 448.  It moves (rarely
+    // after the first tiles) when a row's maximum grows: O, the scores at hand and the C operand are re-based by the difference.
+    f32x16 cinit;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
 
-    auto tile_body = [&](const KvFrag& f) __attribute__((always_inline)) {
-        f32x16 s[2];
+    auto tile_body = [&](const KFrag& fk, int j, bool first) __attribute__((always_inline)) {
+        // this tile's V^T fragments: requested now, consumed after the softmax
+        i32x8 vA[2];
+        int vS[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            f32x16 z;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) z[r] = 0.f;
-            // S^T[kv][q] = sum_d K[kv][d] Q'[q][d]: A = K rows (fp8), B = Q' rows (fp8), both with their block scales
-            s[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f.k[t], qB, z, 0, 0, 0, f.ks[t], 0, qsc);
+            const i32x4* pv = reinterpret_cast<const i32x4*>(v8 + ((long long)j * 64 + 32 * t) * 64);
+            const i32x4 vlo = pv[0], vup = pv[1];
+            vA[t] = i32x8{vlo[0], vlo[1], vlo[2], vlo[3], vup[0], vup[1], vup[2], vup[3]};
+            vS[t] = vsc[((long long)j * 64 + 32 * t) * 2];
         }
-        float mx = s[0][0];
+        f32x16 s[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < 2; ++t)      // S^T[kv][q] - shift[q] = sum_d K[kv][d] Q'[q][d] - shift[q]
+            s[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fk.k[t], qB, cinit, 0, 0, 0, fk.ks[t], 0, qsc);
+        float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m, mx);
-        if (__any(m_new > m)) {          // (first tile: every row; later: only when a row's maximum moves)
-            const float alpha = __builtin_amdgcn_exp2f(m - m_new);
+        const bool grow = mx > 8.f;
+        if (first || __any(grow)) {
+            const float delta = (first || grow) ? mx - 8.f : 0.f;
+            const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-            for (int ff = 0; ff < 2; ++ff)
+            for (int ff = 0; ff < 3; ++ff)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[ff][r] *= alpha;
-            l *= alpha;
-            m = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { cinit[r] -= delta; s[0][r] -= delta; s[1][r] -= delta; }
         }
-        const float shift = m - 8.f;     // the stored probability is exp2(s - m) 2^8
         int pt[2][4];
-        float ls = 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float p[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { p[e] = __builtin_amdgcn_exp2f(s[t][4 * g + e] - shift); ls += p[e]; }
+                for (int e = 0; e < 4; ++e) p[e] = __builtin_amdgcn_exp2f(s[t][4 * g + e]);
                 int w = __builtin_amdgcn_cvt_pk_fp8_f32(p[0], p[1], 0, false);
                 pt[t][g] = __builtin_amdgcn_cvt_pk_fp8_f32(p[2], p[3], w, true);
             }
-        l += ls;
         // lanes 0-31 keep their tile-0 dwords and receive the partner's, lanes 32-63 likewise for tile 1 (see the header)
         i32x8 pB;
 #pragma unroll
@@ -256,22 +267,26 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_fp8(Fp8Args a) {
         }
 #pragma unroll
         for (int ff = 0; ff < 2; ++ff)   // O^T[d][q] += sum_kv V^T[d][kv] P[q][kv]
-            o[ff] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(f.v[ff], pB, o[ff], 0, 0, 0, f.vs[ff], 0, kPScaleByte);
+            o[ff] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vA[ff], pB, o[ff], 0, 0, 0, vS[ff], 0, kPScaleByte);
+        o[2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(onesA, pB, o[2], 0, 0, 0, 127, 0, kPScaleByte);
     };
 
-    KvFrag fa, fb;
-    load_tile(0, fa);
-    int j = 0;
+    KFrag fa, fb;
+    load_k(0, fa);
+    if (n_tiles > 1) load_k(1, fb);
+    tile_body(fa, 0, true);
+    int j = 1;
     for (; j + 2 <= n_tiles; j += 2) {
-        load_tile(j + 1, fb);
-        tile_body(fa);
-        if (j + 2 < n_tiles) load_tile(j + 2, fa);
-        tile_body(fb);
+        load_k(j + 1, fa);
+        tile_body(fb, j, false);
+        if (j + 2 < n_tiles) load_k(j + 2, fb);
+        tile_body(fa, j + 1, false);
     }
-    if (j < n_tiles) tile_body(fa);
+    if (j < n_tiles) tile_body(fb, j, false);
 
-    const float lt = l + __shfl_xor(l, 32);
-    const float inv = 256.f / lt;         // the probabilities carried 2^8
+    // row sum: row 0 of fragment 2 = register 0 of lanes 0-31 (column q = lane)
+    const float lt = __shfl(o[2][0], l31);
+    const float inv = 1.f / lt;           // (numerator and denominator carry the same 2^8 / 2^-8)
     // O^T lane (q, hi), fragment f, register r = channel 32 f + 8 (r >> 2) + 4 hi + (r & 3): four consecutive channels per group
     const int bq = bh / a.Hh, hq = bh - bq * a.Hh;
     T* op = reinterpret_cast<T*>(a.out) + bq * a.o_bs + (long long)(qblk * kRowsPerWg + wave * 32 + l31) * a.o_ss + (long long)hq * a.o_hs;
