@@ -6,16 +6,17 @@
 // internal format.
 //
 // Format.  OCP e4m3 elements with one power-of-two scale (E8M0 byte) per 32 consecutive elements ALONG THE CONTRACTED
-// DIMENSION -- the MX block the instruction dequantises in hardware: lane l of a 32x32x64 operand holds row l % 32, 32 bytes =
-// k-block l / 32, and its scale byte multiplies exactly those 32 bytes.
+// DIMENSION -- the MX block the instruction dequantises in hardware.  Operand layout of the 32x32x64 instruction (measured, round
+// 5: the first version assumed "lane l holds k-block l / 32" and was wrong exactly where the two blocks of a row had different
+// scales): lane l holds row l % 32; with H = l / 32 its bytes 0-15 are k = 16 H .. 16 H + 15 and its bytes 16-31 are
+// k = 32 + 16 H .. (two 32x32x32 operands side by side), while its SCALE byte is that of block H (k = 32 H .. 32 H + 31) of the row.
 //   Q' = Q * softmax_scale * log2 e and K: blocks of 32 along the head dimension (2 per row), scale = 2^(E - 8) with E the
 //        exponent of the block's largest magnitude, so that the scaled block lies in [128, 256) < 448 (no saturation);
 //   V^T: blocks of 32 kv positions of one channel;
-//   P:   exp2(s - m + 8) in [0, 256] with the constant scale 2^-8 (values below 2^-17 of the row maximum flush to zero).
+//   P:   exp2(s - shift) in [0, 256] with the constant scale 2^-8 (values below 2^-17 of the row maximum flush to zero).
 // Two pre-passes (k_fp8_quant_rows for Q and K, k_fp8_quant_vt for V^T) write the 8-bit operands + scale bytes into a
 // workspace: 1 byte per element instead of 2 on every re-read of K / V by the query blocks.  V^T is stored tile-major
-// ([kv tile of 64][channel][64 bytes]) with the 32 bytes of a block PERMUTED to the order in which the probabilities come
-// out of the first product (below), so that the second product needs no data movement beyond one v_permlane32_swap per dword.
+// ([kv tile of 64][channel][64 bytes]).
 //
 // Kernel.  A workgroup = 4 waves x 32 query rows, no LDS, no barrier: K / V^T tiles are 4 KB each and come straight from L2 as
 // two 16-byte loads per lane and operand (the 4 waves of a workgroup and the workgroups of a (batch, head) on one XCD share
@@ -23,11 +24,11 @@
 // S^T = K.Q'^T - shift (two 32 x 32 tiles, the whole head dimension in one instruction each; the row shift enters through the C
 // operand), the probabilities are ONE v_exp_f32 each, packed 4 per dword, and 3 MFMAs add V^T.P^T to the two 32 x 32 halves of
 // O^T and to the row sums (a 33rd channel of ones).
-//   S^T lane (q = l % 32, hi = l / 32) register r of tile t  <->  kv = 32 t + 4 hi + (r & 3) + 8 (r >> 2):
-//   the B operand of V^T.P^T wants, in lane (q, H), the 32 probabilities of kv block H.  Lane (q, 0) owns half of block 0 and
-//   half of block 1, lane (q, 1) the other halves: v_permlane32_swap(tile-0 dword g, tile-1 dword g) hands each lane the
-//   missing half.  Byte position 4 g + e of the operand then is kv 8 g + e, position 16 + 4 g + e is kv 8 g + 4 + e -- the
-//   permutation k_fp8_quant_vt applies to V^T's bytes (a contraction only needs A and B to agree position by position).
+//   S^T lane (q = l % 32, hi = l / 32) register r of tile t  <->  kv = 32 t + 4 hi + (r & 3) + 8 (r >> 2), i.e. the dword of
+//   group g = r >> 2 holds kv 32 t + 8 g + 4 hi + {0..3}.  The B operand of V^T.P^T wants, in lane (q, H), kv 16 H + {0..15} of
+//   tile 0 (bytes 0-15) and of tile 1 (bytes 16-31): groups 0, 1 of both lanes of the pair for H = 0, groups 2, 3 for H = 1.
+//   v_permlane32_swap(group g, group g + 2) for g = 0, 1 hands each lane the partner's half, and the dwords (own g | partner g |
+//   own g + 1 | partner g + 1) are the 16 positions in natural order -- V^T needs no permutation.
 // What bounds it: the softmax on the vector pipe, not the matrix pipe.  Per tile a wave issues 5 MFMAs of 64 cycles (320) beside
 // 64 v_exp_f32, 32 v_cvt_pk_fp8_f32 and 32 v_max3_f32 (~9.4 / 6.4 / 5.5 issue cycles each from one wave, tools/issue_probe.cpp:
 // ~1000 cycles); the first version (running maximum, subtraction and row sum as VALU code: 64 more v_sub, 64 v_add, 32 v_max)
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256) void k_fp8_quant_vt(const T* __restrict__ src,
     }
     const int e = mx_scale_exp(amax);
     int w[8];
-    pack_block<true>(v, e, w);
+    pack_block<false>(v, e, w);
     const int tile = blk >> 1, hh = blk & 1;
     const long long slot = (bh * (Skv / 64) + tile) * 64 + d;
     i32x4* o = reinterpret_cast<i32x4*>(dst8 + slot * 64 + 32 * hh);
@@ -179,20 +180,20 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_fp8(Fp8Args a) {
     const int n_tiles = a.Skv / 64;
     const long long qrow = (long long)bh * a.Sq + qblk * kRowsPerWg + wave * 32 + l31;
 
-    const i32x4* qp = reinterpret_cast<const i32x4*>(a.q8 + qrow * 64 + 32 * hi);
-    const i32x4 q0 = qp[0], q1 = qp[1];
+    const i32x4* qp = reinterpret_cast<const i32x4*>(a.q8 + qrow * 64 + 16 * hi);
+    const i32x4 q0 = qp[0], q1 = qp[2];              // bytes 16 hi .. and 32 + 16 hi .. of the row (operand layout: see the header)
     const i32x8 qB = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
     const int qsc = a.qs[qrow * 2 + hi];
 
-    const unsigned char* k8 = a.k8 + ((long long)bh * a.Skv + l31) * 64 + 32 * hi;
+    const unsigned char* k8 = a.k8 + ((long long)bh * a.Skv + l31) * 64 + 16 * hi;
     const unsigned char* ksc = a.ks + ((long long)bh * a.Skv + l31) * 2 + hi;
-    const unsigned char* v8 = a.v8 + ((long long)bh * n_tiles * 64 + l31) * 64 + 32 * hi;
+    const unsigned char* v8 = a.v8 + ((long long)bh * n_tiles * 64 + l31) * 64 + 16 * hi;
     const unsigned char* vsc = a.vs + ((long long)bh * n_tiles * 64 + l31) * 2 + hi;
     auto load_k = [&](int j, KFrag& f) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const i32x4* p = reinterpret_cast<const i32x4*>(k8 + ((long long)j * 64 + 32 * t) * 64);
-            const i32x4 lo = p[0], up = p[1];
+            const i32x4 lo = p[0], up = p[2];
             f.k[t] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
             f.ks[t] = ksc[((long long)j * 64 + 32 * t) * 2];
         }
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_fp8(Fp8Args a) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const i32x4* pv = reinterpret_cast<const i32x4*>(v8 + ((long long)j * 64 + 32 * t) * 64);
-            const i32x4 vlo = pv[0], vup = pv[1];
+            const i32x4 vlo = pv[0], vup = pv[2];
             vA[t] = i32x8{vlo[0], vlo[1], vlo[2], vlo[3], vup[0], vup[1], vup[2], vup[3]};
             vS[t] = vsc[((long long)j * 64 + 32 * t) * 2];
         }
@@ -257,14 +258,18 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_fp8(Fp8Args a) {
                 int w = __builtin_amdgcn_cvt_pk_fp8_f32(p[0], p[1], 0, false);
                 pt[t][g] = __builtin_amdgcn_cvt_pk_fp8_f32(p[2], p[3], w, true);
             }
-        // lanes 0-31 keep their tile-0 dwords and receive the partner's, lanes 32-63 likewise for tile 1 (see the header)
+        // B operand of V^T.P^T: lane (q, H) wants kv 16 H .. 16 H + 15 of both 32-row score tiles.  Lane (q, 0) keeps its groups
+        // g = 0, 1 and receives the partner's, lane (q, 1) likewise for g = 2, 3 -- one v_permlane32_swap per dword pair -- and the
+        // bytes come out in natural kv order (see the header)
         i32x8 pB;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)pt[0][g], (unsigned)pt[1][g], false, false);
-            pB[g] = (int)sw[0];
-            pB[4 + g] = (int)sw[1];
-        }
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)pt[t][g], (unsigned)pt[t][g + 2], false, false);
+                pB[4 * t + 2 * g] = (int)sw[0];            // lanes 0-31: own (hi 0, g)     | lanes 32-63: (hi 0, g + 2) of the partner
+                pB[4 * t + 2 * g + 1] = (int)sw[1];        // lanes 0-31: (hi 1, g) received | lanes 32-63: own (hi 1, g + 2)
+            }
 #pragma unroll
         for (int ff = 0; ff < 2; ++ff)   // O^T[d][q] += sum_kv V^T[d][kv] P[q][kv]
             o[ff] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vA[ff], pB, o[ff], 0, 0, 0, vS[ff], 0, kPScaleByte);
