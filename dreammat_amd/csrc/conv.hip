@@ -698,475 +698,6 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
 #endif
 }
 
-template <int BMT, int BN, int NW, int WMW, int NSTAGE, int TAPS = 9, int EPI = 0>
-__global__ __launch_bounds__(NW * 64) void k_conv3x3_pp(ConvArgs a, long long n_mt, int n_nt, int stagger_units, int ksplit, float* __restrict__ ws) {
-    // BMT x BN x 64 workgroup tile, NW waves laid out WMW (along M) x NW/WMW (along N), NSTAGE-deep LDS ring.
-    //   <128, 64|128, 4, 2, 3>  wave tile 64 x 32|64, 2-5 workgroups per CU (small problems)
-    //   <256, 128, 8, 4, 3>     wave tile 64 x 64, one workgroup per CU
-    //   <256, 256, 8, 2, 2>     wave tile 128 x 64: 24 ds_read_b128 per 32 MFMA instead of 16 per 16, and half the
-    //   <256, 320, 8, 4, 2>     wave tile 64 x 160    DMA bytes per FLOP (Cout = 320 without a ragged N tile)
-    //   <512, 128, 8, 4, 2>     wave tile 128 x 64 for Cout = 128 (the 512^2 VAE layers)
-    [[maybe_unused]] constexpr int BK = 64;         // (the constants below are used by the device pass only)
-    constexpr int ROWB = 128;                          // bytes per tile row (64 bf16), unpadded
-    constexpr int WNW = NW / WMW;
-    constexpr int TM = BMT / WMW, TN = BN / WNW;       // wave tile
-    [[maybe_unused]] constexpr int MT = TM / 32, NT = TN / 32;     // 32x32 accumulator fragments per wave
-    [[maybe_unused]] constexpr int A_BYTES = BMT * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
-    constexpr int A_INSTR = BMT / 8 / NW;              // wave-instructions (8 rows each) per wave
-    constexpr int B_INSTR = BN / 8 / NW;
-    [[maybe_unused]] constexpr int L = A_INSTR + B_INSTR;    // DMA instructions per wave per tile
-    static_assert(TM % 32 == 0 && TN % 32 == 0 && BMT % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile shape");
-    static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // NSTAGE * STAGE
-#if defined(__HIP_DEVICE_COMPILE__)   // __amdgpu_buffer_rsrc_t does not exist in the host pass (the stub needs no body)
-
-    // PERSISTENT workgroups: gridDim.x (a multiple of 8) workgroups walk the tiles of their XCD's contiguous id range
-    // (block b runs on XCD b % 8, private L2 each) with stride gridDim.x / 8, and the LDS-DMA ring keeps running ACROSS
-    // tile boundaries: while tile t's last K-steps multiply and its epilogue stores, the first K-steps of tile t+1 are
-    // already landing.  One workgroup per tile paid a cold prologue (address set-up, first DMA round trip), a store tail
-    // and a relaunch per tile -- 0.25 ms of the 0.80 ms of the 8 x 128->128 @512^2 layer did not scale with K
-    // (tools/conv_fit.sh), with one workgroup per CU nothing else could cover it.
-    // SPLIT-K (ksplit > 1, small-M problems: 1280->1280 @8x8 has 20 output tiles for 256 CUs): a work item is (output tile,
-    // K range); its fp32 partial sums go to ws[ks][M][Cout] and k_splitk_reduce adds them up with the bias / residual terms
-    constexpr bool SPLIT_OK = false;                   // (the ping-pong form runs whole K ranges only)
-    const int total = (int)(n_mt * n_nt) * ksplit;     // < 2^31 (launcher)
-    const int per_xcd = (total + 7) / 8;
-    const int wpx = (int)(gridDim.x >> 3);             // workgroups per XCD
-    const int xbeg = (int)(blockIdx.x & 7) * per_xcd;
-    const int xend = min(xbeg + per_xcd, total);
-    const int first = xbeg + (int)(blockIdx.x >> 3);
-    if (first >= xend) return;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
-    const int wm = wave / WNW, wn = wave % WNW;
-    // M tile = patch of TW x TH output pixels: rows Y0.. of the tall image [B*Hout, Wout], columns X0..
-    // (tile row r -> pixel (Y0 + r / TW, X0 + r % TW)).  A 1-D run of BMT pixels re-reads 3 full image rows per
-    // tile; the patch re-reads a one-pixel halo: (TH+2)(TW+2)/(TH*TW) = 1.2-1.3x.
-    const int TWm = (1 << a.tw_log2) - 1;
-    const int rows_total = a.B * a.Hout;
-    // 32-bit tile arithmetic (the launcher admits < 2^31 tiles): this runs inside the K loop when the issue cursor
-    // crosses into the next tile, where every cycle is a cycle without MFMAs -- the first persistent version spent 13 k
-    // cycles per tile here on two 64-bit divisions, 64-bit address products and the spills around them
-    // (DREAMMAT_CONV_TIMELINE=2).
-    auto tile_coords = [&](int id, int& Y0, int& X0, int& n0, int& ks) __attribute__((always_inline)) {
-        unsigned uid = (unsigned)id;
-        ks = 0;
-        if (SPLIT_OK && ksplit > 1) { ks = (int)(uid % (unsigned)ksplit); uid /= (unsigned)ksplit; }
-        const unsigned mt = uid / (unsigned)n_nt;
-        const unsigned nt = uid - mt * (unsigned)n_nt;
-        const unsigned tile_y = mt / (unsigned)a.tiles_x;
-        Y0 = a.y_off + (int)(tile_y * (unsigned)(BMT >> a.tw_log2));
-        X0 = (int)((mt - tile_y * (unsigned)a.tiles_x) << a.tw_log2);
-        n0 = (int)nt * BN;
-    };
-    const int kt_per_tap = a.Cin / BK;
-    const int n_steps = TAPS * kt_per_tap;
-    auto k_lo = [&](int ks) __attribute__((always_inline)) {     // first K-step of split ks (ks = ksplit: one past the end)
-        return (SPLIT_OK && ksplit > 1) ? (int)((long long)ks * n_steps / ksplit) : (ks ? n_steps : 0);
-    };
-
-    // issue cursor (wave-uniform => SGPRs).  K order = channel block OUTER, tap INNER: the 9 taps of one 64-channel
-    // block re-read the same 128-byte line of every halo pixel back to back, so the per-CU L2 working set is
-    // (TH+2)(TW+2) lines (41 KB for 16x16) whatever Cin is.  Tap-outer order swept all Cin between re-reads
-    // (83 KB-830 KB per CU, x32 CUs per 4 MB L2): rocprofv3 FETCH_SIZE showed 2.1x (Cin=128) to 6.3x (Cin=320)
-    // the compulsory bytes and a 66-76 % L2 hit rate (profiles/r01_pmc_conv_v0.json).
-    int i_tap = 0, i_kc = 0;
-    int i_step = 0, i_end = 0;                         // K-step at the cursor / end of the cursor's K range
-    int issue_tile = first;                            // work item the cursor is in
-    int issue_on = 1;                                  // 0 once the last item's last step has been requested
-    int n_ahead = 0;                                   // K-steps requested but not yet consumed
-
-    // ---- issue side: buffer-addressed DMA (buffer_load_dwordx4 ... lds).  Both operands are described by a raw buffer
-    // resource (the launcher admits tensors below 4 GB), so a lane's source is a 32-bit byte offset and an out-of-image
-    // tap is the offset OOB >= num_records: the hardware returns zeros for it -- no zero page, no 64-bit pointer
-    // arithmetic, half the address registers of the pointer version (which spilled once the ring ran across tiles).
-    // A rows of this lane: wave*(BMT/NW) + 8*i + lrow.  Everything that depends on the row is computed ONCE per tile:
-    // the byte offset of tap (0,0) / channel 0 of the row's receptive field (pre-swizzled chunk; it may lie before the
-    // tensor -- it wraps mod 2^32 and is only used for taps whose bit is set in a_mask, where offset + tap offset is a
-    // true in-tensor offset again) and a 9-bit tap-validity mask.  The K-loop then needs one 32-bit add and one select
-    // per DMA instruction (the first version recomputed ((b*Hin + y)*Win + x)*Cin per tap: ~110 VALU / 24 quarter-rate
-    // multiplies per K-step per wave, more issue time than the 16 MFMAs they feed).
-    constexpr unsigned OOB = 0xfffffff0u;
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.x, 0, (int)(unsigned)((long long)a.B * a.Hin * a.Win * a.Cin * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.w, 0, (int)(unsigned)((long long)a.Cout * TAPS * a.Cin * 2), 0x00020000);
-    // epilogue tensors: an absent bias / rowbias / residual is a zero-sized descriptor (every load returns 0)
-    const int OC = EPI == 1 ? a.Cout / 2 : a.Cout;      // output channels = row length of y / res
-    const unsigned y_bytes = (unsigned)(a.M * OC * 2);
-    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)y_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, a.res ? (int)y_bytes : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.Cout * 2 : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rbrs =
-        __builtin_amdgcn_make_buffer_rsrc((void*)a.rowbias, 0, a.rowbias ? a.B * a.Cout * 2 : 0, 0x00020000);
-    constexpr int NST = MT * NT * 2 / (EPI == 1 ? 2 : 1);   // 16-byte stores per wave and tile (exact: dropped ones are issued too)
-    unsigned a_off[A_INSTR];
-    unsigned a_mask[A_INSTR];
-    unsigned b_off[B_INSTR];
-    const float rcp_hout = 1.0f / (float)a.Hout;       // B*Hout < 2^22 (launcher): one correction step makes the quotient exact
-    auto setup_issue_tile = [&](int id) __attribute__((always_inline)) {
-        int Y0, X0, n0, ks;
-        tile_coords(id, Y0, X0, n0, ks);
-        i_step = k_lo(ks); i_end = k_lo(ks + 1);
-        i_kc = TAPS == 1 ? i_step : i_step / TAPS;
-        i_tap = TAPS == 1 ? 0 : i_step - i_kc * TAPS;
-        // re-derive the lane constants from an opaque copy of the thread id: computed once before the tile loop they stay
-        // live across the K loop, where there is no register for them -- the compiler spilled them and every reload in
-        // here waited (in order) behind the DMAs just issued: 23 serialized scratch round trips, 11 k cycles per tile
-        int t_ = tid;
-        asm volatile("" : "+v"(t_));
-        const int wave = t_ >> 6, lrow = (t_ & 63) >> 3, lslot = t_ & 7;
-#pragma unroll
-        for (int i = 0; i < A_INSTR; ++i) {
-            const int row = wave * (BMT / NW) + 8 * i + lrow;
-            const int Y = Y0 + (row >> a.tw_log2);
-            const int xo = X0 + (row & TWm);
-            const bool ok = Y < rows_total && xo < a.Wout;
-            const int Yc = ok ? Y : 0;
-            int b = (int)((float)Yc * rcp_hout);
-            int yo = Yc - b * a.Hout;
-            if (yo < 0) { yo += a.Hout; --b; }
-            if (yo >= a.Hout) { yo -= a.Hout; ++b; }
-            const int y0 = yo * a.stride - a.pad_y;
-            const int x0 = (ok ? xo : 0) * a.stride - a.pad_x;
-            // mod 2^32 on purpose (see above): every product wraps consistently
-            a_off[i] = ((((unsigned)b * (unsigned)a.Hin + (unsigned)y0) * (unsigned)a.Win + (unsigned)x0) * (unsigned)a.Cin +
-                        (unsigned)((lslot ^ ((row >> 1) & 7)) * 8)) * 2u;
-            // taps (dy, dx) inside the image: 3 (TAPS == 4: 2) column bits replicated into the valid rows; bit index = tap
-            constexpr int TWX = TAPS == 4 ? 2 : 3;
-            unsigned xb = ((unsigned)x0 < (unsigned)a.Win ? 1u : 0u) | ((unsigned)(x0 + 1) < (unsigned)a.Win ? 2u : 0u) |
-                          (TWX == 3 && (unsigned)(x0 + 2) < (unsigned)a.Win ? 4u : 0u);
-            if (!ok) xb = 0;
-            a_mask[i] = ((unsigned)y0 < (unsigned)a.Hin ? xb : 0u) | ((unsigned)(y0 + 1) < (unsigned)a.Hin ? xb << TWX : 0u) |
-                        (TWX == 3 && (unsigned)(y0 + 2) < (unsigned)a.Hin ? xb << 6 : 0u);
-        }
-        // weight rows past Cout (ragged last tile, e.g. 320 = 2.5 x 128) re-read row Cout-1: finite values that
-        // only reach accumulator rows the epilogue never stores
-#pragma unroll
-        for (int i = 0; i < B_INSTR; ++i) {
-            const int row = wave * (BN / NW) + 8 * i + lrow;
-            const int rc = min(n0 + row, a.Cout - 1);
-            b_off[i] = ((unsigned)rc * (unsigned)TAPS * (unsigned)a.Cin + (unsigned)((lslot ^ ((row >> 1) & 7)) * 8)) * 2u;
-        }
-    };
-    unsigned toff = 0, woff = 0;                       // byte offsets of the step being issued
-    unsigned bit = 1u;
-    auto cursor_set = [&]() __attribute__((always_inline)) {
-        // tap -> (dy, dx): 3 x 3 window (tap / 3, tap % 3 for tap < 9) or, TAPS == 4, the 2 x 2 window of the stride-2 data gradient
-        const int dy = TAPS == 4 ? (i_tap >> 1) : ((i_tap * 11) >> 5), dx = TAPS == 4 ? (i_tap & 1) : (i_tap - 3 * dy);
-        toff = (unsigned)(((dy * a.Win + dx) * a.Cin + i_kc * BK) * 2);              // from a_off
-        woff = (unsigned)((i_tap * a.Cin + i_kc * BK) * 2);                          // weights are [Cout][tap][Cin]
-        bit = 1u << i_tap;
-    };
-    // advance to the next K-step; at the end of a tile move on to this workgroup's next tile (or stop)
-    auto cursor_next = [&]() __attribute__((always_inline)) {
-        ++n_ahead;
-        if (TAPS == 1 || ++i_tap == TAPS) { i_tap = 0; ++i_kc; }
-        if (++i_step == i_end) {
-            issue_tile += wpx;
-            if (issue_tile < xend) setup_issue_tile(issue_tile);
-            else issue_on = 0;
-        }
-    };
-    // DMA piece p of the step at the cursor (p < A_INSTR: 8 activation rows, else 8 weight rows) into `stage`
-    auto piece = [&](int p, int stage) __attribute__((always_inline)) {
-        char* ab = smem + stage * STAGE;
-        if (p < A_INSTR) {
-            // select, never a branch: the DMA must execute with ALL lanes active (an inactive lane would
-            // leave its LDS slot stale); out-of-image taps read zeros through the descriptor's range check
-            const unsigned vo = (a_mask[p] & bit) ? a_off[p] + toff : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(ab + (wave * (BMT / NW) + 8 * p) * ROWB),
-                                                     16, (int)vo, 0, 0, 0);
-        } else {
-            const int q = p - A_INSTR;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(ab + A_BYTES + (wave * (BN / NW) + 8 * q) * ROWB),
-                                                     16, (int)b_off[q], (int)woff, 0, 0);
-        }
-    };
-    auto issue = [&](int stage) __attribute__((always_inline)) {
-        cursor_set();
-#pragma unroll
-        for (int p = 0; p < L; ++p) piece(p, stage);
-        cursor_next();
-    };
-
-    f32x16 acc[MT][NT];
-
-    // PING-PONG schedule (round 5).  Waves w and w + NW/2 share a SIMD (a workgroup's waves go to the SIMDs in the cyclic order
-    // 0 -> 2 -> 1 -> 3); group g = w / (NW/2).  A K-step is four PHASES, each closed by s_barrier; in every phase one group only
-    // issues MFMAs from registers (a "compute" half-step: 2 MT NT MFMAs = 64 MT NT pipe cycles) while the other only reads the
-    // fragments of its next half-step from LDS -- the two streams a SIMD sees are complementary by construction instead of two
-    // copies of the same [read | DMA | multiply] sequence released by the same barrier:
-    //     phase     4s           4s+1         4s+2         4s+3
-    //     group 0   L(s, 0)      C(s, 0)+dma  L(s, 1)      C(s, 1)
-    //     group 1   C(s-1, 1)+dma L(s, 0)     C(s, 0)      L(s, 1)
-    // DMA pieces ride BETWEEN the MFMAs of a compute half (one per MFMA slot: the cheapest place for their issue stall, and only
-    // half of the waves ask the address unit in any phase): group 0 requests step s + 1 in C(s, 0) into the other stage (last read:
-    // group 1's L(s - 1, 1), phase 4s - 1), group 1 requests step s + 2 in C(s, 1) into the stage it has just finished reading.
-    // Each wave waits for its own pieces of step s + 1 (vmcnt(0): nothing younger is in flight) at the end of phase 4s + 3, two
-    // to three phases after it asked.
-    static_assert(NSTAGE == 2, "ping-pong form: two stages");
-    const int grp = __builtin_amdgcn_readfirstlane(wave) / (NW / 2);
-    setup_issue_tile(first);
-    issue(0);
-    if (grp && issue_on) { issue(1); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory"); }      // (group 1 runs a step further ahead)
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                      // step 0 of the first tile is in LDS for everybody
-    auto read_frags = [&](int stage, int kk, elem8 (&af)[MT], elem8 (&bf)[NT]) {
-        const char* ab = smem + stage * STAGE;
-        const char* bb = ab + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            int r = TM * wm + 32 * i + l31;
-            af[i] = *reinterpret_cast<const elem8*>(ab + r * ROWB + (((2 * kk + hi) ^ ((r >> 1) & 7)) << 4));
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            int r = TN * wn + 32 * j + l31;
-            bf[j] = *reinterpret_cast<const elem8*>(bb + r * ROWB + (((2 * kk + hi) ^ ((r >> 1) & 7)) << 4));
-        }
-    };
-    elem8 a0[MT], b0[NT], a1[MT], b1[NT];              // the fragments of one half-step (two chunks of 16 K)
-    auto load_half = [&](int stage, int half) __attribute__((always_inline)) {
-        read_frags(stage, 2 * half, a0, b0);
-        read_frags(stage, 2 * half + 1, a1, b1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    };
-    int issued = 0;                                    // did the last compute half with DMA duty issue (wave-uniform)
-    auto compute_half = [&](bool duty, int st_target) __attribute__((always_inline)) {
-        const bool on = duty && __builtin_amdgcn_readfirstlane(issue_on) != 0;
-        if (on) cursor_set();
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                acc[i][j] = DM_MFMA_32x32x16(b0[j], a0[i], acc[i][j]);
-                if (on && i * NT + j < L) piece(i * NT + j, st_target);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                acc[i][j] = DM_MFMA_32x32x16(b1[j], a1[i], acc[i][j]);
-                if (on && MT * NT + i * NT + j < L) piece(MT * NT + i * NT + j, st_target);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        static_assert(L <= 2 * MT * NT, "one DMA piece per MFMA slot");
-        if (on) cursor_next();
-        if (duty) issued = on ? 1 : 0;
-    };
-    auto stamp = [&]() {};
-    int stage = 0;
-    for (int ct = first; ct < xend; ct += wpx) {
-        int Y0, X0, n0, ks;
-        tile_coords(ct, Y0, X0, n0, ks);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        if (grp) __builtin_amdgcn_s_barrier();         // group 1 runs one phase behind group 0
-        for (int s = 0; s < n_steps; ++s) {
-            const bool last = s + 1 == n_steps;
-            load_half(stage, 0);
-            __builtin_amdgcn_s_barrier();
-            compute_half(grp == 0, stage ^ 1);
-            __builtin_amdgcn_s_barrier();
-            load_half(stage, 1);
-            if (grp && !last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // group 1: its pieces of step s + 1 have landed
-            __builtin_amdgcn_s_barrier();
-            compute_half(grp == 1, stage);
-            if (!grp) {
-                if (!last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // group 0: likewise
-                __builtin_amdgcn_s_barrier();
-            } else if (!last) {
-                __builtin_amdgcn_s_barrier();          // (group 1's last barrier of a tile follows its epilogue)
-            }
-            stage ^= 1;
-        }
-
-        // ---- epilogue: y = acc + bias[n] (+ rowbias[image(m), n]) (+ res[m, n]), one rounding to bf16.
-        // D^T layout: lane = pixel l31 of the fragment, register r = channel (r&3) + 8*(r>>2) + 4*hi.  Group g = r>>2 is
-        // four consecutive channels (8 bytes as bf16); lanes l and l+32 hold the two halves of one 8-channel run.  One
-        // v_permlane32_swap per dword on the group pair (g, g+1) turns that into 16 contiguous bytes per lane: lanes 0-31
-        // get channels 8g..8g+7, lanes 32-63 channels 8g+8..8g+15 of their pixel -> TWO 16-byte stores per 32x32
-        // fragment.  (The first version stored every element on its own: 128 store instructions per wave and tile.)
-        // Every access is a buffer instruction whose out-of-range cases (no bias / rowbias / residual tensor, ragged
-        // pixel or channel) are the offset OOB or a zero-sized descriptor -- loads return 0, stores are dropped -- so the
-        // epilogue is straight-line code: the compiler batches the loads of a fragment ahead of their use (the branchy
-        // version waited vmcnt(0) after each of its 8-byte loads: 12 exposed round trips per fragment, 15 us per tile,
-        // the 0.25 ms of the 512^2 layers that did not scale with K in tools/conv_fit.sh), and each wave issues EXACTLY
-        // NST stores per tile, which is what lets the next tile's first K-steps count them in s_waitcnt (see above).
-        const int img0 = Y0 / a.Hout;                  // image of the patch's first row (wave-uniform)
-        const int rem0 = Y0 - img0 * a.Hout;
-        unsigned poff[MT], rboff[MT];                  // byte offset of this lane's pixel in y / res, of its image's rowbias row
-        int te_ = tid;                                 // (opaque copy: see setup_issue_tile)
-        asm volatile("" : "+v"(te_));
-        const int l31 = te_ & 31, hi = (te_ >> 5) & 1, wm = (te_ >> 6) / WNW, wn = (te_ >> 6) % WNW;
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int d = TM * wm + 32 * i + l31;      // this lane's pixel of the tile
-            const int ty = d >> a.tw_log2;
-            const int Y = Y0 + ty;
-            const int xo = X0 + (d & TWm);
-            const bool pix_ok = Y < rows_total && xo < a.Wout;
-            poff[i] = pix_ok ? ((unsigned)Y * (unsigned)a.Wout + (unsigned)xo) * (unsigned)OC * 2u : OOB;   // m = (b*Hout + yo)*Wout + xo
-            int img = img0, t = rem0 + ty;
-            while (t >= a.Hout) { t -= a.Hout; ++img; }                                       // a patch spans at most TH / Hout + 1 images
-            rboff[i] = (unsigned)(min(img, a.B - 1) * a.Cout * 2);
-        }
-        auto unpack_add = [](float (&v)[4], const u32x2 p) __attribute__((always_inline)) {
-            v[0] += dm_elem_lo(p[0]); v[1] += dm_elem_hi(p[0]);
-            v[2] += dm_elem_lo(p[1]); v[3] += dm_elem_hi(p[1]);
-        };
-        const bool has_res = a.res != nullptr, has_rb = a.rowbias != nullptr;
-        // Loads are issued ahead of the stores (the compiler keeps program order between a buffer load and a buffer store
-        // it cannot prove disjoint): the rowbias row and the residual of fragment f + 1 are requested before the stores of
-        // fragment f, so only the first fragment of a tile waits for a full round trip.
-        auto frag_load = [&](int i, int j, u32x2 (&r)[8]) __attribute__((always_inline)) {
-            const int nbase = n0 + TN * wn + 32 * j;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = nbase + 8 * g + 4 * hi;
-                const bool n_ok = n < a.Cout;
-                if (has_rb) r[g] = __builtin_amdgcn_raw_buffer_load_b64(rbrs, (int)(n_ok ? rboff[i] + (unsigned)n * 2u : OOB), 0, 0);
-                if (has_res)
-                    r[4 + g] = __builtin_amdgcn_raw_buffer_load_b64(rrs, (int)(n_ok && poff[i] != OOB ? poff[i] + (unsigned)n * 2u : OOB), 0, 0);
-            }
-        };
-        if (SPLIT_OK && ksplit > 1) {
-            // fp32 partial sums of this K range: ws[ks][m][n], 16 bytes (4 consecutive channels) per lane and group
-            const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(ws + (long long)ks * a.M * a.Cout), 0, (int)(unsigned)(a.M * a.Cout * 4), 0x00020000);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int n = n0 + TN * wn + 32 * j + 8 * g + 4 * hi;
-                        // (element copies first: __builtin_bit_cast applied directly to an ext-vector element reads element 0)
-                        const float f0 = acc[i][j][4 * g], f1 = acc[i][j][4 * g + 1], f2 = acc[i][j][4 * g + 2], f3 = acc[i][j][4 * g + 3];
-                        const u32x4 out = {__builtin_bit_cast(unsigned, f0), __builtin_bit_cast(unsigned, f1),
-                                           __builtin_bit_cast(unsigned, f2), __builtin_bit_cast(unsigned, f3)};
-                        __builtin_amdgcn_raw_buffer_store_b128(out, prs, (int)(poff[i] != OOB && n < a.Cout ? poff[i] * 2u + (unsigned)n * 4u : OOB), 0, 0);
-                    }
-        } else if constexpr (EPI == 1) {
-            // GEGLU: fragments (2jj, 2jj+1) = value / gate of output channels ob .. ob+31 (rows interleaved by the host)
-            static_assert(EPI == 0 || NT % 2 == 0, "GEGLU needs value/gate fragment pairs");
-#pragma unroll
-            for (int jj = 0; jj < NT / 2; ++jj) {
-                const int nb = n0 + TN * wn + 64 * jj;     // first (interleaved) weight row of the value fragment
-                const int ob = (n0 + TN * wn) / 2 + 32 * jj;
-                u32x2 bpv[4], bpg[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = nb + 8 * g + 4 * hi;
-                    bpv[g] = __builtin_amdgcn_raw_buffer_load_b64(brs, (int)(n < a.Cout ? (unsigned)n * 2u : OOB), 0, 0);
-                    bpg[g] = __builtin_amdgcn_raw_buffer_load_b64(brs, (int)(n + 32 < a.Cout ? (unsigned)(n + 32) * 2u : OOB), 0, 0);
-                }
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int gp = 0; gp < 2; ++gp) {
-                        unsigned w[2][2];
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const int g = 2 * gp + q;
-                            float v[4], gt[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * jj][4 * g + e]; gt[e] = acc[i][2 * jj + 1][4 * g + e]; }
-                            unpack_add(v, bpv[g]);
-                            unpack_add(gt, bpg[g]);
-                            // the Linear output is a bf16 tensor in the unfused path: round value and gate before the gate function
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float vr = (float)(elem_t)v[e], gr = (float)(elem_t)gt[e];
-                                v[e] = vr * (0.5f * gr * (1.f + erff(gr * 0.70710678118654752f)));
-                            }
-                            f32x2 lo = {v[0], v[1]}, hi2 = {v[2], v[3]};
-                            elem2 plo = __builtin_convertvector(lo, elem2), phi = __builtin_convertvector(hi2, elem2);
-                            w[q][0] = __builtin_bit_cast(unsigned, plo);
-                            w[q][1] = __builtin_bit_cast(unsigned, phi);
-                        }
-                        const auto s0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
-                        const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
-                        const int c0 = ob + 16 * gp + 8 * hi;
-                        const u32x4 out = {s0[0], s1[0], s0[1], s1[1]};
-                        __builtin_amdgcn_raw_buffer_store_b128(out, yrs, (int)(poff[i] != OOB && c0 < OC ? poff[i] + (unsigned)c0 * 2u : OOB), 0, 0);
-                    }
-            }
-        } else {
-        u32x2 pre[2][8];                               // [parity of the fragment counter][rowbias g 0..3 | residual g 0..3]
-#pragma unroll
-        for (int g = 0; g < 8; ++g) pre[0][g] = pre[1][g] = u32x2{0u, 0u};
-        // Fragment order.  PIXEL-MAJOR when a wave has at most two channel fragments: the stores that together fill one
-        // 128-byte line of a pixel row (64 channels = 2 fragments x 2 group pairs) are then issued back to back instead of MT
-        // fragments apart, so the write path sees whole lines (WRITE_SIZE was 1.33x the tensor on 8 x 128->128 @512^2:
-        // lines written back partially and again).  Channel-major (bias registers per j) for the 5-fragment wave tile.
-        constexpr bool PIX_MAJOR = NT <= 2;
-        constexpr int NBP = PIX_MAJOR ? NT : 1;
-        u32x2 bp[NBP][4];                              // bias of this lane's 16 channels of fragment j (register 4g+e = channel nbase + 8g + 4hi + e)
-        auto load_bias = [&](int j, u32x2 (&bq)[4]) __attribute__((always_inline)) {
-            const int nbase = n0 + TN * wn + 32 * j;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = nbase + 8 * g + 4 * hi;
-                bq[g] = __builtin_amdgcn_raw_buffer_load_b64(brs, (int)(n < a.Cout ? (unsigned)n * 2u : OOB), 0, 0);
-            }
-        };
-        if (PIX_MAJOR) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) load_bias(j, bp[j % NBP]);
-        }
-        frag_load(0, 0, pre[0]);
-#pragma unroll
-        for (int f = 0; f < MT * NT; ++f) {
-            constexpr int kLast = MT * NT - 1;
-            const int i = PIX_MAJOR ? f / NT : f % MT, j = PIX_MAJOR ? f % NT : f / MT;
-            const int nbase = n0 + TN * wn + 32 * j;   // first channel of this fragment (wave-uniform)
-            if (!PIX_MAJOR && i == 0) load_bias(j, bp[0]);
-            if (f < kLast) frag_load(PIX_MAJOR ? (f + 1) / NT : (f + 1) % MT, PIX_MAJOR ? (f + 1) % NT : (f + 1) / MT, pre[(f + 1) & 1]);
-            {
-#pragma unroll
-                for (int gp = 0; gp < 2; ++gp) {       // group pairs (0,1) and (2,3)
-                    unsigned w[2][2];                  // [group of the pair][dword] = 4 bf16 per group
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int g = 2 * gp + q;
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
-                        unpack_add(v, bp[PIX_MAJOR ? j : 0][g]);
-                        unpack_add(v, pre[f & 1][g]);
-                        unpack_add(v, pre[f & 1][4 + g]);
-                        f32x2 lo = {v[0], v[1]}, hi2 = {v[2], v[3]};
-                        elem2 plo = __builtin_convertvector(lo, elem2), phi = __builtin_convertvector(hi2, elem2);
-                        w[q][0] = __builtin_bit_cast(unsigned, plo);
-                        w[q][1] = __builtin_bit_cast(unsigned, phi);
-                    }
-                    // v_permlane32_swap(vdst = group g, src = group g+1): lanes 32-63 of vdst <-> lanes 0-31 of src.  Afterwards
-                    //   result[0]: lanes 0-31 own group g (ch 8g..8g+3)        | lanes 32-63 the lower lanes' group g+1 (ch 8g+8..+11)
-                    //   result[1]: lanes 0-31 the upper lanes' group g (+4..+7) | lanes 32-63 own group g+1 (ch 8g+12..+15)
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
-                    const int c0 = nbase + 16 * gp + 8 * hi;   // this lane now owns channels c0 .. c0+7 of its pixel
-                    const u32x4 out = {s0[0], s1[0], s0[1], s1[1]};
-                    __builtin_amdgcn_raw_buffer_store_b128(out, yrs, (int)(poff[i] != OOB && c0 < OC ? poff[i] + (unsigned)c0 * 2u : OOB),
-                                                           0, 0);
-                }
-            }
-        }
-        }
-        // the next tile's step 0 (requested before this tile's stores; group 1 also has its step-1 pieces in flight behind it)
-        if (grp && issued) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L + NST) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
-        __builtin_amdgcn_s_barrier();
-    }   // tile loop
-#endif
-}
-
 // split-K reduction: y[m][n] = sum_ks ws[ks][m][n] + bias[n] + rowbias[image(m)][n] + res[m][n], 8 channels per thread
 __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ ws, int ksplit, long long M, int Cout, long long hw,
                                                         const elem_t* __restrict__ bias, const elem_t* __restrict__ rowbias,
@@ -1243,27 +774,13 @@ int cu_count() {
     return n_cu;
 }
 
-// DREAMMAT_CONV_PP=1: the ping-pong form of the two-stage kernels (A/B runs)
-static bool conv_pp() {
-    static const bool on = getenv("DREAMMAT_CONV_PP") && !strcmp(getenv("DREAMMAT_CONV_PP"), "1");
-    return on;
-}
-
-template <int BMT, int BN, int NW, int WMW, int NSTAGE, int TAPS, int EPI, bool PP>
-auto conv_kernel() {
-    if constexpr (PP) return &k_conv3x3_pp<BMT, BN, NW, WMW, NSTAGE, TAPS, EPI>;
-    else return &k_conv3x3_dma<BMT, BN, NW, WMW, NSTAGE, TAPS, EPI>;
-}
-
-template <int BMT, int BN, int NW, int WMW, int NSTAGE, int TAPS = 9, int EPI = 0, bool PP = false>
+template <int BMT, int BN, int NW, int WMW, int NSTAGE, int TAPS = 9, int EPI = 0>
 int launch_conv_dma(const ConvArgs& a_in, hipStream_t stream) {
     constexpr int LDS = NSTAGE * (BMT + BN) * 128;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    static_assert(!PP || NSTAGE == 2, "ping-pong form: two stages");
-    const auto kern = conv_kernel<BMT, BN, NW, WMW, NSTAGE, TAPS, EPI, PP>();
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_dma<BMT, BN, NW, WMW, NSTAGE, TAPS, EPI>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
@@ -1288,7 +805,7 @@ int launch_conv_dma(const ConvArgs& a_in, hipStream_t stream) {
     const int wg_per_cu = std::max(1, std::min((160 * 1024) / LDS, 2048 / (NW * 64)));
     // split-K when the output tiles alone would leave most of the chip idle: enough K ranges to fill it, each at least 6
     // K-steps long (DREAMMAT_CONV_SPLITK = 0 disables, = S forces S)
-    constexpr bool SPLIT_OK = EPI == 0 && BMT <= 256 && BN <= 128 && !PP;
+    constexpr bool SPLIT_OK = EPI == 0 && BMT <= 256 && BN <= 128;
     int ksplit = 1;
     if (SPLIT_OK) {
         const long long slots = (long long)n_cu * wg_per_cu, tiles = n_mt * n_nt;
@@ -1324,7 +841,8 @@ int launch_conv_dma(const ConvArgs& a_in, hipStream_t stream) {
         if (blocks <= 4096) { (void)hipMemsetAsync(tl_buf, 0, 4096 * 64 * 8, stream); a.timeline = tl_buf; }
         a.timeline_steps = atoi(getenv("DREAMMAT_CONV_TIMELINE")) >= 2 ? atoi(getenv("DREAMMAT_CONV_TIMELINE")) : 0;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NW * 64), LDS, stream, a, n_mt, n_nt, stagger, ksplit, ws);
+    hipLaunchKernelGGL((k_conv3x3_dma<BMT, BN, NW, WMW, NSTAGE, TAPS, EPI>), dim3((unsigned)blocks), dim3(NW * 64), LDS, stream, a,
+                       n_mt, n_nt, stagger, ksplit, ws);
     hipError_t e = hipGetLastError();
     if (ksplit > 1 && e == hipSuccess) {
         const long long n8 = a.M * a.Cout / 8;
@@ -1458,7 +976,7 @@ int DM_T(dm_conv3x3_nhwc_, _fused)(const void* x, const void* w, const void* bia
         }
         switch (tile) {
         case 640: {                                                          // wave tile 128 x 64, all 160 KB of LDS
-            int rc = conv_pp() ? launch_conv_dma<512, 128, 8, 4, 2, 9, 0, true>(a, stream) : launch_conv_dma<512, 128, 8, 4, 2>(a, stream);
+            int rc = launch_conv_dma<512, 128, 8, 4, 2>(a, stream);
             if (rc <= 0 || tile_env) return rc;
             return launch_conv_dma<256, 128, 8, 4, 3>(a, stream);            // runtime refused the full-LDS variant
         }
@@ -1475,7 +993,7 @@ int DM_T(dm_conv3x3_nhwc_, _fused)(const void* x, const void* w, const void* bia
         // two-wave kernels is 0-10 % slower than their burst order (conv_two_wave_weave_ab.txt).  What bounds this kernel is
         // the address unit's 64 B/clk against 9 taps re-requesting the same activation rows; the lever left is a halo patch in
         // LDS read at 9 shifted offsets (one DMA of the patch per 64-channel block), a different kernel.)
-        case 512: return conv_pp() ? launch_conv_dma<256, 256, 8, 2, 2, 9, 0, true>(a, stream) : launch_conv_dma<256, 256, 8, 2, 2>(a, stream);      // wave tile 128 x 64
+        case 512: return launch_conv_dma<256, 256, 8, 2, 2>(a, stream);      // wave tile 128 x 64
         case 256: return launch_conv_dma<256, 128, 8, 4, 3>(a, stream);      // wave tile 64 x 64
         default:
             if (Cout % 128 != 0) return launch_conv_dma<128, 64, 4, 2, 3>(a, stream);
@@ -1552,13 +1070,13 @@ int DM_T(dm_gemm_, _fused)(const void* x, const void* w, const void* bias, const
     if (geglu) {
         if (tile == 320) tile = 256;
         switch (tile) {
-        case 512: return conv_pp() ? launch_conv_dma<256, 256, 8, 2, 2, 1, 1, true>(a, stream) : launch_conv_dma<256, 256, 8, 2, 2, 1, 1>(a, stream);
+        case 512: return launch_conv_dma<256, 256, 8, 2, 2, 1, 1>(a, stream);
         case 256: return launch_conv_dma<256, 128, 8, 4, 3, 1, 1>(a, stream);
         default: return launch_conv_dma<128, 128, 4, 2, 2, 1, 1>(a, stream);
         }
     }
     switch (tile) {
-    case 512: return conv_pp() ? launch_conv_dma<256, 256, 8, 2, 2, 1, 0, true>(a, stream) : launch_conv_dma<256, 256, 8, 2, 2, 1, 0>(a, stream);
+    case 512: return launch_conv_dma<256, 256, 8, 2, 2, 1, 0>(a, stream);
     case 320: return tile_env ? launch_conv_dma<256, 320, 8, 4, 2, 1, 0>(a, stream) : launch_320_balanced<1>(a, stream);
     case 1320: return launch_conv_dma<128, 320, 8, 4, 2, 1, 0>(a, stream);
     case 256: return launch_conv_dma<256, 128, 8, 4, 3, 1, 0>(a, stream);
