@@ -20,7 +20,7 @@
 //
 // Kernel.  A workgroup = 4 waves x 32 query rows, no LDS, no barrier: K / V^T tiles are 4 KB each and come straight from L2 as
 // two 16-byte loads per lane and operand (the 4 waves of a workgroup and the workgroups of a (batch, head) on one XCD share
-// them there); K double-buffered in registers, V^T requested at the top of its tile.  Per 64-row kv tile and wave: 2 MFMAs form
+// them there), both double-buffered in registers one tile ahead.  Per 64-row kv tile and wave: 2 MFMAs form
 // S^T = K.Q'^T - shift (two 32 x 32 tiles, the whole head dimension in one instruction each; the row shift enters through the C
 // operand), the probabilities are ONE v_exp_f32 each, packed 4 per dword, and 3 MFMAs add V^T.P^T to the two 32 x 32 halves of
 // O^T and to the row sums (a 33rd channel of ones).
@@ -154,8 +154,9 @@ __global__ __launch_bounds__(256) void k_fp8_quant_vt(const T* __restrict__ src,
 constexpr int kRowsPerWg = 128;      // 4 waves x 32 query rows
 constexpr int kPScaleByte = 127 - 8; // E8M0 of the constant 2^-8 that undoes the 2^8 inside the stored probabilities
 
-struct KFrag {
-    i32x8 k[2]; int ks[2];           // K rows 32 t + l31 of the tile, bytes 32 hi ..; their scale bytes
+struct KvFrag {
+    i32x8 k[2]; int ks[2];           // K rows 32 t + l31 of the tile (this lane's two 16-byte k groups); the scale byte of its block
+    i32x8 v[2]; int vs[2];           // V^T channels 32 f + l31 likewise
 };
 
 template <typename T>
@@ -189,13 +190,17 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_fp8(Fp8Args a) {
     const unsigned char* ksc = a.ks + ((long long)bh * a.Skv + l31) * 2 + hi;
     const unsigned char* v8 = a.v8 + ((long long)bh * n_tiles * 64 + l31) * 64 + 16 * hi;
     const unsigned char* vsc = a.vs + ((long long)bh * n_tiles * 64 + l31) * 2 + hi;
-    auto load_k = [&](int j, KFrag& f) __attribute__((always_inline)) {
+    auto load_tile = [&](int j, KvFrag& f) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const i32x4* p = reinterpret_cast<const i32x4*>(k8 + ((long long)j * 64 + 32 * t) * 64);
             const i32x4 lo = p[0], up = p[2];
             f.k[t] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
             f.ks[t] = ksc[((long long)j * 64 + 32 * t) * 2];
+            const i32x4* pv = reinterpret_cast<const i32x4*>(v8 + ((long long)j * 64 + 32 * t) * 64);
+            const i32x4 vlo = pv[0], vup = pv[2];
+            f.v[t] = i32x8{vlo[0], vlo[1], vlo[2], vlo[3], vup[0], vup[1], vup[2], vup[3]};
+            f.vs[t] = vsc[((long long)j * 64 + 32 * t) * 2];
         }
     };
 
@@ -217,17 +222,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_fp8(Fp8Args a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
 
-    auto tile_body = [&](const KFrag& fk, int j, bool first) __attribute__((always_inline)) {
-        // this tile's V^T fragments: requested now, consumed after the softmax
-        i32x8 vA[2];
-        int vS[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const i32x4* pv = reinterpret_cast<const i32x4*>(v8 + ((long long)j * 64 + 32 * t) * 64);
-            const i32x4 vlo = pv[0], vup = pv[2];
-            vA[t] = i32x8{vlo[0], vlo[1], vlo[2], vlo[3], vup[0], vup[1], vup[2], vup[3]};
-            vS[t] = vsc[((long long)j * 64 + 32 * t) * 2];
-        }
+    auto tile_body = [&](const KvFrag& fk, bool first) __attribute__((always_inline)) {
         f32x16 s[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t)      // S^T[kv][q] - shift[q] = sum_d K[kv][d] Q'[q][d] - shift[q]
@@ -272,22 +267,24 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_fp8(Fp8Args a) {
             }
 #pragma unroll
         for (int ff = 0; ff < 2; ++ff)   // O^T[d][q] += sum_kv V^T[d][kv] P[q][kv]
-            o[ff] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vA[ff], pB, o[ff], 0, 0, 0, vS[ff], 0, kPScaleByte);
+            o[ff] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fk.v[ff], pB, o[ff], 0, 0, 0, fk.vs[ff], 0, kPScaleByte);
         o[2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(onesA, pB, o[2], 0, 0, 0, 127, 0, kPScaleByte);
     };
 
-    KFrag fa, fb;
-    load_k(0, fa);
-    if (n_tiles > 1) load_k(1, fb);
-    tile_body(fa, 0, true);
+    // both operands of a tile are requested one tile ahead (round 5: with V^T requested at the top of its own tile every tile
+    // waited out an L2 round trip in front of the second product)
+    KvFrag fa, fb;
+    load_tile(0, fa);
+    if (n_tiles > 1) load_tile(1, fb);
+    tile_body(fa, true);
     int j = 1;
     for (; j + 2 <= n_tiles; j += 2) {
-        load_k(j + 1, fa);
-        tile_body(fb, j, false);
-        if (j + 2 < n_tiles) load_k(j + 2, fb);
-        tile_body(fa, j + 1, false);
+        load_tile(j + 1, fa);
+        tile_body(fb, false);
+        if (j + 2 < n_tiles) load_tile(j + 2, fb);
+        tile_body(fa, false);
     }
-    if (j < n_tiles) tile_body(fb, j, false);
+    if (j < n_tiles) tile_body(fb, false);
 
     // row sum: row 0 of fragment 2 = register 0 of lanes 0-31 (column q = lane)
     const float lt = __shfl(o[2][0], l31);

@@ -366,7 +366,7 @@ def test_fp8_attention_running_maximum_and_wide_magnitudes(dev):
     ref = _attn_ref(qb, kb, vb, h)
     assert torch.isfinite(out).all()
     assert ((out - ref).norm() / ref.norm()).item() < 8e-2
-    assert (out[0, 99] - 100.0).abs().max() < 2.0          # row 99 is its spiked key's value row
+    assert (out[0, 99] - 100.0).abs().max() < 7.0          # row 99 is its spiked key's value row (e4m3: 100 -> 96 or 104)
 
 
 def test_fp8_attention_through_the_guidance_switch(dev):
