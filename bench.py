@@ -369,6 +369,37 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kt = hipops.kernel_times()
+    # the shade kernels REPLAYED on the last step's G-buffer (back-to-back launches, each between its own HIP events): once with
+    # the step's own features and once with per-pixel-random features -- at this point of training the field is nearly constant
+    # (roughness 0.525 +- 3e-5, every pixel on one mip pair), which is the kernels' best case
+    shade_replay = {}
+    if rank == 0 and not a.raytracing:
+        hipops.SHADE_KEEP["on"] = True
+        trainer.train_one_step()
+        sync()
+        hipops.SHADE_KEEP["on"] = False
+        kept, hipops.SHADE_KEEP["last"] = hipops.SHADE_KEEP["last"], None
+        if kept is not None and kept[0].shape[0] > 0:
+            feat0 = kept[0]
+            gen = torch.Generator(device=dev).manual_seed(7)
+            cases = {"step_features": feat0, "random_features": torch.randn(feat0.shape, device=dev, generator=gen)}
+            for nm, ft in cases.items():
+                # the same [5, pitch] feature-major storage the field MLP hands the kernels
+                Np = (ft.shape[0] + 3) // 4 * 4
+                st = torch.empty(ft.shape[1], Np, device=dev)[:, :ft.shape[0]]
+                st.copy_(ft.t())
+                f = st.t().requires_grad_(True)
+                g = torch.randn(ft.shape[0], 3, device=dev, generator=gen)
+                for it in range(13):
+                    if it == 3:
+                        sync()
+                        hipops.enable_kernel_timing(True, only=("shade_fwd", "shade_bwd"))
+                    col = hipops.shade(f, *kept[1:], want_debug=False)[0]
+                    col.backward(g)
+                    f.grad = None
+                sync()
+                hipops.enable_kernel_timing(False)
+                shade_replay[nm] = hipops.kernel_times()
     if a.dump_shade and rank == 0:
         hipops.SHADE_DUMP["path"] = a.dump_shade
         trainer.train_one_step()
@@ -450,6 +481,13 @@ def main():
                            "frac": gbs / 8000.0, "traffic": None, "avg_us": r["avg_ms"] * 1e3,
                            "covered_pixels": r["work_per_launch"] / (56.0 if key == "shade_fwd" else 76.0)}
                 res[nm].update(shade_traffic(key, system.material.atlas.texel) or {})
+                res[nm]["measured"] = "inside full steps (cold caches: 70 ms and several GB after the kernel's previous run)"
+                for case, ktr in shade_replay.items():      # replayed back-to-back on the step's G-buffer
+                    if key in ktr:
+                        rr = ktr[key]
+                        g2 = rr["work_per_launch"] / (rr["avg_ms"] * 1e-3) / 1e9
+                        res[nm]["replay_" + case] = {"avg_us": rr["avg_ms"] * 1e3, "achieved": g2, "frac": g2 / 8000.0,
+                                                     "launches_timed": rr["launches"]}
         # SURVEY 8d "report, do not gate" rows: rasterize (+ interpolate, fused into the G-buffer pass), antialias, hash grid --
         # algorithmic bytes per launch / HIP-event time per launch, from the same extra steps as the shade rows
         def hbm_row(kernel, keys):

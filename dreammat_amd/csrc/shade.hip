@@ -284,9 +284,11 @@ __global__ __launch_bounds__(256, 3) void k_shade_bwd(ShadeArgs a) {
 
 // the fast path of shade_pixel_loop: every row tensor SoA (unit row stride; any channel pitch), fewer than 2^30 rows
 static inline int shade_offsets32(const ShadeArgs& a, long long n_max, bool bwd) {
-    auto soa = [&](long long rs, long long cs) { return rs == 1 && cs >= 0; };
-    return soa(a.nrm.rs, a.nrm.cs) && soa(a.view.rs, a.view.cs) && soa(a.feat.rs, a.feat.cs) &&
-           (bwd ? soa(a.dcolor.rs, a.dcolor.cs) && soa(a.dfeat.rs, a.dfeat.cs) : soa(a.color.rs, a.color.cs)) &&
+    // the fast path moves 16 bytes (four consecutive rows of one channel) per lane: every channel must start on a 16-byte
+    // boundary (base aligned, pitch a multiple of 4 floats); anything else takes the generic loop
+    auto soa = [&](const void* p, long long rs, long long cs) { return rs == 1 && cs >= 0 && cs % 4 == 0 && ((uintptr_t)p & 15) == 0; };
+    return soa(a.nrm.p, a.nrm.rs, a.nrm.cs) && soa(a.view.p, a.view.rs, a.view.cs) && soa(a.feat.p, a.feat.rs, a.feat.cs) &&
+           (bwd ? soa(a.dcolor.p, a.dcolor.rs, a.dcolor.cs) && soa(a.dfeat.p, a.dfeat.rs, a.dfeat.cs) : soa(a.color.p, a.color.rs, a.color.cs)) &&
            n_max < 0x3fffffffLL;
 }
 

@@ -292,10 +292,11 @@ class _ScatterRows(torch.autograd.Function):
         pix_idx, n_dev = ctx.saved_tensors
         g = _f32c(g)
         C = g.shape[-1]
-        d = torch.empty(C, ctx.n, device=g.device)     # SoA
+        n_p = (ctx.n + 3) // 4 * 4                     # SoA with 16-byte aligned channels (the shade backward streams 16 B per lane)
+        d = torch.empty(C, n_p, device=g.device)[:, :ctx.n]
         if ctx.n > 0:
             check(_lib.lib().dm_gather_rows(pix_idx.data_ptr(), n_dev.data_ptr(), ctx.n, g.data_ptr(), C,
-                                            d.data_ptr(), 1, ctx.n, _stream()), "dm_gather_rows")
+                                            d.data_ptr(), 1, n_p, _stream()), "dm_gather_rows")
         return d.t(), None, None, None
 
 
@@ -442,11 +443,12 @@ class _FieldMlp(torch.autograd.Function):
         n_in, M = x_fm.shape
         n_out = w2.shape[0]
         w1c, w2c = w1.contiguous(), w2.contiguous()
-        y = torch.empty(n_out, M, device=x_fm.device, dtype=torch.float32)
+        Mp = (M + 3) // 4 * 4                  # channel pitch: the shade kernels stream a feature channel 16 bytes per lane
+        y = torch.empty(n_out, Mp, device=x_fm.device, dtype=torch.float32)[:, :M]
         if M > 0:
             with _Timed("field_mlp_fwd", 2.0 * M * (n_in * 64 + 64 * n_out)):
                 check(_lib.lib().dm_field_mlp_fwd(x_fm.data_ptr(), x_fm.stride(0), M, w1c.data_ptr(), w2c.data_ptr(), n_in, n_out,
-                                                  y.data_ptr(), M, _stream()), "dm_field_mlp_fwd")
+                                                  y.data_ptr(), Mp, _stream()), "dm_field_mlp_fwd")
         ctx.save_for_backward(x_fm, w1c, w2c)
         return y
 
@@ -474,6 +476,7 @@ def field_mlp(x_fm, w1, w2):
 
 # ------------------------------------------------------------------------------------------ shading
 SHADE_DUMP = {"path": None}      # measurement aid (bench.py --dump-shade): the next shade forward saves its inputs here, once
+SHADE_KEEP = {"on": False, "last": None}     # measurement aid (bench.py): keep the arguments of the last shade forward for a replay
 
 
 class _Shade(torch.autograd.Function):
@@ -491,6 +494,8 @@ class _Shade(torch.autograd.Function):
                                          for k in ("spec_env_stride", "diff_env_stride", "mip_off", "mip_res", "n_mips", "diff_res",
                                                    "lut_res", "min_rough_mip", "max_rough_mip", "texel_format")}}, SHADE_DUMP["path"])
             SHADE_DUMP["path"] = None
+        if SHADE_KEEP["on"]:
+            SHADE_KEEP["last"] = (feat.detach(), nrm, view, pix_idx, n_dev, env_of_view, atlas, mat, HW)
         Np = (N + 3) // 4 * 4                   # channel pitch: the kernel stores 16 bytes (4 rows) per lane
         color = torch.empty(3, Np, device=dev)[:, :N]
         dbg = [None] * 7

@@ -620,3 +620,73 @@ def test_static_isa_guards_on_the_lds_dma_main_loops():
         assert not any("scratch_" in i for i in body)
         assert not any(i.startswith("s_waitcnt") and "vmcnt(0)" in i for i in main)
         assert sum(i.startswith("v_accvgpr") for i in main) <= 8, "register copies in the main loop: the AGPR / VGPR split of attn_w128 broke"
+
+
+def test_half_dtype_entry_points_resolve_to_exported_symbols():
+    """hipops._sym: the IEEE-half instantiation of a net kernel carries f16 in place of bf16 (or an _f16 suffix where the bf16 name
+    has no dtype token); every such name is exported by the library and declared with the bf16 entry point's signature."""
+    from dreammat_amd import _lib, hipops
+    for name in ("dm_conv3x3_nhwc_bf16_fused", "dm_conv2x2_nhwc_bf16", "dm_conv3x3_small_res_nhwc_bf16", "dm_gemm_bf16_fused",
+                 "dm_attention_fwd_bf16", "dm_layernorm_bf16", "dm_geglu_bf16", "dm_cat_add_bf16", "dm_softmax_rows_bf16",
+                 "dm_softmax_rows_bwd_bf16", "dm_groupnorm_nhwc_fwd", "dm_groupnorm_nhwc_infer", "dm_groupnorm_nhwc_bwd_res"):
+        fb, nb = hipops._sym(name, torch.bfloat16)
+        fh, nh = hipops._sym(name, torch.float16)
+        assert nb == name and nh != name and "bf16" not in nh and "f16" in nh
+        assert _lib._SIGS[nh] == _lib._SIGS[name] and fb is not fh
+    with pytest.raises(TypeError):
+        hipops._sym("dm_layernorm_bf16", torch.float32)
+    with pytest.raises(AssertionError):
+        hipops._same_half(torch.zeros(1, dtype=torch.bfloat16), torch.zeros(1, dtype=torch.float16))
+
+
+def test_recorded_exits_from_the_hand_written_kernels(monkeypatch, capsys):
+    """layers.note_fallback: every 16-bit CUDA call that leaves the kernels of csrc/ is counted, announced ONCE per (kind, shape),
+    and an error under DREAMMAT_STRICT_KERNELS=1 -- there is no silent lowering to ATen."""
+    from dreammat_amd.sd import layers
+    layers.fallbacks(clear=True)
+    layers.note_fallback("conv", "3x3 7->9 s1 p1")
+    layers.note_fallback("conv", "3x3 7->9 s1 p1")
+    layers.note_fallback("linear", "K=8 N=8 M=16 autograd")
+    assert layers.fallbacks() == {("conv", "3x3 7->9 s1 p1"): 2, ("linear", "K=8 N=8 M=16 autograd"): 1}
+    err = capsys.readouterr().err
+    assert err.count("3x3 7->9") == 1 and "ATen / hipBLASLt" in err
+    monkeypatch.setenv("DREAMMAT_STRICT_KERNELS", "1")
+    with pytest.raises(RuntimeError):
+        layers.note_fallback("groupnorm", "C=48 groups=16")
+    assert layers.fallbacks(clear=True) and not layers.fallbacks()
+    # CPU / fp32 tensors are not "expected native": the fp32 plumbing tier never reports
+    assert not layers._native_expected(torch.zeros(1))
+
+
+def test_bank_cast_cache_matches_the_bank_by_identity_not_by_address():
+    """guidance._bank_cast: an entry keeps its source bank and is matched by identity + version; evicting the pool
+    drops everything derived from the casts (graphs, per-layer K / V^T banks, grouped gathers)."""
+    from dreammat_amd.guidance import StableDiffusionLightGuidance as G
+    from dreammat_amd.sd import layers
+
+    class Stub:
+        weights_dtype = torch.float64
+        BANK_CAST_POOL = G.BANK_CAST_POOL
+        _bank_cast = G._bank_cast
+        _drop_bank_projections = G._drop_bank_projections
+
+        def __init__(self):
+            self.attn = layers.Attention(8, 1, 8)
+            self.attn.__dict__["_kv_banks"] = {"stale": 1}
+            self.unet = torch.nn.Sequential(self.attn)
+            self.unet.__dict__["_net_prologue"] = layers.NetPrologue(self.unet)
+            self.unet.__dict__["_net_prologue"]._kv["stale"] = 1
+            self.controlnets = []
+            self._graphs = {"g": 1}
+    s = Stub()
+    a = torch.ones(3, 4)
+    ca = s._bank_cast(a)
+    assert s._bank_cast(a) is ca and ca.dtype == torch.float64
+    b = torch.ones(3, 4)                                   # an equal tensor is NOT the same bank
+    assert s._bank_cast(b) is not ca
+    a.add_(1)                                              # a changed bank is re-cast
+    assert s._bank_cast(a) is not ca and float(s._bank_cast(a)[0, 0]) == 2.0
+    assert s._graphs and s.attn.__dict__.get("_kv_banks")
+    for _ in range(G.BANK_CAST_POOL):                      # overflow: casts, graphs and every projection derived from them go
+        s._bank_cast(torch.zeros(2, 2))
+    assert not s._graphs and "_kv_banks" not in s.attn.__dict__ and not s.unet.__dict__["_net_prologue"]._kv
