@@ -474,12 +474,19 @@ def main():
                                 "doubled per MI355X_MICROARCH.md); not collected live because rocprofv3 --pmc segfaults "
                                 "under python+torch in this image (profiles/r01_pmc_attempt_segfault.log)")
         for nm, key in (("roofline_shade_fwd", "shade_fwd"), ("roofline_shade_bwd", "shade_bwd")):
-            if key in kt:
-                r = kt[key]
-                gbs = r["work_per_launch"] / (r["avg_ms"] * 1e-3) / 1e9
-                res[nm] = {"kernel": "k_" + key, "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s",
-                           "frac": gbs / 8000.0, "traffic": None, "avg_us": r["avg_ms"] * 1e3,
-                           "covered_pixels": r["work_per_launch"] / (56.0 if key == "shade_fwd" else 76.0)}
+            # the forward inside the step also writes the 7 logging buffers of the reference's render dict (debug_outputs: 17 floats
+            # per covered pixel on top of SURVEY 8d's 56 B): its row counts the bytes that launch moves; the replay rows below run
+            # the kernel without them, on the 56 B / 76 B definition
+            step_key = key + "+dbg" if key + "+dbg" in kt else key
+            if step_key in kt:
+                r = kt[step_key]
+                per_px = (56.0 if key == "shade_fwd" else 76.0)
+                n_px = r["work_per_launch"] / per_px
+                bytes_launch = r["work_per_launch"] + (68.0 * n_px if step_key.endswith("+dbg") else 0.0)
+                gbs = bytes_launch / (r["avg_ms"] * 1e-3) / 1e9
+                res[nm] = {"kernel": "k_" + key + (" (+ 7 logging outputs)" if step_key.endswith("+dbg") else ""), "bound": "hbm",
+                           "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None,
+                           "avg_us": r["avg_ms"] * 1e3, "covered_pixels": n_px, "algorithmic_bytes": bytes_launch}
                 res[nm].update(shade_traffic(key, system.material.atlas.texel) or {})
                 res[nm]["measured"] = "inside full steps (cold caches: 70 ms and several GB after the kernel's previous run)"
                 for case, ktr in shade_replay.items():      # replayed back-to-back on the step's G-buffer
