@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-end validation + measurement pass on the GPU box (rounds 2-4).  Writes small files to gpurun_out/ only; copy what is to be
+# Round-end validation + measurement pass on the GPU box (rounds 2-5).  Writes small files to gpurun_out/ only; copy what is to be
 # judged into profiles/ afterwards (tools/pmc_collect.py for the counters).
 #   1 full GPU test suite   2 default bench line (with the CPU baseline)   3 rocprofv3 --kernel-trace --stats of the same
 #   bench command + per-step kernel tables at 8 views and at 1 view per rank   4 A/B probe (also dumps the bench scene's real
@@ -21,6 +21,15 @@ cut -c1-200 gpurun_out/final_bench_line.json
 timeout 400 python bench.py --raytracing --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null < /dev/null | grep '^{"metric' > gpurun_out/final_bench_line_raytracing.json
 cut -c1-120 gpurun_out/final_bench_line_raytracing.json
 timeout 200 python tools/mc_probe.py 100000 0 2>/dev/null | grep '^{' > gpurun_out/final_mc_probe.jsonl
+# round 5: the same step with the renderer's 7 logging outputs off (round 4's timed region), in IEEE half, and with the MX-FP8
+# self-attention; BASELINE configs[4] as a preset (16 views @1024^2, 200 k triangles, f16 nets + fp8 attention)
+timeout 300 python bench.py --no-cpu-baseline --no-debug-outputs 2>/dev/null < /dev/null | grep '^{"metric' > gpurun_out/final_bench_line_nodebug.json
+timeout 300 python bench.py --no-cpu-baseline --dtype f16 2>/dev/null < /dev/null | grep '^{"metric' > gpurun_out/final_bench_line_f16.json
+timeout 300 python bench.py --no-cpu-baseline --dtype f16 --attention fp8 2>/dev/null < /dev/null | grep '^{"metric' > gpurun_out/final_bench_line_f16_fp8.json
+timeout 600 python bench.py --no-cpu-baseline --cfg5 --steps 3 --warmup 1 2>gpurun_out/final_cfg5.err < /dev/null | grep '^{"metric' > gpurun_out/final_cfg5_bench_line.json
+for f in nodebug f16 f16_fp8; do python3 -c "import json; d=json.load(open('gpurun_out/final_bench_line_$f.json')); print('$f', d['dtype'], round(d['value'],3), round(d['ms_per_step'],2))"; done
+python3 -c "import json; d=json.load(open('gpurun_out/final_cfg5_bench_line.json')); print('cfg5', d['dtype'], round(d['value'],3), round(d['ms_per_step'],1), d['config']['peak_hbm_gb'])" || tail -3 gpurun_out/final_cfg5.err
+tools/_dma_probe > gpurun_out/final_dma_probe.jsonl 2>&1
 [ "${FINAL_QUICK:-0}" = 1 ] && { python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1; exit 0; }
 export TMPDIR=/tmp
 for v in 8 1; do
@@ -35,18 +44,16 @@ timeout 200 bash tools/gemm_fit.sh > gpurun_out/final_gemm_shapes.txt 2>&1
 [ -d _ab_old ] && tools/ab_step.sh > /dev/null 2>&1      # step time against the older tree in _ab_old/, same box -> gpurun_out/ab_step.txt
 # FINAL_SKIP_PMC=1: no probes / counter passes (the conv, attention and shade kernels have not changed since the last collection)
 [ "${FINAL_SKIP_PMC:-0}" = 1 ] && { python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1; exit 0; }
-PYTHONPATH=$R timeout 400 python tools/r2_probe.py --rounds 3 --iters 10 --skip-shade --variants auto,w128,w64,v3l,staged --out final_probe.json > gpurun_out/final_r2_probe.log 2>&1 < /dev/null
+PYTHONPATH=$R timeout 400 python tools/r2_probe.py --rounds 2 --iters 10 --skip-shade --variants auto,w128,w64 --out final_probe.json > gpurun_out/final_r2_probe.log 2>&1 < /dev/null
 # round 4: the shade kernels on the bench scene (row / tile order, round-3 loop vs round-4 loop) + on the step's REAL inputs; the
 # probe also dumps the tile-ordered case for the counter passes
 timeout 300 python bench.py --no-cpu-baseline --steps 4 --dump-shade /tmp/shade_case.pt > /dev/null 2>&1 < /dev/null
 timeout 200 python tools/r4_shade_probe.py --rounds 3 --iters 20 > gpurun_out/final_shade_probe.log 2>&1 < /dev/null
 timeout 200 python tools/r4_shade_probe.py --case /tmp/shade_case.pt --rounds 3 --iters 20 > gpurun_out/final_shade_case.log 2>&1 < /dev/null
 grep '"op": "shade_bench_case"' gpurun_out/final_shade_case.log | cut -c1-200 | tail -5
-tools/_gather_probe > gpurun_out/final_gather_probe.jsonl 2>&1
 PMC_SECTIONS="conv attn shade" SHADE_CASES="rgb18e8" ATTN_VARIANTS="w128 w64" ATTN_MAIN=w128 timeout 900 bash tools/pmc_r2.sh > gpurun_out/final_pmc.log 2>&1
 DREAMMAT_ATTN_TIMELINE=1 tools/_abi_pmc attn 24 5 4096 4096 64 1 w128 2>&1 | grep "wg 300" | tail -4 > gpurun_out/final_attn_timeline.txt
 DREAMMAT_ATTN_TIMELINE=1 tools/_abi_pmc attn 24 5 4096 4096 64 1 w64 2>&1 | grep "wg 300" | tail -4 >> gpurun_out/final_attn_timeline.txt
-tools/_issue_probe > gpurun_out/final_issue_probe.jsonl 2>&1
 bash tools/conv_b3.sh > gpurun_out/final_conv_batch3.txt 2>&1
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 ls gpurun_out/pmc_r2 | wc -l
