@@ -6,8 +6,8 @@ mkdir -p $R/gpurun_out
 : > $R/gpurun_out/ab_step.txt
 for pass in 1 2 3; do
   for which in old new; do
-    if [ $which = old ]; then d=$R/_ab_old; else d=$R; fi
-    (cd $d && timeout 200 python bench.py --steps 15 --warmup 3 --no-cpu-baseline "$@" 2>/dev/null | tail -1 | python -c "
+    if [ $which = old ]; then d=$R/_ab_old; extra=""; else d=$R; extra="${AB_NEW_ARGS:-}"; fi      # AB_NEW_ARGS: flags only the new tree knows
+    (cd $d && timeout 200 python bench.py --steps 15 --warmup 3 --no-cpu-baseline $extra "$@" 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 print('$which', $pass, 'steps/s %.3f  ms %.2f  conv %.3f attn %.3f  shade %.3f / %.3f' % (d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline_attention']['frac'], d['roofline_shade_fwd']['frac'], d['roofline_shade_bwd']['frac']))") >> $R/gpurun_out/ab_step.txt
