@@ -389,11 +389,16 @@ def main():
                 st = torch.empty(ft.shape[1], Np, device=dev)[:, :ft.shape[0]]
                 st.copy_(ft.t())
                 f = st.t().requires_grad_(True)
-                g = torch.randn(ft.shape[0], 3, device=dev, generator=gen)
+                gs = torch.empty(3, Np, device=dev)[:, :ft.shape[0]]
+                gs.copy_(torch.randn(3, ft.shape[0], device=dev, generator=gen))
+                g = gs.t()                                   # the upstream gradient in the SoA form the scatter's backward hands over
                 for it in range(13):
                     if it == 3:
                         sync()
                         hipops.enable_kernel_timing(True, only=("shade_fwd", "shade_bwd"))
+                        # hold the stream while the host enqueues the ten iterations: the launches then run back to back and an
+                        # event pair brackets its kernel only (an idle stream would add the host's launch latency to every pair)
+                        torch.cuda._sleep(int(3e7))
                     col = hipops.shade(f, *kept[1:], want_debug=False)[0]
                     col.backward(g)
                     f.grad = None

@@ -18,7 +18,7 @@
 // workspace: 1 byte per element instead of 2 on every re-read of K / V by the query blocks.  V^T is stored tile-major
 // ([kv tile of 64][channel][64 bytes]).
 //
-// Kernel.  A workgroup = 4 waves x 32 query rows, no LDS, no barrier: K / V^T tiles are 4 KB each and come straight from L2 as
+// Kernel.  A workgroup = 4 waves x 64 query rows (two 32-row blocks per wave, one wave per SIMD), no LDS, no barrier: K / V^T tiles are 4 KB each and come straight from L2 as
 // two 16-byte loads per lane and operand (the 4 waves of a workgroup and the workgroups of a (batch, head) on one XCD share
 // them there), both double-buffered in registers one tile ahead.  Per 64-row kv tile and wave: 2 MFMAs form
 // S^T = K.Q'^T - shift (two 32 x 32 tiles, the whole head dimension in one instruction each; the row shift enters through the C
@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256) void k_fp8_quant_vt(const T* __restrict__ src,
     dsts[slot * 2 + hh] = (unsigned char)e8m0(e);
 }
 
-constexpr int kRowsPerWg = 128;      // 4 waves x 32 query rows
+constexpr int kNQ = 2;               // 32-row query blocks per wave
+constexpr int kRowsPerWg = 4 * 32 * kNQ;      // 4 waves x kNQ x 32 query rows
 constexpr int kPScaleByte = 127 - 8; // E8M0 of the constant 2^-8 that undoes the 2^8 inside the stored probabilities
 
 struct KvFrag {
@@ -160,7 +161,7 @@ struct KvFrag {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256, 2) void k_attn_fwd_fp8(Fp8Args a) {
+__global__ __launch_bounds__(256, 1) void k_attn_fwd_fp8(Fp8Args a) {
     const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // 1-D grid, XCD-aware (block b runs on XCD b % 8): all query blocks of one (batch, head) run on one XCD, whose L2 then serves
@@ -179,12 +180,23 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_fp8(Fp8Args a) {
         }
     }
     const int n_tiles = a.Skv / 64;
-    const long long qrow = (long long)bh * a.Sq + qblk * kRowsPerWg + wave * 32 + l31;
+    const int row0 = qblk * kRowsPerWg + wave * 32 * kNQ;     // this wave's first query row
 
-    const i32x4* qp = reinterpret_cast<const i32x4*>(a.q8 + qrow * 64 + 16 * hi);
-    const i32x4 q0 = qp[0], q1 = qp[2];              // bytes 16 hi .. and 32 + 16 hi .. of the row (operand layout: see the header)
-    const i32x8 qB = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
-    const int qsc = a.qs[qrow * 2 + hi];
+    // ONE wave per SIMD, kNQ query blocks per wave (round 5, second version): the first version (one block per wave, two waves
+    // per SIMD) spent a tile in a serial chain -- scores out of the matrix pipe, row maximum, exponentials, packing, hand-over,
+    // second product -- with only the partner wave to fill the gaps and every wave fetching its own copy of K / V^T: neither
+    // pipe above 40 % busy.  Two independent blocks per wave give the in-order stream a second chain to issue from and halve
+    // the operand bytes per score.
+    i32x8 qB[kNQ];
+    int qsc[kNQ];
+#pragma unroll
+    for (int qb = 0; qb < kNQ; ++qb) {
+        const long long qrow = (long long)bh * a.Sq + row0 + 32 * qb + l31;
+        const i32x4* qp = reinterpret_cast<const i32x4*>(a.q8 + qrow * 64 + 16 * hi);
+        const i32x4 q0 = qp[0], q1 = qp[2];          // bytes 16 hi .. and 32 + 16 hi .. of the row (operand layout: see the header)
+        qB[qb] = i32x8{q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+        qsc[qb] = a.qs[qrow * 2 + hi];
+    }
 
     const unsigned char* k8 = a.k8 + ((long long)bh * a.Skv + l31) * 64 + 16 * hi;
     const unsigned char* ksc = a.ks + ((long long)bh * a.Skv + l31) * 2 + hi;
@@ -204,75 +216,94 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_fp8(Fp8Args a) {
         }
     };
 
-    // O^T accumulators: fragments 0 / 1 = channels 0-31 / 32-63; fragment 2 = a 33rd "channel" of ones in row 0 (lanes 0-31,
-    // register 0), whose product with P^T is the row sum of the probabilities AS ROUNDED to e4m3 -- numerator and denominator see
-    // the same rounding, and the 64 v_add_f32 per tile the sum would cost on the vector pipe (5.5 cycles each, beside 4 MFMAs of
-    // 64) become one more MFMA
-    f32x16 o[3];
+    // O^T accumulators per query block: fragments 0 / 1 = channels 0-31 / 32-63; fragment 2 = a 33rd "channel" of ones in row 0
+    // (lanes 0-31, register 0), whose product with P^T is the row sum of the probabilities AS ROUNDED to e4m3 -- numerator and
+    // denominator see the same rounding, and the 64 v_add_f32 per tile the sum would cost on the vector pipe (5.5 cycles each,
+    // beside MFMAs of 64) become one more MFMA
+    f32x16 o[kNQ][3];
 #pragma unroll
-    for (int f = 0; f < 3; ++f)
+    for (int qb = 0; qb < kNQ; ++qb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[f][r] = 0.f;
+        for (int f = 0; f < 3; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[qb][f][r] = 0.f;
     const int one_w = l31 == 0 ? 0x38383838 : 0;       // e4m3 1.0 = 0x38
     const i32x8 onesA = {one_w, one_w, one_w, one_w, one_w, one_w, one_w, one_w};
     // C operand of the first product: -shift of this lane's query row, so that the MFMA delivers s - shift and a probability is
     // ONE v_exp_f32.  shift = (row maximum so far) - 8: the stored probability exp2(s - shift) <= 2^8 < 448.  It moves (rarely
     // after the first tiles) when a row's maximum grows: O, the scores at hand and the C operand are re-based by the difference.
-    f32x16 cinit;
+    f32x16 cinit[kNQ];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) cinit[r] = 0.f;
+    for (int qb = 0; qb < kNQ; ++qb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cinit[qb][r] = 0.f;
 
     auto tile_body = [&](const KvFrag& fk, bool first) __attribute__((always_inline)) {
-        f32x16 s[2];
+        f32x16 s[kNQ][2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)      // S^T[kv][q] - shift[q] = sum_d K[kv][d] Q'[q][d] - shift[q]
-            s[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fk.k[t], qB, cinit, 0, 0, 0, fk.ks[t], 0, qsc);
-        float mx = fmaxf(s[0][0], s[1][0]);
+        for (int qb = 0; qb < kNQ; ++qb)
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const bool grow = mx > 8.f;
-        if (first || __any(grow)) {
-            const float delta = (first || grow) ? mx - 8.f : 0.f;
-            const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
+            for (int t = 0; t < 2; ++t)  // S^T[kv][q] - shift[q] = sum_d K[kv][d] Q'[q][d] - shift[q]
+                s[qb][t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fk.k[t], qB[qb], cinit[qb], 0, 0, 0, fk.ks[t], 0, qsc[qb]);
+        float mx[kNQ];
+        bool grow_any = false;
 #pragma unroll
-            for (int ff = 0; ff < 3; ++ff)
+        for (int qb = 0; qb < kNQ; ++qb) {
+            float m = fmaxf(s[qb][0][0], s[qb][1][0]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[ff][r] *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { cinit[r] -= delta; s[0][r] -= delta; s[1][r] -= delta; }
+            for (int r = 1; r < 16; ++r) m = fmaxf(fmaxf(m, s[qb][0][r]), s[qb][1][r]);
+            mx[qb] = fmaxf(m, __shfl_xor(m, 32));
+            grow_any = grow_any || mx[qb] > 8.f;
         }
-        int pt[2][4];
+        if (first || __any(grow_any)) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int qb = 0; qb < kNQ; ++qb) {
+                const float delta = (first || mx[qb] > 8.f) ? mx[qb] - 8.f : 0.f;
+                const float alpha = first ? 1.f : __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                float p[4];
+                for (int ff = 0; ff < 3; ++ff)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) p[e] = __builtin_amdgcn_exp2f(s[t][4 * g + e]);
-                int w = __builtin_amdgcn_cvt_pk_fp8_f32(p[0], p[1], 0, false);
-                pt[t][g] = __builtin_amdgcn_cvt_pk_fp8_f32(p[2], p[3], w, true);
+                    for (int r = 0; r < 16; ++r) o[qb][ff][r] *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { cinit[qb][r] -= delta; s[qb][0][r] -= delta; s[qb][1][r] -= delta; }
             }
-        // B operand of V^T.P^T: lane (q, H) wants kv 16 H .. 16 H + 15 of both 32-row score tiles.  Lane (q, 0) keeps its groups
-        // g = 0, 1 and receives the partner's, lane (q, 1) likewise for g = 2, 3 -- one v_permlane32_swap per dword pair -- and the
-        // bytes come out in natural kv order (see the header)
-        i32x8 pB;
+        }
+        i32x8 pB[kNQ];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int qb = 0; qb < kNQ; ++qb) {
+            int pt[2][4];
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)pt[t][g], (unsigned)pt[t][g + 2], false, false);
-                pB[4 * t + 2 * g] = (int)sw[0];            // lanes 0-31: own (hi 0, g)     | lanes 32-63: (hi 0, g + 2) of the partner
-                pB[4 * t + 2 * g + 1] = (int)sw[1];        // lanes 0-31: (hi 1, g) received | lanes 32-63: own (hi 1, g + 2)
-            }
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int ff = 0; ff < 2; ++ff)   // O^T[d][q] += sum_kv V^T[d][kv] P[q][kv]
-            o[ff] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fk.v[ff], pB, o[ff], 0, 0, 0, fk.vs[ff], 0, kPScaleByte);
-        o[2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(onesA, pB, o[2], 0, 0, 0, 127, 0, kPScaleByte);
+                for (int g = 0; g < 4; ++g) {
+                    float p[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) p[e] = __builtin_amdgcn_exp2f(s[qb][t][4 * g + e]);
+                    int w = __builtin_amdgcn_cvt_pk_fp8_f32(p[0], p[1], 0, false);
+                    pt[t][g] = __builtin_amdgcn_cvt_pk_fp8_f32(p[2], p[3], w, true);
+                }
+            // B operand of V^T.P^T: lane (q, H) wants kv 16 H .. 16 H + 15 of both 32-row score tiles.  Lane (q, 0) keeps its
+            // groups g = 0, 1 and receives the partner's, lane (q, 1) likewise for g = 2, 3 -- one v_permlane32_swap per dword
+            // pair -- and the bytes come out in natural kv order (see the header)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)pt[t][g], (unsigned)pt[t][g + 2], false, false);
+                    pB[qb][4 * t + 2 * g] = (int)sw[0];         // lanes 0-31: own (hi 0, g)     | lanes 32-63: (hi 0, g + 2) of the partner
+                    pB[qb][4 * t + 2 * g + 1] = (int)sw[1];     // lanes 0-31: (hi 1, g) received | lanes 32-63: own (hi 1, g + 2)
+                }
+        }
+#pragma unroll
+        for (int qb = 0; qb < kNQ; ++qb) {
+#pragma unroll
+            for (int ff = 0; ff < 2; ++ff)   // O^T[d][q] += sum_kv V^T[d][kv] P[q][kv]
+                o[qb][ff] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fk.v[ff], pB[qb], o[qb][ff], 0, 0, 0, fk.vs[ff], 0, kPScaleByte);
+            o[qb][2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(onesA, pB[qb], o[qb][2], 0, 0, 0, 127, 0, kPScaleByte);
+        }
     };
 
-    // both operands of a tile are requested one tile ahead (round 5: with V^T requested at the top of its own tile every tile
-    // waited out an L2 round trip in front of the second product)
+    // both operands of a tile are requested one tile ahead
     KvFrag fa, fb;
     load_tile(0, fa);
     if (n_tiles > 1) load_tile(1, fb);
@@ -286,22 +317,25 @@ __global__ __launch_bounds__(256, 2) void k_attn_fwd_fp8(Fp8Args a) {
     }
     if (j < n_tiles) tile_body(fb, false);
 
-    // row sum: row 0 of fragment 2 = register 0 of lanes 0-31 (column q = lane)
-    const float lt = __shfl(o[2][0], l31);
-    const float inv = 1.f / lt;           // (numerator and denominator carry the same 2^8 / 2^-8)
-    // O^T lane (q, hi), fragment f, register r = channel 32 f + 8 (r >> 2) + 4 hi + (r & 3): four consecutive channels per group
     const int bq = bh / a.Hh, hq = bh - bq * a.Hh;
-    T* op = reinterpret_cast<T*>(a.out) + bq * a.o_bs + (long long)(qblk * kRowsPerWg + wave * 32 + l31) * a.o_ss + (long long)hq * a.o_hs;
     typedef typename Vec4<T>::type T4;
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int qb = 0; qb < kNQ; ++qb) {
+        // row sum: row 0 of fragment 2 = register 0 of lanes 0-31 (column q = lane)
+        const float lt = __shfl(o[qb][2][0], l31);
+        const float inv = 1.f / lt;           // (numerator and denominator carry the same 2^8 / 2^-8)
+        // O^T lane (q, hi), fragment f, register r = channel 32 f + 8 (r >> 2) + 4 hi + (r & 3): four consecutive channels per group
+        T* op = reinterpret_cast<T*>(a.out) + bq * a.o_bs + (long long)(row0 + 32 * qb + l31) * a.o_ss + (long long)hq * a.o_hs;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            T4 w;
+        for (int f = 0; f < 2; ++f)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) w[e] = (T)(o[f][4 * g + e] * inv);
-            *reinterpret_cast<T4*>(op + 32 * f + 8 * g + 4 * hi) = w;
-        }
+            for (int g = 0; g < 4; ++g) {
+                T4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = (T)(o[qb][f][4 * g + e] * inv);
+                *reinterpret_cast<T4*>(op + 32 * f + 8 * g + 4 * hi) = w;
+            }
+    }
 }
 
 size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
@@ -349,7 +383,7 @@ size_t dm_attention_fp8_workspace_bytes(int B, int Hh, int Sq, int Skv) {
 }
 
 // softmax(q k^T scale) v with the two matrix products on the MX-FP8 matrix instruction.  q, k, vt, out: the tensors and strides of
-// dm_attention_fwd_bf16 (include/dreammat_hip.h) with D = 64; elem_f16 = 0: bf16 tensors, 1: IEEE half.  Sq % 128 == 0,
+// dm_attention_fwd_bf16 (include/dreammat_hip.h) with D = 64; elem_f16 = 0: bf16 tensors, 1: IEEE half.  Sq % 256 == 0,
 // Skv % 64 == 0 (self-attention of the 64-wide SD-2.1 heads; anything else: DM_ERR_UNSUPPORTED, the caller keeps the 16-bit
 // kernels).  ws: dm_attention_fp8_workspace_bytes(B, Hh, Sq, Skv) bytes, 256-byte aligned, scratch.
 int dm_attention_fwd_fp8(const void* q, const void* k, const void* vt, void* out, int B, int Hh, int Sq, int Skv, int D, long long q_bs,

@@ -601,9 +601,9 @@ _FP8_WS = {}
 
 
 def attention_fp8_ok(q, k, heads):
-    """dm_attention_fwd_fp8 serves this call: 64-wide heads, whole 128-row query blocks and 64-row kv tiles"""
+    """dm_attention_fwd_fp8 serves this call: 64-wide heads, whole 256-row query blocks and 64-row kv tiles"""
     D = q.shape[-1] // heads
-    return q.is_cuda and q.dtype in HALF_DTYPES and D == 64 and q.shape[1] % 128 == 0 and k.shape[1] % 64 == 0
+    return q.is_cuda and q.dtype in HALF_DTYPES and D == 64 and q.shape[1] % 256 == 0 and k.shape[1] % 64 == 0
 
 
 def attention_fp8(q, k, vt, heads, scale=None):

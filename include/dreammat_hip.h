@@ -459,7 +459,7 @@ int dm_groupnorm_nhwc_bwd_res_f16(const void* x, const void* gamma, const void* 
 /* BASELINE.json configs[4] "fp8 MFMA attention": softmax(q k^T scale) v of the 64-wide SD-2.1 heads with both matrix products
  * on v_mfma_scale_f32_32x32x64_f8f6f4 (OCP e4m3 elements, one E8M0 scale per 32 elements of the contracted dimension).
  * q, k, vt, out and their strides: as dm_attention_fwd_bf16 with D = 64; elem_f16 = 0: bf16 tensors, 1: IEEE half.
- * Sq % 128 == 0, Skv % 64 == 0 (else DM_ERR_UNSUPPORTED: the caller keeps the 16-bit kernels).
+ * Sq % 256 == 0, Skv % 64 == 0 (else DM_ERR_UNSUPPORTED: the caller keeps the 16-bit kernels).
  * ws: dm_attention_fp8_workspace_bytes(B, Hh, Sq, Skv) bytes of scratch (the quantised operands), 256-byte aligned. */
 size_t dm_attention_fp8_workspace_bytes(int B, int Hh, int Sq, int Skv);
 int dm_attention_fwd_fp8(const void* q, const void* k, const void* vt, void* out, int B, int Hh, int Sq, int Skv, int D,
