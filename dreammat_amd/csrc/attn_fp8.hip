@@ -29,6 +29,11 @@
 //   tile 0 (bytes 0-15) and of tile 1 (bytes 16-31): groups 0, 1 of both lanes of the pair for H = 0, groups 2, 3 for H = 1.
 //   v_permlane32_swap(group g, group g + 2) for g = 0, 1 hands each lane the partner's half, and the dwords (own g | partner g |
 //   own g + 1 | partner g + 1) are the 16 positions in natural order -- V^T needs no permutation.
+// Measured (round 5, S = 4096 x 24 x 5 / S = 16384 x 6 x 5, pre-passes included): 755 us = 683 TF/s / 2.47 ms = 835 TF/s, against
+// 483 us / 1.75 ms of the bf16 kernel (attn_w128.hip) -- 0.14-0.17 of the 5 PFLOP/s MX-FP8 peak.  Three structures were
+// measured and all land within 5 % of each other: one block per wave on two waves per SIMD (770 us), this one, and this one
+// with the kv loop software-pipelined by hand (first product of tile j + 1 issued before the exponentials of tile j: 823 us, 512
+// registers with spills outside the loop).
 // What bounds it: the softmax on the vector pipe, not the matrix pipe.  Per tile a wave issues 5 MFMAs of 64 cycles (320) beside
 // 64 v_exp_f32, 32 v_cvt_pk_fp8_f32 and 32 v_max3_f32 (~9.4 / 6.4 / 5.5 issue cycles each from one wave, tools/issue_probe.cpp:
 // ~1000 cycles); the first version (running maximum, subtraction and row sum as VALU code: 64 more v_sub, 64 v_add, 32 v_max)
@@ -155,8 +160,9 @@ constexpr int kNQ = 2;               // 32-row query blocks per wave
 constexpr int kRowsPerWg = 4 * 32 * kNQ;      // 4 waves x kNQ x 32 query rows
 constexpr int kPScaleByte = 127 - 8; // E8M0 of the constant 2^-8 that undoes the 2^8 inside the stored probabilities
 
-struct OpFrag {                      // one 64-row operand tile as this lane holds it: rows 32 t + l31, its two 16-byte k groups,
-    i32x8 x[2]; int sc[2];           // and the scale byte of its block
+struct KvFrag {
+    i32x8 k[2]; int ks[2];           // K rows 32 t + l31 of the tile (this lane's two 16-byte k groups); the scale byte of its block
+    i32x8 v[2]; int vs[2];           // V^T channels 32 f + l31 likewise
 };
 
 template <typename T>
@@ -201,13 +207,17 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_fp8(Fp8Args a) {
     const unsigned char* ksc = a.ks + ((long long)bh * a.Skv + l31) * 2 + hi;
     const unsigned char* v8 = a.v8 + ((long long)bh * n_tiles * 64 + l31) * 64 + 16 * hi;
     const unsigned char* vsc = a.vs + ((long long)bh * n_tiles * 64 + l31) * 2 + hi;
-    auto load_op = [&](const unsigned char* p8, const unsigned char* psc, int j, OpFrag& f) __attribute__((always_inline)) {
+    auto load_tile = [&](int j, KvFrag& f) __attribute__((always_inline)) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const i32x4* p = reinterpret_cast<const i32x4*>(p8 + ((long long)j * 64 + 32 * t) * 64);
+            const i32x4* p = reinterpret_cast<const i32x4*>(k8 + ((long long)j * 64 + 32 * t) * 64);
             const i32x4 lo = p[0], up = p[2];
-            f.x[t] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
-            f.sc[t] = psc[((long long)j * 64 + 32 * t) * 2];
+            f.k[t] = i32x8{lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+            f.ks[t] = ksc[((long long)j * 64 + 32 * t) * 2];
+            const i32x4* pv = reinterpret_cast<const i32x4*>(v8 + ((long long)j * 64 + 32 * t) * 64);
+            const i32x4 vlo = pv[0], vup = pv[2];
+            f.v[t] = i32x8{vlo[0], vlo[1], vlo[2], vlo[3], vup[0], vup[1], vup[2], vup[3]};
+            f.vs[t] = vsc[((long long)j * 64 + 32 * t) * 2];
         }
     };
 
@@ -233,18 +243,13 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_fp8(Fp8Args a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) cinit[qb][r] = 0.f;
 
-    typedef f32x16 Scores[kNQ][2];
-    // S^T[kv][q] - shift[q] = sum_d K[kv][d] Q'[q][d] - shift[q]: 2 kNQ MFMAs, results consumed by max_check a pipeline stage later
-    auto qk = [&](const OpFrag& fk, Scores& s) __attribute__((always_inline)) {
+    auto tile_body = [&](const KvFrag& fk, bool first) __attribute__((always_inline)) {
+        f32x16 s[kNQ][2];
 #pragma unroll
         for (int qb = 0; qb < kNQ; ++qb)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-                s[qb][t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fk.x[t], qB[qb], cinit[qb], 0, 0, 0, fk.sc[t], 0, qsc[qb]);
-    };
-    // a row whose tile maximum passes the shift window re-bases O, the C operand and the scores at hand (wave-uniform branch, rare
-    // after the first tiles); `first`: the first tile sets the shift
-    auto max_check = [&](Scores& s, bool first) __attribute__((always_inline)) {
+            for (int t = 0; t < 2; ++t)  // S^T[kv][q] - shift[q] = sum_d K[kv][d] Q'[q][d] - shift[q]
+                s[qb][t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fk.k[t], qB[qb], cinit[qb], 0, 0, 0, fk.ks[t], 0, qsc[qb]);
         float mx[kNQ];
         bool grow_any = false;
 #pragma unroll
@@ -268,9 +273,7 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_fp8(Fp8Args a) {
                 for (int r = 0; r < 16; ++r) { cinit[qb][r] -= delta; s[qb][0][r] -= delta; s[qb][1][r] -= delta; }
             }
         }
-    };
-    // probabilities of one tile as the B operands of the second product: exp2, e4m3 pack, hand-over between the lanes of a pair
-    auto softmax_pack = [&](const Scores& s, i32x8 (&pB)[kNQ]) __attribute__((always_inline)) {
+        i32x8 pB[kNQ];
 #pragma unroll
         for (int qb = 0; qb < kNQ; ++qb) {
             int pt[2][4];
@@ -284,9 +287,9 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_fp8(Fp8Args a) {
                     int w = __builtin_amdgcn_cvt_pk_fp8_f32(p[0], p[1], 0, false);
                     pt[t][g] = __builtin_amdgcn_cvt_pk_fp8_f32(p[2], p[3], w, true);
                 }
-            // lane (q, H) wants kv 16 H .. 16 H + 15 of both 32-row score tiles.  Lane (q, 0) keeps its groups g = 0, 1 and
-            // receives the partner's, lane (q, 1) likewise for g = 2, 3 -- one v_permlane32_swap per dword pair -- and the bytes
-            // come out in natural kv order (see the header)
+            // B operand of V^T.P^T: lane (q, H) wants kv 16 H .. 16 H + 15 of both 32-row score tiles.  Lane (q, 0) keeps its
+            // groups g = 0, 1 and receives the partner's, lane (q, 1) likewise for g = 2, 3 -- one v_permlane32_swap per dword
+            // pair -- and the bytes come out in natural kv order (see the header)
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -296,50 +299,28 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_fp8(Fp8Args a) {
                     pB[qb][4 * t + 2 * g + 1] = (int)sw[1];     // lanes 0-31: (hi 1, g) received | lanes 32-63: own (hi 1, g + 2)
                 }
         }
-    };
-    // O^T[d][q] += sum_kv V^T[d][kv] P[q][kv] (+ the ones row): 3 kNQ MFMAs
-    auto pv = [&](const OpFrag& fv, const i32x8 (&pB)[kNQ]) __attribute__((always_inline)) {
 #pragma unroll
         for (int qb = 0; qb < kNQ; ++qb) {
 #pragma unroll
-            for (int ff = 0; ff < 2; ++ff)
-                o[qb][ff] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fv.x[ff], pB[qb], o[qb][ff], 0, 0, 0, fv.sc[ff], 0, kPScaleByte);
+            for (int ff = 0; ff < 2; ++ff)   // O^T[d][q] += sum_kv V^T[d][kv] P[q][kv]
+                o[qb][ff] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fk.v[ff], pB[qb], o[qb][ff], 0, 0, 0, fk.vs[ff], 0, kPScaleByte);
             o[qb][2] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(onesA, pB[qb], o[qb][2], 0, 0, 0, 127, 0, kPScaleByte);
         }
     };
 
-    // SOFTWARE PIPELINE over the kv tiles (third version): the second version issued, per tile, [first product | maximum |
-    // exponentials | second product] in dependency order -- the matrix pipe idle during the exponentials, the vector pipe idle
-    // during the products: 1230 + 640 cycles per tile.  Here iteration j issues the first product of tile j + 1 BEFORE the
-    // exponentials of tile j and the second product of tile j BEFORE the maximum of tile j + 1, so that each pipe's work of one
-    // tile runs under the other pipe's work of its neighbour.  ONE register set per operand: an MFMA reads its operands when it
-    // issues, so K(j + 2) is requested into K's registers right behind the products of K(j + 1), V(j + 1) right behind those of
-    // V(j) -- each a whole iteration before its use.
-    OpFrag kf, vf;
-    Scores sA, sB;
-    i32x8 pB[kNQ];
-    load_op(k8, ksc, 0, kf);
-    load_op(v8, vsc, 0, vf);
-    qk(kf, sA);
-    if (n_tiles > 1) load_op(k8, ksc, 1, kf);
-    max_check(sA, true);
-    auto iter = [&](int j, Scores& s_cur, Scores& s_next) __attribute__((always_inline)) {
-        const bool has_next = j + 1 < n_tiles;
-        if (has_next) qk(kf, s_next);                                  // tile j + 1's scores form under tile j's exponentials
-        if (j + 2 < n_tiles) load_op(k8, ksc, j + 2, kf);
-        softmax_pack(s_cur, pB);
-        pv(vf, pB);
-        if (has_next) {
-            load_op(v8, vsc, j + 1, vf);
-            max_check(s_next, false);                                  // ... and its maximum under tile j's second product
-        }
-    };
-    int j = 0;
+    // both operands of a tile are requested one tile ahead
+    KvFrag fa, fb;
+    load_tile(0, fa);
+    if (n_tiles > 1) load_tile(1, fb);
+    tile_body(fa, true);
+    int j = 1;
     for (; j + 2 <= n_tiles; j += 2) {
-        iter(j, sA, sB);
-        iter(j + 1, sB, sA);
+        load_tile(j + 1, fa);
+        tile_body(fb, false);
+        if (j + 2 < n_tiles) load_tile(j + 2, fb);
+        tile_body(fa, false);
     }
-    if (j < n_tiles) iter(j, sA, sB);
+    if (j < n_tiles) tile_body(fb, false);
 
     const int bq = bh / a.Hh, hq = bh - bq * a.Hh;
     typedef typename Vec4<T>::type T4;
