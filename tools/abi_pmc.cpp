@@ -108,6 +108,8 @@ static int run_attn(int B, int Hh, int Sq, int Skv, int D, int iters) {
 }
 
 static int run_shade(long long N, int n_env, int iters) {
+    N &= ~3LL;                               // whole 16-byte groups per SoA channel (the kernels' fast path; see run_shade_file)
+    const long long Np = N;
     // atlas: envlight geometry (max_res 128 -> min_res 16, diffuse 16), every face with a 1-texel border, RGBA fp32
     dm_env_atlas at;
     memset(&at, 0, sizeof(at));
@@ -138,16 +140,16 @@ static int run_shade(long long N, int n_env, int iters) {
     std::vector<int> hcount(1, (int)N);
     void *dn, *dv, *df, *dg, *dp, *denv, *dcount, *dcol, *ddf;
     if (upload(&dn, hn) || upload(&dv, hv) || upload(&df, hf) || upload(&dg, hg) || upload(&dp, hp) || upload(&denv, henv) || upload(&dcount, hcount)) return 2;
-    CK(hipMalloc(&dcol, 3 * N * 4)); CK(hipMalloc(&ddf, 5 * N * 4));
+    CK(hipMalloc(&dcol, 3 * Np * 4)); CK(hipMalloc(&ddf, 5 * Np * 4));
     float ms_f, ms_b;
     int rc = timed(iters, &ms_f, [&] {
-        return dm_shade_fwd(&at, &mc, (float*)dn, 1, N, (float*)dv, 1, N, (float*)df, 1, N, (int*)dp, (int*)denv, (int*)dcount, N, HW, views,
-                            (float*)dcol, 1, N, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        return dm_shade_fwd(&at, &mc, (float*)dn, 1, Np, (float*)dv, 1, Np, (float*)df, 1, Np, (int*)dp, (int*)denv, (int*)dcount, N, HW, views,
+                            (float*)dcol, 1, Np, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     });
     if (rc) return rc;
     rc = timed(iters, &ms_b, [&] {
-        return dm_shade_bwd(&at, &mc, (float*)dn, 1, N, (float*)dv, 1, N, (float*)df, 1, N, (int*)dp, (int*)denv, (int*)dcount, N, HW, views,
-                            (float*)dg, 1, N, (float*)ddf, 1, N, nullptr);
+        return dm_shade_bwd(&at, &mc, (float*)dn, 1, Np, (float*)dv, 1, Np, (float*)df, 1, Np, (int*)dp, (int*)denv, (int*)dcount, N, HW, views,
+                            (float*)dg, 1, Np, (float*)ddf, 1, Np, nullptr);
     });
     if (rc) return rc;
     printf("{\"op\":\"shade\",\"N\":%lld,\"n_env\":%d,\"fwd_ms\":%.4f,\"bwd_ms\":%.4f,\"fwd_GBps\":%.0f,\"bwd_GBps\":%.0f,\"alg_fwd_MB\":%.1f,\"alg_bwd_MB\":%.1f}\n",
@@ -271,8 +273,18 @@ static int run_shade_file(const char* path, int iters) {
         if (fread(h.data(), 1, bytes, fh) != bytes) { printf("short read\n"); return 1; }
         return upload(dptr, h);
     };
+    // SoA row tensors [C][N] of the file -> device tensors with the channel pitch rounded up to 4 floats: the shade kernels' fast
+    // path streams 16 bytes per lane and (since round 5) requires every channel to start on a 16-byte boundary, which is what
+    // dreammat_amd/hipops.py allocates
+    const long long Np = (N + 3) / 4 * 4;
+    auto rd_soa = [&](int C, void** dptr) -> int {
+        std::vector<float> h((size_t)C * N), hp((size_t)C * Np, 0.f);
+        if (fread(h.data(), 4, (size_t)C * N, fh) != (size_t)C * N) { printf("short read\n"); return 1; }
+        for (int c = 0; c < C; ++c) memcpy(hp.data() + (size_t)c * Np, h.data() + (size_t)c * N, (size_t)N * 4);
+        return upload(dptr, hp);
+    };
     void *dn, *dv, *df, *dg, *dp, *denv, *dspec, *ddiff, *dlut, *dpairs = nullptr, *dcount, *dcol, *ddf;
-    if (rd(12 * N, &dn) || rd(12 * N, &dv) || rd(20 * N, &df) || rd(12 * N, &dg) || rd(4 * N, &dp) || rd(4 * views, &denv) ||
+    if (rd_soa(3, &dn) || rd_soa(3, &dv) || rd_soa(5, &df) || rd_soa(3, &dg) || rd(4 * N, &dp) || rd(4 * views, &denv) ||
         rd(hd[10], &dspec) || rd(hd[11], &ddiff) || rd((size_t)hd[6] * hd[6] * 8, &dlut))
         return 2;
     if (hd[12] && rd((size_t)hd[6] * (hd[6] + 1) * 16, &dpairs)) return 2;
@@ -287,16 +299,16 @@ static int run_shade_file(const char* path, int iters) {
     dm_mat_cfg mc = {0.0f, 0.9f, 0.1f, 0.95f};
     std::vector<int> hcount(1, (int)N);
     if (upload(&dcount, hcount)) return 2;
-    CK(hipMalloc(&dcol, 3 * N * 4)); CK(hipMalloc(&ddf, 5 * N * 4));
+    CK(hipMalloc(&dcol, 3 * Np * 4)); CK(hipMalloc(&ddf, 5 * Np * 4));
     float ms_f, ms_b;
     int rc = timed(iters, &ms_f, [&] {
-        return dm_shade_fwd(&at, &mc, (float*)dn, 1, N, (float*)dv, 1, N, (float*)df, 1, N, (int*)dp, (int*)denv, (int*)dcount, N, HW, views,
-                            (float*)dcol, 1, N, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+        return dm_shade_fwd(&at, &mc, (float*)dn, 1, Np, (float*)dv, 1, Np, (float*)df, 1, Np, (int*)dp, (int*)denv, (int*)dcount, N, HW, views,
+                            (float*)dcol, 1, Np, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     });
     if (rc) return rc;
     rc = timed(iters, &ms_b, [&] {
-        return dm_shade_bwd(&at, &mc, (float*)dn, 1, N, (float*)dv, 1, N, (float*)df, 1, N, (int*)dp, (int*)denv, (int*)dcount, N, HW, views,
-                            (float*)dg, 1, N, (float*)ddf, 1, N, nullptr);
+        return dm_shade_bwd(&at, &mc, (float*)dn, 1, Np, (float*)dv, 1, Np, (float*)df, 1, Np, (int*)dp, (int*)denv, (int*)dcount, N, HW, views,
+                            (float*)dg, 1, Np, (float*)ddf, 1, Np, nullptr);
     });
     if (rc) return rc;
     printf("{\"op\":\"shadef\",\"N\":%lld,\"texel_format\":%d,\"fg_pairs\":%d,\"fwd_ms\":%.4f,\"bwd_ms\":%.4f,\"fwd_GBps\":%.0f,\"bwd_GBps\":%.0f,\"alg_fwd_MB\":%.1f,\"alg_bwd_MB\":%.1f}\n",
