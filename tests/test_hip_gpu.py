@@ -2319,6 +2319,9 @@ def test_full_size_sd21_unet_controlnet_eps_vs_oracle(dev):
         del sd_u, sd_c
         rel32 = ((y - oy).abs().max() / oy.abs().max()).item()
         assert rel32 <= 1e-3, rel32
+        master = [{k: v.clone() for k, v in net.state_dict().items()} for net in (unet, cn)]     # fp32: each 16-bit leg casts from these
+        from dreammat_amd.sd import layers
+        layers.fallbacks(clear=True)
         unet.bfloat16(); cn.bfloat16()
         hipops.enable_kernel_timing(True)
         d, m = cn(x.to(dev).bfloat16(), t.to(dev), ctx.to(dev).bfloat16(), cond.to(dev).bfloat16(), 1.0)
@@ -2328,15 +2331,17 @@ def test_full_size_sd21_unet_controlnet_eps_vs_oracle(dev):
         hipops.enable_kernel_timing(False)
         # IEEE half (round 5): the reference's own precision class (half_precision_weights, dreammat_guidance.py:56) through the
         # f16 instantiations of the same kernels -- 11 significant bits where bf16 has 8
-        from dreammat_amd.sd import layers
-        layers.fallbacks(clear=True)
+        left_bf16 = layers.fallbacks(clear=True)
+        unet.float(); cn.float()
+        unet.load_state_dict(master[0]); cn.load_state_dict(master[1])        # (half of the bf16-ROUNDED weights would carry bf16's error)
+        del master
         unet.half(); cn.half()
         d, m = cn(x.to(dev).half(), t.to(dev), ctx.to(dev).half(), cond.to(dev).half(), 1.0)
         yh = unet(x.to(dev).half(), t.to(dev), ctx.to(dev).half(), d, m).float().cpu()
         left = layers.fallbacks()
     assert sum(v["launches"] for k, v in kt.items() if k.startswith("attention")) == 46
     assert any(k.startswith("conv3x3") for k in kt)
-    assert not left, left                                  # no layer of the frozen nets left the hand-written kernels
+    assert not left and not left_bf16, (left_bf16, left)   # no layer of the frozen nets left the hand-written kernels, in either type
     rel16 = ((yb - oy).abs().max() / oy.abs().max()).item()
     rel16_mean = ((yb - oy).abs().mean() / oy.abs().mean()).item()
     relh = ((yh - oy).abs().max() / oy.abs().max()).item()
