@@ -2350,6 +2350,6 @@ def test_full_size_sd21_unet_controlnet_eps_vs_oracle(dev):
         json.dump({"fp32_rel_max": rel32, "bf16_rel_max": rel16, "bf16_rel_mean": rel16_mean, "f16_rel_max": relh,
                    "f16_rel_mean": relh_mean, "eps_abs_max": float(oy.abs().max())}, fh)
     assert rel16 < 2e-2 and rel16_mean < 2e-2, (rel16, rel16_mean)     # measured 1.0-1.2e-2 / 0.9e-2 (rounds 2, 3)
-    # measured (round 5): 5.4e-3 max / 4.7e-3 mean -- half of bf16's error, not an eighth: what the two have in common is
-    # investigated in DESIGN.md section 2
-    assert torch.isfinite(yh).all() and relh < 8e-3 and relh_mean < 7e-3 and relh_mean < 0.7 * rel16_mean, (relh, relh_mean)
+    # measured (round 5): 1.27e-3 max / 1.15e-3 mean -- an eighth of bf16's error at every module of the stack
+    # (tools/f16_error_profile.py); the first measurement read 5.4e-3 because this test had handed the f16 leg bf16-rounded weights
+    assert torch.isfinite(yh).all() and relh < 2.5e-3 and relh_mean < 2e-3 and relh_mean < 0.25 * rel16_mean, (relh, relh_mean)
