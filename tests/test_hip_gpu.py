@@ -1595,6 +1595,8 @@ def test_rccl_world1_step_through_bench(dev, sharded):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["value"] > 0
+    # the line's second leg (round 5): the same step with the nets cast to IEEE half in place (here: under the captured hipGraph path)
+    assert res.get("f16_leg", {}).get("value") and res["f16_leg"]["final_loss"] == res["f16_leg"]["final_loss"], res.get("f16_leg")
     assert ("reduce-scatter" if sharded else "all-reduce") in res["config"]["parallelism"]
     assert "ProcessGroupNCCL" in r.stderr or "NCCL" in r.stderr.upper() or res["config"].get("process_group") == "nccl"
 
