@@ -333,7 +333,7 @@ def main(argv=None):
     def text(prompts):
         todo = [p for p in dict.fromkeys(prompts) if p not in embed]
         if todo:
-            for p, e in zip(todo, pp._encode([p or " " for p in todo])):
+            for p, e in zip(todo, pp._encode([p or " " for p in todo], keep_encoder=True)):      # (loaded once, not per batch)
                 embed[p] = e[None].to(dev)
         return torch.cat([embed[p] for p in prompts])
     epoch = 0

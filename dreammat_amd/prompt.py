@@ -202,7 +202,9 @@ class StableDiffusionPromptProcessor(BaseObject):
                 return cand
         return None
 
-    def _encode(self, prompts):
+    def _encode(self, prompts, keep_encoder=False):
+        """keep_encoder: leave tokenizer + CLIPTextModel loaded on the processor for later calls (the ControlNet training launcher
+        encodes unseen prompts batch by batch; the SDS path encodes once at start-up and frees the encoder)"""
         root = self._model_dir()
         if root is None:
             if not self._synthetic_allowed():
@@ -216,9 +218,13 @@ class StableDiffusionPromptProcessor(BaseObject):
                 g = torch.Generator().manual_seed(int(hash_prompt(self.cfg.pretrained_model_name_or_path, p)[:8], 16))
                 outs.append(torch.randn(77, self.embed_dim, generator=g))
             return torch.stack(outs)
-        from transformers import AutoTokenizer, CLIPTextModel
-        tok = AutoTokenizer.from_pretrained(os.path.join(root, "tokenizer"))
-        enc = CLIPTextModel.from_pretrained(os.path.join(root, "text_encoder")).to(self.device)
+        tok, enc = self.__dict__.get("_text_encoder", (None, None))
+        if enc is None:
+            from transformers import AutoTokenizer, CLIPTextModel
+            tok = AutoTokenizer.from_pretrained(os.path.join(root, "tokenizer"))
+            enc = CLIPTextModel.from_pretrained(os.path.join(root, "text_encoder")).to(self.device)
+            if keep_encoder:
+                self.__dict__["_text_encoder"] = (tok, enc)
         with torch.no_grad():
             ids = tok(prompts, padding="max_length", max_length=tok.model_max_length, return_tensors="pt")
             emb = enc(ids.input_ids.to(self.device))[0]
