@@ -11,10 +11,6 @@
 //   y = act((x - mean) * rstd * gamma + beta),  act = identity | SiLU.
 // Backward (the VAE encoder is differentiated through; weights are frozen => only dx):
 //   dz = dy * act'(z);  dxhat = dz * gamma;  dx = rstd * (dxhat - mean_g(dxhat) - xhat * mean_g(dxhat * xhat)).
-#include <algorithm>
-#include <cstdlib>
-#include <cstring>
-
 #include "dm_common.h"
 #include "dm_elem.h"
 
@@ -33,7 +29,6 @@ struct GnArgs {
     int B, HW, C, act, nblk;
     float eps;
     int rows_per_block;
-    int reverse;          // k_gn_stats walks images / row blocks backwards (DREAMMAT_GN_REVERSE=0 restores the ascending walk for A/B runs)
 };
 
 __device__ __forceinline__ float siluf(float z) { return z / (1.f + __expf(-z)); }
@@ -96,16 +91,10 @@ __global__ __launch_bounds__(64 * GN_COEF_SLICES) void k_gn_coef(GnArgs a) {
 template <int MODE>
 __global__ __launch_bounds__(256) void k_gn_stats(GnArgs a) {
     extern __shared__ float sh[];          // [row_par][2*C] per-thread partial sums (each slot written once)
-    // REVERSE traversal (round 5): workgroups are dispatched in ascending linear order, and the tensor this pass reads was just
-    // WRITTEN in ascending order by the kernel in front of it (a convolution, or its data gradient) -- on the 0.5 GB activations of
-    // the VAE encoder the 256 MB memory-side cache then still holds the END of the tensor.  Walking images and row blocks
-    // backwards reads that part first; the apply pass behind this one walks forwards and starts on what this pass read last.
-    // The partial of (image, block) lands in the same slot either way: results are bit-identical.
-    const int b = a.reverse ? a.B - 1 - (int)blockIdx.y : (int)blockIdx.y;
-    const int blk = a.reverse ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+    const int b = blockIdx.y;
     const int C = a.C, cpg = C / 32;
     const int chunks = C / 8;              // 16 B chunks per pixel row
-    const long long row0 = (long long)blk * a.rows_per_block;
+    const long long row0 = (long long)blockIdx.x * a.rows_per_block;
     const long long row1 = min((long long)a.HW, row0 + a.rows_per_block);
     const elem_t* __restrict__ xb = a.x + (long long)b * a.HW * C;
     const elem_t* __restrict__ dyb = MODE ? a.dy + (long long)b * a.HW * C : nullptr;
@@ -164,7 +153,7 @@ __global__ __launch_bounds__(256) void k_gn_stats(GnArgs a) {
     }
     __syncthreads();
     if (MODE == 2) {
-        float* out = a.cpart + ((long long)b * a.nblk + blk) * 2 * C;
+        float* out = a.cpart + ((long long)b * a.nblk + blockIdx.x) * 2 * C;
         for (int c = threadIdx.x; c < 2 * C; c += 256) {
             float t = 0.f;
             for (int rp = 0; rp < row_par; ++rp) t += sh[(long long)rp * 2 * C + c];
@@ -181,7 +170,7 @@ __global__ __launch_bounds__(256) void k_gn_stats(GnArgs a) {
             for (int c = 0; c < cpg; ++c) t += src[c];
         }
         float* out = MODE ? a.bpart : a.part;
-        out[((long long)b * a.nblk + blk) * 64 + g * 2 + which] = t;
+        out[((long long)b * a.nblk + blockIdx.x) * 64 + g * 2 + which] = t;
     }
 }
 
@@ -293,8 +282,6 @@ size_t stats_lds_bytes(int C) {
 }
 
 void bind_ws(GnArgs& a, float* ws, int B, int C) {
-    static const bool fwd_walk = getenv("DREAMMAT_GN_REVERSE") && !strcmp(getenv("DREAMMAT_GN_REVERSE"), "0");
-    a.reverse = fwd_walk ? 0 : 1;
     a.coef = ws;
     a.part = ws + (size_t)B * 7 * C;
     a.bpart = a.part + part_floats(B);
