@@ -375,13 +375,15 @@ def main():
     # the step's own features and once with per-pixel-random features -- at this point of training the field is nearly constant
     # (roughness 0.525 +- 3e-5, every pixel on one mip pair), which is the kernels' best case
     shade_replay = {}
-    if rank == 0 and not a.raytracing:
-        hipops.SHADE_KEEP["on"] = True
+    if not a.raytracing:
+        # (the extra step is COLLECTIVE -- every rank takes it, its all-reduce included; only the replay below is rank 0's alone
+        # and contains no collective: a rank-0-only step would leave the other ranks' all-reduce unmatched)
+        hipops.SHADE_KEEP["on"] = rank == 0
         trainer.train_one_step()
         sync()
         hipops.SHADE_KEEP["on"] = False
         kept, hipops.SHADE_KEEP["last"] = hipops.SHADE_KEEP["last"], None
-        if kept is not None and kept[0].shape[0] > 0:
+        if rank == 0 and kept is not None and kept[0].shape[0] > 0:
             feat0 = kept[0]
             gen = torch.Generator(device=dev).manual_seed(7)
             cases = {"step_features": feat0, "random_features": torch.randn(feat0.shape, device=dev, generator=gen)}
@@ -396,7 +398,7 @@ def main():
                 g = gs.t()                                   # the upstream gradient in the SoA form the scatter's backward hands over
                 for it in range(13):
                     if it == 3:
-                        sync()
+                        torch.cuda.synchronize()
                         hipops.enable_kernel_timing(True, only=("shade_fwd", "shade_bwd"))
                         # hold the stream while the host enqueues the ten iterations: the launches then run back to back and an
                         # event pair brackets its kernel only (an idle stream would add the host's launch latency to every pair)
@@ -404,7 +406,7 @@ def main():
                     col = hipops.shade(f, *kept[1:], want_debug=False)[0]
                     col.backward(g)
                     f.grad = None
-                sync()
+                torch.cuda.synchronize()
                 hipops.enable_kernel_timing(False)
                 shade_replay[nm] = hipops.kernel_times()
     # Second leg (1 GPU, default bf16 run only): the SAME step with the nets in IEEE half -- the reference's half_precision_weights
@@ -432,9 +434,10 @@ def main():
                        "final_loss": float(loss2.detach()), "nets": "the same step, UNet / ControlNet / VAE cast to float16 in place"}
         except Exception as e:      # reporting only: never allowed to kill the bench line
             f16_leg = {"value": None, "error": repr(e)}
-    if a.dump_shade and rank == 0:
-        hipops.SHADE_DUMP["path"] = a.dump_shade
-        trainer.train_one_step()
+    if a.dump_shade:
+        if rank == 0:
+            hipops.SHADE_DUMP["path"] = a.dump_shade
+        trainer.train_one_step()        # collective, like the replay's step above
         sync()
     if a.dump_kernels and rank == 0:
         with open(a.dump_kernels, "w") as fh:

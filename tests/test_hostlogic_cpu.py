@@ -690,3 +690,26 @@ def test_bank_cast_cache_matches_the_bank_by_identity_not_by_address():
     for _ in range(G.BANK_CAST_POOL):                      # overflow: casts, graphs and every projection derived from them go
         s._bank_cast(torch.zeros(2, 2))
     assert not s._graphs and "_kv_banks" not in s.attn.__dict__ and not s.unet.__dict__["_net_prologue"]._kv
+
+
+def test_bench_takes_no_collective_step_under_a_rank_test():
+    """bench.py at world > 1: a training step (flat all-reduce) or `sync()` (barrier) inside an `if ... rank == 0 ...` body is taken
+    by rank 0 alone and hangs the job -- the shade replay's extra step was written that way once."""
+    import ast
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tree = ast.parse(open(os.path.join(root, "bench.py")).read())
+
+    def names_rank(test):
+        return any(isinstance(n, ast.Name) and n.id == "rank" for n in ast.walk(test))
+
+    bad = []
+    for node in ast.walk(tree):
+        if isinstance(node, ast.If) and names_rank(node.test):
+            for stmt in node.body:
+                for c in ast.walk(stmt):
+                    if isinstance(c, ast.Call):
+                        f = c.func
+                        nm = f.attr if isinstance(f, ast.Attribute) else getattr(f, "id", "")
+                        if nm in ("train_one_step", "sync", "barrier", "all_reduce"):
+                            bad.append((node.lineno, nm))
+    assert not bad, bad
