@@ -297,15 +297,26 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # test tier only (tests/test_hip_gpu.py): DREAMMAT_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and DREAMMAT_BENCH_BACKEND=gloo
+    # carries the collectives, so the world-2 control flow of this file (who takes which step, who waits at which barrier) runs on
+    # a 1-GPU box.  RCCL refuses two ranks on one device; the driver's multi-GPU runs use neither switch.
+    share_gpu = os.environ.get("DREAMMAT_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("DREAMMAT_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share_gpu else local_rank
+    if share_gpu:
+        os.environ["LOCAL_RANK"] = "0"            # base.get_device() = cuda:{LOCAL_RANK}
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or bool(os.environ.get("DREAMMAT_FORCE_DIST"))   # FORCE_DIST: exercise RCCL at world 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert a.views % world == 0, "views must divide over ranks"
     vpr = a.views // world
 

@@ -598,6 +598,7 @@ def attention(q, k, vt, heads, scale=None):
 
 
 _FP8_WS = {}
+_FP8_WS_RETIRED = []
 
 
 def attention_fp8_ok(q, k, heads):
@@ -620,7 +621,9 @@ def attention_fp8(q, k, vt, heads, scale=None):
     if ws is None or ws.numel() < need:
         if torch.cuda.is_current_stream_capturing():
             raise _lib.DmError("attention_fp8: the 8-bit operand workspace must exist before a stream capture (run the shape eagerly once)")
-        ws = _FP8_WS[q.device] = torch.empty(need, device=q.device, dtype=torch.uint8)
+        if ws is not None:
+            _FP8_WS_RETIRED.append(ws)         # never freed: a captured hipGraph (guidance `hip_graph`) replays launches holding its address
+        ws = _FP8_WS[q.device] = torch.empty(max(need, 2 * (ws.numel() if ws is not None else 0)), device=q.device, dtype=torch.uint8)
     out = torch.empty(B, Sq, C, device=q.device, dtype=dt)
     sc = float(scale) if scale is not None else float(D) ** -0.5
     with _Timed(f"attention_fwd_fp8[Sq={Sq},Skv={Skv},h={heads},D={D}]", 4.0 * B * Sq * Skv * C):

@@ -1601,6 +1601,53 @@ def test_rccl_world1_step_through_bench(dev, sharded):
     assert "ProcessGroupNCCL" in r.stderr or "NCCL" in r.stderr.upper() or res["config"].get("process_group") == "nccl"
 
 
+_GLOO_CUDA_PROBE = """
+import sys, torch, torch.distributed as dist
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d", rank=0, world_size=1)
+t = torch.ones(8, device="cuda:0")
+dist.all_reduce(t); dist.broadcast(t, src=0)
+o = torch.empty(8, device="cuda:0"); dist.all_gather_into_tensor(o, t)
+dist.barrier(); torch.cuda.synchronize(); dist.destroy_process_group()
+print("gloo-cuda-ok")
+"""
+
+
+def test_bench_world2_control_flow_on_one_gpu(dev):
+    """bench.py exactly as the driver launches it at N = 2 (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus
+    2`), with both ranks on this box's one GPU and gloo carrying the collectives (DREAMMAT_BENCH_SHARE_GPU / _BACKEND: RCCL
+    refuses two ranks on a device).  What it pins is the file's CONTROL FLOW at world > 1: every training step and barrier is
+    taken by both ranks (round 5's shade replay once took a step on rank 0 alone -- the all-reduce of that step never returns),
+    rank 0 alone prints the line, the line says 2 GPUs and one view per rank."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def free_port():
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            return sk.getsockname()[1]
+
+    probe = subprocess.run([sys.executable, "-c", _GLOO_CUDA_PROBE % free_port()], capture_output=True, text=True, timeout=300)
+    if "gloo-cuda-ok" not in probe.stdout:
+        pytest.skip("this torch build's gloo does not carry device tensors: " + probe.stderr[-300:])
+    env = dict(os.environ, DREAMMAT_BENCH_SHARE_GPU="1", DREAMMAT_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "DREAMMAT_FORCE_DIST"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--views", "2", "--res", "64", "--sd", "tiny", "--mesh", "sphere:24:24", "--env-res", "32", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["value"] > 0 and res["scaling"] in ("weak", "strong")
+    assert res["config"]["process_group"] == "gloo" and "all-reduce" in res["config"]["parallelism"]
+    assert res["roofline_shade_fwd"]["replay_step_features"]["launches_timed"] > 0       # the replay ran (rank 0), after a step both ranks took
+
+
 def test_conv_and_gemm_chunk_batches_past_the_32bit_addressing_limit(dev, monkeypatch):
     """activations past 4 GB per tensor (cfg5: 16 views at 1024^2 through the VAE) run as image / row chunks of the same
     buffers; exercised here by lowering the limit instead of allocating 4 GB."""
