@@ -584,18 +584,35 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
                         __builtin_amdgcn_raw_buffer_store_b128(out, prs, (int)(poff[i] != OOB && n < a.Cout ? poff[i] * 2u + (unsigned)n * 4u : OOB), 0, 0);
                     }
         } else if constexpr (EPI == 1) {
-            // GEGLU: fragments (2jj, 2jj+1) = value / gate of output channels ob .. ob+31 (rows interleaved by the host)
+            // GEGLU: fragments (2jj, 2jj+1) = value / gate of output channels ob .. ob+31 (rows interleaved by the host).
+            // The gate function is the exact (erf) GELU evaluated as value * gate * Phi(gate) with
+            //   Phi(g) = g < 0 ? h : 1 - h,   h = erfc(|g| / sqrt 2) / 2 = poly5(t) 2^(-z^2),  t = 1 / (1 + p |z|),  z = g sqrt(log2(e) / 2)
+            // (Abramowitz-Stegun 7.1.26, coefficients halved; |error| of Phi < 3e-7, the negative tail without the cancellation
+            // of 1 + erf), two elements per instruction on the packed fp32 pipe: 23 VALU instructions per PAIR of outputs
+            // where 0.5 g (1 + erff(g / sqrt 2)) took ~44 per ELEMENT, divergent branches included.  At K = 320 this epilogue was
+            // 70 % of a tile (2834 VALU instructions per wave against 5 K-steps of 32 MFMAs; round 5).
             static_assert(EPI == 0 || NT % 2 == 0, "GEGLU needs value/gate fragment pairs");
+            const f32x2 kKz = {0.84932180028801905f, 0.84932180028801905f};          // sqrt(log2(e) / 2)
+            const f32x2 kKp = {0.27273748f, 0.27273748f};                              // 0.3275911 / sqrt(log2 e)
+            const f32x2 kA5 = {0.5307027145f, 0.5307027145f}, kA4 = {-0.7265760135f, -0.7265760135f},
+                        kA3 = {0.7107068705f, 0.7107068705f}, kA2 = {-0.142248368f, -0.142248368f}, kA1 = {0.127414796f, 0.127414796f};
+            const f32x2 kOne = {1.f, 1.f};
+            auto widen = [](const unsigned w) __attribute__((always_inline)) { return f32x2{dm_elem_lo(w), dm_elem_hi(w)}; };
+            auto round16 = [&](const f32x2 x) __attribute__((always_inline)) {     // through elem_t and back: the unfused Linear's output is a 16-bit tensor
+                return widen(__builtin_bit_cast(unsigned, __builtin_convertvector(x, elem2)));
+            };
 #pragma unroll
             for (int jj = 0; jj < NT / 2; ++jj) {
                 const int nb = n0 + TN * wn + 64 * jj;     // first (interleaved) weight row of the value fragment
                 const int ob = (n0 + TN * wn) / 2 + 32 * jj;
-                u32x2 bpv[4], bpg[4];
+                f32x2 bv[4][2], bg[4][2];                  // bias of this lane's 16 value / gate channels, widened once per fragment pair
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int n = nb + 8 * g + 4 * hi;
-                    bpv[g] = __builtin_amdgcn_raw_buffer_load_b64(brs, (int)(n < a.Cout ? (unsigned)n * 2u : OOB), 0, 0);
-                    bpg[g] = __builtin_amdgcn_raw_buffer_load_b64(brs, (int)(n + 32 < a.Cout ? (unsigned)(n + 32) * 2u : OOB), 0, 0);
+                    const u32x2 pv = __builtin_amdgcn_raw_buffer_load_b64(brs, (int)(n < a.Cout ? (unsigned)n * 2u : OOB), 0, 0);
+                    const u32x2 pg = __builtin_amdgcn_raw_buffer_load_b64(brs, (int)(n + 32 < a.Cout ? (unsigned)(n + 32) * 2u : OOB), 0, 0);
+                    bv[g][0] = widen(pv[0]); bv[g][1] = widen(pv[1]);
+                    bg[g][0] = widen(pg[0]); bg[g][1] = widen(pg[1]);
                 }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
@@ -605,21 +622,29 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
                             const int g = 2 * gp + q;
-                            float v[4], gt[4];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) { v[e] = acc[i][2 * jj][4 * g + e]; gt[e] = acc[i][2 * jj + 1][4 * g + e]; }
-                            unpack_add(v, bpv[g]);
-                            unpack_add(gt, bpg[g]);
-                            // the Linear output is a bf16 tensor in the unfused path: round value and gate before the gate function
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float vr = (float)(elem_t)v[e], gr = (float)(elem_t)gt[e];
-                                v[e] = vr * (0.5f * gr * (1.f + erff(gr * 0.70710678118654752f)));
+                            for (int h2 = 0; h2 < 2; ++h2) {
+                                // (element copies first: indexing an ext-vector element inside an initialiser list is fine, bit_cast is not)
+                                const float v0 = acc[i][2 * jj][4 * g + 2 * h2], v1 = acc[i][2 * jj][4 * g + 2 * h2 + 1];
+                                const float g0 = acc[i][2 * jj + 1][4 * g + 2 * h2], g1 = acc[i][2 * jj + 1][4 * g + 2 * h2 + 1];
+                                const f32x2 vr = round16(f32x2{v0, v1} + bv[g][h2]);
+                                const f32x2 gr = round16(f32x2{g0, g1} + bg[g][h2]);
+                                const f32x2 z = gr * kKz;
+                                const f32x2 zz = z * z;
+                                const f32x2 az = {__builtin_fabsf(z[0]), __builtin_fabsf(z[1])};
+                                const f32x2 d = __builtin_elementwise_fma(az, kKp, kOne);
+                                const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+                                const f32x2 e2 = {__builtin_amdgcn_exp2f(-zz[0]), __builtin_amdgcn_exp2f(-zz[1])};
+                                f32x2 pl = __builtin_elementwise_fma(t, kA5, kA4);
+                                pl = __builtin_elementwise_fma(pl, t, kA3);
+                                pl = __builtin_elementwise_fma(pl, t, kA2);
+                                pl = __builtin_elementwise_fma(pl, t, kA1);
+                                const f32x2 hh = pl * t * e2;              // erfc(|g| / sqrt 2) / 2
+                                const f32x2 uu = kOne - hh;
+                                const f32x2 phi = {gr[0] < 0.f ? hh[0] : uu[0], gr[1] < 0.f ? hh[1] : uu[1]};
+                                const f32x2 o = vr * gr * phi;
+                                w[q][h2] = __builtin_bit_cast(unsigned, __builtin_convertvector(o, elem2));
                             }
-                            f32x2 lo = {v[0], v[1]}, hi2 = {v[2], v[3]};
-                            elem2 plo = __builtin_convertvector(lo, elem2), phi = __builtin_convertvector(hi2, elem2);
-                            w[q][0] = __builtin_bit_cast(unsigned, plo);
-                            w[q][1] = __builtin_bit_cast(unsigned, phi);
                         }
                         const auto s0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);

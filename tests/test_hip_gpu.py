@@ -1477,6 +1477,32 @@ def test_gemm_geglu_epilogue_vs_unfused_pair(dev, monkeypatch, tile, M, K, inner
     assert err.mean().item() < 2e-3 * ref.abs().mean().item() + 1e-4, err.mean().item()
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_gemm_geglu_gate_function_on_exact_projections(dev, dtype):
+    """The GEGLU epilogue's gate function alone (round 5: Abramowitz-Stegun erfc on the packed fp32 pipe in place of erff): one-hot
+    rows of x make the projection EXACT (an entry of w), so the output differs from value * gelu(gate) evaluated in float64 by the
+    final 16-bit rounding only -- on gates from -12 to 12, the negative tail included (where 1 + erf cancels)."""
+    torch.manual_seed(61)
+    M, K, inner = 256, 64, 256
+    x = torch.zeros(M, K)
+    x[torch.arange(M), torch.arange(M) % K] = 1.0
+    wv = torch.randn(inner, K).to(dtype)
+    wg = (torch.rand(inner, K) * 24.0 - 12.0).to(dtype)
+    wg[0] = torch.linspace(-12.0, 12.0, K).to(dtype)
+    wg[1, :4] = torch.tensor([0.0, -0.0, 1e-3, -1e-3]).to(dtype)
+    w = torch.cat([wv, wg])
+    y = hipops.gemm_fused(x.to(dtype).to(dev), hipops.geglu_interleave(w).to(dev), None, None, geglu=True).double().cpu()
+    v = wv.double().t()[torch.arange(M) % K]              # [M, inner]: the exact projections
+    g = wg.double().t()[torch.arange(M) % K]
+    ref = v * 0.5 * g * (1.0 + torch.erf(g / 2.0 ** 0.5))
+    # final rounding (half an ulp: 2^-9 | 2^-12 relative) + the approximation (relative error < 2e-3 only where |gelu| < 1e-6,
+    # < 1e-4 above 1e-3; absolute < 5e-7 per unit of value) + half's subnormal spacing 2^-24
+    rel, floor = (2.0 ** -8, 2e-6) if dtype == torch.bfloat16 else (2.0 ** -10, 2e-7)
+    err = (y - ref).abs()
+    bound = rel * ref.abs() + floor * v.abs().clamp_min(1.0)
+    assert bool((err <= bound).all()), (err - bound).max().item()
+
+
 def test_transformer_block_fused_gemms_vs_aten(dev):
     """BasicTransformerBlock / Transformer2DModel with the Linear layers, their residual adds and GEGLU on the fused GEMM
     kernel vs the same module evaluated with ATen ops in fp32."""
