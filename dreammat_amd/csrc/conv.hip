@@ -588,7 +588,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
             // The gate function is the exact (erf) GELU evaluated as value * gate * Phi(gate) with
             //   Phi(g) = g < 0 ? h : 1 - h,   h = erfc(|g| / sqrt 2) / 2 = poly5(t) 2^(-z^2),  t = 1 / (1 + p |z|),  z = g sqrt(log2(e) / 2)
             // (Abramowitz-Stegun 7.1.26, coefficients halved; |error| of Phi < 3e-7, the negative tail without the cancellation
-            // of 1 + erf), two elements per instruction on the packed fp32 pipe: 23 VALU instructions per PAIR of outputs
+            // of 1 + erf), two elements per instruction on the packed fp32 pipe: 17 VALU instructions per PAIR of outputs
             // where 0.5 g (1 + erff(g / sqrt 2)) took ~44 per ELEMENT, divergent branches included.  At K = 320 this epilogue was
             // 70 % of a tile (2834 VALU instructions per wave against 5 K-steps of 32 MFMAs; round 5).
             static_assert(EPI == 0 || NT % 2 == 0, "GEGLU needs value/gate fragment pairs");
@@ -598,9 +598,6 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
                         kA3 = {0.7107068705f, 0.7107068705f}, kA2 = {-0.142248368f, -0.142248368f}, kA1 = {0.127414796f, 0.127414796f};
             const f32x2 kOne = {1.f, 1.f};
             auto widen = [](const unsigned w) __attribute__((always_inline)) { return f32x2{dm_elem_lo(w), dm_elem_hi(w)}; };
-            auto round16 = [&](const f32x2 x) __attribute__((always_inline)) {     // through elem_t and back: the unfused Linear's output is a 16-bit tensor
-                return widen(__builtin_bit_cast(unsigned, __builtin_convertvector(x, elem2)));
-            };
 #pragma unroll
             for (int jj = 0; jj < NT / 2; ++jj) {
                 const int nb = n0 + TN * wn + 64 * jj;     // first (interleaved) weight row of the value fragment
@@ -627,8 +624,10 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
                                 // (element copies first: indexing an ext-vector element inside an initialiser list is fine, bit_cast is not)
                                 const float v0 = acc[i][2 * jj][4 * g + 2 * h2], v1 = acc[i][2 * jj][4 * g + 2 * h2 + 1];
                                 const float g0 = acc[i][2 * jj + 1][4 * g + 2 * h2], g1 = acc[i][2 * jj + 1][4 * g + 2 * h2 + 1];
-                                const f32x2 vr = round16(f32x2{v0, v1} + bv[g][h2]);
-                                const f32x2 gr = round16(f32x2{g0, g1} + bg[g][h2]);
+                                // (rounds 2-4 rounded value and gate to 16 bits here, as the unfused Linear -> gelu -> mul sequence does
+                                // between its kernels: 6 of the 23 instructions per pair, for a result FARTHER from the fp32 one)
+                                const f32x2 vr = f32x2{v0, v1} + bv[g][h2];
+                                const f32x2 gr = f32x2{g0, g1} + bg[g][h2];
                                 const f32x2 z = gr * kKz;
                                 const f32x2 zz = z * z;
                                 const f32x2 az = {__builtin_fabsf(z[0]), __builtin_fabsf(z[1])};
