@@ -323,6 +323,14 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
             const int Y = Y0 + (row >> a.tw_log2);
             const int xo = X0 + (row & TWm);
             const bool ok = Y < rows_total && xo < a.Wout;
+            if constexpr (TAPS == 1) {
+                // the Linear layers (dm_gemm: one image, stride 1, no padding): row m = Y * Wout + xo of x, no window to clip.
+                // With K = 320 a tile is 5 K-steps and this set-up runs inside one of them: the general form below was 234 VALU
+                // instructions per crossing, 1600 of a tile's 27 000 cycles (DREAMMAT_CONV_TIMELINE=2, round 5)
+                a_off[i] = (((unsigned)Y * (unsigned)a.Wout + (unsigned)xo) * (unsigned)a.Cin + (unsigned)((lslot ^ ((row >> 1) & 7)) * 8)) * 2u;
+                a_mask[i] = ok ? 1u : 0u;
+                continue;
+            }
             const int Yc = ok ? Y : 0;
             int b = (int)((float)Yc * rcp_hout);
             int yo = Yc - b * a.Hout;
@@ -529,7 +537,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
         // version waited vmcnt(0) after each of its 8-byte loads: 12 exposed round trips per fragment, 15 us per tile,
         // the 0.25 ms of the 512^2 layers that did not scale with K in tools/conv_fit.sh), and each wave issues EXACTLY
         // NST stores per tile, which is what lets the next tile's first K-steps count them in s_waitcnt (see above).
-        const int img0 = Y0 / a.Hout;                  // image of the patch's first row (wave-uniform)
+        const int img0 = TAPS == 1 ? 0 : Y0 / a.Hout;  // image of the patch's first row (wave-uniform)
         const int rem0 = Y0 - img0 * a.Hout;
         unsigned poff[MT], rboff[MT];                  // byte offset of this lane's pixel in y / res, of its image's rowbias row
         int te_ = tid;                                 // (opaque copy: see setup_issue_tile)
@@ -543,6 +551,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
             const int xo = X0 + (d & TWm);
             const bool pix_ok = Y < rows_total && xo < a.Wout;
             poff[i] = pix_ok ? ((unsigned)Y * (unsigned)a.Wout + (unsigned)xo) * (unsigned)OC * 2u : OOB;   // m = (b*Hout + yo)*Wout + xo
+            if constexpr (TAPS == 1) { rboff[i] = 0; continue; }                              // (dm_gemm: no per-image bias row)
             int img = img0, t = rem0 + ty;
             while (t >= a.Hout) { t -= a.Hout; ++img; }                                       // a patch spans at most TH / Hout + 1 images
             rboff[i] = (unsigned)(min(img, a.B - 1) * a.Cout * 2);
@@ -810,6 +819,8 @@ int launch_conv_dma(const ConvArgs& a_in, hipStream_t stream) {
         attr_set = true;
     }
     ConvArgs a = a_in;
+    // the 1-tap instantiation is the Linear kernel of dm_gemm (its row set-up addresses x by the output row alone)
+    if (TAPS == 1 && (a.stride != 1 || a.pad_y != 0 || a.pad_x != 0 || a.Hin != a.Hout || a.Win != a.Wout || a.rowbias)) return DM_ERR_UNSUPPORTED;
     // patch width: 16 output pixels (or the next power of two >= Wout for narrower maps), height BMT / TW
     int tw_log2 = 4;
     while (tw_log2 > 0 && (1 << (tw_log2 - 1)) >= a.Wout) --tw_log2;
