@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 mkdir -p $R/gpurun_out
 : > $R/gpurun_out/ab_step.txt
-for pass in 1 2 3; do
+for pass in $(seq 1 ${AB_PASSES:-3}); do
   for which in old new; do
     if [ $which = old ]; then d=$R/_ab_old; extra=""; else d=$R; extra="${AB_NEW_ARGS:-}"; fi      # AB_NEW_ARGS: flags only the new tree knows
     (cd $d && timeout 200 python bench.py --steps 15 --warmup 3 --no-cpu-baseline $extra "$@" 2>/dev/null | tail -1 | python -c "
