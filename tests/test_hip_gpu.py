@@ -1537,7 +1537,7 @@ def test_transformer_block_fused_gemms_vs_aten(dev):
                                                   ("16", 3, 1280, 1280, 16, 16), ("0", 3, 1280, 1280, 8, 8)])
 def test_conv3x3_split_k_small_m(dev, monkeypatch, split, B, Cin, Cout, H, W):
     """Small-M layers (1 view per rank: batch 3 at 8x8 / 16x16) split the K loop over workgroups; fp32 partials + reduce
-    kernel must reproduce bias + rowbias + residual exactly like the single-pass epilogue."""
+    kernel must reproduce bias + rowbias + residual exactly like the single-pass epilogue, bit for bit the same launch after launch."""
     if split is not None:
         monkeypatch.setenv("DREAMMAT_CONV_SPLITK", split)
     torch.manual_seed(11)
@@ -1545,18 +1545,26 @@ def test_conv3x3_split_k_small_m(dev, monkeypatch, split, B, Cin, Cout, H, W):
     w = (torch.randn(Cout, Cin, 3, 3) * 0.03).bfloat16()
     bias, rowbias, res = torch.randn(Cout).bfloat16(), torch.randn(B, Cout).bfloat16(), torch.randn(B, H, W, Cout).bfloat16()
     wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
-    y = hipops.conv3x3_nhwc(x.to(dev), wt.to(dev), bias.to(dev), 1, (1, 1), None, rowbias.to(dev), res.to(dev)).float().cpu()
+    args = (x.to(dev), wt.to(dev), bias.to(dev), 1, (1, 1), None, rowbias.to(dev), res.to(dev))
+    y_dev = hipops.conv3x3_nhwc(*args)
+    y = y_dev.float().cpu()
     ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias.float(), padding=1).permute(0, 2, 3, 1)
     ref = ref + rowbias.float()[:, None, None, :] + res.float()
     err = (y - ref).abs().max().item()
     assert err < 1e-2 * ref.abs().max().item() + 1e-2, err
+    for _ in range(25):
+        assert torch.equal(hipops.conv3x3_nhwc(*args), y_dev)
     # the linear layers of the same resolution (1-tap instantiation)
     xm = torch.randn(B * H * W // 16 * 16, Cin).bfloat16()
     wm = (torch.randn(Cout, Cin) * 0.05).bfloat16()
     rm = torch.randn(xm.shape[0], Cout).bfloat16()
-    ym = hipops.gemm_fused(xm.to(dev), wm.to(dev), bias.to(dev), rm.to(dev)).float().cpu()
+    margs = (xm.to(dev), wm.to(dev), bias.to(dev), rm.to(dev))
+    ym_dev = hipops.gemm_fused(*margs)
+    ym = ym_dev.float().cpu()
     refm = xm.float() @ wm.float().t() + bias.float() + rm.float()
     assert (ym - refm).abs().max().item() < 1e-2 * refm.abs().max().item() + 1e-2
+    for _ in range(25):
+        assert torch.equal(hipops.gemm_fused(*margs), ym_dev)
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,stride,act", [(2, 22, 16, 40, 24, 1, 1), (1, 16, 16, 33, 17, 1, 1), (2, 16, 32, 32, 32, 2, 1),
