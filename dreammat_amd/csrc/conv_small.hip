@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_small(SmallConvArgs a) {
 #pragma unroll
     for (int c = 0; c < CO; ++c) {
         float z = acc[c];
-        if (a.act) z = z / (1.f + __expf(-z));
+        if (a.act) z = z * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));     // SiLU on v_exp / v_rcp (an IEEE division was 10 instructions)
         o[c] = (elem_t)z;
     }
     uint4* dst = reinterpret_cast<uint4*>(a.y + p * a.Cout + cog * CO);
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(SmallConvArgs a, int cin,
                     }
                     if (a.act) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.f + __expf(-v[e]));
+                        for (int e = 0; e < 4; ++e) v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v[e]));
                     }
                     if (ok) {
                         f32x2 lo = {v[0], v[1]}, hi2 = {v[2], v[3]};

@@ -69,6 +69,8 @@ TRAIN_KERNELS = True
 # V^T projections of the self-attention layers through the fused GEMM kernel with swapped operands (project_vt); tools may
 # assign False to time the hipBLASLt strided-batched product it replaces.
 VT_BY_FUSED_GEMM = True
+# q | k of the frozen self-attention layers from one GEMM (Attention._qk_fused_weight); tests assign False for the two-GEMM reference
+QK_FUSED = True
 # "fp8": the self-attention of the frozen nets (64-wide heads, S >= 1024) on the MX-FP8 matrix instruction (csrc/attn_fp8.hip) --
 # BASELINE configs[4] "fp8 MFMA attention"; guidance.attention_precision sets it.  "16bit" (default): the bf16 / f16 kernels.
 ATTENTION_PRECISION = "16bit"
@@ -415,12 +417,35 @@ class Attention(nn.Module):
         self.to_v = nn.Linear(cross_dim, query_dim, bias=bias)
         self.to_out = nn.ModuleList([nn.Linear(query_dim, query_dim), nn.Identity()])
 
+    def _qk_fused_weight(self, x):
+        """[Wq; Wk] for the fused projection of a frozen self-attention layer, or None when the two run on their own"""
+        wq, wk = self.to_q.weight, self.to_k.weight
+        C, K = wq.shape
+        if not (QK_FUSED and C % 128 == 0 and 2 * C % 256 == 0 and C >= 640 and wk.shape == wq.shape and self.to_q.bias is None
+                and self.to_k.bias is None and _rows_kernel_ok(x, wq, wk, self.to_v.weight) and wq.dtype == x.dtype and wk.dtype == x.dtype
+                and hipops.gemm_fused_ok(x.numel() // K, K, 2 * C)):
+            return None
+        key = (wq.data_ptr(), wq._version, wk.data_ptr(), wk._version, wq.dtype)
+        if self.__dict__.get("_wqk_key") != key:
+            self.__dict__["_wqk"] = torch.cat([wq.detach(), wk.detach()]).contiguous()
+            self.__dict__["_wqk_key"] = key
+        return self.__dict__["_wqk"]
+
     def forward(self, x, context=None, residual=None):
         """-> to_out(attention) (+ residual, added in the output projection's epilogue)."""
         if context is None:
             src, kv_len = x, x.shape[1]
         else:
             src, kv_len = context.t, context.len
+        wqk = self._qk_fused_weight(x) if context is None else None
+        if wqk is not None:
+            # self-attention, frozen: q | k from ONE GEMM (x is read once; tools/gemm_fit.sh: 2 x 40 -> 62 us at C = 640 and
+            # 2 x 33 -> 50 us at C = 1280 per layer; at C = 320 two single-tile N = 320 launches are the faster form, so not there).
+            # q and k are row-strided views of its output -- the attention kernels take strides.
+            C = self.to_q.weight.shape[0]
+            qk = hipops.gemm_fused(x.contiguous(), wqk, None, None)
+            return linear_fused(attention_core(qk[..., :C], qk[..., C:], self.to_v.weight, self.to_v.bias, src, self.heads, kv_len),
+                                self.to_out[0].weight, self.to_out[0].bias, residual)
         q = linear_fused(x, self.to_q.weight, self.to_q.bias)
         frozen = not (torch.is_grad_enabled() and (self.to_k.weight.requires_grad or self.to_v.weight.requires_grad))
         if (context is not None and context.bank is not None and frozen and x.is_cuda and x.dtype in HALF

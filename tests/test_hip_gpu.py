@@ -1504,6 +1504,35 @@ def test_gemm_geglu_gate_function_on_exact_projections(dev, dtype):
     assert bool((err <= bound).all()), (err - bound).max().item()
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C,heads,S", [(640, 10, 1024), (1280, 20, 256), (640, 10, 208)])
+def test_self_attention_fused_qk_projection_vs_two_gemms(dev, monkeypatch, dtype, C, heads, S):
+    """frozen self-attention at C >= 640: q | k from one GEMM over [Wq; Wk], handed to the attention kernels as row-strided views of
+    its [B, S, 2C] output -- against the same layer with the two projections run on their own (layers.QK_FUSED = False) and
+    against fp32."""
+    from dreammat_amd.sd import layers
+    torch.manual_seed(21)
+    att = layers.Attention(C, heads).to(dev)
+    for p_ in att.parameters():
+        p_.requires_grad_(False)
+    x = torch.randn(3, S, C, device=dev)
+    res = torch.randn(3, S, C, device=dev)
+    with torch.no_grad():
+        ref = att(x, None, res).float()
+        a16 = att.to(dtype)
+        hipops.enable_kernel_timing(True)
+        y = a16(x.to(dtype), None, res.to(dtype))
+        torch.cuda.synchronize()
+        keys = list(hipops.kernel_times())
+        hipops.enable_kernel_timing(False)
+        monkeypatch.setattr(layers, "QK_FUSED", False)
+        y2 = a16(x.to(dtype), None, res.to(dtype))
+    assert any(k.startswith(f"gemm[M={3 * S},K={C},N={2 * C}]") for k in keys), keys        # the fused projection ran
+    assert (y.float() - y2.float()).abs().max().item() <= 2.0 ** -7 * y2.float().abs().max().item()     # same sums, another tile order at most
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    assert (y.float() - ref).abs().max().item() < tol * ref.abs().max().item() + tol
+
+
 def test_transformer_block_fused_gemms_vs_aten(dev):
     """BasicTransformerBlock / Transformer2DModel with the Linear layers, their residual adds and GEGLU on the fused GEMM
     kernel vs the same module evaluated with ATen ops in fp32."""
