@@ -45,6 +45,10 @@ struct ConvArgs {
     int tiles_x;         // ceil(Wout / TW)
     int y_off;           // first row of the tall image this launch covers (0; > 0: the second launch of launch_320_balanced)
     long long mt_cap;    // at most this many M tiles from y_off on (0 = to the end)
+    // 2 x 2 instantiation with EPI = 2 only: store the four Cs-channel blocks of an output pixel as the four sub-pixels of a [B, 2H', 2W', Cs] tensor
+    // (0 = plain [B, Hout, Wout, Cout] rows).  1: block (py, px) of pixel (u, v) -> (2u + py, 2v + px), H' = Hout, W' = Wout (the stride-2
+    // data gradient).  2: -> (2u - py, 2v - px) where that is inside H' = Hout - 1, W' = Wout - 1 (upsample + conv on its (h+1) x (w+1) grid)
+    int shuf_mode, shuf_cs;
     unsigned long long* timeline;   // DREAMMAT_CONV_TIMELINE=1 (development): s_memtime stamps per tile, else null
     int timeline_steps;             // DREAMMAT_CONV_TIMELINE=2: stamp every K-step instead; 4: per-wave sums of body / waits / barrier
 };
@@ -197,6 +201,7 @@ __global__ __launch_bounds__(256) void k_conv3x3(ConvArgs a, long long n_mt, int
 // DATA GRADIENT (dm_conv2x2_nhwc_bf16 below).
 // TAPS = 9: 3x3 convolution.  TAPS = 1: the same machine as a plain GEMM y[M, N] = x[M, K] w[N, K]^T (the launcher presents
 // x as a [1, M/16, 16, K] image, no padding) -- the Linear / 1x1 layers of the UNet, with the same fused epilogues.
+// EPI = 2 (TAPS = 4 only): the plain epilogue with the sub-pixel store of ConvArgs::shuf_mode.
 // EPI = 1 (TAPS = 1 only): GEGLU epilogue.  The weight rows arrive interleaved in blocks of 32 (32 value rows, then their
 // 32 gate rows), so fragment pair (2jj, 2jj+1) of a wave holds value and gate of the same 32 output channels and the
 // epilogue writes value * gelu(gate) into y[M, N/2]: the 2x wide intermediate never reaches HBM.
@@ -540,6 +545,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
         const int img0 = TAPS == 1 ? 0 : Y0 / a.Hout;  // image of the patch's first row (wave-uniform)
         const int rem0 = Y0 - img0 * a.Hout;
         unsigned poff[MT], rboff[MT];                  // byte offset of this lane's pixel in y / res, of its image's rowbias row
+        // (EPI == 2, sub-pixel store) byte offset of sub-pixel (0, 0) of this lane's pixel in the 2x finer tensor, and which of its
+        // four sub-pixels exist there (bit 2 py + px)
+        [[maybe_unused]] unsigned s_base[MT], s_ok[MT];
         int te_ = tid;                                 // (opaque copy: see setup_issue_tile)
         asm volatile("" : "+v"(te_));
         const int l31 = te_ & 31, hi = (te_ >> 5) & 1, wm = (te_ >> 6) / WNW, wn = (te_ >> 6) % WNW;
@@ -555,6 +563,20 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
             int img = img0, t = rem0 + ty;
             while (t >= a.Hout) { t -= a.Hout; ++img; }                                       // a patch spans at most TH / Hout + 1 images
             rboff[i] = (unsigned)(min(img, a.B - 1) * a.Cout * 2);
+            if constexpr (EPI == 2) {
+                const bool up = a.shuf_mode == 2;
+                const int Wd = up ? 2 * (a.Wout - 1) : 2 * a.Wout;
+                const int row = 2 * Y - (up ? 2 * img : 0), col = 2 * xo;          // mode 2: image b starts at tall row 2 b (Hout - 1)
+                s_base[i] = ((unsigned)row * (unsigned)Wd + (unsigned)col) * (unsigned)a.shuf_cs * 2u;      // (mod 2^32 when a sub-pixel is missing)
+                unsigned okb = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int py = q >> 1, px = q & 1;
+                    const bool ok = !up || (t >= py && t - py < a.Hout - 1 && xo >= px && xo - px < a.Wout - 1);
+                    okb |= (pix_ok && ok ? 1u : 0u) << q;
+                }
+                s_ok[i] = okb;
+            }
         }
         auto unpack_add = [](float (&v)[4], const u32x2 p) __attribute__((always_inline)) {
             v[0] += dm_elem_lo(p[0]); v[1] += dm_elem_hi(p[0]);
@@ -600,7 +622,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
             // of 1 + erf), two elements per instruction on the packed fp32 pipe: 17 VALU instructions per PAIR of outputs
             // where 0.5 g (1 + erff(g / sqrt 2)) took ~44 per ELEMENT, divergent branches included.  At K = 320 this epilogue was
             // 70 % of a tile (2834 VALU instructions per wave against 5 K-steps of 32 MFMAs; round 5).
-            static_assert(EPI == 0 || NT % 2 == 0, "GEGLU needs value/gate fragment pairs");
+            static_assert(EPI != 1 || NT % 2 == 0, "GEGLU needs value/gate fragment pairs");
             const f32x2 kKz = {0.84932180028801905f, 0.84932180028801905f};          // sqrt(log2(e) / 2)
             const f32x2 kKp = {0.27273748f, 0.27273748f};                              // 0.3275911 / sqrt(log2 e)
             const f32x2 kA5 = {0.5307027145f, 0.5307027145f}, kA4 = {-0.7265760135f, -0.7265760135f},
@@ -717,8 +739,18 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
                     const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
                     const int c0 = nbase + 16 * gp + 8 * hi;   // this lane now owns channels c0 .. c0+7 of its pixel
                     const u32x4 out = {s0[0], s1[0], s0[1], s1[1]};
-                    __builtin_amdgcn_raw_buffer_store_b128(out, yrs, (int)(poff[i] != OOB && c0 < OC ? poff[i] + (unsigned)c0 * 2u : OOB),
-                                                           0, 0);
+                    unsigned off = poff[i] != OOB && c0 < OC ? poff[i] + (unsigned)c0 * 2u : OOB;
+                    if constexpr (EPI == 2) {
+                        // sub-pixel store.  Cs % 16 == 0: the 16 channels of this store pair lie inside ONE block, which block is
+                        // wave-uniform (scalar arithmetic); block 2 py + px of pixel (u, v) -> sub-pixel (2u +- py, 2v +- px)
+                        const int cs = a.shuf_cs, cb = nbase + 16 * gp;
+                        const int blk = (cb >= cs) + (cb >= 2 * cs) + (cb >= 3 * cs), py = blk >> 1, px = blk & 1;
+                        const bool up = a.shuf_mode == 2;
+                        const int Wd = up ? 2 * (a.Wout - 1) : 2 * a.Wout;
+                        const int delta = ((up ? -1 : 1) * (py * Wd + px) * cs + (cb - blk * cs)) * 2;
+                        off = ((s_ok[i] >> blk) & 1u) && c0 < OC ? s_base[i] + (unsigned)delta + 16u * (unsigned)hi : OOB;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(out, yrs, (int)off, 0, 0);
                 }
             }
         }
@@ -1062,18 +1094,37 @@ int DM_T(dm_conv3x3_nhwc_, )(const void* x, const void* w, const void* bias, voi
 // that fall on the same source pixel; evaluated with pad 1 on a (h + 1) x (w + 1) grid, parity (py, px) of output (u, v) is
 // channel block 2 py + px at grid position (u + py, v + px) (hipops.subpixel_upsample_weights / conv3x3_upsampled_nhwc).
 // bias [Cout] bf16 or NULL.
-int DM_T(dm_conv2x2_nhwc_, )(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin, int Hout, int Wout,
-                         int Cout, int pad_y, int pad_x, hipStream_t stream) {
+static int conv2x2_launch(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin, int Hout, int Wout,
+                          int Cout, int pad_y, int pad_x, int shuf_mode, hipStream_t stream) {
     if (!x || !w || !y || B <= 0 || Hin <= 0 || Win <= 0 || Hout <= 0 || Wout <= 0) return DM_ERR_ARG;
     if (Cin % 64 != 0 || Cout % 256 != 0) return DM_ERR_UNSUPPORTED;
     if ((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) || ((uintptr_t)bias & 7)) return DM_ERR_ARG;
+    if (shuf_mode < 0 || shuf_mode > 2 || (shuf_mode && (Cout / 4) % 16 != 0) || (shuf_mode == 2 && (Hout < 2 || Wout < 2))) return DM_ERR_ARG;
     ConvArgs a = {};
     a.x = (const elem_t*)x; a.w = (const elem_t*)w; a.bias = (const elem_t*)bias; a.y = (elem_t*)y;
     a.rowbias = nullptr; a.res = nullptr; a.timeline = nullptr; a.timeline_steps = 0;
     a.B = B; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Hout = Hout; a.Wout = Wout; a.Cout = Cout;
     a.stride = 1; a.pad_y = pad_y; a.pad_x = pad_x;
     a.M = (long long)B * Hout * Wout;
+    a.shuf_mode = shuf_mode; a.shuf_cs = Cout / 4;
+    if (shuf_mode) return launch_conv_dma<256, 256, 8, 2, 2, 4, 2>(a, stream);
     return launch_conv_dma<256, 256, 8, 2, 2, 4, 0>(a, stream);
+}
+
+int DM_T(dm_conv2x2_nhwc_, )(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin, int Hout, int Wout,
+                         int Cout, int pad_y, int pad_x, hipStream_t stream) {
+    return conv2x2_launch(x, w, bias, y, B, Hin, Win, Cin, Hout, Wout, Cout, pad_y, pad_x, 0, stream);
+}
+
+// The same products with the four Cout / 4-channel blocks of an output pixel stored as the four SUB-PIXELS of the 2x finer tensor the
+// two callers want (ABI v12; they used to interleave the blocks with a copy of the whole tensor: 0.48 ms of the step for the three
+// stride-2 data gradients of the VAE encoder).  mode 1: y is [B, 2 Hout, 2 Wout, Cout / 4], block 2 py + px of pixel (u, v) goes to
+// (2u + py, 2v + px) -- the data gradient of a stride-2 convolution.  mode 2: y is [B, 2 (Hout - 1), 2 (Wout - 1), Cout / 4], block
+// 2 py + px of grid position (u, v) goes to (2u - py, 2v - px) where that lies inside -- nearest-2x upsampling + 3x3 convolution.
+int DM_T(dm_conv2x2_subpixel_nhwc_, )(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin, int Hout,
+                                  int Wout, int Cout, int pad_y, int pad_x, int mode, hipStream_t stream) {
+    if (mode != 1 && mode != 2) return DM_ERR_ARG;
+    return conv2x2_launch(x, w, bias, y, B, Hin, Win, Cin, Hout, Wout, Cout, pad_y, pad_x, mode, stream);
 }
 
 // y[M, N] = x[M, K] w[N, K]^T + bias[N] (+ residual[M, N]); all bf16 row-major, fp32 accumulate, one rounding.

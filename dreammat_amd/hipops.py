@@ -859,24 +859,38 @@ def conv3x3_stem_autograd(x_nhwc, w4, w_dgrad4, bias):
     return _ConvStemS1.apply(x_nhwc, w4, w_dgrad4, bias)
 
 
-def conv2x2_nhwc(x_nhwc, w4, bias, out_hw, pad=(1, 1), label="conv2x2"):
+# the 2 x 2 kernel stores its four channel blocks as the sub-pixels of the finer tensor (round 5); tests assign False for the
+# interleaving-copy form it replaces
+SUBPIXEL_STORE = True
+
+
+def conv2x2_nhwc(x_nhwc, w4, bias, out_hw, pad=(1, 1), label="conv2x2", subpixel=0):
     """dm_conv2x2_nhwc_bf16: y[b, yo, xo, n] = sum over the 2 x 2 window from (yo - pad, xo - pad) of x . w4[n][2 dy + dx]; x [B,H,W,Cin],
     w4 [Cout, 4 * Cin], y [B, Ho, Wo, Cout] bf16.  Like conv3x3_nhwc, batches whose tensors pass the kernel's 32-bit byte offsets
-    run as consecutive image chunks."""
+    run as consecutive image chunks.
+    subpixel (dm_conv2x2_subpixel_nhwc_bf16): the four Cout / 4-channel blocks of a pixel are stored as the four sub-pixels of the 2x
+    finer tensor -- 1: [B, 2 Ho, 2 Wo, Cout / 4], block 2 py + px of (u, v) at (2u + py, 2v + px); 2: [B, 2 (Ho - 1), 2 (Wo - 1),
+    Cout / 4], block 2 py + px of grid position (u, v) at (2u - py, 2v - px) where that is inside."""
     _need_cuda(x_nhwc, w4, bias)
-    assert x_nhwc.is_contiguous() and w4.is_contiguous()
-    fn, name = _sym("dm_conv2x2_nhwc_bf16", _same_half(x_nhwc, w4, bias))
+    assert x_nhwc.is_contiguous() and w4.is_contiguous() and subpixel in (0, 1, 2)
+    fn, name = _sym("dm_conv2x2_subpixel_nhwc_bf16" if subpixel else "dm_conv2x2_nhwc_bf16", _same_half(x_nhwc, w4, bias))
     B, H, W, Cin = x_nhwc.shape
     Cout = w4.shape[0]
     Ho, Wo = out_hw
-    y = torch.empty(B, Ho, Wo, Cout, device=x_nhwc.device, dtype=x_nhwc.dtype)
+    if subpixel:
+        assert (Cout // 4) % 16 == 0
+        Hd, Wd = (2 * Ho, 2 * Wo) if subpixel == 1 else (2 * (Ho - 1), 2 * (Wo - 1))
+        y = torch.empty(B, Hd, Wd, Cout // 4, device=x_nhwc.device, dtype=x_nhwc.dtype)
+    else:
+        y = torch.empty(B, Ho, Wo, Cout, device=x_nhwc.device, dtype=x_nhwc.dtype)
     per_img = 2 * max(H * W * Cin, Ho * Wo * Cout)
     step = B if B * per_img <= CONV_MAX_TENSOR_BYTES else max(1, CONV_MAX_TENSOR_BYTES // per_img)
     for b0 in range(0, B, step):
         b1 = min(B, b0 + step)
         with _Timed(f"{label}[{Cin}->{Cout}@{Ho}x{Wo}]", 2.0 * (b1 - b0) * Ho * Wo * 4.0 * Cin * Cout):
-            check(fn(x_nhwc[b0:b1].data_ptr(), w4.data_ptr(), bias.data_ptr() if bias is not None else None,
-                     y[b0:b1].data_ptr(), b1 - b0, H, W, Cin, Ho, Wo, Cout, pad[0], pad[1], _stream()), name)
+            args = (x_nhwc[b0:b1].data_ptr(), w4.data_ptr(), bias.data_ptr() if bias is not None else None,
+                    y[b0:b1].data_ptr(), b1 - b0, H, W, Cin, Ho, Wo, Cout, pad[0], pad[1])
+            check(fn(*args, subpixel, _stream()) if subpixel else fn(*args, _stream()), name)
     return y
 
 
@@ -907,6 +921,9 @@ def conv3x3_upsampled_nhwc(x_nhwc, w4, b4):
     B, h, w, Cin = x_nhwc.shape
     C4 = w4.shape[0]
     Cout = C4 // 4
+    if SUBPIXEL_STORE and Cout % 16 == 0 and h >= 1 and w >= 1:
+        # the kernel stores parity (py, px) of grid position (u + py, v + px) at output pixel (2u + py, 2v + px) itself
+        return conv2x2_nhwc(x_nhwc, w4, b4, (h + 1, w + 1), (1, 1), "conv2x2_upsample", subpixel=2)
     y = conv2x2_nhwc(x_nhwc, w4, b4, (h + 1, w + 1), (1, 1), "conv2x2_upsample")
     out = torch.empty(B, h, 2, w, 2, Cout, device=x_nhwc.device, dtype=x_nhwc.dtype)
     for py in range(2):
@@ -954,6 +971,8 @@ class _Conv3x3S2(torch.autograd.Function):
         ws = ctx.w_sub                          # subpixel_dgrad_weights of the layer (the caller's cache, tied to the layer's lifetime)
         if (ws is not None and ctx.p == 0 and H == 2 * Ho and W == 2 * Wo and C % 64 == 0 and Cin % 64 == 0
                 and tuple(ws.shape) == (4 * Cin, 4 * C) and os.environ.get("DREAMMAT_S2_DGRAD", "subpixel") != "zeroins"):
+            if SUBPIXEL_STORE and Cin % 16 == 0:        # the four parities stored where they belong: dx itself, no interleaving copy
+                return conv2x2_nhwc(g.contiguous(), ws, None, (Ho, Wo), (1, 1), "conv2x2_dgrad", subpixel=1), None, None, None, None, None
             y = conv2x2_nhwc(g.contiguous(), ws, None, (Ho, Wo), (1, 1), "conv2x2_dgrad")
             dx = y.view(B, Ho, Wo, 2, 2, Cin).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, Cin)       # (u, py, v, px) -> (2u + py, 2v + px)
             return dx, None, None, None, None, None

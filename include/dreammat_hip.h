@@ -340,6 +340,15 @@ int dm_conv3x3_wgrad_nhwc_bf16(const void* x, const void* dy, float* part, int B
 int dm_conv2x2_nhwc_bf16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin, int Hout, int Wout,
                          int Cout, int pad_y, int pad_x, dm_stream_t stream);
 
+/* The same products (ABI v12) with the four Cout / 4-channel blocks of an output pixel stored as the four SUB-PIXELS of the 2x finer
+ * tensor both callers want, instead of as 4 Cs channels of one pixel (hipops interleaved the blocks with a copy of the whole tensor:
+ * 0.48 ms of the step for the three stride-2 data gradients of the VAE encoder, dreammat_guidance.py:284-292).  (Cout / 4) % 16 == 0.
+ *   mode 1: y [B, 2 Hout, 2 Wout, Cout / 4]; block 2 py + px of pixel (u, v) -> (2u + py, 2v + px): the data gradient of a stride-2 conv.
+ *   mode 2: y [B, 2 (Hout - 1), 2 (Wout - 1), Cout / 4]; block 2 py + px of grid position (u, v) -> (2u - py, 2v - px) where that lies
+ *           inside: nearest-2x upsampling + 3x3 convolution evaluated on its (h + 1) x (w + 1) grid (Hout = h + 1, Wout = w + 1). */
+int dm_conv2x2_subpixel_nhwc_bf16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin, int Hout,
+                                  int Wout, int Cout, int pad_y, int pad_x, int mode, dm_stream_t stream);
+
 /* The few-channel stem convolutions of the same nets (ControlNetConditioningEmbedding 22->16, 16->16, 16->32 s2, 32->32,
  * 32->96 s2; conv_in 4->320): direct form, one thread per output pixel x 16 output channels, no im2col.  Same tensor
  * layouts as dm_conv3x3_nhwc_bf16; Cin in {4, 8, 16, 22, 32}, Cout % 16 == 0; act = 1 applies the SiLU that follows these
@@ -432,6 +441,8 @@ int dm_conv3x3_nhwc_f16_fused(const void* x, const void* w, const void* bias, co
                                int pad_y, int pad_x, dm_stream_t stream);
 int dm_conv2x2_nhwc_f16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin, int Hout, int Wout,
                          int Cout, int pad_y, int pad_x, dm_stream_t stream);
+int dm_conv2x2_subpixel_nhwc_f16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin, int Hout,
+                                 int Wout, int Cout, int pad_y, int pad_x, int mode, dm_stream_t stream);
 int dm_conv3x3_small_nhwc_f16(const void* x, const void* w, const void* bias, void* y, int B, int Hin, int Win, int Cin,
                                int Hout, int Wout, int Cout, int stride, int pad_y, int pad_x, int act, dm_stream_t stream);
 int dm_conv3x3_small_res_nhwc_f16(const void* x, const void* w, const void* bias, const void* residual, int res_B, void* y, int B,

@@ -1219,6 +1219,34 @@ def test_upsample2d_subpixel_conv_vs_torch(dev, monkeypatch, B, C, h, w):
     assert (y - y_mat).abs().max() <= 2e-2 * ref.abs().max()
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,Cs,Cin,Ho,Wo", [(2, 64, 64, 8, 12), (1, 128, 128, 35, 19), (3, 320, 64, 16, 16), (2, 512, 64, 5, 7)])
+def test_conv2x2_subpixel_store_equals_interleaving_copy(dev, monkeypatch, dtype, B, Cs, Cin, Ho, Wo):
+    """dm_conv2x2_subpixel_nhwc (ABI v12): the four Cs-channel blocks of an output pixel stored as the four sub-pixels of the 2x finer
+    tensor -- mode 1 (stride-2 data gradient: block (py, px) of (u, v) -> (2u + py, 2v + px)) and mode 2 (upsample + conv on its
+    (h + 1) x (w + 1) grid: -> (2u - py, 2v - px) where inside) -- must be BIT-equal to the plain kernel followed by the interleaving
+    copy it replaces, ragged tiles, image boundaries and Cs = 320 (blocks that straddle the 256-wide N tiles) included."""
+    torch.manual_seed(5)
+    x = torch.randn(B, Ho, Wo, Cin).to(dtype).to(dev)
+    w4 = (torch.randn(4 * Cs, 4 * Cin) * 0.05).to(dtype).to(dev)
+    b4 = torch.randn(4 * Cs).to(dtype).to(dev)
+    y = hipops.conv2x2_nhwc(x, w4, b4, (Ho, Wo), (1, 1))
+    ref1 = y.view(B, Ho, Wo, 2, 2, Cs).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * Ho, 2 * Wo, Cs)
+    assert torch.equal(hipops.conv2x2_nhwc(x, w4, b4, (Ho, Wo), (1, 1), subpixel=1), ref1)
+    h, w = Ho - 1, Wo - 1                       # mode 2: the same grid read as the (h + 1) x (w + 1) grid of an h x w source
+    ref2 = torch.empty(B, h, 2, w, 2, Cs, device=dev, dtype=dtype)
+    for py in range(2):
+        for px in range(2):
+            blk = (2 * py + px) * Cs
+            ref2[:, :, py, :, px] = y[:, py:py + h, px:px + w, blk:blk + Cs]
+    out2 = hipops.conv2x2_nhwc(x, w4, b4, (Ho, Wo), (1, 1), subpixel=2)
+    assert torch.equal(out2, ref2.view(B, 2 * h, 2 * w, Cs))
+    if B > 1:                                   # image chunks (tensors past the 32-bit offsets)
+        monkeypatch.setattr(hipops, "CONV_MAX_TENSOR_BYTES", 2 * Ho * Wo * 4 * max(Cs, Cin) + 1)
+        assert torch.equal(hipops.conv2x2_nhwc(x, w4, b4, (Ho, Wo), (1, 1), subpixel=1), ref1)
+        assert torch.equal(hipops.conv2x2_nhwc(x, w4, b4, (Ho, Wo), (1, 1), subpixel=2), out2)
+
+
 def test_vae_encoder_bf16_gradient_vs_fp32_oracle(dev):
     """the differentiated bf16 VAE-encoder path (MFMA convs incl. data gradients, fused GroupNorm fwd/bwd,
     strided downsamplers) against the fp32 CPU functional oracle."""

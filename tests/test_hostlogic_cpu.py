@@ -626,7 +626,7 @@ def test_half_dtype_entry_points_resolve_to_exported_symbols():
     """hipops._sym: the IEEE-half instantiation of a net kernel carries f16 in place of bf16 (or an _f16 suffix where the bf16 name
     has no dtype token); every such name is exported by the library and declared with the bf16 entry point's signature."""
     from dreammat_amd import _lib, hipops
-    for name in ("dm_conv3x3_nhwc_bf16_fused", "dm_conv2x2_nhwc_bf16", "dm_conv3x3_small_res_nhwc_bf16", "dm_gemm_bf16_fused",
+    for name in ("dm_conv3x3_nhwc_bf16_fused", "dm_conv2x2_nhwc_bf16", "dm_conv2x2_subpixel_nhwc_bf16", "dm_conv3x3_small_res_nhwc_bf16", "dm_gemm_bf16_fused",
                  "dm_attention_fwd_bf16", "dm_layernorm_bf16", "dm_geglu_bf16", "dm_cat_add_bf16", "dm_softmax_rows_bf16",
                  "dm_softmax_rows_bwd_bf16", "dm_groupnorm_nhwc_fwd", "dm_groupnorm_nhwc_infer", "dm_groupnorm_nhwc_bwd_res"):
         fb, nb = hipops._sym(name, torch.bfloat16)
