@@ -1561,6 +1561,35 @@ def test_self_attention_fused_qk_projection_vs_two_gemms(dev, monkeypatch, dtype
     assert (y.float() - ref).abs().max().item() < tol * ref.abs().max().item() + tol
 
 
+@pytest.mark.parametrize("variant", ["auto", "w128", "w64", "v3l", "staged", "fp8"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_attention_kernels_take_row_strided_q_and_k(dev, variant, dtype):
+    """q and k as the two halves of ONE [B, S, 2C] tensor (the fused q | k projection: row stride 2C, k's base 2C bytes into a row)
+    give bit for bit the output of contiguous copies, in every kernel family and in the MX-FP8 kernel (its quantisation pre-passes
+    read through the same strides)."""
+    torch.manual_seed(33)
+    B, S, heads, D = 2, 1024, 10, 64
+    C = heads * D
+    qk = torch.randn(B, S, 2 * C, device=dev).to(dtype)
+    v = torch.randn(B, S, C, device=dev).to(dtype)
+    vt = v.transpose(1, 2).contiguous()
+    q, k = qk[..., :C], qk[..., C:]
+    fn = hipops.attention_fp8 if variant == "fp8" else hipops.attention
+    if variant not in ("auto", "fp8"):
+        hipops.attention_select(variant)
+    try:
+        y_strided = fn(q, k, vt, heads)
+        y_contig = fn(q.contiguous(), k.contiguous(), vt, heads)
+    finally:
+        hipops.attention_select(None)
+    assert torch.equal(y_strided, y_contig)
+    ref = torch.nn.functional.scaled_dot_product_attention(
+        q.float().view(B, S, heads, D).transpose(1, 2), k.float().view(B, S, heads, D).transpose(1, 2),
+        v.float().view(B, S, heads, D).transpose(1, 2)).transpose(1, 2).reshape(B, S, C)
+    tol = 0.12 if variant == "fp8" else (2e-2 if dtype == torch.bfloat16 else 4e-3)
+    assert (y_strided.float() - ref).abs().max().item() < tol * ref.abs().max().item() + tol * 0.1
+
+
 def test_transformer_block_fused_gemms_vs_aten(dev):
     """BasicTransformerBlock / Transformer2DModel with the Linear layers, their residual adds and GEGLU on the fused GEMM
     kernel vs the same module evaluated with ATen ops in fp32."""
