@@ -1129,7 +1129,9 @@ int DM_T(dm_conv2x2_subpixel_nhwc_, )(const void* x, const void* w, const void* 
 
 // y[M, N] = x[M, K] w[N, K]^T + bias[N] (+ residual[M, N]); all bf16 row-major, fp32 accumulate, one rounding.
 // geglu != 0: w / bias rows are interleaved in blocks of 32 (32 value rows, their 32 gate rows, ...) and
-// y[M, N/2] = value * gelu(gate) with value and gate rounded to bf16 first (what the unfused Linear -> GEGLU pair computes).
+// y[M, N/2] = value * gelu(gate), value and gate kept in fp32 up to the product (ONE rounding, round 5; the unfused Linear -> GEGLU pair
+// rounds both to 16 bits first) and gelu = the exact erf form evaluated as gate * Phi(gate) with Abramowitz-Stegun 7.1.26 for erfc
+// (|error of Phi| < 3e-7; see the EPI = 1 epilogue above).
 // Runs the 1-tap instantiation of the LDS-DMA convolution kernel above (M % 16 == 0, K % 64 == 0, N % 64 == 0; geglu: N % 128).
 int DM_T(dm_gemm_, _fused)(const void* x, const void* w, const void* bias, const void* residual, void* y, long long M, int K,
                        int N, int geglu, hipStream_t stream) {

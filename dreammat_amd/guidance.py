@@ -61,7 +61,9 @@ class StableDiffusionLightGuidance(BaseObject):
         grad_clip_val: Optional[float] = None
         grad_normalize: Optional[bool] = False
         # additions: compute dtype on the accelerator and the init seed used when no weights are on disk
-        weights_dtype: str = "bfloat16"      # "bfloat16" | "float16" (the reference's half_precision_weights) on the accelerator
+        # "float16" (default: what the reference's half_precision_weights means, dreammat_guidance.py:56, 92-94 -- noise
+        # prediction 1.3e-3 of fp32 at full size) | "bfloat16" (BASELINE configs[1]'s type: 1e-2 of fp32, ~3 % faster) on the accelerator
+        weights_dtype: str = "float16"
         # "16bit" | "fp8": the S >= 1024 self-attention of the frozen nets on the MX-FP8 matrix instruction (BASELINE configs[4])
         attention_precision: str = "16bit"
         synthetic_seed: int = 1234
@@ -86,8 +88,8 @@ class StableDiffusionLightGuidance(BaseObject):
             self.weights_dtype = torch.float32
         if self.cfg.attention_precision not in ("16bit", "fp8"):
             raise ValueError(f"guidance.attention_precision must be '16bit' or 'fp8', got '{self.cfg.attention_precision}'")
-        from .sd import layers as _layers
-        _layers.ATTENTION_PRECISION = self.cfg.attention_precision if on_gpu and self.cfg.half_precision_weights else "16bit"
+        # carried by the Attention modules of THIS guidance's nets (set below), not by a process-global
+        self.attention_precision = self.cfg.attention_precision if on_gpu and self.cfg.half_precision_weights else "16bit"
         arch = arch_for(self.cfg.pretrained_model_name_or_path)
         self.arch = arch
         root = self._model_root()
@@ -134,6 +136,9 @@ class StableDiffusionLightGuidance(BaseObject):
                 p.requires_grad_(False)
             if self.cfg.enable_channels_last_format:
                 m.to(memory_format=torch.channels_last)
+        from .sd import layers as _layers
+        for m in [self.unet] + self.controlnets:
+            _layers.set_attention_precision(m, self.attention_precision)
         self.scheduler = DDIMScheduler()
         self.num_train_timesteps = self.scheduler.num_train_timesteps
         self.set_min_max_steps()
@@ -258,9 +263,7 @@ class StableDiffusionLightGuidance(BaseObject):
             if hasattr(self, "_graphs"):
                 self._graphs.clear()
             self._drop_bank_projections()
-        cast = bank.to(self.weights_dtype)
-        if cast is bank:                       # (already in the nets' dtype: .to() returns the tensor itself)
-            cast = bank
+        cast = bank.to(self.weights_dtype)     # (already in the nets' dtype: .to() returns the tensor itself)
         casts.append((bank, bank._version, self.weights_dtype, cast))
         return cast
 

@@ -609,7 +609,11 @@ def attention_fp8_ok(q, k, heads):
 
 def attention_fp8(q, k, vt, heads, scale=None):
     """attention() with both matrix products on the MX-FP8 matrix instruction (csrc/attn_fp8.hip: BASELINE configs[4]); the same
-    16-bit tensors in and out, the 8-bit operands live in a per-device scratch buffer (stream order, grow-only)."""
+    16-bit tensors in and out, the 8-bit operands live in a per-device scratch buffer (stream order, grow-only).
+    SINGLE-STREAM ASSUMPTION: the scratch buffer is shared by every call on the device and baked into captured
+    graphs; two calls are ordered only by the stream they run on.  The nets of this repo run on one stream (the capture of
+    guidance.hip_graph replays on that same stream; its warm-up side stream is joined before the capture starts), so nothing
+    overlaps; a caller that runs fp8 attention on two streams at once must serialise them with events itself."""
     _need_cuda(q, k, vt)
     dt = _same_half(q, k, vt)
     assert attention_fp8_ok(q, k, heads) and q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1

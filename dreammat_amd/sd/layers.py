@@ -72,7 +72,10 @@ VT_BY_FUSED_GEMM = True
 # q | k of the frozen self-attention layers from one GEMM (Attention._qk_fused_weight); tests assign False for the two-GEMM reference
 QK_FUSED = True
 # "fp8": the self-attention of the frozen nets (64-wide heads, S >= 1024) on the MX-FP8 matrix instruction (csrc/attn_fp8.hip) --
-# BASELINE configs[4] "fp8 MFMA attention"; guidance.attention_precision sets it.  "16bit" (default): the bf16 / f16 kernels.
+# BASELINE configs[4] "fp8 MFMA attention".  "16bit" (default): the bf16 / f16 kernels.  The setting is carried by every
+# Attention MODULE (`attention_precision`, set on a guidance's own nets by set_attention_precision below -- two guidance objects
+# in one process do not switch each other); this module attribute is only the default of modules nobody configured
+# (tests assign it).
 ATTENTION_PRECISION = "16bit"
 FP8_MIN_SEQ = 1024
 
@@ -378,7 +381,16 @@ def project_vt(v_weight, v_bias, kv_src, kv_len):
     return vt
 
 
-def attention_core(q, k, v_weight, v_bias, kv_src, heads, kv_len):
+def set_attention_precision(net, precision):
+    """guidance.attention_precision -> the Attention modules of ONE net (a captured hipGraph keeps what its net had at capture)."""
+    if precision not in ("16bit", "fp8"):
+        raise ValueError(f"attention precision must be '16bit' or 'fp8', got '{precision}'")
+    for m in net.modules():
+        if isinstance(m, Attention):
+            m.attention_precision = precision
+
+
+def attention_core(q, k, v_weight, v_bias, kv_src, heads, kv_len, precision=None):
     """softmax(QK^T/sqrt(d)) V with V = kv_src @ v_weight^T (+bias).  q [B,Sq,C], k [B,Skv,C].
     CUDA+bf16 -> MFMA kernels (inference: V produced directly transposed by the projection GEMM; under autograd:
     hipops.attention_train, whose backward recomputes the probabilities); otherwise plain fp32-style math."""
@@ -388,7 +400,7 @@ def attention_core(q, k, v_weight, v_bias, kv_src, heads, kv_len):
                                               or v_weight.requires_grad)
     if q.is_cuda and q.dtype in HALF and not needs_grad:     # inference: V arrives transposed from its projection
         vt = project_vt(v_weight, v_bias, kv_src, kv_len)
-        if (ATTENTION_PRECISION == "fp8" and kv_len == k.shape[1] and kv_len >= FP8_MIN_SEQ and Sq >= FP8_MIN_SEQ
+        if ((precision or ATTENTION_PRECISION) == "fp8" and kv_len == k.shape[1] and kv_len >= FP8_MIN_SEQ and Sq >= FP8_MIN_SEQ
                 and hipops.attention_fp8_ok(q, k, heads)):
             return hipops.attention_fp8(q, k, vt, heads)
         return hipops.attention(q, k[:, :kv_len], vt, heads)
@@ -444,7 +456,8 @@ class Attention(nn.Module):
             # q and k are row-strided views of its output -- the attention kernels take strides.
             C = self.to_q.weight.shape[0]
             qk = hipops.gemm_fused(x.contiguous(), wqk, None, None)
-            return linear_fused(attention_core(qk[..., :C], qk[..., C:], self.to_v.weight, self.to_v.bias, src, self.heads, kv_len),
+            return linear_fused(attention_core(qk[..., :C], qk[..., C:], self.to_v.weight, self.to_v.bias, src, self.heads, kv_len,
+                                               getattr(self, "attention_precision", None)),
                                 self.to_out[0].weight, self.to_out[0].bias, residual)
         q = linear_fused(x, self.to_q.weight, self.to_q.bias)
         frozen = not (torch.is_grad_enabled() and (self.to_k.weight.requires_grad or self.to_v.weight.requires_grad))
@@ -473,7 +486,7 @@ class Attention(nn.Module):
                 o = hipops.attention(q, kb.index_select(0, context.ids)[:, :kv_len], vtb.index_select(0, context.ids), self.heads)
         else:
             k = linear_fused(src, self.to_k.weight, self.to_k.bias)
-            o = attention_core(q, k, self.to_v.weight, self.to_v.bias, src, self.heads, kv_len)
+            o = attention_core(q, k, self.to_v.weight, self.to_v.bias, src, self.heads, kv_len, getattr(self, "attention_precision", None))
         return linear_fused(o, self.to_out[0].weight, self.to_out[0].bias, residual)
 
 

@@ -367,8 +367,9 @@ int dm_conv3x3_small_res_nhwc_bf16(const void* x, const void* w, const void* bia
  * models/guidance/dreammat_guidance.py:205-292) on the 1-tap instantiation of the same kernel:
  * y[M,N] = x[M,K] w[N,K]^T + bias[N] (+ residual[M,N]), bf16 row-major, fp32 accumulate, rounded once.
  * geglu != 0 fuses diffusers' GEGLU (`hidden, gate = proj(x).chunk(2); hidden * gelu(gate)`): w and bias rows interleaved in
- * blocks of 32 (32 value rows, then their 32 gate rows), y is [M, N/2]; value and gate are rounded to bf16 before the gate
- * function, as the unfused pair does.  M % 16 == 0, K % 64 == 0, N % 64 == 0 (geglu: N % 128 == 0, no residual). */
+ * blocks of 32 (32 value rows, then their 32 gate rows), y is [M, N/2]; value and gate stay in fp32 up to the product (one
+ * rounding -- the unfused pair rounds both to 16 bits first) and gelu is the exact erf form, evaluated as gate * Phi(gate) with
+ * an erfc polynomial (Abramowitz-Stegun 7.1.26, |error of Phi| < 3e-7).  M % 16 == 0, K % 64 == 0, N % 64 == 0 (geglu: N % 128 == 0, no residual). */
 int dm_gemm_bf16_fused(const void* x, const void* w, const void* bias, const void* residual, void* y, long long M, int K,
                        int N, int geglu, dm_stream_t stream);
 

@@ -370,8 +370,9 @@ def test_fp8_attention_running_maximum_and_wide_magnitudes(dev):
 
 
 def test_fp8_attention_through_the_guidance_switch(dev):
-    """layers.ATTENTION_PRECISION = "fp8" (guidance.attention_precision) routes the S >= 1024 self-attention of a Transformer
-    block to the fp8 kernel and nothing else (cross-attention, short sequences)."""
+    """layers.set_attention_precision(net, "fp8") (what guidance.attention_precision does to ITS nets) routes the S >= 1024
+    self-attention of a Transformer block to the fp8 kernel and nothing else (cross-attention, short sequences); a second
+    block in the same process keeps its own setting (the switch used to be a module global)."""
     from dreammat_amd.sd import layers
     torch.manual_seed(0)
     blk = layers.BasicTransformerBlock(320, 5, 1024).to(dev, torch.float16).eval()
@@ -381,15 +382,18 @@ def test_fp8_attention_through_the_guidance_switch(dev):
     ctx = layers.PaddedContext(torch.randn(2, 77, 1024, device=dev, dtype=torch.float16))
     with torch.no_grad():
         y16 = blk(x, ctx)
-        layers.ATTENTION_PRECISION = "fp8"
+        import copy
+        other = copy.deepcopy(blk)                    # a second net of the process: stays on the 16-bit kernels
+        layers.set_attention_precision(blk, "fp8")
         try:
             hipops.enable_kernel_timing(True)
             y8 = blk(x, ctx)
             torch.cuda.synchronize()
             kt = hipops.kernel_times()
             hipops.enable_kernel_timing(False)
+            assert torch.equal(other(x, ctx), y16)
         finally:
-            layers.ATTENTION_PRECISION = "16bit"
+            layers.set_attention_precision(blk, "16bit")
     assert sum(v["launches"] for k, v in kt.items() if k.startswith("attention_fwd_fp8")) == 1
     assert sum(v["launches"] for k, v in kt.items() if k.startswith("attention_fwd_bf16")) == 1       # (the timing key of the 16-bit kernels)
     assert ((y8.float() - y16.float()).norm() / y16.float().norm()).item() < 5e-2
