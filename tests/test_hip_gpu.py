@@ -1716,8 +1716,11 @@ def test_rccl_world1_step_through_bench(dev, sharded):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 1 and res["value"] > 0
-    # the line's second leg (round 5): the same step with the nets cast to IEEE half in place (here: under the captured hipGraph path)
-    assert res.get("f16_leg", {}).get("value") and res["f16_leg"]["final_loss"] == res["f16_leg"]["final_loss"], res.get("f16_leg")
+    # the line's second leg: the same step with the nets cast in place to the other 16-bit type (round 6: the main line runs IEEE half, the
+    # reference's type, the leg bf16; here under the captured hipGraph path), and the box calibration beside them
+    assert res["dtype"] == "f16"
+    assert res.get("bf16_leg", {}).get("value") and res["bf16_leg"]["final_loss"] == res["bf16_leg"]["final_loss"], res.get("bf16_leg")
+    assert res["box_calibration"]["gemm_bf16_8192_tflops"] > 100 and res["box_calibration"]["copy_1gb_tbps"] > 1, res["box_calibration"]
     assert ("reduce-scatter" if sharded else "all-reduce") in res["config"]["parallelism"]
     assert "ProcessGroupNCCL" in r.stderr or "NCCL" in r.stderr.upper() or res["config"].get("process_group") == "nccl"
 
