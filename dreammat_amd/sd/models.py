@@ -301,11 +301,19 @@ class VaeAttention(nn.Module):
             # autograd, the softmax between them on the row kernels
             layers.note_fallback("vae_attention", f"C={C} S={H * W} autograd: 4 projections + QK^T + PV")
         q, k, v = self.to_q(h), self.to_k(h), self.to_v(h)
-        s = torch.matmul(q, k.transpose(1, 2))
-        if hipops.softmax_rows_ok(s) and layers.CONV_BACKEND == "mfma":
-            p = hipops.softmax_rows(s, C ** -0.5)       # scale, fp32 softmax and the rounding in one pass (and one pass back)
+        if q.dtype == torch.float16:
+            # IEEE half: the UNSCALED q.k of 512 channels (22.6x the scaled logits) can pass 65504 -> inf -> NaN in the stored
+            # score matrix; the scale is applied inside the product, in fp32, before the rounding (what diffusers'
+            # attention does), and the row kernel gets scale 1
+            s = torch.baddbmm(q.new_empty(B, H * W, H * W), q, k.transpose(1, 2), beta=0.0, alpha=C ** -0.5)
+            s_scale = 1.0
         else:
-            p = torch.softmax((s * (C ** -0.5)).float(), dim=-1).to(q.dtype)
+            s = torch.matmul(q, k.transpose(1, 2))
+            s_scale = C ** -0.5
+        if hipops.softmax_rows_ok(s) and layers.CONV_BACKEND == "mfma":
+            p = hipops.softmax_rows(s, s_scale)         # scale, fp32 softmax and the rounding in one pass (and one pass back)
+        else:
+            p = torch.softmax((s * s_scale).float(), dim=-1).to(q.dtype)
         o = self.to_out[0](torch.matmul(p, v))
         return o.reshape(B, H, W, C).permute(0, 3, 1, 2) + x
 

@@ -369,6 +369,37 @@ def test_fp8_attention_running_maximum_and_wide_magnitudes(dev):
     assert (out[0, 99] - 100.0).abs().max() < 7.0          # row 99 is its spiked key's value row (e4m3: 100 -> 96 or 104)
 
 
+def test_f16_vae_attention_large_logits_stay_finite(dev):
+    """the VAE mid-block attention (1 head of 512) stored the UNSCALED q.k in 16 bits; with q, k of magnitude ~16 the
+    unscaled product of 512 channels passes half's 65504 (inf -> NaN through the softmax) although the scaled logits are modest.
+    The scale now enters inside the product: forward and gradient stay finite and match fp32 math on the same half inputs."""
+    from dreammat_amd.sd.models import VaeAttention
+    torch.manual_seed(3)
+    C, Hh = 512, 16
+    att = VaeAttention(C).to(dev, H16).eval()
+    with torch.no_grad():
+        for lin in (att.to_q, att.to_k):          # projections that keep the magnitude of their (normalised) input, times 16
+            lin.weight.copy_(torch.eye(C) * 16.0); lin.bias.zero_()
+    for p in att.parameters():
+        p.requires_grad_(False)
+    x = torch.randn(1, C, Hh, Hh, device=dev).to(H16).requires_grad_()
+    y = att(x)
+    y.float().sum().backward()
+    assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
+    # (unscaled, row maxima of q.k sit near 16 * 16 * 512 = 131072 > 65504)
+    att32 = VaeAttention(C).to(dev).eval()
+    att32.load_state_dict({k: v.float() for k, v in att.state_dict().items()})
+    x32 = x.detach().float().requires_grad_()
+    from dreammat_amd.sd import layers
+    old = layers.CONV_BACKEND
+    try:
+        layers.CONV_BACKEND = "aten"
+        y32 = att32(x32)
+    finally:
+        layers.CONV_BACKEND = old
+    assert ((y.float() - y32).abs().max() / y32.abs().max()).item() < 2e-2
+
+
 def test_fp8_attention_through_the_guidance_switch(dev):
     """layers.set_attention_precision(net, "fp8") (what guidance.attention_precision does to ITS nets) routes the S >= 1024
     self-attention of a Transformer block to the fp8 kernel and nothing else (cross-attention, short sequences); a second
