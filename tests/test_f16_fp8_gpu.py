@@ -393,7 +393,7 @@ def test_f16_vae_attention_large_logits_stay_finite(dev):
     from dreammat_amd.sd import layers
     old = layers.CONV_BACKEND
     try:
-        layers.CONV_BACKEND = "aten"
+        layers.CONV_BACKEND = "gemm"
         y32 = att32(x32)
     finally:
         layers.CONV_BACKEND = old
