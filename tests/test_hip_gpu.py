@@ -2463,6 +2463,55 @@ def test_cfg5_mesh_1024_render_vs_oracle(dev, envs):
                    "mask_off_companion": companion}, fh)
 
 
+def test_full_size_sd15_unet_controlnet_eps_vs_oracle(dev):
+    """The SD-1.5 shape set north_star names (8 heads of 40 / 80 / 160 / 160, 768-wide context, conv projections; the reference's
+    fallback control types name sd15 ControlNets, dreammat_guidance.py:103-106) at full size, one branch item: fp32 on the GPU within
+    1e-3 of the CPU oracle, the IEEE-half production path (staged MFMA attention at D = 40 / 80 / 160, conv / GroupNorm kernels)
+    within half's rounding class -- VERDICT r5 row N3 / next #10."""
+    from dreammat_amd.sd import ARCHS, ControlNetModel, UNet2DConditionModel
+    from dreammat_amd.sd import layers
+    from oracle import sd_nets as osd
+    a = ARCHS["sd15"]
+    torch.manual_seed(0)
+    with torch.device(dev):
+        unet = UNet2DConditionModel(a).eval()
+        cn = ControlNetModel.from_unet(unet).eval()
+    for conv in list(cn.controlnet_down_blocks) + [cn.controlnet_mid_block, cn.controlnet_cond_embedding.conv_out]:
+        torch.nn.init.normal_(conv.weight, std=0.02)
+    for p in list(unet.parameters()) + list(cn.parameters()):
+        p.requires_grad_(False)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 4, 64, 64, generator=g); t = torch.tensor([437])
+    ctx = torch.randn(1, 77, a.cross_dim, generator=g); cond = torch.rand(1, 22, 512, 512, generator=g)
+    with torch.no_grad():
+        d, m = cn(x.to(dev), t.to(dev), ctx.to(dev), cond.to(dev), 1.0)
+        y = unet(x.to(dev), t.to(dev), ctx.to(dev), d, m).cpu()
+        sd_u = {k: v.float().cpu() for k, v in unet.state_dict().items()}
+        sd_c = {k: v.float().cpu() for k, v in cn.state_dict().items()}
+        od, om = osd.controlnet_forward(sd_c, x, t, ctx, cond, 1.0, a.heads, a.use_linear_projection)
+        oy = osd.unet_forward(sd_u, x, t, ctx, a.heads, a.use_linear_projection, od, om)
+        del sd_u, sd_c
+        rel32 = ((y - oy).abs().max() / oy.abs().max()).item()
+        assert rel32 <= 1e-3, rel32
+        layers.fallbacks(clear=True)
+        unet.half(); cn.half()
+        hipops.enable_kernel_timing(True, only=("attention",))
+        d, m = cn(x.to(dev).half(), t.to(dev), ctx.to(dev).half(), cond.to(dev).half(), 1.0)
+        yh = unet(x.to(dev).half(), t.to(dev), ctx.to(dev).half(), d, m).float().cpu()
+        torch.cuda.synchronize()
+        kt = hipops.kernel_times()
+        hipops.enable_kernel_timing(False)
+        left = layers.fallbacks()
+    assert sum(v["launches"] for k, v in kt.items() if k.startswith("attention")) == 46
+    assert not left, left
+    relh = ((yh - oy).abs().max() / oy.abs().max()).item()
+    relh_mean = ((yh - oy).abs().mean() / oy.abs().mean()).item()
+    with open(os.path.join(OUT, "full_size_eps_parity_sd15.json"), "w") as fh:
+        json.dump({"arch": "sd15", "fp32_rel_max": rel32, "f16_rel_max": relh, "f16_rel_mean": relh_mean,
+                   "eps_abs_max": float(oy.abs().max())}, fh)
+    assert torch.isfinite(yh).all() and relh < 4e-3 and relh_mean < 3e-3, (relh, relh_mean)
+
+
 def test_full_size_sd21_unet_controlnet_eps_vs_oracle(dev):
     """One branch-item of the guidance's frozen stack at the bench's real shapes (SD-2.1-base UNet 865.9 M parameters + the
     22-channel ControlNet, 64^2 latents, S = 4096 self-attention, 512^2 condition maps; seeded random weights -- no
@@ -2512,6 +2561,20 @@ def test_full_size_sd21_unet_controlnet_eps_vs_oracle(dev):
         d, m = cn(x.to(dev).half(), t.to(dev), ctx.to(dev).half(), cond.to(dev).half(), 1.0)
         yh = unet(x.to(dev).half(), t.to(dev), ctx.to(dev).half(), d, m).float().cpu()
         left = layers.fallbacks()
+        # f16 nets + MX-FP8 self-attention (guidance.attention_precision: fp8, BASELINE configs[4]; VERDICT r5 missing #6: what the
+        # switch does to the noise prediction at full size, not to one block) -- the S >= 1024 self-attention layers of both nets
+        layers.set_attention_precision(unet, "fp8"); layers.set_attention_precision(cn, "fp8")
+        hipops.enable_kernel_timing(True, only=("attention",))
+        d, m = cn(x.to(dev).half(), t.to(dev), ctx.to(dev).half(), cond.to(dev).half(), 1.0)
+        y8 = unet(x.to(dev).half(), t.to(dev), ctx.to(dev).half(), d, m).float().cpu()
+        torch.cuda.synchronize()
+        kt8 = hipops.kernel_times()
+        hipops.enable_kernel_timing(False)
+        layers.set_attention_precision(unet, "16bit"); layers.set_attention_precision(cn, "16bit")
+    n_fp8 = sum(v["launches"] for k, v in kt8.items() if k.startswith("attention_fwd_fp8"))
+    assert n_fp8 == 14, kt8.keys()              # the S = 4096 and S = 1024 self-attention layers: 5 + 5 in the UNet, 2 + 2 in the ControlNet
+    rel8 = ((y8 - oy).abs().max() / oy.abs().max()).item()
+    rel8_mean = ((y8 - oy).abs().mean() / oy.abs().mean()).item()
     assert sum(v["launches"] for k, v in kt.items() if k.startswith("attention")) == 46
     assert any(k.startswith("conv3x3") for k in kt)
     assert not left and not left_bf16, (left_bf16, left)   # no layer of the frozen nets left the hand-written kernels, in either type
@@ -2521,8 +2584,12 @@ def test_full_size_sd21_unet_controlnet_eps_vs_oracle(dev):
     relh_mean = ((yh - oy).abs().mean() / oy.abs().mean()).item()
     with open(os.path.join(OUT, "full_size_eps_parity.json"), "w") as fh:
         json.dump({"fp32_rel_max": rel32, "bf16_rel_max": rel16, "bf16_rel_mean": rel16_mean, "f16_rel_max": relh,
-                   "f16_rel_mean": relh_mean, "eps_abs_max": float(oy.abs().max())}, fh)
+                   "f16_rel_mean": relh_mean, "f16+fp8attn_rel_max": rel8, "f16+fp8attn_rel_mean": rel8_mean,
+                   "fp8_attention_layers": n_fp8, "eps_abs_max": float(oy.abs().max())}, fh)
     assert rel16 < 2e-2 and rel16_mean < 2e-2, (rel16, rel16_mean)     # measured 1.0-1.2e-2 / 0.9e-2 (rounds 2, 3)
     # measured (round 5): 1.27e-3 max / 1.15e-3 mean -- an eighth of bf16's error at every module of the stack
     # (tools/f16_error_profile.py); the first measurement read 5.4e-3 because this test had handed the f16 leg bf16-rounded weights
     assert torch.isfinite(yh).all() and relh < 2.5e-3 and relh_mean < 2e-3 and relh_mean < 0.25 * rel16_mean, (relh, relh_mean)
+    # fp8 attention (e4m3 operands: 3 mantissa bits on Q, K, P, V of 14 layers): reported, gated loosely -- an experimental precision
+    # class, far outside north_star's 1e-3
+    assert torch.isfinite(y8).all() and rel8 < 0.2 and rel8_mean < 0.1, (rel8, rel8_mean)
