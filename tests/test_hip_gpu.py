@@ -865,7 +865,7 @@ def test_noise_prediction_hip_graph_replay_equals_eager(dev, tmp_path, monkeypat
     torch.manual_seed(0)
     ge = StableDiffusionLightGuidance(dict(cfg, hip_graph=False))      # both: the same seeded synthetic weights, on the GPU
     gg = StableDiffusionLightGuidance(dict(cfg, hip_graph=True))
-    assert next(ge.unet.parameters()).is_cuda and next(ge.unet.parameters()).dtype == torch.bfloat16
+    assert next(ge.unet.parameters()).is_cuda and next(ge.unet.parameters()).dtype == torch.float16      # (the default: the reference's half_precision_weights type)
     pp = StableDiffusionPromptProcessor({"prompt": "a wooden chair", "negative_prompt": "ugly",
                                          "pretrained_model_name_or_path": "tiny"})
     B = 2
