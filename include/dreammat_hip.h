@@ -141,7 +141,9 @@ int dm_hashgrid2d_bwd(const float* x, long long x_rs, long long x_cs, const int3
 /* The feature network behind the encoding (dreammat_mesh.py:246-254 -> networks.py:150-187, VanillaMLP: bias-free
  * Linear(n_in, 64) -> ReLU -> Linear(64, n_out), fp32), fused: x [n_in][M] and y / dx likewise by feature stride (points
  * contiguous: the layout dm_hashgrid_fwd writes), w1 [64][n_in], w2 [n_out][64]; n_in = 16 | 32, n_out <= 8.  bwd writes dx
- * and ADDS into dw1 / dw2 (float atomics, one set per wave); dy[m * dy_rs + k * dy_cs]. */
+ * and ADDS into dw1 / dw2 (float atomics, one set per workgroup); dy[m * dy_rs + k * dy_cs].  The backward runs its five
+ * products on the bf16 matrix pipe with SPLIT operands (a = hi + lo, 16 significant bits, three MFMAs per product; 24 bits / six
+ * MFMAs for the pre-activation whose sign gates the ReLU): results within 1e-5 of fp32 math (csrc/field_mlp.hip, round 6). */
 int dm_field_mlp_fwd(const float* x, long long x_fs, long long M, const float* w1, const float* w2, int n_in, int n_out, float* y,
                      long long y_fs, dm_stream_t stream);
 int dm_field_mlp_bwd(const float* x, long long x_fs, long long M, const float* w1, const float* w2, int n_in, int n_out,
