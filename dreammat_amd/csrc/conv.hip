@@ -243,7 +243,10 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     const int xend = min(xbeg + per_xcd, total);
     const int first = xbeg + (int)(blockIdx.x >> 3);
     if (first >= xend) return;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    // (the wave index as an SGPR value: every LDS-DMA piece needs its wave's LDS base in M0, and with `wave` derived from the
+    // thread id in a VGPR each piece paid a v_add + v_readfirstlane + s_mov m0 chain with its wait states; now one s_add into m0
+    // -- round 6: +2-5 % on the 320-wide tiles, +1-2 % on the Linear shapes, nothing lost elsewhere)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
     const int wm = wave / WNW, wn = wave % WNW;
     // M tile = patch of TW x TH output pixels: rows Y0.. of the tall image [B*Hout, Wout], columns X0..
     // (tile row r -> pixel (Y0 + r / TW, X0 + r % TW)).  A 1-D run of BMT pixels re-reads 3 full image rows per
@@ -262,6 +265,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
         const unsigned nt = uid - mt * (unsigned)n_nt;
         const unsigned tile_y = mt / (unsigned)a.tiles_x;
         Y0 = a.y_off + (int)(tile_y * (unsigned)(BMT >> a.tw_log2));
+#if defined(DM_ABL_L2HOT)
+        if (TAPS == 9) Y0 = Y0 & 63;                    // ABLATION (wrong results): every tile reads (and writes) the first 64 rows: operands L2-resident
+#endif
         X0 = (int)((mt - tile_y * (unsigned)a.tiles_x) << a.tw_log2);
         n0 = (int)nt * BN;
     };
@@ -384,6 +390,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     };
     // DMA piece p of the step at the cursor (p < A_INSTR: 8 activation rows, else 8 weight rows) into `stage`
     auto piece = [&](int p, int stage) __attribute__((always_inline)) {
+#if defined(DM_ABL_NODMA)
+        return;                                         // ABLATION (wrong results): no operand traffic at all
+#endif
         char* ab = smem + stage * STAGE;
         if (p < A_INSTR) {
             // select, never a branch: the DMA must execute with ALL lanes active (an inactive lane would
@@ -425,7 +434,11 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     // one chunk earlier -- so LDS latency and the DMA issue time (60-180 cycles per 1 KB piece) sit under MFMA
     // execution instead of in front of it (the first version issued all pieces, then read, then multiplied:
     // SQ_WAIT_ANY 39 %, MFMA busy 29 %, profiles/r01_pmc_conv_v0.json).
+    [[maybe_unused]] bool abl_read = true;
     auto read_frags = [&](int stage, int kk, elem8 (&af)[MT], elem8 (&bf)[NT]) {
+#if defined(DM_ABL_NOLDS)
+        if (!abl_read) { asm volatile("" : "+v"(af[0]), "+v"(bf[0])); return; }       // ABLATION (wrong results): fragments read in a tile's first K-step only
+#endif
         const char* ab = smem + stage * STAGE;
         const char* bb = ab + A_BYTES;
 #pragma unroll
@@ -511,6 +524,10 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
             if (tl4) { t_a = __builtin_amdgcn_s_memtime(); tl_sum[0] += t_a - tl_prev; }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (tl4) { t_b = __builtin_amdgcn_s_memtime(); tl_sum[1] += t_b - t_a; }
+#if defined(DM_ABL_NOWAIT)
+            if (false) {}                               // ABLATION (wrong results): DMA issued, never waited for
+            else
+#endif
             if (s - s_lo < NSTAGE - 1 && ct != first && !(SPLIT_OK && ksplit > 1)) {
                 if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L + NST) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
@@ -519,14 +536,18 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             if (tl4) { t_c = __builtin_amdgcn_s_memtime(); tl_sum[2] += t_c - t_b; }
-            __builtin_amdgcn_s_barrier();
+#if !defined(DM_ABL_NOBAR)
+            __builtin_amdgcn_s_barrier();               // (ABLATION DM_ABL_NOBAR, wrong results: no workgroup barrier in the K loop)
+#endif
             if (tl4) { tl_prev = __builtin_amdgcn_s_memtime(); tl_sum[3] += tl_prev - t_c; ++tl_sum[4]; }
             if (a.timeline_steps == 2) stamp();
             --n_ahead;
             int st2 = stage + NSTAGE - 1; if (st2 >= NSTAGE) st2 -= NSTAGE;
             kstep(stage, st2, s > s_lo);
             stage = stage + 1; if (stage >= NSTAGE) stage = 0;
+            abl_read = false;
         }
+        abl_read = true;
         if (PEND) mma(a1, b1);                         // the last step's last chunk
         stamp();
 
