@@ -219,8 +219,13 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     constexpr int TM = BMT / WMW, TN = BN / WNW;       // wave tile
     [[maybe_unused]] constexpr int MT = TM / 32, NT = TN / 32;     // 32x32 accumulator fragments per wave
     [[maybe_unused]] constexpr int A_BYTES = BMT * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
-    constexpr int A_INSTR = BMT / 8 / NW;              // wave-instructions (8 rows each) per wave
-    constexpr int B_INSTR = BN / 8 / NW;
+#if defined(DM_ASYM_DMA)
+    constexpr int NWL = NW == 8 ? 4 : NW;              // EXPERIMENT: loader waves (the first wave of each SIMD pair requests for both)
+#else
+    constexpr int NWL = NW;
+#endif
+    constexpr int A_INSTR = BMT / 8 / NWL;             // wave-instructions (8 rows each) per loader wave
+    constexpr int B_INSTR = BN / 8 / NWL;
     [[maybe_unused]] constexpr int L = A_INSTR + B_INSTR;    // DMA instructions per wave per tile
     static_assert(TM % 32 == 0 && TN % 32 == 0 && BMT % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile shape");
     static_assert(NSTAGE == 2 || NSTAGE == 3, "ring depth");
@@ -330,7 +335,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
         const int wave = t_ >> 6, lrow = (t_ & 63) >> 3, lslot = t_ & 7;
 #pragma unroll
         for (int i = 0; i < A_INSTR; ++i) {
-            const int row = wave * (BMT / NW) + 8 * i + lrow;
+            const int row = wave * (BMT / NWL) + 8 * i + lrow;
             const int Y = Y0 + (row >> a.tw_log2);
             const int xo = X0 + (row & TWm);
             const bool ok = Y < rows_total && xo < a.Wout;
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
         // only reach accumulator rows the epilogue never stores
 #pragma unroll
         for (int i = 0; i < B_INSTR; ++i) {
-            const int row = wave * (BN / NW) + 8 * i + lrow;
+            const int row = wave * (BN / NWL) + 8 * i + lrow;
             const int rc = min(n0 + row, a.Cout - 1);
             b_off[i] = ((unsigned)rc * (unsigned)TAPS * (unsigned)a.Cin + (unsigned)((lslot ^ ((row >> 1) & 7)) * 8)) * 2u;
         }
@@ -392,6 +397,13 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     auto piece = [&](int p, int stage) __attribute__((always_inline)) {
 #if defined(DM_ABL_NODMA)
         return;                                         // ABLATION (wrong results): no operand traffic at all
+#endif
+        if (NWL != NW && wave >= NWL) return;           // (asymmetric DMA: this wave requests nothing)
+#if defined(DM_ABL_NOA)
+        if (p < A_INSTR) return;                        // ABLATION (wrong results): weights only
+#endif
+#if defined(DM_ABL_NOB)
+        if (p >= A_INSTR) return;                       // ABLATION (wrong results): activations only
 #endif
         char* ab = smem + stage * STAGE;
         if (p < A_INSTR) {
@@ -529,10 +541,10 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
             else
 #endif
             if (s - s_lo < NSTAGE - 1 && ct != first && !(SPLIT_OK && ksplit > 1)) {
-                if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L + NST) : "memory");
+                if (two && (NWL == NW || wave < NWL)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L + NST) : "memory");
                 else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
             } else {
-                if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+                if (two && (NWL == NW || wave < NWL)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
             if (tl4) { t_c = __builtin_amdgcn_s_memtime(); tl_sum[2] += t_c - t_b; }
@@ -782,6 +794,326 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     if (a.timeline && a.timeline_steps == 4 && lane == 0)      // every wave's sums: slots 8 + 5 * wave ..
         for (int i = 0; i < 5; ++i) a.timeline[(long long)blockIdx.x * 64 + 8 + 5 * wave + i] = tl_sum[i];
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// Variant 3 (round 6): HALO PATCH.  The ablation builds of round 6 (profiles/r06_conv_ablation.md) say what the K loop of the
+// kernel above loses its time to: not waiting for its operands (+0-1.5 % with the waits removed) but REQUESTING them -- every
+// `buffer_load_dwordx4 ... lds` holds its SIMD for the better part of 100 cycles, 8-10 of them per wave and 64-wide K-step beside
+// 32 MFMAs, +17-33 % with none of them, and roughly linear in their number (weights only: +12-24 %, activations only: +6-7 %).
+// A 3 x 3 convolution requests every activation row NINE times (once per tap).  Here a workgroup owns a TW x TH patch of output
+// pixels of ONE image and keeps the (TH + 2) x (TW + 2)-pixel input patch of a 64-channel block in LDS: it is requested ONCE per
+// channel block (its pieces spread over the nine K-steps of the block BEFORE, into the other of two buffers) and read at nine
+// shifted offsets; only the weights still arrive per K-step.  Requests per MFMA: 512 x 128 tile 1.25 -> 384 x 128 patch 0.47;
+// 256 x 256 tile 1.0 -> 256 x 256 patch 0.57.
+//  * patch pixel p = prow * (TW + 2) + pcol lives at p * 128 B, its 16-byte chunks XOR-swizzled by (pcol >> 1) & 7: the 16 lanes
+//    of a ds_read_b128 group are 16 consecutive columns (whatever the tap's shift), pcol & 1 picks the bank half (the row
+//    pitch of 18 pixels is even) and (pcol >> 1) & 7 the 16-byte group -> conflict-free for all nine taps;
+//  * K order: channel block outer, then tap COLUMN dx, then tap row dy: a lane's MT x 4 fragment addresses are recomputed when
+//    dx changes (three times per block), dy is an immediate offset.  (The kernel above runs dy-major: same sums, fp32 additions
+//    in another order -- the two kernels agree to the last bf16 rounding, not bit for bit.)
+//  * out-of-image patch pixels (the zero padding, and rows / columns past a ragged last band) are buffer offsets beyond
+//    num_records, as above; a patch never straddles two images (bands are per image, the last one ragged).
+//  * stride 1, pad 1, 3 x 3 only; no split-K (large-M layers only); epilogue = the plain one of the kernel above.
+template <int TH, int BN, int WMW, int NB>
+__global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs a, int tiles_x, int tiles_y, int n_nt) {
+    constexpr int NW = 8, TW = 16, BMT = TW * TH, PW = TW + 2, PH = TH + 2, NPIX = PW * PH;
+    constexpr int PA = (NPIX + 7) / 8;                      // 1 KB pieces (8 pixels x 128 B) of a patch
+    constexpr int A_BYTES = PA * 1024, B_BYTES = BN * 128;
+    [[maybe_unused]] constexpr int WNW = NW / WMW, TM = BMT / WMW, TN = BN / WNW, MT = TM / 32, NT = TN / 32;
+    [[maybe_unused]] constexpr int B_INSTR = BN / 8 / NW;   // weight pieces per wave and K-step
+    static_assert(TM % 32 == 0 && TN % 32 == 0 && BN % (8 * NW) == 0, "tile shape");
+    static_assert((PA + NW - 1) / NW <= 9, "a wave requests at most one patch piece per tap");
+    static_assert(NB == 2 || NB == 3, "weight ring depth");
+    static_assert(2 * A_BYTES + NB * B_BYTES <= 160 * 1024, "LDS budget");
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // patch 0 | patch 1 | NB weight stages
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int total = (int)(a.B * tiles_y * tiles_x) * n_nt;
+    const int per_xcd = (total + 7) / 8;
+    const int wpx = (int)(gridDim.x >> 3);
+    const int xbeg = (int)(blockIdx.x & 7) * per_xcd;
+    const int xend = min(xbeg + per_xcd, total);
+    const int first = xbeg + (int)(blockIdx.x >> 3);
+    if (first >= xend) return;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+    const int wm = wave / WNW, wn = wave % WNW;
+    const int H = a.Hout, W = a.Wout, Cin = a.Cin;
+    const int n_kc = Cin / 64;
+    constexpr unsigned OOB = 0xfffffff0u;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(unsigned)((long long)a.B * H * W * Cin * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (int)(unsigned)((long long)a.Cout * 9 * Cin * 2), 0x00020000);
+    const unsigned y_bytes = (unsigned)(a.M * a.Cout * 2);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, 0, (int)y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.res, 0, a.res ? (int)y_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)a.bias, 0, a.bias ? a.Cout * 2 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.rowbias, 0, a.rowbias ? a.B * a.Cout * 2 : 0, 0x00020000);
+    constexpr int NST = MT * NT * 2;                        // 16-byte stores per wave and tile
+
+    // work item id -> image, first row / column of the patch's interior, first output channel (wave-uniform)
+    auto coords = [&](int id, int& b, int& Y0, int& X0, int& n0) __attribute__((always_inline)) {
+        const unsigned uid = (unsigned)id;
+        const unsigned mt = uid / (unsigned)n_nt;
+        n0 = (int)(uid - mt * (unsigned)n_nt) * BN;
+        const unsigned row = mt / (unsigned)tiles_x;
+        X0 = (int)(mt - row * (unsigned)tiles_x) * TW;
+        const unsigned bb = row / (unsigned)tiles_y;
+        Y0 = (int)(row - bb * (unsigned)tiles_y) * TH;
+        b = (int)bb;
+    };
+    [[maybe_unused]] int sidx_abl = 0;                      // (ablation builds: 0 during the prologue, then 1)
+    // patch piece j of this wave (piece index wave + 8 j), channel block kc of the patch at (image b, rows from Y0, columns from X0), into `buf`
+    auto issue_a = [&](int b, int Y0, int X0, int kc, int j, char* buf) __attribute__((always_inline)) {
+        const int i = wave + NW * j;
+        if (i >= PA) return;
+#if defined(DM_ABL_NOA) || defined(DM_ABL_NODMA)
+        if (sidx_abl > 0) return;                           // ABLATION (wrong results)
+#endif
+        // (the lane's pixel of the piece from an opaque copy of the thread id: left visible, the nine pieces' row / column pairs are
+        // hoisted out of the K loop and spilled -- a scratch reload, i.e. one more vector-memory request, per step)
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));
+        const int p = 8 * i + ((t_ & 63) >> 3);
+        const int prow = p / PW, pcol = p - prow * PW;
+        const int y = Y0 + prow - 1, x = X0 + pcol - 1;
+        const bool ok = p < NPIX && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        // all lanes execute the request (an inactive lane would leave its LDS slot stale); out-of-image = zeros through the range check
+        const unsigned off = ok ? ((((unsigned)b * (unsigned)H + (unsigned)y) * (unsigned)W + (unsigned)x) * (unsigned)Cin + (unsigned)(kc * 64) +
+                                   (unsigned)(((t_ & 7) ^ ((pcol >> 1) & 7)) * 8)) * 2u : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(buf + i * 1024), 16, (int)off, 0, 0, 0);
+    };
+    // weight piece q of this wave for (first output channel n0, channel block kc, tap) into stage `st`
+    auto issue_b = [&](int n0, int kc, int tap, int q, char* st) __attribute__((always_inline)) {
+#if defined(DM_ABL_NOB) || defined(DM_ABL_NODMA)
+        if (sidx_abl > 0) return;                           // ABLATION (wrong results)
+#endif
+        const int row = wave * (BN / NW) + 8 * q + (lane >> 3);
+        const int rc = min(n0 + row, a.Cout - 1);           // rows past Cout re-read the last one (never stored)
+        const unsigned off = ((unsigned)rc * 9u * (unsigned)Cin + (unsigned)(((lane & 7) ^ ((row >> 1) & 7)) * 8)) * 2u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(st + (wave * (BN / NW) + 8 * q) * 128), 16,
+                                                 (int)off, (tap * Cin + kc * 64) * 2, 0, 0);
+    };
+    char* const bst0 = smem + 2 * A_BYTES;              // patch buffer k at smem + k * A_BYTES
+
+    f32x16 acc[MT][NT];
+    elem8 a0[MT], b0[NT], a1[MT], b1[NT];
+    // this lane's rows of the tile: r = TM wm + 32 i + l31 -> (ty, tx) = (r >> 4, r & 15)
+    int a4[MT][4];                                          // LDS byte offsets of the fragment reads at (dy = 0, current dx, current patch buffer)
+    auto set_a4 = [&](int dx, int buf_off) __attribute__((always_inline)) {
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));                        // (opaque copy: keeps the lane constants out of the K loop's live set)
+        const int l31_ = t_ & 31, hi_ = (t_ >> 5) & 1;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int r = TM * wm + 32 * i + l31_;
+            const int ty = r >> 4, c = (r & 15) + dx;
+            const int base = buf_off + (ty * PW + c) * 128;
+            const int sw = (c >> 1) & 7;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) a4[i][kk] = base + (((2 * kk + hi_) ^ sw) << 4);
+        }
+    };
+    auto read_frags = [&](int dy, int kk, const char* bb, elem8 (&af)[MT], elem8 (&bf)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const elem8*>(smem + a4[i][kk] + dy * PW * 128);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int r = TN * wn + 32 * j + l31;
+            bf[j] = *reinterpret_cast<const elem8*>(bb + r * 128 + (((2 * kk + hi) ^ ((r >> 1) & 7)) << 4));
+        }
+    };
+    auto mma = [&](const elem8 (&af)[MT], const elem8 (&bf)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = DM_MFMA_32x32x16(bf[j], af[i], acc[i][j]);
+    };
+
+    // ---- prologue: the first block's patch and the first step's weights
+    {
+        int b_, Y_, X_, n_;
+        coords(first, b_, Y_, X_, n_);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) issue_a(b_, Y_, X_, 0, j, smem);
+#pragma unroll
+        for (int q = 0; q < B_INSTR; ++q) issue_b(n_, 0, 0, q, bst0);
+    }
+    sidx_abl = 1;
+    int sidx = 0;                                           // K-steps taken so far (weight stage = sidx % NB)
+    int blk = 0;                                            // channel blocks taken so far (patch buffer = blk & 1)
+    bool after_epilogue = false;
+    for (int ct = first; ct < xend; ct += wpx) {
+        int cb, Y0, X0, n0;
+        coords(ct, cb, Y0, X0, n0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        bool pending = false;
+        for (int kc = 0; kc < n_kc; ++kc, ++blk) {
+            // the block after this one (its patch is requested during this block's nine steps), if any
+            const bool last_kc = kc + 1 == n_kc;
+            const int nid = last_kc ? ct + wpx : ct, nkc = last_kc ? 0 : kc + 1;
+            const bool has_next = nid < xend;
+            int nb_ = cb, nY0 = Y0, nX0 = X0, nn0 = n0;              // (the next block's patch: another tile's only after this tile's last block)
+            if (last_kc && has_next) coords(nid, nb_, nY0, nX0, nn0);
+            const int cur_off = (blk & 1) * A_BYTES;
+            char* const nbuf = smem + ((blk + 1) & 1) * A_BYTES;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                set_a4(dx, cur_off);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    constexpr int kDummy = 0; (void)kDummy;
+                    const int seq = 3 * dx + dy;                    // position of this step (tap 3 dy + dx) in the block
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // every request this step needs is older than the previous tile's NST stores (issued after them: nothing)
+                    if (after_epilogue) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    after_epilogue = false;
+#if !defined(DM_ABL_NOBAR)
+                    __builtin_amdgcn_s_barrier();
+#endif
+                    const char* bb = bst0 + (sidx % NB) * B_BYTES;
+                    char* const nst = bst0 + ((sidx + 1) % NB) * B_BYTES;
+                    // the step after this one: (this block, next tap in dx-major order) or (next block, first tap)
+                    const bool step_next = seq < 8 || has_next;
+                    const int s_n0 = seq < 8 ? n0 : nn0, s_kc = seq < 8 ? kc : nkc;
+                    const int s_tap = seq < 8 ? (seq + 1 < 9 ? 3 * ((seq + 1) % 3) + (seq + 1) / 3 : 0) : 0;
+                    read_frags(dy, 0, bb, a0, b0);
+                    // the patch piece FIRST: it is this wave's only request that comes from HBM (every patch pixel is requested
+                    // once), and the next step's vmcnt(0) -- which is there for the weights, requested behind it -- also waits for
+                    // it: requested in the last chunk it had ~300 cycles of its ~1000 and every step stalled (-21 % measured)
+                    if (has_next) issue_a(nb_, nY0, nX0, nkc, seq, nbuf);
+                    if (pending) mma(a1, b1);                       // chunk 3 of the previous step of this tile
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_frags(dy, 1, bb, a1, b1);
+                    if (step_next) {
+#pragma unroll
+                        for (int q = 0; q < (B_INSTR + 1) / 2; ++q) issue_b(s_n0, s_kc, s_tap, q, nst);
+                    }
+                    mma(a0, b0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_frags(dy, 2, bb, a0, b0);
+                    if (step_next) {
+#pragma unroll
+                        for (int q = (B_INSTR + 1) / 2; q < B_INSTR; ++q) issue_b(s_n0, s_kc, s_tap, q, nst);
+                    }
+                    mma(a1, b1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_frags(dy, 3, bb, a1, b1);
+                    mma(a0, b0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    pending = true;
+                    ++sidx;
+                }
+            }
+        }
+        mma(a1, b1);                                        // the last step's last chunk
+
+        // ---- epilogue (the plain one of k_conv3x3_dma): y = acc + bias[n] (+ rowbias[image, n]) (+ res[m, n]), one rounding
+        unsigned poff[MT];
+        int te_ = tid;
+        asm volatile("" : "+v"(te_));
+        const int l31e = te_ & 31, hie = (te_ >> 5) & 1;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int d = TM * wm + 32 * i + l31e;
+            const int y = Y0 + (d >> 4), x = X0 + (d & 15);
+            poff[i] = (y < H && x < W) ? (((unsigned)cb * (unsigned)H + (unsigned)y) * (unsigned)W + (unsigned)x) * (unsigned)a.Cout * 2u : OOB;
+        }
+        const unsigned rboff = (unsigned)(cb * a.Cout * 2);
+        auto unpack_add = [](float (&v)[4], const u32x2 p) __attribute__((always_inline)) {
+            v[0] += dm_elem_lo(p[0]); v[1] += dm_elem_hi(p[0]);
+            v[2] += dm_elem_lo(p[1]); v[3] += dm_elem_hi(p[1]);
+        };
+        const bool has_res = a.res != nullptr, has_rb = a.rowbias != nullptr;
+        auto frag_load = [&](int i, int j, u32x2 (&r)[8]) __attribute__((always_inline)) {
+            const int nbase = n0 + TN * wn + 32 * j;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = nbase + 8 * g + 4 * hie;
+                const bool n_ok = n < a.Cout;
+                if (has_rb) r[g] = __builtin_amdgcn_raw_buffer_load_b64(rbrs, (int)(n_ok ? rboff + (unsigned)n * 2u : OOB), 0, 0);
+                if (has_res)
+                    r[4 + g] = __builtin_amdgcn_raw_buffer_load_b64(rrs, (int)(n_ok && poff[i] != OOB ? poff[i] + (unsigned)n * 2u : OOB), 0, 0);
+            }
+        };
+        u32x2 pre[2][8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) pre[0][g] = pre[1][g] = u32x2{0u, 0u};
+        static_assert(NT <= 2, "pixel-major epilogue");
+        u32x2 bp[NT][4];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + TN * wn + 32 * j + 8 * g + 4 * hie;
+                bp[j][g] = __builtin_amdgcn_raw_buffer_load_b64(brs, (int)(n < a.Cout ? (unsigned)n * 2u : OOB), 0, 0);
+            }
+        frag_load(0, 0, pre[0]);
+#pragma unroll
+        for (int f = 0; f < MT * NT; ++f) {
+            constexpr int kLast = MT * NT - 1;
+            const int i = f / NT, j = f % NT;
+            const int nbase = n0 + TN * wn + 32 * j;
+            if (f < kLast) frag_load((f + 1) / NT, (f + 1) % NT, pre[(f + 1) & 1]);
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                unsigned w[2][2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int g = 2 * gp + q;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+                    unpack_add(v, bp[j][g]);
+                    unpack_add(v, pre[f & 1][g]);
+                    unpack_add(v, pre[f & 1][4 + g]);
+                    f32x2 lo = {v[0], v[1]}, hi2 = {v[2], v[3]};
+                    elem2 plo = __builtin_convertvector(lo, elem2), phi = __builtin_convertvector(hi2, elem2);
+                    w[q][0] = __builtin_bit_cast(unsigned, plo);
+                    w[q][1] = __builtin_bit_cast(unsigned, phi);
+                }
+                const auto s0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+                const int c0 = nbase + 16 * gp + 8 * hie;
+                const u32x4 out = {s0[0], s1[0], s0[1], s1[1]};
+                const unsigned off = poff[i] != OOB && c0 < a.Cout ? poff[i] + (unsigned)c0 * 2u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(out, yrs, (int)off, 0, 0);
+            }
+        }
+        after_epilogue = true;
+    }
+#endif
+}
+
+int cu_count();
+template <int TH, int BN, int WMW, int NB>
+int launch_conv_halo(const ConvArgs& a, hipStream_t stream) {
+    constexpr int PA = ((16 + 2) * (TH + 2) + 7) / 8;
+    constexpr int LDS = 2 * PA * 1024 + NB * BN * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_halo<TH, BN, WMW, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    if (a.stride != 1 || a.pad_y != 1 || a.pad_x != 1 || a.Hin != a.Hout || a.Win != a.Wout || a.Cin % 64 != 0) return DM_ERR_UNSUPPORTED;
+    if ((long long)a.B * a.Hin * a.Win * a.Cin * 2 > 0xffffff00LL || (long long)a.Cout * 9 * a.Cin * 2 > 0xffffff00LL || a.M * a.Cout * 2 > 0xffffff00LL)
+        return DM_ERR_UNSUPPORTED;                                                    // 32-bit buffer offsets
+    const int tiles_x = (a.Wout + 15) / 16, tiles_y = (a.Hout + TH - 1) / TH, n_nt = (a.Cout + BN - 1) / BN;
+    const long long total = (long long)a.B * tiles_y * tiles_x * n_nt;
+    if (total > 0x7fffffffLL) return DM_ERR_UNSUPPORTED;
+    const int n_cu = cu_count();
+    if (n_cu <= 0) return DM_ERR_UNSUPPORTED;
+    const long long per_xcd = (total + 7) / 8;
+    const long long wpx = std::max<long long>(1, std::min<long long>(per_xcd, n_cu / 8));       // one 512-thread workgroup per CU
+    DM_ENTER();
+    hipLaunchKernelGGL((k_conv3x3_halo<TH, BN, WMW, NB>), dim3((unsigned)(8 * wpx)), dim3(512), LDS, stream, a, tiles_x, tiles_y, n_nt);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? DM_OK : (int)e;
 }
 
 // split-K reduction: y[m][n] = sum_ks ws[ks][m][n] + bias[n] + rowbias[image(m)][n] + res[m][n], 8 channels per thread
@@ -1061,6 +1393,21 @@ int DM_T(dm_conv3x3_nhwc_, _fused)(const void* x, const void* w, const void* bia
             // workgroups per CU and all 480 run at once: 47 -> 41 us, 93 -> 79 us (tools/conv_b3.sh)
             else if (Cout % 128 != 0 && n_wg(256, 128) < 400) tile = 128;
             else tile = 256;
+        }
+        // halo-patch kernel (round 6) for the stride-1 pad-1 layers with enough patches to fill the chip; DREAMMAT_CONV_HALO=0: off
+        // (A/B runs, and the tile-variant tests that compare the per-tap kernels bit for bit)
+        const char* halo_env = getenv("DREAMMAT_CONV_HALO");
+        const bool halo_ok = !(halo_env && halo_env[0] == '0') && stride == 1 && pad_y == 1 && pad_x == 1 && Hin == Hout && Win == Wout && !tile_env;
+        // DREAMMAT_CONV_HALO=24 | 16 forces a patch variant whatever the size (tests: ragged bands / columns, tiny images)
+        if (halo_ok && halo_env && !strcmp(halo_env, "24")) return launch_conv_halo<24, 128, 4, 2>(a, stream);
+        if (halo_ok && halo_env && !strcmp(halo_env, "16")) return launch_conv_halo<16, 256, 2, 2>(a, stream);
+        if (halo_ok && tile == 640 && Cout == 128) {
+            int rc = launch_conv_halo<24, 128, 4, 2>(a, stream);
+            if (rc != DM_ERR_UNSUPPORTED) return rc;
+        }
+        if (halo_ok && tile == 512) {
+            int rc = launch_conv_halo<16, 256, 2, 2>(a, stream);
+            if (rc != DM_ERR_UNSUPPORTED) return rc;
         }
         switch (tile) {
         case 640: {                                                          // wave tile 128 x 64, all 160 KB of LDS
