@@ -16,7 +16,7 @@ if os.environ.get("DREAMMAT_LIB"):       # development aid (tools/grad_budget.py
     LIB_PATH = os.environ["DREAMMAT_LIB"]
 
 _lib = None
-ABI_VERSION = 12     # dm_abi_version() of the library this binding was written for (csrc/host.cpp, include/dreammat_hip.h)
+ABI_VERSION = 13     # dm_abi_version() of the library this binding was written for (csrc/host.cpp, include/dreammat_hip.h)
 
 DM_ERRORS = {-1: "DM_ERR_ARG", -2: "DM_ERR_WORKSPACE", -3: "DM_ERR_UNSUPPORTED"}
 
@@ -141,6 +141,9 @@ _SIGS = {
     "dm_groupnorm_workspace_floats": (c_size_t, [c_int, c_int]),
     "dm_groupnorm_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                       c_int, c_void_p]),
+    "dm_groupnorm_nhwc_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "dm_conv3x3_gn_ok": (c_int, [c_int] * 5),
+    "dm_conv3x3_gn_nhwc_bf16_fused": (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
     "dm_groupnorm_nhwc_infer": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                         c_int, c_void_p]),
     "dm_groupnorm_nhwc_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
@@ -161,9 +164,10 @@ _SIGS = {
 # IEEE-half instantiations of the net kernels (csrc/dm_elem.h, built from the same sources with -DDM_F16): same signatures
 for _n in ("dm_attention_fwd_bf16", "dm_attention_fwd_lse_bf16", "dm_conv3x3_nhwc_bf16", "dm_conv3x3_nhwc_bf16_fused",
            "dm_conv2x2_nhwc_bf16", "dm_conv2x2_subpixel_nhwc_bf16", "dm_conv3x3_small_nhwc_bf16", "dm_conv3x3_small_res_nhwc_bf16", "dm_gemm_bf16_fused",
-           "dm_layernorm_bf16", "dm_geglu_bf16", "dm_cat_add_bf16", "dm_softmax_rows_bf16", "dm_softmax_rows_bwd_bf16"):
+           "dm_layernorm_bf16", "dm_geglu_bf16", "dm_cat_add_bf16", "dm_softmax_rows_bf16", "dm_softmax_rows_bwd_bf16",
+           "dm_conv3x3_gn_nhwc_bf16_fused"):
     _SIGS[_n.replace("bf16", "f16")] = _SIGS[_n]
-for _n in ("dm_groupnorm_nhwc_fwd", "dm_groupnorm_nhwc_infer", "dm_groupnorm_nhwc_bwd", "dm_groupnorm_nhwc_bwd_res"):
+for _n in ("dm_groupnorm_nhwc_fwd", "dm_groupnorm_nhwc_infer", "dm_groupnorm_nhwc_bwd", "dm_groupnorm_nhwc_bwd_res", "dm_groupnorm_nhwc_stats"):
     _SIGS[_n + "_f16"] = _SIGS[_n]
 del _n
 

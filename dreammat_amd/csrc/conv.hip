@@ -29,6 +29,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 struct ConvArgs {
     const elem_t* x;     // [B, Hin, Win, Cin]
@@ -49,6 +50,11 @@ struct ConvArgs {
     // (0 = plain [B, Hout, Wout, Cout] rows).  1: block (py, px) of pixel (u, v) -> (2u + py, 2v + px), H' = Hout, W' = Wout (the stride-2
     // data gradient).  2: -> (2u - py, 2v - px) where that is inside H' = Hout - 1, W' = Wout - 1 (upsample + conv on its (h+1) x (w+1) grid)
     int shuf_mode, shuf_cs;
+    // halo-patch kernel with the GroupNorm apply pass folded in (round 6): x is the UN-normalised tensor, gn_coef = the fp32
+    // coefficient rows dm_groupnorm_nhwc_stats leaves ([B][7][Cin]: row 0 = rstd * gamma, row 1 = beta - mean * rstd * gamma), the
+    // patch in LDS becomes act(x * A + S) rounded to 16 bits (what the apply kernel would have written) before any tap reads it
+    const float* gn_coef;
+    int gn_act;
     unsigned long long* timeline;   // DREAMMAT_CONV_TIMELINE=1 (development): s_memtime stamps per tile, else null
     int timeline_steps;             // DREAMMAT_CONV_TIMELINE=2: stamp every K-step instead; 4: per-wave sums of body / waits / barrier
 };
@@ -815,7 +821,13 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
 //  * out-of-image patch pixels (the zero padding, and rows / columns past a ragged last band) are buffer offsets beyond
 //    num_records, as above; a patch never straddles two images (bands are per image, the last one ragged).
 //  * stride 1, pad 1, 3 x 3 only; no split-K (large-M layers only); epilogue = the plain one of the kernel above.
-template <int TH, int BN, int WMW, int NB>
+//  * GN = true (round 6): the GroupNorm [+ SiLU] that diffusers runs in front of the convolution (ResnetBlock2D: conv(silu(norm(x))))
+//    is applied to the patch IN LDS: a wave transforms the 1 KB piece it requested one step earlier (it knows the piece has landed:
+//    its own vmcnt), y = act(x * A[image, channel] + S[image, channel]) rounded to 16 bits -- the value the apply pass would have
+//    stored -- and out-of-image pixels stay zero (the convolution pads the NORMALISED tensor).  The 64 + 64 coefficients of a
+//    channel block arrive by two 256-byte LDS-DMA requests of one wave per block.  The apply pass (a read and a write of the whole
+//    activation per GroupNorm) disappears; the statistics pass stays.
+template <int TH, int BN, int WMW, int NB, bool GN = false>
 __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs a, int tiles_x, int tiles_y, int n_nt) {
     constexpr int NW = 8, TW = 16, BMT = TW * TH, PW = TW + 2, PH = TH + 2, NPIX = PW * PH;
     constexpr int PA = (NPIX + 7) / 8;                      // 1 KB pieces (8 pixels x 128 B) of a patch
@@ -826,7 +838,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs a, int tiles_x, i
     static_assert((PA + NW - 1) / NW <= 9, "a wave requests at most one patch piece per tap");
     static_assert(NB == 2 || NB == 3, "weight ring depth");
     static_assert(2 * A_BYTES + NB * B_BYTES <= 160 * 1024, "LDS budget");
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // patch 0 | patch 1 | NB weight stages
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // patch 0 | patch 1 | NB weight stages | (GN) 2 x (A[64] | S[64]) fp32
 #if defined(__HIP_DEVICE_COMPILE__)
     const int total = (int)(a.B * tiles_y * tiles_x) * n_nt;
     const int per_xcd = (total + 7) / 8;
@@ -893,6 +905,45 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs a, int tiles_x, i
                                                  (int)off, (tap * Cin + kc * 64) * 2, 0, 0);
     };
     char* const bst0 = smem + 2 * A_BYTES;              // patch buffer k at smem + k * A_BYTES
+    [[maybe_unused]] float* const cbuf0 = reinterpret_cast<float*>(smem + 2 * A_BYTES + NB * B_BYTES);     // (GN) coefficient buffer k at cbuf0 + 128 k
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t crs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)a.gn_coef, 0, GN ? (int)(unsigned)((long long)a.B * 7 * Cin * 4) : 0, 0x00020000);
+    // (GN) the A and S rows of channel block kc of image b -> coefficient buffer `cb` (one wave: two 256-byte requests)
+    [[maybe_unused]] auto issue_coef = [&](int b, int kc, float* cb) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(crs, (__attribute__((address_space(3))) void*)cb, 4, lane * 4, ((b * 7) * Cin + kc * 64) * 4, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(crs, (__attribute__((address_space(3))) void*)(cb + 64), 4, lane * 4, ((b * 7 + 1) * Cin + kc * 64) * 4, 0, 0);
+    };
+    // (GN) patch piece j of this wave, landed in `buf` (patch of image rows from Y0, columns from X0): x -> act(x A + S) in place
+    [[maybe_unused]] auto gn_transform = [&](int Y0, int X0, int j, char* buf, const float* cb) __attribute__((always_inline)) {
+        const int i = wave + NW * j;
+        if (i >= PA) return;
+        int t_ = tid;
+        asm volatile("" : "+v"(t_));
+        const int L = t_ & 63;
+        const int p = 8 * i + (L >> 3);
+        const int prow = p / PW, pcol = p - prow * PW;
+        const int y = Y0 + prow - 1, x = X0 + pcol - 1;
+        const bool ok = p < NPIX && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        const int cidx = (L & 7) ^ ((pcol >> 1) & 7);           // which 8 channels of the block this slot holds
+        char* const q = buf + i * 1024 + L * 16;
+        const elem8 v = *reinterpret_cast<const elem8*>(q);
+        const f32x4v A0 = *reinterpret_cast<const f32x4v*>(cb + cidx * 8), A1 = *reinterpret_cast<const f32x4v*>(cb + cidx * 8 + 4);
+        const f32x4v S0 = *reinterpret_cast<const f32x4v*>(cb + 64 + cidx * 8), S1 = *reinterpret_cast<const f32x4v*>(cb + 64 + cidx * 8 + 4);
+        elem8 o;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            float z0 = (float)v[e] * (e < 4 ? A0[e] : A1[e - 4]) + (e < 4 ? S0[e] : S1[e - 4]);
+            float z1 = (float)v[e + 1] * (e < 4 ? A0[e + 1] : A1[e - 3]) + (e < 4 ? S0[e + 1] : S1[e - 3]);
+            if (a.gn_act) {        // SiLU on the hardware's 2^x and 1/x, as csrc/groupnorm.hip
+                z0 *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z0));
+                z1 *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z1));
+            }
+            const f32x2 two = {z0, z1};
+            const elem2 pk = __builtin_convertvector(two, elem2);
+            o[e] = pk[0]; o[e + 1] = pk[1];
+        }
+        if (ok) *reinterpret_cast<elem8*>(q) = o;               // out-of-image pixels stay zero: the convolution pads the normalised tensor
+    };
 
     f32x16 acc[MT][NT];
     elem8 a0[MT], b0[NT], a1[MT], b1[NT];
@@ -936,6 +987,13 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs a, int tiles_x, i
         for (int j = 0; j < 9; ++j) issue_a(b_, Y_, X_, 0, j, smem);
 #pragma unroll
         for (int q = 0; q < B_INSTR; ++q) issue_b(n_, 0, 0, q, bst0);
+        if constexpr (GN) {
+            if (wave == NW - 1) issue_coef(b_, 0, cbuf0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                    // the coefficients (one wave's request) are visible to all
+#pragma unroll
+            for (int j = 0; j < 9; ++j) gn_transform(Y_, X_, j, smem, cbuf0);
+        }
     }
     sidx_abl = 1;
     int sidx = 0;                                           // K-steps taken so far (weight stage = sidx % NB)
@@ -986,6 +1044,9 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs a, int tiles_x, i
                     // once), and the next step's vmcnt(0) -- which is there for the weights, requested behind it -- also waits for
                     // it: requested in the last chunk it had ~300 cycles of its ~1000 and every step stalled (-21 % measured)
                     if (has_next) issue_a(nb_, nY0, nX0, nkc, seq, nbuf);
+                    if constexpr (GN) {
+                        if (has_next && seq == 0 && wave == NW - 1) issue_coef(nb_, nkc, cbuf0 + 128 * ((blk + 1) & 1));
+                    }
                     if (pending) mma(a1, b1);                       // chunk 3 of the previous step of this tile
                     __builtin_amdgcn_sched_barrier(0);
                     read_frags(dy, 1, bb, a1, b1);
@@ -1003,6 +1064,11 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs a, int tiles_x, i
                     mma(a1, b1);
                     __builtin_amdgcn_sched_barrier(0);
                     read_frags(dy, 3, bb, a1, b1);
+                    if constexpr (GN) {
+                        // the piece this wave requested a step ago has landed (this step's vmcnt(0)); its coefficients were requested at
+                        // the block's first step and are visible since this step's barrier
+                        if (has_next && seq >= 1) gn_transform(nY0, nX0, seq - 1, nbuf, cbuf0 + 128 * ((blk + 1) & 1));
+                    }
                     mma(a0, b0);
                     __builtin_amdgcn_sched_barrier(0);
                     pending = true;
@@ -1090,13 +1156,16 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs a, int tiles_x, i
 }
 
 int cu_count();
-template <int TH, int BN, int WMW, int NB>
+template <int TH, int BN, int WMW, int NB, bool GN = false>
 int launch_conv_halo(const ConvArgs& a, hipStream_t stream) {
     constexpr int PA = ((16 + 2) * (TH + 2) + 7) / 8;
-    constexpr int LDS = 2 * PA * 1024 + NB * BN * 128;
+    static_assert(PA <= 64, "no patch piece is requested in a block's last step (GN transforms a piece one step after its request)");
+    constexpr int LDS = 2 * PA * 1024 + NB * BN * 128 + (GN ? 1024 : 0);
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    if (GN && !a.gn_coef) return DM_ERR_ARG;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_halo<TH, BN, WMW, NB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_halo<TH, BN, WMW, NB, GN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
@@ -1111,7 +1180,7 @@ int launch_conv_halo(const ConvArgs& a, hipStream_t stream) {
     const long long per_xcd = (total + 7) / 8;
     const long long wpx = std::max<long long>(1, std::min<long long>(per_xcd, n_cu / 8));       // one 512-thread workgroup per CU
     DM_ENTER();
-    hipLaunchKernelGGL((k_conv3x3_halo<TH, BN, WMW, NB>), dim3((unsigned)(8 * wpx)), dim3(512), LDS, stream, a, tiles_x, tiles_y, n_nt);
+    hipLaunchKernelGGL((k_conv3x3_halo<TH, BN, WMW, NB, GN>), dim3((unsigned)(8 * wpx)), dim3(512), LDS, stream, a, tiles_x, tiles_y, n_nt);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? DM_OK : (int)e;
 }
@@ -1350,9 +1419,80 @@ int launch_conv(const ConvArgs& a, hipStream_t stream) {
     return e == hipSuccess ? DM_OK : (int)e;
 }
 
+// Tile variant of a 3 x 3 LDS-DMA launch (DREAMMAT_CONV_TILE=128|256|512|320|640 forces one: tests / A-B measurements).
+int conv_tile_choice(long long M, int Cout) {
+    const char* tile_env = getenv("DREAMMAT_CONV_TILE");   // read per call: tests toggle it
+    int tile = tile_env ? atoi(tile_env) : 0;
+    auto n_wg = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
+    if (!tile) {
+        if (!(Cout >= 128 && M >= 2048)) tile = 128;
+        else if (Cout % 256 == 0 && n_wg(256, 256) >= 200) tile = 512;
+        else if ((Cout == 128 || Cout == 640) && n_wg(512, 128) >= 200) tile = 640;
+        else if (Cout % 320 == 0 && Cout % 256 != 0 && n_wg(256, 320) >= 160) tile = 320;
+        // Cout = 320 at batch 3-6 (1 view per rank): 256-row tiles leave the chip half empty (144 tiles), 128x64 tiles fit two
+        // workgroups per CU and all 480 run at once: 47 -> 41 us, 93 -> 79 us (tools/conv_b3.sh)
+        else if (Cout % 128 != 0 && n_wg(256, 128) < 400) tile = 128;
+        else tile = 256;
+    }
+    return tile;
+}
+
+// Which halo-patch variant (k_conv3x3_halo) serves this launch: 24 = 384 x 128 patches (the Cout = 128 layers that took the
+// 512 x 128 tile), 16 = 256 x 256 patches (where the 256 x 256 tile ran), 0 = none (the per-tap kernels).  Stride 1, pad 1,
+// Cin % 64 == 0, enough patches to fill the chip.  DREAMMAT_CONV_HALO=0: off (A/B runs; a forced tile variant also turns it off:
+// the tile-variant tests compare the per-tap kernels bit for bit); =24 | 16 forces a variant whatever the size (tests: ragged
+// bands / columns, tiny images).
+int conv_halo_choice(const ConvArgs& a) {
+    if (a.stride != 1 || a.pad_y != 1 || a.pad_x != 1 || a.Hin != a.Hout || a.Win != a.Wout || a.Cin % 64 != 0 || a.Cout % 64 != 0) return 0;
+    if (getenv("DREAMMAT_CONV_TILE")) return 0;
+    const char* halo_env = getenv("DREAMMAT_CONV_HALO");
+    if (halo_env && halo_env[0] == '0') return 0;
+    if (halo_env && !strcmp(halo_env, "24")) return 24;
+    if (halo_env && !strcmp(halo_env, "16")) return 16;
+    const int tile = conv_tile_choice(a.M, a.Cout);
+    if (tile == 640 && a.Cout == 128) return 24;      // (the Cout = 640 layers at 32 x 32 lose a third to the ragged second band and re-request the patch per channel tile: 800 vs 1100 TF/s)
+    if (tile == 512) return 16;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+#if !defined(DM_F16)      // (dtype-independent: exported once)
+// 1 when dm_conv3x3_gn_nhwc_*_fused serves this stride-1 pad-1 problem (the halo-patch kernel takes it), else 0: the caller then runs
+// the GroupNorm apply pass and the plain convolution.
+int dm_conv3x3_gn_ok(int B, int H, int W, int Cin, int Cout) {
+    ConvArgs a = {};
+    a.B = B; a.Hin = a.Hout = H; a.Win = a.Wout = W; a.Cin = Cin; a.Cout = Cout; a.stride = 1; a.pad_y = a.pad_x = 1;
+    a.M = (long long)B * H * W;
+    return B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && conv_halo_choice(a) != 0;
+}
+#endif
+
+// conv3x3(act(GroupNorm(x))) + bias (+ rowbias) (+ residual) with the GroupNorm APPLY pass folded into the convolution (round 6):
+// x [B,H,W,Cin] is the un-normalised activation, gn_coef the fp32 workspace dm_groupnorm_nhwc_stats left for it ([B][7][Cin]; rows
+// 0 and 1 are read), gn_act 0 | 1 (SiLU).  Stride 1, pad 1.  Same results as dm_groupnorm_nhwc_fwd + dm_conv3x3_nhwc_*_fused up to the
+// summation order of the taps.  DM_ERR_UNSUPPORTED when dm_conv3x3_gn_ok says 0.
+int DM_T(dm_conv3x3_gn_nhwc_, _fused)(const void* x, const float* gn_coef, int gn_act, const void* w, const void* bias, const void* rowbias,
+                                  const void* residual, void* y, int B, int H, int W, int Cin, int Cout, hipStream_t stream) {
+    if (!x || !gn_coef || !w || !y || B <= 0 || H <= 0 || W <= 0) return DM_ERR_ARG;
+    if (Cin % 64 != 0 || Cout % 64 != 0) return DM_ERR_UNSUPPORTED;
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)gn_coef) & 15) return DM_ERR_ARG;
+    if (((uintptr_t)bias | (uintptr_t)rowbias | (uintptr_t)residual) & 7) return DM_ERR_ARG;
+    ConvArgs a = {};
+    a.x = (const elem_t*)x; a.w = (const elem_t*)w; a.bias = (const elem_t*)bias; a.y = (elem_t*)y;
+    a.rowbias = (const elem_t*)rowbias; a.res = (const elem_t*)residual; a.timeline = nullptr; a.timeline_steps = 0;
+    a.B = B; a.Hin = a.Hout = H; a.Win = a.Wout = W; a.Cin = Cin; a.Cout = Cout;
+    a.stride = 1; a.pad_y = 1; a.pad_x = 1;
+    a.M = (long long)B * H * W;
+    a.gn_coef = gn_coef; a.gn_act = gn_act;
+    switch (conv_halo_choice(a)) {
+    case 24: return launch_conv_halo<24, 128, 4, 2, true>(a, stream);
+    case 16: return launch_conv_halo<16, 256, 2, 2, true>(a, stream);
+    default: return DM_ERR_UNSUPPORTED;
+    }
+}
 
 // x [B,Hin,Win,Cin] NHWC bf16; w [Cout,3,3,Cin] (= [Cout, 9*Cin], tap-major) bf16; bias [Cout] bf16 or NULL;
 // y [B,Hout,Wout,Cout] NHWC bf16 with Hout = (Hin + pad_y + pad_y_end - 3)/stride + 1 chosen by the caller
@@ -1382,32 +1522,13 @@ int DM_T(dm_conv3x3_nhwc_, _fused)(const void* x, const void* w, const void* bia
         // => the widest tile that divides Cout, as long as it still yields enough workgroups to fill the chip.
         // DREAMMAT_CONV_TILE=128|256|512|320|640 forces a variant (tests / A-B measurements).
         const char* tile_env = getenv("DREAMMAT_CONV_TILE");   // read per call: tests toggle it
-        int tile = tile_env ? atoi(tile_env) : 0;
         auto n_wg = [&](int bm, int bn) { return ((a.M + bm - 1) / bm) * ((Cout + bn - 1) / bn); };
-        if (!tile) {
-            if (!(Cout >= 128 && a.M >= 2048)) tile = 128;
-            else if (Cout % 256 == 0 && n_wg(256, 256) >= 200) tile = 512;
-            else if ((Cout == 128 || Cout == 640) && n_wg(512, 128) >= 200) tile = 640;
-            else if (Cout % 320 == 0 && Cout % 256 != 0 && n_wg(256, 320) >= 160) tile = 320;
-            // Cout = 320 at batch 3-6 (1 view per rank): 256-row tiles leave the chip half empty (144 tiles), 128x64 tiles fit two
-            // workgroups per CU and all 480 run at once: 47 -> 41 us, 93 -> 79 us (tools/conv_b3.sh)
-            else if (Cout % 128 != 0 && n_wg(256, 128) < 400) tile = 128;
-            else tile = 256;
-        }
-        // halo-patch kernel (round 6) for the stride-1 pad-1 layers with enough patches to fill the chip; DREAMMAT_CONV_HALO=0: off
-        // (A/B runs, and the tile-variant tests that compare the per-tap kernels bit for bit)
-        const char* halo_env = getenv("DREAMMAT_CONV_HALO");
-        const bool halo_ok = !(halo_env && halo_env[0] == '0') && stride == 1 && pad_y == 1 && pad_x == 1 && Hin == Hout && Win == Wout && !tile_env;
-        // DREAMMAT_CONV_HALO=24 | 16 forces a patch variant whatever the size (tests: ragged bands / columns, tiny images)
-        if (halo_ok && halo_env && !strcmp(halo_env, "24")) return launch_conv_halo<24, 128, 4, 2>(a, stream);
-        if (halo_ok && halo_env && !strcmp(halo_env, "16")) return launch_conv_halo<16, 256, 2, 2>(a, stream);
-        if (halo_ok && tile == 640 && Cout == 128) {
-            int rc = launch_conv_halo<24, 128, 4, 2>(a, stream);
-            if (rc != DM_ERR_UNSUPPORTED) return rc;
-        }
-        if (halo_ok && tile == 512) {
-            int rc = launch_conv_halo<16, 256, 2, 2>(a, stream);
-            if (rc != DM_ERR_UNSUPPORTED) return rc;
+        const int tile = conv_tile_choice(a.M, Cout);
+        // halo-patch kernel (round 6) where conv_halo_choice says so
+        switch (conv_halo_choice(a)) {
+        case 24: { int rc = launch_conv_halo<24, 128, 4, 2>(a, stream); if (rc != DM_ERR_UNSUPPORTED) return rc; break; }
+        case 16: { int rc = launch_conv_halo<16, 256, 2, 2>(a, stream); if (rc != DM_ERR_UNSUPPORTED) return rc; break; }
+        default: break;
         }
         switch (tile) {
         case 640: {                                                          // wave tile 128 x 64, all 160 KB of LDS

@@ -321,6 +321,26 @@ int DM_S(dm_groupnorm_nhwc_fwd)(const void* x, const void* gamma, const void* be
     return DM_OK;
 }
 
+// Statistics + coefficients only (round 6): ws as dm_groupnorm_nhwc_fwd leaves it (coefficient rows 0-4 and the partial sums), no
+// output tensor -- the apply pass rides in the consuming convolution (dm_conv3x3_gn_nhwc_*_fused reads rows 0 and 1); the workspace
+// also serves dm_groupnorm_nhwc_bwd(_res) of the same GroupNorm.
+int DM_S(dm_groupnorm_nhwc_stats)(const void* x, const void* gamma, const void* beta, float* ws, int B, int HW, int C, float eps,
+                            hipStream_t stream) {
+    if (!x || !gamma || !beta || !ws || !check_args(B, HW, C)) return DM_ERR_ARG;
+    GnArgs a = {};
+    a.x = (const elem_t*)x; a.gamma = (const elem_t*)gamma; a.beta = (const elem_t*)beta; a.y = nullptr;
+    bind_ws(a, ws, B, C);
+    a.B = B; a.HW = HW; a.C = C; a.act = 0; a.eps = eps;
+    dim3 g;
+    launch_cfg(B, HW, C, g, a.rows_per_block);
+    a.nblk = (int)g.x;
+    DM_ENTER();
+    hipLaunchKernelGGL(k_gn_stats<0>, g, dim3(256), stats_lds_bytes(C), stream, a);
+    hipLaunchKernelGGL(k_gn_coef<0>, dim3(dm_div_up(C, 64 * GN_COEF_SLICES), B), dim3(64 * GN_COEF_SLICES), 0, stream, a);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
 // Forward only (frozen nets under no_grad: nothing will ask for the backward): statistics + apply, the coefficient kernel
 // folded into the apply kernel.  Same arithmetic as dm_groupnorm_nhwc_fwd; ws is scratch of the same size.
 int DM_S(dm_groupnorm_nhwc_infer)(const void* x, const void* gamma, const void* beta, void* y, float* ws, int B, int HW,

@@ -1117,6 +1117,90 @@ class _GroupNormAct(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None
 
 
+# ---- GroupNorm [+ SiLU] with its apply pass folded into the consuming 3 x 3 convolution (round 6, ABI v13)
+# tests / tools assign False for the two-call form (apply pass + convolution) it replaces; DREAMMAT_GN_FOLD=0 does the same for a
+# whole process (A/B runs of bench.py)
+GN_CONV_FOLD = os.environ.get("DREAMMAT_GN_FOLD", "1") != "0"
+
+
+def gn_conv3x3_ok(x_nhwc, gamma, cout):
+    """the halo-patch kernel serves conv3x3(act(GroupNorm32(x))) at this shape (stride 1, pad 1): dm_conv3x3_gn_ok"""
+    B, H, W, C = x_nhwc.shape
+    return (GN_CONV_FOLD and x_nhwc.is_cuda and x_nhwc.dtype in HALF_DTYPES and gamma.dtype == x_nhwc.dtype and C % 64 == 0
+            and 2 * B * H * W * max(C, cout) <= CONV_MAX_TENSOR_BYTES and bool(_lib.lib().dm_conv3x3_gn_ok(B, H, W, C, cout)))
+
+
+def _gn_stats(x_nhwc, gamma, beta, eps):
+    """statistics + coefficient kernels of GroupNorm32(x): the workspace dm_groupnorm_nhwc_fwd would leave, no output tensor"""
+    B, H, W, C = x_nhwc.shape
+    ws = torch.empty(int(_lib.lib().dm_groupnorm_workspace_floats(B, C)), device=x_nhwc.device, dtype=torch.float32)
+    fn, name = _sym("dm_groupnorm_nhwc_stats", _same_half(x_nhwc, gamma, beta))
+    with _Timed(f"groupnorm_stats[C={C},HW={H * W}]", 2.0 * B * H * W * C):
+        check(fn(x_nhwc.data_ptr(), gamma.data_ptr(), beta.data_ptr(), ws.data_ptr(), B, H * W, C, float(eps), _stream()), name)
+    return ws
+
+
+def _gn_conv(x_nhwc, ws, act, w_tap_major, bias, rowbias, residual):
+    B, H, W, Cin = x_nhwc.shape
+    Cout = w_tap_major.shape[0]
+    y = torch.empty(B, H, W, Cout, device=x_nhwc.device, dtype=x_nhwc.dtype)
+    fn, name = _sym("dm_conv3x3_gn_nhwc_bf16_fused", _same_half(x_nhwc, w_tap_major, bias, rowbias, residual))
+    with _Timed(f"conv3x3[gn+{Cin}->{Cout}@{H}x{W},s1]", 2.0 * B * H * W * Cout * 9 * Cin):
+        check(fn(x_nhwc.data_ptr(), ws.data_ptr(), int(act), w_tap_major.data_ptr(), bias.data_ptr() if bias is not None else None,
+                 rowbias.data_ptr() if rowbias is not None else None, residual.data_ptr() if residual is not None else None,
+                 y.data_ptr(), B, H, W, Cin, Cout, _stream()), name)
+    return y
+
+
+class _GnConv3x3S1(torch.autograd.Function):
+    """conv3x3(act(GroupNorm32(x))) + bias (+ residual), frozen conv weights, differentiable wrt x (and the residual): _GroupNormAct
+    and _Conv3x3S1 as ONE node whose forward never writes the normalised tensor.  Backward = the two nodes' backwards in sequence
+    (data-gradient convolution, then the GroupNorm backward kernels on the saved statistics).  with_skip: as _GroupNormAct --
+    x is handed back as a second output so that a caller using x twice receives both gradients in the GroupNorm backward pass."""
+
+    @staticmethod
+    def forward(ctx, x_nhwc, gamma, beta, eps, act, w_fwd, w_dgrad, bias, residual, with_skip=False):
+        ws = _gn_stats(x_nhwc, gamma, beta, eps)
+        y = _gn_conv(x_nhwc, ws, act, w_fwd, bias, None, residual)
+        ctx.save_for_backward(x_nhwc, gamma, beta, ws)
+        ctx.eps, ctx.act, ctx.w_dgrad, ctx.with_skip = eps, act, w_dgrad, with_skip
+        ctx.set_materialize_grads(False)
+        return (y, x_nhwc.view_as(x_nhwc)) if with_skip else y
+
+    @staticmethod
+    def backward(ctx, g, g_skip=None):
+        x, gamma, beta, ws = ctx.saved_tensors
+        B, H, W, C = x.shape
+        d_res = None
+        if g is None:
+            return g_skip, None, None, None, None, None, None, None, None, None
+        g = g.contiguous()
+        if ctx.needs_input_grad[8]:
+            d_res = g
+        dh = conv3x3_nhwc(g, ctx.w_dgrad, None, 1, (1, 1))              # gradient of the (never materialised) normalised tensor
+        if g_skip is not None:
+            g_skip = g_skip.contiguous()
+        dx = torch.empty_like(x)
+        fn, name = _sym("dm_groupnorm_nhwc_bwd_res", _same_half(x, gamma, beta, dh, g_skip))
+        check(fn(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dh.data_ptr(), g_skip.data_ptr() if g_skip is not None else None,
+                 dx.data_ptr(), ws.data_ptr(), B, H * W, C, float(ctx.eps), int(ctx.act), _stream()), name)
+        return dx, None, None, None, None, None, None, None, d_res, None
+
+
+def gn_conv3x3_nhwc(x_nhwc, gamma, beta, eps, act, w_fwd, w_dgrad, bias, rowbias=None, residual=None, with_skip=False):
+    """conv3x3(act(GroupNorm32(x)), stride 1, pad 1) + bias (+ rowbias[:, None, None]) (+ residual) without the normalised tensor
+    (callers check gn_conv3x3_ok first).  Differentiable wrt x and residual when grad is enabled (frozen gamma / beta / weights; no
+    rowbias there); with_skip -> (y, x) as groupnorm_nhwc_skip."""
+    _need_cuda(x_nhwc, gamma, beta, w_fwd)
+    assert x_nhwc.is_contiguous() and w_fwd.is_contiguous()
+    if torch.is_grad_enabled() and (x_nhwc.requires_grad or (residual is not None and residual.requires_grad)):
+        assert rowbias is None and not gamma.requires_grad and not beta.requires_grad
+        return _GnConv3x3S1.apply(x_nhwc, gamma, beta, eps, act, w_fwd, w_dgrad, bias, residual, with_skip)
+    ws = _gn_stats(x_nhwc, gamma, beta, eps)
+    y = _gn_conv(x_nhwc, ws, act, w_fwd, bias, rowbias, residual)
+    return (y, x_nhwc) if with_skip else y
+
+
 def groupnorm_nhwc(x_nhwc, gamma, beta, eps, act):
     """x [B,H,W,C] bf16 contiguous -> act(GroupNorm32(x)) [B,H,W,C]; differentiable wrt x, gamma and beta."""
     _need_cuda(x_nhwc, gamma, beta)

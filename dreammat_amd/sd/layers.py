@@ -156,6 +156,26 @@ class Conv2d(nn.Conv2d):
             y = hipops.conv3x3_nhwc(xn, w_fwd, self._bias_p, 1, (1, 1), None, None, rn)
         return y.permute(0, 3, 1, 2)
 
+    def gn_fold_ok(self, norm, x):
+        """conv(act(norm(x))) as ONE convolution launch with the GroupNorm apply pass folded in (hipops.gn_conv3x3_nhwc, round 6):
+        frozen 3 x 3 stride-1 pad-1 layer, frozen 32-group norm, a shape the halo-patch kernel serves."""
+        Cout, Cin = self.weight.shape[:2]
+        return (self.mfma_ok(x) and Cin % 64 == 0 and Cout % 64 == 0 and self.stride == (1, 1) and self.padding == (1, 1)
+                and _gn_kernel_ok(norm, x) and not (torch.is_grad_enabled() and (norm.weight.requires_grad or norm.bias.requires_grad))
+                and hipops.gn_conv3x3_ok(x.permute(0, 2, 3, 1), norm.weight, Cout))
+
+    def forward_gn_fold(self, norm, x, silu=True, rowbias=None, residual=None, with_skip=False):
+        """conv(act(norm(x))) + bias (+ rowbias[:, :, None, None]) (+ residual); logical NCHW in / out.  with_skip -> (y, x): x routed
+        through the same autograd node (a ResnetBlock2D's input feeds norm1 and the skip connection)."""
+        w_fwd, w_dgrad = self._prepared()
+        xn = x.permute(0, 2, 3, 1).contiguous()
+        rn = residual.permute(0, 2, 3, 1).contiguous() if residual is not None else None
+        rb = rowbias.contiguous() if rowbias is not None else None
+        out = hipops.gn_conv3x3_nhwc(xn, norm.weight, norm.bias, norm.eps, 1 if silu else 0, w_fwd, w_dgrad, self._bias_p, rb, rn, with_skip)
+        if with_skip:
+            return out[0].permute(0, 3, 1, 2), out[1].permute(0, 3, 1, 2)
+        return out.permute(0, 3, 1, 2)
+
     def small_ok(self, x):
         """few-channel stem layers on the direct kernel (forward only, frozen nets)."""
         Cout, Cin, kh, kw = self.weight.shape
@@ -653,6 +673,22 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = Conv2d(in_ch, out_ch, 1) if in_ch != out_ch else None
 
     def forward(self, x, temb=None):
+        needs_grad = torch.is_grad_enabled() and x.requires_grad
+        if self.conv1.gn_fold_ok(self.norm1, x) and (not needs_grad or (temb is None and self.time_emb_proj is None)):
+            # round 6: both GroupNorm apply passes ride in the convolutions they feed (no normalised tensor is written or read);
+            # under autograd (VAE encoder) x reaches norm1 and the skip through ONE node, as in the branch below
+            tproj = self.__dict__.pop("_tproj", None)
+            if tproj is None and self.time_emb_proj is not None:
+                tproj = self.time_emb_proj(F.silu(temb))
+            if needs_grad:
+                h, x = self.conv1.forward_gn_fold(self.norm1, x, True, with_skip=True)
+            else:
+                h = self.conv1.forward_gn_fold(self.norm1, x, True, rowbias=tproj)
+            res = self.conv_shortcut(x) if self.conv_shortcut is not None else x
+            if self.conv2.gn_fold_ok(self.norm2, h):
+                return self.conv2.forward_gn_fold(self.norm2, h, True, residual=res)
+            h = group_norm_act(self.norm2, h, True)
+            return self.conv2.forward_fused(h, residual=res) if self.conv2.fused_ok(h) else self.conv2.forward_residual(h, res)
         if torch.is_grad_enabled() and x.requires_grad and _gn_kernel_ok(self.norm1, x) and not self.norm1.weight.requires_grad:
             # differentiated (VAE encoder) and x feeds norm1 AND the skip (directly or through conv_shortcut): both gradients meet
             # in the GroupNorm backward kernel

@@ -380,6 +380,18 @@ int dm_gemm_bf16_fused(const void* x, const void* w, const void* bias, const voi
  * 3, same arithmetic; ws = scratch of dm_groupnorm_workspace_floats(B,C), nothing is kept in it. */
 int dm_groupnorm_nhwc_infer(const void* x, const void* gamma, const void* beta, void* y, float* ws, int B, int HW, int C,
                             float eps, int act, dm_stream_t stream);
+/* ABI v13: GroupNorm with its APPLY pass folded into the consuming 3 x 3 convolution -- diffusers ResnetBlock2D.forward
+ * `conv(nonlinearity(norm(x)))` behind models/guidance/dreammat_guidance.py:261-292.  dm_groupnorm_nhwc_stats runs the
+ * statistics and coefficient kernels only and leaves ws as dm_groupnorm_nhwc_fwd does (it also serves dm_groupnorm_nhwc_bwd(_res)
+ * of the same GroupNorm); dm_conv3x3_gn_nhwc_bf16_fused is dm_conv3x3_nhwc_bf16_fused (stride 1, pad 1) on the UN-normalised x with
+ * act(x * A + S), rounded to 16 bits, formed in LDS (gn_coef = that ws; gn_act 0 | 1 = SiLU) -- same results as the two calls up
+ * to the summation order of the taps.  dm_conv3x3_gn_ok: 1 when the halo-patch kernel serves the shape, else the fused entry
+ * returns DM_ERR_UNSUPPORTED and the caller runs apply pass + convolution. */
+int dm_groupnorm_nhwc_stats(const void* x, const void* gamma, const void* beta, float* ws, int B, int HW, int C, float eps,
+                            dm_stream_t stream);
+int dm_conv3x3_gn_ok(int B, int H, int W, int Cin, int Cout);
+int dm_conv3x3_gn_nhwc_bf16_fused(const void* x, const float* gn_coef, int gn_act, const void* w, const void* bias, const void* rowbias,
+                                  const void* residual, void* y, int B, int H, int W, int Cin, int Cout, dm_stream_t stream);
 /* GroupNorm(32) [+ SiLU] of the ResnetBlock2D / Transformer2DModel / conv_norm_out layers of the same nets,
  * NHWC bf16: x,y [B,HW,C], gamma/beta [C] bf16.  ws: dm_groupnorm_workspace_floats(B,C) fp32, kept by the caller
  * between fwd and bwd.  act: 0 = none, 1 = SiLU.  bwd returns dx (the frozen nets of the SDS step need nothing else). */
@@ -464,6 +476,10 @@ int dm_groupnorm_nhwc_fwd_f16(const void* x, const void* gamma, const void* beta
                           int C, float eps, int act, dm_stream_t stream);
 int dm_groupnorm_nhwc_infer_f16(const void* x, const void* gamma, const void* beta, void* y, float* ws, int B, int HW, int C,
                             float eps, int act, dm_stream_t stream);
+int dm_groupnorm_nhwc_stats_f16(const void* x, const void* gamma, const void* beta, float* ws, int B, int HW, int C, float eps,
+                            dm_stream_t stream);
+int dm_conv3x3_gn_nhwc_f16_fused(const void* x, const float* gn_coef, int gn_act, const void* w, const void* bias, const void* rowbias,
+                                  const void* residual, void* y, int B, int H, int W, int Cin, int Cout, dm_stream_t stream);
 int dm_groupnorm_nhwc_bwd_f16(const void* x, const void* gamma, const void* beta, const void* dy, void* dx, float* ws,
                           int B, int HW, int C, float eps, int act, dm_stream_t stream);
 int dm_groupnorm_nhwc_bwd_res_f16(const void* x, const void* gamma, const void* beta, const void* dy, const void* dres, void* dx,

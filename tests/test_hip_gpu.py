@@ -1080,6 +1080,108 @@ def test_conv3x3_dma_tile_variants(dev, monkeypatch, tile, B, Cin, Cout, H, W):
     assert err < 2e-2 * ref.abs().max().item() + 1e-2, err
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("halo,B,Cin,Cout,H,W", [
+    ("24", 2, 128, 128, 200, 72),       # 384 x 128 patches: ragged last band (200 = 8 x 24 + 8) and columns (72 = 4.5 x 16)
+    ("16", 2, 128, 128, 200, 72),       # 256 x 256 patches on the same problem: Cout below a channel tile
+    ("24", 3, 256, 512, 40, 24),        # several channel tiles of 128
+    ("16", 3, 256, 512, 40, 24),
+    ("24", 5, 64, 320, 8, 8),           # images smaller than a patch; 320 = 2.5 x 128 (ragged channel tile)
+    ("16", 1, 192, 64, 17, 33),         # odd sizes, three channel blocks
+    (None, 2, 128, 128, 256, 512),      # the dispatcher's own choice: 384 x 128 patches (the VAE's 512^2 layers' variant)
+    (None, 8, 256, 256, 96, 96),        # ... 256 x 256 patches
+])
+def test_conv3x3_halo_patch_kernel(dev, monkeypatch, dtype, halo, B, Cin, Cout, H, W):
+    """k_conv3x3_halo (round 6): the input patch of a 64-channel block requested once and read at nine shifted offsets -- against
+    fp32 conv2d with bias, per-image channel bias and residual, both patch variants forced on ragged problems, and against the
+    per-tap kernel (same products, taps summed in another order: agreement to the output's rounding)."""
+    if halo:
+        monkeypatch.setenv("DREAMMAT_CONV_HALO", halo)
+    torch.manual_seed(21)
+    x = torch.randn(B, H, W, Cin).to(dtype)
+    w = (torch.randn(Cout, Cin, 3, 3) * 0.05).to(dtype)
+    bias, rowbias, res = torch.randn(Cout).to(dtype), torch.randn(B, Cout).to(dtype), torch.randn(B, H, W, Cout).to(dtype)
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    hipops.enable_kernel_timing(True)
+    yd = hipops.conv3x3_nhwc(x.to(dev), wt.to(dev), bias.to(dev), 1, (1, 1), None, rowbias.to(dev), res.to(dev))
+    torch.cuda.synchronize()
+    hipops.enable_kernel_timing(False)
+    assert int(_lib.lib().dm_conv3x3_gn_ok(B, H, W, Cin, Cout)) == 1          # the patch kernel took it
+    ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias.float(), padding=1).permute(0, 2, 3, 1)
+    ref = ref + rowbias.float()[:, None, None, :] + res.float()
+    tol = (2e-2 if dtype == torch.bfloat16 else 3e-3) * ref.abs().max().item() + (1e-2 if dtype == torch.bfloat16 else 2e-3)
+    assert (yd.float().cpu() - ref).abs().max().item() < tol
+    monkeypatch.setenv("DREAMMAT_CONV_HALO", "0")
+    yt = hipops.conv3x3_nhwc(x.to(dev), wt.to(dev), bias.to(dev), 1, (1, 1), None, rowbias.to(dev), res.to(dev))
+    ulp = 2.0 ** (-7 if dtype == torch.bfloat16 else -10)
+    assert (yd.float() - yt.float()).abs().max().item() <= 2 * ulp * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("halo,act,B,Cin,Cout,H,W", [
+    ("24", 1, 2, 128, 128, 200, 72), ("16", 0, 3, 256, 512, 40, 24), ("24", 1, 5, 64, 320, 8, 8), ("16", 1, 1, 192, 64, 17, 33),
+    (None, 1, 2, 128, 128, 256, 512), (None, 1, 8, 256, 256, 96, 96)])
+def test_conv3x3_with_groupnorm_apply_folded_in(dev, monkeypatch, dtype, halo, act, B, Cin, Cout, H, W):
+    """dm_conv3x3_gn_nhwc_*_fused (ABI v13): conv(act(GroupNorm32(x))) with the apply pass done on the patch in LDS -- equal to the
+    apply kernel + the same convolution kernel BIT FOR BIT (the patch holds exactly the 16-bit values the apply pass would have
+    stored, out-of-image pixels stay zero), and within rounding of fp32 torch."""
+    if halo:
+        monkeypatch.setenv("DREAMMAT_CONV_HALO", halo)
+    torch.manual_seed(22)
+    x = (torch.randn(B, H, W, Cin) * 2 + 0.5).to(dtype)
+    gm, bt = (torch.rand(Cin) + 0.5).to(dtype), torch.randn(Cin).to(dtype)
+    w = (torch.randn(Cout, Cin, 3, 3) * 0.05).to(dtype)
+    bias, rowbias, res = torch.randn(Cout).to(dtype), torch.randn(B, Cout).to(dtype), torch.randn(B, H, W, Cout).to(dtype)
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().to(dev)
+    xd, gd, bd = x.to(dev), gm.to(dev), bt.to(dev)
+    assert hipops.gn_conv3x3_ok(xd, gd, Cout)
+    y = hipops.gn_conv3x3_nhwc(xd, gd, bd, 1e-5, act, wt, wt, bias.to(dev), rowbias.to(dev), res.to(dev))
+    y2 = hipops.conv3x3_nhwc(hipops.groupnorm_nhwc(xd, gd, bd, 1e-5, act), wt, bias.to(dev), 1, (1, 1), None, rowbias.to(dev), res.to(dev))
+    assert torch.equal(y, y2)
+    h = torch.nn.functional.group_norm(x.float().permute(0, 3, 1, 2), 32, gm.float(), bt.float(), 1e-5)
+    h = torch.nn.functional.silu(h) if act else h
+    ref = torch.nn.functional.conv2d(h, w.float(), bias.float(), padding=1).permute(0, 2, 3, 1) + rowbias.float()[:, None, None, :] + res.float()
+    tol = (3e-2 if dtype == torch.bfloat16 else 4e-3) * ref.abs().max().item() + (1e-2 if dtype == torch.bfloat16 else 2e-3)
+    assert (y.float().cpu() - ref).abs().max().item() < tol
+
+
+@pytest.mark.parametrize("cin,cout,temb_ch,B,HW,grad", [(128, 128, 0, 4, 96, True), (128, 256, 0, 4, 96, True), (256, 256, 1280, 8, 96, False)])
+def test_resnet_block_with_folded_groupnorm_equals_the_two_call_form(dev, cin, cout, temb_ch, B, HW, grad):
+    """ResnetBlock2D with both GroupNorm apply passes folded into its convolutions (hipops.GN_CONV_FOLD) against the block with
+    the apply kernels in front of the same convolution kernels: outputs and input gradients bit-equal (VAE encoder: under autograd,
+    x reaching norm1 and the skip through one node; frozen nets: time-embedding row bias and residual in the epilogues), and no
+    apply / forward GroupNorm launch left."""
+    from dreammat_amd.sd import layers
+    torch.manual_seed(23)
+    blk = layers.ResnetBlock2D(cin, cout, temb_ch, eps=1e-6).to(dev, torch.float16).eval()
+    for p in blk.parameters():
+        p.requires_grad_(False)
+    x0 = torch.randn(B, cin, HW, HW, device=dev).to(torch.float16).contiguous(memory_format=torch.channels_last)
+    temb = torch.randn(B, temb_ch, device=dev).to(torch.float16) if temb_ch else None
+    g = torch.randn(B, cout, HW, HW, device=dev).to(torch.float16).contiguous(memory_format=torch.channels_last)
+    outs = {}
+    try:
+        for fold in (False, True):
+            hipops.GN_CONV_FOLD = fold
+            x = x0.clone().requires_grad_(grad)
+            hipops.enable_kernel_timing(True)
+            with torch.set_grad_enabled(grad):
+                y = blk(x, temb)
+                if grad:
+                    y.backward(g)
+            torch.cuda.synchronize()
+            keys = sorted(hipops.kernel_times())
+            hipops.enable_kernel_timing(False)
+            outs[fold] = (y.detach(), x.grad if grad else None, keys)
+    finally:
+        hipops.GN_CONV_FOLD = True
+    assert torch.equal(outs[True][0], outs[False][0])
+    if grad:
+        assert torch.equal(outs[True][1], outs[False][1])
+    assert sum(k.startswith("conv3x3[gn+") for k in outs[True][2]) == (2 if cin == cout else 2) and not any(k.startswith("groupnorm_fwd") for k in outs[True][2])
+    assert any(k.startswith("groupnorm_fwd") for k in outs[False][2])
+
+
 def test_raster_edge_cases_bit_exact(dev):
     """object partly off-screen, behind the camera (discarded), degenerate and sub-pixel triangles, and a
     camera that sees nothing (empty coverage) -- ids/barycentrics stay bit-identical to the oracle."""
