@@ -31,6 +31,15 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+// compile-time loop (indices as types: bodies whose register indices must all be constants)
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_c(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_c<I + 1, N>(f);
+    }
+}
+
 struct ConvArgs {
     const elem_t* x;     // [B, Hin, Win, Cin]
     const elem_t* w;     // [Cout, 9, Cin]
@@ -873,13 +882,10 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs a, int tiles_x, i
         b = (int)bb;
     };
     [[maybe_unused]] int sidx_abl = 0;                      // (ablation builds: 0 during the prologue, then 1)
-    // patch piece j of this wave (piece index wave + 8 j), channel block kc of the patch at (image b, rows from Y0, columns from X0), into `buf`
-    auto issue_a = [&](int b, int Y0, int X0, int kc, int j, char* buf) __attribute__((always_inline)) {
-        const int i = wave + NW * j;
-        if (i >= PA) return;
-#if defined(DM_ABL_NOA) || defined(DM_ABL_NODMA)
-        if (sidx_abl > 0) return;                           // ABLATION (wrong results)
-#endif
+    // patch piece j of this wave (piece index wave + 8 j), channel block kc of the patch at (image b, rows from Y0, columns from X0):
+    // this lane's source offset (straight-line code: it is scheduled behind an MFMA, see the K-step) ...
+    auto a_offset = [&](int b, int Y0, int X0, int kc, int j) __attribute__((always_inline)) {
+        const int i = min(wave + NW * j, PA - 1);
         // (the lane's pixel of the piece from an opaque copy of the thread id: left visible, the nine pieces' row / column pairs are
         // hoisted out of the K loop and spilled -- a scratch reload, i.e. one more vector-memory request, per step)
         int t_ = tid;
@@ -888,10 +894,23 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs a, int tiles_x, i
         const int prow = p / PW, pcol = p - prow * PW;
         const int y = Y0 + prow - 1, x = X0 + pcol - 1;
         const bool ok = p < NPIX && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-        // all lanes execute the request (an inactive lane would leave its LDS slot stale); out-of-image = zeros through the range check
-        const unsigned off = ok ? ((((unsigned)b * (unsigned)H + (unsigned)y) * (unsigned)W + (unsigned)x) * (unsigned)Cin + (unsigned)(kc * 64) +
-                                   (unsigned)(((t_ & 7) ^ ((pcol >> 1) & 7)) * 8)) * 2u : OOB;
+        // out-of-image = zeros through the descriptor's range check (all lanes execute the request: an inactive lane would leave its
+        // LDS slot stale)
+        const unsigned off = ((((unsigned)b * (unsigned)H + (unsigned)y) * (unsigned)W + (unsigned)x) * (unsigned)Cin + (unsigned)(kc * 64) +
+                              (unsigned)(((t_ & 7) ^ ((pcol >> 1) & 7)) * 8)) * 2u;
+        return ok ? off : OOB;
+    };
+    // ... and the request itself (waves whose piece index is past the patch request nothing)
+    auto issue_a_at = [&](unsigned off, int j, char* buf) __attribute__((always_inline)) {
+        const int i = wave + NW * j;
+        if (i >= PA) return;
+#if defined(DM_ABL_NOA) || defined(DM_ABL_NODMA)
+        if (sidx_abl > 0) return;                           // ABLATION (wrong results)
+#endif
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(buf + i * 1024), 16, (int)off, 0, 0, 0);
+    };
+    auto issue_a = [&](int b, int Y0, int X0, int kc, int j, char* buf) __attribute__((always_inline)) {
+        issue_a_at(a_offset(b, Y0, X0, kc, j), j, buf);
     };
     // weight piece q of this wave for (first output channel n0, channel block kc, tap) into stage `st`
     auto issue_b = [&](int n0, int kc, int tap, int q, char* st) __attribute__((always_inline)) {
@@ -913,36 +932,64 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs a, int tiles_x, i
         __builtin_amdgcn_raw_ptr_buffer_load_lds(crs, (__attribute__((address_space(3))) void*)cb, 4, lane * 4, ((b * 7) * Cin + kc * 64) * 4, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(crs, (__attribute__((address_space(3))) void*)(cb + 64), 4, lane * 4, ((b * 7 + 1) * Cin + kc * 64) * 4, 0, 0);
     };
-    // (GN) patch piece j of this wave, landed in `buf` (patch of image rows from Y0, columns from X0): x -> act(x A + S) in place
-    [[maybe_unused]] auto gn_transform = [&](int Y0, int X0, int j, char* buf, const float* cb) __attribute__((always_inline)) {
-        const int i = wave + NW * j;
-        if (i >= PA) return;
-        int t_ = tid;
-        asm volatile("" : "+v"(t_));
-        const int L = t_ & 63;
-        const int p = 8 * i + (L >> 3);
-        const int prow = p / PW, pcol = p - prow * PW;
-        const int y = Y0 + prow - 1, x = X0 + pcol - 1;
-        const bool ok = p < NPIX && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-        const int cidx = (L & 7) ^ ((pcol >> 1) & 7);           // which 8 channels of the block this slot holds
-        char* const q = buf + i * 1024 + L * 16;
-        const elem8 v = *reinterpret_cast<const elem8*>(q);
-        const f32x4v A0 = *reinterpret_cast<const f32x4v*>(cb + cidx * 8), A1 = *reinterpret_cast<const f32x4v*>(cb + cidx * 8 + 4);
-        const f32x4v S0 = *reinterpret_cast<const f32x4v*>(cb + 64 + cidx * 8), S1 = *reinterpret_cast<const f32x4v*>(cb + 64 + cidx * 8 + 4);
-        elem8 o;
+    // (GN) patch piece j of this wave, landed in `buf` (patch of image rows from Y0, columns from X0): x -> act(x A + S) in place.
+    // STRAIGHT-LINE code in SIX PHASES (`live` false: the same instructions on a 1 KB dummy area, nothing kept): the ~90 vector
+    // instructions have to sit BETWEEN the MFMAs of a chunk -- as one block they held the matrix pipe idle for their whole length,
+    // every step (conv + GroupNorm 713 us where the plain patch kernel takes 605), and neither the scheduler on its own nor
+    // sched_group_barrier patterns would interleave them.  Phase 0: addresses + the five LDS reads; 1-4: a channel pair each ... 5: the write.
+    [[maybe_unused]] char* const dummy = smem + 2 * A_BYTES + NB * B_BYTES + 1024;
+    [[maybe_unused]] u32x4 gs_raw = {0u, 0u, 0u, 0u}, gs_o = {0u, 0u, 0u, 0u};      // (the transform's state between its phases)
+    [[maybe_unused]] f32x4v gs_A0 = {0.f, 0.f, 0.f, 0.f}, gs_A1 = gs_A0, gs_S0 = gs_A0, gs_S1 = gs_A0;
+    [[maybe_unused]] int gs_q = 0;                                                   // LDS byte offset of this lane's slot
+    [[maybe_unused]] bool gs_ok = false;
+    [[maybe_unused]] float gs_z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // phases: 0 = the lane's pixel / slot, 1 = the five LDS reads, 2 .. 9 = one channel each (z = x A + S, SiLU), 10 = pack + select, 11 = write
+    constexpr int kGnPhases = 12;
+    [[maybe_unused]] int gs_p = 0, gs_i = 0;
+    [[maybe_unused]] bool gs_live = false;
+    [[maybe_unused]] auto gn_phase = [&](auto ph_tag, bool live, int Y0, int X0, int j, char* buf, const float* cb) __attribute__((always_inline)) {
+        constexpr int PH = decltype(ph_tag)::value;
+        if constexpr (PH == 0) {
+            const int i_raw = wave + NW * j;
+            gs_live = live && i_raw < PA;
+            gs_i = gs_live ? i_raw : 0;
+            int t_ = tid;
+            asm volatile("" : "+v"(t_));
+            gs_p = 8 * gs_i + ((t_ & 63) >> 3);
+        } else if constexpr (PH == 1) {
+            int t_ = tid;
+            asm volatile("" : "+v"(t_));
+            const int L = t_ & 63;
+            const int prow = gs_p / PW, pcol = gs_p - prow * PW;
+            const int y = Y0 + prow - 1, x = X0 + pcol - 1;
+            gs_ok = gs_live && gs_p < NPIX && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+            const int cidx = (L & 7) ^ ((pcol >> 1) & 7);       // which 8 channels of the block this slot holds
+            gs_q = (int)((gs_live ? buf + gs_i * 1024 : dummy) - smem) + L * 16;
+            gs_raw = *reinterpret_cast<const u32x4*>(smem + gs_q);
+            gs_A0 = *reinterpret_cast<const f32x4v*>(cb + cidx * 8); gs_A1 = *reinterpret_cast<const f32x4v*>(cb + cidx * 8 + 4);
+            gs_S0 = *reinterpret_cast<const f32x4v*>(cb + 64 + cidx * 8); gs_S1 = *reinterpret_cast<const f32x4v*>(cb + 64 + cidx * 8 + 4);
+        } else if constexpr (PH <= 9) {
+            constexpr int e = PH - 2;                           // channel e of the slot
+            const unsigned wraw = gs_raw[e / 2];                // (element copy first: __builtin_bit_cast applied directly to an ext-vector element reads element 0)
+            const float xv = (e & 1) ? dm_elem_hi(wraw) : dm_elem_lo(wraw);
+            float z = xv * (e < 4 ? gs_A0[e & 3] : gs_A1[e & 3]) + (e < 4 ? gs_S0[e & 3] : gs_S1[e & 3]);
+            // SiLU on the hardware's 2^x and 1/x, as csrc/groupnorm.hip (a select, not a branch: the phase stays in its MFMA's block)
+            const float sg = z * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+            gs_z[e] = a.gn_act ? sg : z;
+        } else if constexpr (PH == 10) {
 #pragma unroll
-        for (int e = 0; e < 8; e += 2) {
-            float z0 = (float)v[e] * (e < 4 ? A0[e] : A1[e - 4]) + (e < 4 ? S0[e] : S1[e - 4]);
-            float z1 = (float)v[e + 1] * (e < 4 ? A0[e + 1] : A1[e - 3]) + (e < 4 ? S0[e + 1] : S1[e - 3]);
-            if (a.gn_act) {        // SiLU on the hardware's 2^x and 1/x, as csrc/groupnorm.hip
-                z0 *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z0));
-                z1 *= __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z1));
+            for (int e = 0; e < 8; e += 2) {
+                const f32x2 two = {gs_z[e], gs_z[e + 1]};
+                const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(two, elem2));
+                const unsigned old_w = gs_raw[e / 2];
+                gs_o[e / 2] = gs_ok ? pk : old_w;               // out-of-image pixels stay zero (the convolution pads the normalised tensor)
             }
-            const f32x2 two = {z0, z1};
-            const elem2 pk = __builtin_convertvector(two, elem2);
-            o[e] = pk[0]; o[e + 1] = pk[1];
+        } else {
+            *reinterpret_cast<u32x4*>(smem + gs_q) = gs_o;
         }
-        if (ok) *reinterpret_cast<elem8*>(q) = o;               // out-of-image pixels stay zero: the convolution pads the normalised tensor
+    };
+    [[maybe_unused]] auto gn_transform = [&](bool live, int Y0, int X0, int j, char* buf, const float* cb) __attribute__((always_inline)) {
+        static_for_c<0, kGnPhases>([&](auto ph) __attribute__((always_inline)) { gn_phase(ph, live, Y0, X0, j, buf, cb); });
     };
 
     f32x16 acc[MT][NT];
@@ -992,7 +1039,7 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs a, int tiles_x, i
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                    // the coefficients (one wave's request) are visible to all
 #pragma unroll
-            for (int j = 0; j < 9; ++j) gn_transform(Y_, X_, j, smem, cbuf0);
+            for (int j = 0; j < 9; ++j) gn_transform(true, Y_, X_, j, smem, cbuf0);
         }
     }
     sidx_abl = 1;
@@ -1008,7 +1055,12 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs a, int tiles_x, i
             for (int j = 0; j < NT; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        bool pending = false;
+        // the MFMAs of a step's last chunk run at the top of the NEXT step (behind its first fragment reads, with the patch piece's
+        // address arithmetic woven between them); a tile's first step multiplies zero fragments there: 6-8 idle MFMAs per tile, no branch
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a1[i] = elem8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b1[j] = elem8{0, 0, 0, 0, 0, 0, 0, 0};
         for (int kc = 0; kc < n_kc; ++kc, ++blk) {
             // the block after this one (its patch is requested during this block's nine steps), if any
             const bool last_kc = kc + 1 == n_kc;
@@ -1040,38 +1092,67 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs a, int tiles_x, i
                     const int s_n0 = seq < 8 ? n0 : nn0, s_kc = seq < 8 ? kc : nkc;
                     const int s_tap = seq < 8 ? (seq + 1 < 9 ? 3 * ((seq + 1) % 3) + (seq + 1) / 3 : 0) : 0;
                     read_frags(dy, 0, bb, a0, b0);
-                    // the patch piece FIRST: it is this wave's only request that comes from HBM (every patch pixel is requested
-                    // once), and the next step's vmcnt(0) -- which is there for the weights, requested behind it -- also waits for
-                    // it: requested in the last chunk it had ~300 cycles of its ~1000 and every step stalled (-21 % measured)
-                    if (has_next) issue_a(nb_, nY0, nX0, nkc, seq, nbuf);
-                    if constexpr (GN) {
-                        if (has_next && seq == 0 && wave == NW - 1) issue_coef(nb_, nkc, cbuf0 + 128 * ((blk + 1) & 1));
-                    }
-                    if (pending) mma(a1, b1);                       // chunk 3 of the previous step of this tile
+                    // chunk 3 of the previous step, and behind its first MFMA the address arithmetic of this step's patch piece (~35
+                    // vector instructions that otherwise stand between the barrier and the first MFMA, every step); the request itself
+                    // right behind the second -- early in the step: it is this wave's only request that comes from HBM (every patch
+                    // pixel is requested once), and the next step's vmcnt(0), which is there for the weights requested behind it, also
+                    // waits for it: requested in the last chunk it had ~300 cycles of its ~1000 and every step stalled (-21 % measured)
+                    unsigned a_off_now = OOB;
+                    static_for_c<0, MT * NT>([&](auto k_tag) __attribute__((always_inline)) {
+                        constexpr int k = decltype(k_tag)::value;
+                        acc[k / NT][k % NT] = DM_MFMA_32x32x16(b1[k % NT], a1[k / NT], acc[k / NT][k % NT]);
+                        if constexpr (k == 0) a_off_now = a_offset(nb_, nY0, nX0, nkc, seq);
+                        if constexpr (k == 1) {
+                            if (has_next) issue_a_at(a_off_now, seq, nbuf);
+                            if constexpr (GN) {
+                                if (has_next && seq == 0 && wave == NW - 1) issue_coef(nb_, nkc, cbuf0 + 128 * ((blk + 1) & 1));
+                            }
+                        }
+                        if constexpr (k <= 1) __builtin_amdgcn_sched_barrier(0);
+                    });
                     __builtin_amdgcn_sched_barrier(0);
+                    // chunks 1-3: fragment reads of the next chunk, the weight requests, the chunk's MFMAs -- and (GN) behind each MFMA one
+                    // phase of the transform of the patch piece this wave requested a step ago (it has landed: this step's vmcnt(0); its
+                    // coefficients were requested at the block's first step and are visible since this step's barrier): ~8 vector
+                    // instructions per MFMA shadow.  As one block in front of a chunk's MFMAs the ~100 instructions held the matrix pipe
+                    // idle for their whole length, every step (conv + GroupNorm 713 us where the plain patch kernel took 605)
+                    [[maybe_unused]] const bool gn_live = has_next && seq >= 1;
+                    [[maybe_unused]] const int gn_j = seq >= 1 ? seq - 1 : 0;
+                    [[maybe_unused]] const float* gn_cb = cbuf0 + 128 * ((blk + 1) & 1);
+                    auto chunk_mma = [&](auto c_tag, const elem8 (&af)[MT], const elem8 (&bf)[NT]) __attribute__((always_inline)) {
+                        constexpr int C = decltype(c_tag)::value;       // 0, 1, 2 = chunks 1, 2, 3 of the step
+                        if constexpr (GN) {
+                            static_for_c<0, MT * NT>([&](auto k_tag) __attribute__((always_inline)) {
+                                constexpr int k = decltype(k_tag)::value;
+                                acc[k / NT][k % NT] = DM_MFMA_32x32x16(bf[k % NT], af[k / NT], acc[k / NT][k % NT]);
+                                // phase schedule: chunk 1 carries phases 0, 1 behind its MFMAs 2 and 4 (the weight requests sit in front of
+                                // them), chunks 2 and 3 the rest, one per MFMA
+                                constexpr int ph = C == 0 ? (k == 2 ? 0 : (k == 4 ? 1 : -1)) : 2 + (C - 1) * (MT * NT) + k;
+                                if constexpr (ph >= 0 && ph < kGnPhases) gn_phase(std::integral_constant<int, ph>{}, gn_live, nY0, nX0, gn_j, nbuf, gn_cb);
+                                __builtin_amdgcn_sched_barrier(0);
+                            });
+                        } else {
+                            mma(af, bf);
+                        }
+                    };
+                    static_assert(!GN || 2 + 2 * MT * NT >= kGnPhases, "enough MFMAs in chunks 2 and 3 for the transform's phases");
                     read_frags(dy, 1, bb, a1, b1);
                     if (step_next) {
 #pragma unroll
                         for (int q = 0; q < (B_INSTR + 1) / 2; ++q) issue_b(s_n0, s_kc, s_tap, q, nst);
                     }
-                    mma(a0, b0);
+                    chunk_mma(std::integral_constant<int, 0>{}, a0, b0);
                     __builtin_amdgcn_sched_barrier(0);
                     read_frags(dy, 2, bb, a0, b0);
                     if (step_next) {
 #pragma unroll
                         for (int q = (B_INSTR + 1) / 2; q < B_INSTR; ++q) issue_b(s_n0, s_kc, s_tap, q, nst);
                     }
-                    mma(a1, b1);
+                    chunk_mma(std::integral_constant<int, 1>{}, a1, b1);
                     __builtin_amdgcn_sched_barrier(0);
                     read_frags(dy, 3, bb, a1, b1);
-                    if constexpr (GN) {
-                        // the piece this wave requested a step ago has landed (this step's vmcnt(0)); its coefficients were requested at
-                        // the block's first step and are visible since this step's barrier
-                        if (has_next && seq >= 1) gn_transform(nY0, nX0, seq - 1, nbuf, cbuf0 + 128 * ((blk + 1) & 1));
-                    }
-                    mma(a0, b0);
+                    chunk_mma(std::integral_constant<int, 2>{}, a0, b0);
                     __builtin_amdgcn_sched_barrier(0);
-                    pending = true;
                     ++sidx;
                 }
             }
@@ -1160,7 +1241,7 @@ template <int TH, int BN, int WMW, int NB, bool GN = false>
 int launch_conv_halo(const ConvArgs& a, hipStream_t stream) {
     constexpr int PA = ((16 + 2) * (TH + 2) + 7) / 8;
     static_assert(PA <= 64, "no patch piece is requested in a block's last step (GN transforms a piece one step after its request)");
-    constexpr int LDS = 2 * PA * 1024 + NB * BN * 128 + (GN ? 1024 : 0);
+    constexpr int LDS = 2 * PA * 1024 + NB * BN * 128 + (GN ? 2048 : 0);        // (GN: coefficient buffers + the transform's dummy piece)
     static_assert(LDS <= 160 * 1024, "LDS budget");
     if (GN && !a.gn_coef) return DM_ERR_ARG;
     static bool attr_set = false;
