@@ -157,7 +157,7 @@ def pmc_traffic(kernel_key, batch):
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_final.json")))
     if not files:
         return None
-    m = re.search(r"conv3x3\[(\d+)->(\d+)@(\d+)x(\d+),s1\]", kernel_key)
+    m = re.search(r"conv3x3\[(?:gn\+)?(\d+)->(\d+)@(\d+)x(\d+),s1\]", kernel_key)      # (a `gn+` launch moves the same tensors)
     m2 = re.search(r"attention_fwd_bf16\[Sq=(\d+),Skv=(\d+),h=(\d+),D=(\d+)\]", kernel_key)
     if m:
         cin, cout, h, w = (int(g) for g in m.groups())
@@ -552,10 +552,20 @@ def main():
             conv[roof_key] = dict(kt_live[roof_key], launches=kt_live[roof_key]["launches"] * roof_steps / a.steps)
         gemm = {k: v for k, v in kt.items() if k.startswith("gemm")}
         if conv:      # the dominant hand-written kernel of the step by time
-            res["roofline"] = mfma_entry("k_conv3x3_dma<9 taps> (persistent LDS-DMA implicit GEMM)", conv, roof_steps,
+            res["roofline"] = mfma_entry("k_conv3x3_halo / k_conv3x3_dma<9 taps> (persistent LDS-DMA implicit GEMM; halo-patch kernel where "
+                                         "the shape has enough patches, `gn+` = GroupNorm apply + SiLU folded into it)", conv, roof_steps,
                                          "dominant shape: timed region; all_shapes: extra steps after it")
             if roof_key in kt_live:
                 res["roofline"]["launches_timed"] = kt_live[roof_key]["launches"]
+            # a `gn+` row's time includes the folded GroupNorm apply pass (its FLOPs are not counted): the SAME shape without it (the
+            # data-gradient launches of the VAE encoder's backward) beside it
+            if roof_key.startswith("conv3x3[gn+"):
+                plain = roof_key.replace("conv3x3[gn+", "conv3x3[")
+                if plain in kt:
+                    rp = kt[plain]
+                    tfp = rp["work_per_launch"] / (rp["avg_ms"] * 1e-3) / 1e12
+                    res["roofline"]["same_shape_without_groupnorm"] = {"kernel": plain, "avg_us": rp["avg_ms"] * 1e3, "achieved": tfp, "frac": tfp / 2500.0,
+                                                                       "launches_timed": rp["launches"]}
         if attn:      # north_star target: >= 50 % MFMA
             res["roofline_attention"] = mfma_entry(("k_attn_fwd_fp8 (S >= 1024) + " if a.attention == "fp8" else "") + "k_attn_fwd_w128 / k_attn_fwd_w64 / k_attn_fwd_v3 (dispatch: " + hipops.attention_variant() + ")", attn)
             if "roofline" not in res:

@@ -1519,7 +1519,8 @@ int conv_tile_choice(long long M, int Cout) {
 }
 
 // Which halo-patch variant (k_conv3x3_halo) serves this launch: 24 = 384 x 128 patches (the Cout = 128 layers that took the
-// 512 x 128 tile), 16 = 256 x 256 patches (where the 256 x 256 tile ran), 0 = none (the per-tap kernels).  Stride 1, pad 1,
+// 512 x 128 tile), 16 = 256 x 256 patches (where the 256 x 256 tile ran), 128 = 256 x 128 patches with three weight stages (where the
+// 256 x 128 tile ran on whole channel tiles and whole 16 x 16 patches), 0 = none (the per-tap kernels).  Stride 1, pad 1,
 // Cin % 64 == 0, enough patches to fill the chip.  DREAMMAT_CONV_HALO=0: off (A/B runs; a forced tile variant also turns it off:
 // the tile-variant tests compare the per-tap kernels bit for bit); =24 | 16 forces a variant whatever the size (tests: ragged
 // bands / columns, tiny images).
@@ -1530,9 +1531,14 @@ int conv_halo_choice(const ConvArgs& a) {
     if (halo_env && halo_env[0] == '0') return 0;
     if (halo_env && !strcmp(halo_env, "24")) return 24;
     if (halo_env && !strcmp(halo_env, "16")) return 16;
+    if (halo_env && !strcmp(halo_env, "128")) return 128;
     const int tile = conv_tile_choice(a.M, a.Cout);
     if (tile == 640 && a.Cout == 128) return 24;      // (the Cout = 640 layers at 32 x 32 lose a third to the ragged second band and re-request the patch per channel tile: 800 vs 1100 TF/s)
     if (tile == 512) return 16;
+    // 256 x 128 patches, three weight stages, where the 256 x 128 tile ran with whole 128-wide channel tiles (the 1280-channel layers
+    // at 16 x 16: one patch per image): 24 x 1280->1280 909 -> 1097 TF/s, 2560->1280 826 -> 1012; not the 640-channel layers at 32 x 32
+    // (-2 %), not ragged channel tiles (320: -15 %)
+    if (tile == 256 && a.Cout % 128 == 0 && a.Hout % 16 == 0 && a.Wout % 16 == 0) return 128;
     return 0;
 }
 
@@ -1571,6 +1577,7 @@ int DM_T(dm_conv3x3_gn_nhwc_, _fused)(const void* x, const float* gn_coef, int g
     switch (conv_halo_choice(a)) {
     case 24: return launch_conv_halo<24, 128, 4, 2, true>(a, stream);
     case 16: return launch_conv_halo<16, 256, 2, 2, true>(a, stream);
+    case 128: return launch_conv_halo<16, 128, 4, 3, true>(a, stream);
     default: return DM_ERR_UNSUPPORTED;
     }
 }
@@ -1609,6 +1616,7 @@ int DM_T(dm_conv3x3_nhwc_, _fused)(const void* x, const void* w, const void* bia
         switch (conv_halo_choice(a)) {
         case 24: { int rc = launch_conv_halo<24, 128, 4, 2>(a, stream); if (rc != DM_ERR_UNSUPPORTED) return rc; break; }
         case 16: { int rc = launch_conv_halo<16, 256, 2, 2>(a, stream); if (rc != DM_ERR_UNSUPPORTED) return rc; break; }
+        case 128: { int rc = launch_conv_halo<16, 128, 4, 3>(a, stream); if (rc != DM_ERR_UNSUPPORTED) return rc; break; }
         default: break;
         }
         switch (tile) {
