@@ -102,6 +102,9 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
     const int k_tile_bytes = (int)(a.k_ss * 2 * kTile);
     // piece 0, 1: this wave's two 1 KiB slices of the K tile; 2, 3: of the V^T tile
     auto issue_piece = [&](int tile, int stage, int i) __attribute__((always_inline)) {
+#if defined(DM_ABL_NODMA)
+        if (tile > 4) return;                             // ABLATION (wrong results): K / V^T requested for the first tiles only
+#endif
         const int tc = min(tile, n_tiles - 1);            // tiles past the end re-fetch the last one (keeps the vmcnt counts
         char* sb = smem + stage * kStage;                 // uniform; their stage is never read)
         if (i < 2)
@@ -355,8 +358,12 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
                 }
                 {
                     constexpr int qb = p % NQ, ks = p / NQ, t = ks >> 1, r = 8 * (ks & 1) + 2 * c4;
+#if defined(DM_ABL_NOEXP)
+                    asm volatile("" : "+v"(s[qb][t][r]), "+v"(s[qb][t][r + 1]));      // ABLATION (wrong results): no exponentials
+#else
                     s[qb][t][r] = __builtin_amdgcn_exp2f(s[qb][t][r]);
                     s[qb][t][r + 1] = __builtin_amdgcn_exp2f(s[qb][t][r + 1]);
+#endif
                 }
             }
             __builtin_amdgcn_sched_barrier(0);                     // exponentials first: their consumers are a whole chunk away
@@ -368,8 +375,10 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
                 elem2 pk = __builtin_convertvector(two, elem2);
                 pf[pq & 1][2 * e] = pk[0];
                 pf[pq & 1][2 * e + 1] = pk[1];
+#if !defined(DM_ABL_NOSUM)
                 lA[qb] += v0;
                 lB[qb] += v1;
+#endif
                 // keep the chains where they are: left alone, the SLP vectoriser gathers the adds into v_pk_add_f32
                 asm volatile("" : "+v"(lA[qb]), "+v"(lB[qb]));
             }
@@ -397,7 +406,9 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
     auto one = [&](auto r_tag) __attribute__((always_inline)) {     // tile j with j % NST == R: stages of tiles j+1, j+2, j+2+PD
         constexpr int R = decltype(r_tag)::value;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * kL) : "memory");     // tile j+2 has landed
+#if !defined(DM_ABL_NOBAR)
         __builtin_amdgcn_s_barrier();
+#endif
         tile_body(std::integral_constant<int, R>{}, std::integral_constant<int, (R + 1) % NST>{}, std::integral_constant<int, (R + 2) % NST>{},
                   std::integral_constant<int, (R + 2 + PD) % NST>{}, j + 2 + PD, std::false_type{}, 0);
         ++j;
@@ -426,6 +437,9 @@ __global__ __launch_bounds__(256, 1) void k_attn_fwd_w128(AttnArgs a) {
         l_tot[qb] = lt + __shfl_xor(lt, 32);
         bad = bad || !(l_tot[qb] < DM_P_SUM_MAX) || !(l_tot[qb] > DM_P_SUM_MIN);     // overflow, NaN, or a row underflowed by a shared shift
     }
+#if defined(DM_ABL_NOEXP) || defined(DM_ABL_NOSUM) || defined(DM_ABL_NODMA)
+    bad = false;                                         // (ablation builds: garbage sums must not send the workgroup down the exact path)
+#endif
     // ---- exact path (rare): some row overflowed the lazy shift.  The whole workgroup redoes its block with the textbook
     // online softmax, one tile at a time through stage 0.
     if (__syncthreads_or(bad)) {

@@ -31,6 +31,13 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+// which of `n_ph` phases runs behind MFMA `slot` of `total` when phase p sits behind MFMA ceil(p * total / n_ph) (-1: none)
+constexpr int gn_phase_of_slot(int slot, int total, int n_ph) {
+    for (int p = 0; p < n_ph; ++p)
+        if ((p * total + n_ph - 1) / n_ph == slot) return p;
+    return -1;
+}
+
 // compile-time loop (indices as types: bodies whose register indices must all be constants)
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for_c(F&& f) {
@@ -1125,17 +1132,18 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs a, int tiles_x, i
                             static_for_c<0, MT * NT>([&](auto k_tag) __attribute__((always_inline)) {
                                 constexpr int k = decltype(k_tag)::value;
                                 acc[k / NT][k % NT] = DM_MFMA_32x32x16(bf[k % NT], af[k / NT], acc[k / NT][k % NT]);
-                                // phase schedule: chunk 1 carries phases 0, 1 behind its MFMAs 2 and 4 (the weight requests sit in front of
-                                // them), chunks 2 and 3 the rest, one per MFMA
-                                constexpr int ph = C == 0 ? (k == 2 ? 0 : (k == 4 ? 1 : -1)) : 2 + (C - 1) * (MT * NT) + k;
-                                if constexpr (ph >= 0 && ph < kGnPhases) gn_phase(std::integral_constant<int, ph>{}, gn_live, nY0, nX0, gn_j, nbuf, gn_cb);
+                                // phase schedule: the twelve phases spread evenly over the 3 MT NT MFMAs of chunks 1-3 (phase p behind MFMA
+                                // ceil(p * total / 12): every MFMA at 2 x 2 fragments, every second one at 4 x 2)
+                                constexpr int total = 3 * MT * NT, slot = C * MT * NT + k;
+                                constexpr int ph = gn_phase_of_slot(slot, total, kGnPhases);
+                                if constexpr (ph >= 0) gn_phase(std::integral_constant<int, ph>{}, gn_live, nY0, nX0, gn_j, nbuf, gn_cb);
                                 __builtin_amdgcn_sched_barrier(0);
                             });
                         } else {
                             mma(af, bf);
                         }
                     };
-                    static_assert(!GN || 2 + 2 * MT * NT >= kGnPhases, "enough MFMAs in chunks 2 and 3 for the transform's phases");
+                    static_assert(!GN || 3 * MT * NT >= kGnPhases, "enough MFMAs in chunks 1-3 for the transform's phases");
                     read_frags(dy, 1, bb, a1, b1);
                     if (step_next) {
 #pragma unroll
