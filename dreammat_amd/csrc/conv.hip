@@ -735,6 +735,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
                         const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
                         const int c0 = ob + 16 * gp + 8 * hi;
                         const u32x4 out = {s0[0], s1[0], s0[1], s1[1]};
+#if defined(DM_ABL_NOSTORE)
+                        if (a.M < 0)      // ABLATION (wrong results): the output is never stored
+#endif
                         __builtin_amdgcn_raw_buffer_store_b128(out, yrs, (int)(poff[i] != OOB && c0 < OC ? poff[i] + (unsigned)c0 * 2u : OOB), 0, 0);
                     }
             }
@@ -805,6 +808,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
                         const int delta = ((up ? -1 : 1) * (py * Wd + px) * cs + (cb - blk * cs)) * 2;
                         off = ((s_ok[i] >> blk) & 1u) && c0 < OC ? s_base[i] + (unsigned)delta + 16u * (unsigned)hi : OOB;
                     }
+#if defined(DM_ABL_NOSTORE)
+                    if (a.M < 0)      // ABLATION (wrong results): the output is never stored
+#endif
                     __builtin_amdgcn_raw_buffer_store_b128(out, yrs, (int)off, 0, 0);
                 }
             }
