@@ -895,22 +895,27 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs a, int tiles_x, i
         b = (int)bb;
     };
     [[maybe_unused]] int sidx_abl = 0;                      // (ablation builds: 0 during the prologue, then 1)
-    // patch piece j of this wave (piece index wave + 8 j), channel block kc of the patch at (image b, rows from Y0, columns from X0):
+    // Where this lane's slot of this wave's patch piece j (piece index wave + 8 j) lies in the patch does not depend on the tile: one
+    // packed word per piece, formed once -- patch row | column << 8 | 16-byte channel chunk of the slot << 16 | (inside the patch) << 20.
+    // (Recomputed per step it was ~25 vector instructions per piece, twice with the GroupNorm transform: a division by 18 each.)
+    int pinfo[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int i = wave + NW * j;
+        const int p = 8 * min(i, PA - 1) + (lane >> 3);
+        const int prow = p / PW, pcol = p - prow * PW;
+        pinfo[j] = prow | (pcol << 8) | (((lane & 7) ^ ((pcol >> 1) & 7)) << 16) | ((i < PA && p < NPIX) ? 1 << 20 : 0);
+    }
+    // patch piece j of this wave, channel block kc of the patch at (image b, rows from Y0, columns from X0):
     // this lane's source offset (straight-line code: it is scheduled behind an MFMA, see the K-step) ...
     auto a_offset = [&](int b, int Y0, int X0, int kc, int j) __attribute__((always_inline)) {
-        const int i = min(wave + NW * j, PA - 1);
-        // (the lane's pixel of the piece from an opaque copy of the thread id: left visible, the nine pieces' row / column pairs are
-        // hoisted out of the K loop and spilled -- a scratch reload, i.e. one more vector-memory request, per step)
-        int t_ = tid;
-        asm volatile("" : "+v"(t_));
-        const int p = 8 * i + ((t_ & 63) >> 3);
-        const int prow = p / PW, pcol = p - prow * PW;
-        const int y = Y0 + prow - 1, x = X0 + pcol - 1;
-        const bool ok = p < NPIX && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        const int pi = pinfo[j];
+        const int y = Y0 + (pi & 0xff) - 1, x = X0 + ((pi >> 8) & 0xff) - 1;
+        const bool ok = (pi >> 20) && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
         // out-of-image = zeros through the descriptor's range check (all lanes execute the request: an inactive lane would leave its
         // LDS slot stale)
         const unsigned off = ((((unsigned)b * (unsigned)H + (unsigned)y) * (unsigned)W + (unsigned)x) * (unsigned)Cin + (unsigned)(kc * 64) +
-                              (unsigned)(((t_ & 7) ^ ((pcol >> 1) & 7)) * 8)) * 2u;
+                              (unsigned)(((pi >> 16) & 7) * 8)) * 2u;
         return ok ? off : OOB;
     };
     // ... and the request itself (waves whose piece index is past the patch request nothing)
@@ -958,26 +963,20 @@ __global__ __launch_bounds__(512) void k_conv3x3_halo(ConvArgs a, int tiles_x, i
     [[maybe_unused]] float gs_z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // phases: 0 = the lane's pixel / slot, 1 = the five LDS reads, 2 .. 9 = one channel each (z = x A + S, SiLU), 10 = pack + select, 11 = write
     constexpr int kGnPhases = 12;
-    [[maybe_unused]] int gs_p = 0, gs_i = 0;
     [[maybe_unused]] bool gs_live = false;
     [[maybe_unused]] auto gn_phase = [&](auto ph_tag, bool live, int Y0, int X0, int j, char* buf, const float* cb) __attribute__((always_inline)) {
         constexpr int PH = decltype(ph_tag)::value;
         if constexpr (PH == 0) {
             const int i_raw = wave + NW * j;
             gs_live = live && i_raw < PA;
-            gs_i = gs_live ? i_raw : 0;
+            const int pi = pinfo[j];
+            const int y = Y0 + (pi & 0xff) - 1, x = X0 + ((pi >> 8) & 0xff) - 1;
+            gs_ok = gs_live && (pi >> 20) && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
             int t_ = tid;
             asm volatile("" : "+v"(t_));
-            gs_p = 8 * gs_i + ((t_ & 63) >> 3);
+            gs_q = (int)((gs_live ? buf + i_raw * 1024 : dummy) - smem) + (t_ & 63) * 16;
         } else if constexpr (PH == 1) {
-            int t_ = tid;
-            asm volatile("" : "+v"(t_));
-            const int L = t_ & 63;
-            const int prow = gs_p / PW, pcol = gs_p - prow * PW;
-            const int y = Y0 + prow - 1, x = X0 + pcol - 1;
-            gs_ok = gs_live && gs_p < NPIX && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-            const int cidx = (L & 7) ^ ((pcol >> 1) & 7);       // which 8 channels of the block this slot holds
-            gs_q = (int)((gs_live ? buf + gs_i * 1024 : dummy) - smem) + L * 16;
+            const int cidx = (pinfo[j] >> 16) & 7;              // which 8 channels of the block this slot holds
             gs_raw = *reinterpret_cast<const u32x4*>(smem + gs_q);
             gs_A0 = *reinterpret_cast<const f32x4v*>(cb + cidx * 8); gs_A1 = *reinterpret_cast<const f32x4v*>(cb + cidx * 8 + 4);
             gs_S0 = *reinterpret_cast<const f32x4v*>(cb + 64 + cidx * 8); gs_S1 = *reinterpret_cast<const f32x4v*>(cb + 64 + cidx * 8 + 4);

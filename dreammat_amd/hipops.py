@@ -1123,10 +1123,20 @@ class _GroupNormAct(torch.autograd.Function):
 GN_CONV_FOLD = os.environ.get("DREAMMAT_GN_FOLD", "1") != "0"
 
 
+# The fold pays where the apply pass it removes is expensive: measured (tools/halo_gn_time.py, one box, f16, microseconds: statistics +
+# folded convolution | two-launch GroupNorm + the same patch kernel):  8 x 512^2 x 128: 912 | 969    8 x 256^2 x 256: 602 | 690
+# 8 x 128^2 x 512: 554 | 562    8 x 64^2 x 512: 155 | 157    24 x 16^2 x 1280: 195 | 179 -- the transform (~110 vector instructions per 1 KB
+# piece beside the MFMAs) costs the convolution 40-180 us, the apply pass costs two passes over the tensor.  From 192 MB on (the VAE
+# encoder's 512^2 and 256^2 levels at 8 views); tests assign 0 to exercise the fold on small tensors.
+GN_FOLD_MIN_BYTES = 192 << 20
+
+
 def gn_conv3x3_ok(x_nhwc, gamma, cout):
-    """the halo-patch kernel serves conv3x3(act(GroupNorm32(x))) at this shape (stride 1, pad 1): dm_conv3x3_gn_ok"""
+    """the halo-patch kernel serves conv3x3(act(GroupNorm32(x))) at this shape (stride 1, pad 1: dm_conv3x3_gn_ok) and the tensor is
+    large enough for the fold to pay"""
     B, H, W, C = x_nhwc.shape
     return (GN_CONV_FOLD and x_nhwc.is_cuda and x_nhwc.dtype in HALF_DTYPES and gamma.dtype == x_nhwc.dtype and C % 64 == 0
+            and 2 * B * H * W * C >= GN_FOLD_MIN_BYTES
             and 2 * B * H * W * max(C, cout) <= CONV_MAX_TENSOR_BYTES and bool(_lib.lib().dm_conv3x3_gn_ok(B, H, W, C, cout)))
 
 

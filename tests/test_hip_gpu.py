@@ -1131,6 +1131,7 @@ def test_conv3x3_with_groupnorm_apply_folded_in(dev, monkeypatch, dtype, halo, a
     stored, out-of-image pixels stay zero), and within rounding of fp32 torch."""
     if halo:
         monkeypatch.setenv("DREAMMAT_CONV_HALO", halo)
+    monkeypatch.setattr(hipops, "GN_FOLD_MIN_BYTES", 0)           # (the product folds from 192 MB on: where it pays)
     torch.manual_seed(22)
     x = (torch.randn(B, H, W, Cin) * 2 + 0.5).to(dtype)
     gm, bt = (torch.rand(Cin) + 0.5).to(dtype), torch.randn(Cin).to(dtype)
@@ -1153,12 +1154,13 @@ def test_conv3x3_with_groupnorm_apply_folded_in(dev, monkeypatch, dtype, halo, a
 
 
 @pytest.mark.parametrize("cin,cout,temb_ch,B,HW,grad", [(128, 128, 0, 8, 128, True), (128, 256, 0, 4, 128, True), (256, 256, 1280, 8, 96, False)])
-def test_resnet_block_with_folded_groupnorm_equals_the_two_call_form(dev, cin, cout, temb_ch, B, HW, grad):
+def test_resnet_block_with_folded_groupnorm_equals_the_two_call_form(dev, monkeypatch, cin, cout, temb_ch, B, HW, grad):
     """ResnetBlock2D with both GroupNorm apply passes folded into its convolutions (hipops.GN_CONV_FOLD) against the block with
     the apply kernels in front of the same convolution kernels: outputs and input gradients bit-equal (VAE encoder: under autograd,
     x reaching norm1 and the skip through one node; frozen nets: time-embedding row bias and residual in the epilogues), and no
     apply / forward GroupNorm launch left."""
     from dreammat_amd.sd import layers
+    monkeypatch.setattr(hipops, "GN_FOLD_MIN_BYTES", 0)
     torch.manual_seed(23)
     blk = layers.ResnetBlock2D(cin, cout, temb_ch, eps=1e-6).to(dev, torch.float16).eval()
     for p in blk.parameters():
