@@ -6,7 +6,7 @@ mkdir -p $R/gpurun_out
 : > $R/gpurun_out/ab_step.txt
 for pass in $(seq 1 ${AB_PASSES:-3}); do
   for which in old new; do
-    if [ $which = old ]; then d=$R/_ab_old; extra=""; else d=$R; extra="${AB_NEW_ARGS:-}"; fi      # AB_NEW_ARGS: flags only the new tree knows
+    if [ $which = old ]; then d=$R/_ab_old; extra="${AB_OLD_ARGS:-}"; else d=$R; extra="${AB_NEW_ARGS:-}"; fi      # AB_NEW_ARGS / AB_OLD_ARGS: flags only one tree knows
     (cd $d && timeout 200 python bench.py --steps 15 --warmup 3 --no-cpu-baseline $extra "$@" 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-end validation + measurement pass on the GPU box (rounds 2-5).  Writes small files to gpurun_out/ only; copy what is to be
+# Round-end validation + measurement pass on the GPU box (rounds 2-6).  Writes small files to gpurun_out/ only; copy what is to be
 # judged into profiles/ afterwards (tools/pmc_collect.py for the counters).
 #   1 full GPU test suite   2 default bench line (with the CPU baseline)   3 rocprofv3 --kernel-trace --stats of the same
 #   bench command + per-step kernel tables at 8 views and at 1 view per rank   4 A/B probe (also dumps the bench scene's real
@@ -25,31 +25,35 @@ cut -c1-120 gpurun_out/final_bench_line_raytracing.json
 timeout 200 python tools/mc_probe.py 100000 0 2>/dev/null | grep '^{' > gpurun_out/final_mc_probe.jsonl
 # round 5: the same step with the renderer's 7 logging outputs off (round 4's timed region), in IEEE half, and with the MX-FP8
 # self-attention; BASELINE configs[4] as a preset (16 views @1024^2, 200 k triangles, f16 nets + fp8 attention)
-timeout 300 python bench.py --no-cpu-baseline --no-f16-leg --no-debug-outputs 2>/dev/null < /dev/null | grep '^{"metric' > gpurun_out/final_bench_line_nodebug.json
-timeout 300 python bench.py --no-cpu-baseline --dtype f16 2>/dev/null < /dev/null | grep '^{"metric' > gpurun_out/final_bench_line_f16.json
-timeout 300 python bench.py --no-cpu-baseline --dtype f16 --attention fp8 2>/dev/null < /dev/null | grep '^{"metric' > gpurun_out/final_bench_line_f16_fp8.json
+# round 6: the main line runs IEEE half (bf16 = its second leg); the bf16 line on its own, the round-5 conv path (per-tap kernels, no
+# GroupNorm fold) on the same box, fp8 attention, the SD-1.5 shape set, BASELINE configs[4]'s shape
+timeout 300 python bench.py --no-cpu-baseline --no-second-leg --no-debug-outputs 2>/dev/null < /dev/null | grep '^{"metric' > gpurun_out/final_bench_line_nodebug.json
+timeout 300 python bench.py --no-cpu-baseline --no-second-leg --dtype bf16 2>/dev/null < /dev/null | grep '^{"metric' > gpurun_out/final_bench_line_bf16.json
+DREAMMAT_CONV_HALO=0 timeout 300 python bench.py --no-cpu-baseline --no-second-leg --dtype bf16 2>/dev/null < /dev/null | grep '^{"metric' > gpurun_out/final_bench_line_bf16_r5_conv_path.json
+timeout 300 python bench.py --no-cpu-baseline --no-second-leg --attention fp8 2>/dev/null < /dev/null | grep '^{"metric' > gpurun_out/final_bench_line_f16_fp8.json
+timeout 400 python bench.py --no-cpu-baseline --no-second-leg --sd sd15 2>/dev/null < /dev/null | grep '^{"metric' > gpurun_out/final_bench_line_sd15.json
 timeout 600 python bench.py --no-cpu-baseline --cfg5 --steps 3 --warmup 1 2>gpurun_out/final_cfg5.err < /dev/null | grep '^{"metric' > gpurun_out/final_cfg5_bench_line.json
-for f in nodebug f16 f16_fp8; do python3 -c "import json; d=json.load(open('gpurun_out/final_bench_line_$f.json')); print('$f', d['dtype'], round(d['value'],3), round(d['ms_per_step'],2))"; done
+for f in nodebug bf16 bf16_r5_conv_path f16_fp8 sd15; do python3 -c "import json; d=json.load(open('gpurun_out/final_bench_line_$f.json')); print('$f', d['dtype'], round(d['value'],3), round(d['ms_per_step'],2))"; done
 python3 -c "import json; d=json.load(open('gpurun_out/final_cfg5_bench_line.json')); print('cfg5', d['dtype'], round(d['value'],3), round(d['ms_per_step'],1), d['config']['peak_hbm_gb'])" || tail -3 gpurun_out/final_cfg5.err
 tools/_dma_probe > gpurun_out/final_dma_probe.jsonl 2>&1
 [ "${FINAL_QUICK:-0}" = 1 ] && { python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1; exit 0; }
 export TMPDIR=/tmp
 for v in 8 1; do
   rm -rf /tmp/prof_final_$v
-  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_final_$v -- python $R/bench.py --views $v --steps 4 --warmup 2 --no-cpu-baseline --no-f16-leg > $R/gpurun_out/final_rocprof_$v.log 2>&1 < /dev/null)
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_final_$v -- python $R/bench.py --views $v --steps 4 --warmup 2 --no-cpu-baseline --no-second-leg > $R/gpurun_out/final_rocprof_$v.log 2>&1 < /dev/null)
   f=$(find /tmp/prof_final_$v -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/final_kernel_stats_${v}views.csv
   f=$(find /tmp/prof_final_$v -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python3 tools/step_window.py "$f" 3 6 > gpurun_out/final_step_kernels_${v}views.csv
   head -1 gpurun_out/final_step_kernels_${v}views.csv | cut -c40-160
 done
-for v in 8 4 2 1; do timeout 200 python bench.py --views $v --steps 6 --warmup 2 --no-cpu-baseline --no-f16-leg 2>/dev/null < /dev/null | grep '^{"metric' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'views': $v, 'steps_per_s': d['value'], 'ms_per_step': d['ms_per_step']}))"; done > gpurun_out/final_views_table.jsonl
+for v in 8 4 2 1; do timeout 200 python bench.py --views $v --steps 6 --warmup 2 --no-cpu-baseline --no-second-leg 2>/dev/null < /dev/null | grep '^{"metric' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'views': $v, 'steps_per_s': d['value'], 'ms_per_step': d['ms_per_step']}))"; done > gpurun_out/final_views_table.jsonl
 timeout 200 bash tools/gemm_fit.sh > gpurun_out/final_gemm_shapes.txt 2>&1
-[ -d _ab_old ] && AB_NEW_ARGS="--no-debug-outputs --no-f16-leg" tools/ab_step.sh > /dev/null 2>&1      # step time against the older tree in _ab_old/, same box -> gpurun_out/ab_step.txt
+[ -d _ab_old ] && AB_NEW_ARGS="--no-debug-outputs --no-second-leg" tools/ab_step.sh > /dev/null 2>&1      # step time against the older tree in _ab_old/, same box -> gpurun_out/ab_step.txt
 # FINAL_SKIP_PMC=1: no probes / counter passes (the conv, attention and shade kernels have not changed since the last collection)
 [ "${FINAL_SKIP_PMC:-0}" = 1 ] && { python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1; exit 0; }
 PYTHONPATH=$R timeout 400 python tools/r2_probe.py --rounds 2 --iters 10 --skip-shade --variants auto,w128,w64 --out final_probe.json > gpurun_out/final_r2_probe.log 2>&1 < /dev/null
 # round 4: the shade kernels on the bench scene (row / tile order, round-3 loop vs round-4 loop) + on the step's REAL inputs; the
 # probe also dumps the tile-ordered case for the counter passes
-timeout 300 python bench.py --no-cpu-baseline --no-f16-leg --steps 4 --dump-shade /tmp/shade_case.pt > /dev/null 2>&1 < /dev/null
+timeout 300 python bench.py --no-cpu-baseline --no-second-leg --steps 4 --dump-shade /tmp/shade_case.pt > /dev/null 2>&1 < /dev/null
 timeout 200 python tools/r4_shade_probe.py --rounds 3 --iters 20 > gpurun_out/final_shade_probe.log 2>&1 < /dev/null
 timeout 200 python tools/r4_shade_probe.py --case /tmp/shade_case.pt --rounds 3 --iters 20 > gpurun_out/final_shade_case.log 2>&1 < /dev/null
 grep '"op": "shade_bench_case"' gpurun_out/final_shade_case.log | cut -c1-200 | tail -5
@@ -57,5 +61,6 @@ PMC_SECTIONS="conv attn shade" SHADE_CASES="rgb18e8" ATTN_VARIANTS="w128 w64" AT
 DREAMMAT_ATTN_TIMELINE=1 tools/_abi_pmc attn 24 5 4096 4096 64 1 w128 2>&1 | grep "wg 300" | tail -4 > gpurun_out/final_attn_timeline.txt
 DREAMMAT_ATTN_TIMELINE=1 tools/_abi_pmc attn 24 5 4096 4096 64 1 w64 2>&1 | grep "wg 300" | tail -4 >> gpurun_out/final_attn_timeline.txt
 bash tools/conv_b3.sh > gpurun_out/final_conv_batch3.txt 2>&1
+timeout 200 python tools/halo_gn_time.py 2>/dev/null | grep '^{' > gpurun_out/final_halo_gn_time.jsonl
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
 ls gpurun_out/pmc_r2 | wc -l

@@ -26,8 +26,9 @@ rocprofv3 -L > $OUT/counters_available.txt 2>&1
 SECTIONS=${PMC_SECTIONS:-attn shade}
 if [[ " $SECTIONS " == *" conv "* ]]; then
   # the dominant conv shapes: 8 x 128->128 @512^2 (VAE, tile 640) and 24 x 320->320 @64^2 (UNet, tile 320)
-  for case in "640 8 512 512 128 128" "320 24 64 64 320 320" "512 24 64 64 512 512" "256 24 32 32 640 640"; do
-    set -- $case; export DREAMMAT_CONV_TILE=$1; shift 1
+  # (round 6: "-" = the dispatcher's own choice -- the halo-patch kernel for the first and third shape; a forced tile turns it off)
+  for case in "- 8 512 512 128 128" "- 8 128 128 512 512" "320 24 64 64 320 320" "256 24 32 32 640 640"; do
+    set -- $case; if [ "$1" != "-" ]; then export DREAMMAT_CONV_TILE=$1; fi; shift 1
     nm=$(echo "$@" | tr ' ' '_')              # conv_<B>_<H>_<W>_<Cin>_<Cout>: the tag bench.py's pmc_traffic() looks up
     run_stats conv_$nm conv "$@" 10
     run_pmc sq_conv_$nm "$SQ" conv "$@" 5
