@@ -47,7 +47,7 @@ for v in 8 1; do
 done
 for v in 8 4 2 1; do timeout 200 python bench.py --views $v --steps 6 --warmup 2 --no-cpu-baseline --no-second-leg 2>/dev/null < /dev/null | grep '^{"metric' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(json.dumps({'views': $v, 'steps_per_s': d['value'], 'ms_per_step': d['ms_per_step']}))"; done > gpurun_out/final_views_table.jsonl
 timeout 200 bash tools/gemm_fit.sh > gpurun_out/final_gemm_shapes.txt 2>&1
-[ -d _ab_old ] && AB_NEW_ARGS="--no-debug-outputs --no-second-leg" tools/ab_step.sh > /dev/null 2>&1      # step time against the older tree in _ab_old/, same box -> gpurun_out/ab_step.txt
+[ -d _ab_old ] && AB_OLD_ARGS="--no-debug-outputs --no-f16-leg --dtype f16" AB_NEW_ARGS="--no-debug-outputs --no-second-leg --no-calibration" tools/ab_step.sh > /dev/null 2>&1      # step time against the older tree in _ab_old/, same box -> gpurun_out/ab_step.txt
 # FINAL_SKIP_PMC=1: no probes / counter passes (the conv, attention and shade kernels have not changed since the last collection)
 [ "${FINAL_SKIP_PMC:-0}" = 1 ] && { python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1; exit 0; }
 PYTHONPATH=$R timeout 400 python tools/r2_probe.py --rounds 2 --iters 10 --skip-shade --variants auto,w128,w64 --out final_probe.json > gpurun_out/final_r2_probe.log 2>&1 < /dev/null
