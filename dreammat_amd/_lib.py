@@ -141,6 +141,7 @@ _SIGS = {
     "dm_groupnorm_workspace_floats": (c_size_t, [c_int, c_int]),
     "dm_groupnorm_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                       c_int, c_void_p]),
+    "dm_linear_small_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _LL, c_int, c_int, c_void_p]),
     "dm_groupnorm_nhwc_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "dm_conv3x3_gn_ok": (c_int, [c_int] * 5),
     "dm_conv3x3_gn_nhwc_bf16_fused": (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
@@ -165,7 +166,7 @@ _SIGS = {
 for _n in ("dm_attention_fwd_bf16", "dm_attention_fwd_lse_bf16", "dm_conv3x3_nhwc_bf16", "dm_conv3x3_nhwc_bf16_fused",
            "dm_conv2x2_nhwc_bf16", "dm_conv2x2_subpixel_nhwc_bf16", "dm_conv3x3_small_nhwc_bf16", "dm_conv3x3_small_res_nhwc_bf16", "dm_gemm_bf16_fused",
            "dm_layernorm_bf16", "dm_geglu_bf16", "dm_cat_add_bf16", "dm_softmax_rows_bf16", "dm_softmax_rows_bwd_bf16",
-           "dm_conv3x3_gn_nhwc_bf16_fused"):
+           "dm_conv3x3_gn_nhwc_bf16_fused", "dm_linear_small_bf16"):
     _SIGS[_n.replace("bf16", "f16")] = _SIGS[_n]
 for _n in ("dm_groupnorm_nhwc_fwd", "dm_groupnorm_nhwc_infer", "dm_groupnorm_nhwc_bwd", "dm_groupnorm_nhwc_bwd_res", "dm_groupnorm_nhwc_stats"):
     _SIGS[_n + "_f16"] = _SIGS[_n]

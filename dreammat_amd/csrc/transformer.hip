@@ -4,6 +4,8 @@
 // (LayerNorm: 1 read + 1 write, GEGLU: 2 reads + 1 write of [tokens, C] bf16), so each is one pass with 16 B
 // accesses.  Forward only: the diffusion nets run without autograd in score distillation (the SDS gradient is
 // injected at the latents, dreammat_guidance.py:385-397).
+#include <algorithm>
+
 #include "dm_common.h"
 #include "dm_elem.h"
 
@@ -201,7 +203,50 @@ __global__ __launch_bounds__(256) void k_cat_add(const elem_t* __restrict__ x, c
 
 }  // namespace
 
+// y[m, n] = sum_k x[m, k] w[n, k] + bias[n] for a FEW channels (K = 8 per lane-row, N <= 16): AutoencoderKL's quant_conv (8 -> 8, 1 x 1)
+// behind dreammat_guidance.py:284-292 -- the last Linear of the differentiated VAE encoder that ran on ATen; its data gradient is the
+// same kernel on w^T.  One thread per row: a 16-byte load, N dot products of 8, one or two 16-byte stores.  fp32 accumulate, one rounding.
+template <int N8>
+__global__ __launch_bounds__(256) void k_linear_small(const elem_t* __restrict__ x, const elem_t* __restrict__ w, const elem_t* __restrict__ bias,
+                                                      elem_t* __restrict__ y, long long M, int N) {
+    __shared__ float sw[16 * 8 + 16];
+    for (int i = threadIdx.x; i < 16 * 8; i += 256) sw[i] = i < N * 8 ? (float)w[i] : 0.f;
+    for (int i = threadIdx.x; i < 16; i += 256) sw[128 + i] = (bias && i < N) ? (float)bias[i] : 0.f;
+    __syncthreads();
+    for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256) {
+        const elem8 v = *reinterpret_cast<const elem8*>(x + m * 8);
+        float xf[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) xf[k] = (float)v[k];
+#pragma unroll
+        for (int c = 0; c < N8; ++c) {
+            elem8 o;
+#pragma unroll
+            for (int n = 0; n < 8; ++n) {
+                float a = sw[128 + 8 * c + n];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) a = __builtin_fmaf(xf[k], sw[(8 * c + n) * 8 + k], a);
+                o[n] = (elem_t)a;
+            }
+            *reinterpret_cast<elem8*>(y + m * (8 * N8) + 8 * c) = o;
+        }
+    }
+}
+
 extern "C" {
+
+// x [M, 8], w [N, 8], bias [N] or NULL, y [M, N]; N = 8 | 16; 16-byte aligned rows.
+int DM_T(dm_linear_small_, )(const void* x, const void* w, const void* bias, void* y, long long M, int K, int N, hipStream_t stream) {
+    if (!x || !w || !y || M <= 0) return DM_ERR_ARG;
+    if (K != 8 || (N != 8 && N != 16)) return DM_ERR_UNSUPPORTED;
+    if (((uintptr_t)x | (uintptr_t)y) & 15) return DM_ERR_ARG;
+    const unsigned grid = (unsigned)std::min<long long>((M + 255) / 256, 256 * 8);
+    DM_ENTER();
+    if (N == 8) hipLaunchKernelGGL(k_linear_small<1>, dim3(grid), dim3(256), 0, stream, (const elem_t*)x, (const elem_t*)w, (const elem_t*)bias, (elem_t*)y, M, N);
+    else hipLaunchKernelGGL(k_linear_small<2>, dim3(grid), dim3(256), 0, stream, (const elem_t*)x, (const elem_t*)w, (const elem_t*)bias, (elem_t*)y, M, N);
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
 
 // x, y [rows, C] bf16 (row-contiguous), gamma/beta [C] bf16; C % 8 == 0, C <= 2048.
 int DM_T(dm_layernorm_, )(const void* x, const void* gamma, const void* beta, void* y, long long rows, int C, float eps,

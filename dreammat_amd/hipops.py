@@ -806,6 +806,62 @@ def gemm_fused(x, w, bias=None, residual=None, geglu=False):
     return y
 
 
+def linear_small_ok(M, K, N):
+    return K == 8 and N == 8        # (8 -> 8: the data gradient is the same shape on w^T)
+
+
+class _LinearSmallFrozen(torch.autograd.Function):
+    """few-channel frozen Linear (AutoencoderKL's quant_conv, 8 -> 8) under autograd: dm_linear_small forward, the same on w^T back"""
+
+    @staticmethod
+    def forward(ctx, x, w, w_t, bias):
+        ctx.w_t = w_t
+        return linear_small(x, w, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (linear_small(g.contiguous(), ctx.w_t, None) if ctx.needs_input_grad[0] else None), None, None, None
+
+
+def linear_small(x, w, bias):
+    """x [..., 8] contiguous, w [8, 8] -> [..., 8] (forward only; linear_small_autograd wraps it)"""
+    _need_cuda(x, w, bias)
+    N, K = w.shape
+    M = x.numel() // K
+    assert x.is_contiguous() and w.is_contiguous() and linear_small_ok(M, K, N)
+    y = torch.empty(*x.shape[:-1], N, device=x.device, dtype=x.dtype)
+    fn, name = _sym("dm_linear_small_bf16", _same_half(x, w, bias))
+    with _Timed(f"linear_small[M={M},K={K},N={N}]", 2.0 * M * K * N):
+        check(fn(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None, y.data_ptr(), M, K, N, _stream()), name)
+    return y
+
+
+def linear_small_autograd(x, w, w_t, bias):
+    return _LinearSmallFrozen.apply(x, w, w_t, bias)
+
+
+class _LinearFrozen(torch.autograd.Function):
+    """y = x @ w^T + bias (+ residual) with FROZEN w / bias, differentiable wrt x (and the residual): forward and data gradient on
+    the fused GEMM kernel (round 6: the 1 x 1 shortcut convolutions and the attention projections of the differentiated VAE
+    encoder, dreammat_guidance.py:284-292, ran on ATen / hipBLASLt under autograd).  dx = g @ w: the same kernel on w^T."""
+
+    @staticmethod
+    def forward(ctx, x, w, w_t, bias, residual):
+        ctx.w_t = w_t
+        return gemm_fused(x, w, bias, residual)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        dx = gemm_fused(g, ctx.w_t, None, None) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None, (g if ctx.needs_input_grad[4] else None)
+
+
+def linear_frozen_autograd(x, w, w_t, bias=None, residual=None):
+    """x [..., K] contiguous, w [N, K], w_t = w.t().contiguous() [K, N] (prepared once by the caller); see _LinearFrozen."""
+    return _LinearFrozen.apply(x, w, w_t, bias, residual)
+
+
 def gemm_fused_ok(M, K, N, geglu=False):
     return M % 16 == 0 and K % 64 == 0 and N % (128 if geglu else 64) == 0
 

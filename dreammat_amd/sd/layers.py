@@ -302,6 +302,9 @@ def _rows_kernel_ok(x, *params):
     return x.is_cuda and x.dtype in HALF and CONV_BACKEND == "mfma" and not needs_grad
 
 
+_WT_CACHE = {}        # id(weight) -> ((data_ptr, version, dtype), w contiguous, w^T contiguous) of frozen layers differentiated through
+
+
 def linear_fused(x, weight, bias, residual=None):
     """F.linear(x, weight, bias) (+ residual): frozen bf16 layers on the GPU run the hand-written MFMA GEMM with the adds in
     its epilogue (csrc/conv.hip, 1-tap instantiation); everything else is the ATen call."""
@@ -310,6 +313,30 @@ def linear_fused(x, weight, bias, residual=None):
             and (residual is None or residual.dtype == x.dtype)):
         r = residual.contiguous() if residual is not None else None
         return hipops.gemm_fused(x.contiguous(), weight.detach().contiguous(), bias.detach() if bias is not None else None, r)
+    M = x.numel() // K
+    if (CONV_BACKEND == "mfma" and x.is_cuda and x.dtype in HALF and weight.dtype == x.dtype and torch.is_grad_enabled() and x.requires_grad
+            and not weight.requires_grad and (bias is None or not bias.requires_grad)
+            and hipops.gemm_fused_ok(M, K, N) and hipops.gemm_fused_ok(M, N, K) and (residual is None or residual.dtype == x.dtype)):
+        # differentiated activations through a FROZEN layer (the VAE encoder's 1 x 1 shortcuts and attention projections): forward and
+        # data gradient on the hand-written GEMM (hipops._LinearFrozen); w^T prepared once per weight tensor
+        cache = _WT_CACHE.get(id(weight))
+        key = (weight.data_ptr(), weight._version, weight.dtype)
+        if cache is None or cache[0] != key:
+            with torch.no_grad():
+                cache = (key, weight.detach().contiguous(), weight.detach().t().contiguous())
+            if len(_WT_CACHE) > 64:
+                _WT_CACHE.clear()
+            _WT_CACHE[id(weight)] = cache
+        r = residual.contiguous() if residual is not None else None
+        return hipops.linear_frozen_autograd(x.contiguous(), cache[1], cache[2], bias.detach() if bias is not None else None, r)
+    if (CONV_BACKEND == "mfma" and x.is_cuda and x.dtype in HALF and weight.dtype == x.dtype and residual is None
+            and hipops.linear_small_ok(M, K, N) and not (torch.is_grad_enabled() and (weight.requires_grad or (bias is not None and bias.requires_grad)))):
+        # a few-channel layer (AutoencoderKL's quant_conv, 8 -> 8): its own small kernel, forward and data gradient
+        wd = weight.detach().contiguous()
+        bd = bias.detach() if bias is not None else None
+        if torch.is_grad_enabled() and x.requires_grad:
+            return hipops.linear_small_autograd(x.contiguous(), wd, wd.t().contiguous(), bd)
+        return hipops.linear_small(x.contiguous(), wd, bd)
     if _native_expected(x):
         grad = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)
         note_fallback("linear", f"K={K} N={N} M={x.numel() // K}{' autograd' if grad else ''}")

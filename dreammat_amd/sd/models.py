@@ -299,8 +299,9 @@ class VaeAttention(nn.Module):
         if layers._native_expected(h):
             # the one differentiated attention of the path (1 head of 512): projections and the two products on hipBLASLt under
             # autograd, the softmax between them on the row kernels
-            layers.note_fallback("vae_attention", f"C={C} S={H * W} autograd: 4 projections + QK^T + PV")
-        q, k, v = self.to_q(h), self.to_k(h), self.to_v(h)
+            layers.note_fallback("vae_attention", f"C={C} S={H * W} autograd: QK^T + PV (and their four backward products)")
+        lin = layers.linear_fused        # (frozen projections under autograd: forward + data gradient on the hand-written GEMM, round 6)
+        q, k, v = lin(h, self.to_q.weight, self.to_q.bias), lin(h, self.to_k.weight, self.to_k.bias), lin(h, self.to_v.weight, self.to_v.bias)
         if q.dtype == torch.float16:
             # IEEE half: the UNSCALED q.k of 512 channels (22.6x the scaled logits) can pass 65504 -> inf -> NaN in the stored
             # score matrix; the scale is applied inside the product, in fp32, before the rounding (what diffusers'
@@ -314,7 +315,7 @@ class VaeAttention(nn.Module):
             p = hipops.softmax_rows(s, s_scale)         # scale, fp32 softmax and the rounding in one pass (and one pass back)
         else:
             p = torch.softmax((s * s_scale).float(), dim=-1).to(q.dtype)
-        o = self.to_out[0](torch.matmul(p, v))
+        o = lin(torch.matmul(p, v), self.to_out[0].weight, self.to_out[0].bias)
         return o.reshape(B, H, W, C).permute(0, 3, 1, 2) + x
 
 

@@ -419,6 +419,10 @@ int dm_groupnorm_nhwc_bwd_affine(const void* x, const void* gamma, const void* b
 int dm_layernorm_bf16(const void* x, const void* gamma, const void* beta, void* y, long long rows, int C, float eps,
                       dm_stream_t stream);
 int dm_geglu_bf16(const void* h, void* y, long long rows, int inner, dm_stream_t stream);
+/* ABI v13: a Linear / 1 x 1 layer of a FEW channels -- AutoencoderKL's quant_conv (8 -> 8) behind dreammat_guidance.py:284-292, the last
+ * Linear of the differentiated VAE encoder that ran on ATen; y [M, N] = x [M, 8] w [N, 8]^T + bias, K = 8, N = 8 | 16, fp32 accumulate.
+ * Its data gradient is the same call on w^T. */
+int dm_linear_small_bf16(const void* x, const void* w, const void* bias, void* y, long long M, int K, int N, dm_stream_t stream);
 /* Skip connection of a UNet up block with the ControlNet residual folded in (diffusers' `down_block_res_samples = [s + r]`
  * followed by `torch.cat([hidden, res_sample], dim=1)`, reached from dreammat_guidance.py:261-282): y[row] = x[row] | (s[row] +
  * r_scale * r[row]); x [rows,Cx], s/r [rows,Cs] (r may be NULL), y [rows,Cx+Cs], bf16, Cx % 8 == Cs % 8 == 0. */
@@ -468,6 +472,7 @@ int dm_gemm_f16_fused(const void* x, const void* w, const void* bias, const void
 int dm_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, long long rows, int C, float eps,
                       dm_stream_t stream);
 int dm_geglu_f16(const void* h, void* y, long long rows, int inner, dm_stream_t stream);
+int dm_linear_small_f16(const void* x, const void* w, const void* bias, void* y, long long M, int K, int N, dm_stream_t stream);
 int dm_cat_add_f16(const void* x, const void* s, const void* r, void* y, long long rows, int Cx, int Cs, float r_scale,
                     dm_stream_t stream);
 int dm_softmax_rows_f16(const void* s, void* p, long long rows, int cols, float scale, dm_stream_t stream);

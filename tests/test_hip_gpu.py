@@ -1193,6 +1193,58 @@ def test_resnet_block_with_folded_groupnorm_equals_the_two_call_form(dev, monkey
     assert any(k.startswith("groupnorm_fwd") for k in outs[False][2])
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_frozen_linear_under_autograd_runs_on_the_fused_gemm(dev, dtype):
+    """layers.linear_fused on differentiated activations through a frozen layer (the VAE encoder's 1 x 1 shortcuts and attention
+    projections): forward and data gradient on dm_gemm_*_fused (hipops._LinearFrozen), with bias and residual, against fp32 torch."""
+    from dreammat_amd.sd import layers
+    torch.manual_seed(31)
+    M, K, N = 4096, 128, 256
+    x = torch.randn(M, K).to(dtype); w = (torch.randn(N, K) * 0.1).to(dtype); b = torch.randn(N).to(dtype); res = torch.randn(M, N).to(dtype)
+    g = torch.randn(M, N).to(dtype)
+    xr, rr = x.float().requires_grad_(), res.float().requires_grad_()
+    (xr @ w.float().t() + b.float() + rr).backward(g.float())
+    xd, rd = x.to(dev).requires_grad_(), res.to(dev).requires_grad_()
+    wd, bd = w.to(dev), b.to(dev)
+    layers.fallbacks(clear=True)
+    hipops.enable_kernel_timing(True)
+    y = layers.linear_fused(xd, wd, bd, rd)
+    y.backward(g.to(dev))
+    torch.cuda.synchronize()
+    keys = list(hipops.kernel_times())
+    hipops.enable_kernel_timing(False)
+    assert not layers.fallbacks() and sum(k.startswith("gemm") for k in keys) == 2, keys
+    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
+    ref = (x.float() @ w.float().t() + b.float() + res.float())
+    assert (y.detach().float().cpu() - ref).abs().max().item() < tol * ref.abs().max().item()
+    assert (xd.grad.float().cpu() - xr.grad).abs().max().item() < tol * xr.grad.abs().max().item()
+    assert torch.equal(rd.grad.cpu(), g)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N", [8])
+def test_few_channel_linear_kernel_forward_and_data_gradient(dev, dtype, N):
+    """dm_linear_small (AutoencoderKL's quant_conv, 8 -> 8, differentiated through: dreammat_guidance.py:284-292) through
+    layers.linear_fused: forward and data gradient against fp32 torch, nothing left to ATen."""
+    from dreammat_amd.sd import layers
+    torch.manual_seed(32)
+    M = 5000
+    x = torch.randn(M, 8).to(dtype); w = torch.randn(N, 8).to(dtype); b = torch.randn(N).to(dtype); g = torch.randn(M, N).to(dtype)
+    xr = x.float().requires_grad_()
+    (xr @ w.float().t() + b.float()).backward(g.float())
+    xd = x.to(dev).requires_grad_()
+    layers.fallbacks(clear=True)
+    y = layers.linear_fused(xd, w.to(dev), b.to(dev))
+    y.backward(g.to(dev))
+    assert not layers.fallbacks()
+    tol = 2e-2 if dtype == torch.bfloat16 else 3e-3
+    ref = x.float() @ w.float().t() + b.float()
+    assert (y.detach().float().cpu() - ref).abs().max().item() < tol * ref.abs().max().item()
+    assert (xd.grad.float().cpu() - xr.grad).abs().max().item() < tol * xr.grad.abs().max().item()
+    with torch.no_grad():
+        assert torch.equal(layers.linear_fused(x.to(dev), w.to(dev), b.to(dev)), y.detach())
+
+
 def test_raster_edge_cases_bit_exact(dev):
     """object partly off-screen, behind the camera (discarded), degenerate and sub-pixel triangles, and a
     camera that sees nothing (empty coverage) -- ids/barycentrics stay bit-identical to the oracle."""
