@@ -101,12 +101,13 @@ int launch_small(const SmallConvArgs& a, hipStream_t stream) {
 // 16-byte channel runs.  Cin = 128 -> Cout = 4 is the data gradient of the VAE encoder's conv_in (the rendered image is the leaf).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 
-template <int CP, int STRIDE>
+template <int CP, int STRIDE, int TH_ = 16, int WR_ = 32>
 struct PatchCfg {
-    static constexpr int TW = 16, TH = 16, PW = (TW - 1) * STRIDE + 3, PH = (TH - 1) * STRIDE + 3;
-    static constexpr int RB = CP * 2, NC = CP / 8, RPL = 16 / NC;          // row bytes, 16-byte chunks per row, rows per 256 bytes
-    static constexpr int PATCH_BYTES = ((PH * PW * RB + 255) / 256) * 256, W_BYTES = 32 * 9 * RB;     // W_BYTES: one block of 32 output channels
+    static constexpr int TW = 16, TH = TH_, WR = WR_, PW = (TW - 1) * STRIDE + 3, PH = (TH - 1) * STRIDE + 3;
+    static constexpr int RB = CP * 2, NC = CP / 8, RPL = NC >= 16 ? 1 : 16 / NC;   // row bytes, 16-byte chunks per row, rows per 256 bytes
+    static constexpr int PATCH_BYTES = ((PH * PW * RB + 255) / 256) * 256, W_BYTES = WR * 9 * RB;     // W_BYTES: one block of 32 output channels (WR rows of it stored)
     __device__ __host__ static int swz(int row) { return (row / RPL) & (NC - 1); }
 };
 
@@ -114,9 +115,16 @@ struct PatchCfg {
 // (`w_res` blocks resident; otherwise one block at a time, reloaded per tile), then the workgroup walks tiles -- per tile one patch
 // load between two barriers and no other synchronisation.  (Per-tile, per-block weight loads -- a barrier pair and an L2 round trip
 // in front of 18-36 MFMAs -- were most of the first version's time.)
-template <int CP, int STRIDE>
-__global__ __launch_bounds__(256) void k_conv3x3_patch(SmallConvArgs a, int cin, int tiles_x, int tiles_y, int n_tiles, int w_res) {
-    using C = PatchCfg<CP, STRIDE>;
+//
+// TH = 8, WR = 4 (round 6, the Cin = 128 -> Cout <= 4 launch): a 16 x 8 tile and only the four real weight rows in LDS (lanes of the
+// other 28 rows of the 32-row MFMA operand hold zeros without reading) = 55 KB per workgroup, two workgroups per CU instead of one;
+// the patch arrives by unconditional buffer loads, all in flight before the first LDS store (out-of-image pixels are offsets past the
+// descriptor's end: zeros, no branch -- the bounds-tested form was one serialized HBM round trip per 256 chunks, twelve per tile).
+template <int CP, int STRIDE, int TH = 16, int WR = 32>
+__global__ __launch_bounds__(256, 2) void k_conv3x3_patch(SmallConvArgs a, int cin, int tiles_x, int tiles_y, int n_tiles, int w_res) {
+    using C = PatchCfg<CP, STRIDE, TH, WR>;
+    constexpr int MB = TH / 8;                                             // 32-pixel M blocks (two tile rows each) per wave
+    static_assert(TH == 8 || TH == 16, "tile height");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n_cb = (a.Cout + 31) / 32;
     char* const patch = smem;
@@ -140,7 +148,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(SmallConvArgs a, int cin,
         return make_uint4(v[0], v[1], v[2], v[3]);
     };
     auto load_weights = [&](int cb, char* wl) {                           // block cb as [cout_local][tap][CP], zero rows past Cout
-        for (int i = tid; i < 32 * 9 * C::NC; i += 256) {
+        for (int i = tid; i < WR * 9 * C::NC; i += 256) {
             const int row = i / C::NC, c = i - row * C::NC;
             const int co = cb * 32 + row / 9, tap = row - (row / 9) * 9;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
@@ -151,15 +159,57 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(SmallConvArgs a, int cin,
     for (int i = tid; i < n_cb * 32; i += 256) sbias[i] = (a.bias && i < a.Cout) ? (float)a.bias[i] : 0.f;
     if (w_res >= n_cb)
         for (int cb = 0; cb < n_cb; ++cb) load_weights(cb, wl0 + cb * C::W_BYTES);
-    const int trow0 = 4 * wave + (l31 >> 4), tcol = l31 & 15;             // this lane's pixel of M block 0 (block 1: two tile rows down)
+    const int trow0 = 2 * MB * wave + (l31 >> 4), tcol = l31 & 15;        // this lane's pixel of M block 0 (block 1: two tile rows down)
+    [[maybe_unused]] const bool w_live = l31 < WR;                        // (WR < 32: this lane's weight row exists)
+    // (CP == 128) the NEXT tile's patch is requested into registers before this tile's MFMAs: the loads are in flight while the
+    // workgroup multiplies (the compute phase has no other vector-memory reads), and land in LDS after the barrier that follows.
+    [[maybe_unused]] constexpr int NCH = C::PH * C::PW * C::NC, NTRIP = (NCH + 255) / 256;
+    [[maybe_unused]] u32x4s pv[CP == 128 ? NTRIP : 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+    [[maybe_unused]] auto request_patch = [&](int tile_) __attribute__((always_inline)) {
+        if constexpr (CP == 128) {                                         // (cin == 128: whole chunks; the launcher checked 32-bit offsets)
+            int t_ = tile_;
+            const int tx_ = t_ % tiles_x; t_ /= tiles_x;
+            const int ty_ = t_ % tiles_y;
+            const int b_ = t_ / tiles_y;
+            const int iy0_ = ty_ * C::TH * STRIDE - a.pad_y, ix0_ = tx_ * C::TW * STRIDE - a.pad_x;
+            const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(unsigned)((long long)a.B * a.Hin * a.Win * CP * 2), 0x00020000);
+#pragma unroll
+            for (int t = 0; t < NTRIP; ++t) {
+                const int i = tid + 256 * t;
+                const int row = i / C::NC, c = i - row * C::NC;
+                const int py = row / C::PW, px = row - py * C::PW;
+                const int yy = iy0_ + py, xx = ix0_ + px;
+                const bool ok = i < NCH && tile_ < n_tiles && (unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)a.Win;
+                const unsigned off = ok ? ((((unsigned)b_ * (unsigned)a.Hin + (unsigned)yy) * (unsigned)a.Win + (unsigned)xx) * (unsigned)CP + 8u * (unsigned)c) * 2u : 0xfffffff0u;
+#if defined(DM_ABL_SMALL_NOLOAD)
+                pv[t] = u32x4s{off, 0u, 0u, 0u};
+#else
+                pv[t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 0, 0);
+#endif
+            }
+        }
+    };
+    if constexpr (CP == 128) request_patch((int)blockIdx.x);
+#endif
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         int t = tile;
         const int tx = t % tiles_x; t /= tiles_x;
         const int ty = t % tiles_y;
         const int b = t / tiles_y;
         const int oy0 = ty * C::TH, ox0 = tx * C::TW;
-        const int iy0 = oy0 * STRIDE - a.pad_y, ix0 = ox0 * STRIDE - a.pad_x;
+        [[maybe_unused]] const int iy0 = oy0 * STRIDE - a.pad_y, ix0 = ox0 * STRIDE - a.pad_x;
         __syncthreads();                                                   // the previous tile's patch is no longer read
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (CP == 128) {
+#pragma unroll
+            for (int t = 0; t < NTRIP; ++t) {
+                const int i = tid + 256 * t;
+                const int row = i / C::NC, c = i - row * C::NC;
+                if (i < NCH) *reinterpret_cast<u32x4s*>(patch + row * C::RB + ((c ^ C::swz(row)) << 4)) = pv[t];
+            }
+        } else
+#endif
         for (int i = tid; i < C::PH * C::PW * C::NC; i += 256) {          // the patch: one chunk per thread and trip
             const int row = i / C::NC, c = i - row * C::NC;
             const int py = row / C::PW, px = row - py * C::PW;
@@ -170,6 +220,9 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(SmallConvArgs a, int cin,
             *reinterpret_cast<uint4*>(patch + row * C::RB + ((c ^ C::swz(row)) << 4)) = v;
         }
         __syncthreads();
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (CP == 128) request_patch(tile + (int)gridDim.x);
+#endif
         for (int cb = 0; cb < n_cb; ++cb) {
             const char* wl = wl0 + (w_res >= n_cb ? cb : 0) * C::W_BYTES;
             if (w_res < n_cb) {                                            // (the weights do not all fit: one block at a time)
@@ -177,24 +230,30 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(SmallConvArgs a, int cin,
                 load_weights(cb, wl0);
                 __syncthreads();
             }
-            f32x16 acc[2];
+            f32x16 acc[MB];
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-#pragma unroll
+#pragma unroll CP == 128 ? 1 : 9                                            // (128 channels: eight K chunks per tap are enough to overlap; all 72 unrolled spill)
             for (int tap = 0; tap < 9; ++tap) {
                 const int dy = tap / 3, dx = tap - 3 * dy;
-                const int wrow = l31 * 9 + tap;
-                int prow[2];
+                const int wrow = (WR < 32 ? (w_live ? l31 : 0) : l31) * 9 + tap;
+                int prow[MB];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) prow[m] = ((trow0 + 2 * m) * STRIDE + dy) * C::PW + tcol * STRIDE + dx;
+                for (int m = 0; m < MB; ++m) prow[m] = ((trow0 + 2 * m) * STRIDE + dy) * C::PW + tcol * STRIDE + dx;
 #pragma unroll
                 for (int kk = 0; kk < CP / 16; ++kk) {
                     const int ch = 2 * kk + hi;
-                    const elem8 wf = *reinterpret_cast<const elem8*>(wl + wrow * C::RB + ((ch ^ C::swz(wrow)) << 4));
+                    elem8 wf = *reinterpret_cast<const elem8*>(wl + wrow * C::RB + ((ch ^ C::swz(wrow)) << 4));
+                    if constexpr (WR < 32) {
+                        if (!w_live) wf = elem8{};
+                    }
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) {
+                    for (int m = 0; m < MB; ++m) {
+#if defined(DM_ABL_SMALL_NOMMA)
+                        if (CP == 128 && kk) continue;
+#endif
                         const elem8 pf = *reinterpret_cast<const elem8*>(patch + prow[m] * C::RB + ((ch ^ C::swz(prow[m])) << 4));
                         acc[m] = DM_MFMA_32x32x16(wf, pf, acc[m]);
                     }
@@ -202,7 +261,7 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(SmallConvArgs a, int cin,
             }
             // ---- epilogue: register r of a lane = channel cb*32 + (r & 3) + 8 (r >> 2) + 4 hi of its pixel
 #pragma unroll
-            for (int m = 0; m < 2; ++m) {
+            for (int m = 0; m < MB; ++m) {
                 const int oy = oy0 + trow0 + 2 * m, ox = ox0 + tcol;
                 const bool pix_ok = oy < a.Hout && ox < a.Wout;
                 const long long po = (((long long)b * a.Hout + oy) * a.Wout + ox) * a.Cout;
@@ -235,9 +294,11 @@ __global__ __launch_bounds__(256) void k_conv3x3_patch(SmallConvArgs a, int cin,
     }
 }
 
-template <int CP, int STRIDE>
+template <int CP, int STRIDE, int TH = 16, int WR = 32>
 int launch_patch(const SmallConvArgs& a, int cin, hipStream_t stream) {
-    using C = PatchCfg<CP, STRIDE>;
+    using C = PatchCfg<CP, STRIDE, TH, WR>;
+    if (WR < 32 && a.Cout > WR) return DM_ERR_UNSUPPORTED;
+    if (CP == 128 && (long long)a.B * a.Hin * a.Win * CP * 2 > 0xffffff00LL) return DM_ERR_UNSUPPORTED;      // 32-bit buffer offsets of the patch loads
     const int n_cb = (a.Cout + 31) / 32;
     const size_t fixed = (size_t)C::PATCH_BYTES + (size_t)n_cb * 32 * 4;
     static_assert(C::PATCH_BYTES + C::W_BYTES + 128 <= 160 * 1024, "LDS budget");
@@ -248,7 +309,7 @@ int launch_patch(const SmallConvArgs& a, int cin, hipStream_t stream) {
     const size_t lds = fixed + (size_t)w_res * C::W_BYTES;
     static size_t lds_set = 0;
     if (lds > lds_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_patch<CP, STRIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_patch<CP, STRIDE, TH, WR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         lds_set = lds;
     }
@@ -263,7 +324,7 @@ int launch_patch(const SmallConvArgs& a, int cin, hipStream_t stream) {
     const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
     const long long blocks = std::min<long long>(n_tiles, (long long)n_cu * wg_per_cu);
     DM_ENTER();
-    hipLaunchKernelGGL((k_conv3x3_patch<CP, STRIDE>), dim3((unsigned)blocks), dim3(256), lds, stream, a, cin, tiles_x, tiles_y, (int)n_tiles, w_res);
+    hipLaunchKernelGGL((k_conv3x3_patch<CP, STRIDE, TH, WR>), dim3((unsigned)blocks), dim3(256), lds, stream, a, cin, tiles_x, tiles_y, (int)n_tiles, w_res);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }
@@ -278,7 +339,11 @@ int try_patch(const SmallConvArgs& a, int cin, hipStream_t stream) {
     if (a.stride == 1) {
         if (cin <= 16) return launch_patch<16, 1>(a, cin, stream);
         if (cin <= 32) return launch_patch<32, 1>(a, cin, stream);
-        return launch_patch<128, 1>(a, cin, stream);             // (the image gradient of the VAE encoder's conv_in)
+        if (a.Cout <= 4) {                                       // (the image gradient of the VAE encoder's conv_in)
+            const int rc = launch_patch<128, 1, 8, 4>(a, cin, stream);
+            if (rc != DM_ERR_UNSUPPORTED) return rc;
+        }
+        return launch_patch<128, 1>(a, cin, stream);
     } else {
         if (cin <= 16) return launch_patch<16, 2>(a, cin, stream);
         if (cin <= 32) return launch_patch<32, 2>(a, cin, stream);

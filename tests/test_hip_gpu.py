@@ -1820,7 +1820,8 @@ def test_conv3x3_split_k_small_m(dev, monkeypatch, split, B, Cin, Cout, H, W):
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,stride,act", [(2, 22, 16, 40, 24, 1, 1), (1, 16, 16, 33, 17, 1, 1), (2, 16, 32, 32, 32, 2, 1),
                                                          (1, 32, 96, 24, 24, 2, 1), (3, 4, 320, 16, 16, 1, 0), (1, 32, 32, 9, 13, 1, 0),
-                                                         (1, 8, 48, 12, 12, 1, 1)])
+                                                         (1, 8, 48, 12, 12, 1, 1),
+                                                         (2, 128, 4, 21, 37, 1, 0), (1, 128, 4, 64, 48, 1, 0), (1, 128, 8, 19, 16, 1, 0)])
 def test_conv3x3_small_channel_direct_kernel(dev, B, Cin, Cout, H, W, stride, act):
     """the few-channel stem convs (ControlNet conditioning embedding, conv_in) on the direct kernel, with the fused SiLU."""
     torch.manual_seed(4)
