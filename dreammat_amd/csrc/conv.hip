@@ -1551,7 +1551,10 @@ int conv_halo_choice(const ConvArgs& a) {
     // 256 x 128 patches, three weight stages, where the 256 x 128 tile ran with whole 128-wide channel tiles (the 1280-channel layers
     // at 16 x 16: one patch per image): 24 x 1280->1280 909 -> 1097 TF/s, 2560->1280 826 -> 1012; not the 640-channel layers at 32 x 32
     // (-2 %), not ragged channel tiles (320: -15 %)
-    if (tile == 256 && a.Cout % 128 == 0 && a.Hout % 16 == 0 && a.Wout % 16 == 0) return 128;
+    // -- and only with enough (patch, channel tile) items to fill the chip: there is no split-K here, and 3 images (one view per rank
+    // of an 8-GPU job) are 30 items for 256 CUs: 84 us against 42 us on the per-tap kernel with its K ranges
+    if (tile == 256 && a.Cout % 128 == 0 && a.Hout % 16 == 0 && a.Wout % 16 == 0 &&
+        (long long)a.B * (a.Hout / 16) * (a.Wout / 16) * (a.Cout / 128) * 4 >= 3LL * cu_count()) return 128;
     return 0;
 }
 

@@ -1090,7 +1090,7 @@ def test_conv3x3_dma_tile_variants(dev, monkeypatch, tile, B, Cin, Cout, H, W):
     ("16", 1, 192, 64, 17, 33),         # odd sizes, three channel blocks
     ("128", 3, 256, 512, 40, 24),       # 256 x 128 patches, three weight stages
     ("128", 5, 64, 320, 8, 8),
-    (None, 12, 1280, 1280, 16, 16),     # ... the dispatcher's choice for the 1280-channel layers at 16 x 16
+    (None, 24, 1280, 1280, 16, 16),     # ... the dispatcher's choice for the 1280-channel layers at 16 x 16 (8 views x 3 branches)
     (None, 2, 128, 128, 256, 512),      # the dispatcher's own choice: 384 x 128 patches (the VAE's 512^2 layers' variant)
     (None, 8, 256, 256, 96, 96),        # ... 256 x 256 patches
 ])
@@ -1110,6 +1110,8 @@ def test_conv3x3_halo_patch_kernel(dev, monkeypatch, dtype, halo, B, Cin, Cout, 
     torch.cuda.synchronize()
     hipops.enable_kernel_timing(False)
     assert int(_lib.lib().dm_conv3x3_gn_ok(B, H, W, Cin, Cout)) == 1          # the patch kernel took it
+    if halo is None and H == 16 and Cout == 1280:      # ... but not with 3 images (30 items for 256 CUs, no split-K): the per-tap kernel
+        assert int(_lib.lib().dm_conv3x3_gn_ok(3, H, W, Cin, Cout)) == 0
     ref = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float(), bias.float(), padding=1).permute(0, 2, 3, 1)
     ref = ref + rowbias.float()[:, None, None, :] + res.float()
     tol = (2e-2 if dtype == torch.bfloat16 else 3e-3) * ref.abs().max().item() + (1e-2 if dtype == torch.bfloat16 else 2e-3)
@@ -1123,7 +1125,7 @@ def test_conv3x3_halo_patch_kernel(dev, monkeypatch, dtype, halo, B, Cin, Cout, 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("halo,act,B,Cin,Cout,H,W", [
     ("24", 1, 2, 128, 128, 200, 72), ("16", 0, 3, 256, 512, 40, 24), ("24", 1, 5, 64, 320, 8, 8), ("16", 1, 1, 192, 64, 17, 33),
-    ("128", 1, 3, 256, 512, 40, 24), (None, 1, 12, 1280, 1280, 16, 16),
+    ("128", 1, 3, 256, 512, 40, 24), (None, 1, 24, 1280, 1280, 16, 16),
     (None, 1, 2, 128, 128, 256, 512), (None, 1, 8, 256, 256, 96, 96)])
 def test_conv3x3_with_groupnorm_apply_folded_in(dev, monkeypatch, dtype, halo, act, B, Cin, Cout, H, W):
     """dm_conv3x3_gn_nhwc_*_fused (ABI v13): conv(act(GroupNorm32(x))) with the apply pass done on the patch in LDS -- equal to the
