@@ -16,7 +16,7 @@ if os.environ.get("DREAMMAT_LIB"):       # development aid (tools/grad_budget.py
     LIB_PATH = os.environ["DREAMMAT_LIB"]
 
 _lib = None
-ABI_VERSION = 13     # dm_abi_version() of the library this binding was written for (csrc/host.cpp, include/dreammat_hip.h)
+ABI_VERSION = 14     # dm_abi_version() of the library this binding was written for (csrc/host.cpp, include/dreammat_hip.h)
 
 DM_ERRORS = {-1: "DM_ERR_ARG", -2: "DM_ERR_WORKSPACE", -3: "DM_ERR_UNSUPPORTED"}
 
@@ -138,6 +138,7 @@ _SIGS = {
     "dm_conv3x3_small_nhwc_bf16": (c_int, [c_void_p] * 4 + [c_int] * 11 + [c_void_p]),
     "dm_conv3x3_small_res_nhwc_bf16": (c_int, [c_void_p] * 4 + [c_int, c_void_p] + [c_int] * 11 + [c_void_p]),
     "dm_gemm_bf16_fused": (c_int, [c_void_p] * 5 + [_LL, c_int, c_int, c_int, c_void_p]),
+    "dm_gemm_bf16_batched": (c_int, [c_void_p] * 3 + [c_int, _LL, c_int, c_int, c_void_p]),
     "dm_groupnorm_workspace_floats": (c_size_t, [c_int, c_int]),
     "dm_groupnorm_nhwc_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                                       c_int, c_void_p]),
@@ -155,6 +156,7 @@ _SIGS = {
     "dm_layernorm_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _LL, c_int, c_float, c_void_p]),
     "dm_geglu_bf16": (c_int, [c_void_p, c_void_p, _LL, c_int, c_void_p]),
     "dm_cat_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _LL, c_int, c_int, c_float, c_void_p]),
+    "dm_transpose_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "dm_softmax_rows_bf16": (c_int, [c_void_p, c_void_p, _LL, c_int, c_float, c_void_p]),
     "dm_softmax_rows_bwd_bf16": (c_int, [c_void_p, c_void_p, c_void_p, _LL, c_int, c_float, c_void_p]),
     "dm_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, _LL, c_int, c_float, c_float, c_float, c_float,
@@ -164,9 +166,9 @@ _SIGS = {
 
 # IEEE-half instantiations of the net kernels (csrc/dm_elem.h, built from the same sources with -DDM_F16): same signatures
 for _n in ("dm_attention_fwd_bf16", "dm_attention_fwd_lse_bf16", "dm_conv3x3_nhwc_bf16", "dm_conv3x3_nhwc_bf16_fused",
-           "dm_conv2x2_nhwc_bf16", "dm_conv2x2_subpixel_nhwc_bf16", "dm_conv3x3_small_nhwc_bf16", "dm_conv3x3_small_res_nhwc_bf16", "dm_gemm_bf16_fused",
+           "dm_conv2x2_nhwc_bf16", "dm_conv2x2_subpixel_nhwc_bf16", "dm_conv3x3_small_nhwc_bf16", "dm_conv3x3_small_res_nhwc_bf16", "dm_gemm_bf16_fused", "dm_gemm_bf16_batched",
            "dm_layernorm_bf16", "dm_geglu_bf16", "dm_cat_add_bf16", "dm_softmax_rows_bf16", "dm_softmax_rows_bwd_bf16",
-           "dm_conv3x3_gn_nhwc_bf16_fused", "dm_linear_small_bf16"):
+           "dm_conv3x3_gn_nhwc_bf16_fused", "dm_linear_small_bf16", "dm_transpose_bf16"):
     _SIGS[_n.replace("bf16", "f16")] = _SIGS[_n]
 for _n in ("dm_groupnorm_nhwc_fwd", "dm_groupnorm_nhwc_infer", "dm_groupnorm_nhwc_bwd", "dm_groupnorm_nhwc_bwd_res", "dm_groupnorm_nhwc_stats"):
     _SIGS[_n + "_f16"] = _SIGS[_n]

@@ -70,6 +70,9 @@ struct ConvArgs {
     // coefficient rows dm_groupnorm_nhwc_stats leaves ([B][7][Cin]: row 0 = rstd * gamma, row 1 = beta - mean * rstd * gamma), the
     // patch in LDS becomes act(x * A + S) rounded to 16 bits (what the apply kernel would have written) before any tap reads it
     const float* gn_coef;
+    // batched 1-tap launch (dm_gemm_*_batched, round 6): w = [wb_count][Cout][Cin], the rows of x / y in blocks of 16 * wb_y per
+    // item (a multiple of every M tile: no tile straddles two items); 0 = one weight matrix for all rows
+    int wb_y, wb_count;
     int gn_act;
     unsigned long long* timeline;   // DREAMMAT_CONV_TIMELINE=1 (development): s_memtime stamps per tile, else null
     int timeline_steps;             // DREAMMAT_CONV_TIMELINE=2: stamp every K-step instead; 4: per-wave sums of body / waits / barrier
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.x, 0, (int)(unsigned)((long long)a.B * a.Hin * a.Win * a.Cin * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)a.w, 0, (int)(unsigned)((long long)a.Cout * TAPS * a.Cin * 2), 0x00020000);
+        (void*)a.w, 0, (int)(unsigned)((long long)a.Cout * TAPS * a.Cin * 2 * (a.wb_y > 0 ? a.wb_count : 1)), 0x00020000);
     // epilogue tensors: an absent bias / rowbias / residual is a zero-sized descriptor (every load returns 0)
     const int OC = EPI == 1 ? a.Cout / 2 : a.Cout;      // output channels = row length of y / res
     const unsigned y_bytes = (unsigned)(a.M * OC * 2);
@@ -343,9 +346,12 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
     unsigned a_mask[A_INSTR];
     unsigned b_off[B_INSTR];
     const float rcp_hout = 1.0f / (float)a.Hout;       // B*Hout < 2^22 (launcher): one correction step makes the quotient exact
+    [[maybe_unused]] unsigned wb_off = 0;              // byte offset of the issue tile's weight matrix (batched 1-tap launches)
     auto setup_issue_tile = [&](int id) __attribute__((always_inline)) {
         int Y0, X0, n0, ks;
         tile_coords(id, Y0, X0, n0, ks);
+        if constexpr (TAPS == 1)                            // (batched GEMM: this tile's weight matrix)
+            wb_off = a.wb_y > 0 ? (unsigned)(Y0 / a.wb_y) * (unsigned)(a.Cout * a.Cin * 2) : 0u;
         i_step = k_lo(ks); i_end = k_lo(ks + 1);
         i_kc = TAPS == 1 ? i_step : i_step / TAPS;
         i_tap = TAPS == 1 ? 0 : i_step - i_kc * TAPS;
@@ -402,7 +408,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
         // tap -> (dy, dx): 3 x 3 window (tap / 3, tap % 3 for tap < 9) or, TAPS == 4, the 2 x 2 window of the stride-2 data gradient
         const int dy = TAPS == 4 ? (i_tap >> 1) : ((i_tap * 11) >> 5), dx = TAPS == 4 ? (i_tap & 1) : (i_tap - 3 * dy);
         toff = (unsigned)(((dy * a.Win + dx) * a.Cin + i_kc * BK) * 2);              // from a_off
-        woff = (unsigned)((i_tap * a.Cin + i_kc * BK) * 2);                          // weights are [Cout][tap][Cin]
+        woff = (unsigned)((i_tap * a.Cin + i_kc * BK) * 2) + (TAPS == 1 ? wb_off : 0u);   // weights are [Cout][tap][Cin] (+ the item's matrix)
         bit = 1u << i_tap;
     };
     // advance to the next K-step; at the end of a tile move on to this workgroup's next tile (or stop)
@@ -1727,19 +1733,16 @@ int DM_T(dm_conv2x2_subpixel_nhwc_, )(const void* x, const void* w, const void* 
 // rounds both to 16 bits first) and gelu = the exact erf form evaluated as gate * Phi(gate) with Abramowitz-Stegun 7.1.26 for erfc
 // (|error of Phi| < 3e-7; see the EPI = 1 epilogue above).
 // Runs the 1-tap instantiation of the LDS-DMA convolution kernel above (M % 16 == 0, K % 64 == 0, N % 64 == 0; geglu: N % 128).
-int DM_T(dm_gemm_, _fused)(const void* x, const void* w, const void* bias, const void* residual, void* y, long long M, int K,
-                       int N, int geglu, hipStream_t stream) {
-    if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0) return DM_ERR_ARG;
-    if (M % 16 != 0 || K % 64 != 0 || N % 64 != 0 || (geglu && (N % 128 != 0 || residual))) return DM_ERR_UNSUPPORTED;
-    if (M / 16 >= (1 << 22)) return DM_ERR_UNSUPPORTED;
-    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return DM_ERR_ARG;
-    if (((uintptr_t)bias | (uintptr_t)residual) & 7) return DM_ERR_ARG;
+static int gemm_dispatch(const void* x, const void* w, const void* bias, const void* residual, void* y, long long M, int K, int N, int geglu,
+                         int batch, hipStream_t stream) {
+    // batch > 0: w = [batch][N][K], x / y rows in `batch` blocks of M / batch (dm_gemm_*_batched)
     ConvArgs a = {};
     a.x = (const elem_t*)x; a.w = (const elem_t*)w; a.bias = (const elem_t*)bias; a.y = (elem_t*)y;
     a.rowbias = nullptr; a.res = (const elem_t*)residual; a.timeline = nullptr; a.timeline_steps = 0;
     a.B = 1; a.Hin = a.Hout = (int)(M / 16); a.Win = a.Wout = 16; a.Cin = K; a.Cout = N;
     a.stride = 1; a.pad_y = 0; a.pad_x = 0;
     a.M = M;
+    if (batch > 0) { a.wb_y = (int)(M / batch / 16); a.wb_count = batch; }
     auto n_wg = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((N + bn - 1) / bn); };
     const char* tile_env = getenv("DREAMMAT_GEMM_TILE");     // 128 | 256 | 320 | 512 forces a variant (tests / A-B measurements)
     int tile = tile_env ? atoi(tile_env) : 0;
@@ -1749,6 +1752,7 @@ int DM_T(dm_gemm_, _fused)(const void* x, const void* w, const void* bias, const
         else if (!geglu && N == 320 && n_wg(256, 320) >= 160) tile = 320;   // no ragged N tile, x read once (K = 320: 64 -> 59 us, K = 1280: 163 -> 152)
         else tile = 256;
     }
+    if (batch > 0 && tile == 320) tile = 256;               // (the balanced two-launch form does not carry the batch offset)
     if (geglu) {
         if (tile == 320) tile = 256;
         switch (tile) {
@@ -1768,6 +1772,27 @@ int DM_T(dm_gemm_, _fused)(const void* x, const void* w, const void* bias, const
         return (N % 128 == 0) ? launch_conv_dma<128, 128, 4, 2, 2, 1, 0>(a, stream)
                               : launch_conv_dma<128, 64, 4, 2, 3, 1, 0>(a, stream);
     }
+}
+
+int DM_T(dm_gemm_, _fused)(const void* x, const void* w, const void* bias, const void* residual, void* y, long long M, int K,
+                       int N, int geglu, hipStream_t stream) {
+    if (!x || !w || !y || M <= 0 || K <= 0 || N <= 0) return DM_ERR_ARG;
+    if (M % 16 != 0 || K % 64 != 0 || N % 64 != 0 || (geglu && (N % 128 != 0 || residual))) return DM_ERR_UNSUPPORTED;
+    if (M / 16 >= (1 << 22)) return DM_ERR_UNSUPPORTED;
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return DM_ERR_ARG;
+    if (((uintptr_t)bias | (uintptr_t)residual) & 7) return DM_ERR_ARG;
+    return gemm_dispatch(x, w, bias, residual, y, M, K, N, geglu, 0, stream);
+}
+
+// `batch` independent products in one launch: y[i] = x[i] w[i]^T, x [batch, M, K], w [batch, N, K], y [batch, M, N] (all contiguous,
+// 16-bit; no bias / residual).  M % 256 == 0 (no tile of any variant straddles two items), K % 64 == N % 64 == 0.  The per-image
+// products of the VAE mid-block attention's GEMM form, several images per launch (hipops._WideHeadAttention).
+int DM_T(dm_gemm_, _batched)(const void* x, const void* w, void* y, int batch, long long M, int K, int N, hipStream_t stream) {
+    if (!x || !w || !y || batch <= 0 || M <= 0 || K <= 0 || N <= 0) return DM_ERR_ARG;
+    if (M % 256 != 0 || K % 64 != 0 || N % 64 != 0) return DM_ERR_UNSUPPORTED;
+    if ((long long)batch * M / 16 >= (1 << 22) || (long long)batch * N * K * 2 > 0xffffff00LL) return DM_ERR_UNSUPPORTED;
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return DM_ERR_ARG;
+    return gemm_dispatch(x, w, nullptr, nullptr, y, (long long)batch * M, K, N, 0, batch, stream);
 }
 
 }  // extern "C"

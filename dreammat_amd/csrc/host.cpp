@@ -87,7 +87,7 @@ struct BvhBuilder {
 
 extern "C" {
 
-int dm_abi_version(void) { return 13; }    // 4: + dm_grid_build / dm_grid_any_hit_rays / dm_host_free, dm_mc_scene.grid; 5: + dm_attention_fwd_lse_bf16 / dm_attention_bwd_bf16; 6: + dm_conv3x3_wgrad_*; 7: + dm_groupnorm_nhwc_bwd_affine; 8: dm_attention_fwd_lse_bf16 takes V untransposed; 9: + dm_gbuffer_compact_tiled; 10: + dm_softmax_rows_bf16 / _bwd, dm_groupnorm_nhwc_bwd_res, dm_conv3x3_small_res_nhwc_bf16, dm_conv2x2_nhwc_bf16; 11: + the _f16 instantiations of the net kernels (dm_elem.h), dm_attention_fwd_fp8; 12: + dm_conv2x2_subpixel_nhwc_bf16 / _f16; 13: + dm_groupnorm_nhwc_stats, dm_conv3x3_gn_ok, dm_conv3x3_gn_nhwc_bf16_fused / _f16 (GroupNorm apply folded into the halo-patch convolution)
+int dm_abi_version(void) { return 14; }    // 4: + dm_grid_build / dm_grid_any_hit_rays / dm_host_free, dm_mc_scene.grid; 5: + dm_attention_fwd_lse_bf16 / dm_attention_bwd_bf16; 6: + dm_conv3x3_wgrad_*; 7: + dm_groupnorm_nhwc_bwd_affine; 8: dm_attention_fwd_lse_bf16 takes V untransposed; 9: + dm_gbuffer_compact_tiled; 10: + dm_softmax_rows_bf16 / _bwd, dm_groupnorm_nhwc_bwd_res, dm_conv3x3_small_res_nhwc_bf16, dm_conv2x2_nhwc_bf16; 11: + the _f16 instantiations of the net kernels (dm_elem.h), dm_attention_fwd_fp8; 12: + dm_conv2x2_subpixel_nhwc_bf16 / _f16; 13: + dm_groupnorm_nhwc_stats, dm_conv3x3_gn_ok, dm_conv3x3_gn_nhwc_bf16_fused / _f16 (GroupNorm apply folded into the halo-patch convolution); 14: + dm_transpose_bf16 / _f16, dm_gemm_bf16_batched / _f16, dm_softmax_rows_* up to 16384 columns (the VAE mid-block attention on dm_gemm_*_fused)
 
 // opp[t][i] = vertex opposite to edge i of triangle t in the other triangle sharing that edge,
 // -1 if none.  Edge 0 = (v1,v2), edge 1 = (v2,v0), edge 2 = (v0,v1).  Host pointers.

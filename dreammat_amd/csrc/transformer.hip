@@ -175,6 +175,38 @@ __global__ __launch_bounds__(256) void k_softmax_rows(const elem_t* __restrict__
     }
 }
 
+// 16-bit matrix transpose, batched: src [batch, R, C] -> dst [batch, C, R] (R % 64 == C % 64 == 0).  64 x 64 tiles through LDS,
+// 16-byte loads and stores on both sides; the operands of the VAE mid-block attention's GEMM form that must be contracted along
+// their rows (V^T for P V, K^T / Q^T / dO^T and the transposed probabilities / score gradients of its backward).
+__global__ __launch_bounds__(256) void k_transpose16(const elem_t* __restrict__ src, elem_t* __restrict__ dst, int R, int C) {
+    __shared__ unsigned short t[64][66];                       // (pitch 33 words: a column walk touches every bank once)
+    const int tid = threadIdx.x;
+    const long long base = (long long)blockIdx.z * R * C;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int rr = tid >> 3, ch = tid & 7;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int r = rr + 32 * k;
+        const uint4 v = *reinterpret_cast<const uint4*>(src + base + (long long)(r0 + r) * C + c0 + ch * 8);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            t[r][ch * 8 + 2 * e] = (unsigned short)(w[e] & 0xffffu);
+            t[r][ch * 8 + 2 * e + 1] = (unsigned short)(w[e] >> 16);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int oc = rr + 32 * k;                            // output row = source column
+        unsigned w[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            w[e] = (unsigned)t[ch * 8 + 2 * e][oc] | ((unsigned)t[ch * 8 + 2 * e + 1][oc] << 16);
+        *reinterpret_cast<uint4*>(dst + base + (long long)(c0 + oc) * R + r0 + ch * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 // Skip connection of a UNet up block with the ControlNet residual folded in (diffusers UNet2DConditionModel.forward:
 // `down_block_res_samples = [s + r ...]` then `torch.cat([hidden, res_sample], dim=1)` in every up-block resnet):
 // y[row, 0:Cx] = x[row], y[row, Cx:Cx+Cs] = s[row] (+ r[row] * r_scale) -- one pass instead of an add pass and a cat pass.
@@ -285,10 +317,10 @@ int DM_T(dm_geglu_, )(const void* h, void* y, long long rows, int inner, hipStre
     return DM_OK;
 }
 
-// s, p [rows, cols] bf16 row-contiguous: p = softmax(scale * s) over the columns, fp32 arithmetic.  cols % 8 == 0, cols <= 8192.
+// s, p [rows, cols] bf16 row-contiguous: p = softmax(scale * s) over the columns, fp32 arithmetic.  cols % 8 == 0, cols <= 16384; p may alias s.
 int DM_T(dm_softmax_rows_, )(const void* s, void* p, long long rows, int cols, float scale, hipStream_t stream) {
     if (!s || !p || rows < 0 || cols <= 0) return DM_ERR_ARG;
-    if (cols % 8 != 0 || cols > 8192) return DM_ERR_UNSUPPORTED;
+    if (cols % 8 != 0 || cols > 16384) return DM_ERR_UNSUPPORTED;
     if (((uintptr_t)s | (uintptr_t)p) & 15) return DM_ERR_ARG;
     if (rows == 0) return DM_OK;
     const int nch = (cols / 8 + 255) / 256;
@@ -299,7 +331,8 @@ int DM_T(dm_softmax_rows_, )(const void* s, void* p, long long rows, int cols, f
     switch (nch) {
     case 1: DM_SM(1); break;
     case 2: DM_SM(2); break;
-    default: DM_SM(4); break;
+    case 3: case 4: DM_SM(4); break;
+    default: DM_SM(8); break;
     }
 #undef DM_SM
     DM_LAUNCH_CHECK();
@@ -309,7 +342,7 @@ int DM_T(dm_softmax_rows_, )(const void* s, void* p, long long rows, int cols, f
 // Backward of the above: ds = scale * p * (dp - rowsum(p * dp)); p, dp, ds [rows, cols] bf16 (ds may alias dp).
 int DM_T(dm_softmax_rows_bwd_, )(const void* p, const void* dp, void* ds, long long rows, int cols, float scale, hipStream_t stream) {
     if (!p || !dp || !ds || rows < 0 || cols <= 0) return DM_ERR_ARG;
-    if (cols % 8 != 0 || cols > 8192) return DM_ERR_UNSUPPORTED;
+    if (cols % 8 != 0 || cols > 16384) return DM_ERR_UNSUPPORTED;
     if (((uintptr_t)p | (uintptr_t)dp | (uintptr_t)ds) & 15) return DM_ERR_ARG;
     if (rows == 0) return DM_OK;
     const int nch = (cols / 8 + 255) / 256;
@@ -320,9 +353,21 @@ int DM_T(dm_softmax_rows_bwd_, )(const void* p, const void* dp, void* ds, long l
     switch (nch) {
     case 1: DM_SM(1); break;
     case 2: DM_SM(2); break;
-    default: DM_SM(4); break;
+    case 3: case 4: DM_SM(4); break;
+    default: DM_SM(8); break;
     }
 #undef DM_SM
+    DM_LAUNCH_CHECK();
+    return DM_OK;
+}
+
+// src [batch, R, C] -> dst [batch, C, R], 16-bit elements, R % 64 == C % 64 == 0, 16-byte aligned, src != dst.
+int DM_T(dm_transpose_, )(const void* src, void* dst, int batch, int R, int C, hipStream_t stream) {
+    if (!src || !dst || src == dst || batch <= 0 || R <= 0 || C <= 0) return DM_ERR_ARG;
+    if (R % 64 != 0 || C % 64 != 0 || batch > 65535 || R / 64 > 65535) return DM_ERR_UNSUPPORTED;
+    if (((uintptr_t)src | (uintptr_t)dst) & 15) return DM_ERR_ARG;
+    DM_ENTER();
+    hipLaunchKernelGGL(k_transpose16, dim3(C / 64, R / 64, batch), dim3(256), 0, stream, (const elem_t*)src, (elem_t*)dst, R, C);
     DM_LAUNCH_CHECK();
     return DM_OK;
 }

@@ -777,9 +777,10 @@ def conv3x3_small_nhwc(x_nhwc, w_tap_major, bias, stride=1, pad=(1, 1), act=0, r
     return y
 
 
-def gemm_fused(x, w, bias=None, residual=None, geglu=False):
+def gemm_fused(x, w, bias=None, residual=None, geglu=False, out=None):
     """y[..., N] = x[..., K] @ w[N, K]^T + bias (+ residual[..., N]) on the 1-tap LDS-DMA kernel (forward only).
-    geglu: `w` / `bias` rows interleaved by `geglu_interleave`; returns value * gelu(gate), [..., N/2]."""
+    geglu: `w` / `bias` rows interleaved by `geglu_interleave`; returns value * gelu(gate), [..., N/2].
+    out: a contiguous tensor of the result's shape and dtype to write into (a reused workspace)."""
     _need_cuda(x, w, bias, residual)
     assert x.is_contiguous() and w.is_contiguous()
     fn, name = _sym("dm_gemm_bf16_fused", _same_half(x, w, bias, residual))
@@ -787,7 +788,11 @@ def gemm_fused(x, w, bias=None, residual=None, geglu=False):
     M = x.numel() // K
     assert x.shape[-1] == K
     No = N // 2 if geglu else N
-    y = torch.empty(*x.shape[:-1], No, device=x.device, dtype=x.dtype)
+    if out is not None:
+        assert out.is_contiguous() and out.dtype == x.dtype and out.numel() == M * No and 2 * M * max(K, No) <= CONV_MAX_TENSOR_BYTES
+        y = out
+    else:
+        y = torch.empty(*x.shape[:-1], No, device=x.device, dtype=x.dtype)
     if 2 * M * max(K, No) > CONV_MAX_TENSOR_BYTES:           # same 32-bit addressing limit: row chunks of the same buffers
         rows = max(16, (CONV_MAX_TENSOR_BYTES // (2 * max(K, No))) // 16 * 16)
         x2, y2 = x.reshape(M, K), y.view(M, No)
@@ -799,11 +804,24 @@ def gemm_fused(x, w, bias=None, residual=None, geglu=False):
     if bias is not None:
         assert bias.is_contiguous() and bias.numel() == N
     if residual is not None:
-        assert residual.is_contiguous() and residual.shape == y.shape
+        assert residual.is_contiguous() and residual.numel() == y.numel()
     with _Timed(f"gemm{'+geglu' if geglu else ''}{'+res' if residual is not None else ''}[M={M},K={K},N={N}]", 2.0 * M * K * N):
         check(fn(x.data_ptr(), w.data_ptr(), bias.data_ptr() if bias is not None else None,
                  residual.data_ptr() if residual is not None else None, y.data_ptr(), M, K, N, 1 if geglu else 0, _stream()), name)
     return y
+
+
+def gemm_batched(x, w, out):
+    """out[i] = x[i] @ w[i]^T for every item of the leading dimension (dm_gemm_*_batched): x [G, M, K], w [G, N, K], out [G, M, N]
+    contiguous 16-bit, M % 256 == 0, K % 64 == N % 64 == 0 (forward only)."""
+    _need_cuda(x, w, out)
+    G, M, K = x.shape
+    N = w.shape[1]
+    assert x.is_contiguous() and w.is_contiguous() and out.is_contiguous() and w.shape == (G, N, K) and out.numel() == G * M * N
+    fn, name = _sym("dm_gemm_bf16_batched", _same_half(x, w, out))
+    with _Timed(f"gemm_batched[G={G},M={M},K={K},N={N}]", 2.0 * G * M * K * N):
+        check(fn(x.data_ptr(), w.data_ptr(), out.data_ptr(), G, M, K, N, _stream()), name)
+    return out
 
 
 def linear_small_ok(M, K, N):
@@ -1525,8 +1543,144 @@ class _SoftmaxRows(torch.autograd.Function):
         return ds, None
 
 
+def transpose_rows(x, out=None):
+    """x [..., R, C] (16-bit, contiguous) -> [..., C, R] contiguous (dm_transpose_bf16 / _f16; R % 64 == C % 64 == 0)."""
+    _need_cuda(x)
+    assert x.dtype in HALF_DTYPES and x.is_contiguous() and x.dim() >= 2
+    R, C = x.shape[-2], x.shape[-1]
+    batch = x.numel() // (R * C)
+    if out is None:
+        out = torch.empty(*x.shape[:-2], C, R, device=x.device, dtype=x.dtype)
+    assert out.is_contiguous() and out.dtype == x.dtype and out.numel() == x.numel() and out.data_ptr() != x.data_ptr()
+    with _Timed(f"transpose[{R}x{C}]", 4.0 * x.numel()):
+        fn, name = _sym("dm_transpose_bf16", x.dtype)
+        check(fn(x.data_ptr(), out.data_ptr(), batch, R, C, _stream()), name)
+    return out
+
+
+def _softmax_rows_(s, scale):
+    """in place: s <- softmax(scale * s) per row (no autograd)"""
+    cols = s.shape[-1]
+    rows = s.numel() // cols
+    with _Timed(f"softmax_rows[{cols}]", 4.0 * rows * cols):
+        fn, name = _sym("dm_softmax_rows_bf16", s.dtype)
+        check(fn(s.data_ptr(), s.data_ptr(), rows, cols, float(scale), _stream()), name)
+    return s
+
+
+def _softmax_rows_bwd_(p, dp, scale):
+    """in place: dp <- scale * p * (dp - rowsum(p * dp)) (no autograd)"""
+    cols = p.shape[-1]
+    rows = p.numel() // cols
+    with _Timed(f"softmax_rows_bwd[{cols}]", 6.0 * rows * cols):
+        fn, name = _sym("dm_softmax_rows_bwd_bf16", p.dtype)
+        check(fn(p.data_ptr(), dp.data_ptr(), dp.data_ptr(), rows, cols, float(scale), _stream()), name)
+    return dp
+
+
+_WIDE_ATTN_WS = {}      # (device, dtype, G, Sq, Skv, D) -> workspace of wide_head_attention, reused by every call (one stream)
+WIDE_ATTN_GROUP_BYTES = 128 << 20      # score bytes (G * Sq * Skv * 2) one launch group may cover: 4 images at S = 4096, 1 at 16384
+
+
+def _wide_attn_group(B, Sq, Skv):
+    """images per launch: enough to fill the chip's 256 CUs with tiles (one 4096 x 4096 x 512 product is ONE round of 256 tiles, a
+    [4096, 512] output 64 tiles), bounded so the score workspace stays independent of the batch"""
+    g = 1
+    while g * 2 <= B and B % (g * 2) == 0 and (g * 2) * Sq * Skv * 2 <= WIDE_ATTN_GROUP_BYTES:
+        g *= 2
+    return g
+
+
+def _wide_attn_ws(q, G, Sq, Skv, D, backward):
+    """score-sized buffers ([G, Sq, Skv]: one forward, four backward) and [G, D, S] buffers for the transposed operands of a group"""
+    key = (q.device, q.dtype, G, Sq, Skv, D)
+    ws = _WIDE_ATTN_WS.get(key)
+    if ws is None:
+        ws = _WIDE_ATTN_WS[key] = {"score": [], "small": []}
+    mk = lambda n: torch.empty(n, device=q.device, dtype=q.dtype)
+    while len(ws["score"]) < (4 if backward else 1):
+        ws["score"].append(mk(G * Sq * Skv))
+    while len(ws["small"]) < (3 if backward else 1):
+        ws["small"].append(mk(G * D * max(Sq, Skv)))
+    return ws["score"], ws["small"]
+
+
+def wide_head_attention_ok(q, k, v):
+    """q [B, Sq, D], k / v [B, Skv, D]: every product of the GEMM form (forward and backward) inside dm_gemm_*_batched's and
+    dm_transpose_*'s domains, the rows inside dm_softmax_rows_*'s."""
+    if not (q.is_cuda and q.dtype in HALF_DTYPES and q.dim() == 3 and k.shape == v.shape and k.shape[0] == q.shape[0] and k.shape[2] == q.shape[2]):
+        return False
+    Sq, D, Skv = q.shape[1], q.shape[2], k.shape[1]
+    return Sq % 256 == 0 and Skv % 256 == 0 and D % 64 == 0 and Skv <= 16384 and 2 * Sq * Skv <= CONV_MAX_TENSOR_BYTES // 4
+
+
+class _WideHeadAttention(torch.autograd.Function):
+    """softmax(scale * q k^T) v for ONE head too wide for the flash kernels' register tiles (AutoencoderKL's mid block: d = 512,
+    S = 4096 at 512^2; the one differentiated attention of the path, dreammat_guidance.py:284-292): a few images at a time on the
+    hand-written GEMM (dm_gemm_*_batched), the row-softmax kernels and dm_transpose_*, over ONE reused [G, Sq, Skv] score buffer
+    (four in the backward; G = 4 images at S = 4096, whatever the batch) -- no [B, S, S] tensor in either direction, nothing saved
+    but q, k, v: the backward recomputes a group's probabilities (one more product and softmax pass).  Products per group:
+    forward s = q k^T, o = p (v^T)^T; backward s, dp = do v^T, dq = ds (k^T)^T, dv = p^T (do^T)^T, dk = ds^T (q^T)^T -- every operand
+    contracted along its rows is transposed first (v, k, q, do of the group into [G, D, S] buffers; p, ds into two more score
+    buffers)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, scale):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        B, Sq, D = q.shape
+        Skv = k.shape[1]
+        G = _wide_attn_group(B, Sq, Skv)
+        score, small = _wide_attn_ws(q, G, Sq, Skv, D, False)
+        s, vt = score[0].view(G, Sq, Skv), small[0][:G * D * Skv].view(G, D, Skv)
+        o = torch.empty_like(q)
+        for b in range(0, B, G):
+            gemm_batched(q[b:b + G], k[b:b + G], s)
+            _softmax_rows_(s, scale)
+            transpose_rows(v[b:b + G], out=vt)
+            gemm_batched(s, vt, o[b:b + G])
+        ctx.save_for_backward(q, k, v)
+        ctx.scale = float(scale)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v = ctx.saved_tensors
+        B, Sq, D = q.shape
+        Skv = k.shape[1]
+        do = do.contiguous()
+        G = _wide_attn_group(B, Sq, Skv)
+        score, small = _wide_attn_ws(q, G, Sq, Skv, D, True)
+        p, dp = score[0].view(G, Sq, Skv), score[1].view(G, Sq, Skv)
+        pt, dst = score[2].view(G, Skv, Sq), score[3].view(G, Skv, Sq)
+        kt, qt, dot = small[0][:G * D * Skv].view(G, D, Skv), small[1][:G * D * Sq].view(G, D, Sq), small[2][:G * D * Sq].view(G, D, Sq)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        for b in range(0, B, G):
+            g = slice(b, b + G)
+            gemm_batched(q[g], k[g], p)
+            _softmax_rows_(p, ctx.scale)
+            gemm_batched(do[g], v[g], dp)
+            _softmax_rows_bwd_(p, dp, ctx.scale)             # dp <- ds
+            transpose_rows(k[g], out=kt)
+            gemm_batched(dp, kt, dq[g])
+            transpose_rows(p, out=pt)
+            transpose_rows(do[g], out=dot)
+            gemm_batched(pt, dot, dv[g])
+            transpose_rows(dp, out=dst)
+            transpose_rows(q[g], out=qt)
+            gemm_batched(dst, qt, dk[g])
+        return dq, dk, dv, None
+
+
+def wide_head_attention(q, k, v, scale):
+    """softmax(scale * q k^T) v, q [B, Sq, D], k / v [B, Skv, D] 16-bit (one head), differentiable; see _WideHeadAttention.
+    The caller keeps scale * |q k^T| inside the element type's range (IEEE half: fold a power of two into q)."""
+    _need_cuda(q, k, v)
+    assert wide_head_attention_ok(q, k, v)
+    return _WideHeadAttention.apply(q, k, v, scale)
+
+
 def softmax_rows_ok(s):
-    return s.is_cuda and s.dtype in HALF_DTYPES and s.shape[-1] % 8 == 0 and s.shape[-1] <= 8192
+    return s.is_cuda and s.dtype in HALF_DTYPES and s.shape[-1] % 8 == 0 and s.shape[-1] <= 16384
 
 
 def softmax_rows(s, scale):

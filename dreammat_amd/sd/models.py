@@ -8,6 +8,8 @@ task statement names SD-1.5.
 from dataclasses import dataclass, field
 from typing import Optional, Tuple
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -283,6 +285,17 @@ class VaeAttention(nn.Module):
         self.to_k = nn.Linear(ch, ch)
         self.to_v = nn.Linear(ch, ch)
         self.to_out = nn.ModuleList([nn.Linear(ch, ch), nn.Identity()])
+        self._q16 = None
+
+    def _q_sixteenth(self):
+        """(to_q.weight / 16, to_q.bias / 16) of the frozen projection, formed once per weight version (persistent tensors: the
+        transposed-weight cache of layers.linear_fused is keyed by the tensor)"""
+        w, b = self.to_q.weight, self.to_q.bias
+        key = (w.data_ptr(), w._version, b._version, w.dtype)
+        if self._q16 is None or self._q16[0] != key:
+            with torch.no_grad():
+                self._q16 = (key, (w.detach() * 0.0625).contiguous(), (b.detach() * 0.0625).contiguous())
+        return self._q16[1], self._q16[2]
 
     def forward(self, x):
         B, C, H, W = x.shape
@@ -296,11 +309,21 @@ class VaeAttention(nn.Module):
             h = h.reshape(B, H * W, C)
         else:
             h = group_norm_act(self.group_norm, x, False).permute(0, 2, 3, 1).reshape(B, H * W, C)
-        if layers._native_expected(h):
-            # the one differentiated attention of the path (1 head of 512): projections and the two products on hipBLASLt under
-            # autograd, the softmax between them on the row kernels
-            layers.note_fallback("vae_attention", f"C={C} S={H * W} autograd: QK^T + PV (and their four backward products)")
         lin = layers.linear_fused        # (frozen projections under autograd: forward + data gradient on the hand-written GEMM, round 6)
+        frozen = not (self.to_q.weight.requires_grad or self.to_q.bias.requires_grad)
+        if (layers._native_expected(h) and frozen and h.shape[1] % 256 == 0 and C % 64 == 0 and h.shape[1] <= 16384
+                and hipops.gemm_fused_ok(B * H * W, C, C) and os.environ.get("DREAMMAT_VAE_ATTENTION") != "blas"):
+            # the one differentiated attention of the path (1 head of 512): a few images at a time on the hand-written GEMM, the
+            # row-softmax kernels and dm_transpose over one reused [G, S, S] buffer (hipops._WideHeadAttention; round 6 -- it was
+            # torch.matmul on hipBLASLt over a [B, S, S] score tensor).  to_q carries 2^-4 of the scale -- exact, and it keeps the unscaled q.k of 512
+            # channels (22.6x the logits) inside IEEE half -- the softmax kernel the other 16 / sqrt(C), in fp32.
+            wq, bq = self._q_sixteenth()
+            q, k, v = lin(h, wq, bq), lin(h, self.to_k.weight, self.to_k.bias), lin(h, self.to_v.weight, self.to_v.bias)
+            o = hipops.wide_head_attention(q, k, v, 16.0 * C ** -0.5)
+            o = lin(o, self.to_out[0].weight, self.to_out[0].bias)
+            return o.reshape(B, H, W, C).permute(0, 3, 1, 2) + x
+        if layers._native_expected(h):
+            layers.note_fallback("vae_attention", f"C={C} S={H * W} autograd: QK^T + PV (and their four backward products)")
         q, k, v = lin(h, self.to_q.weight, self.to_q.bias), lin(h, self.to_k.weight, self.to_k.bias), lin(h, self.to_v.weight, self.to_v.bias)
         if q.dtype == torch.float16:
             # IEEE half: the UNSCALED q.k of 512 channels (22.6x the scaled logits) can pass 65504 -> inf -> NaN in the stored

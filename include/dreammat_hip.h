@@ -374,6 +374,10 @@ int dm_conv3x3_small_res_nhwc_bf16(const void* x, const void* w, const void* bia
  * an erfc polynomial (Abramowitz-Stegun 7.1.26, |error of Phi| < 3e-7).  M % 16 == 0, K % 64 == 0, N % 64 == 0 (geglu: N % 128 == 0, no residual). */
 int dm_gemm_bf16_fused(const void* x, const void* w, const void* bias, const void* residual, void* y, long long M, int K,
                        int N, int geglu, dm_stream_t stream);
+/* `batch` independent products in one launch (ABI v14): y[i] = x[i] w[i]^T, x [batch,M,K], w [batch,N,K], y [batch,M,N] contiguous,
+ * no bias / residual; M % 256 == 0, K % 64 == 0, N % 64 == 0.  The per-image products of the VAE mid-block attention (one head of
+ * 512, differentiated: dreammat_guidance.py:284-292 -> diffusers' Attention in AutoencoderKL's mid block), a few images per launch. */
+int dm_gemm_bf16_batched(const void* x, const void* w, void* y, int batch, long long M, int K, int N, dm_stream_t stream);
 
 /* ---- normalisation ----------------------------------------------------------------------- */
 /* Forward only (frozen nets under no_grad): the coefficient kernel folded into the apply kernel -- 2 launches instead of
@@ -433,9 +437,13 @@ int dm_cat_add_bf16(const void* x, const void* s, const void* r, void* y, long l
  * head of width 512, differentiated: dreammat_guidance.py:284-292 -> diffusers' Attention in AutoencoderKL's mid block) keeps
  * its two matrix products on the GEMM library and replaces the scale / cast / softmax / cast chain between them.
  * fwd: p = softmax(scale * s) per row; bwd: ds = scale * p * (dp - rowsum(p * dp)).  [rows, cols] bf16 row-contiguous, fp32
- * arithmetic, cols % 8 == 0, cols <= 8192; ds may alias dp. */
+ * arithmetic, cols % 8 == 0, cols <= 16384; p may alias s, ds may alias dp.
+ * ABI v14: the two products (and the four of the backward) run on dm_gemm_*_fused one image at a time over one reusable
+ * [S, S] score buffer -- no [B, S, S] tensor, nothing left on the GEMM library; operands that must be contracted along their
+ * rows are transposed by dm_transpose_*: src [batch, R, C] -> dst [batch, C, R], 16-bit elements, R % 64 == C % 64 == 0. */
 int dm_softmax_rows_bf16(const void* s, void* p, long long rows, int cols, float scale, dm_stream_t stream);
 int dm_softmax_rows_bwd_bf16(const void* p, const void* dp, void* ds, long long rows, int cols, float scale, dm_stream_t stream);
+int dm_transpose_bf16(const void* src, void* dst, int batch, int R, int C, dm_stream_t stream);
 
 /* ---- IEEE-half instantiations of the net kernels (ABI v11) --------------------------------- */
 /* The reference's nets run in fp16 (`half_precision_weights`, threestudio/models/guidance/dreammat_guidance.py:56,92-94;
@@ -469,6 +477,7 @@ int dm_conv3x3_small_res_nhwc_f16(const void* x, const void* w, const void* bias
                                    dm_stream_t stream);
 int dm_gemm_f16_fused(const void* x, const void* w, const void* bias, const void* residual, void* y, long long M, int K,
                        int N, int geglu, dm_stream_t stream);
+int dm_gemm_f16_batched(const void* x, const void* w, void* y, int batch, long long M, int K, int N, dm_stream_t stream);
 int dm_layernorm_f16(const void* x, const void* gamma, const void* beta, void* y, long long rows, int C, float eps,
                       dm_stream_t stream);
 int dm_geglu_f16(const void* h, void* y, long long rows, int inner, dm_stream_t stream);
@@ -477,6 +486,7 @@ int dm_cat_add_f16(const void* x, const void* s, const void* r, void* y, long lo
                     dm_stream_t stream);
 int dm_softmax_rows_f16(const void* s, void* p, long long rows, int cols, float scale, dm_stream_t stream);
 int dm_softmax_rows_bwd_f16(const void* p, const void* dp, void* ds, long long rows, int cols, float scale, dm_stream_t stream);
+int dm_transpose_f16(const void* src, void* dst, int batch, int R, int C, dm_stream_t stream);
 int dm_groupnorm_nhwc_fwd_f16(const void* x, const void* gamma, const void* beta, void* y, float* ws, int B, int HW,
                           int C, float eps, int act, dm_stream_t stream);
 int dm_groupnorm_nhwc_infer_f16(const void* x, const void* gamma, const void* beta, void* y, float* ws, int B, int HW, int C,

@@ -203,7 +203,7 @@ def test_c_abi_exports_every_declared_symbol():
     """The library loads on a GPU-less box and exports exactly what include/dreammat_hip.h declares."""
     import os, re
     L = _lib.lib()
-    assert L.dm_abi_version() == _lib.ABI_VERSION == 13
+    assert L.dm_abi_version() == _lib.ABI_VERSION == 14
     hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "dreammat_hip.h")).read()
     declared = set(re.findall(r"\b(dm_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())

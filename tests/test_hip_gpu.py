@@ -1196,6 +1196,105 @@ def test_resnet_block_with_folded_groupnorm_equals_the_two_call_form(dev, monkey
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("R,C,batch", [(64, 64, 1), (192, 512, 3), (4096, 512, 2)])
+def test_transpose_kernel_is_exact(dev, dtype, R, C, batch):
+    """dm_transpose_bf16 / _f16 (ABI v14): [batch, R, C] -> [batch, C, R], bit for bit"""
+    torch.manual_seed(33)
+    x = torch.randn(batch, R, C).to(dtype).to(dev)
+    y = hipops.transpose_rows(x)
+    assert y.shape == (batch, C, R) and torch.equal(y, x.transpose(1, 2).contiguous())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,Sq,Skv,D", [(2, 256, 256, 128), (3, 256, 512, 64), (1, 256, 16384, 64), (8, 4096, 4096, 512)])
+def test_wide_head_attention_gemm_form_forward_and_gradients(dev, dtype, B, Sq, Skv, D):
+    """hipops.wide_head_attention (the VAE mid-block attention's form: per group of images s = q k^T, row softmax, p v on dm_gemm_*_batched /
+    dm_softmax_rows_* / dm_transpose_*, probabilities recomputed in the backward) against fp32 softmax attention: output and the
+    three gradients; rectangular scores; 16384 columns (the 1024^2 shape's row length); the bench shape (8 x 4096 x 512), where
+    forward + backward must allocate less than ONE [B, S, S] score tensor beyond the reusable per-image workspace."""
+    torch.manual_seed(34)
+    q, k, v = torch.randn(B, Sq, D).to(dtype), torch.randn(B, Skv, D).to(dtype), torch.randn(B, Skv, D).to(dtype)
+    g = torch.randn(B, Sq, D).to(dtype)
+    scale = 2.0 * D ** -0.5
+    qr, kr, vr = (t.float().requires_grad_() for t in (q, k, v))
+    ref = torch.softmax(scale * qr @ kr.transpose(1, 2), -1) @ vr
+    ref.backward(g.float())
+    qd, kd, vd = (t.to(dev).requires_grad_() for t in (q, k, v))
+    assert hipops.wide_head_attention_ok(qd, kd, vd)
+    gd = g.to(dev)
+    if B * Sq * Skv >= 1 << 27:
+        hipops.wide_head_attention(qd.detach().requires_grad_(), kd.detach(), vd.detach(), scale).backward(gd)     # (the workspace, once)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    hipops.enable_kernel_timing(True)
+    o = hipops.wide_head_attention(qd, kd, vd, scale)
+    o.backward(gd)
+    torch.cuda.synchronize()
+    if B * Sq * Skv >= 1 << 27:
+        assert torch.cuda.max_memory_allocated() - base < B * Sq * Skv * 2, (torch.cuda.max_memory_allocated() - base, B * Sq * Skv * 2)
+    keys = hipops.kernel_times()
+    hipops.enable_kernel_timing(False)
+    groups = B // hipops._wide_attn_group(B, Sq, Skv)
+    assert sum(r["launches"] for k_, r in keys.items() if k_.startswith("gemm_batched")) == 7 * groups     # 2 forward + 5 backward products per group of images
+    tol = 3e-2 if dtype == torch.bfloat16 else 4e-3       # (scores and probabilities are stored in 16 bits between the kernels)
+    for got, want in ((o.detach(), ref.detach()), (qd.grad, qr.grad), (kd.grad, kr.grad), (vd.grad, vr.grad)):
+        assert torch.isfinite(got).all()
+        assert (got.float().cpu() - want).abs().max().item() < tol * want.abs().max().item() + tol * 1e-1
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_vae_attention_runs_on_hand_written_kernels_without_a_batch_score_tensor(dev, dtype):
+    """VaeAttention (8 x 512 channels x 96 x 96: S = 9216 -- at the bench's 64 x 64 one [B, S, S] tensor is the size of eight
+    activations, which the module's own projections add up to), frozen weights, differentiated input: no call leaves the
+    hand-written kernels (it was torch.matmul on hipBLASLt), forward + backward allocate less than ONE [B, S, S] score tensor
+    beyond the reusable per-image workspace (the old path held two and made two more in the backward), and output and input
+    gradient match the fp32 ATen evaluation of the same module."""
+    from dreammat_amd.sd import layers
+    from dreammat_amd.sd.models import VaeAttention
+    torch.manual_seed(35)
+    B, C, Hh = 8, 512, 96
+    att32 = VaeAttention(C).to(dev).eval()
+    att = VaeAttention(C).to(dev, dtype).eval()
+    att.load_state_dict({k: v.to(dtype) for k, v in att32.state_dict().items()})
+    att32.load_state_dict({k: v.float() for k, v in att.state_dict().items()})
+    for m in (att, att32):
+        for p_ in m.parameters():
+            p_.requires_grad_(False)
+    x = torch.randn(B, C, Hh, Hh, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(B, C, Hh, Hh, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+
+    def run(xin):
+        y = att(xin)
+        y.backward(g)
+        return y
+
+    run(x.clone().requires_grad_())                       # (workspace of the shape allocated here, once)
+    torch.cuda.synchronize()
+    layers.fallbacks(clear=True)
+    xd = x.clone().requires_grad_()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    y = run(xd)
+    torch.cuda.synchronize()
+    delta = torch.cuda.max_memory_allocated() - base
+    score_tensor = B * (Hh * Hh) ** 2 * 2
+    assert not layers.fallbacks(), layers.fallbacks()
+    assert delta < score_tensor, (delta, score_tensor)
+    x32 = x.float().requires_grad_()
+    old = layers.CONV_BACKEND
+    try:
+        layers.CONV_BACKEND = "gemm"
+        y32 = att32(x32)
+        y32.backward(g.float())
+    finally:
+        layers.CONV_BACKEND = old
+    tol = 3e-2 if dtype == torch.bfloat16 else 4e-3
+    assert ((y.detach().float() - y32.detach()).abs().max() / y32.abs().max()).item() < tol
+    assert ((xd.grad.float() - x32.grad).abs().max() / x32.grad.abs().max()).item() < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_frozen_linear_under_autograd_runs_on_the_fused_gemm(dev, dtype):
     """layers.linear_fused on differentiated activations through a frozen layer (the VAE encoder's 1 x 1 shortcuts and attention
     projections): forward and data gradient on dm_gemm_*_fused (hipops._LinearFrozen), with bias and residual, against fp32 torch."""
