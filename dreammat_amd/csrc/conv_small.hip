@@ -161,36 +161,52 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(SmallConvArgs a, int c
         for (int cb = 0; cb < n_cb; ++cb) load_weights(cb, wl0 + cb * C::W_BYTES);
     const int trow0 = 2 * MB * wave + (l31 >> 4), tcol = l31 & 15;        // this lane's pixel of M block 0 (block 1: two tile rows down)
     [[maybe_unused]] const bool w_live = l31 < WR;                        // (WR < 32: this lane's weight row exists)
-    // (CP == 128) the NEXT tile's patch is requested into registers before this tile's MFMAs: the loads are in flight while the
-    // workgroup multiplies (the compute phase has no other vector-memory reads), and land in LDS after the barrier that follows.
-    [[maybe_unused]] constexpr int NCH = C::PH * C::PW * C::NC, NTRIP = (NCH + 255) / 256;
-    [[maybe_unused]] u32x4s pv[CP == 128 ? NTRIP : 1];
+    // The patch arrives by unconditional buffer loads, all of a tile's in flight before the first LDS store (out-of-image pixels and
+    // channel chunks beyond Cin are offsets past the descriptor's end: zeros, no branch; a chunk that straddles Cin -- 22 = 2.75
+    // chunks -- is loaded whole and its tail dwords cleared).  The bounds-tested form it replaces was one serialized HBM round trip
+    // per 256 chunks.  AHEAD (at most 12 chunks per thread): the NEXT tile's patch is requested into registers before this tile's
+    // MFMAs, the loads are in flight while the workgroup multiplies, and land in LDS after the barrier that follows.
+    constexpr int NCH = C::PH * C::PW * C::NC, NTRIP = (NCH + 255) / 256;
+    [[maybe_unused]] constexpr bool AHEAD = NTRIP <= 12;
+    [[maybe_unused]] u32x4s pv[NTRIP];
 #if defined(__HIP_DEVICE_COMPILE__)
-    [[maybe_unused]] auto request_patch = [&](int tile_) __attribute__((always_inline)) {
-        if constexpr (CP == 128) {                                         // (cin == 128: whole chunks; the launcher checked 32-bit offsets)
-            int t_ = tile_;
-            const int tx_ = t_ % tiles_x; t_ /= tiles_x;
-            const int ty_ = t_ % tiles_y;
-            const int b_ = t_ / tiles_y;
-            const int iy0_ = ty_ * C::TH * STRIDE - a.pad_y, ix0_ = tx_ * C::TW * STRIDE - a.pad_x;
-            const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(unsigned)((long long)a.B * a.Hin * a.Win * CP * 2), 0x00020000);
+    auto request_patch = [&](int tile_) __attribute__((always_inline)) {
+        int t_ = tile_;
+        const int tx_ = t_ % tiles_x; t_ /= tiles_x;
+        const int ty_ = t_ % tiles_y;
+        const int b_ = t_ / tiles_y;
+        const int iy0_ = ty_ * C::TH * STRIDE - a.pad_y, ix0_ = tx_ * C::TW * STRIDE - a.pad_x;
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(unsigned)((long long)a.B * a.Hin * a.Win * cin * 2), 0x00020000);
 #pragma unroll
-            for (int t = 0; t < NTRIP; ++t) {
-                const int i = tid + 256 * t;
-                const int row = i / C::NC, c = i - row * C::NC;
-                const int py = row / C::PW, px = row - py * C::PW;
-                const int yy = iy0_ + py, xx = ix0_ + px;
-                const bool ok = i < NCH && tile_ < n_tiles && (unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)a.Win;
-                const unsigned off = ok ? ((((unsigned)b_ * (unsigned)a.Hin + (unsigned)yy) * (unsigned)a.Win + (unsigned)xx) * (unsigned)CP + 8u * (unsigned)c) * 2u : 0xfffffff0u;
+        for (int t = 0; t < NTRIP; ++t) {
+            const int i = tid + 256 * t;
+            const int row = i / C::NC, c = i - row * C::NC;
+            const int py = row / C::PW, px = row - py * C::PW;
+            const int yy = iy0_ + py, xx = ix0_ + px;
+            const bool ok = i < NCH && tile_ < n_tiles && 8 * c < cin && (unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)a.Win;
+            const unsigned off = ok ? ((((unsigned)b_ * (unsigned)a.Hin + (unsigned)yy) * (unsigned)a.Win + (unsigned)xx) * (unsigned)cin + 8u * (unsigned)c) * 2u : 0xfffffff0u;
 #if defined(DM_ABL_SMALL_NOLOAD)
-                pv[t] = u32x4s{off, 0u, 0u, 0u};
+            pv[t] = u32x4s{off, 0u, 0u, 0u};
 #else
-                pv[t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 0, 0);
+            pv[t] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 0, 0);
 #endif
-            }
         }
     };
-    if constexpr (CP == 128) request_patch((int)blockIdx.x);
+    auto store_patch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < NTRIP; ++t) {
+            const int i = tid + 256 * t;
+            const int row = i / C::NC, c = i - row * C::NC;
+            u32x4s v = pv[t];
+            if constexpr (CP != 128) {                                     // (Cin even: whole dwords are inside or outside)
+#pragma unroll
+                for (int k = 1; k < 4; ++k)
+                    if (8 * c + 2 * k >= cin) v[k] = 0u;
+            }
+            if (i < NCH) *reinterpret_cast<u32x4s*>(patch + row * C::RB + ((c ^ C::swz(row)) << 4)) = v;
+        }
+    };
+    if constexpr (AHEAD) request_patch((int)blockIdx.x);
 #endif
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         int t = tile;
@@ -198,30 +214,14 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(SmallConvArgs a, int c
         const int ty = t % tiles_y;
         const int b = t / tiles_y;
         const int oy0 = ty * C::TH, ox0 = tx * C::TW;
-        [[maybe_unused]] const int iy0 = oy0 * STRIDE - a.pad_y, ix0 = ox0 * STRIDE - a.pad_x;
         __syncthreads();                                                   // the previous tile's patch is no longer read
 #if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (CP == 128) {
-#pragma unroll
-            for (int t = 0; t < NTRIP; ++t) {
-                const int i = tid + 256 * t;
-                const int row = i / C::NC, c = i - row * C::NC;
-                if (i < NCH) *reinterpret_cast<u32x4s*>(patch + row * C::RB + ((c ^ C::swz(row)) << 4)) = pv[t];
-            }
-        } else
+        if constexpr (!AHEAD) request_patch(tile);
+        store_patch();
 #endif
-        for (int i = tid; i < C::PH * C::PW * C::NC; i += 256) {          // the patch: one chunk per thread and trip
-            const int row = i / C::NC, c = i - row * C::NC;
-            const int py = row / C::PW, px = row - py * C::PW;
-            const int yy = iy0 + py, xx = ix0 + px;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if ((unsigned)yy < (unsigned)a.Hin && (unsigned)xx < (unsigned)a.Win)
-                v = chunk_of(a.x + (((long long)b * a.Hin + yy) * a.Win + xx) * cin, 8 * c);
-            *reinterpret_cast<uint4*>(patch + row * C::RB + ((c ^ C::swz(row)) << 4)) = v;
-        }
         __syncthreads();
 #if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr (CP == 128) request_patch(tile + (int)gridDim.x);
+        if constexpr (AHEAD) request_patch(tile + (int)gridDim.x);
 #endif
         for (int cb = 0; cb < n_cb; ++cb) {
             const char* wl = wl0 + (w_res >= n_cb ? cb : 0) * C::W_BYTES;
@@ -298,7 +298,7 @@ template <int CP, int STRIDE, int TH = 16, int WR = 32>
 int launch_patch(const SmallConvArgs& a, int cin, hipStream_t stream) {
     using C = PatchCfg<CP, STRIDE, TH, WR>;
     if (WR < 32 && a.Cout > WR) return DM_ERR_UNSUPPORTED;
-    if (CP == 128 && (long long)a.B * a.Hin * a.Win * CP * 2 > 0xffffff00LL) return DM_ERR_UNSUPPORTED;      // 32-bit buffer offsets of the patch loads
+    if ((long long)a.B * a.Hin * a.Win * cin * 2 > 0xffffff00LL) return DM_ERR_UNSUPPORTED;                  // 32-bit buffer offsets of the patch loads
     const int n_cb = (a.Cout + 31) / 32;
     const size_t fixed = (size_t)C::PATCH_BYTES + (size_t)n_cb * 32 * 4;
     static_assert(C::PATCH_BYTES + C::W_BYTES + 128 <= 160 * 1024, "LDS budget");
