@@ -298,7 +298,25 @@ template <int CP, int STRIDE, int TH = 16, int WR = 32>
 int launch_patch(const SmallConvArgs& a, int cin, hipStream_t stream) {
     using C = PatchCfg<CP, STRIDE, TH, WR>;
     if (WR < 32 && a.Cout > WR) return DM_ERR_UNSUPPORTED;
-    if ((long long)a.B * a.Hin * a.Win * cin * 2 > 0xffffff00LL) return DM_ERR_UNSUPPORTED;                  // 32-bit buffer offsets of the patch loads
+    {   // 32-bit buffer offsets of the patch loads: an input beyond 4 GB (16 x 1024^2 x 128 channels) goes image group by image group
+        const long long per_img = (long long)a.Hin * a.Win * cin * 2;
+        if (per_img > 0xffffff00LL) return DM_ERR_UNSUPPORTED;
+        if ((long long)a.B * per_img > 0xffffff00LL) {
+            long long nb = 0xffffff00LL / per_img;
+            if (a.res && a.res_B > 1) nb -= nb % a.res_B;                 // (image b takes residual image b % res_B: groups start on a multiple)
+            if (nb <= 0) return DM_ERR_UNSUPPORTED;
+            for (long long b0 = 0; b0 < a.B; b0 += nb) {
+                SmallConvArgs c = a;
+                c.B = (int)std::min<long long>(nb, a.B - b0);
+                c.x = a.x + b0 * a.Hin * a.Win * cin;
+                c.y = a.y + b0 * a.Hout * a.Wout * a.Cout;
+                c.n_pix = (long long)c.B * a.Hout * a.Wout;
+                const int rc = launch_patch<CP, STRIDE, TH, WR>(c, cin, stream);
+                if (rc != DM_OK) return rc;
+            }
+            return DM_OK;
+        }
+    }
     const int n_cb = (a.Cout + 31) / 32;
     const size_t fixed = (size_t)C::PATCH_BYTES + (size_t)n_cb * 32 * 4;
     static_assert(C::PATCH_BYTES + C::W_BYTES + 128 <= 160 * 1024, "LDS budget");

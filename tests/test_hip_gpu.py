@@ -1939,6 +1939,20 @@ def test_conv3x3_small_channel_direct_kernel(dev, B, Cin, Cout, H, W, stride, ac
     assert (y - ref).abs().max().item() < 1e-2 * ref.abs().max().item() + 1e-2
 
 
+def test_conv3x3_small_input_beyond_4gb_goes_in_image_groups(dev):
+    """the image gradient of the VAE's conv_in at BASELINE configs[4]'s shape (16 views at 1024^2: 128 channels in = 4.3 GB, past the
+    patch kernel's 32-bit buffer offsets): the launcher walks the batch in groups of images -- same values as image-by-image calls."""
+    torch.manual_seed(36)
+    B, H, Cin, Cout = 17, 1024, 128, 4
+    x = torch.randn(B, H, H, Cin, device=dev, dtype=torch.float16)
+    assert x.numel() * 2 > 0xffffff00
+    w = (torch.randn(Cout, 9 * Cin, device=dev) * 0.05).to(torch.float16)
+    y = hipops.conv3x3_small_nhwc(x, w, None, 1, (1, 1), 0)
+    for b in (0, 7, 15, 16):
+        assert torch.equal(y[b:b + 1], hipops.conv3x3_small_nhwc(x[b:b + 1].contiguous(), w, None, 1, (1, 1), 0))
+    assert torch.isfinite(y).all()
+
+
 def test_controlnet_cond_embedding_stem_kernels_vs_aten(dev):
     """ControlNetConditioningEmbedding (22 -> 16 -> 32 -> 96 -> 256 -> 320, SiLU between) on the direct stem kernel + the
     Cout-padded MFMA kernel vs the ATen fp32 evaluation; no im2col launch may remain."""

@@ -33,7 +33,13 @@ DREAMMAT_CONV_HALO=0 timeout 300 python bench.py --no-cpu-baseline --no-second-l
 timeout 300 python bench.py --no-cpu-baseline --no-second-leg --attention fp8 2>/dev/null < /dev/null | grep '^{"metric' > gpurun_out/final_bench_line_f16_fp8.json
 timeout 400 python bench.py --no-cpu-baseline --no-second-leg --sd sd15 2>/dev/null < /dev/null | grep '^{"metric' > gpurun_out/final_bench_line_sd15.json
 timeout 600 python bench.py --no-cpu-baseline --cfg5 --steps 3 --warmup 1 2>gpurun_out/final_cfg5.err < /dev/null | grep '^{"metric' > gpurun_out/final_cfg5_bench_line.json
-for f in nodebug bf16 bf16_r5_conv_path f16_fp8 sd15; do python3 -c "import json; d=json.load(open('gpurun_out/final_bench_line_$f.json')); print('$f', d['dtype'], round(d['value'],3), round(d['ms_per_step'],2))"; done
+# round 6: the VAE mid-block attention on the GEMM library (the round-5 form) on the same box; its products one by one; the stem
+# convolutions; the per-key HIP-event table of the step
+DREAMMAT_VAE_ATTENTION=blas timeout 300 python bench.py --no-cpu-baseline --no-second-leg 2>/dev/null < /dev/null | grep '^{"metric' > gpurun_out/final_bench_line_vae_attention_blas.json
+PYTHONPATH=$R timeout 200 python tools/wide_attn_time.py 4 2>/dev/null | grep -v amdgpu.ids > gpurun_out/final_wide_attn_time.txt
+PYTHONPATH=$R timeout 200 python tools/small_conv_time.py 2>/dev/null | grep -v amdgpu.ids > gpurun_out/final_small_conv_time.txt
+timeout 300 python bench.py --no-cpu-baseline --no-second-leg --no-calibration --dump-kernels /tmp/kernels.json > /dev/null 2>&1 < /dev/null && python tools/kernel_dump_table.py /tmp/kernels.json > gpurun_out/final_kernel_event_table.txt
+for f in nodebug bf16 bf16_r5_conv_path f16_fp8 sd15 vae_attention_blas; do python3 -c "import json; d=json.load(open('gpurun_out/final_bench_line_$f.json')); print('$f', d['dtype'], round(d['value'],3), round(d['ms_per_step'],2))"; done
 python3 -c "import json; d=json.load(open('gpurun_out/final_cfg5_bench_line.json')); print('cfg5', d['dtype'], round(d['value'],3), round(d['ms_per_step'],1), d['config']['peak_hbm_gb'])" || tail -3 gpurun_out/final_cfg5.err
 tools/_dma_probe > gpurun_out/final_dma_probe.jsonl 2>&1
 [ "${FINAL_QUICK:-0}" = 1 ] && { python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1; exit 0; }
