@@ -628,7 +628,8 @@ def test_half_dtype_entry_points_resolve_to_exported_symbols():
     from dreammat_amd import _lib, hipops
     for name in ("dm_conv3x3_nhwc_bf16_fused", "dm_conv2x2_nhwc_bf16", "dm_conv2x2_subpixel_nhwc_bf16", "dm_conv3x3_small_res_nhwc_bf16", "dm_gemm_bf16_fused",
                  "dm_attention_fwd_bf16", "dm_layernorm_bf16", "dm_geglu_bf16", "dm_cat_add_bf16", "dm_softmax_rows_bf16",
-                 "dm_softmax_rows_bwd_bf16", "dm_groupnorm_nhwc_fwd", "dm_groupnorm_nhwc_infer", "dm_groupnorm_nhwc_bwd_res"):
+                 "dm_softmax_rows_bwd_bf16", "dm_groupnorm_nhwc_fwd", "dm_groupnorm_nhwc_infer", "dm_groupnorm_nhwc_bwd_res",
+                 "dm_gemm_bf16_batched", "dm_transpose_bf16", "dm_linear_small_bf16", "dm_conv3x3_gn_nhwc_bf16_fused", "dm_groupnorm_nhwc_stats"):
         fb, nb = hipops._sym(name, torch.bfloat16)
         fh, nh = hipops._sym(name, torch.float16)
         assert nb == name and nh != name and "bf16" not in nh and "f16" in nh
@@ -637,6 +638,22 @@ def test_half_dtype_entry_points_resolve_to_exported_symbols():
         hipops._sym("dm_layernorm_bf16", torch.float32)
     with pytest.raises(AssertionError):
         hipops._same_half(torch.zeros(1, dtype=torch.bfloat16), torch.zeros(1, dtype=torch.float16))
+
+
+def test_wide_head_attention_groups_and_domain():
+    """hipops._WideHeadAttention's host side: images per launch (a power of two that divides the batch, score bytes per group bounded
+    whatever the batch: the workspace never scales with B) and the shapes its kernels take; a CPU tensor is refused loudly."""
+    grp = hipops._wide_attn_group
+    assert grp(8, 4096, 4096) == 4 and grp(16, 4096, 4096) == 4 and grp(2, 4096, 4096) == 2 and grp(1, 4096, 4096) == 1
+    assert grp(16, 16384, 16384) == 1                          # BASELINE configs[4]: one 512 MB score matrix at a time
+    assert grp(3, 256, 256) == 1 and grp(6, 256, 256) == 2 and grp(8, 256, 512) == 8
+    for B in (1, 2, 8, 16, 24):
+        g = grp(B, 4096, 4096)
+        assert B % g == 0 and g * 4096 * 4096 * 2 <= hipops.WIDE_ATTN_GROUP_BYTES
+    q = torch.zeros(2, 256, 128, dtype=torch.float16)
+    assert not hipops.wide_head_attention_ok(q, q, q)          # (CPU tensor)
+    with pytest.raises(Exception):
+        hipops.wide_head_attention(q, q, q, 1.0)
 
 
 def test_recorded_exits_from_the_hand_written_kernels(monkeypatch, capsys):
