@@ -213,23 +213,52 @@ __global__ __launch_bounds__(256) void k_hashgrid_bwd2(HashArgs a, int level_bas
 // issues ONE global atomic pair per distinct entry.  The run-combining variant above merges along an image row
 // only; the strip also shares entries between rows.  Open addressing, linear probing; a point that cannot find a
 // slot within LH_PROBES falls back to the direct global atomic, so a full table costs time, never correctness.
-constexpr int LH_SLOTS = 2048;                 // 8 KB keys + 16 KB values => 6 workgroups per CU
+// The values are 64-bit FIXED POINT (round 6, as the binned route below since round 3): ds_add_f32 is a slow path on this chip --
+// 99 G tuple pairs/s chip-wide against 855 G/s for ds_add_u64 (tools/lds_atomic_probe.cpp) -- and this kernel issued 48 M of them
+// per step.  Scale = 2^44 / the workgroup's own largest |dL/denc| (a first pass over its 1024 points; the table is per workgroup):
+// 8192 corner updates of magnitude <= max cannot wrap, the sums resolve 2^-44 of the largest gradient and no longer depend on
+// the order of the updates inside the workgroup.
+constexpr int LH_SLOTS = 2048;                 // 8 KB keys + 32 KB values => 4 workgroups per CU
 constexpr int LH_THREADS = 256;
 constexpr int LH_PTS = 4;                      // points per thread (1024 consecutive points per workgroup)
 constexpr int LH_PROBES = 8;
 constexpr unsigned LH_EMPTY = 0xffffffffu;
 constexpr unsigned LH_INVALID = 0xfffffffeu;   // key of lanes past the end of the point list (never inserted)
 
+// round-to-nearest double -> int64 for |d| < 2^51 (two plain fp64 / integer ops)
+__device__ __forceinline__ long long lh_fixed(double d) {
+    const double magic = 6755399441055744.0;               // 1.5 * 2^52
+    return __double_as_longlong(d + magic) - __double_as_longlong(magic);
+}
+
 __global__ __launch_bounds__(LH_THREADS) void k_hashgrid_bwd_lds(HashArgs a, int level_base) {
     __shared__ unsigned keys[LH_SLOTS];
-    __shared__ float vals[2 * LH_SLOTS];
+    __shared__ unsigned long long vals[2 * LH_SLOTS];
+    __shared__ unsigned wg_max;
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < LH_SLOTS; i += LH_THREADS) { keys[i] = LH_EMPTY; vals[2 * i] = 0.f; vals[2 * i + 1] = 0.f; }
+    for (int i = tid; i < LH_SLOTS; i += LH_THREADS) { keys[i] = LH_EMPTY; vals[2 * i] = 0ull; vals[2 * i + 1] = 0ull; }
+    if (tid == 0) wg_max = 0u;
     __syncthreads();
     const long long M = a.m_dev ? (long long)*a.m_dev : a.m_max;
     const int l = level_base + blockIdx.y;
     const float scale = a.lv.scale[l];
     const unsigned res = a.lv.res[l], size = a.lv.size[l], off = a.lv.offset[l];
+    {   // the workgroup's largest |gradient| of this level (NaN / Inf are left out: their sums are garbage either way)
+        float gm = 0.f;
+#pragma unroll
+        for (int q = 0; q < LH_PTS; ++q) {
+            const long long m = ((long long)blockIdx.x * LH_PTS + q) * LH_THREADS + tid;
+            if (m < M) gm = fmaxf(gm, fmaxf(fabsf(a.dout[m * a.dout_rs + (2 * l) * a.dout_cs]), fabsf(a.dout[m * a.dout_rs + (2 * l + 1) * a.dout_cs])));
+        }
+        if (!(gm <= 3.0e38f)) gm = 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gm = fmaxf(gm, __shfl_xor(gm, o));
+        if (lane == 0) atomicMax(&wg_max, __float_as_uint(gm));          // (non-negative floats order like their bits)
+    }
+    __syncthreads();
+    const float gmax = __uint_as_float(wg_max);
+    const double two44 = 17592186044416.0;
+    const double S = gmax > 0.f ? two44 / (double)gmax : 0.0, S_inv = (double)gmax / two44;
     // cells >= ~7 pixels wide: whole runs of lanes share a corner, and 64 LDS atomics on one address serialise --
     // combine each run with a segmented wave scan first (as k_hashgrid_bwd2<true>) and insert once per run
     const bool premerge = res <= 64;
@@ -281,8 +310,8 @@ __global__ __launch_bounds__(LH_THREADS) void k_hashgrid_bwd_lds(HashArgs a, int
                 for (int pr = 0; pr < LH_PROBES; ++pr) {
                     unsigned old = atomicCAS(&keys[h], LH_EMPTY, idx);
                     if (old == LH_EMPTY || old == idx) {
-                        atomicAdd(&vals[2 * h], v0);
-                        atomicAdd(&vals[2 * h + 1], v1);
+                        atomicAdd(&vals[2 * h], (unsigned long long)lh_fixed((double)v0 * S));
+                        atomicAdd(&vals[2 * h + 1], (unsigned long long)lh_fixed((double)v1 * S));
                         placed = true;
                         break;
                     }
@@ -301,8 +330,8 @@ __global__ __launch_bounds__(LH_THREADS) void k_hashgrid_bwd_lds(HashArgs a, int
         const unsigned k = keys[i];
         if (k != LH_EMPTY) {
             float* dst = a.dtable + 2 * (size_t)(off + k);
-            atomicAdd(dst, vals[2 * i]);
-            atomicAdd(dst + 1, vals[2 * i + 1]);
+            atomicAdd(dst, (float)((double)(long long)vals[2 * i] * S_inv));
+            atomicAdd(dst + 1, (float)((double)(long long)vals[2 * i + 1] * S_inv));
         }
     }
 }
