@@ -355,7 +355,7 @@ __global__ __launch_bounds__(LH_THREADS) void k_hashgrid_bwd_lds(HashArgs a, int
 // correctness.  Bytes: 8 B per tuple written and read once = 0.13 GB per level and pass at 1 M points.
 constexpr int HB_LOG2 = 13, HB_ENTRIES = 1 << HB_LOG2;     // table entries per bin: 2 x 8192 x 8 B fixed point = 128 KB of LDS
 constexpr int HB_MAX_BINS = 128;                           // log2_hashmap_size <= 20
-constexpr int HB_SPLITS = 4;
+constexpr int HB_SPLITS = 4;                               // at most: BinArgs::splits (1: pass 2 adds into dtable itself, no slabs, no pass 3)
 constexpr int HB_ACC_THREADS = 1024;
 
 struct BinArgs {
@@ -366,7 +366,8 @@ struct BinArgs {
     int bins;                      // bins of the largest binned level (row pitch of `tuples`)
     unsigned* counts;              // [n_binned][HB_MAX_BINS]   (zeroed by the launcher)
     unsigned* gmax_bits;           // [n_binned] max |dL/denc| of the level as float bits (zeroed by the launcher)
-    long long* partial;            // [n_binned][HB_SPLITS][max_size * 2] fixed point
+    long long* partial;            // [n_binned][splits][max_size * 2] fixed point (splits > 1)
+    int splits;                    // workgroups per (level, bin) in pass 2
     long long cap;                 // tuples per bin
     long long max_size;            // largest level size among the binned levels
 };
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(HB_ACC_THREADS) void k_hg_acc(BinArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long tab[];      // [HB_ENTRIES][2] fixed point
     const int tid = threadIdx.x;
     const int li = blockIdx.y, l = a.levels[li];
-    const int bin = blockIdx.x / HB_SPLITS, split = blockIdx.x - bin * HB_SPLITS;
+    const int bin = blockIdx.x / a.splits, split = blockIdx.x - bin * a.splits;
     const unsigned size = a.h.lv.size[l];
     if ((long long)bin * HB_ENTRIES >= (long long)size) return;      // this level has fewer bins
     for (int i = tid; i < HB_ENTRIES; i += HB_ACC_THREADS) reinterpret_cast<uint4*>(tab)[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(HB_ACC_THREADS) void k_hg_acc(BinArgs a) {
     [[maybe_unused]] const double S = gmax > 0.f ? hb_pow2_scale(a.cap) / (double)gmax : 0.0;   // |q| <= 2^shift, cap terms at most: no wrap
     __syncthreads();
     const long long n = min((long long)a.counts[li * HB_MAX_BINS + bin], a.cap);
-    [[maybe_unused]] const long long lo = n * split / HB_SPLITS, hi = n * (split + 1) / HB_SPLITS;      // (host pass: unused)
+    [[maybe_unused]] const long long lo = n * split / a.splits, hi = n * (split + 1) / a.splits;      // (host pass: unused)
     [[maybe_unused]] const uint2* src = a.tuples + ((long long)li * a.bins + bin) * a.cap;
     // eight independent 16-byte loads in flight per thread.  They are BUFFER loads whose descriptor ends at this split's
     // last tuple: lanes past the end read zeros (index 0, value 0: adds nothing) without a branch -- a conditional
@@ -511,7 +512,21 @@ __global__ __launch_bounds__(HB_ACC_THREADS) void k_hg_acc(BinArgs a) {
 #endif
     __syncthreads();
     const int n_ent = (int)min((long long)HB_ENTRIES, (long long)size - (long long)bin * HB_ENTRIES);
-    long long* dst = a.partial + ((long long)li * HB_SPLITS + split) * a.max_size * 2 + (long long)bin * HB_ENTRIES * 2;
+    if (a.splits == 1) {
+        // one workgroup per (level, bin): it owns the bin's table entries -- convert and add into dtable here (no slab, no pass 3)
+        const double inv = (double)gmax / hb_pow2_scale(a.cap);
+        float2* dt = reinterpret_cast<float2*>(a.h.dtable) + a.h.lv.offset[l] + (long long)bin * HB_ENTRIES;
+        for (int i = tid; i < n_ent; i += HB_ACC_THREADS) {
+            const long long q0 = (long long)tab[2 * i], q1 = (long long)tab[2 * i + 1];
+            if ((q0 | q1) != 0) {
+                float2 cur = dt[i];
+                cur.x += (float)((double)q0 * inv); cur.y += (float)((double)q1 * inv);
+                dt[i] = cur;
+            }
+        }
+        return;
+    }
+    long long* dst = a.partial + ((long long)li * a.splits + split) * a.max_size * 2 + (long long)bin * HB_ENTRIES * 2;
     for (int i = tid; i < n_ent; i += HB_ACC_THREADS) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<uint4*>(tab)[i];
 }
 
@@ -522,8 +537,8 @@ __global__ __launch_bounds__(256) void k_hg_sum(BinArgs a) {
     if (e >= size) return;
     long long q0 = 0, q1 = 0;
 #pragma unroll
-    for (int s = 0; s < HB_SPLITS; ++s) {
-        const longlong2 p = reinterpret_cast<const longlong2*>(a.partial + ((long long)li * HB_SPLITS + s) * a.max_size * 2)[e];
+    for (int s = 0; s < a.splits; ++s) {
+        const longlong2 p = reinterpret_cast<const longlong2*>(a.partial + ((long long)li * a.splits + s) * a.max_size * 2)[e];
         q0 += p.x; q1 += p.y;
     }
     const double inv = (double)__uint_as_float(a.gmax_bits[li]) / hb_pow2_scale(a.cap);
@@ -699,8 +714,14 @@ int dm_hashgrid_bwd_binned(const float* x, long long x_rs, long long x_cs, const
         }
         const int max_bins = (int)((max_size + HB_ENTRIES - 1) / HB_ENTRIES);
         hipLaunchKernelGGL(k_hg_bin, dim3(dm_div_up(m_max, 256), b.n_binned), dim3(256), 0, stream, b);
-        hipLaunchKernelGGL(k_hg_acc, dim3(max_bins * HB_SPLITS, b.n_binned), dim3(HB_ACC_THREADS), HB_ENTRIES * 16, stream, b);
-        hipLaunchKernelGGL(k_hg_sum, dim3(dm_div_up(max_size, 256), b.n_binned), dim3(256), 0, stream, b);
+        // workgroups per (level, bin): one when the (level, bin) pairs alone fill the chip twice over (the bench: 11 levels x 64 bins
+        // = 704 workgroups of 1024 threads: pass 2 then adds into dtable itself -- no 128 KB slab per workgroup written and read back,
+        // no pass 3), else up to HB_SPLITS
+        static const int env_splits = getenv("DREAMMAT_HASHGRID_SPLITS") ? atoi(getenv("DREAMMAT_HASHGRID_SPLITS")) : 0;
+        const long long pairs = (long long)max_bins * b.n_binned;
+        b.splits = env_splits >= 1 && env_splits <= HB_SPLITS ? env_splits : (int)std::max<long long>(1, std::min<long long>(HB_SPLITS, 512 / std::max<long long>(1, pairs)));
+        hipLaunchKernelGGL(k_hg_acc, dim3(max_bins * b.splits, b.n_binned), dim3(HB_ACC_THREADS), HB_ENTRIES * 16, stream, b);
+        if (b.splits > 1) hipLaunchKernelGGL(k_hg_sum, dim3(dm_div_up(max_size, 256), b.n_binned), dim3(256), 0, stream, b);
     }
     DM_LAUNCH_CHECK();
     return DM_OK;
