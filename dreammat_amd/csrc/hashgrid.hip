@@ -438,7 +438,11 @@ __global__ __launch_bounds__(256) void k_hg_bin(BinArgs a) {
             idx[c] = grid_index(cx, cy, cz, res, size);
             v0[c] = g0 * wt;
             v1[c] = g1 * wt;
+#if defined(DM_ABL_HG_NORANK)
+            rank[c] = (unsigned)(c * 4 + (tid & 3));        // ABLATION (wrong results): no LDS ranking atomics
+#else
             rank[c] = atomicAdd(&lcnt[idx[c] >> HB_LOG2], 1u);
+#endif
         }
     }
     // the level's largest |gradient| (scale of pass 2's fixed point): wave max, one global atomicMax per wave; NaN / Inf
@@ -451,7 +455,11 @@ __global__ __launch_bounds__(256) void k_hg_bin(BinArgs a) {
     __syncthreads();
     if (tid < HB_MAX_BINS) {
         const unsigned n = lcnt[tid];
+#if defined(DM_ABL_HG_NOGATOMIC)
+        lbase[tid] = (unsigned)((blockIdx.x * 37u) % 100000u);      // ABLATION (wrong results): no global reservation
+#else
         lbase[tid] = n ? atomicAdd(&a.counts[li * HB_MAX_BINS + tid], n) : 0u;
+#endif
     }
     // one same-address global atomic per WORKGROUP at most, and only while this workgroup's max still beats the published
     // one (a plain read first): 15 k waves per level hammering one address cost 4 ms
@@ -463,6 +471,9 @@ __global__ __launch_bounds__(256) void k_hg_bin(BinArgs a) {
             const unsigned bin = idx[c] >> HB_LOG2;
             const long long pos = (long long)lbase[bin] + rank[c];
             if (pos < a.cap) {
+#if defined(DM_ABL_HG_NOSTORE)
+                if (v0[c] == 123.456f)                      // ABLATION (wrong results): tuples never stored
+#endif
                 a.tuples[((long long)li * a.bins + bin) * a.cap + pos] = hb_pack(idx[c] & (HB_ENTRIES - 1), v0[c], v1[c]);
             } else {                                       // bin full: the slow, always-correct route
                 float* dst = a.h.dtable + 2 * (size_t)(off + idx[c]);
