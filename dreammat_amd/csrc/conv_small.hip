@@ -101,6 +101,7 @@ int launch_small(const SmallConvArgs& a, hipStream_t stream) {
 // 16-byte channel runs.  Cin = 128 -> Cout = 4 is the data gradient of the VAE encoder's conv_in (the rendered image is the leaf).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 
 template <int CP, int STRIDE, int TH_ = 16, int WR_ = 32>
@@ -230,6 +231,63 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(SmallConvArgs a, int c
                 load_weights(cb, wl0);
                 __syncthreads();
             }
+            if constexpr (WR == 4) {
+                // Four output channels: the 16 x 16 x 32 MFMA (A = 16 weight rows, 4 of them real; B = the 16 pixels of ONE tile row; a
+                // lane holds the k-quarter lane >> 4 of a 32-channel step) -- half the matrix-pipe time of the 32 x 32 x 16 form, whose 32
+                // weight rows did 4 rows of work.  A wave owns TH / 4 tile rows; D = [4 (lane >> 4) + r][lane & 15]: lanes 0-15 hold the
+                // four channels of their pixel and store them as one 8-byte run, 128 contiguous bytes per tile row.
+                static_assert(STRIDE == 1 && CP % 32 == 0, "the 4-channel form");
+                constexpr int RW = TH / 4;
+                const int l15 = lane & 15, kq = lane >> 4;
+                const bool live4 = l15 < WR;
+                f32x4 acc4[RW];
+#pragma unroll
+                for (int m = 0; m < RW; ++m) acc4[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+                for (int tap = 0; tap < 9; ++tap) {
+                    const int dy = tap / 3, dx = tap - 3 * dy;
+                    const int wrow = (live4 ? l15 : 0) * 9 + tap;
+                    int prow[RW];
+#pragma unroll
+                    for (int m = 0; m < RW; ++m) prow[m] = (RW * wave + m + dy) * C::PW + l15 + dx;
+#pragma unroll
+                    for (int kk = 0; kk < CP / 32; ++kk) {
+                        const int ch = 4 * kk + kq;
+                        elem8 wf = *reinterpret_cast<const elem8*>(wl + wrow * C::RB + ((ch ^ C::swz(wrow)) << 4));
+                        if (!live4) wf = elem8{};
+#pragma unroll
+                        for (int m = 0; m < RW; ++m) {
+                            const elem8 pf = *reinterpret_cast<const elem8*>(patch + prow[m] * C::RB + ((ch ^ C::swz(prow[m])) << 4));
+                            acc4[m] = DM_MFMA_16x16x32(wf, pf, acc4[m]);
+                        }
+                    }
+                }
+                if (kq == 0) {
+#pragma unroll
+                    for (int m = 0; m < RW; ++m) {
+                        const int oy = oy0 + RW * wave + m, ox = ox0 + l15;
+                        if (oy < a.Hout && ox < a.Wout) {
+                            const long long po = (((long long)b * a.Hout + oy) * a.Wout + ox) * a.Cout;
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc4[m][e] + sbias[e];
+                            if (a.res) {
+                                const elem4 rv = *reinterpret_cast<const elem4*>(a.res + (((long long)(b % a.res_B) * a.Hout + oy) * a.Wout + ox) * a.Cout);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                            }
+                            if (a.act) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v[e]));
+                            }
+                            f32x2 lo = {v[0], v[1]}, hi2 = {v[2], v[3]};
+                            const elem2 plo = __builtin_convertvector(lo, elem2), phi = __builtin_convertvector(hi2, elem2);
+                            *reinterpret_cast<elem4*>(a.y + po) = elem4{plo[0], plo[1], phi[0], phi[1]};
+                        }
+                    }
+                }
+                continue;
+            }
             f32x16 acc[MB];
 #pragma unroll
             for (int m = 0; m < MB; ++m)
@@ -297,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(SmallConvArgs a, int c
 template <int CP, int STRIDE, int TH = 16, int WR = 32>
 int launch_patch(const SmallConvArgs& a, int cin, hipStream_t stream) {
     using C = PatchCfg<CP, STRIDE, TH, WR>;
-    if (WR < 32 && a.Cout > WR) return DM_ERR_UNSUPPORTED;
+    if (WR < 32 && a.Cout != WR) return DM_ERR_UNSUPPORTED;                                                 // (the 4-channel form stores whole 8-byte pixels)
     {   // 32-bit buffer offsets of the patch loads: an input beyond 4 GB (16 x 1024^2 x 128 channels) goes image group by image group
         const long long per_img = (long long)a.Hin * a.Win * cin * 2;
         if (per_img > 0xffffff00LL) return DM_ERR_UNSUPPORTED;
@@ -357,7 +415,7 @@ int try_patch(const SmallConvArgs& a, int cin, hipStream_t stream) {
     if (a.stride == 1) {
         if (cin <= 16) return launch_patch<16, 1>(a, cin, stream);
         if (cin <= 32) return launch_patch<32, 1>(a, cin, stream);
-        if (a.Cout <= 4) {                                       // (the image gradient of the VAE encoder's conv_in)
+        if (a.Cout == 4) {                                       // (the image gradient of the VAE encoder's conv_in)
             const int rc = launch_patch<128, 1, 8, 4>(a, cin, stream);
             if (rc != DM_ERR_UNSUPPORTED) return rc;
         }

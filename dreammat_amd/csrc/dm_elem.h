@@ -11,6 +11,7 @@ typedef _Float16 elem_t;
 #define DM_T(pre, post) pre##f16##post
 #define DM_S(name) name##_f16
 #define DM_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define DM_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
 #define DM_MFMA_ASM "v_mfma_f32_32x32x16_f16"
 #define DM_FDOT2(a, b, c) __builtin_amdgcn_fdot2(a, b, c, false)
 #define dm_attn dm_attn_f16                 // (namespace of the attention kernels' cross-file symbols)
@@ -25,6 +26,7 @@ typedef __bf16 elem_t;
 #define DM_T(pre, post) pre##bf16##post
 #define DM_S(name) name
 #define DM_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define DM_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #define DM_MFMA_ASM "v_mfma_f32_32x32x16_bf16"
 #define DM_FDOT2(a, b, c) __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false)
 #define DM_P_SUM_MAX 0x1p100f
