@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(SmallConvArgs a, int c
     for (int i = tid; i < n_cb * 32; i += 256) sbias[i] = (a.bias && i < a.Cout) ? (float)a.bias[i] : 0.f;
     if (w_res >= n_cb)
         for (int cb = 0; cb < n_cb; ++cb) load_weights(cb, wl0 + cb * C::W_BYTES);
+    [[maybe_unused]] const bool wide_store = a.Cout % 32 == 0 && (((uintptr_t)a.y) & 15) == 0;      // (whole 32-channel blocks: Cout = 16 has nothing to pair)
     const int trow0 = 2 * MB * wave + (l31 >> 4), tcol = l31 & 15;        // this lane's pixel of M block 0 (block 1: two tile rows down)
     [[maybe_unused]] const bool w_live = l31 < WR;                        // (WR < 32: this lane's weight row exists)
     // The patch arrives by unconditional buffer loads, all of a tile's in flight before the first LDS store (out-of-image pixels and
@@ -324,6 +325,41 @@ __global__ __launch_bounds__(256, 2) void k_conv3x3_patch(SmallConvArgs a, int c
                 const bool pix_ok = oy < a.Hout && ox < a.Wout;
                 const long long po = (((long long)b * a.Hout + oy) * a.Wout + ox) * a.Cout;
                 const long long pr = (((long long)(b % a.res_B) * a.Hout + oy) * a.Wout + ox) * a.Cout;
+#if defined(__HIP_DEVICE_COMPILE__)
+                if (wide_store) {
+                    // 16-byte stores (Cout % 32 == 0): the two halves of the wave exchange one dword pair per channel octet
+                    // (v_permlane32_swap, as csrc/conv.hip): a lane then holds 8 consecutive channels of its pixel
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        unsigned w[2][2];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int g = 2 * gp + q;
+                            const int c0 = cb * 32 + 8 * g + 4 * hi;
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[m][4 * g + e] + sbias[c0 + e];
+                            if (a.res && pix_ok && c0 < a.Cout) {
+                                const elem4 rv = *reinterpret_cast<const elem4*>(a.res + pr + c0);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += (float)rv[e];
+                            }
+                            if (a.act) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v[e]));
+                            }
+                            f32x2 lo = {v[0], v[1]}, hi2 = {v[2], v[3]};
+                            w[q][0] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, elem2));
+                            w[q][1] = __builtin_bit_cast(unsigned, __builtin_convertvector(hi2, elem2));
+                        }
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(w[0][0], w[1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(w[0][1], w[1][1], false, false);
+                        const int c8 = cb * 32 + 16 * gp + 8 * hi;
+                        if (pix_ok && c8 < a.Cout) *reinterpret_cast<u32x4s*>(a.y + po + c8) = u32x4s{s0[0], s1[0], s0[1], s1[1]};
+                    }
+                    continue;
+                }
+#endif
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int cl = 8 * g + 4 * hi, c0 = cb * 32 + cl;     // four consecutive channels
