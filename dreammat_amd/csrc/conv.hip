@@ -421,6 +421,11 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
             else issue_on = 0;
         }
     };
+#if defined(DM_ABL_VGPRSTAGE)
+    u32x4 abl_v[L];
+#pragma unroll
+    for (int p = 0; p < L; ++p) abl_v[p] = u32x4{0u, 0u, 0u, 0u};
+#endif
     // DMA piece p of the step at the cursor (p < A_INSTR: 8 activation rows, else 8 weight rows) into `stage`
     auto piece = [&](int p, int stage) __attribute__((always_inline)) {
 #if defined(DM_ABL_NODMA)
@@ -434,6 +439,16 @@ __global__ __launch_bounds__(NW * 64) void k_conv3x3_dma(ConvArgs a, long long n
         if (p >= A_INSTR) return;                       // ABLATION (wrong results): activations only
 #endif
         char* ab = smem + stage * STAGE;
+#if defined(DM_ABL_VGPRSTAGE)
+        // ABLATION (wrong results, right traffic): the same requests as plain buffer_load_dwordx4 into registers, written to LDS with
+        // ds_write_b128 one step after they were requested (into the stage this call names) -- the classic global -> VGPR -> LDS path in
+        // place of the LDS-DMA.  Round 6: 577 vs 792 TF/s on [24576, 2560, 640], 416 vs 504 on [24576, 640, 640], 486 vs 617 on
+        // [6144, 1280, 1280] (the 256 x 128 tile, 217 registers, no spills): the LDS-DMA is the cheaper way to ask on this chip.
+        *reinterpret_cast<u32x4*>(ab + (p < A_INSTR ? (wave * (BMT / NW) + 8 * p) * ROWB : A_BYTES + (wave * (BN / NW) + 8 * (p - A_INSTR)) * ROWB) + lane * 16) = abl_v[p];
+        if (p < A_INSTR) abl_v[p] = __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)((a_mask[p] & bit) ? a_off[p] + toff : OOB), 0, 0);
+        else abl_v[p] = __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)b_off[p - A_INSTR], (int)woff, 0);
+        return;
+#endif
         if (p < A_INSTR) {
             // select, never a branch: the DMA must execute with ALL lanes active (an inactive lane would
             // leave its LDS slot stale); out-of-image taps read zeros through the descriptor's range check
