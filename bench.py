@@ -622,7 +622,7 @@ def main():
                                  ("roofline_antialias", "k_aa_plan + k_aa_apply<C> + k_aa_grad<C>",
                                   [k for k in kt if k.startswith("antialias")]),
                                  ("roofline_hashgrid_fwd", "k_hashgrid<false>", ["hashgrid_fwd"]),
-                                 ("roofline_hashgrid_bwd", "k_hg_bin / k_hg_acc / k_hg_sum", [k for k in kt if k.startswith("hashgrid_bwd")])):
+                                 ("roofline_hashgrid_bwd", "k_hashgrid_bwd_lds (dense levels) + k_hg_bin / k_hg_acc (hashed levels; k_hg_sum only when pass 2 is split)", [k for k in kt if k.startswith("hashgrid_bwd")])):
             row = hbm_row(kernel, keys)
             if row:
                 res[nm] = row
